@@ -1,0 +1,156 @@
+/*
+ * mdb.h - C ABI of libmdb_hip.so: ModelarDB's model-compression / grid / segment-aggregate hot
+ * path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * This is the drop-in boundary. The reference has no plugin API: modelardb_storage and
+ * modelardb_server call the modelardb_compression crate directly. Each entry point below replaces
+ * one of those call sites at BATCH granularity (one call per Arrow RecordBatch instead of one per
+ * row); INTEGRATION.md shows the Rust `extern "C"` block and the patched call sites.
+ *
+ * Conventions (mirroring the reference's own C API, crates/modelardb_embedded/src/capi.rs:58-80
+ * and bindings/c/modelardb_embedded.h:74-78,202-203):
+ *   - every function returns 0 on success and 1 on failure;
+ *   - mdb_last_error() returns the message of the last failure on the calling thread, valid until
+ *     the next failing call on that thread;
+ *   - malformed segments (the reference panics: models/mod.rs:170,237, macaque_v.rs:224,279-280,
+ *     types.rs:316-318,391,405) are error returns, never aborts;
+ *   - inputs are borrowed for the duration of the call; outputs are written into caller-allocated
+ *     buffers, or returned as mdb_segments_owned that the caller frees with mdb_segments_free().
+ *   - a context (mdb_ctx) owns one HIP stream and scratch memory. Calls on one context are
+ *     serialised by an internal mutex; use one context per thread for concurrency.
+ *
+ * "host" entry points take host pointers (straight into Arrow buffers) and return after the
+ * results are in host memory. "_dev" entry points take device pointers, enqueue on the context's
+ * stream and return after the stream has been synchronised unless stated otherwise.
+ *
+ * Paths in the citations are relative to the reference repository root.
+ */
+#ifndef MDB_H
+#define MDB_H
+
+#include "mdb_format.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdb_ctx mdb_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`. Constructor convention of capi.rs:218-229. */
+int mdb_init(int device, mdb_ctx **ctx);
+int mdb_close(mdb_ctx *ctx);
+const char *mdb_last_error(void);
+/* "libmdb_hip <version> gfx950"; never fails. */
+const char *mdb_version(void);
+/* Use an externally created hipStream_t (e.g. torch's current stream) instead of the context's. */
+int mdb_set_stream(mdb_ctx *ctx, void *hip_stream);
+/* Name, CU count, HBM bytes of the context's device. */
+int mdb_device_info(mdb_ctx *ctx, char *name, uint64_t name_cap, int32_t *compute_units,
+                    uint64_t *hbm_bytes);
+
+/* ---- device memory owned by the library (so the bench needs no other allocator) -------------- */
+
+int mdb_dev_alloc(mdb_ctx *ctx, uint64_t bytes, void **dev_ptr);
+int mdb_dev_free(mdb_ctx *ctx, void *dev_ptr);
+int mdb_dev_upload(mdb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
+int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+int mdb_dev_sync(mdb_ctx *ctx);
+/* Copy a host batch of segments (Arrow buffers) to the device; the result has on_device = 1. */
+int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_owned **dev);
+/* Copy a device batch back; the result has on_device = 0 and one data buffer per column. */
+int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **host);
+void mdb_segments_free(mdb_segments_owned *segments);
+
+/* ---- grid: replaces the per-row loop of GridStream::grid_and_append_to_leftovers_in_current_batch
+ *      (crates/modelardb_storage/src/query/grid_exec.rs:323-356) which calls
+ *      modelardb_compression::grid (crates/modelardb_compression/src/models/mod.rs:190-251) ------ */
+
+/* Number of data points the batch reconstructs to (sum over rows of the timestamps a row
+ * decompresses to), so the caller can allocate the outputs. */
+int mdb_grid_count(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out);
+
+/* Reconstruct every data point of every segment, in segment order. out_ts/out_val need `cap`
+ * elements (cap >= mdb_grid_count). out_rows_per_segment (optional, n entries) is what the caller
+ * uses to replicate tag values (grid_exec.rs:339-346). metrics is optional (grid_exec.rs:511-518). */
+int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                   uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                   mdb_grid_metrics *metrics);
+
+/* Device resident variant: `in` holds device pointers (e.g. from mdb_segments_upload or
+ * mdb_compress_chunks_dev), outputs are device buffers. */
+int mdb_grid_count_dev(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out);
+int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                       uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                       mdb_grid_metrics *metrics);
+
+/* ---- aggregates: replaces Model{Count,Min,Max,Sum,Avg}Accumulator::update_batch
+ *      (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:345-358, 395-401,
+ *      438-444, 481-513, 553-587) which call modelardb_compression::{len,sum}
+ *      (crates/modelardb_compression/src/models/mod.rs:98-184) ---------------------------------- */
+
+/* Fold the batch into *inout for the aggregates in which_mask (MDB_AGG_*). COUNT/MIN/MAX are exact;
+ * SUM adds the f32 per-segment sums in f64 with a fixed (deterministic) tree order, so it can
+ * differ from the reference's sequential f64 accumulation in the last bits (the reference's own
+ * tests allow 0.001 %: crates/modelardb_server/tests/integration_test.rs:1155-1171). */
+int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout);
+int mdb_agg_batch_dev(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask,
+                      mdb_agg_state *inout);
+
+/* Extension (BASELINE config 3): aggregates over the data points with
+ * t_lo <= timestamp <= t_hi without materialising them. The reference has no such operator: any
+ * WHERE on the timestamp falls back to GridExec + filter + AggregateExec
+ * (model_simple_aggregates.rs:284-302), and that result is the parity oracle. */
+int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                        uint32_t which_mask, mdb_agg_state *inout);
+int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                            uint32_t which_mask, mdb_agg_state *inout);
+
+/* ---- fit: replaces try_compress_univariate_time_series
+ *      (crates/modelardb_compression/src/compression.rs:191-275), called per field column by
+ *      crates/modelardb_server/src/storage/uncompressed_data_manager.rs:563-581 and, through
+ *      try_compress_multivariate_time_series (compression.rs:42-179), by
+ *      crates/modelardb_embedded/src/operations/data_folder.rs:214-217 and
+ *      crates/modelardb_bulkloader/src/main.rs:429-432 ------------------------------------------- */
+
+/* Compress one sorted univariate series. n == 0 gives an empty batch (compression.rs:208-211). */
+int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, uint64_t n,
+                        mdb_error_bound error_bound, mdb_segments_owned **out);
+
+/* Compress many independent series chunks in one launch: chunk c is
+ * [chunk_offsets[c], chunk_offsets[c + 1]) of ts/values. Segments come out grouped by chunk in
+ * chunk order, each chunk's segments in time order; out->chunk_index names the chunk. */
+int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
+                        const uint64_t *chunk_offsets, uint64_t n_chunks,
+                        mdb_error_bound error_bound, mdb_segments_owned **out);
+
+/* Device resident variant. ts may be NULL: then chunk c has the regular timestamps
+ * regular_start + i * regular_interval (i counted from the start of the chunk's series, given by
+ * series_first_index[c], or from 0 if that is NULL), synthesised on the fly. */
+int mdb_compress_chunks_dev(mdb_ctx *ctx, const int64_t *ts, const float *values,
+                            const uint64_t *chunk_offsets, uint64_t n_chunks,
+                            mdb_error_bound error_bound, int64_t regular_start,
+                            int64_t regular_interval, const uint64_t *series_first_index,
+                            mdb_segments_owned **out);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* When enabled every kernel launch is bracketed with hipEvents on the context's stream. */
+int mdb_profile_enable(mdb_ctx *ctx, int enabled);
+int mdb_profile_reset(mdb_ctx *ctx);
+/* Accumulated launches and milliseconds of kernel `name` since the last reset. */
+int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *total_ms);
+/* Names of all profiled kernels, '\n' separated. */
+int mdb_profile_names(mdb_ctx *ctx, char *out, uint64_t cap);
+
+/* Fill out[i] = synthetic series value: series s = first_series + i / n_per_series,
+ * point j = i % n_per_series: 100 + 10 sin(2 pi j / P_s + phi_s) + U(-0.05, 0.05). Device buffer. */
+int mdb_synth_values_dev(mdb_ctx *ctx, float *out, uint64_t first_series, uint64_t n_series,
+                         uint64_t n_per_series, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MDB_H */

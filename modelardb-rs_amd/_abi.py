@@ -1,0 +1,181 @@
+"""ctypes mirror of include/mdb_format.h and include/mdb.h, plus the loader of libmdb_hip.so.
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded,
+``load_hip_library`` raises. The structs here are shared with the oracle wrapper in ``tests/`` so
+both sides consume exactly the same in-memory segment batches.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+HIP_LIBRARY_PATH = os.path.join(_HERE, "csrc", "libmdb_hip.so")
+
+MDB_PMC_MEAN_ID = 0
+MDB_SWING_ID = 1
+MDB_MACAQUE_V_ID = 2
+MODEL_TYPE_NAMES = ("pmc_mean", "swing", "macaque_v")  # models/mod.rs:44
+
+MDB_EB_LOSSLESS = 0
+MDB_EB_ABSOLUTE = 1
+MDB_EB_RELATIVE = 2
+
+MDB_AGG_COUNT = 1
+MDB_AGG_MIN = 2
+MDB_AGG_MAX = 4
+MDB_AGG_SUM = 8
+MDB_AGG_AVG = 16
+
+F32_MAX = 3.4028234663852886e38
+
+
+class ErrorBoundC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("value", C.c_float)]
+
+
+class BinViewColC(C.Structure):
+    _fields_ = [
+        ("views", C.c_void_p),
+        ("buffers", C.POINTER(C.c_void_p)),
+        ("buffer_sizes", C.POINTER(C.c_int64)),
+        ("n_buffers", C.c_int32),
+    ]
+
+
+class SegmentsC(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("model_type_id", C.c_void_p),
+        ("start_time", C.c_void_p),
+        ("end_time", C.c_void_p),
+        ("timestamps", BinViewColC),
+        ("min_value", C.c_void_p),
+        ("max_value", C.c_void_p),
+        ("values", BinViewColC),
+        ("residuals", BinViewColC),
+    ]
+
+
+class GridMetricsC(C.Structure):
+    _fields_ = [
+        ("rows_created", C.c_uint64),
+        ("rows_created_by_model_type", C.c_uint64 * 3),
+        ("segments_with_residuals", C.c_uint64),
+        ("segments_with_model_type", C.c_uint64 * 3),
+        ("segments_regular", C.c_uint64),
+        ("segments_irregular", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        out = {"rows_created": self.rows_created}
+        for i, name in enumerate(MODEL_TYPE_NAMES):
+            out[f"rows_created_by_{name}"] = self.rows_created_by_model_type[i]
+        out["segments_with_residuals"] = self.segments_with_residuals
+        for i, name in enumerate(MODEL_TYPE_NAMES):
+            out[f"segments_with_{name}"] = self.segments_with_model_type[i]
+        out["regular_segments"] = self.segments_regular
+        out["irregular_segments"] = self.segments_irregular
+        return out
+
+
+class AggStateC(C.Structure):
+    _fields_ = [
+        ("sum", C.c_double),
+        ("count", C.c_int64),
+        ("min", C.c_float),
+        ("max", C.c_float),
+    ]
+
+    @classmethod
+    def fresh(cls):
+        # model_simple_aggregates.rs:413,456: min starts at f32::MAX, max at f32::MIN.
+        return cls(0.0, 0, F32_MAX, -F32_MAX)
+
+
+class SegmentsOwnedC(C.Structure):
+    _fields_ = [
+        ("seg", SegmentsC),
+        ("error", C.c_void_p),
+        ("chunk_index", C.c_void_p),
+        ("on_device", C.c_int32),
+        ("priv_", C.c_void_p),
+    ]
+
+
+_HIP_SYMBOLS = {
+    # name: (restype, argtypes)
+    "mdb_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mdb_close": (C.c_int, [C.c_void_p]),
+    "mdb_last_error": (C.c_char_p, []),
+    "mdb_version": (C.c_char_p, []),
+    "mdb_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdb_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_uint64)]),
+    "mdb_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mdb_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdb_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "mdb_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "mdb_dev_sync": (C.c_int, [C.c_void_p]),
+    "mdb_segments_upload": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC),
+                                      C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_segments_download": (C.c_int, [C.c_void_p, C.POINTER(SegmentsOwnedC),
+                                        C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_segments_free": (None, [C.POINTER(SegmentsOwnedC)]),
+    "mdb_grid_count": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.POINTER(C.c_uint64)]),
+    "mdb_grid_batch": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                 C.POINTER(GridMetricsC)]),
+    "mdb_grid_count_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.POINTER(C.c_uint64)]),
+    "mdb_grid_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                     C.POINTER(GridMetricsC)]),
+    "mdb_agg_batch": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,
+                                C.POINTER(AggStateC)]),
+    "mdb_agg_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,
+                                    C.POINTER(AggStateC)]),
+    "mdb_agg_batch_range": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,
+                                      C.c_uint32, C.POINTER(AggStateC)]),
+    "mdb_agg_batch_range_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,
+                                          C.c_uint32, C.POINTER(AggStateC)]),
+    "mdb_compress_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, ErrorBoundC,
+                                      C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_compress_chunks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                      ErrorBoundC, C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_compress_chunks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_uint64, ErrorBoundC, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mdb_profile_reset": (C.c_int, [C.c_void_p]),
+    "mdb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_double)]),
+    "mdb_profile_names": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
+    "mdb_synth_values_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.c_uint64]),
+}
+
+_hip_library = None
+
+
+def hip_symbol_names():
+    """Every symbol include/mdb.h declares (checked against the built library by the tests)."""
+    return sorted(_HIP_SYMBOLS)
+
+
+def load_hip_library():
+    """Load libmdb_hip.so and declare its prototypes. Raises if it is missing: no fallback."""
+    global _hip_library
+    if _hip_library is not None:
+        return _hip_library
+    if not os.path.exists(HIP_LIBRARY_PATH):
+        raise RuntimeError(
+            f"{HIP_LIBRARY_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    library = C.CDLL(HIP_LIBRARY_PATH, mode=C.RTLD_GLOBAL)
+    for name, (restype, argtypes) in _HIP_SYMBOLS.items():
+        function = getattr(library, name)  # AttributeError if the library lacks a declared symbol
+        function.restype = restype
+        function.argtypes = argtypes
+    _hip_library = library
+    return library

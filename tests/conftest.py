@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for path in (REPO_ROOT, os.path.join(REPO_ROOT, "tests")):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The HIP product library bound to cuda:0. Fails loudly when it is missing: no fallback."""
+    import modelardb_rs_amd as mdb
+    from modelardb_rs_amd import api
+    return api.Context(0)

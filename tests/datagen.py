@@ -1,0 +1,84 @@
+"""Seeded synthetic series for the parity tests.
+
+Restates the *recipes* of the reference's test generator
+(crates/modelardb_test/src/data_generation.rs:108-284): regular timestamps 0,100,200,... or
+irregular ones with gaps drawn from [100,200); value runs that are Constant, Linear
+(slope in [-10,10) \\ {0}, intercept in [1,50)) or uniformly Random, optionally multiplied... the
+reference ADDS noise drawn from `add_noise_range` (randomize_and_collect_iterator, :270-284).
+The reference uses rand's ChaCha StdRng, which cannot be reproduced without the crate, so numpy's
+PCG64 is used instead: the recipes are the same, the random draws are not.
+"""
+
+import numpy as np
+
+F32_MAX = float(np.finfo(np.float32).max)
+
+
+def generate_timestamps(length, irregular, rng=None):
+    """data_generation.rs:197-210"""
+    if irregular:
+        rng = rng or np.random.default_rng(0)
+        gaps = rng.integers(100, 200, size=length).astype(np.int64)
+        out = np.zeros(length, dtype=np.int64)
+        out[1:] = np.cumsum(gaps[:-1])
+        return out
+    return np.arange(length, dtype=np.int64) * 100
+
+
+def generate_values(timestamps, structure, rng, noise_range=None, value_range=None):
+    """data_generation.rs:222-266. structure in {"constant", "linear", "random"}."""
+    n = len(timestamps)
+    if structure == "constant":
+        values = np.full(n, np.float32(rng.random()), dtype=np.float32)
+    elif structure == "linear":
+        slope = 0
+        while slope == 0:
+            slope = int(rng.integers(-10, 10))
+        intercept = int(rng.integers(1, 50))
+        values = (slope * np.asarray(timestamps, dtype=np.int64) + intercept).astype(np.float32)
+    elif structure == "random":
+        low, high = value_range
+        values = rng.uniform(low, high, size=n).astype(np.float32)
+        return values
+    else:
+        raise ValueError(structure)
+    if noise_range is not None:
+        noise = rng.uniform(noise_range[0], noise_range[1], size=n).astype(np.float32)
+        values = (values + noise).astype(np.float32)
+    return values
+
+
+def largest_random_without_overflow():
+    """ValuesStructure::largest_random_without_overflow (data_generation.rs:83-90)."""
+    return (-F32_MAX / 2.0, F32_MAX / 2.0)
+
+
+def generate_univariate_time_series(length, segment_length_range, irregular, noise_range,
+                                    random_value_range, seed):
+    """data_generation.rs:108-195 for one field column."""
+    rng = np.random.default_rng(seed)
+    timestamps = generate_timestamps(length, irregular, rng)
+    values = np.zeros(0, dtype=np.float32)
+    structures = ("constant", "linear", "random")
+    while len(values) < length:
+        segment_length = int(rng.integers(segment_length_range[0], segment_length_range[1]))
+        structure = structures[int(rng.integers(0, 3))]
+        end = min(length, len(values) + segment_length)
+        part = generate_values(timestamps[len(values):end], structure, rng, noise_range,
+                               random_value_range)
+        values = np.concatenate([values, part])
+    return timestamps, values[:length]
+
+
+def sine_series(series_index, n_points, seed=0x4D44425F52454631, t0=0, delta=1000):
+    """SURVEY 8(d) benchmark recipe evaluated on the host in f64 then rounded to f32:
+    v = 100 + 10 sin(2 pi i / P_s + phi_s) + u, P_s = 2000 + 37 (s mod 64),
+    phi_s = 2 pi frac(s * 0.61803), u ~ U(-0.05, 0.05)."""
+    rng = np.random.default_rng([seed & 0xFFFFFFFF, seed >> 32, series_index])
+    i = np.arange(n_points, dtype=np.float64)
+    period = 2000.0 + 37.0 * (series_index % 64)
+    phase = 2.0 * np.pi * ((series_index * 0.61803) % 1.0)
+    noise = rng.uniform(-0.05, 0.05, size=n_points)
+    values = (100.0 + 10.0 * np.sin(2.0 * np.pi * i / period + phase) + noise).astype(np.float32)
+    timestamps = t0 + np.arange(n_points, dtype=np.int64) * delta
+    return timestamps, values
