@@ -1,0 +1,236 @@
+"""Thin Python binding of the C ABI in include/mdb.h (ctypes; no torch types cross the boundary).
+
+``Context`` owns one ``mdb_ctx`` (one HIP stream + scratch). The host methods take numpy-backed
+``SegmentBatch`` objects whose buffers are handed to the library as plain pointers, exactly like
+the Rust shim in INTEGRATION.md would hand over Arrow buffers. There is no CPU fallback: if the HIP
+library cannot be loaded or a call fails, ``HipError`` is raised.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .segments import SegmentBatch
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class DeviceSegments:
+    """A batch of segments resident in HBM (``mdb_segments_owned`` with on_device = 1)."""
+
+    def __init__(self, context, pointer):
+        self._context = context
+        self.pointer = pointer
+
+    def __len__(self):
+        return int(self.pointer.contents.seg.n)
+
+    @property
+    def seg(self):
+        return self.pointer.contents.seg
+
+    def free(self):
+        if self.pointer:
+            self._context.lib.mdb_segments_free(self.pointer)
+            self.pointer = None
+
+    def download(self):
+        """Copy back to the host as a ``SegmentBatch``."""
+        out = C.POINTER(_abi.SegmentsOwnedC)()
+        self._context._check(self._context.lib.mdb_segments_download(
+            self._context.handle, self.pointer, C.byref(out)))
+        try:
+            return SegmentBatch.from_owned(out)
+        finally:
+            self._context.lib.mdb_segments_free(out)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = _abi.load_hip_library()
+        self.handle = C.c_void_p()
+        if self.lib.mdb_init(int(device), C.byref(self.handle)) != 0:
+            raise HipError(self.lib.mdb_last_error().decode())
+        self.device = device
+
+    def _check(self, code):
+        if code != 0:
+            raise HipError(self.lib.mdb_last_error().decode())
+
+    def close(self):
+        if self.handle:
+            self.lib.mdb_close(self.handle)
+            self.handle = C.c_void_p()
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int32(), C.c_uint64()
+        self._check(self.lib.mdb_device_info(self.handle, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def set_stream(self, hip_stream):
+        self._check(self.lib.mdb_set_stream(self.handle, C.c_void_p(hip_stream)))
+
+    # ---- device memory -----------------------------------------------------------------------
+
+    def dev_alloc(self, nbytes):
+        pointer = C.c_void_p()
+        self._check(self.lib.mdb_dev_alloc(self.handle, int(nbytes), C.byref(pointer)))
+        return pointer.value
+
+    def dev_free(self, pointer):
+        self._check(self.lib.mdb_dev_free(self.handle, C.c_void_p(pointer)))
+
+    def upload_array(self, array):
+        array = np.ascontiguousarray(array)
+        pointer = self.dev_alloc(max(array.nbytes, 1))
+        self._check(self.lib.mdb_dev_upload(self.handle, C.c_void_p(pointer),
+                                            array.ctypes.data_as(C.c_void_p), array.nbytes))
+        return pointer
+
+    def download_array(self, pointer, count, dtype, offset_elements=0):
+        out = np.empty(count, dtype=dtype)
+        source = pointer + offset_elements * out.itemsize
+        self._check(self.lib.mdb_dev_download(self.handle, out.ctypes.data_as(C.c_void_p),
+                                              C.c_void_p(source), out.nbytes))
+        return out
+
+    def sync(self):
+        self._check(self.lib.mdb_dev_sync(self.handle))
+
+    def upload_segments(self, batch):
+        seg = batch.as_c()
+        out = C.POINTER(_abi.SegmentsOwnedC)()
+        self._check(self.lib.mdb_segments_upload(self.handle, C.byref(seg), C.byref(out)))
+        return DeviceSegments(self, out)
+
+    # ---- grid ------------------------------------------------------------------------------------
+
+    def grid_count(self, batch):
+        seg = batch.as_c()
+        n_out = C.c_uint64()
+        self._check(self.lib.mdb_grid_count(self.handle, C.byref(seg), C.byref(n_out)))
+        return n_out.value
+
+    def grid_batch(self, batch, cap=None):
+        """Returns (timestamps i64[], values f32[], rows_per_segment u32[], metrics dict)."""
+        seg = batch.as_c()
+        if cap is None:
+            cap = self.grid_count(batch)
+        out_ts = np.empty(cap, dtype=np.int64)
+        out_val = np.empty(cap, dtype=np.float32)
+        rows = np.empty(len(batch), dtype=np.uint32)
+        n_out = C.c_uint64()
+        metrics = _abi.GridMetricsC()
+        self._check(self.lib.mdb_grid_batch(
+            self.handle, C.byref(seg), out_ts.ctypes.data_as(C.c_void_p),
+            out_val.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), cap,
+            C.byref(n_out), C.byref(metrics)))
+        return out_ts[: n_out.value], out_val[: n_out.value], rows, metrics.as_dict()
+
+    def grid_count_dev(self, dev_segments):
+        n_out = C.c_uint64()
+        self._check(self.lib.mdb_grid_count_dev(self.handle, C.byref(dev_segments.seg),
+                                                C.byref(n_out)))
+        return n_out.value
+
+    def grid_batch_dev(self, dev_segments, out_ts_ptr, out_val_ptr, cap, rows_ptr=None):
+        n_out = C.c_uint64()
+        metrics = _abi.GridMetricsC()
+        self._check(self.lib.mdb_grid_batch_dev(
+            self.handle, C.byref(dev_segments.seg), C.c_void_p(out_ts_ptr), C.c_void_p(out_val_ptr),
+            C.c_void_p(rows_ptr), cap, C.byref(n_out), C.byref(metrics)))
+        return n_out.value, metrics.as_dict()
+
+    # ---- aggregates ------------------------------------------------------------------------------
+
+    def agg_batch(self, batch, which_mask, state=None):
+        seg = batch.as_c()
+        state = state or _abi.AggStateC.fresh()
+        self._check(self.lib.mdb_agg_batch(self.handle, C.byref(seg), which_mask, C.byref(state)))
+        return state
+
+    def agg_batch_range(self, batch, t_lo, t_hi, which_mask, state=None):
+        seg = batch.as_c()
+        state = state or _abi.AggStateC.fresh()
+        self._check(self.lib.mdb_agg_batch_range(self.handle, C.byref(seg), t_lo, t_hi, which_mask,
+                                                 C.byref(state)))
+        return state
+
+    def agg_batch_dev(self, dev_segments, which_mask, state=None):
+        state = state or _abi.AggStateC.fresh()
+        self._check(self.lib.mdb_agg_batch_dev(self.handle, C.byref(dev_segments.seg), which_mask,
+                                               C.byref(state)))
+        return state
+
+    def agg_batch_range_dev(self, dev_segments, t_lo, t_hi, which_mask, state=None):
+        state = state or _abi.AggStateC.fresh()
+        self._check(self.lib.mdb_agg_batch_range_dev(self.handle, C.byref(dev_segments.seg), t_lo,
+                                                     t_hi, which_mask, C.byref(state)))
+        return state
+
+    # ---- fit -------------------------------------------------------------------------------------
+
+    def compress_chunks(self, timestamps, values, chunk_offsets, eb):
+        ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        if len(ts) != len(v):
+            # compression.rs:202-206
+            raise HipError(
+                "Uncompressed timestamps and uncompressed values have different lengths.")
+        offsets = np.ascontiguousarray(chunk_offsets, dtype=np.uint64)
+        out = C.POINTER(_abi.SegmentsOwnedC)()
+        self._check(self.lib.mdb_compress_chunks(
+            self.handle, ts.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+            offsets.ctypes.data_as(C.c_void_p), len(offsets) - 1, eb, C.byref(out)))
+        try:
+            return SegmentBatch.from_owned(out)
+        finally:
+            self.lib.mdb_segments_free(out)
+
+    def try_compress_univariate_time_series(self, timestamps, values, eb):
+        """compression.rs:191-275 for one sorted series."""
+        return self.compress_chunks(timestamps, values, [0, len(values)], eb)
+
+    def compress_chunks_dev(self, ts_ptr, values_ptr, chunk_offsets_ptr, n_chunks, eb,
+                            regular_start=0, regular_interval=0, series_first_index_ptr=None):
+        out = C.POINTER(_abi.SegmentsOwnedC)()
+        self._check(self.lib.mdb_compress_chunks_dev(
+            self.handle, C.c_void_p(ts_ptr), C.c_void_p(values_ptr), C.c_void_p(chunk_offsets_ptr),
+            n_chunks, eb, regular_start, regular_interval, C.c_void_p(series_first_index_ptr),
+            C.byref(out)))
+        return DeviceSegments(self, out)
+
+    def synth_values_dev(self, out_ptr, first_series, n_series, n_per_series,
+                         seed=0x4D44425F52454631):
+        self._check(self.lib.mdb_synth_values_dev(self.handle, C.c_void_p(out_ptr), first_series,
+                                                  n_series, n_per_series, seed))
+
+    # ---- measurement -----------------------------------------------------------------------------
+
+    def profile_enable(self, enabled=True):
+        self._check(self.lib.mdb_profile_enable(self.handle, int(enabled)))
+
+    def profile_reset(self):
+        self._check(self.lib.mdb_profile_reset(self.handle))
+
+    def profile(self):
+        """{kernel name: (launches, total_ms)} since the last reset."""
+        names = C.create_string_buffer(4096)
+        self._check(self.lib.mdb_profile_names(self.handle, names, 4096))
+        out = {}
+        for name in filter(None, names.value.decode().split("\n")):
+            launches, total_ms = C.c_uint64(), C.c_double()
+            self._check(self.lib.mdb_profile_get(self.handle, name.encode(), C.byref(launches),
+                                                 C.byref(total_ms)))
+            out[name] = (launches.value, total_ms.value)
+        return out

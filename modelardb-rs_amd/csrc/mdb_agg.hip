@@ -1,0 +1,449 @@
+// mdb_agg.hip - COUNT / MIN / MAX / SUM / AVG computed directly on segments.
+//
+// Replaces Model{Count,Min,Max,Sum,Avg}Accumulator::update_batch
+// (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:345-358, 395-401, 438-444,
+// 481-513, 553-587) and the functions they call, modelardb_compression::{len,sum}
+// (crates/modelardb_compression/src/models/mod.rs:98-184, pmc_mean.rs:98-100, swing.rs:264-300,
+// macaque_v.rs:220-265). The time-range variant is the SURVEY 8(f) N1 extension: it produces what
+// the reference computes with GridExec + filter + AggregateExec, without materialising points.
+//
+// k_agg_segments: 1 thread / segment -> per-segment {f32 sum widened to f64, count, min, max},
+// reduced with a fixed tree (wave shuffles, LDS across waves) to one partial per workgroup;
+// k_agg_finish reduces the partials with one workgroup. The fixed tree makes SUM run-to-run
+// deterministic; it differs from the reference's sequential f64 accumulation only in rounding order.
+// Algorithmic bytes: COUNT 32 B/segment, MIN 4, MAX 4, SUM/AVG 73 B/segment + payloads.
+#include "mdb_segment_dev.hpp"
+
+#include <cfloat>
+
+namespace mdb {
+
+constexpr int AGG_THREADS = 256;
+
+struct AggPartial {
+    double sum;
+    long long count;
+    float min;
+    float max;
+    unsigned int error;
+    unsigned int pad;
+};
+
+__device__ __forceinline__ double shfl_down_f64(double v, int delta) {
+    unsigned long long bits = __double_as_longlong(v);
+    uint32_t lo = __shfl_down((uint32_t)bits, delta, MDB_WAVE);
+    uint32_t hi = __shfl_down((uint32_t)(bits >> 32), delta, MDB_WAVE);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ long long shfl_down_i64(long long v, int delta) {
+    uint32_t lo = __shfl_down((uint32_t)v, delta, MDB_WAVE);
+    uint32_t hi = __shfl_down((uint32_t)((unsigned long long)v >> 32), delta, MDB_WAVE);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// Fixed-order reduction of one value per thread to thread 0 of the block.
+__device__ __forceinline__ void block_reduce(AggPartial &p, AggPartial *lds) {
+#pragma unroll
+    for (int delta = MDB_WAVE / 2; delta > 0; delta >>= 1) {
+        p.sum += shfl_down_f64(p.sum, delta);
+        p.count += shfl_down_i64(p.count, delta);
+        p.min = min_num(p.min, __shfl_down(p.min, delta, MDB_WAVE));
+        p.max = max_num(p.max, __shfl_down(p.max, delta, MDB_WAVE));
+        p.error |= __shfl_down(p.error, delta, MDB_WAVE);
+    }
+    const int lane = threadIdx.x & (MDB_WAVE - 1);
+    const int wave = threadIdx.x / MDB_WAVE;
+    if (lane == 0) lds[wave] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n_waves = blockDim.x / MDB_WAVE;
+        for (int w = 1; w < n_waves; w++) {
+            p.sum += lds[w].sum;
+            p.count += lds[w].count;
+            p.min = min_num(p.min, lds[w].min);
+            p.max = max_num(p.max, lds[w].max);
+            p.error |= lds[w].error;
+        }
+    }
+}
+
+__device__ __forceinline__ AggPartial empty_partial() {
+    AggPartial p;
+    p.sum = 0.0;
+    p.count = 0;
+    p.min = FLT_MAX;   // f32::MAX (model_simple_aggregates.rs:413)
+    p.max = -FLT_MAX;  // f32::MIN (model_simple_aggregates.rs:456)
+    p.error = 0;
+    p.pad = 0;
+    return p;
+}
+
+// models/mod.rs:129-184: the f32 sum of one segment.
+__device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, const SegInfo &info,
+                                             uint32_t length, uint32_t *error) {
+    const SegDesc &d = info.desc;
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    const uint32_t n_res = d.n_total - d.n_model;
+    if (length < n_res) {
+        *error |= ERR_RESIDUALS;
+        return 0.0f;
+    }
+    const uint32_t model_length = length - n_res;
+    float model_last_value = 0.0f;
+    float model_sum = 0.0f;
+    if (type == MDB_PMC_MEAN_ID) {
+        model_last_value = d.value;
+        model_sum = (float)model_length * d.value; // pmc_mean.rs:98-100
+    } else if (type == MDB_SWING_ID) {
+        model_last_value = info.swing_last;
+        // swing.rs:264-300, called with the SEGMENT's end_time.
+        const int64_t end = s.end_time[i];
+        LineDev line = line_through(d.start, (double)info.swing_first, end, (double)info.swing_last);
+        if (d.flags & FLAG_REGULAR) {
+            double first = line.slope * (double)d.start + line.intercept;
+            double last = line.slope * (double)end + line.intercept;
+            double average = (first + last) / 2.0;
+            model_sum = (float)(average * (double)model_length);
+        } else {
+            const uint4 vt = s.timestamps.views[i];
+            double sum = 0.0;
+            decode_irregular_timestamps(view_data(s.timestamps, i, vt), vt.x, d.start, end,
+                                        0xffffffffu, error, [&](uint32_t k, int64_t t) {
+                                            if (k < d.n_model)
+                                                sum += line.slope * (double)t + line.intercept;
+                                        });
+            model_sum = (float)sum;
+        }
+    } else {
+        model_last_value = __uint_as_float(0x7fc00000u); // f32::NAN (models/mod.rs:167)
+        const uint4 vv = s.values.views[i];
+        float sum = 0.0f;
+        decode_macaque_v(view_data(s.values, i, vv), vv.x, model_length, false, 0, error,
+                         [&](uint32_t k, uint32_t bits) {
+                             // macaque_v.rs:228-235: the sum starts AS the first value.
+                             if (k == 0) sum = __uint_as_float(bits);
+                             else sum += __uint_as_float(bits);
+                         });
+        model_sum = sum;
+    }
+    if (!(d.flags & FLAG_HAS_RESIDUALS)) return model_sum;
+    const uint4 vr = s.residuals.views[i];
+    float residuals_sum = 0.0f;
+    decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, n_res, true,
+                     __float_as_uint(model_last_value), error,
+                     [&](uint32_t, uint32_t bits) { residuals_sum += __uint_as_float(bits); });
+    return model_sum + residuals_sum;
+}
+
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uint32_t which_mask,
+                                                              AggPartial *__restrict__ partials) {
+    __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
+    AggPartial p = empty_partial();
+    const bool need_len = which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM);
+    for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
+         i += (uint64_t)gridDim.x * AGG_THREADS) {
+        if (which_mask & MDB_AGG_MIN) p.min = min_num(p.min, s.min_value[i]);
+        if (which_mask & MDB_AGG_MAX) p.max = max_num(p.max, s.max_value[i]);
+        if (!need_len) continue;
+        SegInfo info = analyse_segment(s, i);
+        // Only what len()/sum() themselves would trip over is an error here.
+        uint32_t error = info.error & (ERR_TIMESTAMPS | ERR_TOO_LONG);
+        // len() (models/mod.rs:98-124): a regular stream reports its stored length.
+        const uint32_t length = (info.desc.flags & FLAG_REGULAR) ? info.regular_length
+                                                                 : info.desc.n_total;
+        if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) p.count += length;
+        if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) {
+            error |= info.error;
+            if (!error) p.sum += (double)segment_sum(s, i, info, length, &error);
+        }
+        p.error |= error;
+    }
+    block_reduce(p, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_finish(const AggPartial *__restrict__ partials,
+                                                            uint32_t n_partials,
+                                                            AggPartial *__restrict__ result) {
+    __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
+    AggPartial p = empty_partial();
+    for (uint32_t i = threadIdx.x; i < n_partials; i += AGG_THREADS) {
+        const AggPartial q = partials[i];
+        p.sum += q.sum;
+        p.count += q.count;
+        p.min = min_num(p.min, q.min);
+        p.max = max_num(p.max, q.max);
+        p.error |= q.error;
+    }
+    block_reduce(p, lds);
+    if (threadIdx.x == 0) *result = p;
+}
+
+// ---- time-range extension ---------------------------------------------------------------------------
+
+struct RangeAcc {
+    double sum = 0.0;
+    long long count = 0;
+    float min = FLT_MAX;
+    float max = -FLT_MAX;
+    __device__ __forceinline__ void point(float v) {
+        sum += (double)v;
+        count += 1;
+        min = min_num(min, v);
+        max = max_num(max, v);
+    }
+};
+
+__device__ __forceinline__ float model_value_at(const SegDesc &d, uint32_t type, int64_t t) {
+    return type == MDB_PMC_MEAN_ID ? d.value : (float)(d.slope * (double)t + d.intercept);
+}
+
+// Aggregate the points of segment i whose timestamp lies in [t_lo, t_hi].
+__device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, const SegInfo &info,
+                                              int64_t t_lo, int64_t t_hi, RangeAcc &acc,
+                                              uint32_t *error) {
+    const SegDesc &d = info.desc;
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    const int64_t end = s.end_time[i];
+    const uint32_t n_res = d.n_total - d.n_model;
+    if (!(d.flags & FLAG_REGULAR)) {
+        // Irregular timestamps: one serial pass, every point tested.
+        if (end < t_lo || d.start > t_hi) return;
+        const uint4 vt = s.timestamps.views[i];
+        const uint8_t *ts_bytes = view_data(s.timestamps, i, vt);
+        if (type != MDB_MACAQUE_V_ID && n_res == 0) {
+            decode_irregular_timestamps(ts_bytes, vt.x, d.start, end, 0xffffffffu, error,
+                                        [&](uint32_t, int64_t t) {
+                                            if (t >= t_lo && t <= t_hi)
+                                                acc.point(model_value_at(d, type, t));
+                                        });
+            return;
+        }
+        // Values are a bitstream too (MacaqueV model or residual tail): first find the index
+        // interval of the in-range timestamps, then decode the values once. Rare combination.
+        uint32_t k_lo = 0xffffffffu, k_hi = 0;
+        decode_irregular_timestamps(ts_bytes, vt.x, d.start, end, 0xffffffffu, error,
+                                    [&](uint32_t k, int64_t t) {
+                                        if (t >= t_lo && t <= t_hi) {
+                                            if (k < k_lo) k_lo = k;
+                                            if (k > k_hi) k_hi = k;
+                                        }
+                                    });
+        if (k_lo == 0xffffffffu) return;
+        // Timestamps are sorted, so the in-range points are exactly the indices k_lo..k_hi.
+        float seed = d.value;
+        if (type == MDB_MACAQUE_V_ID) {
+            const uint4 vv = s.values.views[i];
+            uint32_t last_bits = 0;
+            decode_macaque_v(view_data(s.values, i, vv), vv.x, d.n_model, false, 0, error,
+                             [&](uint32_t k, uint32_t bits) {
+                                 if (k >= k_lo && k <= k_hi) acc.point(__uint_as_float(bits));
+                                 last_bits = bits;
+                             });
+            seed = __uint_as_float(last_bits);
+        } else {
+            decode_irregular_timestamps(ts_bytes, vt.x, d.start, end, d.n_model, error,
+                                        [&](uint32_t k, int64_t t) {
+                                            if (k >= k_lo && k <= k_hi)
+                                                acc.point(model_value_at(d, type, t));
+                                        });
+        }
+        if (n_res > 0) {
+            const uint4 vr = s.residuals.views[i];
+            decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, n_res, true,
+                             __float_as_uint(seed), error, [&](uint32_t k, uint32_t bits) {
+                                 uint32_t index = d.n_model + k;
+                                 if (index >= k_lo && index <= k_hi) acc.point(__uint_as_float(bits));
+                             });
+        }
+        return;
+    }
+
+    // Regular timestamps start + k * delta: the in-range indices are an interval [k_lo, k_hi].
+    uint32_t k_lo = 0, k_hi = 0;
+    if (d.n_total <= 2 || d.delta <= 0) {
+        // One or two points (or a degenerate interval): test them one by one.
+        bool any = false;
+        for (uint32_t k = 0; k < d.n_total; k++) {
+            int64_t t = d.start + (int64_t)((uint64_t)k * (uint64_t)d.delta);
+            if (t < t_lo || t > t_hi) continue;
+            if (!any) { k_lo = k; any = true; }
+            k_hi = k;
+        }
+        if (!any) return;
+    } else {
+        const int64_t last_t = d.start + (int64_t)((uint64_t)(d.n_total - 1) * (uint64_t)d.delta);
+        if (last_t < t_lo || d.start > t_hi) return;
+        const uint64_t delta = (uint64_t)d.delta;
+        if (t_lo > d.start) {
+            uint64_t gap = (uint64_t)t_lo - (uint64_t)d.start;
+            uint64_t k = (gap + delta - 1) / delta;
+            if (k > d.n_total - 1) return;
+            k_lo = (uint32_t)k;
+        }
+        if (t_hi >= last_t) {
+            k_hi = d.n_total - 1;
+        } else {
+            k_hi = (uint32_t)(((uint64_t)t_hi - (uint64_t)d.start) / delta);
+        }
+        if (k_hi < k_lo) return;
+    }
+
+    // Model part [a, b] of the interval.
+    if (type != MDB_MACAQUE_V_ID && k_lo < d.n_model) {
+        const uint32_t a = k_lo;
+        const uint32_t b = min(k_hi, d.n_model - 1);
+        const uint32_t n = b - a + 1;
+        const int64_t ta = d.start + (int64_t)((uint64_t)a * (uint64_t)d.delta);
+        const int64_t tb = d.start + (int64_t)((uint64_t)b * (uint64_t)d.delta);
+        const float va = model_value_at(d, type, ta);
+        const float vb = model_value_at(d, type, tb);
+        // (float)(slope * t + intercept) is monotone in t, so the extremes sit at the ends.
+        acc.min = min_num(acc.min, min_num(va, vb));
+        acc.max = max_num(acc.max, max_num(va, vb));
+        acc.count += n;
+        if (type == MDB_PMC_MEAN_ID) {
+            acc.sum += (double)d.value * (double)n;
+        } else {
+            // Sum of the line over n equally spaced points (f64 closed form of the f32 values).
+            double fa = d.slope * (double)ta + d.intercept;
+            double fb = d.slope * (double)tb + d.intercept;
+            acc.sum += (fa + fb) / 2.0 * (double)n;
+        }
+    }
+    float seed = d.value;
+    if (type == MDB_MACAQUE_V_ID) {
+        const uint4 vv = s.values.views[i];
+        uint32_t last_bits = 0;
+        // Decode only as far as needed unless the residual seed (last value) is needed too.
+        const bool residuals_in_range = n_res > 0 && k_hi >= d.n_model;
+        const uint32_t upto = residuals_in_range ? d.n_model : min(d.n_model, k_hi + 1);
+        if (k_lo < d.n_model || residuals_in_range) {
+            decode_macaque_v(view_data(s.values, i, vv), vv.x, upto, false, 0, error,
+                             [&](uint32_t k, uint32_t bits) {
+                                 if (k >= k_lo && k <= k_hi) acc.point(__uint_as_float(bits));
+                                 last_bits = bits;
+                             });
+        }
+        seed = __uint_as_float(last_bits);
+    }
+    if (n_res > 0 && k_hi >= d.n_model) {
+        const uint4 vr = s.residuals.views[i];
+        const uint32_t upto = k_hi - d.n_model + 1;
+        decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, upto, true, __float_as_uint(seed),
+                         error, [&](uint32_t k, uint32_t bits) {
+                             uint32_t index = d.n_model + k;
+                             if (index >= k_lo) acc.point(__uint_as_float(bits));
+                         });
+    }
+}
+
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_t t_lo, int64_t t_hi,
+                                                           AggPartial *__restrict__ partials) {
+    __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
+    AggPartial p = empty_partial();
+    for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
+         i += (uint64_t)gridDim.x * AGG_THREADS) {
+        // Cheap rejection on the two columns the reference prunes on (start_time / end_time).
+        if (s.end_time[i] < t_lo || s.start_time[i] > t_hi) continue;
+        SegInfo info = analyse_segment(s, i);
+        uint32_t error = info.error;
+        if (!error) {
+            RangeAcc acc;
+            segment_range(s, i, info, t_lo, t_hi, acc, &error);
+            p.sum += acc.sum;
+            p.count += acc.count;
+            p.min = min_num(p.min, acc.min);
+            p.max = max_num(p.max, acc.max);
+        }
+        p.error |= error;
+    }
+    block_reduce(p, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
+int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int64_t t_hi,
+            uint32_t which_mask, mdb_agg_state *inout) {
+    if (in->n == 0) return 0;
+    const uint32_t max_blocks = 256 * 8; // grid-stride beyond 8 workgroups per CU
+    const uint32_t n_blocks =
+        (uint32_t)std::min<uint64_t>((in->n + AGG_THREADS - 1) / AGG_THREADS, max_blocks);
+    void *p;
+    if (scratch_reserve(ctx, SCRATCH_AGG_PARTIALS, (uint64_t)(n_blocks + 1) * sizeof(AggPartial), &p))
+        return 1;
+    AggPartial *partials = static_cast<AggPartial *>(p);
+    AggPartial *result = partials + n_blocks;
+    DevSegments s = to_dev(in);
+    if (range) {
+        LaunchTimer timer(ctx, "k_agg_range");
+        hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
+                           t_hi, partials);
+    } else {
+        LaunchTimer timer(ctx, "k_agg_segments");
+        hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
+                           which_mask, partials);
+    }
+    {
+        LaunchTimer timer(ctx, "k_agg_finish");
+        hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(AGG_THREADS), 0, ctx->stream, partials,
+                           n_blocks, result);
+    }
+    AggPartial host;
+    MDB_HIP_CHECK(hipMemcpyAsync(&host, result, sizeof(AggPartial), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipGetLastError());
+    if (host.error) return fail(describe_error(host.error));
+    // Fold into the caller's running state exactly as update_batch would continue it.
+    if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) inout->count += host.count;
+    if (which_mask & MDB_AGG_MIN) inout->min = (inout->min != inout->min) ? host.min
+                                               : (host.min < inout->min ? host.min : inout->min);
+    if (which_mask & MDB_AGG_MAX) inout->max = (inout->max != inout->max) ? host.max
+                                               : (host.max > inout->max ? host.max : inout->max);
+    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) inout->sum += host.sum;
+    return 0;
+}
+
+} // namespace mdb
+
+using namespace mdb;
+
+extern "C" {
+
+int mdb_agg_batch_dev(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask,
+                      mdb_agg_state *inout) {
+    if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    return agg_run(ctx, in, false, 0, 0, which_mask, inout);
+}
+
+int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                            uint32_t which_mask, mdb_agg_state *inout) {
+    if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    return agg_run(ctx, in, true, t_lo, t_hi, which_mask, inout);
+}
+
+int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout) {
+    if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    mdb_segments_owned *dev = nullptr;
+    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    int rc = mdb_agg_batch_dev(ctx, &dev->seg, which_mask, inout);
+    mdb_segments_free(dev);
+    return rc;
+}
+
+int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                        uint32_t which_mask, mdb_agg_state *inout) {
+    if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    mdb_segments_owned *dev = nullptr;
+    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    int rc = mdb_agg_batch_range_dev(ctx, &dev->seg, t_lo, t_hi, which_mask, inout);
+    mdb_segments_free(dev);
+    return rc;
+}
+
+} // extern "C"

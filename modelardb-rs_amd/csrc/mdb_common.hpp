@@ -1,0 +1,305 @@
+// mdb_common.hpp - context, error handling, launch/profiling helpers and device-side primitives
+// shared by the HIP translation units of libmdb_hip.so. gfx950 (MI355X) only: wave64, no
+// compatibility paths. Everything on the value path is built with -ffp-contract=off because the
+// reference (Rust) never fuses a*b+c.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mdb.h"
+
+namespace mdb {
+
+// ---- errors (capi.rs:58-80 convention: 0 ok, 1 failure + thread-local message) -----------------
+
+extern thread_local std::string g_last_error;
+
+inline int fail(const std::string &message) {
+    g_last_error = message;
+    return 1;
+}
+
+#define MDB_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t mdb_err_ = (expr);                                                              \
+        if (mdb_err_ != hipSuccess)                                                                \
+            return ::mdb::fail(std::string(#expr) + ": " + hipGetErrorString(mdb_err_));          \
+    } while (0)
+
+// ---- context -----------------------------------------------------------------------------------
+
+struct KernelTime {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct PendingEvent {
+    std::string name;
+    hipEvent_t start;
+    hipEvent_t stop;
+};
+
+enum ScratchSlot {
+    SCRATCH_DESC = 0,
+    SCRATCH_COUNTS,
+    SCRATCH_OFFSETS,
+    SCRATCH_BLOCK_SUMS,
+    SCRATCH_SERIAL_IDS,
+    SCRATCH_TILE_MAP,
+    SCRATCH_HEADER,
+    SCRATCH_AGG_PARTIALS,
+    SCRATCH_FIT_A,
+    SCRATCH_FIT_B,
+    SCRATCH_FIT_C,
+    SCRATCH_FIT_D,
+    SCRATCH_FIT_E,
+    SCRATCH_FIT_F,
+    SCRATCH_STAGE_DEV,
+    SCRATCH_SLOT_COUNT
+};
+
+} // namespace mdb
+
+struct mdb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mutex;
+    int compute_units = 0;
+
+    void *scratch[mdb::SCRATCH_SLOT_COUNT] = {};
+    uint64_t scratch_bytes[mdb::SCRATCH_SLOT_COUNT] = {};
+    void *pinned = nullptr; // pinned host staging
+    uint64_t pinned_bytes = 0;
+
+    bool profiling = false;
+    std::map<std::string, mdb::KernelTime> kernel_times;
+    std::vector<mdb::PendingEvent> pending_events;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace mdb {
+
+// Grow-only device scratch, one allocation per slot.
+int scratch_reserve(mdb_ctx *ctx, ScratchSlot slot, uint64_t bytes, void **out);
+int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out);
+int profile_collect(mdb_ctx *ctx);
+
+// Brackets a launch with events when profiling is on.
+struct LaunchTimer {
+    mdb_ctx *ctx;
+    const char *name;
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+    LaunchTimer(mdb_ctx *c, const char *n);
+    ~LaunchTimer();
+};
+
+// Owner bookkeeping behind mdb_segments_owned::priv_.
+struct OwnedSegments {
+    mdb_segments_owned c;
+    int device = -1;                   // -1: host memory
+    std::vector<void *> device_allocs; // hipFree'd on release
+    std::vector<std::vector<uint8_t>> host_allocs;
+    const uint8_t *buffer_ptrs[3] = {nullptr, nullptr, nullptr}; // host view of per-column data ptr
+    int64_t buffer_sizes[3] = {0, 0, 0};
+};
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// ---- device primitives ---------------------------------------------------------------------------
+
+#define MDB_WAVE 64
+
+// The three 32-bit payload words of a BinaryView are [1..3] of the 16-byte view loaded as uint4.
+__device__ __forceinline__ uint32_t view_inline_byte(const uint4 &view, uint32_t k) {
+    uint32_t word = (k < 4) ? view.y : ((k < 8) ? view.z : view.w);
+    return (word >> (8u * (k & 3u))) & 0xffu;
+}
+
+struct DevCol {
+    const uint4 *views;
+    const uint8_t *const *buffers;
+};
+
+// Global-memory pointer to the bytes of row `row` (inline bytes live inside the view itself).
+__device__ __forceinline__ const uint8_t *view_data(const DevCol &col, uint64_t row,
+                                                    const uint4 &view) {
+    int32_t length = (int32_t)view.x;
+    if (length <= 12) return reinterpret_cast<const uint8_t *>(col.views + row) + 4;
+    return col.buffers[(int32_t)view.z] + (int32_t)view.w;
+}
+
+struct DevSegments {
+    uint64_t n;
+    const int8_t *model_type_id;
+    const int64_t *start_time;
+    const int64_t *end_time;
+    DevCol timestamps;
+    const float *min_value;
+    const float *max_value;
+    DevCol values;
+    DevCol residuals;
+};
+
+inline DevSegments to_dev(const mdb_segments *s) {
+    DevSegments d;
+    d.n = s->n;
+    d.model_type_id = s->model_type_id;
+    d.start_time = s->start_time;
+    d.end_time = s->end_time;
+    d.timestamps = {reinterpret_cast<const uint4 *>(s->timestamps.views), s->timestamps.buffers};
+    d.min_value = s->min_value;
+    d.max_value = s->max_value;
+    d.values = {reinterpret_cast<const uint4 *>(s->values.views), s->values.buffers};
+    d.residuals = {reinterpret_cast<const uint4 *>(s->residuals.views), s->residuals.buffers};
+    return d;
+}
+
+// MSB-first bit reader over global memory (models/bits.rs:25-83 semantics). Loads aligned 32-bit
+// words; a word that contains at least one payload byte never crosses a page, so touching the
+// slack bytes of the first/last word is safe.
+struct BitReaderDev {
+    const uint32_t *words; // aligned base
+    uint32_t next_word;
+    uint32_t n_words;
+    uint64_t buffer; // MSB aligned
+    int32_t available;
+    uint64_t used_bits;
+    uint64_t total_bits;
+
+    __device__ __forceinline__ void init(const uint8_t *bytes, uint64_t nbytes) {
+        uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        uint32_t misalign = (uint32_t)(address & 3u);
+        words = reinterpret_cast<const uint32_t *>(address - misalign);
+        n_words = (uint32_t)((nbytes + misalign + 3u) >> 2);
+        next_word = 0;
+        buffer = 0;
+        available = 0;
+        used_bits = 0;
+        total_bits = nbytes * 8u;
+        if (misalign) {
+            refill();
+            buffer <<= 8u * misalign;
+            available -= 8 * (int32_t)misalign;
+        }
+    }
+
+    __device__ __forceinline__ void refill() {
+        while (available <= 32 && next_word < n_words) {
+            uint32_t w = __builtin_bswap32(words[next_word++]);
+            buffer |= (uint64_t)w << (32 - available);
+            available += 32;
+        }
+    }
+
+    __device__ __forceinline__ uint64_t remaining() const { return total_bits - used_bits; }
+    __device__ __forceinline__ bool exhausted() const { return used_bits >= total_bits; }
+
+    // count in [0, 32]. Reads past the end return zeros and are flagged by overrun().
+    __device__ __forceinline__ uint32_t get(uint32_t count) {
+        if (count == 0) return 0;
+        refill();
+        uint32_t value = (uint32_t)(buffer >> (64u - count));
+        buffer <<= count;
+        available -= (int32_t)count;
+        used_bits += count;
+        return value;
+    }
+
+    __device__ __forceinline__ uint64_t get64(uint32_t count) {
+        if (count <= 32) return get(count);
+        uint64_t high = get(count - 32);
+        return (high << 32) | get(32);
+    }
+
+    __device__ __forceinline__ bool overrun() const { return used_bits > total_bits; }
+};
+
+// Rust f32::min / f32::max as the oracle defines them: minNum / maxNum, first operand kept on ties.
+__device__ __forceinline__ float min_num(float a, float b) {
+    if (a != a) return b;
+    return (b < a) ? b : a;
+}
+__device__ __forceinline__ float max_num(float a, float b) {
+    if (a != a) return b;
+    return (b > a) ? b : a;
+}
+__device__ __forceinline__ double min_num(double a, double b) {
+    if (a != a) return b;
+    return (b < a) ? b : a;
+}
+__device__ __forceinline__ double max_num(double a, double b) {
+    if (a != a) return b;
+    return (b > a) ? b : a;
+}
+
+__device__ __forceinline__ bool equal_or_nan(double a, double b) {
+    return a == b || (a != a && b != b);
+}
+
+struct LineDev {
+    double slope;
+    double intercept;
+};
+
+// models/swing.rs:323-340
+__device__ __forceinline__ LineDev line_through(int64_t t0, double v0, int64_t t1, double v1) {
+    if (equal_or_nan(v0, v1)) return {0.0, v0};
+    double slope = (v1 - v0) / (double)(t1 - t0);
+    double intercept = v0 - slope * (double)t0;
+    return {slope, intercept};
+}
+
+// Wave-wide and block-wide exclusive scans of 64-bit values (the "wavefront prefix-sum").
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int delta) {
+    uint32_t lo = __shfl_up((uint32_t)v, delta, MDB_WAVE);
+    uint32_t hi = __shfl_up((uint32_t)(v >> 32), delta, MDB_WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v) {
+    int lane = threadIdx.x & (MDB_WAVE - 1);
+#pragma unroll
+    for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+        uint64_t up = shfl_up_u64(v, delta);
+        if (lane >= delta) v += up;
+    }
+    return v;
+}
+
+// Exclusive scan over the block (blockDim.x multiple of 64, <= 1024). `total` gets the block sum.
+// `lds` needs 17 uint64_t.
+__device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t *lds,
+                                                             uint64_t *total) {
+    int lane = threadIdx.x & (MDB_WAVE - 1);
+    int wave = threadIdx.x / MDB_WAVE;
+    int n_waves = (blockDim.x + MDB_WAVE - 1) / MDB_WAVE;
+    uint64_t inclusive = wave_inclusive_scan_u64(v);
+    if (lane == MDB_WAVE - 1) lds[wave] = inclusive;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t running = 0;
+        for (int w = 0; w < n_waves; w++) {
+            uint64_t t = lds[w];
+            lds[w] = running;
+            running += t;
+        }
+        lds[16] = running;
+    }
+    __syncthreads();
+    uint64_t result = lds[wave] + inclusive - v;
+    *total = lds[16];
+    __syncthreads();
+    return result;
+}
+
+} // namespace mdb

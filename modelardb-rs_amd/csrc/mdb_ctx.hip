@@ -1,0 +1,441 @@
+// mdb_ctx.hip - context lifetime, device memory, segment upload/download and launch profiling of
+// libmdb_hip.so (see include/mdb.h for the contract of every entry point).
+#include "mdb_common.hpp"
+
+namespace mdb {
+
+thread_local std::string g_last_error;
+
+int scratch_reserve(mdb_ctx *ctx, ScratchSlot slot, uint64_t bytes, void **out) {
+    if (bytes == 0) bytes = 256;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            MDB_HIP_CHECK(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        uint64_t grown = align_up(bytes + bytes / 8, 1 << 12);
+        MDB_HIP_CHECK(hipMalloc(&ctx->scratch[slot], grown));
+        ctx->scratch_bytes[slot] = grown;
+    }
+    *out = ctx->scratch[slot];
+    return 0;
+}
+
+int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out) {
+    if (bytes == 0) bytes = 256;
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) {
+            MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            MDB_HIP_CHECK(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        uint64_t grown = align_up(bytes + bytes / 8, 1 << 12);
+        MDB_HIP_CHECK(hipHostMalloc(&ctx->pinned, grown, hipHostMallocDefault));
+        ctx->pinned_bytes = grown;
+    }
+    *out = ctx->pinned;
+    return 0;
+}
+
+LaunchTimer::LaunchTimer(mdb_ctx *c, const char *n) : ctx(c), name(n) {
+    if (!ctx->profiling) return;
+    auto take = [&]() {
+        hipEvent_t e = nullptr;
+        if (!ctx->event_pool.empty()) {
+            e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        return e;
+    };
+    start = take();
+    stop = take();
+    if (start) (void)hipEventRecord(start, ctx->stream);
+}
+
+LaunchTimer::~LaunchTimer() {
+    if (!ctx->profiling || !start || !stop) return;
+    (void)hipEventRecord(stop, ctx->stream);
+    ctx->pending_events.push_back({name, start, stop});
+}
+
+int profile_collect(mdb_ctx *ctx) {
+    if (ctx->pending_events.empty()) return 0;
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->pending_events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            KernelTime &k = ctx->kernel_times[p.name];
+            k.launches += 1;
+            k.total_ms += ms;
+        }
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->pending_events.clear();
+    return 0;
+}
+
+} // namespace mdb
+
+using namespace mdb;
+
+extern "C" {
+
+const char *mdb_last_error(void) { return g_last_error.c_str(); }
+
+const char *mdb_version(void) { return "libmdb_hip 0.1.0 gfx950"; }
+
+int mdb_init(int device, mdb_ctx **out) {
+    if (!out) return fail("ctx must not be NULL.");
+    *out = nullptr;
+    int count = 0;
+    MDB_HIP_CHECK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return fail("No such HIP device: " + std::to_string(device) + " of " + std::to_string(count));
+    MDB_HIP_CHECK(hipSetDevice(device));
+    mdb_ctx *ctx = new mdb_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->compute_units = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail("hipStreamCreate failed.");
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return 0;
+}
+
+int mdb_close(mdb_ctx *ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending_events) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < SCRATCH_SLOT_COUNT; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int mdb_set_stream(mdb_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return 0;
+}
+
+int mdb_device_info(mdb_ctx *ctx, char *name, uint64_t name_cap, int32_t *compute_units,
+                    uint64_t *hbm_bytes) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    hipDeviceProp_t prop;
+    MDB_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap) {
+        std::string full = std::string(prop.name) + " " + prop.gcnArchName;
+        std::strncpy(name, full.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return 0;
+}
+
+int mdb_dev_alloc(mdb_ctx *ctx, uint64_t bytes, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return fail("ctx and dev_ptr must not be NULL.");
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    MDB_HIP_CHECK(hipMalloc(dev_ptr, bytes ? bytes : 256));
+    return 0;
+}
+
+int mdb_dev_free(mdb_ctx *ctx, void *dev_ptr) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipFree(dev_ptr));
+    return 0;
+}
+
+int mdb_dev_upload(mdb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    if (bytes == 0) return 0;
+    MDB_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    if (bytes == 0) return 0;
+    MDB_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int mdb_dev_sync(mdb_ctx *ctx) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Layout of an uploaded batch: one device blob holding, 256-byte aligned each, the five primitive
+// columns, the three view arrays, every variadic data buffer, and three pointer tables.
+int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_owned **out) {
+    if (!ctx || !host || !out) return fail("ctx, host and out must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n = host->n;
+    const mdb_binview_col *cols[3] = {&host->timestamps, &host->values, &host->residuals};
+    for (int c = 0; c < 3; c++) {
+        if (cols[c]->n_buffers < 0) return fail("n_buffers must not be negative.");
+        if (cols[c]->n_buffers > 0 && (!cols[c]->buffers || !cols[c]->buffer_sizes))
+            return fail("buffers and buffer_sizes must be given when n_buffers > 0.");
+    }
+
+    struct Piece {
+        const void *src;
+        uint64_t bytes;
+        uint64_t offset;
+    };
+    std::vector<Piece> pieces;
+    uint64_t cursor = 0;
+    auto add = [&](const void *src, uint64_t bytes) {
+        uint64_t offset = cursor;
+        pieces.push_back({src, bytes, offset});
+        cursor = align_up(cursor + bytes, 256);
+        return offset;
+    };
+    uint64_t off_type = add(host->model_type_id, n);
+    uint64_t off_start = add(host->start_time, 8 * n);
+    uint64_t off_end = add(host->end_time, 8 * n);
+    uint64_t off_min = add(host->min_value, 4 * n);
+    uint64_t off_max = add(host->max_value, 4 * n);
+    uint64_t off_views[3];
+    std::vector<uint64_t> off_buffers[3];
+    uint64_t off_tables[3];
+    for (int c = 0; c < 3; c++) {
+        off_views[c] = add(cols[c]->views, 16 * n);
+        for (int b = 0; b < cols[c]->n_buffers; b++)
+            off_buffers[c].push_back(add(cols[c]->buffers[b], (uint64_t)cols[c]->buffer_sizes[b]));
+    }
+    for (int c = 0; c < 3; c++) off_tables[c] = add(nullptr, 8 * (uint64_t)(cols[c]->n_buffers + 1));
+    uint64_t total = cursor ? cursor : 256;
+
+    OwnedSegments *owned = new OwnedSegments();
+    void *blob = nullptr;
+    if (hipMalloc(&blob, total) != hipSuccess) {
+        delete owned;
+        return fail("hipMalloc of " + std::to_string(total) + " bytes failed.");
+    }
+    owned->device = ctx->device;
+    owned->device_allocs.push_back(blob);
+    uint8_t *dev = static_cast<uint8_t *>(blob);
+
+    void *stage_v = nullptr;
+    if (pinned_reserve(ctx, total, &stage_v)) {
+        (void)hipFree(blob);
+        delete owned;
+        return 1;
+    }
+    uint8_t *stage = static_cast<uint8_t *>(stage_v);
+    for (auto &p : pieces)
+        if (p.src && p.bytes) std::memcpy(stage + p.offset, p.src, p.bytes);
+    for (int c = 0; c < 3; c++) {
+        uint64_t *table = reinterpret_cast<uint64_t *>(stage + off_tables[c]);
+        for (int b = 0; b < cols[c]->n_buffers; b++)
+            table[b] = reinterpret_cast<uint64_t>(dev + off_buffers[c][b]);
+        table[cols[c]->n_buffers] = 0;
+    }
+    if (hipMemcpyAsync(dev, stage, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(blob);
+        delete owned;
+        return fail("hipMemcpy host to device failed.");
+    }
+
+    // Host-side copy of the buffer sizes so a later download knows how much to copy.
+    owned->host_allocs.resize(3);
+    mdb_segments &s = owned->c.seg;
+    s.n = n;
+    s.model_type_id = reinterpret_cast<const int8_t *>(dev + off_type);
+    s.start_time = reinterpret_cast<const int64_t *>(dev + off_start);
+    s.end_time = reinterpret_cast<const int64_t *>(dev + off_end);
+    s.min_value = reinterpret_cast<const float *>(dev + off_min);
+    s.max_value = reinterpret_cast<const float *>(dev + off_max);
+    mdb_binview_col *out_cols[3] = {&s.timestamps, &s.values, &s.residuals};
+    for (int c = 0; c < 3; c++) {
+        owned->host_allocs[c].resize(8 * (size_t)(cols[c]->n_buffers + 1));
+        int64_t *sizes = reinterpret_cast<int64_t *>(owned->host_allocs[c].data());
+        for (int b = 0; b < cols[c]->n_buffers; b++) sizes[b] = cols[c]->buffer_sizes[b];
+        out_cols[c]->views = reinterpret_cast<const mdb_view16 *>(dev + off_views[c]);
+        out_cols[c]->buffers = reinterpret_cast<const uint8_t *const *>(dev + off_tables[c]);
+        out_cols[c]->buffer_sizes = sizes;
+        out_cols[c]->n_buffers = cols[c]->n_buffers;
+    }
+    owned->c.error = nullptr;
+    owned->c.chunk_index = nullptr;
+    owned->c.on_device = 1;
+    owned->c.priv_ = owned;
+    *out = &owned->c;
+    return 0;
+}
+
+int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **out) {
+    if (!ctx || !dev || !out) return fail("ctx, dev and out must not be NULL.");
+    if (!dev->on_device) return fail("The batch is already in host memory.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    const mdb_segments &d = dev->seg;
+    const uint64_t n = d.n;
+    OwnedSegments *owned = new OwnedSegments();
+    // 0 type, 1 start, 2 end, 3 min, 4 max, 5-7 views, 8-10 data, 11 error, 12 chunk_index
+    owned->host_allocs.resize(13);
+    auto fetch = [&](int slot, const void *src, uint64_t bytes) -> int {
+        owned->host_allocs[slot].resize(bytes);
+        if (bytes == 0 || !src) return 0;
+        MDB_HIP_CHECK(hipMemcpyAsync(owned->host_allocs[slot].data(), src, bytes,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    };
+    int rc = 0;
+    rc |= fetch(0, d.model_type_id, n);
+    rc |= fetch(1, d.start_time, 8 * n);
+    rc |= fetch(2, d.end_time, 8 * n);
+    rc |= fetch(3, d.min_value, 4 * n);
+    rc |= fetch(4, d.max_value, 4 * n);
+    const mdb_binview_col *cols[3] = {&d.timestamps, &d.values, &d.residuals};
+    // Pointer tables live on the device; read them back to find each data buffer.
+    std::vector<uint64_t> tables[3];
+    for (int c = 0; c < 3 && !rc; c++) {
+        rc |= fetch(5 + c, cols[c]->views, 16 * n);
+        tables[c].resize((size_t)cols[c]->n_buffers);
+        if (cols[c]->n_buffers > 0 &&
+            hipMemcpyAsync(tables[c].data(), cols[c]->buffers, 8 * (size_t)cols[c]->n_buffers,
+                           hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            rc = fail("hipMemcpy of the buffer table failed.");
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+    // Concatenate the variadic buffers of each column into one host buffer and rebase the views.
+    for (int c = 0; c < 3 && !rc; c++) {
+        uint64_t total = 0;
+        std::vector<uint64_t> base((size_t)cols[c]->n_buffers);
+        for (int b = 0; b < cols[c]->n_buffers; b++) {
+            base[b] = total;
+            total += (uint64_t)cols[c]->buffer_sizes[b];
+        }
+        if (total > 0x7fffffffull) rc = fail("A downloaded column exceeds 2 GiB of payload.");
+        owned->host_allocs[8 + c].resize(total);
+        for (int b = 0; b < cols[c]->n_buffers && !rc; b++) {
+            uint64_t bytes = (uint64_t)cols[c]->buffer_sizes[b];
+            if (bytes && hipMemcpyAsync(owned->host_allocs[8 + c].data() + base[b],
+                                        reinterpret_cast<const void *>(tables[c][b]), bytes,
+                                        hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy of a data buffer failed.");
+        }
+        if (!rc && cols[c]->n_buffers > 1) {
+            mdb_view16 *views = reinterpret_cast<mdb_view16 *>(owned->host_allocs[5 + c].data());
+            for (uint64_t i = 0; i < n; i++) {
+                if (views[i].length > 12) {
+                    views[i].u.ref.offset += (int32_t)base[views[i].u.ref.buffer_index];
+                    views[i].u.ref.buffer_index = 0;
+                }
+            }
+        }
+    }
+    if (!rc && dev->error) rc |= fetch(11, dev->error, 4 * n);
+    if (!rc && dev->chunk_index) rc |= fetch(12, dev->chunk_index, 4 * n);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+    if (rc) {
+        delete owned;
+        return 1;
+    }
+    mdb_segments &s = owned->c.seg;
+    s.n = n;
+    s.model_type_id = reinterpret_cast<const int8_t *>(owned->host_allocs[0].data());
+    s.start_time = reinterpret_cast<const int64_t *>(owned->host_allocs[1].data());
+    s.end_time = reinterpret_cast<const int64_t *>(owned->host_allocs[2].data());
+    s.min_value = reinterpret_cast<const float *>(owned->host_allocs[3].data());
+    s.max_value = reinterpret_cast<const float *>(owned->host_allocs[4].data());
+    mdb_binview_col *out_cols[3] = {&s.timestamps, &s.values, &s.residuals};
+    for (int c = 0; c < 3; c++) {
+        owned->buffer_ptrs[c] = owned->host_allocs[8 + c].data();
+        owned->buffer_sizes[c] = (int64_t)owned->host_allocs[8 + c].size();
+        out_cols[c]->views = reinterpret_cast<const mdb_view16 *>(owned->host_allocs[5 + c].data());
+        out_cols[c]->buffers = &owned->buffer_ptrs[c];
+        out_cols[c]->buffer_sizes = &owned->buffer_sizes[c];
+        out_cols[c]->n_buffers = 1;
+    }
+    owned->c.error = dev->error ? reinterpret_cast<const float *>(owned->host_allocs[11].data()) : nullptr;
+    owned->c.chunk_index =
+        dev->chunk_index ? reinterpret_cast<const uint32_t *>(owned->host_allocs[12].data()) : nullptr;
+    owned->c.on_device = 0;
+    owned->c.priv_ = owned;
+    *out = &owned->c;
+    return 0;
+}
+
+void mdb_segments_free(mdb_segments_owned *segments) {
+    if (!segments) return;
+    OwnedSegments *owned = static_cast<OwnedSegments *>(segments->priv_);
+    if (!owned) return;
+    if (owned->device >= 0) {
+        (void)hipSetDevice(owned->device);
+        (void)hipDeviceSynchronize();
+        for (void *p : owned->device_allocs) (void)hipFree(p);
+    }
+    delete owned;
+}
+
+int mdb_profile_enable(mdb_ctx *ctx, int enabled) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (profile_collect(ctx)) return 1;
+    ctx->profiling = enabled != 0;
+    return 0;
+}
+
+int mdb_profile_reset(mdb_ctx *ctx) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (profile_collect(ctx)) return 1;
+    ctx->kernel_times.clear();
+    return 0;
+}
+
+int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *total_ms) {
+    if (!ctx || !name) return fail("ctx and name must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (profile_collect(ctx)) return 1;
+    auto it = ctx->kernel_times.find(name);
+    if (launches) *launches = it == ctx->kernel_times.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == ctx->kernel_times.end() ? 0.0 : it->second.total_ms;
+    return 0;
+}
+
+int mdb_profile_names(mdb_ctx *ctx, char *out, uint64_t cap) {
+    if (!ctx || !out || cap == 0) return fail("ctx and out must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (profile_collect(ctx)) return 1;
+    std::string joined;
+    for (auto &kv : ctx->kernel_times) {
+        if (!joined.empty()) joined += "\n";
+        joined += kv.first;
+    }
+    std::strncpy(out, joined.c_str(), cap - 1);
+    out[cap - 1] = 0;
+    return 0;
+}
+
+} // extern "C"

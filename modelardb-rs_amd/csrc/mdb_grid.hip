@@ -1,0 +1,508 @@
+// mdb_grid.hip - grid(): segment -> data point reconstruction on gfx950.
+//
+// Replaces the per-row loop of GridStream (crates/modelardb_storage/src/query/grid_exec.rs:323-356)
+// and modelardb_compression::grid (crates/modelardb_compression/src/models/mod.rs:190-251).
+//
+// Pipeline (all on the context's stream):
+//   k_grid_prepass   1 thread / segment: len(), residual count, values-column decode, Swing
+//                    slope/intercept (f64 divide once per segment, not per point) -> 48 B descriptor
+//                    + per-segment point count; per-block totals.
+//   k_scan_blocks    one block scans the per-block totals.
+//   k_grid_offsets   block-wide wavefront prefix sums -> 64-bit output offsets, the compacted list of
+//                    segments with serial work, rows-per-segment, and the tile -> first segment map.
+//   k_grid_tiles     the HBM-store-bound kernel: one 4096-point output tile per workgroup, each
+//                    lane writes 4 consecutive points with 16-byte stores; handles every point of a
+//                    regular-timestamp segment that a PMC-Mean / Swing model represents.
+//   k_grid_serial    1 lane / segment with a serial dependency: MacaqueV value streams, residual
+//                    tails (<= 255 values) and irregular (delta-of-delta) timestamps.
+// Algorithmic bytes: 73 B/segment read + 12 B/point written (8 B timestamp + 4 B value).
+#include "mdb_segment_dev.hpp"
+
+namespace mdb {
+
+constexpr int PREPASS_THREADS = 256;
+constexpr int PREPASS_ITEMS = 4; // segments per thread in the scan kernels
+constexpr int SEGS_PER_BLOCK = PREPASS_THREADS * PREPASS_ITEMS;
+constexpr uint32_t TILE_POINTS = 4096;
+constexpr int TILE_THREADS = 256;
+constexpr int TILE_LDS_SEGMENTS = 1024; // more segments than this in one tile -> global search
+struct GridHeader {
+    unsigned long long total_points;
+    unsigned long long n_serial;
+    unsigned int error;
+    unsigned int pad;
+    unsigned long long metrics[10]; // mdb_grid_metrics minus rows_created (= total_points)
+};
+
+__global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
+    DevSegments s, SegDesc *__restrict__ desc, uint32_t *__restrict__ counts,
+    unsigned long long *__restrict__ block_points, unsigned long long *__restrict__ block_serial,
+    GridHeader *__restrict__ header) {
+    __shared__ unsigned long long lds_metrics[12];
+    if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * SEGS_PER_BLOCK;
+    unsigned long long points = 0, serial = 0;
+    unsigned long long m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t error = 0;
+#pragma unroll 1
+    for (int k = 0; k < PREPASS_ITEMS; k++) {
+        uint64_t i = base + (uint64_t)k * PREPASS_THREADS + threadIdx.x;
+        if (i >= s.n) break;
+        SegInfo info = analyse_segment(s, i);
+        error |= info.error;
+        const SegDesc &d = info.desc;
+        desc[i] = d;
+        bool is_serial = (d.flags & FLAG_SERIAL) != 0;
+        counts[i] = d.n_total | (is_serial ? SERIAL_BIT : 0u);
+        points += d.n_total;
+        serial += is_serial ? 1 : 0;
+        uint32_t type = d.flags & FLAG_TYPE_MASK;
+        if (type < 3) {
+            m[type] += d.n_total;  // rows_created_by_model_type
+            m[4 + type] += 1;      // segments_with_model_type
+        }
+        m[3] += (d.flags & FLAG_HAS_RESIDUALS) ? 1 : 0;
+        m[7] += (d.flags & FLAG_REGULAR) ? 1 : 0;
+        m[8] += (d.flags & FLAG_REGULAR) ? 0 : 1;
+    }
+    // Block totals through LDS atomics (few per thread, once per block).
+    atomicAdd(&lds_metrics[10], points);
+    atomicAdd(&lds_metrics[11], serial);
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        if (m[k]) atomicAdd(&lds_metrics[k], m[k]);
+    if (error) atomicOr(&header->error, error);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_points[blockIdx.x] = lds_metrics[10];
+        block_serial[blockIdx.x] = lds_metrics[11];
+    }
+    if (threadIdx.x < 9 && lds_metrics[threadIdx.x])
+        atomicAdd(&header->metrics[threadIdx.x], lds_metrics[threadIdx.x]);
+}
+
+// One block: exclusive scan of the per-block totals (in place), totals into the header.
+__global__ __launch_bounds__(1024) void k_scan_blocks(unsigned long long *__restrict__ block_points,
+                                                      unsigned long long *__restrict__ block_serial,
+                                                      uint32_t n_blocks, GridHeader *__restrict__ header) {
+    __shared__ uint64_t lds[17];
+    uint64_t carry_points = 0, carry_serial = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t p = i < n_blocks ? block_points[i] : 0;
+        uint64_t q = i < n_blocks ? block_serial[i] : 0;
+        uint64_t total_p, total_q;
+        uint64_t ep = block_exclusive_scan_u64(p, lds, &total_p);
+        uint64_t eq = block_exclusive_scan_u64(q, lds, &total_q);
+        if (i < n_blocks) {
+            block_points[i] = carry_points + ep;
+            block_serial[i] = carry_serial + eq;
+        }
+        carry_points += total_p;
+        carry_serial += total_q;
+    }
+    if (threadIdx.x == 0) {
+        header->total_points = carry_points;
+        header->n_serial = carry_serial;
+    }
+}
+
+__global__ __launch_bounds__(PREPASS_THREADS) void k_grid_offsets(
+    const uint32_t *__restrict__ counts, uint64_t n, const unsigned long long *__restrict__ block_points,
+    const unsigned long long *__restrict__ block_serial, unsigned long long *__restrict__ offsets,
+    uint32_t *__restrict__ serial_ids, uint32_t *__restrict__ tile_first,
+    uint32_t *__restrict__ rows_per_segment) {
+    __shared__ uint64_t lds[17];
+    const uint64_t first = (uint64_t)blockIdx.x * SEGS_PER_BLOCK + (uint64_t)threadIdx.x * PREPASS_ITEMS;
+    uint32_t c[PREPASS_ITEMS];
+    if (first + PREPASS_ITEMS <= n) {
+        uint4 v = *reinterpret_cast<const uint4 *>(counts + first);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PREPASS_ITEMS; k++) c[k] = (first + k < n) ? counts[first + k] : 0u;
+    }
+    uint64_t local_points = 0, local_serial = 0;
+#pragma unroll
+    for (int k = 0; k < PREPASS_ITEMS; k++) {
+        local_points += c[k] & COUNT_MASK;
+        local_serial += c[k] >> 31;
+    }
+    uint64_t total;
+    uint64_t point_offset = block_points[blockIdx.x] + block_exclusive_scan_u64(local_points, lds, &total);
+    uint64_t serial_offset = block_serial[blockIdx.x] + block_exclusive_scan_u64(local_serial, lds, &total);
+#pragma unroll
+    for (int k = 0; k < PREPASS_ITEMS; k++) {
+        uint64_t i = first + k;
+        if (i >= n) break;
+        uint32_t count = c[k] & COUNT_MASK;
+        offsets[i] = point_offset;
+        if (rows_per_segment) rows_per_segment[i] = count;
+        if (c[k] >> 31) serial_ids[serial_offset++] = (uint32_t)i;
+        // This segment owns every tile whose first point lies inside it.
+        uint64_t end = point_offset + count;
+        for (uint64_t t = (point_offset + TILE_POINTS - 1) / TILE_POINTS; t * TILE_POINTS < end; t++)
+            tile_first[t] = (uint32_t)i;
+        point_offset = end;
+        if (i == n - 1) offsets[n] = end;
+    }
+}
+
+// ---- the tile kernel -------------------------------------------------------------------------------
+
+struct PointSegment {
+    uint32_t segment;
+    uint32_t index; // index of the point inside its segment
+};
+
+__device__ __forceinline__ void store_point(const SegDesc &d, uint32_t index, uint64_t p,
+                                            int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    if (!(d.flags & FLAG_REGULAR)) return; // irregular: k_grid_serial writes timestamps and values
+    int64_t t = d.start + (int64_t)((uint64_t)index * (uint64_t)d.delta);
+    out_ts[p] = t;
+    uint32_t type = d.flags & FLAG_TYPE_MASK;
+    if (index < d.n_model) {
+        if (type == MDB_PMC_MEAN_ID) out_val[p] = d.value;
+        else if (type == MDB_SWING_ID) out_val[p] = (float)(d.slope * (double)t + d.intercept);
+    }
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
+    const SegDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
+    uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    __shared__ uint32_t rel[TILE_LDS_SEGMENTS + 1]; // rel[k] = offsets[s0 + k] - tile_start, k >= 1
+    const uint64_t tile = blockIdx.x;
+    const uint64_t tile_start = tile * TILE_POINTS;
+    const uint64_t tile_end = min(total_points, tile_start + TILE_POINTS);
+    const uint32_t s0 = tile_first[tile];
+    const uint32_t s1 = (tile + 1 < n_tiles) ? tile_first[tile + 1] : (uint32_t)(n_segments - 1);
+    const uint32_t n_in_tile = s1 - s0 + 1;
+    const bool use_lds = n_in_tile <= TILE_LDS_SEGMENTS;
+    const uint64_t s0_offset = offsets[s0];
+    if (use_lds) {
+        for (uint32_t k = 1 + threadIdx.x; k < n_in_tile; k += TILE_THREADS)
+            rel[k] = (uint32_t)(offsets[s0 + k] - tile_start);
+        __syncthreads();
+    }
+
+#pragma unroll 1
+    for (uint32_t j = 0; j < TILE_POINTS / (TILE_THREADS * 4); j++) {
+        const uint64_t p = tile_start + (uint64_t)j * (TILE_THREADS * 4) + (uint64_t)threadIdx.x * 4;
+        if (p >= tile_end) break;
+        const uint32_t local = (uint32_t)(p - tile_start);
+        // Largest k in [0, n_in_tile) with offsets[s0 + k] <= p.
+        uint32_t lo = 0, hi = n_in_tile;
+        if (use_lds) {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (rel[mid] <= local) lo = mid; else hi = mid;
+            }
+        } else {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (offsets[s0 + mid] <= p) lo = mid; else hi = mid;
+            }
+        }
+        uint32_t segment = s0 + lo;
+        uint64_t segment_offset =
+            lo == 0 ? s0_offset : (use_lds ? tile_start + rel[lo] : (uint64_t)offsets[segment]);
+        SegDesc d = desc[segment];
+        uint32_t index = (uint32_t)(p - segment_offset);
+        const uint32_t type = d.flags & FLAG_TYPE_MASK;
+        const bool same_segment = (p + 4 <= tile_end) && (index + 4 <= d.n_total) &&
+                                  (d.flags & FLAG_REGULAR);
+        if (same_segment) {
+            // 4 points of one regular segment: two 16-byte timestamp stores, and one 16-byte value
+            // store when a PMC-Mean / Swing model represents all four.
+            int64_t t0 = d.start + (int64_t)((uint64_t)index * (uint64_t)d.delta);
+            int64_t t1 = t0 + d.delta, t2 = t1 + d.delta, t3 = t2 + d.delta;
+            longlong2 *ts_out = reinterpret_cast<longlong2 *>(out_ts + p);
+            ts_out[0] = make_longlong2(t0, t1);
+            ts_out[1] = make_longlong2(t2, t3);
+            if (type != MDB_MACAQUE_V_ID) {
+                float4 v;
+                if (type == MDB_PMC_MEAN_ID) {
+                    v = make_float4(d.value, d.value, d.value, d.value);
+                } else {
+                    v.x = (float)(d.slope * (double)t0 + d.intercept);
+                    v.y = (float)(d.slope * (double)t1 + d.intercept);
+                    v.z = (float)(d.slope * (double)t2 + d.intercept);
+                    v.w = (float)(d.slope * (double)t3 + d.intercept);
+                }
+                if (index + 4 <= d.n_model) {
+                    *reinterpret_cast<float4 *>(out_val + p) = v;
+                } else { // the model ends inside the group; the rest are residuals (k_grid_serial)
+                    if (index + 0 < d.n_model) out_val[p + 0] = v.x;
+                    if (index + 1 < d.n_model) out_val[p + 1] = v.y;
+                    if (index + 2 < d.n_model) out_val[p + 2] = v.z;
+                }
+            }
+        } else {
+            // Slow path: the 4 points straddle a segment / model / tile boundary.
+            uint64_t next_offset = segment_offset + d.n_total;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 4; k++) {
+                uint64_t q = p + k;
+                if (q >= tile_end) break;
+                while (q >= next_offset) { // advance to the segment holding q
+                    segment += 1;
+                    segment_offset = next_offset;
+                    d = desc[segment];
+                    next_offset = segment_offset + d.n_total;
+                }
+                store_point(d, (uint32_t)(q - segment_offset), q, out_ts, out_val);
+            }
+        }
+    }
+}
+
+// ---- the serial kernel -------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_grid_serial(DevSegments s, const SegDesc *__restrict__ desc,
+                                                     const unsigned long long *__restrict__ offsets,
+                                                     const uint32_t *__restrict__ serial_ids,
+                                                     uint64_t n_serial, int64_t *__restrict__ out_ts,
+                                                     float *__restrict__ out_val,
+                                                     GridHeader *__restrict__ header) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_serial) return;
+    const uint32_t i = serial_ids[slot];
+    const SegDesc d = desc[i];
+    const uint64_t o = offsets[i];
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    uint32_t error = 0;
+    float seed = d.value;
+    if (!(d.flags & FLAG_REGULAR)) {
+        // Irregular timestamps, and the model values that depend on them.
+        const uint4 vt = s.timestamps.views[i];
+        const uint8_t *bytes = view_data(s.timestamps, i, vt);
+        decode_irregular_timestamps(bytes, vt.x, d.start, s.end_time[i], 0xffffffffu, &error,
+                                    [&](uint32_t k, int64_t t) {
+                                        out_ts[o + k] = t;
+                                        if (k < d.n_model) {
+                                            if (type == MDB_PMC_MEAN_ID) out_val[o + k] = d.value;
+                                            else if (type == MDB_SWING_ID)
+                                                out_val[o + k] = (float)(d.slope * (double)t + d.intercept);
+                                        }
+                                    });
+    }
+    if (type == MDB_MACAQUE_V_ID) {
+        const uint4 vv = s.values.views[i];
+        uint32_t last_bits = 0;
+        decode_macaque_v(view_data(s.values, i, vv), vv.x, d.n_model, false, 0, &error,
+                         [&](uint32_t k, uint32_t bits) {
+                             out_val[o + k] = __uint_as_float(bits);
+                             last_bits = bits;
+                         });
+        seed = __uint_as_float(last_bits);
+    }
+    const uint32_t n_res = d.n_total - d.n_model;
+    if (n_res > 0) {
+        // models/mod.rs:241-249: XOR-seeded with the last RECONSTRUCTED value.
+        const uint4 vr = s.residuals.views[i];
+        decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, n_res, true, __float_as_uint(seed),
+                         &error, [&](uint32_t k, uint32_t bits) {
+                             out_val[o + d.n_model + k] = __uint_as_float(bits);
+                         });
+    }
+    if (error) atomicOr(&header->error, error);
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+struct GridPlan {
+    SegDesc *desc;
+    uint32_t *counts;
+    unsigned long long *offsets;
+    unsigned long long *block_points;
+    unsigned long long *block_serial;
+    uint32_t *serial_ids;
+    uint32_t *tile_first;
+    GridHeader *header;
+    GridHeader host_header;
+    uint32_t n_blocks;
+};
+
+// Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
+// capacity_tiles bounds the tile map: if the batch needs more the caller gets an error before any
+// out-of-bounds write can happen (tile map writes are guarded by the allocation made here).
+int grid_plan(mdb_ctx *ctx, const mdb_segments *in, uint32_t *rows_per_segment, bool want_tiles,
+              uint64_t cap_points, GridPlan *plan) {
+    const uint64_t n = in->n;
+    if (n > 0xfffffff0ull) return fail("Too many segments in one batch.");
+    const uint32_t n_blocks = (uint32_t)((n + SEGS_PER_BLOCK - 1) / SEGS_PER_BLOCK);
+    plan->n_blocks = n_blocks;
+    void *p;
+    if (scratch_reserve(ctx, SCRATCH_DESC, n * sizeof(SegDesc), &p)) return 1;
+    plan->desc = static_cast<SegDesc *>(p);
+    if (scratch_reserve(ctx, SCRATCH_COUNTS, (n + 4) * 4, &p)) return 1;
+    plan->counts = static_cast<uint32_t *>(p);
+    if (scratch_reserve(ctx, SCRATCH_OFFSETS, (n + 1) * 8, &p)) return 1;
+    plan->offsets = static_cast<unsigned long long *>(p);
+    if (scratch_reserve(ctx, SCRATCH_BLOCK_SUMS, (uint64_t)(n_blocks + 1) * 16, &p)) return 1;
+    plan->block_points = static_cast<unsigned long long *>(p);
+    plan->block_serial = plan->block_points + n_blocks + 1;
+    if (scratch_reserve(ctx, SCRATCH_SERIAL_IDS, (n + 1) * 4, &p)) return 1;
+    plan->serial_ids = static_cast<uint32_t *>(p);
+    const uint64_t cap_tiles = want_tiles ? (cap_points + TILE_POINTS - 1) / TILE_POINTS + 1 : 0;
+    if (scratch_reserve(ctx, SCRATCH_TILE_MAP, (cap_tiles + 1) * 4, &p)) return 1;
+    plan->tile_first = static_cast<uint32_t *>(p);
+    if (scratch_reserve(ctx, SCRATCH_HEADER, sizeof(GridHeader), &p)) return 1;
+    plan->header = static_cast<GridHeader *>(p);
+
+    MDB_HIP_CHECK(hipMemsetAsync(plan->header, 0, sizeof(GridHeader), ctx->stream));
+    std::memset(&plan->host_header, 0, sizeof(GridHeader));
+    if (n == 0) return 0;
+    DevSegments s = to_dev(in);
+    {
+        LaunchTimer timer(ctx, "k_grid_prepass");
+        hipLaunchKernelGGL(k_grid_prepass, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s,
+                           plan->desc, plan->counts, plan->block_points, plan->block_serial,
+                           plan->header);
+    }
+    {
+        LaunchTimer timer(ctx, "k_scan_blocks");
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, plan->block_points,
+                           plan->block_serial, n_blocks, plan->header);
+    }
+    MDB_HIP_CHECK(hipMemcpyAsync(&plan->host_header, plan->header, sizeof(GridHeader),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (plan->host_header.error) return fail(describe_error(plan->host_header.error));
+    if (!want_tiles) return 0;
+    if (plan->host_header.total_points > cap_points)
+        return fail("Output buffers too small: " + std::to_string(plan->host_header.total_points) +
+                    " data points but capacity " + std::to_string(cap_points) + ".");
+    {
+        LaunchTimer timer(ctx, "k_grid_offsets");
+        hipLaunchKernelGGL(k_grid_offsets, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream,
+                           plan->counts, n, plan->block_points, plan->block_serial, plan->offsets,
+                           plan->serial_ids, plan->tile_first, rows_per_segment);
+    }
+    return 0;
+}
+
+void fill_metrics(const GridHeader &h, mdb_grid_metrics *m) {
+    if (!m) return;
+    m->rows_created = h.total_points;
+    for (int k = 0; k < 3; k++) {
+        m->rows_created_by_model_type[k] = h.metrics[k];
+        m->segments_with_model_type[k] = h.metrics[4 + k];
+    }
+    m->segments_with_residuals = h.metrics[3];
+    m->segments_regular = h.metrics[7];
+    m->segments_irregular = h.metrics[8];
+}
+
+int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                          uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
+                          mdb_grid_metrics *metrics) {
+    GridPlan plan;
+    if (grid_plan(ctx, in, out_rows, true, cap, &plan)) return 1;
+    const uint64_t total = plan.host_header.total_points;
+    if (n_out) *n_out = total;
+    fill_metrics(plan.host_header, metrics);
+    if (total == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(out_ts) & 15u) || (reinterpret_cast<uintptr_t>(out_val) & 15u))
+        return fail("Output buffers must be 16-byte aligned.");
+    DevSegments s = to_dev(in);
+    const uint64_t n_tiles = (total + TILE_POINTS - 1) / TILE_POINTS;
+    if (n_tiles > 0x7fffffffull) return fail("Too many output tiles for one launch.");
+    {
+        LaunchTimer timer(ctx, "k_grid_tiles");
+        hipLaunchKernelGGL(k_grid_tiles, dim3((uint32_t)n_tiles), dim3(TILE_THREADS), 0, ctx->stream,
+                           plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, out_ts,
+                           out_val);
+    }
+    const uint64_t n_serial = plan.host_header.n_serial;
+    if (n_serial > 0) {
+        LaunchTimer timer(ctx, "k_grid_serial");
+        hipLaunchKernelGGL(k_grid_serial, dim3((uint32_t)((n_serial + 255) / 256)), dim3(256), 0,
+                           ctx->stream, s, plan.desc, plan.offsets, plan.serial_ids, n_serial, out_ts,
+                           out_val, plan.header);
+    }
+    uint32_t late_error = 0;
+    MDB_HIP_CHECK(hipMemcpyAsync(&late_error, &plan.header->error, 4, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipGetLastError());
+    if (late_error) return fail(describe_error(late_error));
+    return 0;
+}
+
+} // namespace mdb
+
+using namespace mdb;
+
+extern "C" {
+
+int mdb_grid_count_dev(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
+    if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    GridPlan plan;
+    if (grid_plan(ctx, in, nullptr, false, 0, &plan)) return 1;
+    *n_out = plan.host_header.total_points;
+    return 0;
+}
+
+int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                       uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                       mdb_grid_metrics *metrics) {
+    if (!ctx || !in) return fail("ctx and in must not be NULL.");
+    if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    return grid_batch_dev_locked(ctx, in, out_ts, out_val, out_rows_per_segment, cap, n_out, metrics);
+}
+
+int mdb_grid_count(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
+    if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
+    mdb_segments_owned *dev = nullptr;
+    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    int rc = mdb_grid_count_dev(ctx, &dev->seg, n_out);
+    mdb_segments_free(dev);
+    return rc;
+}
+
+int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                   uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                   mdb_grid_metrics *metrics) {
+    if (!ctx || !in) return fail("ctx and in must not be NULL.");
+    if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
+    mdb_segments_owned *dev = nullptr;
+    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        void *stage = nullptr;
+        // Device staging for the outputs: timestamps, values, rows-per-segment (256 B aligned).
+        const uint64_t ts_bytes = align_up(cap * 8, 256), val_bytes = align_up(cap * 4, 256);
+        const uint64_t rows_bytes = align_up(in->n * 4, 256);
+        rc = scratch_reserve(ctx, SCRATCH_STAGE_DEV, ts_bytes + val_bytes + rows_bytes, &stage);
+        uint8_t *base = static_cast<uint8_t *>(stage);
+        int64_t *dev_ts = reinterpret_cast<int64_t *>(base);
+        float *dev_val = reinterpret_cast<float *>(base + ts_bytes);
+        uint32_t *dev_rows = reinterpret_cast<uint32_t *>(base + ts_bytes + val_bytes);
+        uint64_t total = 0;
+        if (!rc)
+            rc = grid_batch_dev_locked(ctx, &dev->seg, dev_ts, dev_val,
+                                       out_rows_per_segment ? dev_rows : nullptr, cap, &total, metrics);
+        if (n_out) *n_out = total;
+        auto copy_back = [&](void *dst, const void *src, uint64_t bytes) {
+            if (rc || bytes == 0) return;
+            if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy device to host failed.");
+        };
+        copy_back(out_ts, dev_ts, total * 8);
+        copy_back(out_val, dev_val, total * 4);
+        if (out_rows_per_segment) copy_back(out_rows_per_segment, dev_rows, in->n * 4);
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+    }
+    mdb_segments_free(dev);
+    return rc;
+}
+
+} // extern "C"

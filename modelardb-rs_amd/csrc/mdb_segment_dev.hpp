@@ -1,0 +1,314 @@
+// mdb_segment_dev.hpp - device-side understanding of one compressed segment, shared by the grid
+// and aggregate kernels: descriptor, MacaqueTS / MacaqueV decoders and the values-column codecs.
+// Citations are relative to crates/modelardb_compression/src/ in the reference.
+#pragma once
+
+#include "mdb_common.hpp"
+
+namespace mdb {
+
+constexpr uint32_t COUNT_MASK = 0x7fffffffu;
+constexpr uint32_t SERIAL_BIT = 0x80000000u;
+
+enum : uint32_t {
+    FLAG_TYPE_MASK = 3u,
+    FLAG_REGULAR = 1u << 2,
+    FLAG_HAS_RESIDUALS = 1u << 3,
+    FLAG_SERIAL = 1u << 4,
+};
+
+enum : uint32_t {
+    ERR_TIMESTAMPS = 1u << 0,
+    ERR_VALUES = 1u << 1,
+    ERR_MODEL_TYPE = 1u << 2,
+    ERR_RESIDUALS = 1u << 3,
+    ERR_BITSTREAM = 1u << 4,
+    ERR_TOO_LONG = 1u << 5,
+};
+
+struct SegDesc { // 48 bytes
+    int64_t start;
+    int64_t delta;
+    double slope;
+    double intercept;
+    uint32_t n_total;
+    uint32_t n_model;
+    float value; // PMC-Mean: the model value. Swing: the last reconstructed value (residual seed).
+    uint32_t flags;
+};
+
+// ---- MacaqueTS irregular decode (models/timestamps.rs:228-292) ---------------------------------
+
+// Calls emit(index, timestamp) for every timestamp; returns the count. `limit` stops early.
+template <typename Emit>
+__device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *bytes, uint32_t nbytes,
+                                                              int64_t start_time, int64_t end_time,
+                                                              uint32_t limit, uint32_t *error,
+                                                              Emit emit) {
+    uint32_t count = 0;
+    emit(count++, start_time);
+    if (count >= limit) return count;
+    BitReaderDev r;
+    r.init(bytes, nbytes);
+    r.get(1);
+    uint64_t last_delta = 0;
+    int64_t timestamp = start_time;
+    while (!r.exhausted()) {
+        uint32_t ones = 0;
+        while (ones < 5 && !r.exhausted() && r.get(1)) ones++;
+        if (ones != 0 && r.remaining() < 7) break;
+        if (ones != 0) {
+            uint32_t width = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : ones == 4 ? 32u : 64u;
+            if (r.remaining() < width) {
+                *error |= ERR_TIMESTAMPS;
+                return count;
+            }
+            uint64_t encoded = r.get64(width);
+            uint64_t dod = encoded;
+            if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
+            last_delta += dod;
+        }
+        timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+        if (count == COUNT_MASK) {
+            *error |= ERR_TOO_LONG;
+            return count;
+        }
+        emit(count++, timestamp);
+        if (count >= limit) return count;
+    }
+    emit(count++, end_time);
+    return count;
+}
+
+// ---- prepass -----------------------------------------------------------------------------------
+
+__device__ __forceinline__ float f32_from_inline(const uint4 &view, uint32_t first_byte) {
+    uint32_t bits = view_inline_byte(view, first_byte) | (view_inline_byte(view, first_byte + 1) << 8) |
+                    (view_inline_byte(view, first_byte + 2) << 16) |
+                    (view_inline_byte(view, first_byte + 3) << 24);
+    return __uint_as_float(bits);
+}
+
+// types.rs:307-321
+__device__ __forceinline__ bool decode_pmc_value(const uint4 &view, float mn, float mx, float *value) {
+    switch ((int32_t)view.x) {
+    case 0: *value = mn; return true;
+    case 1: *value = mx; return true;
+    case 4: *value = __uint_as_float(view.y); return true;
+    default: return false;
+    }
+}
+
+// types.rs:374-407
+__device__ __forceinline__ bool decode_swing_values(const uint4 &view, float mn, float mx, float *first,
+                                                    float *last) {
+    switch ((int32_t)view.x) {
+    case 0: *first = mn; *last = mx; return true;
+    case 1: *first = mx; *last = mn; return true;
+    case 5: {
+        float value = f32_from_inline(view, 1);
+        switch (view_inline_byte(view, 0)) {
+        case 0: *first = value; *last = mx; return true;
+        case 1: *first = mx; *last = value; return true;
+        case 2: *first = mn; *last = value; return true;
+        case 3: *first = value; *last = mn; return true;
+        default: return false;
+        }
+    }
+    case 8: *first = __uint_as_float(view.y); *last = __uint_as_float(view.z); return true;
+    default: return false;
+    }
+}
+
+// Everything grid()/sum()/len() need to know about one segment before touching its points.
+struct SegInfo {
+    SegDesc desc;
+    uint32_t error;
+    float swing_first; // Swing only: decoded (first, last) model values
+    float swing_last;
+    uint32_t regular_length; // len() of a regular stream = the stored big-endian integer
+};
+
+__device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i) {
+    SegInfo info;
+    info.error = 0;
+    info.swing_first = 0.0f;
+    info.swing_last = 0.0f;
+    SegDesc &d = info.desc;
+    const int32_t type = s.model_type_id[i];
+    const int64_t start = s.start_time[i];
+    const int64_t end = s.end_time[i];
+    const uint4 vt = s.timestamps.views[i];
+    const uint4 vv = s.values.views[i];
+    const uint4 vr = s.residuals.views[i];
+    const float mn = s.min_value[i];
+    const float mx = s.max_value[i];
+    d.start = start;
+    d.delta = 0;
+    d.slope = 0.0;
+    d.intercept = 0.0;
+    d.value = 0.0f;
+    uint32_t flags = (uint32_t)type & FLAG_TYPE_MASK;
+    if (type < 0 || type >= MDB_MODEL_TYPE_COUNT) info.error |= ERR_MODEL_TYPE;
+
+    // len() / decompress_all_timestamps() count (models/mod.rs:98-124, timestamps.rs:163-223).
+    const int32_t ts_len = (int32_t)vt.x;
+    uint32_t n_total = 0;
+    bool regular = true;
+    const uint8_t *ts_bytes = nullptr;
+    info.regular_length = 0;
+    if (ts_len < 0) {
+        info.error |= ERR_TIMESTAMPS;
+    } else if (ts_len == 0) {
+        n_total = (start == end) ? 1u : 2u;
+        d.delta = end - start;
+        info.regular_length = n_total;
+    } else {
+        // timestamps.rs:199-202. Byte 0 of an out-of-line view is byte 0 of its 4-byte prefix, which
+        // sits where the inline bytes start, so one accessor serves both.
+        regular = (view_inline_byte(vt, 0) & 0x80u) == 0;
+    }
+    if (ts_len > 0 && regular) {
+        if (ts_len > 8) {
+            info.error |= ERR_TIMESTAMPS;
+        } else {
+            uint64_t length = 0;
+            for (int32_t k = 0; k < ts_len; k++) length = (length << 8) | view_inline_byte(vt, k);
+            info.regular_length = (uint32_t)(length > COUNT_MASK ? COUNT_MASK : length);
+            uint64_t span = (uint64_t)(end - start);
+            if (length < 2 || end < start) {
+                info.error |= ERR_TIMESTAMPS;
+            } else {
+                uint64_t interval = span / (length - 1);
+                if (interval == 0) {
+                    info.error |= ERR_TIMESTAMPS;
+                } else {
+                    uint64_t produced = span / interval + 1; // (start..=end).step_by(interval)
+                    if (produced > COUNT_MASK) info.error |= ERR_TOO_LONG;
+                    n_total = (uint32_t)produced;
+                    d.delta = (int64_t)interval;
+                }
+            }
+        }
+    } else if (ts_len > 0) {
+        regular = false;
+        ts_bytes = view_data(s.timestamps, i, vt);
+        n_total = decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, 0xffffffffu,
+                                              &info.error, [](uint32_t, int64_t) {});
+    }
+    if (regular) flags |= FLAG_REGULAR;
+
+    // residuals_length() (models/mod.rs:277-284)
+    const int32_t res_len = (int32_t)vr.x;
+    uint32_t n_res = 0;
+    if (res_len < 0) {
+        info.error |= ERR_RESIDUALS;
+    } else if (res_len > 0) {
+        flags |= FLAG_HAS_RESIDUALS;
+        n_res = (res_len <= 12) ? view_inline_byte(vr, (uint32_t)res_len - 1)
+                                : (uint32_t)view_data(s.residuals, i, vr)[res_len - 1];
+        if (res_len < 2) info.error |= ERR_RESIDUALS; // BitReader::try_new(&[]) fails (macaque_v.rs:279)
+    }
+    if (n_res > n_total) {
+        info.error |= ERR_RESIDUALS;
+        n_res = n_total;
+    }
+    const uint32_t n_model = n_total - n_res;
+    d.n_total = n_total;
+    d.n_model = n_model;
+
+    if (type == MDB_PMC_MEAN_ID) {
+        if (!decode_pmc_value(vv, mn, mx, &d.value)) info.error |= ERR_VALUES;
+    } else if (type == MDB_SWING_ID) {
+        float first = 0.0f, last = 0.0f;
+        if (!decode_swing_values(vv, mn, mx, &first, &last)) info.error |= ERR_VALUES;
+        if (n_model == 0) {
+            info.error |= ERR_VALUES; // expect("Model should represent at least one value.")
+        } else if (!info.error) {
+            int64_t model_end = start;
+            if (regular) {
+                model_end = start + (int64_t)((uint64_t)(n_model - 1) * (uint64_t)d.delta);
+            } else {
+                decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, n_model,
+                                            &info.error,
+                                            [&](uint32_t, int64_t t) { model_end = t; });
+            }
+            // models/mod.rs:219-234 + swing.rs:304-319: the line goes through the MODEL's end.
+            LineDev line = line_through(start, (double)first, model_end, (double)last);
+            d.slope = line.slope;
+            d.intercept = line.intercept;
+            d.value = (float)(line.slope * (double)model_end + line.intercept);
+        }
+        info.swing_first = first;
+        info.swing_last = last;
+    } else if (type == MDB_MACAQUE_V_ID) {
+        if ((int32_t)vv.x <= 0 || n_model == 0) info.error |= ERR_VALUES;
+    }
+    if (!regular || type == MDB_MACAQUE_V_ID || n_res > 0) flags |= FLAG_SERIAL;
+    d.flags = flags;
+    return info;
+}
+
+// MacaqueV decoder (models/macaque_v.rs:272-323). emit(i, bits) for i in [0, count).
+template <typename Emit>
+__device__ __forceinline__ void decode_macaque_v(const uint8_t *bytes, uint32_t nbytes, uint32_t count,
+                                                 bool seeded, uint32_t seed_bits, uint32_t *error,
+                                                 Emit emit) {
+    if (nbytes == 0) {
+        if (count > 0 || !seeded) *error |= ERR_BITSTREAM;
+        return;
+    }
+    BitReaderDev r;
+    r.init(bytes, nbytes);
+    uint32_t leading = 255, trailing = 0;
+    uint32_t last;
+    uint32_t emitted = 0;
+    if (seeded) {
+        last = seed_bits;
+    } else {
+        last = r.get(32);
+        if (count == 0) {
+            *error |= ERR_BITSTREAM;
+            return;
+        }
+        emit(emitted++, last);
+    }
+    while (emitted < count) {
+        bool decode_value = true;
+        if (r.get(1)) {
+            if (r.get(1)) {
+                leading = r.get(5);
+                uint32_t meaningful = r.get(6);
+                trailing = 32u - meaningful - leading; // wraps for malformed streams, checked below
+            } else {
+                decode_value = false;
+            }
+        }
+        if (decode_value) {
+            uint32_t meaningful = 32u - leading - trailing;
+            if (meaningful > 32u || trailing > 31u) {
+                *error |= ERR_BITSTREAM;
+                return;
+            }
+            uint32_t value = r.get(meaningful);
+            value <<= trailing;
+            value ^= last;
+            last = value;
+        }
+        emit(emitted++, last);
+    }
+    if (r.overrun()) *error |= ERR_BITSTREAM;
+}
+
+inline std::string describe_error(uint32_t error) {
+    std::string message = "Malformed segment:";
+    if (error & ERR_TIMESTAMPS) message += " compressed timestamps;";
+    if (error & ERR_VALUES) message += " values are not encoded for the model type;";
+    if (error & ERR_MODEL_TYPE) message += " unknown model type;";
+    if (error & ERR_RESIDUALS) message += " residuals;";
+    if (error & ERR_BITSTREAM) message += " MacaqueV bitstream;";
+    if (error & ERR_TOO_LONG) message += " more than 2^31-1 data points in one segment;";
+    return message;
+}
+
+} // namespace mdb

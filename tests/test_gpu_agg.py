@@ -1,0 +1,104 @@
+"""Parity of the HIP segment aggregates with the CPU oracle, through the C ABI.
+
+Bar (from the reference's own tests, crates/modelardb_server/tests/integration_test.rs:1128-1246):
+COUNT / MIN / MAX exact; SUM / AVG within 0.001 % relative (the GPU reduces in a fixed tree, the
+reference accumulates sequentially in f64)."""
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ora
+import modelardb_rs_amd as mdb
+from modelardb_rs_amd import MDB_AGG_AVG, MDB_AGG_COUNT, MDB_AGG_MAX, MDB_AGG_MIN, MDB_AGG_SUM
+
+pytestmark = pytest.mark.gpu
+
+ALL = MDB_AGG_COUNT | MDB_AGG_MIN | MDB_AGG_MAX | MDB_AGG_SUM
+SUM_TOLERANCE = 1e-5  # 0.001 %
+
+
+def _assert_state(got, expected):
+    assert got.count == expected.count
+    assert np.float32(got.min) == np.float32(expected.min)
+    assert np.float32(got.max) == np.float32(expected.max)
+    if np.isnan(expected.sum) or np.isinf(expected.sum):
+        assert np.isnan(got.sum) == np.isnan(expected.sum)
+        assert np.isinf(got.sum) == np.isinf(expected.sum)
+    else:
+        assert abs(got.sum - expected.sum) <= SUM_TOLERANCE * max(abs(expected.sum), 1e-30)
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+@pytest.mark.parametrize("eb_name", ["lossless", "abs5", "rel5", "rel1"])
+def test_aggregates_match_oracle(hip, eb_name, irregular):
+    eb = cases.error_bounds()[eb_name]
+    _, _, batch = cases.mixed_batch(eb, irregular, seed=21)
+    _assert_state(hip.agg_batch(batch, ALL), ora.agg_batch(batch, ALL))
+    for mask in (MDB_AGG_COUNT, MDB_AGG_MIN, MDB_AGG_MAX, MDB_AGG_SUM, MDB_AGG_AVG):
+        got, expected = hip.agg_batch(batch, mask), ora.agg_batch(batch, mask)
+        _assert_state(got, expected)
+
+
+def test_aggregates_continue_a_running_state(hip):
+    eb = cases.error_bounds()["rel5"]
+    _, _, batch = cases.mixed_batch(eb, False, seed=22)
+    half = len(batch) // 2
+    first, second = batch.slice(0, half), batch.slice(half, len(batch))
+    state = hip.agg_batch(first, ALL)
+    state = hip.agg_batch(second, ALL, state)
+    _assert_state(state, ora.agg_batch(batch, ALL))
+
+
+def test_aggregates_three_point_series(hip):
+    # crates/modelardb_embedded/src/operations/data_folder.rs:1165-1234
+    for values, mn, mx, total in (([37.0, 38.0, 39.0], 37.0, 39.0, 114.0),
+                                  ([73.0, 72.0, 71.0], 71.0, 73.0, 216.0)):
+        batch = ora.try_compress_univariate_time_series([100, 200, 300], values, cases.LOSSLESS)
+        state = hip.agg_batch(batch, ALL)
+        assert (state.count, state.min, state.max, state.sum) == (3, mn, mx, total)
+
+
+def test_aggregates_edge_cases(hip):
+    for name, ts, values in cases.edge_case_series():
+        batch = ora.try_compress_univariate_time_series(ts, values, cases.LOSSLESS)
+        _assert_state(hip.agg_batch(batch, ALL), ora.agg_batch(batch, ALL))
+
+
+def test_aggregates_empty_batch(hip):
+    state = hip.agg_batch(mdb.SegmentBatch.from_rows([]), ALL)
+    fresh = mdb._abi.AggStateC.fresh()
+    assert (state.count, state.sum, state.min, state.max) == (0, 0.0, fresh.min, fresh.max)
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+@pytest.mark.parametrize("eb_name", ["lossless", "rel5", "abs5"])
+def test_range_aggregates_match_grid_filter_aggregate(hip, eb_name, irregular):
+    # The reference evaluates WHERE timestamp BETWEEN lo AND hi as GridExec + filter + aggregate
+    # (model_simple_aggregates.rs:284-302); ora.agg_batch_range is that plan.
+    eb = cases.error_bounds()[eb_name]
+    timestamps, _, batch = cases.mixed_batch(eb, irregular, seed=23)
+    n = len(timestamps)
+    windows = [
+        (int(timestamps[n // 4]), int(timestamps[3 * n // 4])),
+        (int(timestamps[0]), int(timestamps[-1])),
+        (int(timestamps[10]) + 1, int(timestamps[11]) - 1) if timestamps[11] - timestamps[10] > 1
+        else (int(timestamps[10]), int(timestamps[10])),
+        (int(timestamps[100]), int(timestamps[100])),
+        (int(timestamps[-1]) + 1, int(timestamps[-1]) + 1000),
+        (-(1 << 62), 1 << 62),
+        (int(timestamps[n // 2]) - 37, int(timestamps[n // 2]) + 4242),
+    ]
+    for t_lo, t_hi in windows:
+        got = hip.agg_batch_range(batch, t_lo, t_hi, ALL)
+        expected = ora.agg_batch_range(batch, t_lo, t_hi, ALL)
+        _assert_state(got, expected)
+
+
+def test_range_aggregates_edge_cases(hip):
+    for name, ts, values in cases.edge_case_series():
+        batch = ora.try_compress_univariate_time_series(ts, values, cases.LOSSLESS)
+        for t_lo, t_hi in ((int(ts[0]), int(ts[-1])), (int(ts[len(ts) // 2]), int(ts[-1])),
+                           (int(ts[0]) - 5, int(ts[len(ts) // 2]))):
+            _assert_state(hip.agg_batch_range(batch, t_lo, t_hi, ALL),
+                          ora.agg_batch_range(batch, t_lo, t_hi, ALL))

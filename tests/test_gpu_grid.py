@@ -1,0 +1,151 @@
+"""Parity of the HIP grid() path with the CPU oracle, through the C ABI (mdb_grid_batch).
+
+Bar: timestamps bit-exact and values bit-exact against the oracle's reconstruction of the same
+segments (the segments are lossy w.r.t. the raw data within epsilon; decoding them is exact)."""
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ora
+import modelardb_rs_amd as mdb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+@pytest.mark.parametrize("eb_name", ["lossless", "abs5", "rel5", "rel1"])
+def test_grid_matches_oracle_on_synthetic_series(hip, eb_name, irregular):
+    eb = cases.error_bounds()[eb_name]
+    timestamps, values, batch = cases.mixed_batch(eb, irregular, seed=11)
+    expected = ora.grid_batch(batch)
+    assert hip.grid_count(batch) == len(expected[0])
+    got = hip.grid_batch(batch)
+    cases.assert_grid_equal(got, expected)
+    assert np.array_equal(got[2], expected[2])      # rows per segment
+    assert got[3] == expected[3]                    # GridStreamMetrics counters
+    assert np.array_equal(got[0], timestamps)       # round trip: timestamps bit-exact
+
+
+def test_grid_edge_cases(hip):
+    for eb_name in ("lossless", "rel5", "abs5"):
+        batch = cases.edge_case_batch(cases.error_bounds()[eb_name])
+        expected = ora.grid_batch(batch)
+        got = hip.grid_batch(batch)
+        cases.assert_grid_equal(got, expected)
+        assert np.array_equal(got[2], expected[2])
+        assert got[3] == expected[3]
+
+
+def test_grid_each_edge_case_alone(hip):
+    for name, ts, values in cases.edge_case_series():
+        batch = ora.try_compress_univariate_time_series(ts, values, cases.LOSSLESS)
+        got = hip.grid_batch(batch)
+        assert np.array_equal(got[0], ts), name
+        assert np.array_equal(got[1].view(np.uint32), values.view(np.uint32)), name
+
+
+def test_grid_empty_batch(hip):
+    batch = mdb.SegmentBatch.from_rows([])
+    assert hip.grid_count(batch) == 0
+    ts, values, rows, metrics = hip.grid_batch(batch)
+    assert len(ts) == 0 and len(values) == 0 and len(rows) == 0
+    assert metrics["rows_created"] == 0
+
+
+def test_grid_reference_size_batches(hip):
+    # DataFusion hands GridExec batches of 8192 segment rows (SessionConfig default).
+    eb = cases.error_bounds()["rel1"]
+    _, _, batch = cases.mixed_batch(eb, False, seed=12, length=400_000, noise=None)
+    expected = ora.grid_batch(batch)
+    for start in range(0, len(batch), 8192):
+        part = batch.slice(start, min(len(batch), start + 8192))
+        cases.assert_grid_equal(hip.grid_batch(part), ora.grid_batch(part))
+    cases.assert_grid_equal(hip.grid_batch(batch), expected)
+
+
+def test_grid_many_tiny_segments_in_one_tile(hip):
+    # > 1024 segments inside one 4096-point output tile exercises the global-search path.
+    rows = [(0, 10 * i, 10 * i, b"", float(i), float(i), b"", b"") for i in range(5000)]
+    rows += [(0, 100_000 + 10 * i, 100_000 + 10 * i + 5, b"", 1.0, 1.0, b"", b"") for i in range(3000)]
+    batch = mdb.SegmentBatch.from_rows(rows)
+    cases.assert_grid_equal(hip.grid_batch(batch), ora.grid_batch(batch))
+
+
+def test_grid_one_huge_segment_and_neighbours(hip):
+    n = 1_000_003
+    rows = [
+        (0, 0, 90, bytes([10]), 2.5, 2.5, b"", b""),
+        (1, 1000, 1000 + (n - 1) * 10, n.to_bytes(3, "big"), -5.0, 5.0, b"", b""),
+        (0, 20_000_000, 20_000_070, bytes([8]), 7.5, 7.5, b"", b""),
+    ]
+    batch = mdb.SegmentBatch.from_rows(rows)
+    cases.assert_grid_equal(hip.grid_batch(batch), ora.grid_batch(batch))
+
+
+def test_grid_multi_buffer_binary_views(hip):
+    # Arrow may spread out-of-line payloads over several variadic buffers.
+    eb = cases.error_bounds()["lossless"]
+    _, _, batch = cases.mixed_batch(eb, True, seed=13, length=5_000)
+    expected = ora.grid_batch(batch)
+    for column_name in ("timestamps", "values", "residuals"):
+        column = getattr(batch, column_name)
+        items = column.to_bytes_list()
+        views = column.views.copy()
+        buffers = [np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+        for i, item in enumerate(items):
+            if len(item) <= 12:
+                continue
+            which = i % 2
+            views[i, 8:12] = np.frombuffer(np.int32(which).tobytes(), dtype=np.uint8)
+            views[i, 12:16] = np.frombuffer(np.int32(len(buffers[which])).tobytes(), dtype=np.uint8)
+            buffers[which] = np.concatenate([buffers[which], np.frombuffer(item, dtype=np.uint8)])
+        setattr(batch, column_name, mdb.BinaryViewColumn(views, buffers))
+    cases.assert_grid_equal(hip.grid_batch(batch), expected)
+
+
+@pytest.mark.parametrize("rows,message", [
+    ([(3, 0, 10, b"", 0.0, 0.0, b"", b"")], "unknown model type"),
+    ([(0, 0, 10, bytes([1]), 0.0, 0.0, b"", b"")], "timestamps"),             # length 1: div by zero
+    ([(0, 0, 10, bytes([5]), 0.0, 0.0, b"ab", b"")], "values"),               # types.rs:316-318
+    ([(1, 0, 10, bytes([5]), 0.0, 0.0, b"abc", b"")], "values"),              # types.rs:405
+    ([(2, 0, 10, bytes([5]), 0.0, 0.0, b"", b"")], "values"),                 # macaque_v.rs:279-280
+    ([(0, 0, 40, bytes([5]), 0.0, 0.0, b"", bytes([9]))], "residuals"),
+    ([(2, 0, 40, bytes([5]), 0.0, 0.0, bytes([1, 2, 3, 4, 0]), b"")], "bitstream"),
+])
+def test_malformed_segments_are_errors(hip, rows, message):
+    # The reference panics on these (models/mod.rs:170,237 etc.); the C ABI returns an error.
+    batch = mdb.SegmentBatch.from_rows(rows)
+    with pytest.raises(mdb.HipError, match=message):
+        hip.grid_batch(batch, cap=64)
+    with pytest.raises(ora.OracleError):
+        ora.grid_batch(batch)
+
+
+def test_output_capacity_is_checked(hip):
+    batch = mdb.SegmentBatch.from_rows([(0, 0, 90, bytes([10]), 2.5, 2.5, b"", b"")])
+    with pytest.raises(mdb.HipError, match="too small"):
+        hip.grid_batch(batch, cap=4)
+
+
+def test_grid_full_size_properties(hip):
+    """Size-independent properties on a large batch: counts add up, timestamps strictly increase
+    inside every series, every value within epsilon of the raw data."""
+    eb = cases.error_bounds()["rel1"]
+    n_series, n_points = 16, 200_000
+    timestamps = np.arange(n_points, dtype=np.int64) * 1000
+    all_values, parts = [], []
+    import datagen
+    for s in range(n_series):
+        _, values = datagen.sine_series(s, n_points)
+        all_values.append(values)
+        parts.append(ora.try_compress_univariate_time_series(timestamps, values, eb))
+    batch = mdb.SegmentBatch.concat(parts)
+    ts, values, rows, metrics = hip.grid_batch(batch)
+    assert len(ts) == n_series * n_points == int(rows.sum()) == metrics["rows_created"]
+    ts = ts.reshape(n_series, n_points)
+    assert (ts == timestamps[None, :]).all()
+    raw = np.stack(all_values)
+    approx = values.reshape(n_series, n_points)
+    relative = np.abs((raw - approx) / raw) * np.float32(100.0)
+    assert (relative <= np.float32(1.0)).all()
