@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the ModelarDB hot path on MI355X.
+
+One "step" = one pass of grid() (segment -> data point reconstruction, the GridExec hot loop) over
+the whole synthetic batch of BASELINE.json configs[1]: 1 000 series x 10 000 000 points of
+sine + noise compressed with a 1 % relative error bound, per GPU (weak scaling: every rank holds its
+own 1k x 10M shard; series shard embarrassingly, no data-path collective). Segments are resident in
+HBM before the timed region and the reconstructed (timestamp, value) columns are written to HBM.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
+kernel (k_grid_tiles: algorithmic bytes / HIP-event time measured on the launch stream) and
+`cpu_baseline` (the CPU oracle, a port of the reference's per-row GridStream loop, timed on the
+host cores on a bounded sample of the same segments).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--series S] [--points P]
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
+for _path in (REPO_ROOT, os.path.join(REPO_ROOT, "tests")):
+    if _path not in sys.path:
+        sys.path.insert(0, _path)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+CHUNK_POINTS = 65536    # ingest buffer of the reference server (storage/mod.rs:58)
+SEED = 0x4D44425F52454631
+INTERVAL_US = 1000
+
+
+def parse_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=5)
+    parser.add_argument("--warmup", type=int, default=2)
+    parser.add_argument("--series", type=int, default=1000)
+    parser.add_argument("--points", type=int, default=10_000_000)
+    parser.add_argument("--error-bound", type=float, default=1.0, help="relative bound in percent")
+    parser.add_argument("--cpu-sample-series", type=int, default=8)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    return parser.parse_args()
+
+
+def init_distributed(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_module
+        torch.cuda.set_device(local_rank)
+        dist_module.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_module
+    return rank, local_rank, world, dist
+
+
+def barrier_and_sync(context, dist):
+    context.sync()
+    if dist is not None:
+        dist.barrier()
+    context.sync()
+
+
+def fit_on_gpu(context, mdb, args, rank):
+    """Generate this rank's series on the device and compress them with the HIP fitter, in groups of
+    series so that raw values never need more than a few GB of HBM at once."""
+    import ctypes as C
+    eb = mdb.error_bound("relative", args.error_bound)
+    chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
+    group = max(1, min(args.series, (1 << 31) // max(args.points, 1)))  # <= 2^31 points per launch
+    parts, fit_seconds, fit_points = [], 0.0, 0
+    first_series_of_rank = rank * args.series
+    for first in range(0, args.series, group):
+        n_series = min(group, args.series - first)
+        total = n_series * args.points
+        values = context.dev_alloc(4 * total)
+        context.synth_values_dev(values, first_series_of_rank + first, n_series, args.points, SEED)
+        offsets = np.zeros(n_series * chunks_per_series + 1, dtype=np.uint64)
+        first_index = np.zeros(n_series * chunks_per_series, dtype=np.uint64)
+        k = 0
+        for s in range(n_series):
+            for c in range(chunks_per_series):
+                start = c * CHUNK_POINTS
+                offsets[k] = s * args.points + start
+                first_index[k] = start
+                k += 1
+        offsets[k] = total
+        offsets_dev = context.upload_array(offsets)
+        first_index_dev = context.upload_array(first_index)
+        context.sync()
+        t0 = time.perf_counter()
+        parts.append(context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US,
+                                                 first_index_dev))
+        context.sync()
+        fit_seconds += time.perf_counter() - t0
+        fit_points += total
+        for pointer in (values, offsets_dev, first_index_dev):
+            context.dev_free(pointer)
+    return parts, fit_seconds, fit_points
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world, dist = init_distributed(args.gpus)
+    import modelardb_rs_amd as mdb
+
+    context = mdb.Context(local_rank)
+    info = context.device_info()
+
+    # ---- build the workload: fit on the GPU, keep the segments in HBM ---------------------------
+    parts, fit_seconds, fit_points = fit_on_gpu(context, mdb, args, rank)
+    n_segments = sum(len(p) for p in parts)
+
+    total_points = 0
+    for part in parts:
+        total_points += context.grid_count_dev(part)
+    assert total_points == args.series * args.points, (total_points, args.series * args.points)
+    largest = max(context.grid_count_dev(p) for p in parts)
+    out_ts = context.dev_alloc(8 * total_points)
+    out_val = context.dev_alloc(4 * total_points)
+
+    def step():
+        at = 0
+        metrics_total = None
+        for part in parts:
+            n, metrics = context.grid_batch_dev(part, out_ts + 8 * at, out_val + 4 * at,
+                                                total_points - at)
+            at += n
+            if metrics_total is None:
+                metrics_total = dict(metrics)
+            else:
+                for key, value in metrics.items():
+                    metrics_total[key] += value
+        return at, metrics_total
+
+    for _ in range(args.warmup):
+        step()
+    barrier_and_sync(context, dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        produced, metrics = step()
+    barrier_and_sync(context, dist)
+    elapsed = time.perf_counter() - t0
+    assert produced == total_points
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream ------------------------
+    context.profile_enable(True)
+    context.profile_reset()
+    for _ in range(args.steps):
+        step()
+    profile = context.profile()
+    context.profile_enable(False)
+    launches, total_ms = profile.get("k_grid_tiles", (0, 0.0))
+    kernel_ms = total_ms / max(launches, 1)
+    # Algorithmic bytes of one launch (SURVEY 8(d) / BASELINE.md 3): 73 B per segment read + payloads
+    # larger than 12 B (out of line) + 12 B per reconstructed point written. The tile kernel itself
+    # reads a 48 B descriptor + 8 B offset per segment instead of the raw 73 B (the prepass did that),
+    # so pricing it at 73 B/segment + 12 B/point is the figure the contract names.
+    points_per_launch = total_points / len(parts)
+    segments_per_launch = n_segments / len(parts)
+    algorithmic_bytes = 73.0 * segments_per_launch + 12.0 * points_per_launch
+    achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    # ---- CPU baseline: the oracle's per-row grid loop on a bounded sample -------------------------
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle_lib as ora
+        sample = parts[0].download()
+        wanted = args.cpu_sample_series * args.points
+        rows_needed, acc = 0, 0
+        lengths = None
+        # Take whole leading series: segments are ordered by chunk, chunks by series.
+        chunk = sample.chunk_index
+        chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
+        keep = np.nonzero(chunk < args.cpu_sample_series * chunks_per_series)[0]
+        sample = sample.take(keep)
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ts_cpu, _, _, _ = ora.grid_batch(sample, n_threads=cores)
+        cpu_seconds = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        single = sample.take(np.nonzero(sample.chunk_index < chunks_per_series)[0])
+        ts_single, _, _, _ = ora.grid_batch(single, n_threads=1)
+        single_seconds = time.perf_counter() - t0
+        cpu_baseline = {
+            "value": len(ts_cpu) / cpu_seconds,
+            "unit": "values/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"grid() of the first {args.cpu_sample_series} series "
+                      f"({len(ts_cpu)} points, {len(sample)} segments) of the same workload, "
+                      f"series-sharded over {cores} threads",
+            "single_thread_value": len(ts_single) / single_seconds,
+        }
+
+    if rank == 0:
+        value = world * total_points * args.steps / elapsed
+        result = {
+            "metric": "gridded values/sec",
+            "value": value,
+            "unit": "values/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.series} series x {args.points} points sine+noise, "
+                            f"relative error bound {args.error_bound} %, grid() decode of the "
+                            f"segments to (timestamp i64, value f32) columns in HBM, per GPU",
+                "series_per_gpu": args.series,
+                "points_per_series": args.points,
+                "segments_per_gpu": n_segments,
+                "segment_mix": metrics,
+                "parallelism": f"series-sharded x{world}, no data-path collective",
+                "device": info["name"],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_grid_tiles",
+                "achieved": achieved_gbps,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved_gbps / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": algorithmic_bytes,
+                "other_kernels_ms": {name: ms / max(n, 1) for name, (n, ms) in profile.items()
+                                     if name != "k_grid_tiles"},
+            },
+            "cpu_baseline": cpu_baseline,
+            "fit": {
+                "points_per_s": fit_points / fit_seconds if fit_seconds > 0 else None,
+                "segments_per_s": n_segments / fit_seconds if fit_seconds > 0 else None,
+                "seconds": fit_seconds,
+                "note": "PMC-Mean/Swing/MacaqueV fit of this rank's series on the GPU (setup, not "
+                        "in the timed region), regular timestamps synthesised on the fly",
+            },
+        }
+        print(json.dumps(result))
+
+    for part in parts:
+        part.free()
+    context.dev_free(out_ts)
+    context.dev_free(out_val)
+    context.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

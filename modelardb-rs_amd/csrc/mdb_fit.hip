@@ -1,8 +1,1076 @@
-// placeholder replaced below
-#include "mdb_common.hpp"
-using namespace mdb;
-extern "C" {
-int mdb_compress_series(mdb_ctx *, const int64_t *, const float *, uint64_t, mdb_error_bound, mdb_segments_owned **) { return fail("not built yet"); }
-int mdb_compress_chunks(mdb_ctx *, const int64_t *, const float *, const uint64_t *, uint64_t, mdb_error_bound, mdb_segments_owned **) { return fail("not built yet"); }
-int mdb_compress_chunks_dev(mdb_ctx *, const int64_t *, const float *, const uint64_t *, uint64_t, mdb_error_bound, int64_t, int64_t, const uint64_t *, mdb_segments_owned **) { return fail("not built yet"); }
+// mdb_fit.hip - model-based compression (PMC-Mean / Swing / MacaqueV fitting) on gfx950.
+//
+// Replaces try_compress_univariate_time_series and everything under it
+// (crates/modelardb_compression/src/compression.rs:191-400, types.rs:40-278, models/pmc_mean.rs,
+// models/swing.rs, models/macaque_v.rs, models/timestamps.rs:56-155). Citations below are relative to
+// crates/modelardb_compression/src/.
+//
+// The greedy segmentation is strictly sequential inside a series chunk (each accepted model's end
+// decides the next start), so the parallel unit is the chunk: C4 has 1.6 M of them.
+//   k_fit_models   1 lane / chunk: the greedy loop (compression.rs:224-263); every point goes through
+//                  PMC-Mean and Swing exactly as in the reference; emits 16-byte model records and
+//                  the chunk's segment count.
+//   (scan)         chunk -> first segment.
+//   k_fit_plan     1 lane / chunk: model records -> per-segment work items (model + residual tail,
+//                  or a MacaqueV-only run), the rules of compression.rs:310-362.
+//   k_fit_size     1 lane / segment: exact byte length of the timestamps / values / residuals payloads
+//                  (encoders run with a counting sink).
+//   (scans)        out-of-line payload offsets per BinaryView column.
+//   k_fit_encode   1 lane / segment: writes the nine columns in Arrow layout (BinaryView views with
+//                  <= 12 bytes inline, larger payloads in one data buffer per column).
+// Output is bit-identical to the CPU oracle: same segment boundaries, same bytes.
+// Algorithmic bytes: 4 B/point read (12 B/point when timestamps are materialised) + segments written.
+#include "mdb_scan.hpp"
+#include "mdb_segment_dev.hpp"
+
+namespace mdb {
+
+__global__ __launch_bounds__(1024) void k_scan_block_sums(unsigned long long *__restrict__ block_sums,
+                                                          uint32_t n_blocks,
+                                                          unsigned long long *__restrict__ total_out) {
+    __shared__ uint64_t lds[17];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t v = i < n_blocks ? block_sums[i] : 0;
+        uint64_t total;
+        uint64_t e = block_exclusive_scan_u64(v, lds, &total);
+        if (i < n_blocks) block_sums[i] = carry + e;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
 }
+
+// ---- error bound math (models/mod.rs:53-95) --------------------------------------------------------
+
+__device__ __forceinline__ bool within_error_bound(mdb_error_bound eb, float real_value,
+                                                   float approximate_value) {
+    if (equal_or_nan((double)real_value, (double)approximate_value)) return true;
+    if (eb.kind == MDB_EB_ABSOLUTE) return fabsf(real_value - approximate_value) <= eb.value;
+    if (eb.kind == MDB_EB_RELATIVE) {
+        float difference = real_value - approximate_value;
+        float result = fabsf(difference / real_value);
+        return (result * 100.0f) <= eb.value;
+    }
+    return false;
+}
+
+__device__ __forceinline__ double max_allowed_deviation(mdb_error_bound eb, double value) {
+    if (eb.kind == MDB_EB_ABSOLUTE) return (double)eb.value * 0.99;
+    if (eb.kind == MDB_EB_RELATIVE) return fabs(value * ((double)eb.value / 100.1));
+    return 0.0;
+}
+
+// ---- timestamps of a chunk: materialised or synthesised regular ----------------------------------------
+
+struct TimestampSource {
+    const int64_t *ts; // nullptr: regular
+    int64_t regular_start;
+    int64_t regular_interval;
+    const unsigned long long *series_first_index; // per chunk, may be nullptr
+};
+
+struct ChunkTimestamps {
+    const int64_t *ts;
+    int64_t first; // timestamp of point 0 of the chunk when regular
+    int64_t interval;
+    __device__ __forceinline__ int64_t at(uint32_t j) const {
+        return ts ? ts[j] : first + (int64_t)((uint64_t)j * (uint64_t)interval);
+    }
+};
+
+__device__ __forceinline__ ChunkTimestamps chunk_timestamps(const TimestampSource &src, uint64_t chunk,
+                                                            uint64_t chunk_base) {
+    ChunkTimestamps t;
+    t.ts = src.ts ? src.ts + chunk_base : nullptr;
+    uint64_t first_index = src.series_first_index ? src.series_first_index[chunk] : 0;
+    t.first = src.regular_start + (int64_t)(first_index * (uint64_t)src.regular_interval);
+    t.interval = src.regular_interval;
+    return t;
+}
+
+// ---- PMC-Mean (models/pmc_mean.rs:31-93) ---------------------------------------------------------------
+
+struct PmcDev {
+    float min_value, max_value;
+    double sum;
+    uint32_t length;
+    __device__ __forceinline__ void reset() {
+        min_value = __uint_as_float(0x7fc00000u);
+        max_value = __uint_as_float(0x7fc00000u);
+        sum = 0.0;
+        length = 0;
+    }
+    __device__ __forceinline__ bool fit(mdb_error_bound eb, float value) {
+        float next_min = min_num(min_value, value);
+        float next_max = max_num(max_value, value);
+        double next_sum = sum + (double)value;
+        uint32_t next_length = length + 1;
+        float average = (float)(next_sum / (double)next_length);
+        if (within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average)) {
+            min_value = next_min;
+            max_value = next_max;
+            sum = next_sum;
+            length = next_length;
+            return true;
+        }
+        return false;
+    }
+};
+
+// ---- Swing (models/swing.rs:34-259) -----------------------------------------------------------------------
+
+struct SwingDev {
+    int64_t start_time, end_time;
+    double first_value;
+    LineDev upper, lower;
+    double numerator, denominator;
+    uint32_t length;
+    __device__ __forceinline__ void reset() {
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        start_time = 0;
+        end_time = 0;
+        first_value = nan;
+        upper = {nan, nan};
+        lower = {nan, nan};
+        numerator = 0.0;
+        denominator = 0.0;
+        length = 0;
+    }
+    __device__ __forceinline__ bool fit(mdb_error_bound eb, int64_t timestamp, float value32) {
+        double value = (double)value32;
+        double deviation = max_allowed_deviation(eb, value);
+        if (length == 0) {
+            start_time = timestamp;
+            end_time = timestamp;
+            first_value = value;
+            length = 1;
+            return true;
+        }
+        if (!isfinite(first_value) || !isfinite(value)) {
+            if (!equal_or_nan(first_value, value)) return false;
+            end_time = timestamp;
+            upper = {value, value};
+            lower = {value, value};
+            length += 1;
+            return true;
+        }
+        if (length == 1) {
+            end_time = timestamp;
+            upper = line_through(start_time, first_value, timestamp, value + deviation);
+            lower = line_through(start_time, first_value, timestamp, value - deviation);
+            length += 1;
+            return true;
+        }
+        double t = (double)timestamp;
+        double upper_approximation = upper.slope * t + upper.intercept;
+        double lower_approximation = lower.slope * t + lower.intercept;
+        if (upper_approximation + deviation < value || lower_approximation - deviation > value)
+            return false;
+        end_time = timestamp;
+        if (upper_approximation - deviation > value)
+            upper = line_through(start_time, first_value, timestamp, value + deviation);
+        if (lower_approximation + deviation < value)
+            lower = line_through(start_time, first_value, timestamp, value - deviation);
+        if (!equal_or_nan(first_value, value)) { // swing.rs:212-228
+            double dt = (double)(timestamp - start_time);
+            numerator += (value - first_value) * dt;
+            denominator += dt * dt;
+        } else {
+            numerator += 0.0;
+            denominator += 0.0;
+        }
+        length += 1;
+        return true;
+    }
+    __device__ __forceinline__ void model(float *first, float *last) const { // swing.rs:246-259
+        double projected = numerator / denominator;
+        double slope = max_num(lower.slope, min_num(projected, upper.slope));
+        double last_value = slope * (double)(end_time - start_time) + first_value;
+        *first = (float)first_value;
+        *last = (float)last_value;
+    }
+};
+
+// ---- bit sinks (models/bits.rs:86-174, MSB first) -------------------------------------------------------
+
+struct CountSink {
+    uint64_t bits = 0;
+    __device__ __forceinline__ void put(uint32_t, uint32_t count) { bits += count; }
+    __device__ __forceinline__ uint64_t bytes() const { return (bits + 7) >> 3; }
+};
+
+struct ByteSink {
+    uint8_t *dst;
+    uint64_t acc = 0;
+    uint32_t pending = 0; // < 8 between calls
+    uint64_t written = 0;
+    __device__ __forceinline__ explicit ByteSink(uint8_t *d) : dst(d) {}
+    // count in [0, 32]
+    __device__ __forceinline__ void put(uint32_t value, uint32_t count) {
+        if (count == 0) return;
+        uint64_t masked = count == 32 ? (uint64_t)value : ((uint64_t)value & ((1ull << count) - 1ull));
+        acc = (acc << count) | masked;
+        pending += count;
+        while (pending >= 8) {
+            dst[written++] = (uint8_t)(acc >> (pending - 8));
+            pending -= 8;
+        }
+    }
+    __device__ __forceinline__ void finish(bool pad_with_ones) {
+        if (pending == 0) return;
+        uint32_t pad = 8 - pending;
+        uint32_t byte = (uint32_t)(acc << pad) & 0xffu;
+        if (pad_with_ones) byte |= (1u << pad) - 1u;
+        dst[written++] = (uint8_t)byte;
+        pending = 0;
+    }
+};
+
+template <typename Sink> __device__ __forceinline__ void put64(Sink &sink, uint64_t value, uint32_t count) {
+    if (count > 32) {
+        sink.put((uint32_t)(value >> 32), count - 32);
+        sink.put((uint32_t)value, 32);
+    } else {
+        sink.put((uint32_t)value, count);
+    }
+}
+
+// ---- MacaqueV encoder (models/macaque_v.rs:76-214) -----------------------------------------------------
+
+__device__ __forceinline__ int saturating_f32_to_i32(float v) { // Rust `as i32`
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+struct MacaqueState {
+    float min_value = __uint_as_float(0x7fc00000u);
+    float max_value = __uint_as_float(0x7fc00000u);
+    float last_value = 0.0f;
+    uint32_t last_leading = 255;
+    uint32_t last_trailing = 0;
+};
+
+__device__ __forceinline__ float rewrite_least_mantissa_bits(mdb_error_bound eb, float value) {
+    if (fabsf(value) == 0.0f || value != value || isinf(value)) return value;
+    uint32_t bits = __float_as_uint(value);
+    float abs_error_bound = (float)max_allowed_deviation(eb, (double)value);
+    int exponent = (int)((bits >> 23) & 0xffu) - 127;
+    float factorized_epsilon = abs_error_bound / ldexpf(1.0f, exponent);
+    // (float)log2((double)x): correctly rounded log2f, the same definition the oracle uses.
+    float magnitude = floorf(fabsf((float)log2((double)factorized_epsilon)));
+    int position = (int)(23ll - (long long)saturating_f32_to_i32(magnitude) < -2147483647ll
+                             ? -2147483647ll
+                             : 23ll - (long long)saturating_f32_to_i32(magnitude));
+    auto rewrite = [](uint32_t b, int pos) -> uint32_t {
+        if (pos < 0) pos = 0; // clamp instead of wrapping the shift
+        if (pos > 31) return 0u;
+        return b & (0xFFFFFFFFu << pos);
+    };
+    float rewritten = __uint_as_float(rewrite(bits, position));
+    if (!within_error_bound(eb, value, rewritten)) {
+        position -= 1;
+        rewritten = __uint_as_float(rewrite(bits, position));
+    }
+    return rewritten;
+}
+
+template <typename Sink>
+__device__ __forceinline__ void macaque_update(MacaqueState &m, float value) {
+    m.min_value = min_num(m.min_value, value);
+    m.max_value = max_num(m.max_value, value);
+    m.last_value = value;
+}
+
+template <typename Sink>
+__device__ __forceinline__ void macaque_xor_value(MacaqueState &m, Sink &sink, mdb_error_bound eb,
+                                                  float value) {
+    if (eb.kind != MDB_EB_LOSSLESS) {
+        if (within_error_bound(eb, value, m.last_value)) value = m.last_value;
+        else value = rewrite_least_mantissa_bits(eb, value);
+    }
+    uint32_t x = __float_as_uint(value) ^ __float_as_uint(m.last_value);
+    if (x == 0) {
+        sink.put(0b10u, 2);
+    } else {
+        uint32_t leading = (uint32_t)__clz((int)x);
+        uint32_t trailing = (uint32_t)__ffs((int)x) - 1u;
+        if (leading >= m.last_leading && trailing >= m.last_trailing) {
+            sink.put(0, 1);
+            uint32_t meaningful = 32u - m.last_leading - m.last_trailing;
+            sink.put(x >> m.last_trailing, meaningful);
+        } else {
+            uint32_t meaningful = 32u - leading - trailing;
+            sink.put((0b11u << 11) | (leading << 6) | meaningful, 13);
+            sink.put(x >> trailing, meaningful);
+            m.last_leading = leading;
+            m.last_trailing = trailing;
+        }
+    }
+    macaque_update<Sink>(m, value);
+}
+
+// compress_values (first value raw) or compress_values_without_first (seeded).
+template <typename Sink>
+__device__ __forceinline__ void macaque_encode(MacaqueState &m, Sink &sink, mdb_error_bound eb,
+                                               const float *__restrict__ values, uint32_t n, bool seeded,
+                                               float seed) {
+    uint32_t i = 0;
+    if (seeded) {
+        m.last_value = seed;
+    } else if (n > 0) {
+        sink.put(__float_as_uint(values[0]), 32);
+        macaque_update<Sink>(m, values[0]);
+        i = 1;
+    }
+    for (; i < n; i++) macaque_xor_value(m, sink, eb, values[i]);
+}
+
+// ---- MacaqueTS encoder (models/timestamps.rs:56-155) ----------------------------------------------------
+
+__device__ __forceinline__ uint32_t regular_length_bytes(uint64_t length) { // timestamps.rs:99-108
+    uint32_t significant = 64u - (uint32_t)__clzll((long long)length);
+    return (significant + 1u + 7u) / 8u;
+}
+
+__device__ __forceinline__ bool chunk_range_regular(const ChunkTimestamps &t, uint32_t a, uint32_t b) {
+    if (!t.ts) return true;
+    if (b - a + 1 < 2) return true;
+    int64_t expected = t.ts[a + 1] - t.ts[a];
+    for (uint32_t j = a + 1; j <= b; j++)
+        if (t.ts[j] - t.ts[j - 1] != expected) return false;
+    return true;
+}
+
+template <typename Sink>
+__device__ __forceinline__ void encode_irregular_timestamps(Sink &sink, const ChunkTimestamps &t, uint32_t a,
+                                                            uint32_t b) {
+    sink.put(1, 1);
+    uint64_t last_timestamp = (uint64_t)t.at(a);
+    uint64_t last_delta = 0;
+    for (uint32_t j = a + 1; j < b; j++) {
+        uint64_t current = (uint64_t)t.at(j);
+        uint64_t delta = current - last_timestamp;
+        int64_t dod = (int64_t)(delta - last_delta);
+        if (dod == 0) {
+            sink.put(0, 1);
+        } else if (dod >= -63 && dod <= 64) {
+            sink.put((0b10u << 7) | ((uint32_t)dod & 0x7fu), 9);
+        } else if (dod >= -255 && dod <= 256) {
+            sink.put((0b110u << 9) | ((uint32_t)dod & 0x1ffu), 12);
+        } else if (dod >= -2047 && dod <= 2048) {
+            sink.put((0b1110u << 12) | ((uint32_t)dod & 0xfffu), 16);
+        } else if (dod >= -2147483647ll && dod <= 2147483648ll) {
+            sink.put(0b11110u, 5);
+            sink.put((uint32_t)dod, 32);
+        } else {
+            sink.put(0b11111u, 5);
+            put64(sink, (uint64_t)dod, 64);
+        }
+        last_delta = delta;
+        last_timestamp = current;
+    }
+}
+
+// Length in bytes of compress_residual_timestamps(ts[a..=b]) and whether it is the regular form.
+__device__ __forceinline__ uint32_t timestamps_payload_length(const ChunkTimestamps &t, uint32_t a,
+                                                              uint32_t b, bool *regular) {
+    uint32_t count = b - a + 1;
+    *regular = true;
+    if (count <= 2) return 0;
+    if (chunk_range_regular(t, a, b)) return regular_length_bytes(count);
+    *regular = false;
+    CountSink sink;
+    encode_irregular_timestamps(sink, t, a, b);
+    return (uint32_t)sink.bytes();
+}
+
+// ---- values column codecs (types.rs:283-370) ------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t encode_values_for_pmc_mean(float mn, float mx, float rmin, float rmax,
+                                                               uint8_t *out) {
+    if (mn > rmin) {
+        if (mx >= rmax) {
+            out[0] = 1;
+            return 1;
+        }
+        uint32_t bits = __float_as_uint(mn);
+        for (int k = 0; k < 4; k++) out[k] = (uint8_t)(bits >> (8 * k));
+        return 4;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ uint32_t encode_values_for_swing(float mn, float mx, bool min_is_first, float rmin,
+                                                            float rmax, uint8_t *out) {
+    auto put = [&](uint32_t at, float v) {
+        uint32_t bits = __float_as_uint(v);
+        for (int k = 0; k < 4; k++) out[at + k] = (uint8_t)(bits >> (8 * k));
+    };
+    if (rmin < mn && mx < rmax) {
+        put(0, min_is_first ? mn : mx);
+        put(4, min_is_first ? mx : mn);
+        return 8;
+    }
+    if (rmin < mn) {
+        out[0] = min_is_first ? 0 : 1;
+        put(1, mn);
+        return 5;
+    }
+    if (mx < rmax) {
+        out[0] = min_is_first ? 2 : 3;
+        put(1, mx);
+        return 5;
+    }
+    if (!min_is_first) {
+        out[0] = 0;
+        return 1;
+    }
+    return 0;
+}
+
+// ---- k_fit_models -----------------------------------------------------------------------------------------
+
+struct ModelRec { // 16 bytes
+    uint32_t start_and_type; // bit 31: 1 = Swing, 0 = PMC-Mean; low 31 bits: first point in the chunk
+    uint32_t end;            // last point in the chunk the model represents
+    float p0;                // PMC-Mean: value. Swing: first value
+    float p1;                // Swing: last value
+};
+
+struct ChunkPlan { // per chunk
+    uint32_t n_models;
+    uint32_t n_segments;
+};
+
+struct FitArgs {
+    const float *values;
+    TimestampSource timestamps;
+    const unsigned long long *chunk_offsets;
+    uint64_t n_chunks;
+    mdb_error_bound eb;
+};
+
+__device__ __forceinline__ uint64_t chunk_record_capacity(uint64_t length) { return length / 8 + 1; }
+
+struct RecordCapacity {
+    const unsigned long long *chunk_offsets;
+    __device__ uint64_t operator()(uint64_t c) const {
+        return chunk_record_capacity(chunk_offsets[c + 1] - chunk_offsets[c]);
+    }
+};
+
+__global__ __launch_bounds__(256) void k_fit_models(FitArgs args, const unsigned long long *__restrict__ record_base,
+                                                    ModelRec *__restrict__ records,
+                                                    ChunkPlan *__restrict__ plans,
+                                                    unsigned int *__restrict__ error) {
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= args.n_chunks) return;
+    const uint64_t base = args.chunk_offsets[chunk];
+    const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
+    if (length64 > COUNT_MASK) {
+        atomicOr(error, ERR_TOO_LONG);
+        plans[chunk] = {0, 0};
+        return;
+    }
+    const uint32_t n = (uint32_t)length64;
+    const float *__restrict__ values = args.values + base;
+    const ChunkTimestamps ts = chunk_timestamps(args.timestamps, chunk, base);
+    const mdb_error_bound eb = args.eb;
+    ModelRec *__restrict__ out = records + record_base[chunk];
+
+    uint32_t n_models = 0, n_segments = 0;
+    bool have_previous = false;
+    uint32_t previous_end = 0;
+    uint32_t current = 0;
+    PmcDev pmc;
+    SwingDev swing;
+    while (current < n) {
+        // fit_next_model (compression.rs:280-301, types.rs:61-81)
+        pmc.reset();
+        swing.reset();
+        bool pmc_fits = true, swing_fits = true;
+        for (uint32_t j = current; j < n && (pmc_fits || swing_fits); j++) {
+            const float v = values[j];
+            if (pmc_fits) pmc_fits = pmc.fit(eb, v);
+            if (swing_fits) swing_fits = swing.fit(eb, ts.at(j), v);
+        }
+        // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
+        const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc.length;
+        const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing.length;
+        const bool choose_pmc = pmc_bpv <= swing_bpv;
+        const float bpv = choose_pmc ? pmc_bpv : swing_bpv;
+        if (bpv <= (float)MDB_VALUE_SIZE_IN_BYTES) { // compression.rs:238
+            ModelRec rec;
+            if (choose_pmc) {
+                rec.start_and_type = current;
+                rec.end = current + pmc.length - 1;
+                rec.p0 = (float)(pmc.sum / (double)pmc.length); // pmc_mean.rs:91-93
+                rec.p1 = rec.p0;
+            } else {
+                rec.start_and_type = current | 0x80000000u;
+                rec.end = current + swing.length - 1;
+                swing.model(&rec.p0, &rec.p1);
+            }
+            // Segments implied by the gap before this model (compression.rs:240-249, 310-362).
+            if (have_previous) {
+                if (current - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
+            } else if (current > 0) {
+                n_segments += 1;
+            }
+            out[n_models++] = rec;
+            n_segments += 1;
+            have_previous = true;
+            previous_end = rec.end;
+            current = rec.end + 1;
+        } else {
+            current += 1;
+        }
+    }
+    if (n > 0) {
+        if (have_previous) {
+            if (n - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
+        } else {
+            n_segments += 1;
+        }
+    }
+    plans[chunk] = {n_models, n_segments};
+}
+
+// ---- k_fit_plan --------------------------------------------------------------------------------------------
+
+struct SegItem { // 16 bytes
+    uint32_t chunk;
+    uint32_t first;  // first point of the segment in the chunk
+    uint32_t last;   // last point (residuals included)
+    uint32_t record; // index into the chunk's model records, 0xffffffff: MacaqueV-only segment
+};
+
+struct SegmentCount {
+    const ChunkPlan *plans;
+    __device__ uint64_t operator()(uint64_t c) const { return plans[c].n_segments; }
+};
+
+__global__ __launch_bounds__(256) void k_fit_plan(const unsigned long long *__restrict__ chunk_offsets,
+                                                  uint64_t n_chunks,
+                                                  const unsigned long long *__restrict__ record_base,
+                                                  const ModelRec *__restrict__ records,
+                                                  const ChunkPlan *__restrict__ plans,
+                                                  const unsigned long long *__restrict__ segment_base,
+                                                  SegItem *__restrict__ items) {
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= n_chunks) return;
+    const uint32_t n = (uint32_t)(chunk_offsets[chunk + 1] - chunk_offsets[chunk]);
+    const ModelRec *__restrict__ recs = records + record_base[chunk];
+    const uint32_t n_models = plans[chunk].n_models;
+    SegItem *__restrict__ out = items + segment_base[chunk];
+    uint32_t k = 0;
+    if (n == 0) return;
+    if (n_models == 0) {
+        out[k++] = {(uint32_t)chunk, 0, n - 1, 0xffffffffu};
+        return;
+    }
+    for (uint32_t m = 0; m < n_models; m++) {
+        const uint32_t start = recs[m].start_and_type & COUNT_MASK;
+        if (m == 0) {
+            if (start > 0) out[k++] = {(uint32_t)chunk, 0, start - 1, 0xffffffffu};
+            continue;
+        }
+        const uint32_t previous_start = recs[m - 1].start_and_type & COUNT_MASK;
+        const uint32_t previous_end = recs[m - 1].end;
+        const uint32_t residuals_end = start - 1;
+        if (residuals_end - previous_end <= MDB_RESIDUAL_VALUES_MAX_LENGTH) {
+            out[k++] = {(uint32_t)chunk, previous_start, residuals_end, m - 1};
+        } else {
+            out[k++] = {(uint32_t)chunk, previous_start, previous_end, m - 1};
+            out[k++] = {(uint32_t)chunk, previous_end + 1, residuals_end, 0xffffffffu};
+        }
+    }
+    const uint32_t last_start = recs[n_models - 1].start_and_type & COUNT_MASK;
+    const uint32_t last_end = recs[n_models - 1].end;
+    if (n - 1 - last_end <= MDB_RESIDUAL_VALUES_MAX_LENGTH) {
+        out[k++] = {(uint32_t)chunk, last_start, n - 1, n_models - 1};
+    } else {
+        out[k++] = {(uint32_t)chunk, last_start, last_end, n_models - 1};
+        out[k++] = {(uint32_t)chunk, last_end + 1, n - 1, 0xffffffffu};
+    }
+}
+
+// ---- k_fit_size / k_fit_encode -------------------------------------------------------------------------------
+
+struct SegSizes { // payload bytes per BinaryView column
+    uint32_t timestamps;
+    uint32_t values;
+    uint32_t residuals;
+    uint32_t pad;
+};
+
+struct OutOfLineBytes {
+    const SegSizes *sizes;
+    int column;
+    __device__ uint64_t operator()(uint64_t i) const {
+        uint32_t n = column == 0 ? sizes[i].timestamps : (column == 1 ? sizes[i].values : sizes[i].residuals);
+        return n > 12 ? n : 0;
+    }
+};
+
+struct EncodeTargets {
+    int8_t *model_type_id;
+    int64_t *start_time;
+    int64_t *end_time;
+    float *min_value;
+    float *max_value;
+    float *error;
+    uint32_t *chunk_index;
+    uint4 *views[3];
+    uint8_t *data[3];
+    const unsigned long long *data_offsets[3];
+};
+
+// Runs every encoder of one segment against `Sink`-typed sinks created by `make_sink(column, bytes)`.
+// With CountSink it sizes the payloads; with ByteSink it writes them.
+template <bool WRITE>
+__device__ __forceinline__ void process_segment(const FitArgs &args, const unsigned long long *record_base,
+                                                const ModelRec *records, const SegItem &item,
+                                                uint64_t segment, SegSizes *sizes_io,
+                                                const EncodeTargets *targets) {
+    const uint64_t base = args.chunk_offsets[item.chunk];
+    const float *__restrict__ values = args.values + base;
+    const ChunkTimestamps ts = chunk_timestamps(args.timestamps, item.chunk, base);
+    const mdb_error_bound eb = args.eb;
+
+    // Destination of a payload: inline in the view (<= 12 bytes) or in the column's data buffer.
+    auto payload_destination = [&](int column, uint32_t bytes) -> uint8_t * {
+        if (!WRITE) return nullptr;
+        if (bytes <= 12) return reinterpret_cast<uint8_t *>(targets->views[column] + segment) + 4;
+        return targets->data[column] + targets->data_offsets[column][segment];
+    };
+    auto finish_view = [&](int column, uint32_t bytes) {
+        if (!WRITE || bytes <= 12) return;
+        // Out-of-line view: length, 4-byte prefix, buffer index 0, offset (Arrow BinaryView).
+        const uint64_t offset = targets->data_offsets[column][segment];
+        const uint8_t *p = targets->data[column] + offset;
+        uint4 view;
+        view.x = bytes;
+        view.y = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        view.z = 0;
+        view.w = (uint32_t)offset;
+        targets->views[column][segment] = view;
+    };
+    if (WRITE) {
+        // Inline views start as {length, 0, 0, 0}; payload bytes are then stored into the zeros.
+        targets->views[0][segment] = make_uint4(sizes_io->timestamps, 0, 0, 0);
+        targets->views[1][segment] = make_uint4(sizes_io->values, 0, 0, 0);
+        targets->views[2][segment] = make_uint4(sizes_io->residuals, 0, 0, 0);
+    }
+
+    // -- timestamps (timestamps.rs:56-155) over [first, last]
+    const uint32_t count = item.last - item.first + 1;
+    uint32_t ts_bytes;
+    if (!WRITE) {
+        bool regular;
+        ts_bytes = timestamps_payload_length(ts, item.first, item.last, &regular);
+        sizes_io->pad = regular ? 1u : 0u;
+    } else {
+        ts_bytes = sizes_io->timestamps;
+        uint8_t *dst = payload_destination(0, ts_bytes);
+        if (ts_bytes > 0) {
+            if (sizes_io->pad) { // regular: the length, big endian
+                for (uint32_t k = 0; k < ts_bytes; k++)
+                    dst[k] = (uint8_t)((uint64_t)count >> (8 * (ts_bytes - 1 - k)));
+            } else {
+                ByteSink sink(dst);
+                encode_irregular_timestamps(sink, ts, item.first, item.last);
+                sink.finish(true);
+            }
+        }
+        finish_view(0, ts_bytes);
+    }
+
+    int8_t type;
+    float min_value, max_value;
+    uint32_t values_bytes = 0, residual_bytes = 0;
+    if (item.record == 0xffffffffu) {
+        // compress_and_store_residuals_in_a_separate_segment (compression.rs:367-400)
+        type = MDB_MACAQUE_V_ID;
+        MacaqueState m;
+        if (!WRITE) {
+            CountSink sink;
+            macaque_encode(m, sink, eb, values + item.first, count, false, 0.0f);
+            values_bytes = (uint32_t)sink.bytes();
+        } else {
+            values_bytes = sizes_io->values;
+            ByteSink sink(payload_destination(1, values_bytes));
+            macaque_encode(m, sink, eb, values + item.first, count, false, 0.0f);
+            sink.finish(false);
+            finish_view(1, values_bytes);
+        }
+        min_value = m.min_value;
+        max_value = m.max_value;
+    } else {
+        // CompressedSegmentBuilder::finish (types.rs:197-267)
+        const ModelRec rec = records[record_base[item.chunk] + item.record];
+        const bool is_swing = (rec.start_and_type & 0x80000000u) != 0;
+        type = is_swing ? MDB_SWING_ID : MDB_PMC_MEAN_ID;
+        float model_last_value;
+        uint8_t encoded[8];
+        if (is_swing) { // types.rs:122-144
+            min_value = min_num(rec.p0, rec.p1);
+            max_value = max_num(rec.p0, rec.p1);
+            model_last_value = rec.p1;
+            if (!(rec.p0 < rec.p1)) {
+                encoded[0] = 0;
+                values_bytes = 1;
+            }
+        } else { // types.rs:104-119
+            min_value = rec.p0;
+            max_value = rec.p0;
+            model_last_value = rec.p0;
+        }
+        if (rec.end < item.last) {
+            const uint32_t n_residuals = item.last - rec.end;
+            MacaqueState m;
+            if (!WRITE) {
+                CountSink sink;
+                macaque_encode(m, sink, eb, values + rec.end + 1, n_residuals, true, model_last_value);
+                residual_bytes = (uint32_t)sink.bytes() + 1;
+            } else {
+                residual_bytes = sizes_io->residuals;
+                uint8_t *dst = payload_destination(2, residual_bytes);
+                ByteSink sink(dst);
+                macaque_encode(m, sink, eb, values + rec.end + 1, n_residuals, true, model_last_value);
+                sink.finish(false);
+                dst[residual_bytes - 1] = (uint8_t)n_residuals; // types.rs:249-250
+                finish_view(2, residual_bytes);
+            }
+            const float rmin = m.min_value, rmax = m.max_value;
+            if (is_swing)
+                values_bytes = encode_values_for_swing(min_value, max_value, values_bytes == 0, rmin, rmax, encoded);
+            else
+                values_bytes = encode_values_for_pmc_mean(min_value, max_value, rmin, rmax, encoded);
+            min_value = min_num(min_value, rmin);
+            max_value = max_num(max_value, rmax);
+        }
+        if (WRITE) {
+            uint8_t *dst = payload_destination(1, values_bytes); // always <= 8 bytes: inline
+            for (uint32_t k = 0; k < values_bytes; k++) dst[k] = encoded[k];
+        }
+    }
+
+    if (!WRITE) {
+        sizes_io->timestamps = ts_bytes;
+        sizes_io->values = values_bytes;
+        sizes_io->residuals = residual_bytes;
+    } else {
+        targets->model_type_id[segment] = type;
+        targets->start_time[segment] = ts.at(item.first);
+        targets->end_time[segment] = ts.at(item.last);
+        targets->min_value[segment] = min_value;
+        targets->max_value[segment] = max_value;
+        targets->error[segment] = __uint_as_float(0x7fc00000u); // f32::NAN (types.rs:265)
+        targets->chunk_index[segment] = item.chunk;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fit_size(FitArgs args, const unsigned long long *__restrict__ record_base,
+                                                  const ModelRec *__restrict__ records,
+                                                  const SegItem *__restrict__ items, uint64_t n_segments,
+                                                  SegSizes *__restrict__ sizes) {
+    const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (segment >= n_segments) return;
+    SegSizes s = {0, 0, 0, 0};
+    process_segment<false>(args, record_base, records, items[segment], segment, &s, nullptr);
+    sizes[segment] = s;
+}
+
+__global__ __launch_bounds__(256) void k_fit_encode(FitArgs args, const unsigned long long *__restrict__ record_base,
+                                                    const ModelRec *__restrict__ records,
+                                                    const SegItem *__restrict__ items, uint64_t n_segments,
+                                                    const SegSizes *__restrict__ sizes, EncodeTargets targets) {
+    const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (segment >= n_segments) return;
+    SegSizes s = sizes[segment];
+    process_segment<true>(args, record_base, records, items[segment], segment, &s, &targets);
+}
+
+// ---- host driver ----------------------------------------------------------------------------------------------
+
+static bool valid_error_bound(mdb_error_bound eb) { // crates/modelardb_types/src/types.rs:312-334
+    if (eb.kind == MDB_EB_LOSSLESS) return true;
+    if (eb.kind == MDB_EB_ABSOLUTE) return std::isfinite(eb.value) && eb.value > 0.0f;
+    if (eb.kind == MDB_EB_RELATIVE) return 0.0f < eb.value && eb.value <= 100.0f;
+    return false;
+}
+
+int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *values,
+                               const uint64_t *chunk_offsets, uint64_t n_chunks, mdb_error_bound eb,
+                               int64_t regular_start, int64_t regular_interval,
+                               const uint64_t *series_first_index, mdb_segments_owned **out) {
+    if (!valid_error_bound(eb)) return fail("Invalid error bound.");
+    if (n_chunks > 0xfffffff0ull) return fail("Too many chunks in one call.");
+    if (!ts && regular_interval <= 0 )
+        return fail("Either timestamps or a positive regular_interval must be given.");
+    FitArgs args;
+    args.values = values;
+    args.timestamps = {ts, regular_start, regular_interval,
+                       reinterpret_cast<const unsigned long long *>(series_first_index)};
+    args.chunk_offsets = reinterpret_cast<const unsigned long long *>(chunk_offsets);
+    args.n_chunks = n_chunks;
+    args.eb = eb;
+
+    OwnedSegments *owned = new OwnedSegments();
+    owned->device = ctx->device;
+    owned->host_allocs.resize(3);
+    auto release = [&]() {
+        for (void *p : owned->device_allocs) (void)hipFree(p);
+        delete owned;
+    };
+#define FIT_CHECK(expr)                                                                            \
+    do {                                                                                           \
+        if ((expr) != hipSuccess) {                                                                \
+            release();                                                                             \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(hipGetLastError()));  \
+        }                                                                                          \
+    } while (0)
+#define FIT_TRY(expr)                                                                              \
+    do {                                                                                           \
+        if (expr) {                                                                                \
+            release();                                                                             \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+    void *p = nullptr;
+    // Scratch: A record_base (n_chunks+1 u64) + block sums, B model records, C chunk plans,
+    // D segment_base (n_chunks+1 u64), E items, F sizes + 3 x offsets.
+    const uint64_t sums_bytes = scan_block_sums_bytes(std::max<uint64_t>(n_chunks, 1));
+    FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_A, (n_chunks + 1) * 8 + sums_bytes + 64, &p));
+    unsigned long long *record_base = static_cast<unsigned long long *>(p);
+    unsigned long long *block_sums = record_base + n_chunks + 1;
+    FIT_TRY(scratch_reserve(ctx, SCRATCH_HEADER, sizeof(unsigned int) * 64, &p));
+    unsigned int *error_flag = static_cast<unsigned int *>(p);
+    FIT_CHECK(hipMemsetAsync(error_flag, 0, 4, ctx->stream));
+
+    unsigned long long total_records = 0;
+    unsigned long long n_segments = 0;
+    if (n_chunks > 0) {
+        FIT_TRY(device_exclusive_scan(ctx, RecordCapacity{args.chunk_offsets}, n_chunks, record_base,
+                                      block_sums, "k_fit_scan"));
+        FIT_CHECK(hipMemcpyAsync(&total_records, record_base + n_chunks, 8, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+        FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
+        ModelRec *records = static_cast<ModelRec *>(p);
+        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_C, n_chunks * sizeof(ChunkPlan), &p));
+        ChunkPlan *plans = static_cast<ChunkPlan *>(p);
+        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_D, (n_chunks + 1) * 8, &p));
+        unsigned long long *segment_base = static_cast<unsigned long long *>(p);
+        const uint32_t chunk_blocks = (uint32_t)((n_chunks + 255) / 256);
+        {
+            LaunchTimer timer(ctx, "k_fit_models");
+            hipLaunchKernelGGL(k_fit_models, dim3(chunk_blocks), dim3(256), 0, ctx->stream, args,
+                               record_base, records, plans, error_flag);
+        }
+        FIT_TRY(device_exclusive_scan(ctx, SegmentCount{plans}, n_chunks, segment_base, block_sums,
+                                      "k_fit_scan"));
+        unsigned int error = 0;
+        FIT_CHECK(hipMemcpyAsync(&n_segments, segment_base + n_chunks, 8, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+        FIT_CHECK(hipMemcpyAsync(&error, error_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        FIT_CHECK(hipGetLastError());
+        if (error) {
+            release();
+            return fail("A chunk holds more than 2^31-1 data points.");
+        }
+        if (n_segments > 0x7ffffff0ull) {
+            release();
+            return fail("Too many segments for one batch.");
+        }
+
+        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_E, n_segments * sizeof(SegItem), &p));
+        SegItem *items = static_cast<SegItem *>(p);
+        const uint64_t seg_sums = scan_block_sums_bytes(std::max<uint64_t>(n_segments, 1));
+        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_F,
+                                n_segments * sizeof(SegSizes) + 3 * (n_segments + 1) * 8 + seg_sums + 64, &p));
+        SegSizes *sizes = static_cast<SegSizes *>(p);
+        unsigned long long *data_offsets[3];
+        data_offsets[0] = reinterpret_cast<unsigned long long *>(sizes + n_segments);
+        data_offsets[1] = data_offsets[0] + n_segments + 1;
+        data_offsets[2] = data_offsets[1] + n_segments + 1;
+        unsigned long long *seg_block_sums = data_offsets[2] + n_segments + 1;
+        {
+            LaunchTimer timer(ctx, "k_fit_plan");
+            hipLaunchKernelGGL(k_fit_plan, dim3(chunk_blocks), dim3(256), 0, ctx->stream,
+                               args.chunk_offsets, n_chunks, record_base, records, plans, segment_base,
+                               items);
+        }
+        const uint32_t segment_blocks = (uint32_t)((n_segments + 255) / 256);
+        if (n_segments > 0) {
+            LaunchTimer timer(ctx, "k_fit_size");
+            hipLaunchKernelGGL(k_fit_size, dim3(segment_blocks), dim3(256), 0, ctx->stream, args,
+                               record_base, records, items, (uint64_t)n_segments, sizes);
+        }
+        unsigned long long data_bytes[3] = {0, 0, 0};
+        for (int c = 0; c < 3; c++) {
+            FIT_TRY(device_exclusive_scan(ctx, OutOfLineBytes{sizes, c}, n_segments, data_offsets[c],
+                                          seg_block_sums, "k_fit_scan"));
+            FIT_CHECK(hipMemcpyAsync(&data_bytes[c], data_offsets[c] + n_segments, 8,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+            FIT_CHECK(hipStreamSynchronize(ctx->stream)); // seg_block_sums is reused by the next scan
+        }
+        for (int c = 0; c < 3; c++)
+            if (data_bytes[c] > 0x7fffffffull) {
+                release();
+                return fail("A BinaryView data buffer would exceed 2 GiB; compress fewer chunks per call.");
+            }
+
+        // One device blob for the output batch.
+        const uint64_t n = n_segments;
+        uint64_t cursor = 0;
+        auto carve = [&](uint64_t bytes) {
+            uint64_t at = cursor;
+            cursor = align_up(cursor + bytes, 256);
+            return at;
+        };
+        const uint64_t off_type = carve(n), off_start = carve(8 * n), off_end = carve(8 * n);
+        const uint64_t off_min = carve(4 * n), off_max = carve(4 * n), off_error = carve(4 * n);
+        const uint64_t off_chunk = carve(4 * n);
+        uint64_t off_views[3], off_data[3], off_table[3];
+        for (int c = 0; c < 3; c++) off_views[c] = carve(16 * n);
+        for (int c = 0; c < 3; c++) off_data[c] = carve(data_bytes[c]);
+        for (int c = 0; c < 3; c++) off_table[c] = carve(16);
+        void *blob = nullptr;
+        FIT_CHECK(hipMalloc(&blob, cursor ? cursor : 256));
+        owned->device_allocs.push_back(blob);
+        uint8_t *dev = static_cast<uint8_t *>(blob);
+
+        EncodeTargets targets;
+        targets.model_type_id = reinterpret_cast<int8_t *>(dev + off_type);
+        targets.start_time = reinterpret_cast<int64_t *>(dev + off_start);
+        targets.end_time = reinterpret_cast<int64_t *>(dev + off_end);
+        targets.min_value = reinterpret_cast<float *>(dev + off_min);
+        targets.max_value = reinterpret_cast<float *>(dev + off_max);
+        targets.error = reinterpret_cast<float *>(dev + off_error);
+        targets.chunk_index = reinterpret_cast<uint32_t *>(dev + off_chunk);
+        uint64_t tables[3][2];
+        for (int c = 0; c < 3; c++) {
+            targets.views[c] = reinterpret_cast<uint4 *>(dev + off_views[c]);
+            targets.data[c] = dev + off_data[c];
+            targets.data_offsets[c] = data_offsets[c];
+            tables[c][0] = reinterpret_cast<uint64_t>(dev + off_data[c]);
+            tables[c][1] = 0;
+            FIT_CHECK(hipMemcpyAsync(dev + off_table[c], tables[c], 16, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (n_segments > 0) {
+            LaunchTimer timer(ctx, "k_fit_encode");
+            hipLaunchKernelGGL(k_fit_encode, dim3(segment_blocks), dim3(256), 0, ctx->stream, args,
+                               record_base, records, items, (uint64_t)n_segments, sizes, targets);
+        }
+        FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        FIT_CHECK(hipGetLastError());
+
+        mdb_segments &s = owned->c.seg;
+        s.n = n;
+        s.model_type_id = targets.model_type_id;
+        s.start_time = targets.start_time;
+        s.end_time = targets.end_time;
+        s.min_value = targets.min_value;
+        s.max_value = targets.max_value;
+        mdb_binview_col *cols[3] = {&s.timestamps, &s.values, &s.residuals};
+        for (int c = 0; c < 3; c++) {
+            owned->host_allocs[c].resize(16);
+            int64_t *size_slot = reinterpret_cast<int64_t *>(owned->host_allocs[c].data());
+            size_slot[0] = (int64_t)data_bytes[c];
+            cols[c]->views = reinterpret_cast<const mdb_view16 *>(targets.views[c]);
+            cols[c]->buffers = reinterpret_cast<const uint8_t *const *>(dev + off_table[c]);
+            cols[c]->buffer_sizes = size_slot;
+            cols[c]->n_buffers = 1;
+        }
+        owned->c.error = targets.error;
+        owned->c.chunk_index = targets.chunk_index;
+    } else {
+        std::memset(&owned->c.seg, 0, sizeof(owned->c.seg));
+        owned->c.error = nullptr;
+        owned->c.chunk_index = nullptr;
+    }
+    owned->c.on_device = 1;
+    owned->c.priv_ = owned;
+    *out = &owned->c;
+    return 0;
+#undef FIT_CHECK
+#undef FIT_TRY
+}
+
+} // namespace mdb
+
+using namespace mdb;
+
+extern "C" {
+
+int mdb_compress_chunks_dev(mdb_ctx *ctx, const int64_t *ts, const float *values,
+                            const uint64_t *chunk_offsets, uint64_t n_chunks,
+                            mdb_error_bound error_bound, int64_t regular_start,
+                            int64_t regular_interval, const uint64_t *series_first_index,
+                            mdb_segments_owned **out) {
+    if (!ctx || !out) return fail("ctx and out must not be NULL.");
+    if (n_chunks > 0 && (!values || !chunk_offsets)) return fail("values and chunk_offsets must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    return compress_chunks_dev_locked(ctx, ts, values, chunk_offsets, n_chunks, error_bound,
+                                      regular_start, regular_interval, series_first_index, out);
+}
+
+int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
+                        const uint64_t *chunk_offsets, uint64_t n_chunks, mdb_error_bound error_bound,
+                        mdb_segments_owned **out) {
+    if (!ctx || !out) return fail("ctx and out must not be NULL.");
+    if (n_chunks > 0 && !chunk_offsets) return fail("chunk_offsets must not be NULL.");
+    const uint64_t total = n_chunks ? chunk_offsets[n_chunks] : 0;
+    if (total > 0 && (!ts || !values)) return fail("ts and values must not be NULL.");
+    for (uint64_t c = 0; c < n_chunks; c++)
+        if (chunk_offsets[c] > chunk_offsets[c + 1]) return fail("chunk_offsets must be non-decreasing.");
+    mdb_segments_owned *dev = nullptr;
+    int rc = 0;
+    void *dev_ts = nullptr, *dev_values = nullptr, *dev_offsets = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        MDB_HIP_CHECK(hipSetDevice(ctx->device));
+        auto upload = [&](void **dst, const void *src, uint64_t bytes) {
+            if (rc) return;
+            if (hipMalloc(dst, bytes ? bytes : 256) != hipSuccess) {
+                rc = fail("hipMalloc failed.");
+                return;
+            }
+            if (bytes && hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy host to device failed.");
+        };
+        upload(&dev_ts, ts, total * 8);
+        upload(&dev_values, values, total * 4);
+        upload(&dev_offsets, chunk_offsets, (n_chunks + 1) * 8);
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+        if (!rc)
+            rc = compress_chunks_dev_locked(ctx, static_cast<const int64_t *>(dev_ts),
+                                            static_cast<const float *>(dev_values),
+                                            static_cast<const uint64_t *>(dev_offsets), n_chunks,
+                                            error_bound, 0, 0, nullptr, &dev);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (dev_ts) (void)hipFree(dev_ts);
+        if (dev_values) (void)hipFree(dev_values);
+        if (dev_offsets) (void)hipFree(dev_offsets);
+    }
+    if (rc) return 1;
+    rc = mdb_segments_download(ctx, dev, out);
+    mdb_segments_free(dev);
+    return rc;
+}
+
+int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, uint64_t n,
+                        mdb_error_bound error_bound, mdb_segments_owned **out) {
+    const uint64_t offsets[2] = {0, n};
+    return mdb_compress_chunks(ctx, ts, values, offsets, 1, error_bound, out);
+}
+
+} // extern "C"

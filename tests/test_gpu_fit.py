@@ -1,0 +1,149 @@
+"""Parity of the HIP fitter (PMC-Mean / Swing / MacaqueV compression) with the CPU oracle through
+the C ABI (mdb_compress_chunks / mdb_compress_series).
+
+Bar: the same segments, byte for byte - model type ids, start/end times, min/max values and the
+timestamps / values / residuals payloads - and the reference's own acceptance criterion
+(compression.rs:865-929): decoded timestamps equal, every value within the error bound."""
+
+import numpy as np
+import pytest
+
+import cases
+import datagen
+import oracle_lib as ora
+import modelardb_rs_amd as mdb
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_segments(got, expected):
+    assert len(got) == len(expected)
+    assert np.array_equal(got.model_type_id, expected.model_type_id)
+    assert np.array_equal(got.start_time, expected.start_time)
+    assert np.array_equal(got.end_time, expected.end_time)
+    assert np.array_equal(got.min_value.view(np.uint32), expected.min_value.view(np.uint32))
+    assert np.array_equal(got.max_value.view(np.uint32), expected.max_value.view(np.uint32))
+    assert got.timestamps.to_bytes_list() == expected.timestamps.to_bytes_list()
+    assert got.values.to_bytes_list() == expected.values.to_bytes_list()
+    assert got.residuals.to_bytes_list() == expected.residuals.to_bytes_list()
+    assert np.isnan(got.error).all()
+    if expected.chunk_index is not None:
+        assert np.array_equal(got.chunk_index, expected.chunk_index)
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+@pytest.mark.parametrize("noise", [None, (1.0, 1.05)])
+@pytest.mark.parametrize("eb_name", ["lossless", "abs5", "rel5", "rel1", "abs0.01"])
+def test_fit_matches_oracle_on_synthetic_series(hip, eb_name, noise, irregular):
+    # The recipe of compression.rs:733-863.
+    eb = cases.error_bounds()[eb_name]
+    timestamps, values = cases.synthetic_series(50_000, irregular, noise, seed=31)
+    expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
+    got = hip.try_compress_univariate_time_series(timestamps, values, eb)
+    assert_same_segments(got, expected)
+    ts, reconstructed, _, _ = hip.grid_batch(got)
+    assert np.array_equal(ts, timestamps)
+
+
+def test_fit_edge_cases(hip):
+    for eb_name in ("lossless", "rel5", "abs5"):
+        eb = cases.error_bounds()[eb_name]
+        for name, ts, values in cases.edge_case_series():
+            expected = ora.try_compress_univariate_time_series(ts, values, eb)
+            got = hip.try_compress_univariate_time_series(ts, values, eb)
+            assert_same_segments(got, expected)
+
+
+def test_fit_empty_and_mismatched_input(hip):
+    assert len(hip.try_compress_univariate_time_series([], [], cases.LOSSLESS)) == 0  # :422-434
+    with pytest.raises(mdb.HipError, match="different lengths"):                      # :202-206
+        hip.try_compress_univariate_time_series([1, 2], [1.0], cases.LOSSLESS)
+    with pytest.raises(mdb.HipError, match="error bound"):
+        hip.try_compress_univariate_time_series([1, 2], [1.0, 2.0], mdb._abi.ErrorBoundC(1, -1.0))
+
+
+def test_fit_known_answer_segment(hip):  # compression.rs:932-978
+    batch = hip.try_compress_univariate_time_series([100, 200, 300, 400, 500],
+                                                    [73.0, 37.0, 37.0, 37.0, 73.0], cases.LOSSLESS)
+    assert batch.rows() == [(2, 100, 500, bytes([5]), 37.0, 73.0, bytes.fromhex("42920000d03c3a43"), b"")]
+
+
+def test_fit_many_chunks_in_one_launch(hip):
+    # The server hands the compressor one <= 65 536 point buffer per series (storage/mod.rs:58);
+    # the batch entry point takes many at once. Chunks of ragged lengths, including empty ones.
+    eb = cases.error_bounds()["rel1"]
+    rng = np.random.default_rng(41)
+    lengths = [0, 1, 2, 7, 8, 9, 300, 65536, 1000, 0, 4097] + [int(x) for x in rng.integers(1, 5000, 40)]
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    total = int(offsets[-1])
+    values = np.concatenate([datagen.sine_series(s, n)[1] if n else np.zeros(0, np.float32)
+                             for s, n in enumerate(lengths)])
+    timestamps = np.concatenate([np.arange(n, dtype=np.int64) * 1000 for n in lengths])
+    assert len(values) == total
+    expected = ora.compress_chunks(timestamps, values, offsets, eb)
+    got = hip.compress_chunks(timestamps, values, offsets, eb)
+    assert_same_segments(got, expected)
+
+
+def test_fit_sine_workload_full_chunks(hip):
+    # The benchmark's series cut into 65 536 point chunks.
+    eb = cases.error_bounds()["rel1"]
+    n_series, n_points = 8, 300_000
+    timestamps = np.tile(np.arange(n_points, dtype=np.int64) * 1000, n_series)
+    values = np.concatenate([datagen.sine_series(s, n_points)[1] for s in range(n_series)])
+    offsets = []
+    for s in range(n_series):
+        offsets += [s * n_points + c for c in range(0, n_points, 65536)]
+    offsets = np.array(offsets + [n_series * n_points], dtype=np.uint64)
+    expected = ora.compress_chunks(timestamps, values, offsets, eb, n_threads=8)
+    got = hip.compress_chunks(timestamps, values, offsets, eb)
+    assert_same_segments(got, expected)
+    ts, reconstructed, rows, _ = hip.grid_batch(got)
+    assert np.array_equal(ts, timestamps)
+    relative = np.abs((values - reconstructed) / values) * np.float32(100.0)
+    assert (relative <= np.float32(1.0)).all()
+
+
+def test_fit_device_resident_with_synthesised_timestamps(hip):
+    # mdb_compress_chunks_dev with ts == NULL must equal materialised regular timestamps.
+    eb = cases.error_bounds()["rel1"]
+    n_series, n_points, chunk = 3, 200_000, 65536
+    values = np.concatenate([datagen.sine_series(s, n_points)[1] for s in range(n_series)])
+    offsets, first_index = [], []
+    for s in range(n_series):
+        for c in range(0, n_points, chunk):
+            offsets.append(s * n_points + c)
+            first_index.append(c)
+    offsets = np.array(offsets + [n_series * n_points], dtype=np.uint64)
+    first_index = np.array(first_index, dtype=np.uint64)
+    timestamps = np.tile(np.arange(n_points, dtype=np.int64) * 1000, n_series)
+    expected = ora.compress_chunks(timestamps, values, offsets, eb, n_threads=8)
+    values_dev = hip.upload_array(values)
+    offsets_dev = hip.upload_array(offsets)
+    first_dev = hip.upload_array(first_index)
+    dev = hip.compress_chunks_dev(0, values_dev, offsets_dev, len(offsets) - 1, eb, 0, 1000, first_dev)
+    got = dev.download()
+    assert_same_segments(got, expected)
+    # and grid straight from the device-resident segments
+    total = hip.grid_count_dev(dev)
+    assert total == n_series * n_points
+    out_ts, out_val = hip.dev_alloc(8 * total), hip.dev_alloc(4 * total)
+    hip.grid_batch_dev(dev, out_ts, out_val, total)
+    assert np.array_equal(hip.download_array(out_ts, total, np.int64), timestamps)
+    for pointer in (values_dev, offsets_dev, first_dev, out_ts, out_val):
+        hip.dev_free(pointer)
+    dev.free()
+
+
+def test_synthetic_generator_statistics(hip):
+    n_series, n_points = 4, 100_000
+    pointer = hip.dev_alloc(4 * n_series * n_points)
+    hip.synth_values_dev(pointer, 0, n_series, n_points)
+    values = hip.download_array(pointer, n_series * n_points, np.float32).reshape(n_series, n_points)
+    hip.dev_free(pointer)
+    assert np.isfinite(values).all()
+    assert 89.9 <= values.min() <= 90.2 and 109.8 <= values.max() <= 110.1
+    i = np.arange(n_points, dtype=np.float64)
+    for s in range(n_series):
+        clean = 100.0 + 10.0 * np.sin(2 * np.pi * i / (2000.0 + 37.0 * (s % 64)) + 2 * np.pi * ((s * 0.61803) % 1.0))
+        assert np.abs(values[s] - clean).max() <= 0.0501
