@@ -1,0 +1,1059 @@
+// mdb_host.cpp - implementation of the host-side operators declared in mdb_host.hpp and of the C
+// surface (mdbh_*) the tests drive them through. No model arithmetic happens here: grid, aggregate
+// and fit go to libmdb_hip.so through the C ABI of include/mdb.h.
+#include "mdb_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace mdbhost {
+
+namespace {
+
+void check(int code) {
+    if (code != 0) throw Error(mdb_last_error());
+}
+
+size_t width_of(Type type) {
+    switch (type) {
+    case Type::Int8: return 1;
+    case Type::Int16: return 2;
+    case Type::Float32: return 4;
+    case Type::Int64:
+    case Type::Timestamp:
+    case Type::Float64:
+    case Type::UInt64: return 8;
+    case Type::BinaryView:
+    case Type::Utf8View: return 16;
+    }
+    return 0;
+}
+
+bool is_view(Type type) { return type == Type::BinaryView || type == Type::Utf8View; }
+
+const char *format_of(Type type) {
+    switch (type) {
+    case Type::Int8: return "c";
+    case Type::Int16: return "s";
+    case Type::Int64: return "l";
+    case Type::UInt64: return "L";
+    case Type::Float32: return "f";
+    case Type::Float64: return "g";
+    case Type::Timestamp: return "tsu:";
+    case Type::BinaryView: return "vz";
+    case Type::Utf8View: return "vu";
+    }
+    return "";
+}
+
+Type type_of(const char *format) {
+    std::string f(format);
+    if (f == "c") return Type::Int8;
+    if (f == "s") return Type::Int16;
+    if (f == "l") return Type::Int64;
+    if (f == "L") return Type::UInt64;
+    if (f == "f") return Type::Float32;
+    if (f == "g") return Type::Float64;
+    if (f.rfind("tsu:", 0) == 0) return Type::Timestamp;
+    if (f == "vz") return Type::BinaryView;
+    if (f == "vu") return Type::Utf8View;
+    throw Error("Unsupported Arrow format: " + f);
+}
+
+// Keeps an imported ArrowArray / ArrowSchema alive until the last column referencing it dies.
+struct ImportHolder {
+    ArrowArray array{};
+    ArrowSchema schema{};
+    ~ImportHolder() {
+        if (array.release) array.release(&array);
+        if (schema.release) schema.release(&schema);
+    }
+};
+
+ColumnPtr column_from_c(const ArrowArray *array, const ArrowSchema *schema, std::shared_ptr<void> holder) {
+    auto column = std::make_shared<Column>();
+    column->type = type_of(schema->format);
+    column->length = array->length;
+    column->keep_alive = std::move(holder);
+    if (array->null_count > 0) throw Error("Nullable columns are not supported on this path.");
+    const size_t width = width_of(column->type);
+    if (array->n_buffers < 2) throw Error("Malformed Arrow array: too few buffers.");
+    const uint8_t *base = static_cast<const uint8_t *>(array->buffers[1]);
+    column->values = base ? base + static_cast<size_t>(array->offset) * width : nullptr;
+    if (is_view(column->type)) {
+        // buffers: validity, views, variadic data buffers..., variadic buffer sizes (int64)
+        const int64_t n_variadic = array->n_buffers - 3;
+        if (n_variadic < 0) throw Error("Malformed Arrow view array.");
+        const int64_t *sizes = static_cast<const int64_t *>(array->buffers[array->n_buffers - 1]);
+        for (int64_t b = 0; b < n_variadic; b++) {
+            column->buffer_ptrs.push_back(static_cast<const uint8_t *>(array->buffers[2 + b]));
+            column->buffer_sizes.push_back(sizes ? sizes[b] : 0);
+        }
+    }
+    return column;
+}
+
+// ---- export ---------------------------------------------------------------------------------------------
+
+struct ExportedSchema {
+    std::string name;
+    std::vector<ArrowSchema> children;
+    std::vector<ArrowSchema *> child_ptrs;
+};
+
+void release_schema(ArrowSchema *schema) {
+    if (!schema || !schema->release) return;
+    ExportedSchema *state = static_cast<ExportedSchema *>(schema->private_data);
+    for (auto &child : state->children)
+        if (child.release) child.release(&child); // a consumer that moved a child cleared its release
+    delete state;
+    schema->release = nullptr;
+}
+
+void fill_schema(ArrowSchema *out, const char *format, const std::string &name, ExportedSchema *state) {
+    state->name = name;
+    out->format = format;
+    out->name = state->name.c_str();
+    out->metadata = nullptr;
+    out->flags = 0;
+    out->n_children = 0;
+    out->children = nullptr;
+    out->dictionary = nullptr;
+    out->release = release_schema;
+    out->private_data = state;
+}
+
+struct ExportedArray {
+    ColumnPtr column;
+    std::vector<const void *> buffers;
+    std::vector<int64_t> variadic_sizes;
+    std::vector<ArrowArray> children;
+    std::vector<ArrowArray *> child_ptrs;
+};
+
+void release_array(ArrowArray *array) {
+    if (!array || !array->release) return;
+    ExportedArray *state = static_cast<ExportedArray *>(array->private_data);
+    for (auto &child : state->children)
+        if (child.release) child.release(&child);
+    delete state;
+    array->release = nullptr;
+}
+
+void export_column(const ColumnPtr &column, ArrowArray *out) {
+    auto *state = new ExportedArray();
+    state->column = column;
+    state->buffers.push_back(nullptr);
+    state->buffers.push_back(column->values);
+    if (is_view(column->type)) {
+        for (size_t b = 0; b < column->buffer_ptrs.size(); b++) {
+            state->buffers.push_back(column->buffer_ptrs[b]);
+            state->variadic_sizes.push_back(column->buffer_sizes[b]);
+        }
+        if (state->variadic_sizes.empty()) state->variadic_sizes.push_back(0); // never a null pointer
+        state->buffers.push_back(state->variadic_sizes.data());
+    }
+    out->length = column->length;
+    out->null_count = 0;
+    out->offset = 0;
+    out->n_buffers = static_cast<int64_t>(state->buffers.size());
+    out->n_children = 0;
+    out->buffers = state->buffers.data();
+    out->children = nullptr;
+    out->dictionary = nullptr;
+    out->release = release_array;
+    out->private_data = state;
+}
+
+template <typename T> ColumnPtr owned_column(Type type, const std::vector<T> &values) {
+    return make_primitive_column(type, values.data(), static_cast<int64_t>(values.size()));
+}
+
+struct ViewWord {
+    int32_t length;
+    uint8_t rest[12];
+};
+static_assert(sizeof(ViewWord) == 16, "Arrow views are 16 bytes");
+
+} // namespace
+
+// ---- Column / RecordBatch ---------------------------------------------------------------------------------
+
+std::string_view Column::view_value(int64_t i) const {
+    const mdb_view16 &view = as<mdb_view16>()[i];
+    if (view.length <= 12)
+        return {reinterpret_cast<const char *>(view.u.inlined), static_cast<size_t>(view.length)};
+    return {reinterpret_cast<const char *>(buffer_ptrs[view.u.ref.buffer_index] + view.u.ref.offset),
+            static_cast<size_t>(view.length)};
+}
+
+ColumnPtr make_primitive_column(Type type, const void *values, int64_t length) {
+    auto column = std::make_shared<Column>();
+    column->type = type;
+    column->length = length;
+    column->data.resize(std::max<size_t>(static_cast<size_t>(length) * width_of(type), 1));
+    if (length > 0) std::memcpy(column->data.data(), values, static_cast<size_t>(length) * width_of(type));
+    column->values = column->data.data();
+    return column;
+}
+
+ColumnPtr make_view_column(Type type, const std::vector<std::string_view> &rows) {
+    auto column = std::make_shared<Column>();
+    column->type = type;
+    column->length = static_cast<int64_t>(rows.size());
+    column->data.assign(std::max<size_t>(rows.size() * 16, 16), 0);
+    column->owned_buffers.emplace_back();
+    std::vector<uint8_t> &payload = column->owned_buffers[0];
+    mdb_view16 *views = reinterpret_cast<mdb_view16 *>(column->data.data());
+    for (size_t i = 0; i < rows.size(); i++) {
+        views[i].length = static_cast<int32_t>(rows[i].size());
+        if (rows[i].size() <= 12) {
+            std::memcpy(views[i].u.inlined, rows[i].data(), rows[i].size());
+        } else {
+            std::memcpy(views[i].u.ref.prefix, rows[i].data(), 4);
+            views[i].u.ref.buffer_index = 0;
+            views[i].u.ref.offset = static_cast<int32_t>(payload.size());
+            payload.insert(payload.end(), rows[i].begin(), rows[i].end());
+        }
+    }
+    column->values = column->data.data();
+    if (!payload.empty()) {
+        column->buffer_ptrs.push_back(payload.data());
+        column->buffer_sizes.push_back(static_cast<int64_t>(payload.size()));
+    }
+    return column;
+}
+
+RecordBatch RecordBatch::new_empty(const std::vector<Field> &schema) {
+    RecordBatch batch;
+    batch.schema = schema;
+    for (const Field &field : schema) {
+        auto column = std::make_shared<Column>();
+        column->type = field.type;
+        column->data.assign(16, 0);
+        column->values = column->data.data();
+        batch.columns.push_back(column);
+    }
+    return batch;
+}
+
+RecordBatch RecordBatch::slice(int64_t offset, int64_t length) const {
+    RecordBatch out;
+    out.schema = schema;
+    out.num_rows = length;
+    for (const ColumnPtr &parent : columns) {
+        auto column = std::make_shared<Column>();
+        column->type = parent->type;
+        column->length = length;
+        column->values = static_cast<const uint8_t *>(parent->values) + static_cast<size_t>(offset) * width_of(parent->type);
+        column->buffer_ptrs = parent->buffer_ptrs;
+        column->buffer_sizes = parent->buffer_sizes;
+        column->keep_alive = parent; // zero-copy: the slice shares the parent's storage
+        out.columns.push_back(column);
+    }
+    return out;
+}
+
+ColumnPtr import_array(ArrowArray *array, ArrowSchema *schema) {
+    auto holder = std::make_shared<ImportHolder>();
+    holder->array = *array;
+    holder->schema = *schema;
+    array->release = nullptr;
+    schema->release = nullptr;
+    return column_from_c(&holder->array, &holder->schema, holder);
+}
+
+RecordBatch import_record_batch(ArrowArray *array, ArrowSchema *schema) {
+    auto holder = std::make_shared<ImportHolder>();
+    holder->array = *array;
+    holder->schema = *schema;
+    array->release = nullptr;
+    schema->release = nullptr;
+    if (std::string(holder->schema.format) != "+s") throw Error("A RecordBatch must be exported as a struct array.");
+    if (holder->array.n_children != holder->schema.n_children) throw Error("Schema and array disagree.");
+    RecordBatch batch;
+    batch.num_rows = holder->array.length;
+    for (int64_t c = 0; c < holder->array.n_children; c++) {
+        const ArrowSchema *child_schema = holder->schema.children[c];
+        ColumnPtr column = column_from_c(holder->array.children[c], child_schema, holder);
+        if (holder->array.offset != 0) throw Error("Sliced struct arrays are not supported; slice the columns.");
+        batch.schema.push_back({child_schema->name ? child_schema->name : "", column->type});
+        batch.columns.push_back(column);
+    }
+    return batch;
+}
+
+void export_record_batch(const RecordBatch &batch, ArrowArray *out_array, ArrowSchema *out_schema) {
+    auto *schema_state = new ExportedSchema();
+    fill_schema(out_schema, "+s", "", schema_state);
+    const size_t n = batch.columns.size();
+    schema_state->children.resize(n);
+    schema_state->child_ptrs.resize(n);
+    for (size_t c = 0; c < n; c++) {
+        // Each child owns its own state; the parent's release releases the children.
+        fill_schema(&schema_state->children[c], format_of(batch.schema[c].type), batch.schema[c].name,
+                    new ExportedSchema());
+        schema_state->child_ptrs[c] = &schema_state->children[c];
+    }
+    out_schema->n_children = static_cast<int64_t>(n);
+    out_schema->children = schema_state->child_ptrs.data();
+
+    auto *array_state = new ExportedArray();
+    array_state->buffers.push_back(nullptr);
+    array_state->children.resize(n);
+    array_state->child_ptrs.resize(n);
+    for (size_t c = 0; c < n; c++) {
+        export_column(batch.columns[c], &array_state->children[c]);
+        array_state->child_ptrs[c] = &array_state->children[c];
+    }
+    out_array->length = batch.num_rows;
+    out_array->null_count = 0;
+    out_array->offset = 0;
+    out_array->n_buffers = 1;
+    out_array->n_children = static_cast<int64_t>(n);
+    out_array->buffers = array_state->buffers.data();
+    out_array->children = array_state->child_ptrs.data();
+    out_array->dictionary = nullptr;
+    out_array->release = release_array;
+    out_array->private_data = array_state;
+}
+
+// ---- schemas ------------------------------------------------------------------------------------------------
+
+std::vector<Field> query_compressed_schema() {
+    return {{"model_type_id", Type::Int8},   {"start_time", Type::Timestamp}, {"end_time", Type::Timestamp},
+            {"timestamps", Type::BinaryView}, {"min_value", Type::Float32},   {"max_value", Type::Float32},
+            {"values", Type::BinaryView},     {"residuals", Type::BinaryView}, {"error", Type::Float32}};
+}
+
+std::vector<Field> compressed_schema(const std::vector<std::string> &tag_names) {
+    std::vector<Field> schema = query_compressed_schema();
+    schema.push_back({"field_column", Type::Int16});
+    for (const std::string &tag : tag_names) schema.push_back({tag, Type::Utf8View});
+    return schema;
+}
+
+std::vector<Field> grid_schema(const std::vector<std::string> &tag_names) {
+    std::vector<Field> schema = {{"timestamp", Type::Timestamp}, {"value", Type::Float32}};
+    for (const std::string &tag : tag_names) schema.push_back({tag, Type::Utf8View});
+    return schema;
+}
+
+ErrorBound ErrorBound::try_new_absolute(float value) {
+    if (!std::isfinite(value) || value <= 0.0f)
+        throw Error("An absolute error bound must be a positive finite value.");
+    ErrorBound eb;
+    eb.c = {MDB_EB_ABSOLUTE, value};
+    return eb;
+}
+
+ErrorBound ErrorBound::try_new_relative(float percentage) {
+    if (!(0.0f < percentage && percentage <= 100.0f))
+        throw Error("A relative error bound must be a positive value that is at most 100.0%.");
+    ErrorBound eb;
+    eb.c = {MDB_EB_RELATIVE, percentage};
+    return eb;
+}
+
+// ---- QueueExec ----------------------------------------------------------------------------------------------
+
+namespace {
+struct QueueStream : SegmentStream {
+    std::shared_ptr<QueueExec::State> state;
+    PollState poll_next(RecordBatch *out) override {
+        if (!state->queue.empty()) {
+            *out = std::move(state->queue.front());
+            state->queue.pop_front();
+            return PollState::ReadySome;
+        }
+        return state->finished ? PollState::ReadyNone : PollState::Pending;
+    }
+};
+
+// The mdb_segments view of the first eight columns of a segment batch.
+struct SegmentsView {
+    mdb_segments seg{};
+    std::vector<const uint8_t *> pointers[3];
+    std::vector<int64_t> sizes[3];
+};
+
+void fill_segments_view(const std::vector<ColumnPtr> &columns, SegmentsView *view) {
+    if (columns.size() < 8) throw Error("A segment batch needs the columns of QUERY_COMPRESSED_SCHEMA.");
+    const Type expected[8] = {Type::Int8, Type::Timestamp, Type::Timestamp, Type::BinaryView,
+                              Type::Float32, Type::Float32, Type::BinaryView, Type::BinaryView};
+    for (int c = 0; c < 8; c++) {
+        Type got = columns[c]->type;
+        if (got == Type::Int64 && expected[c] == Type::Timestamp) continue;
+        if (got != expected[c]) throw Error("Segment column " + std::to_string(c) + " has the wrong type.");
+    }
+    mdb_segments &s = view->seg;
+    s.n = static_cast<uint64_t>(columns[0]->length);
+    s.model_type_id = columns[0]->as<int8_t>();
+    s.start_time = columns[1]->as<int64_t>();
+    s.end_time = columns[2]->as<int64_t>();
+    s.min_value = columns[4]->as<float>();
+    s.max_value = columns[5]->as<float>();
+    const int view_columns[3] = {3, 6, 7};
+    mdb_binview_col *out[3] = {&s.timestamps, &s.values, &s.residuals};
+    for (int k = 0; k < 3; k++) {
+        const Column &column = *columns[view_columns[k]];
+        view->pointers[k] = column.buffer_ptrs;
+        view->sizes[k] = column.buffer_sizes;
+        out[k]->views = column.as<mdb_view16>();
+        out[k]->buffers = view->pointers[k].data();
+        out[k]->buffer_sizes = view->sizes[k].data();
+        out[k]->n_buffers = static_cast<int32_t>(view->pointers[k].size());
+    }
+}
+} // namespace
+
+std::unique_ptr<SegmentStream> QueueExec::execute_segments(size_t) {
+    auto stream = std::make_unique<QueueStream>();
+    stream->state = state_;
+    return stream;
+}
+
+// ---- GridExec / GridStream ----------------------------------------------------------------------------------
+
+void GridStreamMetrics::add(const mdb_grid_metrics &m) {
+    rows_created += m.rows_created;
+    segments_with_residuals += m.segments_with_residuals;
+    segments_regular += m.segments_regular;
+    segments_irregular += m.segments_irregular;
+    for (int k = 0; k < MDB_MODEL_TYPE_COUNT; k++) {
+        rows_created_by_model_type[k] += m.rows_created_by_model_type[k];
+        segments_with_model_type[k] += m.segments_with_model_type[k];
+    }
+}
+
+std::shared_ptr<GridExec> GridExec::make(mdb_ctx *ctx, std::vector<Field> schema,
+                                         std::optional<TimestampPredicate> maybe_predicate,
+                                         std::optional<size_t> limit, std::shared_ptr<ExecutionPlan> input) {
+    auto exec = std::make_shared<GridExec>();
+    exec->ctx_ = ctx;
+    exec->schema_ = std::move(schema);
+    exec->maybe_predicate_ = maybe_predicate;
+    exec->limit_ = limit;
+    exec->input_ = std::move(input);
+    return exec;
+}
+
+std::shared_ptr<GridExec> GridExec::with_new_children(std::vector<std::shared_ptr<ExecutionPlan>> children) const {
+    if (children.size() != 1) throw Error("Exactly one child must be provided GridExec.");
+    return GridExec::make(ctx_, schema_, maybe_predicate_, limit_, children[0]);
+}
+
+std::unique_ptr<GridStream> GridExec::execute(size_t partition, size_t batch_size) {
+    return std::make_unique<GridStream>(ctx_, schema_, maybe_predicate_, limit_,
+                                        input_->execute_segments(partition), batch_size, metrics_);
+}
+
+std::string GridExec::fmt_as() const {
+    return std::string("GridExec: limit=") + (limit_ ? "Some(" + std::to_string(*limit_) + ")" : "None");
+}
+
+GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<TimestampPredicate> maybe_predicate,
+                       std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
+                       std::shared_ptr<GridStreamMetrics> metrics)
+    : ctx_(ctx), schema_(std::move(schema)), maybe_predicate_(maybe_predicate), input_(std::move(input)),
+      batch_size_(limit ? std::min(*limit, batch_size) : batch_size), // grid_exec.rs:239-246
+      current_batch_(RecordBatch::new_empty(schema_)), metrics_(std::move(metrics)) {}
+
+void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch &batch) {
+    const auto started = std::chrono::steady_clock::now();
+    const size_t n_tags = batch.columns.size() - query_compressed_schema().size();
+    if (schema_.size() != 2 + n_tags) throw Error("GridStream should use a static schema.");
+    SegmentsView view;
+    fill_segments_view(batch.columns, &view);
+
+    // One sizing call and one batch call replace the per-row loop of grid_exec.rs:323-356.
+    uint64_t new_points = 0;
+    check(mdb_grid_count(ctx_, &view.seg, &new_points));
+    const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
+    const int64_t total = leftovers + static_cast<int64_t>(new_points);
+    std::vector<int64_t> timestamps(static_cast<size_t>(total));
+    std::vector<float> values(static_cast<size_t>(total));
+    if (leftovers > 0) { // keep the batch sorted: leftovers first (grid_exec.rs:302-320)
+        std::memcpy(timestamps.data(), current_batch_.columns[0]->as<int64_t>() + current_batch_offset_, 8 * leftovers);
+        std::memcpy(values.data(), current_batch_.columns[1]->as<float>() + current_batch_offset_, 4 * leftovers);
+    }
+    std::vector<uint32_t> rows_per_segment(static_cast<size_t>(batch.num_rows));
+    mdb_grid_metrics metrics;
+    std::memset(&metrics, 0, sizeof(metrics));
+    uint64_t produced = 0;
+    check(mdb_grid_batch(ctx_, &view.seg, timestamps.data() + leftovers, values.data() + leftovers,
+                         rows_per_segment.data(), new_points, &produced, &metrics));
+    metrics_->add(metrics);
+
+    // Tag columns: the segment's tag value once per created row (grid_exec.rs:341-346). Views are
+    // replicated; long strings stay in the input's data buffers (shared, not copied).
+    std::vector<ColumnPtr> tag_columns;
+    for (size_t t = 0; t < n_tags; t++) {
+        const Column &input_tags = *batch.columns[query_compressed_schema().size() + t];
+        auto column = std::make_shared<Column>();
+        column->type = Type::Utf8View;
+        column->length = total;
+        column->data.assign(std::max<size_t>(static_cast<size_t>(total) * 16, 16), 0);
+        mdb_view16 *views = reinterpret_cast<mdb_view16 *>(column->data.data());
+        // buffer 0: long leftover strings, copied so old inputs can be dropped.
+        column->owned_buffers.emplace_back();
+        std::vector<uint8_t> &leftover_payload = column->owned_buffers[0];
+        if (leftovers > 0) {
+            const Column &previous = *current_batch_.columns[2 + t];
+            for (int64_t i = 0; i < leftovers; i++) {
+                std::string_view value = previous.view_value(current_batch_offset_ + i);
+                views[i].length = static_cast<int32_t>(value.size());
+                if (value.size() <= 12) {
+                    std::memcpy(views[i].u.inlined, value.data(), value.size());
+                } else {
+                    std::memcpy(views[i].u.ref.prefix, value.data(), 4);
+                    views[i].u.ref.buffer_index = 0;
+                    views[i].u.ref.offset = static_cast<int32_t>(leftover_payload.size());
+                    leftover_payload.insert(leftover_payload.end(), value.begin(), value.end());
+                }
+            }
+        }
+        int64_t at = leftovers;
+        const mdb_view16 *input_views = input_tags.as<mdb_view16>();
+        for (int64_t row = 0; row < batch.num_rows; row++) {
+            mdb_view16 tag = input_views[row];
+            if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
+            for (uint32_t k = 0; k < rows_per_segment[static_cast<size_t>(row)]; k++) views[at++] = tag;
+        }
+        column->values = column->data.data();
+        column->buffer_ptrs.push_back(leftover_payload.empty() ? reinterpret_cast<const uint8_t *>(column->data.data())
+                                                               : leftover_payload.data());
+        column->buffer_sizes.push_back(static_cast<int64_t>(leftover_payload.size()));
+        for (size_t b = 0; b < input_tags.buffer_ptrs.size(); b++) {
+            column->buffer_ptrs.push_back(input_tags.buffer_ptrs[b]);
+            column->buffer_sizes.push_back(input_tags.buffer_sizes[b]);
+        }
+        column->keep_alive = batch.columns[query_compressed_schema().size() + t];
+        tag_columns.push_back(column);
+    }
+
+    // Prune by time after reconstruction (grid_exec.rs:366-387).
+    if (maybe_predicate_) {
+        std::vector<int64_t> selected;
+        selected.reserve(static_cast<size_t>(total));
+        for (int64_t i = 0; i < total; i++)
+            if (maybe_predicate_->matches(timestamps[static_cast<size_t>(i)])) selected.push_back(i);
+        std::vector<int64_t> kept_ts(selected.size());
+        std::vector<float> kept_values(selected.size());
+        for (size_t k = 0; k < selected.size(); k++) {
+            kept_ts[k] = timestamps[static_cast<size_t>(selected[k])];
+            kept_values[k] = values[static_cast<size_t>(selected[k])];
+        }
+        timestamps.swap(kept_ts);
+        values.swap(kept_values);
+        for (ColumnPtr &column : tag_columns) {
+            std::vector<uint8_t> kept(std::max<size_t>(selected.size() * 16, 16), 0);
+            const mdb_view16 *views = reinterpret_cast<const mdb_view16 *>(column->data.data());
+            for (size_t k = 0; k < selected.size(); k++)
+                reinterpret_cast<mdb_view16 *>(kept.data())[k] = views[selected[k]];
+            column->data.swap(kept);
+            column->values = column->data.data();
+            column->length = static_cast<int64_t>(selected.size());
+        }
+    }
+
+    RecordBatch current;
+    current.schema = schema_;
+    current.num_rows = static_cast<int64_t>(timestamps.size());
+    current.columns.push_back(owned_column(Type::Timestamp, timestamps));
+    current.columns.push_back(owned_column(Type::Float32, values));
+    for (ColumnPtr &column : tag_columns) current.columns.push_back(column);
+    current_batch_ = std::move(current);
+    current_batch_offset_ = 0; // grid_exec.rs:389-390
+    metrics_->elapsed_compute_ns += static_cast<uint64_t>(
+        std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - started).count());
+}
+
+PollState GridStream::poll_next(RecordBatch *out) {
+    // grid_exec.rs:402-429
+    if (static_cast<size_t>(current_batch_.num_rows - current_batch_offset_) < batch_size_) {
+        RecordBatch batch;
+        PollState state = input_->poll_next(&batch);
+        if (state == PollState::ReadySome) {
+            grid_and_append_to_leftovers_in_current_batch(batch);
+        } else if (state == PollState::ReadyNone && current_batch_offset_ < current_batch_.num_rows) {
+            // Ignore Ready(None): there are data points left in the current batch.
+        } else {
+            return state;
+        }
+    }
+    const int64_t remaining = current_batch_.num_rows - current_batch_offset_;
+    const int64_t length = std::min<int64_t>(static_cast<int64_t>(batch_size_), remaining);
+    *out = current_batch_.slice(current_batch_offset_, length);
+    current_batch_offset_ += length;
+    metrics_->output_rows += static_cast<uint64_t>(length);
+    return PollState::ReadySome;
+}
+
+// ---- accumulators ---------------------------------------------------------------------------------------------
+
+namespace {
+
+class ModelAccumulator : public Accumulator {
+  public:
+    ModelAccumulator(mdb_ctx *ctx, uint32_t mask) : ctx_(ctx), mask_(mask) { reset(); }
+    void update_batch(const std::vector<ColumnPtr> &arrays) override {
+        SegmentsView view;
+        fill_segments_view(arrays, &view);
+        check(mdb_agg_batch(ctx_, &view.seg, mask_, &state_));
+    }
+    size_t size() const override { return sizeof(*this); }
+
+  protected:
+    void reset() {
+        state_.sum = 0.0;
+        state_.count = 0;
+        state_.min = std::numeric_limits<float>::max();    // f32::MAX (:413)
+        state_.max = std::numeric_limits<float>::lowest(); // f32::MIN (:456)
+    }
+    mdb_ctx *ctx_;
+    uint32_t mask_;
+    mdb_agg_state state_;
+};
+
+struct ModelCountAccumulator : ModelAccumulator {
+    explicit ModelCountAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_COUNT) {}
+    std::vector<ScalarValue> state() override { // :367-372
+        ScalarValue v{ScalarValue::Kind::Int64};
+        v.i64 = state_.count;
+        reset();
+        return {v};
+    }
+};
+
+struct ModelMinAccumulator : ModelAccumulator {
+    explicit ModelMinAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_MIN) {}
+    std::vector<ScalarValue> state() override { // :410-415
+        ScalarValue v{ScalarValue::Kind::Float32};
+        v.f32 = state_.min;
+        reset();
+        return {v};
+    }
+};
+
+struct ModelMaxAccumulator : ModelAccumulator {
+    explicit ModelMaxAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_MAX) {}
+    std::vector<ScalarValue> state() override { // :453-458
+        ScalarValue v{ScalarValue::Kind::Float32};
+        v.f32 = state_.max;
+        reset();
+        return {v};
+    }
+};
+
+struct ModelSumAccumulator : ModelAccumulator {
+    explicit ModelSumAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_SUM) {}
+    std::vector<ScalarValue> state() override { // :523-528
+        ScalarValue v{ScalarValue::Kind::Float64};
+        v.f64 = state_.sum;
+        reset();
+        return {v};
+    }
+};
+
+struct ModelAvgAccumulator : ModelAccumulator {
+    explicit ModelAvgAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_AVG) {}
+    std::vector<ScalarValue> state() override { // :597-606: [UInt64 count, Float64 sum]
+        ScalarValue count{ScalarValue::Kind::UInt64};
+        count.u64 = static_cast<uint64_t>(state_.count);
+        ScalarValue sum{ScalarValue::Kind::Float64};
+        sum.f64 = state_.sum;
+        reset();
+        return {count, sum};
+    }
+};
+
+} // namespace
+
+std::unique_ptr<Accumulator> make_model_count_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelCountAccumulator>(ctx); }
+std::unique_ptr<Accumulator> make_model_min_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelMinAccumulator>(ctx); }
+std::unique_ptr<Accumulator> make_model_max_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelMaxAccumulator>(ctx); }
+std::unique_ptr<Accumulator> make_model_sum_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelSumAccumulator>(ctx); }
+std::unique_ptr<Accumulator> make_model_avg_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelAvgAccumulator>(ctx); }
+
+// ---- compression ------------------------------------------------------------------------------------------------
+
+namespace {
+
+// Rows [first, last) of a host-resident owned batch as a RecordBatch with the compressed schema
+// (CompressedSegmentBatchBuilder::finish, crates/modelardb_compression/src/types.rs:492-516).
+RecordBatch record_batch_from_owned(const mdb_segments_owned *owned, uint64_t first, uint64_t last,
+                                    const std::vector<Field> &schema, const std::vector<std::string> &tag_values,
+                                    int16_t field_column_index) {
+    const uint64_t n = last - first;
+    const size_t n_fixed = query_compressed_schema().size() + 1;
+    if (schema.size() != n_fixed + tag_values.size())
+        throw Error("compressed_schema does not match the number of tag values.");
+    const mdb_segments &s = owned->seg;
+    RecordBatch batch;
+    batch.schema = schema;
+    batch.num_rows = static_cast<int64_t>(n);
+    auto view_column = [&](const mdb_binview_col &col) {
+        // Re-pack the rows' payloads so the batch owns exactly what it references.
+        std::vector<std::string_view> rows;
+        rows.reserve(n);
+        for (uint64_t i = first; i < last; i++) {
+            const mdb_view16 &view = col.views[i];
+            const uint8_t *bytes = view.length <= 12 ? view.u.inlined
+                                                     : col.buffers[view.u.ref.buffer_index] + view.u.ref.offset;
+            rows.emplace_back(reinterpret_cast<const char *>(bytes), static_cast<size_t>(view.length));
+        }
+        return make_view_column(Type::BinaryView, rows);
+    };
+    batch.columns.push_back(make_primitive_column(Type::Int8, s.model_type_id + first, n));
+    batch.columns.push_back(make_primitive_column(Type::Timestamp, s.start_time + first, n));
+    batch.columns.push_back(make_primitive_column(Type::Timestamp, s.end_time + first, n));
+    batch.columns.push_back(view_column(s.timestamps));
+    batch.columns.push_back(make_primitive_column(Type::Float32, s.min_value + first, n));
+    batch.columns.push_back(make_primitive_column(Type::Float32, s.max_value + first, n));
+    batch.columns.push_back(view_column(s.values));
+    batch.columns.push_back(view_column(s.residuals));
+    std::vector<float> error(n, std::numeric_limits<float>::quiet_NaN());
+    batch.columns.push_back(owned_column(Type::Float32, error));
+    std::vector<int16_t> field_column(n, field_column_index);
+    batch.columns.push_back(owned_column(Type::Int16, field_column));
+    for (const std::string &tag : tag_values) {
+        std::vector<std::string_view> rows(n, std::string_view(tag));
+        batch.columns.push_back(make_view_column(Type::Utf8View, rows));
+    }
+    return batch;
+}
+
+struct OwnedGuard {
+    mdb_segments_owned *owned = nullptr;
+    ~OwnedGuard() { mdb_segments_free(owned); }
+};
+
+} // namespace
+
+RecordBatch try_compress_univariate_time_series(mdb_ctx *ctx, const Column &uncompressed_timestamps,
+                                                const Column &uncompressed_values, ErrorBound error_bound,
+                                                const std::vector<Field> &compressed_schema,
+                                                const std::vector<std::string> &tag_values,
+                                                int16_t field_column_index) {
+    if (uncompressed_timestamps.length != uncompressed_values.length) // compression.rs:202-206
+        throw Error("Invalid Argument Error: Uncompressed timestamps and uncompressed values have different lengths.");
+    if (uncompressed_timestamps.length == 0) return RecordBatch::new_empty(compressed_schema); // :208-211
+    OwnedGuard guard;
+    check(mdb_compress_series(ctx, uncompressed_timestamps.as<int64_t>(), uncompressed_values.as<float>(),
+                              static_cast<uint64_t>(uncompressed_values.length), error_bound.c, &guard.owned));
+    return record_batch_from_owned(guard.owned, 0, guard.owned->seg.n, compressed_schema, tag_values,
+                                   field_column_index);
+}
+
+std::vector<RecordBatch> try_compress_multivariate_time_series(mdb_ctx *ctx,
+                                                               const TimeSeriesTableMetadata &metadata,
+                                                               const RecordBatch &batch) {
+    const int64_t n = batch.num_rows;
+    if (n == 0) throw Error("The uncompressed time series must contain at least one data point.");
+    const Column &ts_column = *batch.columns[metadata.timestamp_column_index];
+    std::vector<const Column *> tags;
+    for (size_t index : metadata.tag_column_indices) tags.push_back(batch.columns[index].get());
+
+    // sort_time_series_by_tags_and_time (compression.rs:111-141): lexsort(tags..., timestamp).
+    std::vector<int64_t> order(static_cast<size_t>(n));
+    std::iota(order.begin(), order.end(), 0);
+    const int64_t *ts = ts_column.as<int64_t>();
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        for (const Column *tag : tags) {
+            int cmp = tag->view_value(a).compare(tag->view_value(b));
+            if (cmp != 0) return cmp < 0;
+        }
+        return ts[a] < ts[b];
+    });
+
+    // Split on tag change (compression.rs:64-104).
+    struct Series {
+        int64_t first, last; // [first, last) in `order`
+        std::vector<std::string> tag_values;
+    };
+    std::vector<Series> series;
+    auto tags_of = [&](int64_t row) {
+        std::vector<std::string> values;
+        for (const Column *tag : tags) values.emplace_back(tag->view_value(row));
+        return values;
+    };
+    int64_t start = 0;
+    std::vector<std::string> current_tags = tags_of(order[0]);
+    for (int64_t i = 1; i <= n; i++) {
+        bool boundary = i == n;
+        if (!boundary) {
+            for (size_t t = 0; t < tags.size(); t++)
+                if (tags[t]->view_value(order[static_cast<size_t>(i)]) != current_tags[t]) boundary = true;
+        }
+        if (boundary) {
+            series.push_back({start, i, current_tags});
+            if (i < n) {
+                start = i;
+                current_tags = tags_of(order[static_cast<size_t>(i)]);
+            }
+        }
+    }
+
+    // Every series x field is one chunk of a single launch.
+    const size_t n_fields = metadata.field_column_indices.size();
+    std::vector<int64_t> chunk_ts;
+    std::vector<float> chunk_values;
+    std::vector<uint64_t> offsets = {0};
+    chunk_ts.reserve(static_cast<size_t>(n) * n_fields);
+    chunk_values.reserve(static_cast<size_t>(n) * n_fields);
+    // Chunks with different error bounds need separate calls; group fields by bound.
+    std::vector<RecordBatch> result(series.size() * n_fields);
+    for (size_t f = 0; f < n_fields; f++) {
+        const size_t field_index = metadata.field_column_indices[f];
+        const float *values = batch.columns[field_index]->as<float>();
+        chunk_ts.clear();
+        chunk_values.clear();
+        offsets.assign(1, 0);
+        for (const Series &s : series) {
+            for (int64_t i = s.first; i < s.last; i++) {
+                chunk_ts.push_back(ts[order[static_cast<size_t>(i)]]);
+                chunk_values.push_back(values[order[static_cast<size_t>(i)]]);
+            }
+            offsets.push_back(chunk_ts.size());
+        }
+        OwnedGuard guard;
+        check(mdb_compress_chunks(ctx, chunk_ts.data(), chunk_values.data(), offsets.data(), series.size(),
+                                  metadata.error_bounds[field_index].c, &guard.owned));
+        // Segments come back grouped by chunk, in chunk order.
+        uint64_t row = 0;
+        const uint64_t total = guard.owned->seg.n;
+        for (size_t s = 0; s < series.size(); s++) {
+            uint64_t first = row;
+            while (row < total && guard.owned->chunk_index[row] == s) row++;
+            result[s * n_fields + f] = record_batch_from_owned(guard.owned, first, row, metadata.compressed_schema,
+                                                               series[s].tag_values,
+                                                               static_cast<int16_t>(field_index));
+        }
+    }
+    return result;
+}
+
+} // namespace mdbhost
+
+// =================================================================================================
+// C surface for tests and non-C++ callers. 0 = ok, 1 = error (message via mdbh_last_error()).
+// =================================================================================================
+
+namespace {
+thread_local std::string g_host_error;
+
+template <typename F> int guarded(F &&body) {
+    try {
+        body();
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_error = e.what();
+        return 1;
+    }
+}
+
+struct GridHandle {
+    std::shared_ptr<mdbhost::QueueExec> input;
+    std::shared_ptr<mdbhost::GridExec> exec;
+    std::unique_ptr<mdbhost::GridStream> stream;
+};
+} // namespace
+
+extern "C" {
+
+const char *mdbh_last_error(void) { return g_host_error.c_str(); }
+
+int mdbh_grid_exec_create(mdb_ctx *ctx, const char *const *tag_names, int32_t n_tags, int64_t limit,
+                          int32_t has_lower, int64_t lower, int32_t has_upper, int64_t upper,
+                          uint64_t batch_size, void **out) {
+    return guarded([&] {
+        using namespace mdbhost;
+        std::vector<std::string> tags(tag_names, tag_names + n_tags);
+        std::vector<Field> input_schema = query_compressed_schema();
+        for (const std::string &tag : tags) input_schema.push_back({tag, Type::Utf8View});
+        auto handle = std::make_unique<GridHandle>();
+        handle->input = std::make_shared<QueueExec>(input_schema);
+        std::optional<TimestampPredicate> predicate;
+        if (has_lower || has_upper) {
+            predicate = TimestampPredicate{};
+            if (has_lower) predicate->lower = lower;
+            if (has_upper) predicate->upper = upper;
+        }
+        handle->exec = GridExec::make(ctx, grid_schema(tags), predicate,
+                                      limit >= 0 ? std::optional<size_t>(static_cast<size_t>(limit)) : std::nullopt,
+                                      handle->input);
+        handle->stream = handle->exec->execute(0, batch_size);
+        *out = handle.release();
+    });
+}
+
+int mdbh_grid_stream_push(void *handle, ArrowArray *array, ArrowSchema *schema) {
+    return guarded([&] { static_cast<GridHandle *>(handle)->input->push(mdbhost::import_record_batch(array, schema)); });
+}
+
+int mdbh_grid_stream_finish_input(void *handle) {
+    return guarded([&] { static_cast<GridHandle *>(handle)->input->finish(); });
+}
+
+/* state: 0 = Ready(Some(batch)) (out filled), 1 = Ready(None), 2 = Pending */
+int mdbh_grid_stream_poll_next(void *handle, ArrowArray *out_array, ArrowSchema *out_schema, int32_t *state) {
+    return guarded([&] {
+        mdbhost::RecordBatch batch;
+        mdbhost::PollState poll = static_cast<GridHandle *>(handle)->stream->poll_next(&batch);
+        *state = poll == mdbhost::PollState::ReadySome ? 0 : (poll == mdbhost::PollState::ReadyNone ? 1 : 2);
+        if (poll == mdbhost::PollState::ReadySome) mdbhost::export_record_batch(batch, out_array, out_schema);
+    });
+}
+
+/* out[12]: rows_created, by type x3, segments_with_residuals, segments by type x3, regular,
+ * irregular, output_rows, elapsed_compute_ns */
+int mdbh_grid_stream_metrics(void *handle, uint64_t *out) {
+    return guarded([&] {
+        const mdbhost::GridStreamMetrics &m = *static_cast<GridHandle *>(handle)->exec->metrics();
+        out[0] = m.rows_created;
+        for (int k = 0; k < 3; k++) out[1 + k] = m.rows_created_by_model_type[k];
+        out[4] = m.segments_with_residuals;
+        for (int k = 0; k < 3; k++) out[5 + k] = m.segments_with_model_type[k];
+        out[8] = m.segments_regular;
+        out[9] = m.segments_irregular;
+        out[10] = m.output_rows;
+        out[11] = m.elapsed_compute_ns;
+    });
+}
+
+int mdbh_grid_exec_describe(void *handle, char *out, uint64_t cap) {
+    return guarded([&] {
+        GridHandle *h = static_cast<GridHandle *>(handle);
+        std::string text = std::string(h->exec->name()) + "|" + h->exec->fmt_as() + "|children=" +
+                           std::to_string(h->exec->children().size()) + "|batch_size=" +
+                           std::to_string(h->stream->batch_size()) + "|distribution=" +
+                           (h->exec->required_input_distribution()[0] == mdbhost::Distribution::SinglePartition
+                                ? "SinglePartition" : "Unspecified");
+        try {
+            h->exec->with_new_children({});
+        } catch (const mdbhost::Error &e) {
+            text += std::string("|with_new_children([])=Err(") + e.what() + ")";
+        }
+        std::strncpy(out, text.c_str(), cap - 1);
+        out[cap - 1] = 0;
+    });
+}
+
+void mdbh_grid_stream_free(void *handle) { delete static_cast<GridHandle *>(handle); }
+
+/* kind: 0 count, 1 min, 2 max, 3 sum, 4 avg */
+int mdbh_accumulator_create(mdb_ctx *ctx, int32_t kind, void **out) {
+    return guarded([&] {
+        std::unique_ptr<mdbhost::Accumulator> acc;
+        switch (kind) {
+        case 0: acc = mdbhost::make_model_count_accumulator(ctx); break;
+        case 1: acc = mdbhost::make_model_min_accumulator(ctx); break;
+        case 2: acc = mdbhost::make_model_max_accumulator(ctx); break;
+        case 3: acc = mdbhost::make_model_sum_accumulator(ctx); break;
+        case 4: acc = mdbhost::make_model_avg_accumulator(ctx); break;
+        default: throw mdbhost::Error("Aggregate expression is not supported.");
+        }
+        *out = acc.release();
+    });
+}
+
+int mdbh_accumulator_update_batch(void *acc, ArrowArray *array, ArrowSchema *schema) {
+    return guarded([&] {
+        mdbhost::RecordBatch batch = mdbhost::import_record_batch(array, schema);
+        static_cast<mdbhost::Accumulator *>(acc)->update_batch(batch.columns);
+    });
+}
+
+/* Writes up to two state values: kinds[i] (0 i64, 1 u64, 2 f32, 3 f64) and the value as f64 /
+ * i64 bit patterns in values_f64 / values_i64. Returns how many via n_values. */
+int mdbh_accumulator_state(void *acc, int32_t *kinds, double *values_f64, int64_t *values_i64, int32_t *n_values) {
+    return guarded([&] {
+        auto state = static_cast<mdbhost::Accumulator *>(acc)->state();
+        *n_values = static_cast<int32_t>(state.size());
+        for (size_t i = 0; i < state.size(); i++) {
+            kinds[i] = static_cast<int32_t>(state[i].kind);
+            switch (state[i].kind) {
+            case mdbhost::ScalarValue::Kind::Int64: values_i64[i] = state[i].i64; values_f64[i] = 0; break;
+            case mdbhost::ScalarValue::Kind::UInt64: values_i64[i] = static_cast<int64_t>(state[i].u64); values_f64[i] = 0; break;
+            case mdbhost::ScalarValue::Kind::Float32: values_f64[i] = state[i].f32; values_i64[i] = 0; break;
+            case mdbhost::ScalarValue::Kind::Float64: values_f64[i] = state[i].f64; values_i64[i] = 0; break;
+            }
+        }
+    });
+}
+
+int mdbh_accumulator_unreachable(void *acc, int32_t which) {
+    return guarded([&] {
+        if (which == 0) static_cast<mdbhost::Accumulator *>(acc)->merge_batch({});
+        else static_cast<mdbhost::Accumulator *>(acc)->evaluate();
+    });
+}
+
+uint64_t mdbh_accumulator_size(void *acc) { return static_cast<mdbhost::Accumulator *>(acc)->size(); }
+void mdbh_accumulator_free(void *acc) { delete static_cast<mdbhost::Accumulator *>(acc); }
+
+int mdbh_try_compress_univariate_time_series(mdb_ctx *ctx, ArrowArray *ts_array, ArrowSchema *ts_schema,
+                                             ArrowArray *values_array, ArrowSchema *values_schema,
+                                             mdb_error_bound error_bound, const char *const *tag_names,
+                                             const char *const *tag_values, int32_t n_tags,
+                                             int16_t field_column_index, ArrowArray *out_array,
+                                             ArrowSchema *out_schema) {
+    return guarded([&] {
+        using namespace mdbhost;
+        ColumnPtr ts = import_array(ts_array, ts_schema);
+        ColumnPtr values = import_array(values_array, values_schema);
+        std::vector<std::string> names(tag_names, tag_names + n_tags), tag_vals(tag_values, tag_values + n_tags);
+        ErrorBound eb;
+        if (error_bound.kind == MDB_EB_ABSOLUTE) eb = ErrorBound::try_new_absolute(error_bound.value);
+        else if (error_bound.kind == MDB_EB_RELATIVE) eb = ErrorBound::try_new_relative(error_bound.value);
+        RecordBatch batch = try_compress_univariate_time_series(ctx, *ts, *values, eb, compressed_schema(names),
+                                                                tag_vals, field_column_index);
+        export_record_batch(batch, out_array, out_schema);
+    });
+}
+
+/* Compresses a multivariate batch; the resulting RecordBatches are kept in a handle and fetched
+ * one by one. error_bounds has one entry per COLUMN of the input batch (ignored for non-fields). */
+int mdbh_try_compress_multivariate_time_series(mdb_ctx *ctx, ArrowArray *array, ArrowSchema *schema,
+                                               int32_t timestamp_column, const int32_t *field_columns,
+                                               int32_t n_fields, const int32_t *tag_columns, int32_t n_tags,
+                                               const mdb_error_bound *error_bounds, void **out_handle,
+                                               int32_t *n_batches) {
+    return guarded([&] {
+        using namespace mdbhost;
+        RecordBatch batch = import_record_batch(array, schema);
+        TimeSeriesTableMetadata metadata;
+        metadata.timestamp_column_index = static_cast<size_t>(timestamp_column);
+        std::vector<std::string> tag_names;
+        for (int32_t i = 0; i < n_fields; i++) metadata.field_column_indices.push_back(static_cast<size_t>(field_columns[i]));
+        for (int32_t i = 0; i < n_tags; i++) {
+            metadata.tag_column_indices.push_back(static_cast<size_t>(tag_columns[i]));
+            tag_names.push_back(batch.schema[static_cast<size_t>(tag_columns[i])].name);
+        }
+        for (size_t c = 0; c < batch.columns.size(); c++) {
+            ErrorBound eb;
+            eb.c = error_bounds[c];
+            metadata.error_bounds.push_back(eb);
+        }
+        metadata.compressed_schema = compressed_schema(tag_names);
+        auto *result = new std::vector<RecordBatch>(try_compress_multivariate_time_series(ctx, metadata, batch));
+        *out_handle = result;
+        *n_batches = static_cast<int32_t>(result->size());
+    });
+}
+
+int mdbh_batches_get(void *handle, int32_t index, ArrowArray *out_array, ArrowSchema *out_schema) {
+    return guarded([&] {
+        auto *batches = static_cast<std::vector<mdbhost::RecordBatch> *>(handle);
+        mdbhost::export_record_batch(batches->at(static_cast<size_t>(index)), out_array, out_schema);
+    });
+}
+
+void mdbh_batches_free(void *handle) { delete static_cast<std::vector<mdbhost::RecordBatch> *>(handle); }
+
+} // extern "C"

@@ -1,0 +1,262 @@
+// mdb_host.hpp - host-side operators above the C ABI, written in C++ because the reference's host
+// code is compiled Rust and no Rust toolchain exists in this image. They mirror the reference's
+// operator interface for the hot path - same names, argument meaning and error behaviour - so a
+// maintainer can map each class 1:1 onto the Rust type it stands in for:
+//
+//   GridExec / GridStream / GridStreamMetrics   crates/modelardb_storage/src/query/grid_exec.rs:56-519
+//   Model{Count,Min,Max,Sum,Avg}Accumulator     crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:336-618
+//   try_compress_univariate_time_series         crates/modelardb_compression/src/compression.rs:191-275
+//   try_compress_multivariate_time_series       crates/modelardb_compression/src/compression.rs:42-179
+//
+// RecordBatches are exchanged through the Arrow C Data Interface. All model arithmetic happens in
+// libmdb_hip.so; this layer only moves columns, replicates tags, filters and re-batches.
+#pragma once
+
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/mdb.h"
+#include "arrow_c_abi.h"
+
+namespace mdbhost {
+
+// Error type: what the Rust code would return as Err(...) (DataFusionError / ModelarDbCompressionError).
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---- columns and batches ---------------------------------------------------------------------------------
+
+enum class Type { Int8, Int16, Int64, Timestamp, Float32, Float64, UInt64, BinaryView, Utf8View };
+
+struct Field {
+    std::string name;
+    Type type;
+};
+
+// One column. Primitive data lives in `data`; view types use `data` for the 16-byte views and
+// `buffers` for the variadic data buffers. Imported columns may instead point into foreign memory
+// kept alive by `keep_alive`.
+struct Column {
+    Type type = Type::Int8;
+    int64_t length = 0;
+    const void *values = nullptr;                 // primitive values or views
+    std::vector<const uint8_t *> buffer_ptrs;     // view types: variadic buffers
+    std::vector<int64_t> buffer_sizes;
+    std::vector<uint8_t> data;                    // owned storage (may be empty when imported)
+    std::vector<std::vector<uint8_t>> owned_buffers;
+    std::shared_ptr<void> keep_alive;
+
+    template <typename T> const T *as() const { return static_cast<const T *>(values); }
+    std::string_view view_value(int64_t i) const; // bytes of row i of a view column
+};
+using ColumnPtr = std::shared_ptr<Column>;
+
+struct RecordBatch {
+    std::vector<Field> schema;
+    std::vector<ColumnPtr> columns;
+    int64_t num_rows = 0;
+
+    static RecordBatch new_empty(const std::vector<Field> &schema);
+    RecordBatch slice(int64_t offset, int64_t length) const;
+};
+
+// Arrow C Data Interface. import takes ownership of *array and *schema (moves them).
+RecordBatch import_record_batch(ArrowArray *array, ArrowSchema *schema);
+ColumnPtr import_array(ArrowArray *array, ArrowSchema *schema);
+void export_record_batch(const RecordBatch &batch, ArrowArray *out_array, ArrowSchema *out_schema);
+
+ColumnPtr make_primitive_column(Type type, const void *values, int64_t length);
+ColumnPtr make_view_column(Type type, const std::vector<std::string_view> &rows);
+
+// ---- schemas (crates/modelardb_types/src/schemas.rs:31-72) -------------------------------------------------
+
+std::vector<Field> query_compressed_schema();                                       // 9 columns
+std::vector<Field> compressed_schema(const std::vector<std::string> &tag_names);    // + field_column + tags
+std::vector<Field> grid_schema(const std::vector<std::string> &tag_names);          // timestamp, value, tags
+
+// ErrorBound (crates/modelardb_types/src/types.rs:299-335). The constructors throw Error like
+// try_new_absolute / try_new_relative return Err.
+struct ErrorBound {
+    mdb_error_bound c{MDB_EB_LOSSLESS, 0.0f};
+    static ErrorBound lossless() { return {}; }
+    static ErrorBound try_new_absolute(float value);
+    static ErrorBound try_new_relative(float percentage);
+};
+
+// ---- the input of GridExec: any stream of segment batches ---------------------------------------------------
+
+enum class PollState { ReadySome, ReadyNone, Pending };
+
+struct SegmentStream { // SendableRecordBatchStream of the child plan
+    virtual ~SegmentStream() = default;
+    virtual PollState poll_next(RecordBatch *out) = 0;
+};
+
+struct ExecutionPlan { // the slice of datafusion's ExecutionPlan that GridExec touches
+    virtual ~ExecutionPlan() = default;
+    virtual const char *name() const = 0;
+    virtual std::vector<Field> schema() const = 0;
+    virtual std::vector<std::shared_ptr<ExecutionPlan>> children() const = 0;
+    virtual std::unique_ptr<SegmentStream> execute_segments(size_t partition) = 0;
+};
+
+// A child plan fed by hand: batches are pushed, then the input is finished (used by tests and by
+// the C API; in the reference the child is DataSourceExec over Parquet).
+class QueueExec : public ExecutionPlan {
+  public:
+    explicit QueueExec(std::vector<Field> schema) : schema_(std::move(schema)) {}
+    const char *name() const override { return "QueueExec"; }
+    std::vector<Field> schema() const override { return schema_; }
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {}; }
+    std::unique_ptr<SegmentStream> execute_segments(size_t partition) override;
+    void push(RecordBatch batch) { state_->queue.push_back(std::move(batch)); }
+    void finish() { state_->finished = true; }
+
+    struct State {
+        std::deque<RecordBatch> queue;
+        bool finished = false;
+    };
+
+  private:
+    std::vector<Field> schema_;
+    std::shared_ptr<State> state_ = std::make_shared<State>();
+};
+
+// ---- GridExec ------------------------------------------------------------------------------------------------
+
+// The only predicate TimeSeriesTable::scan pushes into GridExec is a range on `timestamp`
+// (query/time_series_table.rs:269-373); it is evaluated after reconstruction (grid_exec.rs:366-387).
+struct TimestampPredicate {
+    std::optional<int64_t> lower; // inclusive
+    std::optional<int64_t> upper; // inclusive
+    bool matches(int64_t t) const { return (!lower || t >= *lower) && (!upper || t <= *upper); }
+};
+
+struct GridStreamMetrics { // grid_exec.rs:441-518 (+ BaselineMetrics' output_rows / elapsed_compute)
+    uint64_t rows_created = 0;
+    uint64_t rows_created_by_model_type[MDB_MODEL_TYPE_COUNT] = {0, 0, 0};
+    uint64_t segments_with_residuals = 0;
+    uint64_t segments_with_model_type[MDB_MODEL_TYPE_COUNT] = {0, 0, 0};
+    uint64_t segments_regular = 0;
+    uint64_t segments_irregular = 0;
+    uint64_t output_rows = 0;
+    uint64_t elapsed_compute_ns = 0;
+    void add(const mdb_grid_metrics &m);
+};
+
+enum class Distribution { UnspecifiedDistribution, SinglePartition };
+
+class GridStream;
+
+class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridExec> {
+  public:
+    // GridExec::new (grid_exec.rs:76-109). `schema` is the grid schema (timestamp, value, tags...).
+    static std::shared_ptr<GridExec> make(mdb_ctx *ctx, std::vector<Field> schema,
+                                          std::optional<TimestampPredicate> maybe_predicate,
+                                          std::optional<size_t> limit,
+                                          std::shared_ptr<ExecutionPlan> input);
+    const char *name() const override { return "GridExec"; }
+    std::vector<Field> schema() const override { return schema_; }
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {input_}; }
+    // Err(Plan("Exactly one child must be provided")) unless children.size() == 1 (:142-160).
+    std::shared_ptr<GridExec> with_new_children(std::vector<std::shared_ptr<ExecutionPlan>> children) const;
+    // execute(partition, task_context): batch_size comes from the session config (:165-182).
+    std::unique_ptr<GridStream> execute(size_t partition, size_t batch_size);
+    std::unique_ptr<SegmentStream> execute_segments(size_t) override {
+        throw Error("GridExec produces data points, not segments.");
+    }
+    std::vector<Distribution> required_input_distribution() const { return {Distribution::SinglePartition}; }
+    std::string fmt_as() const; // "GridExec: limit=Some(5)" (:203-209)
+    std::shared_ptr<GridStreamMetrics> metrics() const { return metrics_; }
+    std::optional<size_t> limit() const { return limit_; }
+
+  private:
+    mdb_ctx *ctx_ = nullptr;
+    std::vector<Field> schema_;
+    std::optional<TimestampPredicate> maybe_predicate_;
+    std::optional<size_t> limit_;
+    std::shared_ptr<ExecutionPlan> input_;
+    std::shared_ptr<GridStreamMetrics> metrics_ = std::make_shared<GridStreamMetrics>();
+};
+
+class GridStream { // grid_exec.rs:213-437
+  public:
+    GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<TimestampPredicate> maybe_predicate,
+               std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
+               std::shared_ptr<GridStreamMetrics> metrics);
+    // Stream::poll_next (:402-429)
+    PollState poll_next(RecordBatch *out);
+    std::vector<Field> schema() const { return schema_; }
+    size_t batch_size() const { return batch_size_; }
+
+  private:
+    void grid_and_append_to_leftovers_in_current_batch(const RecordBatch &batch); // :261-391
+    mdb_ctx *ctx_;
+    std::vector<Field> schema_;
+    std::optional<TimestampPredicate> maybe_predicate_;
+    std::unique_ptr<SegmentStream> input_;
+    size_t batch_size_;
+    RecordBatch current_batch_;
+    int64_t current_batch_offset_ = 0;
+    std::shared_ptr<GridStreamMetrics> metrics_;
+};
+
+// ---- accumulators (model_simple_aggregates.rs:336-618) -------------------------------------------------------
+
+// ScalarValue of the accumulator state handed to DataFusion's Final aggregate.
+struct ScalarValue {
+    enum class Kind { Int64, UInt64, Float32, Float64 } kind;
+    int64_t i64 = 0;
+    uint64_t u64 = 0;
+    float f32 = 0.0f;
+    double f64 = 0.0;
+};
+
+class Accumulator {
+  public:
+    virtual ~Accumulator() = default;
+    // `arrays` are the columns of a segment batch in QUERY_COMPRESSED_SCHEMA order (at least 0..=7).
+    virtual void update_batch(const std::vector<ColumnPtr> &arrays) = 0;
+    virtual std::vector<ScalarValue> state() = 0; // also resets, like the reference
+    virtual size_t size() const = 0;
+    void merge_batch(const std::vector<ColumnPtr> &) { throw std::logic_error("unreachable"); }
+    ScalarValue evaluate() { throw std::logic_error("unreachable"); }
+};
+
+std::unique_ptr<Accumulator> make_model_count_accumulator(mdb_ctx *ctx);
+std::unique_ptr<Accumulator> make_model_min_accumulator(mdb_ctx *ctx);
+std::unique_ptr<Accumulator> make_model_max_accumulator(mdb_ctx *ctx);
+std::unique_ptr<Accumulator> make_model_sum_accumulator(mdb_ctx *ctx);
+std::unique_ptr<Accumulator> make_model_avg_accumulator(mdb_ctx *ctx);
+
+// ---- compression (compression.rs:42-275) -----------------------------------------------------------------------
+
+RecordBatch try_compress_univariate_time_series(mdb_ctx *ctx, const Column &uncompressed_timestamps,
+                                                const Column &uncompressed_values, ErrorBound error_bound,
+                                                const std::vector<Field> &compressed_schema,
+                                                const std::vector<std::string> &tag_values,
+                                                int16_t field_column_index);
+
+struct TimeSeriesTableMetadata { // the fields of types.rs:76-239 that compression reads
+    size_t timestamp_column_index = 0;
+    std::vector<size_t> field_column_indices;
+    std::vector<size_t> tag_column_indices;
+    std::vector<ErrorBound> error_bounds; // indexed by column index, like the reference
+    std::vector<Field> compressed_schema;
+};
+
+// Sorts by (tags..., timestamp), splits into series and compresses every field column of every
+// series - all series x fields of the batch go to the GPU as ONE mdb_compress_chunks call. Returns
+// one RecordBatch per series x field in the reference's order.
+std::vector<RecordBatch> try_compress_multivariate_time_series(mdb_ctx *ctx,
+                                                               const TimeSeriesTableMetadata &metadata,
+                                                               const RecordBatch &uncompressed_time_series);
+
+} // namespace mdbhost

@@ -1,0 +1,243 @@
+"""Python face of the C++ host operators (modelardb-rs_amd/csrc/host, libmdb_host.so): GridExec /
+GridStream, the five Model*Accumulators and try_compress_*. RecordBatches cross as pyarrow objects
+through the Arrow C Data Interface; the operators themselves are C++ and call libmdb_hip.so."""
+
+import ctypes as C
+import os
+
+import pyarrow as pa
+
+from . import _abi
+
+HOST_LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "host",
+                                 "libmdb_host.so")
+
+
+class ArrowSchemaC(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p),
+                ("flags", C.c_int64), ("n_children", C.c_int64), ("children", C.c_void_p),
+                ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowArrayC(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64),
+                ("n_buffers", C.c_int64), ("n_children", C.c_int64), ("buffers", C.c_void_p),
+                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p),
+                ("private_data", C.c_void_p)]
+
+
+class HostError(RuntimeError):
+    """Err(...) of the Rust operator this call stands in for."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _abi.load_hip_library()  # RTLD_GLOBAL: resolves libmdb_host's dependency
+        if not os.path.exists(HOST_LIBRARY_PATH):
+            raise RuntimeError(f"{HOST_LIBRARY_PATH} is missing: run __graft_entry__.build().")
+        _lib = C.CDLL(HOST_LIBRARY_PATH)
+        _lib.mdbh_last_error.restype = C.c_char_p
+        _lib.mdbh_accumulator_size.restype = C.c_uint64
+        _lib.mdbh_grid_stream_free.restype = None
+        _lib.mdbh_accumulator_free.restype = None
+        _lib.mdbh_batches_free.restype = None
+    return _lib
+
+
+def _check(code):
+    if code != 0:
+        raise HostError(lib().mdbh_last_error().decode())
+
+
+def _export(obj):
+    """pyarrow Array / RecordBatch -> (ArrowArrayC, ArrowSchemaC) owned by the caller."""
+    array, schema = ArrowArrayC(), ArrowSchemaC()
+    obj._export_to_c(C.addressof(array), C.addressof(schema))
+    return array, schema
+
+
+def _import_batch(array, schema):
+    return pa.RecordBatch._import_from_c(C.addressof(array), C.addressof(schema))
+
+
+def _strings(values):
+    encoded = [v.encode() for v in values]
+    return (C.c_char_p * max(len(encoded), 1))(*encoded), encoded
+
+
+MODEL_SEGMENT_COLUMNS = ("model_type_id", "start_time", "end_time", "timestamps", "min_value",
+                         "max_value", "values", "residuals", "error")
+
+
+def segments_with_tags(batch, tags):
+    """Append Utf8View tag columns to a segment RecordBatch: what DataSourceExec hands GridExec."""
+    arrays = [batch.column(i) for i in range(batch.num_columns)]
+    names = list(batch.schema.names)
+    for name, value in tags.items():
+        arrays.append(pa.array([value] * batch.num_rows, type=pa.string_view()))
+        names.append(name)
+    return pa.RecordBatch.from_arrays(arrays, names=names)
+
+
+class GridStream:
+    """GridExec::execute(...) of crates/modelardb_storage/src/query/grid_exec.rs, fed by hand."""
+
+    READY_SOME, READY_NONE, PENDING = 0, 1, 2
+
+    def __init__(self, context, tag_names=(), limit=None, predicate=(None, None), batch_size=8192):
+        self._context = context
+        self.handle = C.c_void_p()
+        names, self._keep = _strings(tag_names)
+        lower, upper = predicate
+        _check(lib().mdbh_grid_exec_create(
+            context.handle, names, C.c_int32(len(tag_names)), C.c_int64(-1 if limit is None else limit),
+            C.c_int32(lower is not None), C.c_int64(lower or 0), C.c_int32(upper is not None),
+            C.c_int64(upper or 0), C.c_uint64(batch_size), C.byref(self.handle)))
+
+    def push(self, batch):
+        array, schema = _export(batch)
+        _check(lib().mdbh_grid_stream_push(self.handle, C.byref(array), C.byref(schema)))
+
+    def finish_input(self):
+        _check(lib().mdbh_grid_stream_finish_input(self.handle))
+
+    def poll_next(self):
+        """Returns (state, RecordBatch or None)."""
+        array, schema, state = ArrowArrayC(), ArrowSchemaC(), C.c_int32()
+        _check(lib().mdbh_grid_stream_poll_next(self.handle, C.byref(array), C.byref(schema),
+                                                C.byref(state)))
+        if state.value == self.READY_SOME:
+            return state.value, _import_batch(array, schema)
+        return state.value, None
+
+    def collect(self):
+        batches = []
+        while True:
+            state, batch = self.poll_next()
+            if state != self.READY_SOME:
+                return batches, state
+            batches.append(batch)
+
+    def metrics(self):
+        out = (C.c_uint64 * 12)()
+        _check(lib().mdbh_grid_stream_metrics(self.handle, out))
+        names = ["rows_created"] + [f"rows_created_by_{n}" for n in _abi.MODEL_TYPE_NAMES]
+        names += ["segments_with_residuals"] + [f"segments_with_{n}" for n in _abi.MODEL_TYPE_NAMES]
+        names += ["regular_segments", "irregular_segments", "output_rows", "elapsed_compute_ns"]
+        return dict(zip(names, out))
+
+    def describe(self):
+        out = C.create_string_buffer(1024)
+        _check(lib().mdbh_grid_exec_describe(self.handle, out, C.c_uint64(1024)))
+        return out.value.decode()
+
+    def close(self):
+        if self.handle:
+            lib().mdbh_grid_stream_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _ModelAccumulator:
+    KIND = None
+
+    def __init__(self, context):
+        self.handle = C.c_void_p()
+        _check(lib().mdbh_accumulator_create(context.handle, C.c_int32(self.KIND), C.byref(self.handle)))
+
+    def update_batch(self, batch):
+        array, schema = _export(batch)
+        _check(lib().mdbh_accumulator_update_batch(self.handle, C.byref(array), C.byref(schema)))
+
+    def state(self):
+        kinds, f64, i64 = (C.c_int32 * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
+        n = C.c_int32()
+        _check(lib().mdbh_accumulator_state(self.handle, kinds, f64, i64, C.byref(n)))
+        return [i64[k] if kinds[k] in (0, 1) else f64[k] for k in range(n.value)]
+
+    def size(self):
+        return lib().mdbh_accumulator_size(self.handle)
+
+    def merge_batch(self):
+        _check(lib().mdbh_accumulator_unreachable(self.handle, C.c_int32(0)))
+
+    def evaluate(self):
+        _check(lib().mdbh_accumulator_unreachable(self.handle, C.c_int32(1)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().mdbh_accumulator_free(self.handle)
+        except Exception:
+            pass
+
+
+class ModelCountAccumulator(_ModelAccumulator):
+    KIND = 0
+
+
+class ModelMinAccumulator(_ModelAccumulator):
+    KIND = 1
+
+
+class ModelMaxAccumulator(_ModelAccumulator):
+    KIND = 2
+
+
+class ModelSumAccumulator(_ModelAccumulator):
+    KIND = 3
+
+
+class ModelAvgAccumulator(_ModelAccumulator):
+    KIND = 4
+
+
+def try_compress_univariate_time_series(context, uncompressed_timestamps, uncompressed_values,
+                                        error_bound, tags, field_column_index):
+    """compression.rs:191-275. `tags` is an ordered {tag column name: tag value} mapping."""
+    ts = pa.array(uncompressed_timestamps, type=pa.int64()).cast(pa.timestamp("us"))
+    values = pa.array(uncompressed_values, type=pa.float32())
+    ts_c, values_c = _export(ts), _export(values)
+    names, keep_names = _strings(list(tags.keys()))
+    vals, keep_values = _strings(list(tags.values()))
+    out_array, out_schema = ArrowArrayC(), ArrowSchemaC()
+    _check(lib().mdbh_try_compress_univariate_time_series(
+        context.handle, C.byref(ts_c[0]), C.byref(ts_c[1]), C.byref(values_c[0]), C.byref(values_c[1]),
+        error_bound, names, vals, C.c_int32(len(tags)), C.c_int16(field_column_index),
+        C.byref(out_array), C.byref(out_schema)))
+    return _import_batch(out_array, out_schema)
+
+
+def try_compress_multivariate_time_series(context, batch, timestamp_column, field_columns,
+                                          tag_columns, error_bounds):
+    """compression.rs:42-179. `error_bounds` maps field column index -> ErrorBound."""
+    array, schema = _export(batch)
+    bounds = (_abi.ErrorBoundC * batch.num_columns)()
+    for index in range(batch.num_columns):
+        bounds[index] = error_bounds.get(index, _abi.ErrorBoundC(_abi.MDB_EB_LOSSLESS, 0.0))
+    fields = (C.c_int32 * len(field_columns))(*field_columns)
+    tags = (C.c_int32 * max(len(tag_columns), 1))(*tag_columns)
+    handle, n = C.c_void_p(), C.c_int32()
+    _check(lib().mdbh_try_compress_multivariate_time_series(
+        context.handle, C.byref(array), C.byref(schema), C.c_int32(timestamp_column), fields,
+        C.c_int32(len(field_columns)), tags, C.c_int32(len(tag_columns)), bounds, C.byref(handle),
+        C.byref(n)))
+    try:
+        out = []
+        for index in range(n.value):
+            out_array, out_schema = ArrowArrayC(), ArrowSchemaC()
+            _check(lib().mdbh_batches_get(handle, C.c_int32(index), C.byref(out_array),
+                                          C.byref(out_schema)))
+            out.append(_import_batch(out_array, out_schema))
+        return out
+    finally:
+        lib().mdbh_batches_free(handle)

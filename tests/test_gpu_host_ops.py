@@ -1,0 +1,231 @@
+"""The C++ host operators (GridExec / GridStream, Model*Accumulators, try_compress_*) end to end on
+the GPU, written after the reference's own tests of the same operators:
+crates/modelardb_embedded/src/operations/data_folder.rs:1087-1234 (3-point series, aggregates),
+crates/modelardb_server/tests/integration_test.rs:1128-1246 (segment vs grid aggregates),
+crates/modelardb_compression/src/compression.rs:422-434, 932-978 (compress)."""
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import cases
+import datagen
+import oracle_lib as ora
+import modelardb_rs_amd as mdb
+from modelardb_rs_amd import host
+
+pytestmark = pytest.mark.gpu
+
+
+def _series(seed, length=30_000, irregular=False):
+    eb = cases.error_bounds()["rel5"]
+    timestamps, values = cases.synthetic_series(length, irregular, (1.0, 1.05), seed)
+    return timestamps, values, ora.try_compress_univariate_time_series(timestamps, values, eb)
+
+
+def _segment_batches(batch, tags, rows_per_batch):
+    arrow = host.segments_with_tags(batch.to_arrow(), tags)
+    return [arrow.slice(start, rows_per_batch) for start in range(0, arrow.num_rows, rows_per_batch)]
+
+
+def _concat(batches):
+    table = pa.Table.from_batches(batches)
+    return (table.column("timestamp").cast(pa.int64()).to_numpy(),
+            table.column("value").to_numpy(), table)
+
+
+@pytest.mark.parametrize("batch_size", [8192, 1000])
+def test_grid_stream_reconstructs_two_series_with_tags(hip, batch_size):
+    stream = host.GridStream(hip, tag_names=("tag",), batch_size=batch_size)
+    expected_ts, expected_values, expected_tags = [], [], []
+    total_segments = 0
+    for seed, tag in ((61, "A"), (62, "a-long-tag-value-beyond-12-bytes")):
+        _, _, batch = _series(seed)
+        total_segments += len(batch)
+        for part in _segment_batches(batch, {"tag": tag}, 64):
+            stream.push(part)
+        ts, values, _, _ = ora.grid_batch(batch)
+        expected_ts.append(ts)
+        expected_values.append(values)
+        expected_tags += [tag] * len(ts)
+    stream.finish_input()
+    batches, state = stream.collect()
+    assert state == host.GridStream.READY_NONE
+    assert all(b.num_rows <= batch_size for b in batches)
+    assert all(b.num_rows == batch_size for b in batches[:-1])
+    ts, values, table = _concat(batches)
+    assert table.schema.names == ["timestamp", "value", "tag"]
+    assert np.array_equal(ts, np.concatenate(expected_ts))
+    assert np.array_equal(values.view(np.uint32), np.concatenate(expected_values).view(np.uint32))
+    assert table.column("tag").to_pylist() == expected_tags
+    metrics = stream.metrics()
+    assert metrics["rows_created"] == metrics["output_rows"] == len(ts)
+    assert metrics["regular_segments"] + metrics["irregular_segments"] == total_segments
+    assert metrics["elapsed_compute_ns"] > 0
+
+
+def test_grid_stream_limit_caps_the_batch_size(hip):  # grid_exec.rs:239-246
+    _, _, batch = _series(63)
+    stream = host.GridStream(hip, tag_names=(), limit=5, batch_size=8192)
+    stream.push(batch.to_arrow())
+    stream.finish_input()
+    state, first = stream.poll_next()
+    assert state == host.GridStream.READY_SOME and first.num_rows == 5
+    expected = ora.grid_batch(batch)
+    assert first.column("timestamp").cast(pa.int64()).to_pylist() == expected[0][:5].tolist()
+
+
+def test_grid_stream_predicate_prunes_after_reconstruction(hip):  # grid_exec.rs:366-387
+    timestamps, _, batch = _series(64, irregular=True)
+    lower, upper = int(timestamps[1234]), int(timestamps[20_000])
+    stream = host.GridStream(hip, tag_names=("tag",), predicate=(lower, upper), batch_size=4096)
+    for part in _segment_batches(batch, {"tag": "x"}, 100):
+        stream.push(part)
+    stream.finish_input()
+    batches, _ = stream.collect()
+    ts, values, _ = _concat(batches)
+    all_ts, all_values, _, _ = ora.grid_batch(batch)
+    keep = (all_ts >= lower) & (all_ts <= upper)
+    assert np.array_equal(ts, all_ts[keep])
+    assert np.array_equal(values.view(np.uint32), all_values[keep].view(np.uint32))
+
+
+def test_three_point_series_through_the_operators(hip):
+    # data_folder.rs:1087-1109, 1165-1234: [37,38,39] / [73,72,71] at three timestamps.
+    tags = {"tag": "tag_value"}
+    for values, mn, mx, total in (([37.0, 38.0, 39.0], 37.0, 39.0, 114.0),
+                                  ([73.0, 72.0, 71.0], 71.0, 73.0, 216.0)):
+        segments = host.try_compress_univariate_time_series(hip, [100, 200, 300], values,
+                                                            cases.LOSSLESS, tags, 1)
+        assert segments.schema.names == list(host.MODEL_SEGMENT_COLUMNS) + ["field_column", "tag"]
+        assert segments.column("field_column").to_pylist() == [1] * segments.num_rows
+        assert segments.column("tag").to_pylist() == ["tag_value"] * segments.num_rows
+        query_batch = segments.drop_columns(["field_column"])
+        stream = host.GridStream(hip, tag_names=("tag",))
+        stream.push(query_batch)
+        stream.finish_input()
+        batches, _ = stream.collect()
+        ts, reconstructed, table = _concat(batches)
+        assert ts.tolist() == [100, 200, 300] and reconstructed.tolist() == values
+        assert table.column("tag").to_pylist() == ["tag_value"] * 3
+        results = {}
+        for name, cls in (("count", host.ModelCountAccumulator), ("min", host.ModelMinAccumulator),
+                          ("max", host.ModelMaxAccumulator), ("sum", host.ModelSumAccumulator),
+                          ("avg", host.ModelAvgAccumulator)):
+            accumulator = cls(hip)
+            accumulator.update_batch(query_batch)
+            results[name] = accumulator.state()
+        assert results["count"] == [3] and results["min"] == [mn] and results["max"] == [mx]
+        assert results["sum"] == [total] and results["avg"] == [3, total]
+
+
+def test_accumulators_over_many_batches_and_state_reset(hip):
+    _, _, batch = _series(65)
+    parts = _segment_batches(batch, {}, 97)
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    expected = ora.agg_batch(batch, mask)
+    accumulators = {name: cls(hip) for name, cls in (
+        ("count", host.ModelCountAccumulator), ("min", host.ModelMinAccumulator),
+        ("max", host.ModelMaxAccumulator), ("sum", host.ModelSumAccumulator),
+        ("avg", host.ModelAvgAccumulator))}
+    for part in parts:
+        for accumulator in accumulators.values():
+            accumulator.update_batch(part)
+    assert accumulators["count"].state() == [expected.count]
+    assert accumulators["min"].state() == [expected.min]
+    assert accumulators["max"].state() == [expected.max]
+    total = accumulators["sum"].state()[0]
+    assert abs(total - expected.sum) <= 1e-5 * abs(expected.sum)   # integration_test.rs:1155-1171
+    count, avg_sum = accumulators["avg"].state()
+    assert count == expected.count and abs(avg_sum - expected.sum) <= 1e-5 * abs(expected.sum)
+    # state() leaves the accumulator as created (model_simple_aggregates.rs:367-372, 410-415).
+    assert accumulators["count"].state() == [0]
+    assert accumulators["sum"].state() == [0.0]
+    assert accumulators["min"].state() == [np.finfo(np.float32).max]
+    assert accumulators["max"].state() == [-np.finfo(np.float32).max]
+    assert accumulators["sum"].size() > 0
+    for method in ("merge_batch", "evaluate"):                     # unreachable!() in the reference
+        with pytest.raises(host.HostError, match="unreachable"):
+            getattr(accumulators["sum"], method)()
+
+
+def test_segment_aggregates_equal_grid_aggregates(hip):  # integration_test.rs:1128-1246
+    _, _, batch = _series(66)
+    arrow = batch.to_arrow()
+    stream = host.GridStream(hip, tag_names=())
+    stream.push(arrow)
+    stream.finish_input()
+    batches, _ = stream.collect()
+    _, values, _ = _concat(batches)
+    count = host.ModelCountAccumulator(hip)
+    minimum, maximum, total = (host.ModelMinAccumulator(hip), host.ModelMaxAccumulator(hip),
+                               host.ModelSumAccumulator(hip))
+    for accumulator in (count, minimum, maximum, total):
+        accumulator.update_batch(arrow)
+    assert count.state() == [len(values)]
+    assert minimum.state() == [values.min()] and maximum.state() == [values.max()]
+    grid_sum = float(values.astype(np.float64).sum())
+    assert abs(total.state()[0] - grid_sum) <= 1e-5 * abs(grid_sum)
+
+
+def test_try_compress_univariate_error_behaviour(hip):
+    empty = host.try_compress_univariate_time_series(hip, [], [], cases.LOSSLESS, {"tag": "t"}, 0)
+    assert empty.num_rows == 0                                                        # :422-434
+    assert empty.schema.names == list(host.MODEL_SEGMENT_COLUMNS) + ["field_column", "tag"]
+    with pytest.raises(host.HostError, match="different lengths"):                   # :202-206
+        host.try_compress_univariate_time_series(hip, [1, 2], [1.0], cases.LOSSLESS, {}, 0)
+    with pytest.raises(host.HostError, match="positive finite"):   # ErrorBound::try_new_absolute
+        host.try_compress_univariate_time_series(hip, [1], [1.0], mdb._abi.ErrorBoundC(1, -1.0), {}, 0)
+    with pytest.raises(host.HostError, match="at most 100.0%"):    # ErrorBound::try_new_relative
+        host.try_compress_univariate_time_series(hip, [1], [1.0], mdb._abi.ErrorBoundC(2, 101.0), {}, 0)
+
+
+def test_try_compress_univariate_known_segment(hip):  # compression.rs:932-978
+    segments = host.try_compress_univariate_time_series(
+        hip, [100, 200, 300, 400, 500], [73.0, 37.0, 37.0, 37.0, 73.0], cases.LOSSLESS, {"tag": "tag"}, 0)
+    assert segments.num_rows == 1
+    row = {name: segments.column(name)[0].as_py() for name in segments.schema.names}
+    assert row["model_type_id"] == 2
+    assert segments.column("start_time").cast(pa.int64())[0].as_py() == 100
+    assert segments.column("end_time").cast(pa.int64())[0].as_py() == 500
+    assert row["timestamps"] == bytes([5]) and (row["min_value"], row["max_value"]) == (37.0, 73.0)
+    assert len(row["values"]) == 8 and row["residuals"] == b"" and np.isnan(row["error"])
+
+
+def test_try_compress_multivariate_sorts_splits_and_compresses(hip):  # compression.rs:42-179
+    rng = np.random.default_rng(71)
+    n = 4000
+    series = {("A", "x"): 81, ("B", "a-long-tag-value-beyond-12-bytes"): 82, ("A", "y"): 83}
+    columns = {"timestamp": [], "field_1": [], "field_2": [], "tag_1": [], "tag_2": []}
+    per_series = {}
+    for (tag_1, tag_2), seed in series.items():
+        ts, v1 = cases.synthetic_series(n, False, (1.0, 1.05), seed)
+        _, v2 = datagen.sine_series(seed, n)
+        per_series[(tag_1, tag_2)] = (ts, v1, v2)
+        columns["timestamp"].append(ts)
+        columns["field_1"].append(v1)
+        columns["field_2"].append(v2)
+        columns["tag_1"] += [tag_1] * n
+        columns["tag_2"] += [tag_2] * n
+    order = rng.permutation(3 * n)                                       # unsorted ingest order
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(np.concatenate(columns["timestamp"])[order], type=pa.int64()).cast(pa.timestamp("us")),
+        pa.array(np.concatenate(columns["field_1"])[order], type=pa.float32()),
+        pa.array(np.array(columns["tag_1"])[order], type=pa.string_view()),
+        pa.array(np.concatenate(columns["field_2"])[order], type=pa.float32()),
+        pa.array(np.array(columns["tag_2"])[order], type=pa.string_view()),
+    ], names=["timestamp", "field_1", "tag_1", "field_2", "tag_2"])
+    bounds = {1: mdb.error_bound("relative", 5.0), 3: mdb.error_bound("lossless")}
+    out = host.try_compress_multivariate_time_series(hip, batch, 0, [1, 3], [2, 4], bounds)
+    assert len(out) == len(series) * 2
+    expected_order = sorted(series)                                       # lexsort by tags
+    for s, key in enumerate(expected_order):
+        ts, v1, v2 = per_series[key]
+        for f, (field_index, values) in enumerate(((1, v1), (3, v2))):
+            got = out[s * 2 + f]
+            assert got.column("field_column").to_pylist() == [field_index] * got.num_rows
+            assert got.column("tag_1").to_pylist() == [key[0]] * got.num_rows
+            assert got.column("tag_2").to_pylist() == [key[1]] * got.num_rows
+            expected = ora.try_compress_univariate_time_series(ts, values, bounds[field_index])
+            got_segments = mdb.SegmentBatch.from_arrow(got)
+            assert got_segments.rows() == expected.rows()
