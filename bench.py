@@ -44,6 +44,8 @@ def parse_args():
     parser.add_argument("--error-bound", type=float, default=1.0, help="relative bound in percent")
     parser.add_argument("--cpu-sample-series", type=int, default=8)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--fit-group-points", type=int, default=12_000_000_000,
+                        help="at most this many raw points (4 B each) are resident per fit launch")
     return parser.parse_args()
 
 
@@ -74,7 +76,8 @@ def fit_on_gpu(context, mdb, args, rank):
     import ctypes as C
     eb = mdb.error_bound("relative", args.error_bound)
     chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
-    group = max(1, min(args.series, (1 << 31) // max(args.points, 1)))  # <= 2^31 points per launch
+    # All series of the rank in one launch when they fit (one lane per chunk: occupancy = chunks).
+    group = max(1, min(args.series, args.fit_group_points // max(args.points, 1)))
     parts, fit_seconds, fit_points = [], 0.0, 0
     first_series_of_rank = rank * args.series
     for first in range(0, args.series, group):

@@ -10,11 +10,14 @@
 //   k_scan_blocks    one block scans the per-block totals.
 //   k_grid_offsets   block-wide wavefront prefix sums -> 64-bit output offsets, the compacted list of
 //                    segments with serial work, rows-per-segment, and the tile -> first segment map.
-//   k_grid_tiles     the HBM-store-bound kernel: one 4096-point output tile per workgroup, each
-//                    lane writes 4 consecutive points with 16-byte stores; handles every point of a
-//                    regular-timestamp segment that a PMC-Mean / Swing model represents.
-//   k_grid_serial    1 lane / segment with a serial dependency: MacaqueV value streams, residual
-//                    tails (<= 255 values) and irregular (delta-of-delta) timestamps.
+//   k_grid_tiles     the HBM-store-bound kernel: one 4096-point output tile per workgroup, segment
+//                    offsets and descriptors staged in LDS, each lane reconstructs 4 consecutive
+//                    points; every wave-level store instruction writes 1 KiB contiguous (timestamps
+//                    are transposed through LDS for that). Writes placeholders for points it cannot
+//                    reconstruct.
+//   k_grid_serial    1 lane / segment with a serial dependency, always after k_grid_tiles: MacaqueV
+//                    value streams, residual tails (<= 255 values) and irregular (delta-of-delta)
+//                    timestamps overwrite the placeholders.
 // Algorithmic bytes: 73 B/segment read + 12 B/point written (8 B timestamp + 4 B value).
 #include "mdb_segment_dev.hpp"
 
@@ -23,7 +26,10 @@ namespace mdb {
 constexpr int PREPASS_THREADS = 256;
 constexpr int PREPASS_ITEMS = 4; // segments per thread in the scan kernels
 constexpr int SEGS_PER_BLOCK = PREPASS_THREADS * PREPASS_ITEMS;
-constexpr uint32_t TILE_POINTS = 4096;
+#ifndef MDB_TILE_POINTS
+#define MDB_TILE_POINTS 4096
+#endif
+constexpr uint32_t TILE_POINTS = MDB_TILE_POINTS;
 constexpr int TILE_THREADS = 256;
 constexpr int TILE_LDS_SEGMENTS = 1024; // more segments than this in one tile -> global search
 struct GridHeader {
@@ -150,29 +156,40 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_offsets(
 }
 
 // ---- the tile kernel -------------------------------------------------------------------------------
+//
+// One 4096-point output tile per workgroup. Each lane computes 4 consecutive points per iteration.
+// Values leave as one 16-byte store per lane (1 KiB contiguous per wave instruction). Timestamps
+// (32 bytes per lane) are transposed through a wave-private LDS slab so that each of the two
+// timestamp store instructions also writes 1 KiB contiguous instead of 16 bytes at a 32-byte
+// stride (measured +9 % at 740 points/segment, +18 % at 100; scripts/micro/tiles_ablate.hip).
+//
+// The kernel writes EVERY point of its tile. Points it cannot reconstruct (MacaqueV values,
+// residual values, everything of an irregular segment) get placeholders that k_grid_serial, which
+// always runs after it on the same stream, overwrites. That keeps every store a full-width vector
+// store; the price is 4 (or 12) extra bytes for exactly those points.
 
-struct PointSegment {
-    uint32_t segment;
-    uint32_t index; // index of the point inside its segment
+struct PointValue {
+    int64_t t;
+    float v;
 };
 
-__device__ __forceinline__ void store_point(const SegDesc &d, uint32_t index, uint64_t p,
-                                            int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
-    if (!(d.flags & FLAG_REGULAR)) return; // irregular: k_grid_serial writes timestamps and values
-    int64_t t = d.start + (int64_t)((uint64_t)index * (uint64_t)d.delta);
-    out_ts[p] = t;
-    uint32_t type = d.flags & FLAG_TYPE_MASK;
-    if (index < d.n_model) {
-        if (type == MDB_PMC_MEAN_ID) out_val[p] = d.value;
-        else if (type == MDB_SWING_ID) out_val[p] = (float)(d.slope * (double)t + d.intercept);
-    }
+__device__ __forceinline__ PointValue reconstruct_point(const SegDesc &d, uint32_t index) {
+    PointValue out;
+    out.t = d.start + (int64_t)((uint64_t)index * (uint64_t)d.delta);
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    out.v = type == MDB_SWING_ID ? (float)(d.slope * (double)out.t + d.intercept) : d.value;
+    return out;
 }
+
+constexpr int TILE_LDS_DESCS = 128; // descriptors of the first segments of a tile staged in LDS
 
 __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     const SegDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
     uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
     __shared__ uint32_t rel[TILE_LDS_SEGMENTS + 1]; // rel[k] = offsets[s0 + k] - tile_start, k >= 1
+    __shared__ __attribute__((aligned(16))) SegDesc lds_desc[TILE_LDS_DESCS];
+    __shared__ __attribute__((aligned(16))) longlong2 ts_slab[TILE_THREADS / MDB_WAVE][2 * MDB_WAVE];
     const uint64_t tile = blockIdx.x;
     const uint64_t tile_start = tile * TILE_POINTS;
     const uint64_t tile_end = min(total_points, tile_start + TILE_POINTS);
@@ -181,80 +198,103 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     const uint32_t n_in_tile = s1 - s0 + 1;
     const bool use_lds = n_in_tile <= TILE_LDS_SEGMENTS;
     const uint64_t s0_offset = offsets[s0];
-    if (use_lds) {
+    if (use_lds)
         for (uint32_t k = 1 + threadIdx.x; k < n_in_tile; k += TILE_THREADS)
             rel[k] = (uint32_t)(offsets[s0 + k] - tile_start);
-        __syncthreads();
-    }
+    for (uint32_t k = threadIdx.x; k < min(n_in_tile, (uint32_t)TILE_LDS_DESCS); k += TILE_THREADS)
+        lds_desc[k] = desc[s0 + k];
+    __syncthreads();
+    auto descriptor = [&](uint32_t k) -> SegDesc { // k relative to s0
+        return k < TILE_LDS_DESCS ? lds_desc[k] : desc[s0 + k];
+    };
+    const int lane = threadIdx.x & (MDB_WAVE - 1);
+    const int wave = threadIdx.x / MDB_WAVE;
 
 #pragma unroll 1
     for (uint32_t j = 0; j < TILE_POINTS / (TILE_THREADS * 4); j++) {
-        const uint64_t p = tile_start + (uint64_t)j * (TILE_THREADS * 4) + (uint64_t)threadIdx.x * 4;
-        if (p >= tile_end) break;
-        const uint32_t local = (uint32_t)(p - tile_start);
-        // Largest k in [0, n_in_tile) with offsets[s0 + k] <= p.
-        uint32_t lo = 0, hi = n_in_tile;
-        if (use_lds) {
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (rel[mid] <= local) lo = mid; else hi = mid;
+        // The wave's 256 points of this iteration start at wave_base (wave-uniform).
+        const uint64_t wave_base = tile_start + (uint64_t)j * (TILE_THREADS * 4) + (uint64_t)wave * (MDB_WAVE * 4);
+        if (wave_base >= tile_end) break;
+        const uint64_t p = wave_base + (uint64_t)lane * 4;
+        int64_t t[4] = {0, 0, 0, 0};
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (p < tile_end) {
+            const uint32_t local = (uint32_t)(p - tile_start);
+            // Largest k in [0, n_in_tile) with offsets[s0 + k] <= p.
+            uint32_t lo = 0, hi = n_in_tile;
+            if (use_lds) {
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (rel[mid] <= local) lo = mid; else hi = mid;
+                }
+            } else {
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (offsets[s0 + mid] <= p) lo = mid; else hi = mid;
+                }
             }
-        } else {
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (offsets[s0 + mid] <= p) lo = mid; else hi = mid;
-            }
-        }
-        uint32_t segment = s0 + lo;
-        uint64_t segment_offset =
-            lo == 0 ? s0_offset : (use_lds ? tile_start + rel[lo] : (uint64_t)offsets[segment]);
-        SegDesc d = desc[segment];
-        uint32_t index = (uint32_t)(p - segment_offset);
-        const uint32_t type = d.flags & FLAG_TYPE_MASK;
-        const bool same_segment = (p + 4 <= tile_end) && (index + 4 <= d.n_total) &&
-                                  (d.flags & FLAG_REGULAR);
-        if (same_segment) {
-            // 4 points of one regular segment: two 16-byte timestamp stores, and one 16-byte value
-            // store when a PMC-Mean / Swing model represents all four.
-            int64_t t0 = d.start + (int64_t)((uint64_t)index * (uint64_t)d.delta);
-            int64_t t1 = t0 + d.delta, t2 = t1 + d.delta, t3 = t2 + d.delta;
-            longlong2 *ts_out = reinterpret_cast<longlong2 *>(out_ts + p);
-            ts_out[0] = make_longlong2(t0, t1);
-            ts_out[1] = make_longlong2(t2, t3);
-            if (type != MDB_MACAQUE_V_ID) {
-                float4 v;
-                if (type == MDB_PMC_MEAN_ID) {
-                    v = make_float4(d.value, d.value, d.value, d.value);
+            uint64_t segment_offset =
+                lo == 0 ? s0_offset : (use_lds ? tile_start + rel[lo] : (uint64_t)offsets[s0 + lo]);
+            SegDesc d = descriptor(lo);
+            const uint32_t index = (uint32_t)(p - segment_offset);
+            if (index + 4 <= d.n_total) {
+                // All four points in one segment: the common case.
+                PointValue q0 = reconstruct_point(d, index);
+                t[0] = q0.t; t[1] = q0.t + d.delta; t[2] = t[1] + d.delta; t[3] = t[2] + d.delta;
+                if ((d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) {
+                    v.x = q0.v;
+                    v.y = (float)(d.slope * (double)t[1] + d.intercept);
+                    v.z = (float)(d.slope * (double)t[2] + d.intercept);
+                    v.w = (float)(d.slope * (double)t[3] + d.intercept);
                 } else {
-                    v.x = (float)(d.slope * (double)t0 + d.intercept);
-                    v.y = (float)(d.slope * (double)t1 + d.intercept);
-                    v.z = (float)(d.slope * (double)t2 + d.intercept);
-                    v.w = (float)(d.slope * (double)t3 + d.intercept);
+                    v = make_float4(d.value, d.value, d.value, d.value);
                 }
-                if (index + 4 <= d.n_model) {
-                    *reinterpret_cast<float4 *>(out_val + p) = v;
-                } else { // the model ends inside the group; the rest are residuals (k_grid_serial)
-                    if (index + 0 < d.n_model) out_val[p + 0] = v.x;
-                    if (index + 1 < d.n_model) out_val[p + 1] = v.y;
-                    if (index + 2 < d.n_model) out_val[p + 2] = v.z;
-                }
-            }
-        } else {
-            // Slow path: the 4 points straddle a segment / model / tile boundary.
-            uint64_t next_offset = segment_offset + d.n_total;
+            } else {
+                // The group straddles a segment boundary: walk point by point.
+                uint64_t next_offset = segment_offset + d.n_total;
+                float values[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 1
-            for (uint32_t k = 0; k < 4; k++) {
-                uint64_t q = p + k;
-                if (q >= tile_end) break;
-                while (q >= next_offset) { // advance to the segment holding q
-                    segment += 1;
-                    segment_offset = next_offset;
-                    d = desc[segment];
-                    next_offset = segment_offset + d.n_total;
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint64_t q = p + k;
+                    if (q >= tile_end) break;
+                    while (q >= next_offset) {
+                        lo += 1;
+                        segment_offset = next_offset;
+                        d = descriptor(lo);
+                        next_offset = segment_offset + d.n_total;
+                    }
+                    PointValue point = reconstruct_point(d, (uint32_t)(q - segment_offset));
+                    t[k] = point.t;
+                    values[k] = point.v;
                 }
-                store_point(d, (uint32_t)(q - segment_offset), q, out_ts, out_val);
+                v = make_float4(values[0], values[1], values[2], values[3]);
+            }
+            if (p + 4 <= tile_end) {
+                *reinterpret_cast<float4 *>(out_val + p) = v;
+            } else {
+                if (p + 0 < tile_end) out_val[p + 0] = v.x;
+                if (p + 1 < tile_end) out_val[p + 1] = v.y;
+                if (p + 2 < tile_end) out_val[p + 2] = v.z;
             }
         }
+        // Transpose the timestamps through LDS: lane l holds points 4l..4l+3 (chunks 2l, 2l+1 of
+        // 16 bytes); store instruction A writes chunks 0..63, B writes chunks 64..127.
+        longlong2 *slab = ts_slab[wave];
+        slab[2 * lane] = make_longlong2(t[0], t[1]);
+        slab[2 * lane + 1] = make_longlong2(t[2], t[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const longlong2 chunk_a = slab[lane];
+        const longlong2 chunk_b = slab[MDB_WAVE + lane];
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t point_a = wave_base + 2 * (uint64_t)lane;
+        const uint64_t point_b = point_a + 2 * MDB_WAVE;
+        longlong2 *ts_out = reinterpret_cast<longlong2 *>(out_ts + wave_base);
+        if (point_a + 2 <= tile_end) ts_out[lane] = chunk_a;
+        else if (point_a < tile_end) out_ts[point_a] = chunk_a.x;
+        if (point_b + 2 <= tile_end) ts_out[MDB_WAVE + lane] = chunk_b;
+        else if (point_b < tile_end) out_ts[point_b] = chunk_b.x;
     }
 }
 
