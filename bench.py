@@ -54,13 +54,33 @@ def init_distributed(n_gpus):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # Launched by torch.distributed.run (any world size, so the 1-GPU box exercises the RCCL path too).
+    if world > 1 or os.environ.get("TORCHELASTIC_RUN_ID") is not None:
         import torch
         import torch.distributed as dist_module
         torch.cuda.set_device(local_rank)
         dist_module.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_module
     return rank, local_rank, world, dist
+
+
+def pmc_traffic(args, points_per_launch, segments_per_launch):
+    """HBM bytes per launch of k_grid_tiles from the committed rocprofv3 PMC passes (bench.py cannot
+    collect counters itself): WRITE_SIZE and FETCH_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950. Only reported for the workload the passes ran on."""
+    path = os.path.join(REPO_ROOT, "profiles", "pmc_grid_tiles.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pmc = json.load(f)
+    if (pmc.get("series"), pmc.get("points")) != (args.series, args.points):
+        return None
+    return (pmc["write_bytes_per_point"] * points_per_launch
+            + pmc["fetch_bytes_per_segment_corrected"] * segments_per_launch)
+
+
+def eb_for(args, mdb):
+    return mdb.error_bound("relative", args.error_bound)
 
 
 def barrier_and_sync(context, dist):
@@ -177,37 +197,96 @@ def main():
     algorithmic_bytes = 73.0 * segments_per_launch + 12.0 * points_per_launch
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
+    # ---- secondary measurements on the same resident segments (not the headline) ----------------
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    t_lo, t_hi = (args.points // 4) * INTERVAL_US, (3 * args.points // 4) * INTERVAL_US
+    for part in parts:  # warm
+        context.agg_batch_dev(part, mask)
+    context.profile_enable(True)
+    context.profile_reset()
+    barrier_and_sync(context, dist)
+    t0 = time.perf_counter()
+    state = None
+    for part in parts:
+        state = context.agg_batch_dev(part, mask, state)
+    context.sync()
+    agg_seconds = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ranged = None
+    for part in parts:
+        ranged = context.agg_batch_range_dev(part, t_lo, t_hi, mask, ranged)
+    context.sync()
+    range_seconds = time.perf_counter() - t0
+    agg_profile = context.profile()
+    context.profile_enable(False)
+    if dist is not None:
+        # The one exchange step of the path: merge the per-GPU aggregate partials over RCCL/xGMI.
+        from modelardb_rs_amd import sharding
+        t0 = time.perf_counter()
+        state = sharding.all_reduce_state(state, dist, device=f"cuda:{local_rank}")
+        ranged = sharding.all_reduce_state(ranged, dist, device=f"cuda:{local_rank}")
+        reduce_seconds = time.perf_counter() - t0
+    else:
+        reduce_seconds = 0.0
+    assert state.count == world * total_points, (state.count, world * total_points)
+    aggregates = {
+        "segments_per_s": n_segments / agg_seconds,
+        "seconds": agg_seconds,
+        "kernel_ms": agg_profile.get("k_agg_segments", (1, 0.0))[1] / max(agg_profile.get("k_agg_segments", (1, 0.0))[0], 1),
+        "result": {"count": state.count, "min": state.min, "max": state.max, "sum": state.sum,
+                   "avg": state.sum / max(state.count, 1)},
+        "range": {"t_lo": t_lo, "t_hi": t_hi, "seconds": range_seconds,
+                  "segments_per_s": n_segments / range_seconds,
+                  "kernel_ms": agg_profile.get("k_agg_range", (1, 0.0))[1] / max(agg_profile.get("k_agg_range", (1, 0.0))[0], 1),
+                  "count": ranged.count, "min": ranged.min, "max": ranged.max, "sum": ranged.sum},
+        "final_reduce_seconds": reduce_seconds,
+        "note": "COUNT/MIN/MAX/SUM on the resident segments (BASELINE config 3: no grid); the range "
+                "variant clips to the middle half of the time axis; with N > 1 the partials of all "
+                "ranks are merged by one all-gather over RCCL",
+    }
+
     # ---- CPU baseline: the oracle's per-row grid loop on a bounded sample -------------------------
     cpu_baseline = None
+    fit_cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         import oracle_lib as ora
         sample = parts[0].download()
-        wanted = args.cpu_sample_series * args.points
-        rows_needed, acc = 0, 0
-        lengths = None
-        # Take whole leading series: segments are ordered by chunk, chunks by series.
-        chunk = sample.chunk_index
         chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
-        keep = np.nonzero(chunk < args.cpu_sample_series * chunks_per_series)[0]
-        sample = sample.take(keep)
+        n_sample = min(args.cpu_sample_series, args.series)
+        # Whole leading series: segments are ordered by chunk, chunks by series.
+        sample = sample.take(np.nonzero(sample.chunk_index < n_sample * chunks_per_series)[0])
         cores = os.cpu_count() or 1
-        t0 = time.perf_counter()
-        ts_cpu, _, _, _ = ora.grid_batch(sample, n_threads=cores)
-        cpu_seconds = time.perf_counter() - t0
-        t0 = time.perf_counter()
+        timing = {}
+        ts_cpu = ora.grid_batch(sample, n_threads=cores, timing=timing)[0]
+        cpu_seconds = timing["seconds"]
         single = sample.take(np.nonzero(sample.chunk_index < chunks_per_series)[0])
-        ts_single, _, _, _ = ora.grid_batch(single, n_threads=1)
-        single_seconds = time.perf_counter() - t0
+        ts_single = ora.grid_batch(single, n_threads=1, timing=timing)[0]
         cpu_baseline = {
             "value": len(ts_cpu) / cpu_seconds,
             "unit": "values/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"grid() of the first {args.cpu_sample_series} series "
-                      f"({len(ts_cpu)} points, {len(sample)} segments) of the same workload, "
-                      f"series-sharded over {cores} threads",
-            "single_thread_value": len(ts_single) / single_seconds,
+            "sample": f"grid() of the first {n_sample} series ({len(ts_cpu)} points, {len(sample)} "
+                      f"segments) of the same workload, segment ranges sharded over {cores} host "
+                      f"threads, output buffers pre-touched",
+            "single_thread_value": len(ts_single) / timing["seconds"],
         }
+        # The fitter's CPU baseline: the oracle's greedy compression of a few of the same series.
+        n_fit = min(4, args.series)
+        raw = context.dev_alloc(4 * n_fit * args.points)
+        context.synth_values_dev(raw, rank * args.series, n_fit, args.points, SEED)
+        host_values = context.download_array(raw, n_fit * args.points, np.float32)
+        context.dev_free(raw)
+        host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
+        offsets = np.array([s * args.points + c for s in range(n_fit)
+                            for c in range(0, args.points, CHUNK_POINTS)] + [n_fit * args.points],
+                           dtype=np.uint64)
+        t0 = time.perf_counter()
+        fitted = ora.compress_chunks(host_ts, host_values, offsets, eb_for(args, mdb), n_threads=cores)
+        fit_cpu_seconds = time.perf_counter() - t0
+        fit_cpu = {"points_per_s": n_fit * args.points / fit_cpu_seconds,
+                   "segments_per_s": len(fitted) / fit_cpu_seconds, "cores": cores, "kind": "port",
+                   "sample": f"{n_fit} series x {args.points} points, chunks sharded over {cores} threads"}
 
     if rank == 0:
         value = world * total_points * args.steps / elapsed
@@ -242,14 +321,16 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args, points_per_launch, segments_per_launch),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": algorithmic_bytes,
                 "other_kernels_ms": {name: ms / max(n, 1) for name, (n, ms) in profile.items()
                                      if name != "k_grid_tiles"},
             },
             "cpu_baseline": cpu_baseline,
+            "aggregates": aggregates,
             "fit": {
+                "cpu_baseline": fit_cpu,
                 "points_per_s": fit_points / fit_seconds if fit_seconds > 0 else None,
                 "segments_per_s": n_segments / fit_seconds if fit_seconds > 0 else None,
                 "seconds": fit_seconds,

@@ -1397,34 +1397,71 @@ int ora_grid_batch(const mdb_segments *in, int64_t *out_ts, float *out_val,
 
 int ora_grid_batch_mt(const mdb_segments *in, int64_t *out_ts, float *out_val, uint64_t cap,
                       uint64_t *n_out, int n_threads) {
-    uint64_t workers = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_threads, in->n));
-    std::vector<std::vector<int64_t>> ts_parts(workers);
-    std::vector<std::vector<float>> val_parts(workers);
+    /* Pass 1: how many points each worker's contiguous range of rows produces, so that pass 2 can
+     * write straight into the output at the right offset. Pass 2 is GridStream's per-row loop
+     * (grid_exec.rs:323-356): grid one row into a builder, append it to the output. */
+    const uint64_t workers = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_threads, in->n));
+    std::vector<uint64_t> counts(workers, 0);
     std::vector<int> failed(workers, 0);
-    std::vector<std::thread> threads;
-    for (uint64_t w = 0; w < workers; w++) {
-        threads.emplace_back([&, w]() {
-            uint64_t begin = in->n * w / workers;
-            uint64_t end = in->n * (w + 1) / workers;
-            for (uint64_t row = begin; row < end; row++)
-                if (!grid_row(in, row, ts_parts[w], val_parts[w])) { failed[w] = 1; return; }
-        });
+    auto range = [&](uint64_t w, uint64_t *begin, uint64_t *end) {
+        *begin = in->n * w / workers;
+        *end = in->n * (w + 1) / workers;
+    };
+    {
+        std::vector<std::thread> threads;
+        for (uint64_t w = 0; w < workers; w++) {
+            threads.emplace_back([&, w]() {
+                uint64_t begin, end;
+                range(w, &begin, &end);
+                for (uint64_t row = begin; row < end; row++) {
+                    const uint8_t *ts;
+                    uint64_t ts_len, count;
+                    if (!view_bytes(in->timestamps, row, &ts, &ts_len) ||
+                        !decompressed_timestamp_count(in->start_time[row], in->end_time[row], ts, ts_len, &count)) {
+                        failed[w] = 1;
+                        return;
+                    }
+                    counts[w] += count;
+                }
+            });
+        }
+        for (auto &t : threads) t.join();
     }
-    for (auto &t : threads) t.join();
     uint64_t total = 0;
+    std::vector<uint64_t> offsets(workers, 0);
     for (uint64_t w = 0; w < workers; w++) {
-        if (failed[w]) return fail("Malformed segment or unknown model type.");
-        total += ts_parts[w].size();
+        if (failed[w]) return fail("Malformed compressed timestamps.");
+        offsets[w] = total;
+        total += counts[w];
     }
     *n_out = total;
     if (total > cap) return fail("Output buffer too small.");
-    uint64_t at = 0;
-    for (uint64_t w = 0; w < workers; w++) {
-        if (ts_parts[w].empty()) continue;
-        std::memcpy(out_ts + at, ts_parts[w].data(), ts_parts[w].size() * sizeof(int64_t));
-        std::memcpy(out_val + at, val_parts[w].data(), val_parts[w].size() * sizeof(float));
-        at += ts_parts[w].size();
+    {
+        std::vector<std::thread> threads;
+        for (uint64_t w = 0; w < workers; w++) {
+            threads.emplace_back([&, w]() {
+                uint64_t begin, end;
+                range(w, &begin, &end);
+                std::vector<int64_t> ts_builder;
+                std::vector<float> value_builder;
+                uint64_t at = offsets[w];
+                for (uint64_t row = begin; row < end; row++) {
+                    ts_builder.clear();
+                    value_builder.clear();
+                    if (!grid_row(in, row, ts_builder, value_builder)) {
+                        failed[w] = 1;
+                        return;
+                    }
+                    std::memcpy(out_ts + at, ts_builder.data(), ts_builder.size() * sizeof(int64_t));
+                    std::memcpy(out_val + at, value_builder.data(), value_builder.size() * sizeof(float));
+                    at += ts_builder.size();
+                }
+            });
+        }
+        for (auto &t : threads) t.join();
     }
+    for (uint64_t w = 0; w < workers; w++)
+        if (failed[w]) return fail("Malformed segment or unknown model type.");
     return 0;
 }
 

@@ -62,6 +62,14 @@ def lib():
                                        C.c_float, C.c_uint64]
         _lib.ora_segments_free.argtypes = [C.POINTER(_abi.SegmentsOwnedC)]
         _lib.ora_segments_free.restype = None
+        # Prototypes for everything that takes the error bound struct by value.
+        EB, P, U64 = _abi.ErrorBoundC, C.c_void_p, C.c_uint64
+        _lib.ora_pmc_mean_fit.argtypes = [EB, P, U64, P, P, P]
+        _lib.ora_swing_fit.argtypes = [EB, P, P, U64, P, P, P, P, P]
+        _lib.ora_macaque_v_compress.argtypes = [EB, P, U64, C.c_int, C.c_float, P, U64, P, P, P, P, P, P]
+        _lib.ora_fit_next_model.argtypes = [U64, EB, P, P, U64, P]
+        _lib.ora_model_finish.argtypes = [P, EB, U64, P, P, U64, P]
+        _lib.ora_compress_chunks.argtypes = [P, P, P, U64, EB, C.c_int, P]
     return _lib
 
 
@@ -328,21 +336,31 @@ def grid_count(batch):
     return n_out.value
 
 
-def grid_batch(batch, n_threads=1):
-    """Returns (timestamps, values, rows_per_segment, metrics dict)."""
+def grid_batch(batch, n_threads=1, timing=None):
+    """Returns (timestamps, values, rows_per_segment, metrics dict). With `timing` (a dict) the
+    output buffers are allocated and touched first and only the oracle call itself is timed."""
+    import time
     seg = batch.as_c()
     cap = grid_count(batch)
     out_ts = np.zeros(cap, dtype=np.int64)
     out_val = np.zeros(cap, dtype=np.float32)
     rows = np.zeros(len(batch), dtype=np.uint32)
+    if timing is not None:
+        out_ts.fill(1)
+        out_val.fill(1)
     n_out = C.c_uint64()
+    started = time.perf_counter()
     if n_threads > 1:
         _check(lib().ora_grid_batch_mt(C.byref(seg), _ptr(out_ts), _ptr(out_val), C.c_uint64(cap),
                                        C.byref(n_out), C.c_int(n_threads)))
+        if timing is not None:
+            timing["seconds"] = time.perf_counter() - started
         return out_ts[: n_out.value], out_val[: n_out.value], None, None
     metrics = _abi.GridMetricsC()
     _check(lib().ora_grid_batch(C.byref(seg), _ptr(out_ts), _ptr(out_val), _ptr(rows),
                                 C.c_uint64(cap), C.byref(n_out), C.byref(metrics)))
+    if timing is not None:
+        timing["seconds"] = time.perf_counter() - started
     return out_ts[: n_out.value], out_val[: n_out.value], rows, metrics.as_dict()
 
 
