@@ -117,6 +117,8 @@ def fit_on_gpu(context, mdb, args, rank):
         offsets[k] = total
         offsets_dev = context.upload_array(offsets)
         first_index_dev = context.upload_array(first_index)
+        # The first call grows the context's scratch (tens of GB of hipMalloc); time the second.
+        context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US, first_index_dev).free()
         context.sync()
         t0 = time.perf_counter()
         parts.append(context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US,

@@ -7,8 +7,11 @@
 //
 // The greedy segmentation is strictly sequential inside a series chunk (each accepted model's end
 // decides the next start), so the parallel unit is the chunk: C4 has 1.6 M of them.
-//   k_fit_models   1 lane / chunk: the greedy loop (compression.rs:224-263); every point goes through
-//                  PMC-Mean and Swing exactly as in the reference; emits 16-byte model records and
+//   k_fit_models   1 lane / chunk: the greedy loop (compression.rs:224-263) as a per-lane state
+//                  machine; every point goes through PMC-Mean and Swing exactly as in the reference.
+//                  The wave prefetches each lane's next 24 points into an LDS ring with one
+//                  synchronous burst of independent loads, so the sequential loop waits on memory
+//                  once per ~24 points instead of once per point. Emits 16-byte model records and
 //                  the chunk's segment count.
 //   (scan)         chunk -> first segment.
 //   k_fit_plan     1 lane / chunk: model records -> per-segment work items (model + residual tail,
@@ -59,6 +62,27 @@ __device__ __forceinline__ double max_allowed_deviation(mdb_error_bound eb, doub
     if (eb.kind == MDB_EB_ABSOLUTE) return (double)eb.value * 0.99;
     if (eb.kind == MDB_EB_RELATIVE) return fabs(value * ((double)eb.value / 100.1));
     return 0.0;
+}
+
+// The same function with its loop-invariant part evaluated once: `factor` is (double)eps * 0.99
+// for an absolute bound and (double)eps / 100.1 for a relative one - the identical IEEE operations
+// the per-point form performs, just not repeated per point (the division is ~30 f64 instructions).
+struct DeviationFactor {
+    int32_t kind;
+    double factor;
+    __device__ __forceinline__ double of(double value) const {
+        if (kind == MDB_EB_ABSOLUTE) return factor;
+        if (kind == MDB_EB_RELATIVE) return fabs(value * factor);
+        return 0.0;
+    }
+};
+
+__device__ __forceinline__ DeviationFactor deviation_factor(mdb_error_bound eb) {
+    DeviationFactor d;
+    d.kind = eb.kind;
+    d.factor = eb.kind == MDB_EB_ABSOLUTE ? (double)eb.value * 0.99
+                                          : (eb.kind == MDB_EB_RELATIVE ? (double)eb.value / 100.1 : 0.0);
+    return d;
 }
 
 // ---- timestamps of a chunk: materialised or synthesised regular ----------------------------------------
@@ -126,8 +150,10 @@ struct SwingDev {
     LineDev upper, lower;
     double numerator, denominator;
     uint32_t length;
+    bool all_finite;
     __device__ __forceinline__ void reset() {
         const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        all_finite = false;
         start_time = 0;
         end_time = 0;
         first_value = nan;
@@ -137,17 +163,43 @@ struct SwingDev {
         denominator = 0.0;
         length = 0;
     }
-    __device__ __forceinline__ bool fit(mdb_error_bound eb, int64_t timestamp, float value32) {
-        double value = (double)value32;
-        double deviation = max_allowed_deviation(eb, value);
+    __device__ __forceinline__ bool fit(const DeviationFactor &dev, int64_t timestamp, float value32) {
+        const double value = (double)value32;
+        const double deviation = dev.of(value);
+        // Line 6 onwards of Algorithm 1 (swing.rs:144-197) is what runs for almost every point, so
+        // it is tested first; `all_finite` caches !first_value.is_finite() of swing.rs:113.
+        if (length >= 2 && all_finite) {
+            if (!isfinite(value)) return false; // equal_or_nan(finite, non-finite) is false
+            const double t = (double)timestamp;
+            const double upper_approximation = upper.slope * t + upper.intercept;
+            const double lower_approximation = lower.slope * t + lower.intercept;
+            if (upper_approximation + deviation < value || lower_approximation - deviation > value)
+                return false;
+            end_time = timestamp;
+            if (upper_approximation - deviation > value)
+                upper = line_through(start_time, first_value, timestamp, value + deviation);
+            if (lower_approximation + deviation < value)
+                lower = line_through(start_time, first_value, timestamp, value - deviation);
+            if (first_value != value) { // swing.rs:212-228 (both finite here)
+                const double dt = (double)(timestamp - start_time);
+                numerator += (value - first_value) * dt;
+                denominator += dt * dt;
+            } else {
+                numerator += 0.0;
+                denominator += 0.0;
+            }
+            length += 1;
+            return true;
+        }
         if (length == 0) {
             start_time = timestamp;
             end_time = timestamp;
             first_value = value;
+            all_finite = isfinite(value);
             length = 1;
             return true;
         }
-        if (!isfinite(first_value) || !isfinite(value)) {
+        if (!all_finite || !isfinite(value)) {
             if (!equal_or_nan(first_value, value)) return false;
             end_time = timestamp;
             upper = {value, value};
@@ -155,31 +207,10 @@ struct SwingDev {
             length += 1;
             return true;
         }
-        if (length == 1) {
-            end_time = timestamp;
-            upper = line_through(start_time, first_value, timestamp, value + deviation);
-            lower = line_through(start_time, first_value, timestamp, value - deviation);
-            length += 1;
-            return true;
-        }
-        double t = (double)timestamp;
-        double upper_approximation = upper.slope * t + upper.intercept;
-        double lower_approximation = lower.slope * t + lower.intercept;
-        if (upper_approximation + deviation < value || lower_approximation - deviation > value)
-            return false;
+        // length == 1 (swing.rs:126-143)
         end_time = timestamp;
-        if (upper_approximation - deviation > value)
-            upper = line_through(start_time, first_value, timestamp, value + deviation);
-        if (lower_approximation + deviation < value)
-            lower = line_through(start_time, first_value, timestamp, value - deviation);
-        if (!equal_or_nan(first_value, value)) { // swing.rs:212-228
-            double dt = (double)(timestamp - start_time);
-            numerator += (value - first_value) * dt;
-            denominator += dt * dt;
-        } else {
-            numerator += 0.0;
-            denominator += 0.0;
-        }
+        upper = line_through(start_time, first_value, timestamp, value + deviation);
+        lower = line_through(start_time, first_value, timestamp, value - deviation);
         length += 1;
         return true;
     }
@@ -462,81 +493,155 @@ struct RecordCapacity {
     }
 };
 
-__global__ __launch_bounds__(256) void k_fit_models(FitArgs args, const unsigned long long *__restrict__ record_base,
-                                                    ModelRec *__restrict__ records,
-                                                    ChunkPlan *__restrict__ plans,
-                                                    unsigned int *__restrict__ error) {
-    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (chunk >= args.n_chunks) return;
-    const uint64_t base = args.chunk_offsets[chunk];
-    const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
-    if (length64 > COUNT_MASK) {
-        atomicOr(error, ERR_TOO_LONG);
-        plans[chunk] = {0, 0};
-        return;
+// One lane per chunk, one wave per workgroup. The greedy loop is flattened into a per-lane state
+// machine ("feed one point" or "finish the model") so that all 64 lanes can share wave-synchronous
+// prefetching: every lane keeps a ring of its next FIT_RING values (and timestamps, when they are
+// materialised) in LDS, laid out [slot][lane] so a slot is one bank-conflict-free row. When ANY lane
+// runs dry the WHOLE wave tops its rings up with independent, predicated loads issued back to back
+// and waits once - one HBM/L2 latency per ~FIT_RING-8 points instead of one per point. The ring
+// always keeps the 8 most recent points, because a rejected model restarts at most 7 points back.
+constexpr int FIT_RING = 32;
+constexpr int FIT_HISTORY = 8;
+constexpr int FIT_THREADS = MDB_WAVE;
+
+template <bool HAS_TS>
+__global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
+                                                           const unsigned long long *__restrict__ record_base,
+                                                           ModelRec *__restrict__ records,
+                                                           ChunkPlan *__restrict__ plans,
+                                                           unsigned int *__restrict__ error) {
+    __shared__ float ring_values[FIT_RING][MDB_WAVE];
+    __shared__ long long ring_ts[HAS_TS ? FIT_RING : 1][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t chunk = (uint64_t)blockIdx.x * FIT_THREADS + lane;
+    bool active = chunk < args.n_chunks;
+    uint64_t base = 0;
+    uint32_t n = 0;
+    if (active) {
+        base = args.chunk_offsets[chunk];
+        const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
+        if (length64 > COUNT_MASK) {
+            atomicOr(error, ERR_TOO_LONG);
+            plans[chunk] = {0, 0};
+            active = false;
+        } else {
+            n = (uint32_t)length64;
+        }
     }
-    const uint32_t n = (uint32_t)length64;
     const float *__restrict__ values = args.values + base;
-    const ChunkTimestamps ts = chunk_timestamps(args.timestamps, chunk, base);
+    const int64_t *__restrict__ timestamps = HAS_TS ? args.timestamps.ts + base : nullptr;
+    const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, active ? chunk : 0, base);
     const mdb_error_bound eb = args.eb;
-    ModelRec *__restrict__ out = records + record_base[chunk];
+    const DeviationFactor dev = deviation_factor(eb);
+    ModelRec *__restrict__ out = records + (active ? record_base[chunk] : 0);
 
     uint32_t n_models = 0, n_segments = 0;
     bool have_previous = false;
     uint32_t previous_end = 0;
-    uint32_t current = 0;
+    uint32_t current = 0; // first point of the model being fitted
+    uint32_t j = 0;       // next point to feed
+    uint32_t loaded = 0;  // the ring holds points [low, loaded) of the chunk, loaded - low <= FIT_RING
+    uint32_t low = 0;
     PmcDev pmc;
     SwingDev swing;
-    while (current < n) {
-        // fit_next_model (compression.rs:280-301, types.rs:61-81)
-        pmc.reset();
-        swing.reset();
-        bool pmc_fits = true, swing_fits = true;
-        for (uint32_t j = current; j < n && (pmc_fits || swing_fits); j++) {
-            const float v = values[j];
+    pmc.reset();
+    swing.reset();
+    bool pmc_fits = true, swing_fits = true;
+    if (active && n == 0) {
+        plans[chunk] = {0, 0};
+        active = false;
+    }
+
+    while (__any(active)) {
+        const bool feeding = active && j < n && (pmc_fits || swing_fits);
+        // Wave-synchronous top-up: triggered by any lane whose next point is not in its ring.
+        if (__any(feeding && (j >= loaded || j < low))) {
+            float fetched_values[FIT_RING - FIT_HISTORY];
+            long long fetched_ts[HAS_TS ? FIT_RING - FIT_HISTORY : 1];
+            // Normally the ring is extended at `loaded`. A lane whose next point fell out of the
+            // back of its ring (PMC-Mean chosen although Swing had reached > 8 points further,
+            // types.rs:84-101) restarts its ring at j; points before j are never needed again.
+            if (active && j < low) {
+                loaded = j;
+                low = j;
+            }
+            const uint32_t first = loaded;
+            const uint32_t room = active ? (uint32_t)max(0, (int)(j + FIT_RING - FIT_HISTORY) - (int)first) : 0u;
+#pragma unroll
+            for (int k = 0; k < FIT_RING - FIT_HISTORY; k++) {
+                const uint32_t index = first + k;
+                const bool wanted = (uint32_t)k < room && index < n;
+                fetched_values[k] = wanted ? values[index] : 0.0f;
+                if (HAS_TS) fetched_ts[k] = wanted ? timestamps[index] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < FIT_RING - FIT_HISTORY; k++) {
+                const uint32_t index = first + k;
+                if ((uint32_t)k < room && index < n) {
+                    ring_values[index % FIT_RING][lane] = fetched_values[k];
+                    if (HAS_TS) ring_ts[index % FIT_RING][lane] = fetched_ts[k];
+                }
+            }
+            loaded = min(n, first + min(room, (uint32_t)(FIT_RING - FIT_HISTORY)));
+            if (loaded > low + FIT_RING) low = loaded - FIT_RING;
+            // Only this lane reads its own column: no cross-lane hazard, just LDS program order.
+        }
+        if (feeding) {
+            const float v = ring_values[j % FIT_RING][lane];
+            const int64_t t = HAS_TS ? (int64_t)ring_ts[j % FIT_RING][lane] : regular_ts.at(j);
+            // try_to_update_models (types.rs:74-81): a model that failed once is never fed again.
             if (pmc_fits) pmc_fits = pmc.fit(eb, v);
-            if (swing_fits) swing_fits = swing.fit(eb, ts.at(j), v);
-        }
-        // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
-        const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc.length;
-        const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing.length;
-        const bool choose_pmc = pmc_bpv <= swing_bpv;
-        const float bpv = choose_pmc ? pmc_bpv : swing_bpv;
-        if (bpv <= (float)MDB_VALUE_SIZE_IN_BYTES) { // compression.rs:238
-            ModelRec rec;
-            if (choose_pmc) {
-                rec.start_and_type = current;
-                rec.end = current + pmc.length - 1;
-                rec.p0 = (float)(pmc.sum / (double)pmc.length); // pmc_mean.rs:91-93
-                rec.p1 = rec.p0;
-            } else {
-                rec.start_and_type = current | 0x80000000u;
-                rec.end = current + swing.length - 1;
-                swing.model(&rec.p0, &rec.p1);
-            }
-            // Segments implied by the gap before this model (compression.rs:240-249, 310-362).
-            if (have_previous) {
-                if (current - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
-            } else if (current > 0) {
+            if (swing_fits) swing_fits = swing.fit(dev, t, v);
+            j += 1;
+        } else if (active) {
+            // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
+            const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc.length;
+            const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing.length;
+            const bool choose_pmc = pmc_bpv <= swing_bpv;
+            const float bpv = choose_pmc ? pmc_bpv : swing_bpv;
+            if (bpv <= (float)MDB_VALUE_SIZE_IN_BYTES) { // compression.rs:238
+                ModelRec rec;
+                if (choose_pmc) {
+                    rec.start_and_type = current;
+                    rec.end = current + pmc.length - 1;
+                    rec.p0 = (float)(pmc.sum / (double)pmc.length); // pmc_mean.rs:91-93
+                    rec.p1 = rec.p0;
+                } else {
+                    rec.start_and_type = current | 0x80000000u;
+                    rec.end = current + swing.length - 1;
+                    swing.model(&rec.p0, &rec.p1);
+                }
+                // Segments implied by the gap before this model (compression.rs:240-249, 310-362).
+                if (have_previous) {
+                    if (current - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
+                } else if (current > 0) {
+                    n_segments += 1;
+                }
+                out[n_models++] = rec;
                 n_segments += 1;
+                have_previous = true;
+                previous_end = rec.end;
+                current = rec.end + 1;
+            } else {
+                current += 1; // the point becomes a residual (compression.rs:258-262)
             }
-            out[n_models++] = rec;
-            n_segments += 1;
-            have_previous = true;
-            previous_end = rec.end;
-            current = rec.end + 1;
-        } else {
-            current += 1;
+            if (current >= n) {
+                if (have_previous) {
+                    if (n - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
+                } else {
+                    n_segments += 1;
+                }
+                plans[chunk] = {n_models, n_segments};
+                active = false;
+            } else {
+                pmc.reset();
+                swing.reset();
+                pmc_fits = true;
+                swing_fits = true;
+                j = current;
+            }
         }
     }
-    if (n > 0) {
-        if (have_previous) {
-            if (n - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
-        } else {
-            n_segments += 1;
-        }
-    }
-    plans[chunk] = {n_models, n_segments};
 }
 
 // ---- k_fit_plan --------------------------------------------------------------------------------------------
@@ -870,8 +975,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         const uint32_t chunk_blocks = (uint32_t)((n_chunks + 255) / 256);
         {
             LaunchTimer timer(ctx, "k_fit_models");
-            hipLaunchKernelGGL(k_fit_models, dim3(chunk_blocks), dim3(256), 0, ctx->stream, args,
-                               record_base, records, plans, error_flag);
+            const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
+            if (ts)
+                hipLaunchKernelGGL(k_fit_models<true>, dim3(fit_blocks), dim3(FIT_THREADS), 0, ctx->stream,
+                                   args, record_base, records, plans, error_flag);
+            else
+                hipLaunchKernelGGL(k_fit_models<false>, dim3(fit_blocks), dim3(FIT_THREADS), 0, ctx->stream,
+                                   args, record_base, records, plans, error_flag);
         }
         FIT_TRY(device_exclusive_scan(ctx, SegmentCount{plans}, n_chunks, segment_base, block_sums,
                                       "k_fit_scan"));

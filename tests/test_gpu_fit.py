@@ -147,3 +147,26 @@ def test_synthetic_generator_statistics(hip):
     for s in range(n_series):
         clean = 100.0 + 10.0 * np.sin(2 * np.pi * i / (2000.0 + 37.0 * (s % 64)) + 2 * np.pi * ((s * 0.61803) % 1.0))
         assert np.abs(values[s] - clean).max() <= 0.0501
+
+
+def test_fit_pmc_chosen_while_swing_ran_far_ahead(hip):
+    # PMC-Mean wins ties (types.rs:84-101) even when Swing accepted up to ~3 % more points, so the
+    # next model starts well behind the last point that was fed. Long near-constant runs with a
+    # small drift provoke exactly that; the fitter's prefetch ring must rewind correctly.
+    rng = np.random.default_rng(91)
+    parts = []
+    for k in range(40):
+        length = int(rng.integers(300, 3000))
+        level = float(rng.uniform(50, 150))
+        drift = float(rng.uniform(-0.003, 0.003))
+        parts.append((level * (1.0 + drift * np.arange(length) / length)).astype(np.float32))
+    values = np.concatenate(parts)
+    timestamps = np.arange(len(values), dtype=np.int64) * 1000
+    for eb_name in ("rel1", "rel5", "abs5"):
+        eb = cases.error_bounds()[eb_name]
+        expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
+        got = hip.try_compress_univariate_time_series(timestamps, values, eb)
+        assert_same_segments(got, expected)
+    # the scenario really occurs: some PMC-Mean segment is followed by a model starting before
+    # the point where Swing would have failed
+    assert (expected.model_type_id == 0).any()
