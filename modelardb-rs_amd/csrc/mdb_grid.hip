@@ -299,22 +299,95 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
 }
 
 // ---- the serial kernel -------------------------------------------------------------------------------
+//
+// One lane per segment that carries a serial dependency, one wave per workgroup. MacaqueV streams
+// (a model's values and/or the residual tail) are decoded from an LDS ring: every lane keeps the
+// next SERIAL_RING_WORDS 32-bit words of ITS bitstream in LDS ([slot][lane], bank-conflict free),
+// and when any lane runs low the whole wave tops all rings up with independent predicated loads
+// issued back to back - one memory latency per ~24 words instead of one per word. The decode itself
+// stays sequential per stream: value i's position depends on every earlier value.
+// Irregular (delta-of-delta) timestamps are rare and keep the direct reader.
 
-__global__ __launch_bounds__(256) void k_grid_serial(DevSegments s, const SegDesc *__restrict__ desc,
-                                                     const unsigned long long *__restrict__ offsets,
-                                                     const uint32_t *__restrict__ serial_ids,
-                                                     uint64_t n_serial, int64_t *__restrict__ out_ts,
-                                                     float *__restrict__ out_val,
-                                                     GridHeader *__restrict__ header) {
-    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_serial) return;
-    const uint32_t i = serial_ids[slot];
-    const SegDesc d = desc[i];
-    const uint64_t o = offsets[i];
+constexpr int SERIAL_RING_WORDS = 32;
+constexpr int SERIAL_TOPUP_WORDS = 24;
+constexpr int SERIAL_THREADS = MDB_WAVE;
+
+struct RingBitReader {
+    const uint32_t *words; // aligned base in global memory
+    uint32_t n_words;
+    uint32_t next_word; // next word to move from the ring into the bit buffer
+    uint32_t loaded;    // words [next_word, loaded) are in the ring
+    uint64_t buffer;    // MSB aligned
+    int32_t available;
+    uint32_t skip_bits; // slack bits in front of the first payload byte
+    uint64_t used_bits;
+    uint64_t total_bits;
+
+    __device__ __forceinline__ void begin(const uint8_t *bytes, uint64_t nbytes) {
+        uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        uint32_t misalign = (uint32_t)(address & 3u);
+        words = reinterpret_cast<const uint32_t *>(address - misalign);
+        n_words = (uint32_t)((nbytes + misalign + 3u) >> 2);
+        next_word = 0;
+        loaded = 0;
+        buffer = 0;
+        available = 0;
+        skip_bits = 8u * misalign;
+        used_bits = 0;
+        total_bits = nbytes * 8u;
+    }
+    __device__ __forceinline__ bool hungry() const { return loaded < n_words && loaded - next_word < 3; }
+    __device__ __forceinline__ void pull(const uint32_t (*ring)[MDB_WAVE], int lane) {
+        while (available <= 32 && next_word < loaded) {
+            uint32_t w = __builtin_bswap32(ring[next_word % SERIAL_RING_WORDS][lane]);
+            next_word += 1;
+            if (skip_bits) { // only the very first word can carry slack bytes
+                buffer |= ((uint64_t)w << 32) << skip_bits;
+                available += 32 - (int32_t)skip_bits;
+                skip_bits = 0;
+            } else {
+                buffer |= (uint64_t)w << (32 - available);
+                available += 32;
+            }
+        }
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t count, const uint32_t (*ring)[MDB_WAVE], int lane) {
+        if (count == 0) return 0;
+        pull(ring, lane);
+        uint32_t value = (uint32_t)(buffer >> (64u - count));
+        buffer <<= count;
+        available -= (int32_t)count;
+        used_bits += count;
+        return value;
+    }
+    __device__ __forceinline__ bool overrun() const { return used_bits > total_bits; }
+};
+
+struct MacaqueStream {
+    uint32_t remaining;  // values still to decode
+    uint32_t position;   // where the next value goes, relative to the segment's first point
+    uint32_t last;       // bits of the previous value
+    uint32_t leading, trailing;
+    bool first_is_raw;   // the next value is stored as 32 raw bits (macaque_v.rs:289-293)
+};
+
+__global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
+    DevSegments s, const SegDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ serial_ids, uint64_t n_serial, int64_t *__restrict__ out_ts,
+    float *__restrict__ out_val, GridHeader *__restrict__ header) {
+    __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    const bool present = slot < n_serial;
+    const uint32_t i = present ? serial_ids[slot] : 0;
+    SegDesc d;
+    d.flags = 0; d.n_total = 0; d.n_model = 0; d.value = 0.0f; d.start = 0; d.delta = 0; d.slope = 0.0; d.intercept = 0.0;
+    if (present) d = desc[i];
+    const uint64_t o = present ? (uint64_t)offsets[i] : 0;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     uint32_t error = 0;
-    float seed = d.value;
-    if (!(d.flags & FLAG_REGULAR)) {
+
+    if (present && !(d.flags & FLAG_REGULAR)) {
         // Irregular timestamps, and the model values that depend on them.
         const uint4 vt = s.timestamps.views[i];
         const uint8_t *bytes = view_data(s.timestamps, i, vt);
@@ -328,24 +401,113 @@ __global__ __launch_bounds__(256) void k_grid_serial(DevSegments s, const SegDes
                                         }
                                     });
     }
-    if (type == MDB_MACAQUE_V_ID) {
-        const uint4 vv = s.values.views[i];
-        uint32_t last_bits = 0;
-        decode_macaque_v(view_data(s.values, i, vv), vv.x, d.n_model, false, 0, &error,
-                         [&](uint32_t k, uint32_t bits) {
-                             out_val[o + k] = __uint_as_float(bits);
-                             last_bits = bits;
-                         });
-        seed = __uint_as_float(last_bits);
-    }
+
+    // Up to two MacaqueV streams per segment: the model's values (type 2) and the residual tail.
     const uint32_t n_res = d.n_total - d.n_model;
-    if (n_res > 0) {
-        // models/mod.rs:241-249: XOR-seeded with the last RECONSTRUCTED value.
-        const uint4 vr = s.residuals.views[i];
-        decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, n_res, true, __float_as_uint(seed),
-                         &error, [&](uint32_t k, uint32_t bits) {
-                             out_val[o + d.n_model + k] = __uint_as_float(bits);
-                         });
+    bool values_pending = present && type == MDB_MACAQUE_V_ID && d.n_model > 0;
+    bool residuals_pending = present && n_res > 0;
+    RingBitReader reader;
+    reader.begin(nullptr, 0);
+    MacaqueStream stream;
+    stream.remaining = 0; stream.position = 0; stream.last = __float_as_uint(d.value);
+    stream.leading = 255; stream.trailing = 0; stream.first_is_raw = false;
+    bool active = false;
+    auto open_next_stream = [&]() {
+        if (values_pending) {
+            const uint4 vv = s.values.views[i];
+            reader.begin(view_data(s.values, i, vv), vv.x);
+            if (vv.x == 0) error |= ERR_BITSTREAM;
+            stream.remaining = d.n_model; stream.position = 0; stream.leading = 255; stream.trailing = 0;
+            stream.first_is_raw = true;
+            values_pending = false;
+            active = vv.x != 0;
+        } else if (residuals_pending) {
+            // models/mod.rs:241-249: XOR-seeded with the last RECONSTRUCTED value;
+            // stream.last already holds it (PMC / Swing: d.value, MacaqueV: its last decoded value).
+            const uint4 vr = s.residuals.views[i];
+            reader.begin(view_data(s.residuals, i, vr), vr.x - 1);
+            if (vr.x < 2) error |= ERR_BITSTREAM;
+            stream.remaining = n_res; stream.position = d.n_model; stream.leading = 255; stream.trailing = 0;
+            stream.first_is_raw = false;
+            residuals_pending = false;
+            active = vr.x >= 2;
+        } else {
+            active = false;
+        }
+    };
+    open_next_stream();
+
+    while (__any(active)) {
+        if (__any(active && reader.hungry())) {
+            uint32_t fetched[SERIAL_TOPUP_WORDS];
+            const uint32_t first = reader.loaded;
+            const uint32_t room = active ? SERIAL_RING_WORDS - (reader.loaded - reader.next_word) : 0u;
+#pragma unroll
+            for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
+                const uint32_t index = first + k;
+                fetched[k] = ((uint32_t)k < room && index < reader.n_words) ? reader.words[index] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
+                const uint32_t index = first + k;
+                if ((uint32_t)k < room && index < reader.n_words) ring[index % SERIAL_RING_WORDS][lane] = fetched[k];
+            }
+            reader.loaded = min(reader.n_words, first + min(room, (uint32_t)SERIAL_TOPUP_WORDS));
+        }
+        if (active) {
+            // One value (macaque_v.rs:297-322) is at most 2 + 5 + 6 + 32 = 45 bits. After pull() the
+            // bit buffer holds > 32 bits and the ring >= 64 more, so control bits, window and payload
+            // are peeled off the top of the 64-bit buffer with one refill per field group instead of
+            // one reader call per field.
+            uint32_t bits;
+            reader.pull(ring, lane);
+            if (stream.first_is_raw) {
+                bits = reader.get(32, ring, lane);
+                stream.first_is_raw = false;
+            } else {
+                const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
+                bits = stream.last;
+                uint32_t header_bits, meaningful;
+                bool decode_value = true;
+                if ((top >> 12) == 0) {          // `0`: reuse the previous window
+                    header_bits = 1;
+                    meaningful = 32u - stream.leading - stream.trailing;
+                } else if ((top >> 11) == 2) {   // `10`: the value repeats
+                    header_bits = 2;
+                    meaningful = 0;
+                    decode_value = false;
+                } else {                         // `11` + 5 bits leading zeros + 6 bits length
+                    header_bits = 13;
+                    stream.leading = (top >> 6) & 31u;
+                    meaningful = top & 63u;
+                    stream.trailing = 32u - meaningful - stream.leading;
+                }
+                if (decode_value && (meaningful > 32u || stream.trailing > 31u)) {
+                    error |= ERR_BITSTREAM; // malformed stream: stop after this value
+                    meaningful = 0;
+                    decode_value = false;
+                    stream.remaining = 1;
+                    values_pending = false;
+                    residuals_pending = false;
+                }
+                reader.buffer <<= header_bits;
+                reader.available -= (int32_t)header_bits;
+                reader.used_bits += header_bits;
+                if (decode_value) {
+                    uint32_t value = reader.get(meaningful, ring, lane);
+                    value <<= (stream.trailing & 31u);
+                    bits = value ^ stream.last;
+                }
+            }
+            stream.last = bits;
+            out_val[o + stream.position] = __uint_as_float(bits);
+            stream.position += 1;
+            stream.remaining -= 1;
+            if (stream.remaining == 0) {
+                if (reader.overrun()) error |= ERR_BITSTREAM;
+                open_next_stream();
+            }
+        }
     }
     if (error) atomicOr(&header->error, error);
 }
@@ -459,9 +621,10 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts,
     const uint64_t n_serial = plan.host_header.n_serial;
     if (n_serial > 0) {
         LaunchTimer timer(ctx, "k_grid_serial");
-        hipLaunchKernelGGL(k_grid_serial, dim3((uint32_t)((n_serial + 255) / 256)), dim3(256), 0,
-                           ctx->stream, s, plan.desc, plan.offsets, plan.serial_ids, n_serial, out_ts,
-                           out_val, plan.header);
+        hipLaunchKernelGGL(k_grid_serial,
+                           dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+                           dim3(SERIAL_THREADS), 0, ctx->stream, s, plan.desc, plan.offsets,
+                           plan.serial_ids, n_serial, out_ts, out_val, plan.header);
     }
     uint32_t late_error = 0;
     MDB_HIP_CHECK(hipMemcpyAsync(&late_error, &plan.header->error, 4, hipMemcpyDeviceToHost,
