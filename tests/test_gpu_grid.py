@@ -149,3 +149,43 @@ def test_grid_full_size_properties(hip):
     approx = values.reshape(n_series, n_points)
     relative = np.abs((raw - approx) / raw) * np.float32(100.0)
     assert (relative <= np.float32(1.0)).all()
+
+
+def test_config1_one_series_one_million_points_lossless(hip):
+    # BASELINE configs[0]: 1 univariate series, 1M regular-timestamp f32 points, lossless,
+    # compress + grid. Chunked like the reference server (65 536 point buffers).
+    import datagen
+    n = 1_000_000
+    timestamps, values = datagen.sine_series(0, n)
+    offsets = np.arange(0, n + 65536, 65536, dtype=np.uint64)
+    offsets[-1] = n
+    expected_segments = ora.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
+    segments = hip.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
+    assert segments.rows() == expected_segments.rows()
+    assert len(segments) == 16 and set(segments.model_type_id.tolist()) == {2}
+    ts, reconstructed, rows, metrics = hip.grid_batch(segments)
+    assert np.array_equal(ts, timestamps)
+    assert np.array_equal(reconstructed.view(np.uint32), values.view(np.uint32))  # lossless
+    assert metrics["rows_created_by_macaque_v"] == n
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    state, reference = hip.agg_batch(segments, mask), ora.agg_batch(segments, mask)
+    assert (state.count, state.min, state.max) == (n, values.min(), values.max())
+    assert abs(state.sum - reference.sum) <= 1e-5 * abs(reference.sum)
+
+
+def test_random_bit_patterns_survive_lossless_round_trip(hip):
+    # Any f32 bit pattern (NaN payloads, subnormals, infinities) must come back bit for bit
+    # (the reference's proptests use ProptestValue::ANY: macaque_v.rs:436-475, pmc_mean.rs:141-152).
+    rng = np.random.default_rng(101)
+    for n in (1, 2, 3, 9, 64, 300, 5000):
+        values = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        timestamps = np.arange(n, dtype=np.int64) * 100
+        segments = hip.try_compress_univariate_time_series(timestamps, values, cases.LOSSLESS)
+        assert segments.rows()[0][:3] == ora.try_compress_univariate_time_series(
+            timestamps, values, cases.LOSSLESS).rows()[0][:3]
+        ts, reconstructed, _, _ = hip.grid_batch(segments)
+        assert np.array_equal(ts, timestamps)
+        got, want = reconstructed.view(np.uint32), values.view(np.uint32)
+        nan = np.isnan(values)
+        assert np.array_equal(got[~nan], want[~nan])
+        assert np.isnan(reconstructed[nan]).all()   # NaNs stay NaNs (PMC/Swing may canonicalise payloads)
