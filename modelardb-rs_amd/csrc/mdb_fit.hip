@@ -292,9 +292,8 @@ __device__ __forceinline__ float rewrite_least_mantissa_bits(mdb_error_bound eb,
     float factorized_epsilon = abs_error_bound / ldexpf(1.0f, exponent);
     // (float)log2((double)x): correctly rounded log2f, the same definition the oracle uses.
     float magnitude = floorf(fabsf((float)log2((double)factorized_epsilon)));
-    int position = (int)(23ll - (long long)saturating_f32_to_i32(magnitude) < -2147483647ll
-                             ? -2147483647ll
-                             : 23ll - (long long)saturating_f32_to_i32(magnitude));
+    long long wide_position = 23ll - (long long)saturating_f32_to_i32(magnitude);
+    int position = wide_position < -2147483647ll ? -2147483647 : (int)wide_position;
     auto rewrite = [](uint32_t b, int pos) -> uint32_t {
         if (pos < 0) pos = 0; // clamp instead of wrapping the shift
         if (pos > 31) return 0u;

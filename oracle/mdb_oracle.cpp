@@ -477,7 +477,14 @@ struct MacaqueV {
         float abs_error_bound = (float)max_allowed_deviation(eb, (double)value);
         int exponent = (int)((bits >> 23) & 0xff) - 127;
         float factorized_epsilon = abs_error_bound / std::ldexp(1.0f, exponent); /* 2f32.powi(e) */
-        int position = 23 - (int)std::floor(std::fabs(log2_f32(factorized_epsilon)));
+        /* Rust's `as i32` saturates (and maps NaN to 0); a plain C cast of inf would be undefined.
+         * A non-finite magnitude arises when the deviation underflows to 0 for subnormal values. */
+        const float magnitude = std::floor(std::fabs(log2_f32(factorized_epsilon)));
+        long long saturated = magnitude != magnitude ? 0
+                              : magnitude >= 2147483648.0f ? 2147483647LL
+                              : magnitude <= -2147483648.0f ? -2147483648LL : (long long)magnitude;
+        long long wide_position = 23 - saturated;
+        int position = wide_position < -2147483647LL ? -2147483647 : (int)wide_position;
         auto rewrite = [](uint32_t b, int pos) {
             if (pos < 0) pos = 0; /* SURVEY A.6 Q4 */
             if (pos > 31) return 0u;

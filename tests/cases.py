@@ -61,6 +61,8 @@ def edge_case_series():
          np.concatenate([50.0 - np.arange(12) * 2.0, [-3.4028235e38, 3.4028235e38]])),
         ("big_bucket_timestamps", [0, 5, 5 + 70, 5 + 70 + 300, 700 + 2500, 3200 + 3_000_000_000,
                                    3_000_003_300 + (1 << 40), (1 << 41)], np.arange(8) * 1.0),
+        ("tiny_values", np.arange(12) * 100, [1e-45, 2e-45, 1.1754942e-38, 3e-39, -1e-41, 0.0, 5e-40,
+                                              1e-30, 1e-45, 37.0, -1e-38, 2.5e-38]),
         ("epoch_regular", np.arange(500) * 1000 + 1658671178037,
          100.0 + np.sin(np.arange(500) / 20.0)),
     ]

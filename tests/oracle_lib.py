@@ -14,7 +14,8 @@ from modelardb_rs_amd import _abi
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(REPO_ROOT, "oracle")
-ORACLE_PATH = os.path.join(ORACLE_DIR, "libmdb_oracle.so")
+# MDB_ORACLE_LIB selects another build of the oracle (e.g. the ASan/UBSan one: `make -C oracle asan`).
+ORACLE_PATH = os.environ.get("MDB_ORACLE_LIB", os.path.join(ORACLE_DIR, "libmdb_oracle.so"))
 
 
 class OracleError(RuntimeError):

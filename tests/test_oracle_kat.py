@@ -654,3 +654,21 @@ def test_segment_aggregates_match_grid_aggregates():
         assert on_segments.min == on_points.min
         assert on_segments.max == on_points.max
         assert abs(on_segments.sum - on_points.sum) <= 1e-5 * abs(on_points.sum)
+
+
+def test_macaque_v_lossy_subnormal_and_tiny_values():
+    # The deviation of a subnormal value underflows to 0, log2(0) is -inf and Rust's saturating
+    # `as i32` turns the rewrite position into a huge negative number (macaque_v.rs:185); the oracle
+    # clamps it. Around the subnormal boundary the reference's second, unchecked
+    # rewrite (macaque_v.rs:190-193) can leave the relative bound (e.g. 1.1754942e-38 -> 1.102e-38
+    # under 5 %): that is the reference's behaviour and is restated, not repaired. What must hold:
+    # no undefined behaviour, a decodable stream, and normal-range values within the bound.
+    values = np.array([1e-45, 2e-45, 1.1754942e-38, 3e-39, -1e-41, 0.0, 5e-40, 1e-30, 1e-45, 37.0],
+                      dtype=np.float32)
+    for eb in (REL_FIVE, REL_TEN, error_bound("absolute", 1e-30)):
+        data, mn, mx, _, _, _ = ora.macaque_v_compress(eb, values)
+        decoded = ora.macaque_v_grid(data, len(values))
+        assert decoded.min() == mn and decoded.max() == mx   # min/max are of the STORED values
+        for real, approximate in zip(values, decoded):
+            if abs(real) >= 1e-30:
+                assert ora.is_value_within_error_bound(eb, float(real), float(approximate))
