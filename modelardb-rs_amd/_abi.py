@@ -10,7 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-HIP_LIBRARY_PATH = os.path.join(_HERE, "csrc", "libmdb_hip.so")
+# MDB_HIP_LIBRARY selects another build of the same library (A/B timing of kernel variants).
+HIP_LIBRARY_PATH = os.environ.get("MDB_HIP_LIBRARY", os.path.join(_HERE, "csrc", "libmdb_hip.so"))
 
 MDB_PMC_MEAN_ID = 0
 MDB_SWING_ID = 1
