@@ -42,7 +42,7 @@ def parse_args():
     parser.add_argument("--series", type=int, default=1000)
     parser.add_argument("--points", type=int, default=10_000_000)
     parser.add_argument("--error-bound", type=float, default=1.0, help="relative bound in percent")
-    parser.add_argument("--cpu-sample-series", type=int, default=8)
+    parser.add_argument("--cpu-sample-series", type=int, default=48)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--fit-group-points", type=int, default=12_000_000_000,
                         help="at most this many raw points (4 B each) are resident per fit launch")
