@@ -5,7 +5,7 @@ The directory name carries the reference's repository name, so it is imported ei
 ``importlib.import_module("modelardb-rs_amd")``.
 """
 
-from . import _abi, api, host, segments, sharding  # noqa: F401
+from . import _abi, api, host, segment_files, segments, sharding  # noqa: F401
 from ._abi import (  # noqa: F401
     MDB_AGG_AVG, MDB_AGG_COUNT, MDB_AGG_MAX, MDB_AGG_MIN, MDB_AGG_SUM, MDB_MACAQUE_V_ID,
     MDB_PMC_MEAN_ID, MDB_SWING_ID, MODEL_TYPE_NAMES, load_hip_library,

@@ -838,6 +838,124 @@ std::vector<RecordBatch> try_compress_multivariate_time_series(mdb_ctx *ctx,
     return result;
 }
 
+// ---- UncompressedDataManager --------------------------------------------------------------------------------
+
+UncompressedDataManager::UncompressedDataManager(mdb_ctx *ctx, TimeSeriesTableMetadata metadata,
+                                                 size_t buffer_capacity)
+    : ctx_(ctx), metadata_(std::move(metadata)), capacity_(buffer_capacity) {
+    if (capacity_ == 0) throw Error("The buffer capacity must be positive.");
+}
+
+void UncompressedDataManager::insert_data_points(const RecordBatch &data_points) {
+    const Column &ts_column = *data_points.columns[metadata_.timestamp_column_index];
+    std::vector<const Column *> tags, fields;
+    for (size_t index : metadata_.tag_column_indices) tags.push_back(data_points.columns[index].get());
+    for (size_t index : metadata_.field_column_indices) fields.push_back(data_points.columns[index].get());
+    const uint64_t batch_index = current_batch_index_;
+    for (int64_t row = 0; row < data_points.num_rows; row++) {
+        // calculate_tag_hash stands in: the joined tag values identify the series.
+        std::string key;
+        for (const Column *tag : tags) {
+            key.append(tag->view_value(row));
+            key.push_back('\x1f');
+        }
+        auto it = std::find_if(active_.begin(), active_.end(), [&](const auto &kv) { return kv.first == key; });
+        if (it == active_.end()) {
+            Buffer buffer;
+            for (const Column *tag : tags) buffer.tag_values.emplace_back(tag->view_value(row));
+            buffer.values.resize(fields.size());
+            active_.emplace_back(key, std::move(buffer));
+            it = active_.end() - 1;
+        }
+        Buffer &buffer = it->second;
+        buffer.updated_by_batch_index = batch_index; // uncompressed_data_buffer.rs:141-158
+        buffer.timestamps.push_back(ts_column.as<int64_t>()[row]);
+        for (size_t f = 0; f < fields.size(); f++) buffer.values[f].push_back(fields[f]->as<float>()[row]);
+        if (buffer.timestamps.size() == capacity_) { // is_full(): transfer to the compressor (:301-318)
+            finished_.push_back(std::move(buffer));
+            active_.erase(it);
+        }
+    }
+    // Unused buffers are only finished at the end so buffers needed by this batch survive (:170-174).
+    // fetch_add(1) hands finish_unused_buffers the index of the batch just ingested (:175-176).
+    current_batch_index_ += 1;
+    finish_unused_buffers(batch_index);
+}
+
+void UncompressedDataManager::finish_unused_buffers(uint64_t current_batch_index) {
+    // is_unused(): updated_by_batch_index + RECORD_BATCH_OFFSET_REQUIRED_FOR_UNUSED <= current (:135-137)
+    for (size_t i = 0; i < active_.size();) {
+        if (active_[i].second.updated_by_batch_index + 1 <= current_batch_index) {
+            finished_.push_back(std::move(active_[i].second));
+            active_.erase(active_.begin() + static_cast<std::ptrdiff_t>(i));
+        } else {
+            i++;
+        }
+    }
+}
+
+void UncompressedDataManager::flush() {
+    for (auto &kv : active_) finished_.push_back(std::move(kv.second));
+    active_.clear();
+}
+
+std::vector<RecordBatch> UncompressedDataManager::compress_finished_buffers() {
+    const size_t n_fields = metadata_.field_column_indices.size();
+    std::vector<RecordBatch> result(finished_.size() * n_fields);
+    // record_batch(): sort each buffer by time (sort_to_indices + take).
+    std::vector<std::vector<int64_t>> order(finished_.size());
+    for (size_t b = 0; b < finished_.size(); b++) {
+        order[b].resize(finished_[b].timestamps.size());
+        std::iota(order[b].begin(), order[b].end(), 0);
+        const std::vector<int64_t> &ts = finished_[b].timestamps;
+        std::stable_sort(order[b].begin(), order[b].end(), [&](int64_t x, int64_t y) { return ts[x] < ts[y]; });
+    }
+    // Fields that share an error bound share a launch: chunk = (finished buffer, field).
+    std::vector<bool> done(n_fields, false);
+    for (size_t f0 = 0; f0 < n_fields; f0++) {
+        if (done[f0]) continue;
+        const mdb_error_bound bound = metadata_.error_bounds[metadata_.field_column_indices[f0]].c;
+        std::vector<size_t> group;
+        for (size_t f = f0; f < n_fields; f++) {
+            const mdb_error_bound other = metadata_.error_bounds[metadata_.field_column_indices[f]].c;
+            if (!done[f] && other.kind == bound.kind && (bound.kind == MDB_EB_LOSSLESS || other.value == bound.value)) {
+                group.push_back(f);
+                done[f] = true;
+            }
+        }
+        std::vector<int64_t> chunk_ts;
+        std::vector<float> chunk_values;
+        std::vector<uint64_t> offsets = {0};
+        for (size_t b = 0; b < finished_.size(); b++) {
+            for (size_t f : group) {
+                for (int64_t i : order[b]) {
+                    chunk_ts.push_back(finished_[b].timestamps[static_cast<size_t>(i)]);
+                    chunk_values.push_back(finished_[b].values[f][static_cast<size_t>(i)]);
+                }
+                offsets.push_back(chunk_ts.size());
+            }
+        }
+        OwnedGuard guard;
+        check(mdb_compress_chunks(ctx_, chunk_ts.data(), chunk_values.data(), offsets.data(), offsets.size() - 1,
+                                  bound, &guard.owned));
+        uint64_t row = 0;
+        const uint64_t total = guard.owned->seg.n;
+        uint32_t chunk = 0;
+        for (size_t b = 0; b < finished_.size(); b++) {
+            for (size_t f : group) {
+                uint64_t first = row;
+                while (row < total && guard.owned->chunk_index[row] == chunk) row++;
+                result[b * n_fields + f] = record_batch_from_owned(
+                    guard.owned, first, row, metadata_.compressed_schema, finished_[b].tag_values,
+                    static_cast<int16_t>(metadata_.field_column_indices[f]));
+                chunk++;
+            }
+        }
+    }
+    finished_.clear();
+    return result;
+}
+
 } // namespace mdbhost
 
 // =================================================================================================
@@ -1055,5 +1173,59 @@ int mdbh_batches_get(void *handle, int32_t index, ArrowArray *out_array, ArrowSc
 }
 
 void mdbh_batches_free(void *handle) { delete static_cast<std::vector<mdbhost::RecordBatch> *>(handle); }
+
+/* ---- UncompressedDataManager ---- */
+int mdbh_udm_create(mdb_ctx *ctx, int32_t timestamp_column, const int32_t *field_columns, int32_t n_fields,
+                    const int32_t *tag_columns, const char *const *tag_names, int32_t n_tags,
+                    const mdb_error_bound *error_bounds, int32_t n_columns, uint64_t capacity, void **out) {
+    return guarded([&] {
+        using namespace mdbhost;
+        TimeSeriesTableMetadata metadata;
+        metadata.timestamp_column_index = static_cast<size_t>(timestamp_column);
+        for (int32_t i = 0; i < n_fields; i++) metadata.field_column_indices.push_back(static_cast<size_t>(field_columns[i]));
+        std::vector<std::string> names;
+        for (int32_t i = 0; i < n_tags; i++) {
+            metadata.tag_column_indices.push_back(static_cast<size_t>(tag_columns[i]));
+            names.emplace_back(tag_names[i]);
+        }
+        for (int32_t c = 0; c < n_columns; c++) {
+            ErrorBound eb;
+            eb.c = error_bounds[c];
+            metadata.error_bounds.push_back(eb);
+        }
+        metadata.compressed_schema = compressed_schema(names);
+        *out = new UncompressedDataManager(ctx, metadata, capacity);
+    });
+}
+
+int mdbh_udm_insert_data_points(void *handle, ArrowArray *array, ArrowSchema *schema) {
+    return guarded([&] {
+        static_cast<mdbhost::UncompressedDataManager *>(handle)->insert_data_points(
+            mdbhost::import_record_batch(array, schema));
+    });
+}
+
+int mdbh_udm_flush(void *handle) {
+    return guarded([&] { static_cast<mdbhost::UncompressedDataManager *>(handle)->flush(); });
+}
+
+int mdbh_udm_counts(void *handle, uint64_t *active, uint64_t *finished) {
+    return guarded([&] {
+        auto *manager = static_cast<mdbhost::UncompressedDataManager *>(handle);
+        *active = manager->active_buffer_count();
+        *finished = manager->finished_buffer_count();
+    });
+}
+
+int mdbh_udm_compress_finished_buffers(void *handle, void **out_batches, int32_t *n_batches) {
+    return guarded([&] {
+        auto *result = new std::vector<mdbhost::RecordBatch>(
+            static_cast<mdbhost::UncompressedDataManager *>(handle)->compress_finished_buffers());
+        *out_batches = result;
+        *n_batches = static_cast<int32_t>(result->size());
+    });
+}
+
+void mdbh_udm_free(void *handle) { delete static_cast<mdbhost::UncompressedDataManager *>(handle); }
 
 } // extern "C"

@@ -259,4 +259,43 @@ std::vector<RecordBatch> try_compress_multivariate_time_series(mdb_ctx *ctx,
                                                                const TimeSeriesTableMetadata &metadata,
                                                                const RecordBatch &uncompressed_time_series);
 
+// ---- ingest-side batching ---------------------------------------------------------------------
+
+// The compress side of UncompressedDataManager (crates/modelardb_server/src/storage/
+// uncompressed_data_manager.rs:130-189, 197-322, 405-451, 530-596) with one change: finished buffers
+// are not compressed one at a time on one thread but collected and handed to the GPU together, all
+// series x fields as the chunks of ONE mdb_compress_chunks launch per error bound. Memory pool,
+// spilling to Parquet, WAL batch ids and channels are out of scope (durability / host orchestration).
+class UncompressedDataManager {
+  public:
+    // UNCOMPRESSED_DATA_BUFFER_CAPACITY = 64 * 1024 (storage/mod.rs:58).
+    UncompressedDataManager(mdb_ctx *ctx, TimeSeriesTableMetadata metadata,
+                            size_t buffer_capacity = MDB_UNCOMPRESSED_DATA_BUFFER_CAPACITY);
+    // One ingested batch: every row goes to the buffer of its tag values; a buffer that becomes full
+    // is finished; afterwards buffers not touched by this batch are finished
+    // (RECORD_BATCH_OFFSET_REQUIRED_FOR_UNUSED = 1, storage/uncompressed_data_buffer.rs:42,135-137).
+    void insert_data_points(const RecordBatch &data_points);
+    void flush(); // StorageEngine::flush: finish every active buffer
+    size_t active_buffer_count() const { return active_.size(); }
+    size_t finished_buffer_count() const { return finished_.size(); }
+    // Compress every finished buffer (sorted by time first, uncompressed_data_buffer.rs:175-209).
+    // Returns, per finished buffer in finish order, one RecordBatch per field column.
+    std::vector<RecordBatch> compress_finished_buffers();
+
+  private:
+    struct Buffer {
+        std::vector<std::string> tag_values;
+        std::vector<int64_t> timestamps;
+        std::vector<std::vector<float>> values; // per field
+        uint64_t updated_by_batch_index = 0;
+    };
+    void finish_unused_buffers(uint64_t current_batch_index);
+    mdb_ctx *ctx_;
+    TimeSeriesTableMetadata metadata_;
+    size_t capacity_;
+    uint64_t current_batch_index_ = 0;
+    std::vector<std::pair<std::string, Buffer>> active_; // keyed by the joined tag values
+    std::vector<Buffer> finished_;
+};
+
 } // namespace mdbhost

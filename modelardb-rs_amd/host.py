@@ -45,6 +45,7 @@ def lib():
         _lib.mdbh_grid_stream_free.restype = None
         _lib.mdbh_accumulator_free.restype = None
         _lib.mdbh_batches_free.restype = None
+        _lib.mdbh_udm_free.restype = None
     return _lib
 
 
@@ -241,3 +242,55 @@ def try_compress_multivariate_time_series(context, batch, timestamp_column, fiel
         return out
     finally:
         lib().mdbh_batches_free(handle)
+
+
+class UncompressedDataManager:
+    """The compress side of crates/modelardb_server/src/storage/uncompressed_data_manager.rs with
+    finished buffers compressed together in one GPU launch per error bound."""
+
+    def __init__(self, context, schema, timestamp_column, field_columns, tag_columns, error_bounds,
+                 buffer_capacity=65536):
+        self.handle = C.c_void_p()
+        bounds = (_abi.ErrorBoundC * len(schema.names))()
+        for index in range(len(schema.names)):
+            bounds[index] = error_bounds.get(index, _abi.ErrorBoundC(_abi.MDB_EB_LOSSLESS, 0.0))
+        fields = (C.c_int32 * len(field_columns))(*field_columns)
+        tags = (C.c_int32 * max(len(tag_columns), 1))(*tag_columns)
+        names, self._keep = _strings([schema.names[i] for i in tag_columns])
+        _check(lib().mdbh_udm_create(context.handle, C.c_int32(timestamp_column), fields,
+                                     C.c_int32(len(field_columns)), tags, names,
+                                     C.c_int32(len(tag_columns)), bounds, C.c_int32(len(schema.names)),
+                                     C.c_uint64(buffer_capacity), C.byref(self.handle)))
+
+    def insert_data_points(self, batch):
+        array, schema = _export(batch)
+        _check(lib().mdbh_udm_insert_data_points(self.handle, C.byref(array), C.byref(schema)))
+
+    def flush(self):
+        _check(lib().mdbh_udm_flush(self.handle))
+
+    def counts(self):
+        active, finished = C.c_uint64(), C.c_uint64()
+        _check(lib().mdbh_udm_counts(self.handle, C.byref(active), C.byref(finished)))
+        return active.value, finished.value
+
+    def compress_finished_buffers(self):
+        handle, n = C.c_void_p(), C.c_int32()
+        _check(lib().mdbh_udm_compress_finished_buffers(self.handle, C.byref(handle), C.byref(n)))
+        try:
+            out = []
+            for index in range(n.value):
+                out_array, out_schema = ArrowArrayC(), ArrowSchemaC()
+                _check(lib().mdbh_batches_get(handle, C.c_int32(index), C.byref(out_array),
+                                              C.byref(out_schema)))
+                out.append(_import_batch(out_array, out_schema))
+            return out
+        finally:
+            lib().mdbh_batches_free(handle)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().mdbh_udm_free(self.handle)
+        except Exception:
+            pass

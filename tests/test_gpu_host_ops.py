@@ -229,3 +229,92 @@ def test_try_compress_multivariate_sorts_splits_and_compresses(hip):  # compress
             expected = ora.try_compress_univariate_time_series(ts, values, bounds[field_index])
             got_segments = mdb.SegmentBatch.from_arrow(got)
             assert got_segments.rows() == expected.rows()
+
+
+def test_uncompressed_data_manager_compresses_finished_buffers_in_one_launch(hip):
+    # N4: many series' finished buffers x fields -> one mdb_compress_chunks call per error bound;
+    # the result must equal the reference's per-buffer, per-field compression of the time-sorted
+    # buffer (uncompressed_data_manager.rs:530-596, uncompressed_data_buffer.rs:175-209).
+    rng = np.random.default_rng(111)
+    n_series, n_points, capacity = 5, 3000, 1024
+    data = {}
+    rows = []
+    for s in range(n_series):
+        ts, v1 = cases.synthetic_series(n_points, s % 2 == 1, (1.0, 1.05), 600 + s)
+        _, v2 = datagen.sine_series(s, n_points)
+        data[f"series-{s}"] = (ts, v1, v2)
+    # ingest batches of 500 points per series
+    bounds = {1: mdb.error_bound("relative", 5.0), 2: mdb.error_bound("relative", 5.0)}
+    manager = None
+    expected = []
+    for start in range(0, n_points, 500):
+        cols = {"timestamp": [], "field_1": [], "field_2": [], "tag": []}
+        for tag, (ts, v1, v2) in data.items():
+            cols["timestamp"].append(ts[start:start + 500])
+            cols["field_1"].append(v1[start:start + 500])
+            cols["field_2"].append(v2[start:start + 500])
+            cols["tag"] += [tag] * 500
+        # Series interleaved row by row (each series stays in time order, as a sensor would send it).
+        order = np.arange(500 * n_series).reshape(n_series, 500).T.ravel()
+        batch = pa.RecordBatch.from_arrays([
+            pa.array(np.concatenate(cols["timestamp"])[order], type=pa.int64()).cast(pa.timestamp("us")),
+            pa.array(np.concatenate(cols["field_1"])[order], type=pa.float32()),
+            pa.array(np.concatenate(cols["field_2"])[order], type=pa.float32()),
+            pa.array(np.array(cols["tag"])[order], type=pa.string_view())],
+            names=["timestamp", "field_1", "field_2", "tag"])
+        if manager is None:
+            manager = host.UncompressedDataManager(hip, batch.schema, 0, [1, 2], [3], bounds,
+                                                   buffer_capacity=capacity)
+        manager.insert_data_points(batch)
+    manager.flush()
+    active, finished = manager.counts()
+    assert active == 0 and finished == n_series * ((n_points + capacity - 1) // capacity)
+    compressed = manager.compress_finished_buffers()
+    assert len(compressed) == finished * 2
+    assert manager.counts() == (0, 0)
+    # Every (series, field): the concatenation of its buffers' segments reconstructs the series.
+    per_key = {}
+    for batch in compressed:
+        if batch.num_rows == 0:
+            continue
+        key = (batch.column("tag")[0].as_py(), batch.column("field_column")[0].as_py())
+        per_key.setdefault(key, []).append(batch)
+    assert len(per_key) == n_series * 2
+    for (tag, field), batches in per_key.items():
+        ts, v1, v2 = data[tag]
+        values = v1 if field == 1 else v2
+        segments = mdb.SegmentBatch.concat(
+            [mdb.SegmentBatch.from_arrow(b) for b in sorted(
+                batches, key=lambda b: b.column("start_time").cast(pa.int64())[0].as_py())])
+        got_ts, got_values, _, _ = ora.grid_batch(segments)
+        assert np.array_equal(got_ts, ts)
+        within = np.abs((values - got_values) / values) * np.float32(100.0) <= np.float32(5.0)
+        assert within.all() or np.isclose(values[~within], got_values[~within]).all()
+        # and buffer by buffer it equals the oracle's compression of that time-sorted buffer
+        for b in batches:
+            first = b.column("start_time").cast(pa.int64())[0].as_py()
+            last = b.column("end_time").cast(pa.int64())[b.num_rows - 1].as_py()
+            lo, hi = np.searchsorted(ts, first), np.searchsorted(ts, last) + 1
+            oracle = ora.try_compress_univariate_time_series(ts[lo:hi], values[lo:hi], bounds[field])
+            assert mdb.SegmentBatch.from_arrow(b).rows() == oracle.rows()
+
+
+def test_segment_files_to_device_and_grid(hip, tmp_path):
+    # N2: whole Parquet segment files -> one device batch -> grid, equal to the oracle.
+    from modelardb_rs_amd import segment_files
+    _, _, batch = _series(67)
+    arrow = host.segments_with_tags(batch.to_arrow(), {"tag": "T"})
+    paths = [segment_files.write_segment_file(str(tmp_path / f"part-{k}.parquet"), part)
+             for k, part in enumerate((arrow.slice(0, 100), arrow.slice(100)))]
+    device_segments, tags = segment_files.load_segments(hip, paths)
+    assert tags.column("tag").to_pylist() == ["T"] * len(batch)
+    total = hip.grid_count_dev(device_segments)
+    out_ts, out_val = hip.dev_alloc(8 * total), hip.dev_alloc(4 * total)
+    hip.grid_batch_dev(device_segments, out_ts, out_val, total)
+    expected = ora.grid_batch(batch)
+    assert np.array_equal(hip.download_array(out_ts, total, np.int64), expected[0])
+    assert np.array_equal(hip.download_array(out_val, total, np.float32).view(np.uint32),
+                          expected[1].view(np.uint32))
+    hip.dev_free(out_ts)
+    hip.dev_free(out_val)
+    device_segments.free()

@@ -45,3 +45,28 @@ def test_unknown_aggregate_is_not_supported():
     handle = C.c_void_p()
     assert host.lib().mdbh_accumulator_create(None, C.c_int32(9), C.byref(handle)) == 1
     assert b"not supported" in host.lib().mdbh_last_error()
+
+
+def test_uncompressed_data_manager_buffers_by_series_and_finishes_unused():
+    # storage/uncompressed_data_manager.rs:130-189, 405-451 and uncompressed_data_buffer.rs:135-137:
+    # a buffer is finished when full or when an ingested batch does not touch it.
+    import pyarrow as pa
+    schema_names = ["timestamp", "field_1", "tag"]
+
+    def batch(rows):
+        return pa.RecordBatch.from_arrays([
+            pa.array([r[0] for r in rows], type=pa.int64()).cast(pa.timestamp("us")),
+            pa.array([r[1] for r in rows], type=pa.float32()),
+            pa.array([r[2] for r in rows], type=pa.string_view())], names=schema_names)
+
+    first = batch([(100, 1.0, "A"), (100, 2.0, "B"), (200, 1.5, "A")])
+    manager = host.UncompressedDataManager(_NullContext(), first.schema, 0, [1], [2], {},
+                                           buffer_capacity=4)
+    manager.insert_data_points(first)
+    assert manager.counts() == (2, 0)                      # A and B active
+    manager.insert_data_points(batch([(300, 1.7, "A")]))
+    assert manager.counts() == (1, 1)                      # B was not touched -> finished
+    manager.insert_data_points(batch([(400, 1.9, "A"), (500, 2.0, "A")]))
+    assert manager.counts() == (1, 2)                      # A reached capacity 4 -> finished; new A buffer
+    manager.flush()
+    assert manager.counts() == (0, 3)
