@@ -79,7 +79,10 @@ int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float 
                    mdb_grid_metrics *metrics);
 
 /* Device resident variant: `in` holds device pointers (e.g. from mdb_segments_upload or
- * mdb_compress_chunks_dev), outputs are device buffers. */
+ * mdb_compress_chunks_dev), outputs are device buffers. out_ts may be NULL: then only the values
+ * are reconstructed, which is what a join of several field columns of the same series needs for
+ * every field after the first (SortedJoinExec zips per-field GridExec outputs that share their
+ * timestamps, crates/modelardb_storage/src/query/sorted_join_exec.rs:252-310). */
 int mdb_grid_count_dev(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out);
 int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
                        uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,

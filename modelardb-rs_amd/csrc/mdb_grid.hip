@@ -277,6 +277,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
                 if (p + 2 < tile_end) out_val[p + 2] = v.z;
             }
         }
+        // A join of several field columns reconstructs the shared timestamps only once (N3).
+        if (out_ts == nullptr) continue;
         // Transpose the timestamps through LDS: lane l holds points 4l..4l+3 (chunks 2l, 2l+1 of
         // 16 bytes); store instruction A writes chunks 0..63, B writes chunks 64..127.
         longlong2 *slab = ts_slab[wave];
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
         const uint8_t *bytes = view_data(s.timestamps, i, vt);
         decode_irregular_timestamps(bytes, vt.x, d.start, s.end_time[i], 0xffffffffu, &error,
                                     [&](uint32_t k, int64_t t) {
-                                        out_ts[o + k] = t;
+                                        if (out_ts) out_ts[o + k] = t;
                                         if (k < d.n_model) {
                                             if (type == MDB_PMC_MEAN_ID) out_val[o + k] = d.value;
                                             else if (type == MDB_SWING_ID)
@@ -607,6 +609,7 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts,
     if (n_out) *n_out = total;
     fill_metrics(plan.host_header, metrics);
     if (total == 0) return 0;
+    if (!out_val) return fail("out_val must not be NULL.");
     if ((reinterpret_cast<uintptr_t>(out_ts) & 15u) || (reinterpret_cast<uintptr_t>(out_val) & 15u))
         return fail("Output buffers must be 16-byte aligned.");
     DevSegments s = to_dev(in);
@@ -655,7 +658,7 @@ int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, fl
                        uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
                        mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
-    if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
+    if (cap > 0 && !out_val) return fail("out_val must not be NULL.");
     std::lock_guard<std::mutex> lock(ctx->mutex);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return grid_batch_dev_locked(ctx, in, out_ts, out_val, out_rows_per_segment, cap, n_out, metrics);

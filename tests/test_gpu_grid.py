@@ -189,3 +189,26 @@ def test_random_bit_patterns_survive_lossless_round_trip(hip):
         nan = np.isnan(values)
         assert np.array_equal(got[~nan], want[~nan])
         assert np.isnan(reconstructed[nan]).all()   # NaNs stay NaNs (PMC/Swing may canonicalise payloads)
+
+
+def test_values_only_grid_for_joined_field_columns(hip):
+    # N3: two field columns of the same series share their timestamps; the second field's grid
+    # skips the timestamp stores (out_ts = NULL).
+    import datagen
+    eb = cases.error_bounds()["rel1"]
+    n = 50_000
+    timestamps = np.arange(n, dtype=np.int64) * 1000
+    fields = [ora.try_compress_univariate_time_series(timestamps, datagen.sine_series(s, n)[1], eb)
+              for s in (3, 4)]
+    devices = [hip.upload_segments(f) for f in fields]
+    out_ts = hip.dev_alloc(8 * n)
+    out_vals = [hip.dev_alloc(4 * n) for _ in fields]
+    assert hip.grid_batch_dev(devices[0], out_ts, out_vals[0], n)[0] == n
+    assert hip.grid_batch_dev(devices[1], None, out_vals[1], n)[0] == n
+    assert np.array_equal(hip.download_array(out_ts, n, np.int64), timestamps)
+    for field, pointer in zip(fields, out_vals):
+        expected = ora.grid_batch(field)[1]
+        assert np.array_equal(hip.download_array(pointer, n, np.float32).view(np.uint32),
+                              expected.view(np.uint32))
+    for pointer in [out_ts] + out_vals:
+        hip.dev_free(pointer)
