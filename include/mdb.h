@@ -88,6 +88,21 @@ int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, fl
                        uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
                        mdb_grid_metrics *metrics);
 
+/* Predicate pushdown: only the data points with t_lo <= timestamp <= t_hi are
+ * reconstructed. The reference's GridStream reconstructs every point of every segment the Parquet
+ * filter let through and prunes afterwards (grid_exec.rs:366-387); the result is the same rows in
+ * the same order. rows_per_segment and the row counters of `metrics` count the rows produced. */
+int mdb_grid_count_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                         uint64_t *n_out);
+int mdb_grid_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                         int64_t *out_ts, float *out_val, uint32_t *out_rows_per_segment, uint64_t cap,
+                         uint64_t *n_out, mdb_grid_metrics *metrics);
+int mdb_grid_count_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                             uint64_t *n_out);
+int mdb_grid_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                             int64_t *out_ts, float *out_val, uint32_t *out_rows_per_segment,
+                             uint64_t cap, uint64_t *n_out, mdb_grid_metrics *metrics);
+
 /* ---- aggregates: replaces Model{Count,Min,Max,Sum,Avg}Accumulator::update_batch
  *      (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:345-358, 395-401,
  *      438-444, 481-513, 553-587) which call modelardb_compression::{len,sum}

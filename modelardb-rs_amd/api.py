@@ -137,6 +137,38 @@ class Context:
             C.byref(n_out), C.byref(metrics)))
         return out_ts[: n_out.value], out_val[: n_out.value], rows, metrics.as_dict()
 
+    def grid_batch_range(self, batch, t_lo, t_hi):
+        """grid() with the predicate t_lo <= timestamp <= t_hi pushed down."""
+        seg = batch.as_c()
+        n_out = C.c_uint64()
+        self._check(self.lib.mdb_grid_count_range(self.handle, C.byref(seg), t_lo, t_hi,
+                                                  C.byref(n_out)))
+        cap = n_out.value
+        out_ts = np.empty(cap, dtype=np.int64)
+        out_val = np.empty(cap, dtype=np.float32)
+        rows = np.empty(len(batch), dtype=np.uint32)
+        metrics = _abi.GridMetricsC()
+        self._check(self.lib.mdb_grid_batch_range(
+            self.handle, C.byref(seg), t_lo, t_hi, out_ts.ctypes.data_as(C.c_void_p),
+            out_val.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), cap,
+            C.byref(n_out), C.byref(metrics)))
+        return out_ts[: n_out.value], out_val[: n_out.value], rows, metrics.as_dict()
+
+    def grid_batch_range_dev(self, dev_segments, t_lo, t_hi, out_ts_ptr, out_val_ptr, cap,
+                             rows_ptr=None):
+        n_out = C.c_uint64()
+        metrics = _abi.GridMetricsC()
+        self._check(self.lib.mdb_grid_batch_range_dev(
+            self.handle, C.byref(dev_segments.seg), t_lo, t_hi, C.c_void_p(out_ts_ptr),
+            C.c_void_p(out_val_ptr), C.c_void_p(rows_ptr), cap, C.byref(n_out), C.byref(metrics)))
+        return n_out.value, metrics.as_dict()
+
+    def grid_count_range_dev(self, dev_segments, t_lo, t_hi):
+        n_out = C.c_uint64()
+        self._check(self.lib.mdb_grid_count_range_dev(self.handle, C.byref(dev_segments.seg), t_lo,
+                                                      t_hi, C.byref(n_out)))
+        return n_out.value
+
     def grid_count_dev(self, dev_segments):
         n_out = C.c_uint64()
         self._check(self.lib.mdb_grid_count_dev(self.handle, C.byref(dev_segments.seg),

@@ -470,9 +470,15 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
     SegmentsView view;
     fill_segments_view(batch.columns, &view);
 
-    // One sizing call and one batch call replace the per-row loop of grid_exec.rs:323-356.
+    // One sizing call and one batch call replace the per-row loop of grid_exec.rs:323-356. A
+    // timestamp predicate is pushed down so out-of-range points are neither reconstructed nor
+    // copied over PCIe; the filter below then only has the leftovers to look at.
+    const bool pushdown = maybe_predicate_.has_value();
+    const int64_t t_lo = pushdown && maybe_predicate_->lower ? *maybe_predicate_->lower : INT64_MIN;
+    const int64_t t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
     uint64_t new_points = 0;
-    check(mdb_grid_count(ctx_, &view.seg, &new_points));
+    check(pushdown ? mdb_grid_count_range(ctx_, &view.seg, t_lo, t_hi, &new_points)
+                   : mdb_grid_count(ctx_, &view.seg, &new_points));
     const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
     const int64_t total = leftovers + static_cast<int64_t>(new_points);
     std::vector<int64_t> timestamps(static_cast<size_t>(total));
@@ -485,8 +491,11 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
     mdb_grid_metrics metrics;
     std::memset(&metrics, 0, sizeof(metrics));
     uint64_t produced = 0;
-    check(mdb_grid_batch(ctx_, &view.seg, timestamps.data() + leftovers, values.data() + leftovers,
-                         rows_per_segment.data(), new_points, &produced, &metrics));
+    check(pushdown ? mdb_grid_batch_range(ctx_, &view.seg, t_lo, t_hi, timestamps.data() + leftovers,
+                                          values.data() + leftovers, rows_per_segment.data(), new_points,
+                                          &produced, &metrics)
+                   : mdb_grid_batch(ctx_, &view.seg, timestamps.data() + leftovers, values.data() + leftovers,
+                                    rows_per_segment.data(), new_points, &produced, &metrics));
     metrics_->add(metrics);
 
     // Tag columns: the segment's tag value once per created row (grid_exec.rs:341-346). Views are

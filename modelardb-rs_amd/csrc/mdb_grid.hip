@@ -41,7 +41,7 @@ struct GridHeader {
 };
 
 __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
-    DevSegments s, SegDesc *__restrict__ desc, uint32_t *__restrict__ counts,
+    DevSegments s, TimeRange range, TileDesc *__restrict__ desc, uint32_t *__restrict__ counts,
     unsigned long long *__restrict__ block_points, unsigned long long *__restrict__ block_serial,
     GridHeader *__restrict__ header) {
     __shared__ unsigned long long lds_metrics[12];
@@ -56,17 +56,18 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         uint64_t i = base + (uint64_t)k * PREPASS_THREADS + threadIdx.x;
         if (i >= s.n) break;
         SegInfo info = analyse_segment(s, i);
+        if (range.enabled) apply_time_range(s, i, info, range);
         error |= info.error;
         const SegDesc &d = info.desc;
-        desc[i] = d;
+        desc[i] = make_tile_desc(d);
         bool is_serial = (d.flags & FLAG_SERIAL) != 0;
-        counts[i] = d.n_total | (is_serial ? SERIAL_BIT : 0u);
-        points += d.n_total;
+        counts[i] = d.n_visible | (is_serial ? SERIAL_BIT : 0u);
+        points += d.n_visible;
         serial += is_serial ? 1 : 0;
         uint32_t type = d.flags & FLAG_TYPE_MASK;
         if (type < 3) {
-            m[type] += d.n_total;  // rows_created_by_model_type
-            m[4 + type] += 1;      // segments_with_model_type
+            m[type] += d.n_visible; // rows_created_by_model_type
+            m[4 + type] += 1;       // segments_with_model_type
         }
         m[3] += (d.flags & FLAG_HAS_RESIDUALS) ? 1 : 0;
         m[7] += (d.flags & FLAG_REGULAR) ? 1 : 0;
@@ -173,7 +174,8 @@ struct PointValue {
     float v;
 };
 
-__device__ __forceinline__ PointValue reconstruct_point(const SegDesc &d, uint32_t index) {
+// `index` counts from the first VISIBLE point of the segment (TileDesc::start is that point).
+__device__ __forceinline__ PointValue reconstruct_point(const TileDesc &d, uint32_t index) {
     PointValue out;
     out.t = d.start + (int64_t)((uint64_t)index * (uint64_t)d.delta);
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
@@ -184,11 +186,11 @@ __device__ __forceinline__ PointValue reconstruct_point(const SegDesc &d, uint32
 constexpr int TILE_LDS_DESCS = 128; // descriptors of the first segments of a tile staged in LDS
 
 __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
-    const SegDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
     uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
     __shared__ uint32_t rel[TILE_LDS_SEGMENTS + 1]; // rel[k] = offsets[s0 + k] - tile_start, k >= 1
-    __shared__ __attribute__((aligned(16))) SegDesc lds_desc[TILE_LDS_DESCS];
+    __shared__ __attribute__((aligned(16))) TileDesc lds_desc[TILE_LDS_DESCS];
     __shared__ __attribute__((aligned(16))) longlong2 ts_slab[TILE_THREADS / MDB_WAVE][2 * MDB_WAVE];
     const uint64_t tile = blockIdx.x;
     const uint64_t tile_start = tile * TILE_POINTS;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     for (uint32_t k = threadIdx.x; k < min(n_in_tile, (uint32_t)TILE_LDS_DESCS); k += TILE_THREADS)
         lds_desc[k] = desc[s0 + k];
     __syncthreads();
-    auto descriptor = [&](uint32_t k) -> SegDesc { // k relative to s0
+    auto descriptor = [&](uint32_t k) -> TileDesc { // k relative to s0
         return k < TILE_LDS_DESCS ? lds_desc[k] : desc[s0 + k];
     };
     const int lane = threadIdx.x & (MDB_WAVE - 1);
@@ -235,9 +237,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
             }
             uint64_t segment_offset =
                 lo == 0 ? s0_offset : (use_lds ? tile_start + rel[lo] : (uint64_t)offsets[s0 + lo]);
-            SegDesc d = descriptor(lo);
+            TileDesc d = descriptor(lo);
             const uint32_t index = (uint32_t)(p - segment_offset);
-            if (index + 4 <= d.n_total) {
+            if (index + 4 <= d.n_points) {
                 // All four points in one segment: the common case.
                 PointValue q0 = reconstruct_point(d, index);
                 t[0] = q0.t; t[1] = q0.t + d.delta; t[2] = t[1] + d.delta; t[3] = t[2] + d.delta;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
                 }
             } else {
                 // The group straddles a segment boundary: walk point by point.
-                uint64_t next_offset = segment_offset + d.n_total;
+                uint64_t next_offset = segment_offset + d.n_points;
                 float values[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 1
                 for (uint32_t k = 0; k < 4; k++) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
                         lo += 1;
                         segment_offset = next_offset;
                         d = descriptor(lo);
-                        next_offset = segment_offset + d.n_total;
+                        next_offset = segment_offset + d.n_points;
                     }
                     PointValue point = reconstruct_point(d, (uint32_t)(q - segment_offset));
                     t[k] = point.t;
@@ -367,14 +369,14 @@ struct RingBitReader {
 
 struct MacaqueStream {
     uint32_t remaining;  // values still to decode
-    uint32_t position;   // where the next value goes, relative to the segment's first point
+    uint32_t position;   // index of the next value inside the whole segment
     uint32_t last;       // bits of the previous value
     uint32_t leading, trailing;
     bool first_is_raw;   // the next value is stored as 32 raw bits (macaque_v.rs:289-293)
 };
 
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
-    DevSegments s, const SegDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, int64_t *__restrict__ out_ts,
     float *__restrict__ out_val, GridHeader *__restrict__ header) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
@@ -384,30 +386,48 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint32_t i = present ? serial_ids[slot] : 0;
     SegDesc d;
     d.flags = 0; d.n_total = 0; d.n_model = 0; d.value = 0.0f; d.start = 0; d.delta = 0; d.slope = 0.0; d.intercept = 0.0;
-    if (present) d = desc[i];
+    d.first = 0; d.n_visible = 0;
+    uint32_t error = 0;
+    if (present) {
+        // The few segments with serial work are analysed again here rather than carrying the full
+        // descriptor (first visible index, whole-segment counts) through memory for all of them.
+        SegInfo info = analyse_segment(s, i);
+        if (range.enabled) apply_time_range(s, i, info, range);
+        d = info.desc;
+        error = info.error;
+    }
+    // Points [d.first, visible_end) of the segment are wanted; point f goes to o + (f - d.first).
+    const uint32_t visible_end = d.first + d.n_visible;
     const uint64_t o = present ? (uint64_t)offsets[i] : 0;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
-    uint32_t error = 0;
 
     if (present && !(d.flags & FLAG_REGULAR)) {
         // Irregular timestamps, and the model values that depend on them.
         const uint4 vt = s.timestamps.views[i];
         const uint8_t *bytes = view_data(s.timestamps, i, vt);
-        decode_irregular_timestamps(bytes, vt.x, d.start, s.end_time[i], 0xffffffffu, &error,
+        decode_irregular_timestamps(bytes, vt.x, d.start, s.end_time[i], visible_end, &error,
                                     [&](uint32_t k, int64_t t) {
-                                        if (out_ts) out_ts[o + k] = t;
+                                        if (k < d.first || k >= visible_end) return;
+                                        const uint64_t at = o + (k - d.first);
+                                        if (out_ts) out_ts[at] = t;
                                         if (k < d.n_model) {
-                                            if (type == MDB_PMC_MEAN_ID) out_val[o + k] = d.value;
+                                            if (type == MDB_PMC_MEAN_ID) out_val[at] = d.value;
                                             else if (type == MDB_SWING_ID)
-                                                out_val[o + k] = (float)(d.slope * (double)t + d.intercept);
+                                                out_val[at] = (float)(d.slope * (double)t + d.intercept);
                                         }
                                     });
     }
 
     // Up to two MacaqueV streams per segment: the model's values (type 2) and the residual tail.
+    // A stream is decoded from its beginning (the format has no random access) but only as far as
+    // the last wanted value; the model's values are also needed in full when residuals are wanted,
+    // because the residual stream is seeded with the model's last value.
     const uint32_t n_res = d.n_total - d.n_model;
-    bool values_pending = present && type == MDB_MACAQUE_V_ID && d.n_model > 0;
-    bool residuals_pending = present && n_res > 0;
+    const bool residuals_wanted = present && n_res > 0 && visible_end > d.n_model;
+    const uint32_t values_to_decode = residuals_wanted ? d.n_model : min(d.n_model, visible_end);
+    bool values_pending = present && type == MDB_MACAQUE_V_ID && d.n_model > 0 && d.n_visible > 0 &&
+                          (residuals_wanted || d.first < d.n_model);
+    bool residuals_pending = residuals_wanted;
     RingBitReader reader;
     reader.begin(nullptr, 0);
     MacaqueStream stream;
@@ -419,7 +439,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
             const uint4 vv = s.values.views[i];
             reader.begin(view_data(s.values, i, vv), vv.x);
             if (vv.x == 0) error |= ERR_BITSTREAM;
-            stream.remaining = d.n_model; stream.position = 0; stream.leading = 255; stream.trailing = 0;
+            stream.remaining = values_to_decode; stream.position = 0; stream.leading = 255; stream.trailing = 0;
             stream.first_is_raw = true;
             values_pending = false;
             active = vv.x != 0;
@@ -429,7 +449,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
             const uint4 vr = s.residuals.views[i];
             reader.begin(view_data(s.residuals, i, vr), vr.x - 1);
             if (vr.x < 2) error |= ERR_BITSTREAM;
-            stream.remaining = n_res; stream.position = d.n_model; stream.leading = 255; stream.trailing = 0;
+            stream.remaining = visible_end - d.n_model; stream.position = d.n_model;
+            stream.leading = 255; stream.trailing = 0;
             stream.first_is_raw = false;
             residuals_pending = false;
             active = vr.x >= 2;
@@ -502,7 +523,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
                 }
             }
             stream.last = bits;
-            out_val[o + stream.position] = __uint_as_float(bits);
+            if (stream.position >= d.first && stream.position < visible_end)
+                out_val[o + (stream.position - d.first)] = __uint_as_float(bits);
             stream.position += 1;
             stream.remaining -= 1;
             if (stream.remaining == 0) {
@@ -517,7 +539,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
 // ---- host side ---------------------------------------------------------------------------------
 
 struct GridPlan {
-    SegDesc *desc;
+    TileDesc *desc;
     uint32_t *counts;
     unsigned long long *offsets;
     unsigned long long *block_points;
@@ -532,15 +554,15 @@ struct GridPlan {
 // Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
 // capacity_tiles bounds the tile map: if the batch needs more the caller gets an error before any
 // out-of-bounds write can happen (tile map writes are guarded by the allocation made here).
-int grid_plan(mdb_ctx *ctx, const mdb_segments *in, uint32_t *rows_per_segment, bool want_tiles,
-              uint64_t cap_points, GridPlan *plan) {
+int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint32_t *rows_per_segment,
+              bool want_tiles, uint64_t cap_points, GridPlan *plan) {
     const uint64_t n = in->n;
     if (n > 0xfffffff0ull) return fail("Too many segments in one batch.");
     const uint32_t n_blocks = (uint32_t)((n + SEGS_PER_BLOCK - 1) / SEGS_PER_BLOCK);
     plan->n_blocks = n_blocks;
     void *p;
-    if (scratch_reserve(ctx, SCRATCH_DESC, n * sizeof(SegDesc), &p)) return 1;
-    plan->desc = static_cast<SegDesc *>(p);
+    if (scratch_reserve(ctx, SCRATCH_DESC, n * sizeof(TileDesc), &p)) return 1;
+    plan->desc = static_cast<TileDesc *>(p);
     if (scratch_reserve(ctx, SCRATCH_COUNTS, (n + 4) * 4, &p)) return 1;
     plan->counts = static_cast<uint32_t *>(p);
     if (scratch_reserve(ctx, SCRATCH_OFFSETS, (n + 1) * 8, &p)) return 1;
@@ -563,7 +585,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, uint32_t *rows_per_segment, 
     {
         LaunchTimer timer(ctx, "k_grid_prepass");
         hipLaunchKernelGGL(k_grid_prepass, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s,
-                           plan->desc, plan->counts, plan->block_points, plan->block_serial,
+                           range, plan->desc, plan->counts, plan->block_points, plan->block_serial,
                            plan->header);
     }
     {
@@ -600,11 +622,11 @@ void fill_metrics(const GridHeader &h, mdb_grid_metrics *m) {
     m->segments_irregular = h.metrics[8];
 }
 
-int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
-                          uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
+int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
+                          float *out_val, uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
                           mdb_grid_metrics *metrics) {
     GridPlan plan;
-    if (grid_plan(ctx, in, out_rows, true, cap, &plan)) return 1;
+    if (grid_plan(ctx, in, range, out_rows, true, cap, &plan)) return 1;
     const uint64_t total = plan.host_header.total_points;
     if (n_out) *n_out = total;
     fill_metrics(plan.host_header, metrics);
@@ -626,7 +648,7 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts,
         LaunchTimer timer(ctx, "k_grid_serial");
         hipLaunchKernelGGL(k_grid_serial,
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
-                           dim3(SERIAL_THREADS), 0, ctx->stream, s, plan.desc, plan.offsets,
+                           dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, out_ts, out_val, plan.header);
     }
     uint32_t late_error = 0;
@@ -642,40 +664,43 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts,
 
 using namespace mdb;
 
-extern "C" {
+namespace {
 
-int mdb_grid_count_dev(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
+const TimeRange NO_RANGE = {0, 0, 0};
+
+int grid_count_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
     if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
     std::lock_guard<std::mutex> lock(ctx->mutex);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     GridPlan plan;
-    if (grid_plan(ctx, in, nullptr, false, 0, &plan)) return 1;
+    if (grid_plan(ctx, in, range, nullptr, false, 0, &plan)) return 1;
     *n_out = plan.host_header.total_points;
     return 0;
 }
 
-int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
-                       uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
-                       mdb_grid_metrics *metrics) {
+int grid_batch_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
+                        float *out_val, uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                        mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
     if (cap > 0 && !out_val) return fail("out_val must not be NULL.");
     std::lock_guard<std::mutex> lock(ctx->mutex);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
-    return grid_batch_dev_locked(ctx, in, out_ts, out_val, out_rows_per_segment, cap, n_out, metrics);
+    return grid_batch_dev_locked(ctx, in, range, out_ts, out_val, out_rows_per_segment, cap, n_out,
+                                 metrics);
 }
 
-int mdb_grid_count(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
+int grid_count_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
     if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
     mdb_segments_owned *dev = nullptr;
     if (mdb_segments_upload(ctx, in, &dev)) return 1;
-    int rc = mdb_grid_count_dev(ctx, &dev->seg, n_out);
+    int rc = grid_count_dev_impl(ctx, &dev->seg, range, n_out);
     mdb_segments_free(dev);
     return rc;
 }
 
-int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
-                   uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
-                   mdb_grid_metrics *metrics) {
+int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
+                         float *out_val, uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                         mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
     if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
     mdb_segments_owned *dev = nullptr;
@@ -694,7 +719,7 @@ int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float 
         uint32_t *dev_rows = reinterpret_cast<uint32_t *>(base + ts_bytes + val_bytes);
         uint64_t total = 0;
         if (!rc)
-            rc = grid_batch_dev_locked(ctx, &dev->seg, dev_ts, dev_val,
+            rc = grid_batch_dev_locked(ctx, &dev->seg, range, dev_ts, dev_val,
                                        out_rows_per_segment ? dev_rows : nullptr, cap, &total, metrics);
         if (n_out) *n_out = total;
         auto copy_back = [&](void *dst, const void *src, uint64_t bytes) {
@@ -709,6 +734,54 @@ int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float 
     }
     mdb_segments_free(dev);
     return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int mdb_grid_count_dev(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
+    return grid_count_dev_impl(ctx, in, NO_RANGE, n_out);
+}
+
+int mdb_grid_batch_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                       uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                       mdb_grid_metrics *metrics) {
+    return grid_batch_dev_impl(ctx, in, NO_RANGE, out_ts, out_val, out_rows_per_segment, cap, n_out, metrics);
+}
+
+int mdb_grid_count(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
+    return grid_count_host_impl(ctx, in, NO_RANGE, n_out);
+}
+
+int mdb_grid_batch(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val,
+                   uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                   mdb_grid_metrics *metrics) {
+    return grid_batch_host_impl(ctx, in, NO_RANGE, out_ts, out_val, out_rows_per_segment, cap, n_out, metrics);
+}
+
+int mdb_grid_count_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                             uint64_t *n_out) {
+    return grid_count_dev_impl(ctx, in, TimeRange{t_lo, t_hi, 1}, n_out);
+}
+
+int mdb_grid_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                             int64_t *out_ts, float *out_val, uint32_t *out_rows_per_segment,
+                             uint64_t cap, uint64_t *n_out, mdb_grid_metrics *metrics) {
+    return grid_batch_dev_impl(ctx, in, TimeRange{t_lo, t_hi, 1}, out_ts, out_val, out_rows_per_segment, cap,
+                               n_out, metrics);
+}
+
+int mdb_grid_count_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
+                         uint64_t *n_out) {
+    return grid_count_host_impl(ctx, in, TimeRange{t_lo, t_hi, 1}, n_out);
+}
+
+int mdb_grid_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi, int64_t *out_ts,
+                         float *out_val, uint32_t *out_rows_per_segment, uint64_t cap, uint64_t *n_out,
+                         mdb_grid_metrics *metrics) {
+    return grid_batch_host_impl(ctx, in, TimeRange{t_lo, t_hi, 1}, out_ts, out_val, out_rows_per_segment, cap,
+                                n_out, metrics);
 }
 
 } // extern "C"

@@ -26,16 +26,81 @@ enum : uint32_t {
     ERR_TOO_LONG = 1u << 5,
 };
 
-struct SegDesc { // 48 bytes
+struct SegDesc { // what one lane knows about a segment (registers only)
     int64_t start;
     int64_t delta;
     double slope;
     double intercept;
-    uint32_t n_total;
-    uint32_t n_model;
-    float value; // PMC-Mean: the model value. Swing: the last reconstructed value (residual seed).
+    uint32_t n_total; // points of the whole segment
+    uint32_t n_model; // of which the model represents the first n_model; the rest are residuals
+    float value;      // PMC-Mean: the model value. Swing: the last reconstructed value (residual seed).
+    uint32_t flags;
+    uint32_t first;     // index of the first point inside the requested time range (0 without one)
+    uint32_t n_visible; // points this segment contributes to the output (n_total without a range)
+};
+
+// The 48 bytes k_grid_tiles reads per segment: the VISIBLE part of the segment, i.e. `start` is
+// already advanced to the first point inside the requested time range.
+struct TileDesc {
+    int64_t start;
+    int64_t delta;
+    double slope;
+    double intercept;
+    uint32_t n_points; // visible points
+    uint32_t n_model;  // how many of them the model represents
+    float value;
     uint32_t flags;
 };
+
+__device__ __forceinline__ TileDesc make_tile_desc(const SegDesc &d) {
+    TileDesc t;
+    t.start = d.start + (int64_t)((uint64_t)d.first * (uint64_t)d.delta);
+    t.delta = d.delta;
+    t.slope = d.slope;
+    t.intercept = d.intercept;
+    t.n_points = d.n_visible;
+    t.n_model = d.first < d.n_model ? min(d.n_model - d.first, d.n_visible) : 0u;
+    t.value = d.value;
+    t.flags = d.flags;
+    return t;
+}
+
+// Optional predicate lo <= timestamp <= hi pushed down into grid (grid_exec.rs:366-387 evaluates it
+// after reconstruction; here out-of-range points are never materialised).
+struct TimeRange {
+    int64_t lo;
+    int64_t hi;
+    int32_t enabled;
+};
+
+// Index interval [k_lo, k_hi] of the points start + k * delta, k in [0, n), inside [lo, hi].
+__device__ __forceinline__ bool regular_index_interval(int64_t start, int64_t delta, uint32_t n, int64_t lo,
+                                                       int64_t hi, uint32_t *k_lo, uint32_t *k_hi) {
+    if (n == 0) return false;
+    if (n <= 2 || delta <= 0) { // one or two points, or a degenerate interval: test them one by one
+        bool any = false;
+        for (uint32_t k = 0; k < n; k++) {
+            int64_t t = start + (int64_t)((uint64_t)k * (uint64_t)delta);
+            if (t < lo || t > hi) continue;
+            if (!any) { *k_lo = k; any = true; }
+            *k_hi = k;
+        }
+        return any;
+    }
+    const int64_t last_t = start + (int64_t)((uint64_t)(n - 1) * (uint64_t)delta);
+    if (last_t < lo || start > hi) return false;
+    uint32_t a = 0, b;
+    if (lo > start) {
+        uint64_t k = ((uint64_t)lo - (uint64_t)start + (uint64_t)delta - 1) / (uint64_t)delta;
+        if (k > n - 1) return false;
+        a = (uint32_t)k;
+    }
+    b = hi >= last_t ? n - 1 : (uint32_t)(((uint64_t)hi - (uint64_t)start) / (uint64_t)delta);
+    if (b < a) return false;
+    *k_lo = a;
+    *k_hi = b;
+    return true;
+}
 
 // ---- MacaqueTS irregular decode (models/timestamps.rs:228-292) ---------------------------------
 
@@ -246,7 +311,41 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
     }
     if (!regular || type == MDB_MACAQUE_V_ID || n_res > 0) flags |= FLAG_SERIAL;
     d.flags = flags;
+    d.first = 0;
+    d.n_visible = n_total;
     return info;
+}
+
+// Restrict a segment to the points with lo <= timestamp <= hi: sets first / n_visible and drops
+// the serial flag when no serially decoded point remains visible.
+__device__ __forceinline__ void apply_time_range(const DevSegments &s, uint64_t i, SegInfo &info,
+                                                 const TimeRange &range) {
+    SegDesc &d = info.desc;
+    if (info.error) return;
+    uint32_t k_lo = 0, k_hi = 0;
+    bool any;
+    if (d.flags & FLAG_REGULAR) {
+        any = regular_index_interval(d.start, d.delta, d.n_total, range.lo, range.hi, &k_lo, &k_hi);
+    } else {
+        // Timestamps are sorted (the compressor requires it), so the in-range ones are an interval.
+        any = false;
+        const uint4 vt = s.timestamps.views[i];
+        decode_irregular_timestamps(view_data(s.timestamps, i, vt), vt.x, d.start, s.end_time[i],
+                                    0xffffffffu, &info.error, [&](uint32_t k, int64_t t) {
+                                        if (t >= range.lo && t <= range.hi) {
+                                            if (!any) { k_lo = k; any = true; }
+                                            k_hi = k;
+                                        }
+                                    });
+    }
+    d.first = any ? k_lo : 0;
+    d.n_visible = any ? k_hi - k_lo + 1 : 0;
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    const bool model_visible = any && d.first < d.n_model;
+    const bool residuals_visible = any && d.first + d.n_visible > d.n_model;
+    const bool serial = any && (!(d.flags & FLAG_REGULAR) || (type == MDB_MACAQUE_V_ID && model_visible) ||
+                                residuals_visible);
+    d.flags = (d.flags & ~FLAG_SERIAL) | (serial ? FLAG_SERIAL : 0u);
 }
 
 // MacaqueV decoder (models/macaque_v.rs:272-323). emit(i, bits) for i in [0, count).

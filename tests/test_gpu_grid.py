@@ -212,3 +212,51 @@ def test_values_only_grid_for_joined_field_columns(hip):
                               expected.view(np.uint32))
     for pointer in [out_ts] + out_vals:
         hip.dev_free(pointer)
+
+
+def _expected_range(batch, t_lo, t_hi):
+    ts, values, rows, _ = ora.grid_batch(batch)
+    keep = (ts >= t_lo) & (ts <= t_hi)
+    starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    per_segment = np.array([int(keep[int(starts[k]):int(starts[k + 1])].sum()) for k in range(len(rows))],
+                           dtype=np.uint32)
+    return ts[keep], values[keep], per_segment
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+@pytest.mark.parametrize("eb_name", ["lossless", "rel5", "abs5"])
+def test_grid_with_pushed_down_time_range(hip, eb_name, irregular):
+    # GridStream reconstructs everything and prunes afterwards (grid_exec.rs:366-387); the pushed
+    # down range must give the same rows in the same order.
+    eb = cases.error_bounds()[eb_name]
+    timestamps, _, batch = cases.mixed_batch(eb, irregular, seed=121)
+    n = len(timestamps)
+    windows = [
+        (int(timestamps[n // 4]), int(timestamps[3 * n // 4])),
+        (int(timestamps[0]), int(timestamps[-1])),
+        (int(timestamps[100]), int(timestamps[100])),
+        (int(timestamps[-1]) + 1, int(timestamps[-1]) + 1000),        # nothing
+        (-(1 << 62), 1 << 62),                                        # everything
+        (int(timestamps[n // 2]) - 37, int(timestamps[n // 2]) + 4242),
+        (int(timestamps[17]) + 1, int(timestamps[5000]) - 1),
+    ]
+    for t_lo, t_hi in windows:
+        exp_ts, exp_values, exp_rows = _expected_range(batch, t_lo, t_hi)
+        ts, values, rows, metrics = hip.grid_batch_range(batch, t_lo, t_hi)
+        assert np.array_equal(ts, exp_ts), (t_lo, t_hi)
+        assert np.array_equal(values.view(np.uint32), exp_values.view(np.uint32)), (t_lo, t_hi)
+        assert np.array_equal(rows, exp_rows)
+        assert metrics["rows_created"] == len(exp_ts)
+
+
+def test_grid_time_range_edge_cases(hip):
+    for eb_name in ("lossless", "rel5"):
+        batch = cases.edge_case_batch(cases.error_bounds()[eb_name])
+        all_ts = ora.grid_batch(batch)[0]
+        for t_lo, t_hi in ((0, 0), (100, 450), (1000, 1700), (250, 27_000), (1658671178037, 1658671200000),
+                           (int(all_ts.min()), int(all_ts.max())), (5, 6)):
+            exp_ts, exp_values, exp_rows = _expected_range(batch, t_lo, t_hi)
+            ts, values, rows, _ = hip.grid_batch_range(batch, t_lo, t_hi)
+            assert np.array_equal(ts, exp_ts), (eb_name, t_lo, t_hi)
+            assert np.array_equal(values.view(np.uint32), exp_values.view(np.uint32)), (eb_name, t_lo, t_hi)
+            assert np.array_equal(rows, exp_rows)
