@@ -101,6 +101,10 @@ struct ChunkTimestamps {
     __device__ __forceinline__ int64_t at(uint32_t j) const {
         return ts ? ts[j] : first + (int64_t)((uint64_t)j * (uint64_t)interval);
     }
+    // Regular timestamps only: no pointer test, hence no load the compiler has to wait for.
+    __device__ __forceinline__ int64_t regular_at(uint32_t j) const {
+        return first + (int64_t)((uint64_t)j * (uint64_t)interval);
+    }
 };
 
 __device__ __forceinline__ ChunkTimestamps chunk_timestamps(const TimestampSource &src, uint64_t chunk,
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
         }
         if (feeding) {
             const float v = ring_values[j % FIT_RING][lane];
-            const int64_t t = HAS_TS ? (int64_t)ring_ts[j % FIT_RING][lane] : regular_ts.at(j);
+            const int64_t t = HAS_TS ? (int64_t)ring_ts[j % FIT_RING][lane] : regular_ts.regular_at(j);
             // try_to_update_models (types.rs:74-81): a model that failed once is never fed again.
             if (pmc_fits) pmc_fits = pmc.fit(eb, v);
             if (swing_fits) swing_fits = swing.fit(dev, t, v);
