@@ -1,0 +1,95 @@
+"""Property tests of the CPU oracle (hypothesis), restating the reference's proptests
+(models/bits.rs:314-324, timestamps.rs:419-426, pmc_mean.rs:119-267, swing.rs:366-537,
+macaque_v.rs:354-376,436-475, compression.rs:733-929) over arbitrary f32 bit patterns and series."""
+
+import numpy as np
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import oracle_lib as ora
+from modelardb_rs_amd import error_bound
+
+LOSSLESS = error_bound("lossless")
+ANY_F32 = st.integers(0, (1 << 32) - 1).map(lambda b: float(np.uint32(b).view(np.float32)))
+FINITE_F32 = st.floats(width=32, allow_nan=False, allow_infinity=False)
+SETTINGS = settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+
+
+def _bits(values):
+    return np.asarray(values, dtype=np.float32).view(np.uint32)
+
+
+@SETTINGS
+@given(st.lists(st.tuples(st.integers(0, (1 << 64) - 1), st.integers(1, 64)), min_size=1, max_size=40))
+def test_bit_fields_round_trip(fields):
+    fields = [(value & ((1 << width) - 1), width) for value, width in fields]
+    data = ora.bits_write(fields)
+    assert len(data) == (sum(w for _, w in fields) + 7) // 8
+    assert ora.bits_read(data, [w for _, w in fields])[0] == [v for v, _ in fields]
+
+
+@SETTINGS
+@given(st.lists(st.integers(0, (1 << 62)), min_size=1, max_size=60, unique=True))
+def test_timestamps_round_trip(timestamps):
+    # "Timestamps are assumed to be unique" (models/mod.rs:100): duplicates make the reference
+    # itself divide by a zero sampling interval, so the property is over strictly increasing ones.
+    timestamps = sorted(timestamps)
+    data = ora.compress_residual_timestamps(timestamps)
+    back = ora.decompress_all_timestamps(timestamps[0], timestamps[-1], data)
+    assert back.tolist() == timestamps
+    assert ora.seg_len(timestamps[0], timestamps[-1], data) == len(timestamps)
+
+
+@SETTINGS
+@given(st.lists(ANY_F32, min_size=1, max_size=60), st.one_of(st.none(), ANY_F32))
+def test_macaque_v_lossless_round_trip(values, seed):
+    data = ora.macaque_v_compress(LOSSLESS, values, seed=seed)[0]
+    if seed is not None and not data:
+        return  # nothing stored: every value equalled the seed? impossible: `10` is stored per value
+    decoded = ora.macaque_v_grid(data, len(values), seed=seed)
+    assert np.array_equal(_bits(decoded), _bits(values))
+
+
+@SETTINGS
+@given(ANY_F32, st.integers(1, 30))
+def test_repeated_value_fits_both_models_lossless(value, n):
+    assert ora.pmc_mean_fit(LOSSLESS, [value] * n)[0] == n
+    assert ora.swing_fit(LOSSLESS, list(range(0, 100 * n, 100)), [value] * n)[0] == n
+
+
+@SETTINGS
+@given(st.lists(ANY_F32, min_size=1, max_size=80), st.booleans())
+def test_lossless_compression_round_trips_any_bit_pattern(values, irregular):
+    n = len(values)
+    rng = np.random.default_rng(n)
+    timestamps = np.cumsum(rng.integers(1, 1000, size=n)) if irregular else np.arange(n) * 100
+    batch = ora.try_compress_univariate_time_series(timestamps, values, LOSSLESS)
+    ts, reconstructed, rows, _ = ora.grid_batch(batch)
+    assert np.array_equal(ts, timestamps)
+    want, got = np.asarray(values, dtype=np.float32), reconstructed
+    nan = np.isnan(want)
+    assert np.array_equal(_bits(got[~nan]), _bits(want[~nan]))
+    assert np.isnan(got[nan]).all()
+    assert int(rows.sum()) == n
+
+
+@SETTINGS
+@given(st.lists(st.floats(min_value=-1e6, max_value=1e6, width=32), min_size=1, max_size=200),
+       st.sampled_from([("absolute", 0.5), ("absolute", 5.0), ("relative", 1.0), ("relative", 10.0)]))
+def test_lossy_compression_stays_within_the_error_bound(values, bound):
+    # compression.rs:865-929 for moderate magnitudes (|v| <= 1e6: f32 spacing <= 0.0625, far below
+    # the absolute bounds used, so the reference's f32-spacing hazard cannot trigger).
+    eb = error_bound(*bound)
+    n = len(values)
+    timestamps = np.arange(n, dtype=np.int64) * 100
+    batch = ora.try_compress_univariate_time_series(timestamps, values, eb)
+    ts, reconstructed, _, _ = ora.grid_batch(batch)
+    assert np.array_equal(ts, timestamps)
+    for real, approximate in zip(np.asarray(values, dtype=np.float32), reconstructed):
+        assert ora.is_value_within_error_bound(eb, float(real), float(approximate)), (real, approximate)
+    # segment aggregates agree with aggregates over the reconstructed points
+    from modelardb_rs_amd import MDB_AGG_COUNT, MDB_AGG_MAX, MDB_AGG_MIN, MDB_AGG_SUM
+    mask = MDB_AGG_COUNT | MDB_AGG_MIN | MDB_AGG_MAX | MDB_AGG_SUM
+    on_segments = ora.agg_batch(batch, mask)
+    assert on_segments.count == n
+    assert on_segments.min <= float(reconstructed.min()) + 1e-3 * max(1.0, abs(float(reconstructed.min())))
+    assert on_segments.max >= float(reconstructed.max()) - 1e-3 * max(1.0, abs(float(reconstructed.max())))
