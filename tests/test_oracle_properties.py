@@ -73,11 +73,14 @@ def test_lossless_compression_round_trips_any_bit_pattern(values, irregular):
 
 
 @SETTINGS
-@given(st.lists(st.floats(min_value=-1e6, max_value=1e6, width=32), min_size=1, max_size=200),
+@given(st.lists(st.floats(min_value=-1e6, max_value=1e6, width=32, allow_subnormal=False), min_size=1,
+                max_size=200),
        st.sampled_from([("absolute", 0.5), ("absolute", 5.0), ("relative", 1.0), ("relative", 10.0)]))
 def test_lossy_compression_stays_within_the_error_bound(values, bound):
     # compression.rs:865-929 for moderate magnitudes (|v| <= 1e6: f32 spacing <= 0.0625, far below
-    # the absolute bounds used, so the reference's f32-spacing hazard cannot trigger).
+    # the absolute bounds used, so the reference's f32-spacing hazard cannot trigger; subnormals are
+    # excluded because the reference's mantissa rewriting leaves a relative bound there, see
+    # test_macaque_v_lossy_subnormal_and_tiny_values in test_oracle_kat.py).
     eb = error_bound(*bound)
     n = len(values)
     timestamps = np.arange(n, dtype=np.int64) * 100
