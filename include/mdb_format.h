@@ -125,6 +125,20 @@ typedef struct mdb_segments_owned {
     void *priv_;                 /* owner's bookkeeping */
 } mdb_segments_owned;
 
+/* Reconstructed data points owned by the library: page-locked host memory (so the copy from the
+ * device runs at the full PCIe rate) that the caller wraps without copying (e.g. arrow-rs
+ * Buffer::from_custom_allocation) and returns with mdb_grid_result_free(). */
+typedef struct mdb_grid_result {
+    int64_t *timestamps;        /* n */
+    float *values;              /* n */
+    uint32_t *rows_per_segment; /* n_segments */
+    uint64_t n;
+    uint64_t n_segments;
+    uint64_t reserved_front;    /* writable rows BEFORE timestamps[0] / values[0] (for leftovers) */
+    mdb_grid_metrics metrics;
+    void *priv_;
+} mdb_grid_result;
+
 #ifdef __cplusplus
 }
 #endif

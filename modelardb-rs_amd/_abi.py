@@ -104,6 +104,19 @@ class SegmentsOwnedC(C.Structure):
     ]
 
 
+class GridResultC(C.Structure):
+    _fields_ = [
+        ("timestamps", C.c_void_p),
+        ("values", C.c_void_p),
+        ("rows_per_segment", C.c_void_p),
+        ("n", C.c_uint64),
+        ("n_segments", C.c_uint64),
+        ("reserved_front", C.c_uint64),
+        ("metrics", GridMetricsC),
+        ("priv_", C.c_void_p),
+    ]
+
+
 _HIP_SYMBOLS = {
     # name: (restype, argtypes)
     "mdb_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -141,6 +154,9 @@ _HIP_SYMBOLS = {
     "mdb_grid_batch_range_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.POINTER(C.c_uint64), C.POINTER(GridMetricsC)]),
+    "mdb_grid_batch_owned": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int32, C.c_int64,
+                                       C.c_int64, C.c_uint64, C.POINTER(C.POINTER(GridResultC))]),
+    "mdb_grid_result_free": (None, [C.POINTER(GridResultC)]),
     "mdb_agg_batch": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,
                                 C.POINTER(AggStateC)]),
     "mdb_agg_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,

@@ -470,33 +470,27 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
     SegmentsView view;
     fill_segments_view(batch.columns, &view);
 
-    // One sizing call and one batch call replace the per-row loop of grid_exec.rs:323-356. A
-    // timestamp predicate is pushed down so out-of-range points are neither reconstructed nor
-    // copied over PCIe; the filter below then only has the leftovers to look at.
+    // One library call replaces the per-row loop of grid_exec.rs:323-356. A timestamp predicate is
+    // pushed down so out-of-range points are neither reconstructed nor copied over PCIe (the
+    // leftovers were filtered when they were created), which makes the filter step of
+    // grid_exec.rs:366-387 a no-op here. The points arrive in page-locked memory owned by the
+    // library with room in front for the leftovers; the columns below alias it.
     const bool pushdown = maybe_predicate_.has_value();
     const int64_t t_lo = pushdown && maybe_predicate_->lower ? *maybe_predicate_->lower : INT64_MIN;
     const int64_t t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
-    uint64_t new_points = 0;
-    check(pushdown ? mdb_grid_count_range(ctx_, &view.seg, t_lo, t_hi, &new_points)
-                   : mdb_grid_count(ctx_, &view.seg, &new_points));
     const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
-    const int64_t total = leftovers + static_cast<int64_t>(new_points);
-    std::vector<int64_t> timestamps(static_cast<size_t>(total));
-    std::vector<float> values(static_cast<size_t>(total));
+    mdb_grid_result *raw = nullptr;
+    check(mdb_grid_batch_owned(ctx_, &view.seg, pushdown ? 1 : 0, t_lo, t_hi, static_cast<uint64_t>(leftovers), &raw));
+    std::shared_ptr<mdb_grid_result> result(raw, [](mdb_grid_result *r) { mdb_grid_result_free(r); });
+    const int64_t total = leftovers + static_cast<int64_t>(result->n);
+    int64_t *timestamps = result->timestamps - leftovers;
+    float *values = result->values - leftovers;
     if (leftovers > 0) { // keep the batch sorted: leftovers first (grid_exec.rs:302-320)
-        std::memcpy(timestamps.data(), current_batch_.columns[0]->as<int64_t>() + current_batch_offset_, 8 * leftovers);
-        std::memcpy(values.data(), current_batch_.columns[1]->as<float>() + current_batch_offset_, 4 * leftovers);
+        std::memcpy(timestamps, current_batch_.columns[0]->as<int64_t>() + current_batch_offset_, 8 * leftovers);
+        std::memcpy(values, current_batch_.columns[1]->as<float>() + current_batch_offset_, 4 * leftovers);
     }
-    std::vector<uint32_t> rows_per_segment(static_cast<size_t>(batch.num_rows));
-    mdb_grid_metrics metrics;
-    std::memset(&metrics, 0, sizeof(metrics));
-    uint64_t produced = 0;
-    check(pushdown ? mdb_grid_batch_range(ctx_, &view.seg, t_lo, t_hi, timestamps.data() + leftovers,
-                                          values.data() + leftovers, rows_per_segment.data(), new_points,
-                                          &produced, &metrics)
-                   : mdb_grid_batch(ctx_, &view.seg, timestamps.data() + leftovers, values.data() + leftovers,
-                                    rows_per_segment.data(), new_points, &produced, &metrics));
-    metrics_->add(metrics);
+    const uint32_t *rows_per_segment = result->rows_per_segment;
+    metrics_->add(result->metrics);
 
     // Tag columns: the segment's tag value once per created row (grid_exec.rs:341-346). Views are
     // replicated; long strings stay in the input's data buffers (shared, not copied).
@@ -531,7 +525,7 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
         for (int64_t row = 0; row < batch.num_rows; row++) {
             mdb_view16 tag = input_views[row];
             if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
-            for (uint32_t k = 0; k < rows_per_segment[static_cast<size_t>(row)]; k++) views[at++] = tag;
+            for (uint32_t k = 0; k < rows_per_segment[row]; k++) views[at++] = tag;
         }
         column->values = column->data.data();
         column->buffer_ptrs.push_back(leftover_payload.empty() ? reinterpret_cast<const uint8_t *>(column->data.data())
@@ -545,36 +539,19 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
         tag_columns.push_back(column);
     }
 
-    // Prune by time after reconstruction (grid_exec.rs:366-387).
-    if (maybe_predicate_) {
-        std::vector<int64_t> selected;
-        selected.reserve(static_cast<size_t>(total));
-        for (int64_t i = 0; i < total; i++)
-            if (maybe_predicate_->matches(timestamps[static_cast<size_t>(i)])) selected.push_back(i);
-        std::vector<int64_t> kept_ts(selected.size());
-        std::vector<float> kept_values(selected.size());
-        for (size_t k = 0; k < selected.size(); k++) {
-            kept_ts[k] = timestamps[static_cast<size_t>(selected[k])];
-            kept_values[k] = values[static_cast<size_t>(selected[k])];
-        }
-        timestamps.swap(kept_ts);
-        values.swap(kept_values);
-        for (ColumnPtr &column : tag_columns) {
-            std::vector<uint8_t> kept(std::max<size_t>(selected.size() * 16, 16), 0);
-            const mdb_view16 *views = reinterpret_cast<const mdb_view16 *>(column->data.data());
-            for (size_t k = 0; k < selected.size(); k++)
-                reinterpret_cast<mdb_view16 *>(kept.data())[k] = views[selected[k]];
-            column->data.swap(kept);
-            column->values = column->data.data();
-            column->length = static_cast<int64_t>(selected.size());
-        }
-    }
-
+    auto aliased = [&](Type type, const void *data) {
+        auto column = std::make_shared<Column>();
+        column->type = type;
+        column->length = total;
+        column->values = data;
+        column->keep_alive = result;
+        return column;
+    };
     RecordBatch current;
     current.schema = schema_;
-    current.num_rows = static_cast<int64_t>(timestamps.size());
-    current.columns.push_back(owned_column(Type::Timestamp, timestamps));
-    current.columns.push_back(owned_column(Type::Float32, values));
+    current.num_rows = total;
+    current.columns.push_back(aliased(Type::Timestamp, timestamps));
+    current.columns.push_back(aliased(Type::Float32, values));
     for (ColumnPtr &column : tag_columns) current.columns.push_back(column);
     current_batch_ = std::move(current);
     current_batch_offset_ = 0; // grid_exec.rs:389-390

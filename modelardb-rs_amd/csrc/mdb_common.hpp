@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -66,6 +67,17 @@ enum ScratchSlot {
     SCRATCH_SLOT_COUNT
 };
 
+// Recycled page-locked blocks behind mdb_grid_result (hipHostMalloc is slow). Shared between the
+// context and the results it handed out, so a result may be freed after mdb_close().
+struct PinnedPool {
+    std::mutex mutex;
+    bool closed = false;
+    std::vector<std::pair<void *, uint64_t>> blocks;
+    int take(uint64_t bytes, void **out, uint64_t *capacity);
+    void give(void *block, uint64_t capacity);
+    void close();
+};
+
 } // namespace mdb
 
 struct mdb_ctx {
@@ -79,6 +91,8 @@ struct mdb_ctx {
     uint64_t scratch_bytes[mdb::SCRATCH_SLOT_COUNT] = {};
     void *pinned = nullptr; // pinned host staging
     uint64_t pinned_bytes = 0;
+
+    std::shared_ptr<mdb::PinnedPool> pinned_pool = std::make_shared<mdb::PinnedPool>();
 
     bool profiling = false;
     std::map<std::string, mdb::KernelTime> kernel_times;

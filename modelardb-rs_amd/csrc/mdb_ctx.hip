@@ -40,6 +40,58 @@ int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out) {
     return 0;
 }
 
+int PinnedPool::take(uint64_t bytes, void **out, uint64_t *capacity) {
+    if (bytes == 0) bytes = 256;
+    {
+        // Best fit among the recycled blocks that are not wastefully large.
+        std::lock_guard<std::mutex> lock(mutex);
+        int best = -1;
+        for (size_t i = 0; i < blocks.size(); i++) {
+            uint64_t cap = blocks[i].second;
+            if (cap >= bytes && cap <= 2 * bytes + (1 << 20) && (best < 0 || cap < blocks[(size_t)best].second))
+                best = (int)i;
+        }
+        if (best >= 0) {
+            *out = blocks[(size_t)best].first;
+            *capacity = blocks[(size_t)best].second;
+            blocks.erase(blocks.begin() + best);
+            return 0;
+        }
+    }
+    uint64_t grown = align_up(bytes + bytes / 8, 1 << 16);
+    MDB_HIP_CHECK(hipHostMalloc(out, grown, hipHostMallocDefault));
+    *capacity = grown;
+    return 0;
+}
+
+void PinnedPool::give(void *block, uint64_t capacity) {
+    std::lock_guard<std::mutex> lock(mutex);
+    if (closed) {
+        (void)hipHostFree(block);
+        return;
+    }
+    if (blocks.size() >= 8) { // keep the pool small: drop the smallest block
+        size_t smallest = 0;
+        for (size_t i = 1; i < blocks.size(); i++)
+            if (blocks[i].second < blocks[smallest].second) smallest = i;
+        if (blocks[smallest].second < capacity) {
+            (void)hipHostFree(blocks[smallest].first);
+            blocks[smallest] = {block, capacity};
+        } else {
+            (void)hipHostFree(block);
+        }
+        return;
+    }
+    blocks.push_back({block, capacity});
+}
+
+void PinnedPool::close() {
+    std::lock_guard<std::mutex> lock(mutex);
+    closed = true;
+    for (auto &block : blocks) (void)hipHostFree(block.first);
+    blocks.clear();
+}
+
 LaunchTimer::LaunchTimer(mdb_ctx *c, const char *n) : ctx(c), name(n) {
     if (!ctx->profiling) return;
     auto take = [&]() {
@@ -123,6 +175,7 @@ int mdb_close(mdb_ctx *ctx) {
     for (int i = 0; i < SCRATCH_SLOT_COUNT; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned_pool->close();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

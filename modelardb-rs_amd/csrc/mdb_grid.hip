@@ -554,8 +554,9 @@ struct GridPlan {
 // Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
 // capacity_tiles bounds the tile map: if the batch needs more the caller gets an error before any
 // out-of-bounds write can happen (tile map writes are guarded by the allocation made here).
-int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint32_t *rows_per_segment,
-              bool want_tiles, uint64_t cap_points, GridPlan *plan) {
+// Prepass + scans; leaves descriptors / counts in scratch and the header (totals, error flags,
+// metrics) on the host.
+int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *plan) {
     const uint64_t n = in->n;
     if (n > 0xfffffff0ull) return fail("Too many segments in one batch.");
     const uint32_t n_blocks = (uint32_t)((n + SEGS_PER_BLOCK - 1) / SEGS_PER_BLOCK);
@@ -572,9 +573,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint32_t *r
     plan->block_serial = plan->block_points + n_blocks + 1;
     if (scratch_reserve(ctx, SCRATCH_SERIAL_IDS, (n + 1) * 4, &p)) return 1;
     plan->serial_ids = static_cast<uint32_t *>(p);
-    const uint64_t cap_tiles = want_tiles ? (cap_points + TILE_POINTS - 1) / TILE_POINTS + 1 : 0;
-    if (scratch_reserve(ctx, SCRATCH_TILE_MAP, (cap_tiles + 1) * 4, &p)) return 1;
-    plan->tile_first = static_cast<uint32_t *>(p);
+    plan->tile_first = nullptr;
     if (scratch_reserve(ctx, SCRATCH_HEADER, sizeof(GridHeader), &p)) return 1;
     plan->header = static_cast<GridHeader *>(p);
 
@@ -597,16 +596,20 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint32_t *r
                                  hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (plan->host_header.error) return fail(describe_error(plan->host_header.error));
-    if (!want_tiles) return 0;
-    if (plan->host_header.total_points > cap_points)
-        return fail("Output buffers too small: " + std::to_string(plan->host_header.total_points) +
-                    " data points but capacity " + std::to_string(cap_points) + ".");
-    {
-        LaunchTimer timer(ctx, "k_grid_offsets");
-        hipLaunchKernelGGL(k_grid_offsets, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream,
-                           plan->counts, n, plan->block_points, plan->block_serial, plan->offsets,
-                           plan->serial_ids, plan->tile_first, rows_per_segment);
-    }
+    return 0;
+}
+
+// Output offsets, serial work list, rows-per-segment and the tile map for the planned batch.
+int grid_offsets(mdb_ctx *ctx, const mdb_segments *in, uint32_t *rows_per_segment, GridPlan *plan) {
+    const uint64_t total = plan->host_header.total_points;
+    void *p;
+    if (scratch_reserve(ctx, SCRATCH_TILE_MAP, ((total + TILE_POINTS - 1) / TILE_POINTS + 2) * 4, &p)) return 1;
+    plan->tile_first = static_cast<uint32_t *>(p);
+    if (in->n == 0) return 0;
+    LaunchTimer timer(ctx, "k_grid_offsets");
+    hipLaunchKernelGGL(k_grid_offsets, dim3(plan->n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream,
+                       plan->counts, in->n, plan->block_points, plan->block_serial, plan->offsets,
+                       plan->serial_ids, plan->tile_first, rows_per_segment);
     return 0;
 }
 
@@ -622,14 +625,11 @@ void fill_metrics(const GridHeader &h, mdb_grid_metrics *m) {
     m->segments_irregular = h.metrics[8];
 }
 
-int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
-                          float *out_val, uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
-                          mdb_grid_metrics *metrics) {
-    GridPlan plan;
-    if (grid_plan(ctx, in, range, out_rows, true, cap, &plan)) return 1;
+// Launch the reconstruction of a planned batch into device buffers (enqueue + final error check).
+int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan &plan, int64_t *out_ts,
+                float *out_val, uint32_t *out_rows) {
     const uint64_t total = plan.host_header.total_points;
-    if (n_out) *n_out = total;
-    fill_metrics(plan.host_header, metrics);
+    if (grid_offsets(ctx, in, out_rows, &plan)) return 1;
     if (total == 0) return 0;
     if (!out_val) return fail("out_val must not be NULL.");
     if ((reinterpret_cast<uintptr_t>(out_ts) & 15u) || (reinterpret_cast<uintptr_t>(out_val) & 15u))
@@ -651,6 +651,11 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, out_ts, out_val, plan.header);
     }
+    return 0;
+}
+
+// The serial kernel can still find a malformed bitstream; read its verdict (syncs the stream).
+int grid_late_error(mdb_ctx *ctx, GridPlan &plan) {
     uint32_t late_error = 0;
     MDB_HIP_CHECK(hipMemcpyAsync(&late_error, &plan.header->error, 4, hipMemcpyDeviceToHost,
                                  ctx->stream));
@@ -658,6 +663,21 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
     MDB_HIP_CHECK(hipGetLastError());
     if (late_error) return fail(describe_error(late_error));
     return 0;
+}
+
+int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
+                          float *out_val, uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
+                          mdb_grid_metrics *metrics) {
+    GridPlan plan;
+    if (grid_plan(ctx, in, range, &plan)) return 1;
+    const uint64_t total = plan.host_header.total_points;
+    if (n_out) *n_out = total;
+    fill_metrics(plan.host_header, metrics);
+    if (total > cap)
+        return fail("Output buffers too small: " + std::to_string(total) + " data points but capacity " +
+                    std::to_string(cap) + ".");
+    if (grid_launch(ctx, in, range, plan, out_ts, out_val, out_rows)) return 1;
+    return grid_late_error(ctx, plan);
 }
 
 } // namespace mdb
@@ -673,7 +693,7 @@ int grid_count_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, u
     std::lock_guard<std::mutex> lock(ctx->mutex);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     GridPlan plan;
-    if (grid_plan(ctx, in, range, nullptr, false, 0, &plan)) return 1;
+    if (grid_plan(ctx, in, range, &plan)) return 1;
     *n_out = plan.host_header.total_points;
     return 0;
 }
@@ -736,9 +756,89 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
     return rc;
 }
 
+struct OwnedGridResult {
+    mdb_grid_result c;
+    std::shared_ptr<PinnedPool> pool;
+    void *block;
+    uint64_t capacity;
+};
+
+int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t reserve_front,
+                          mdb_grid_result **out) {
+    if (!ctx || !in || !out) return fail("ctx, in and out must not be NULL.");
+    mdb_segments_owned *dev = nullptr;
+    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    int rc = 0;
+    OwnedGridResult *result = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        GridPlan plan;
+        rc = grid_plan(ctx, &dev->seg, range, &plan);
+        const uint64_t total = plan.host_header.total_points;
+        // The device staging area mirrors the host block (same gaps), so one copy moves it all.
+        const uint64_t front = align_up(reserve_front, 4); // keeps the 16-byte store alignment
+        const uint64_t ts_bytes = align_up((front + total) * 8, 256);
+        const uint64_t val_bytes = align_up((front + total) * 4, 256);
+        const uint64_t rows_bytes = align_up(in->n * 4, 256);
+        void *stage = nullptr;
+        if (!rc) rc = scratch_reserve(ctx, SCRATCH_STAGE_DEV, ts_bytes + val_bytes + rows_bytes, &stage);
+        uint8_t *base = static_cast<uint8_t *>(stage);
+        if (!rc)
+            rc = grid_launch(ctx, &dev->seg, range, plan, reinterpret_cast<int64_t *>(base) + front,
+                             reinterpret_cast<float *>(base + ts_bytes) + front,
+                             reinterpret_cast<uint32_t *>(base + ts_bytes + val_bytes));
+        void *block = nullptr;
+        uint64_t capacity = 0;
+        if (!rc) rc = ctx->pinned_pool->take(ts_bytes + val_bytes + rows_bytes, &block, &capacity);
+        if (!rc) {
+            // One copy of the three columns (they are contiguous in the staging area) into the
+            // page-locked block; then the serial kernel's verdict.
+            if (hipMemcpyAsync(block, stage, ts_bytes + val_bytes + rows_bytes, hipMemcpyDeviceToHost,
+                               ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy device to host failed.");
+            if (!rc) rc = grid_late_error(ctx, plan);
+            if (rc) {
+                ctx->pinned_pool->give(block, capacity);
+            } else {
+                result = new OwnedGridResult();
+                uint8_t *host = static_cast<uint8_t *>(block);
+                result->c.timestamps = reinterpret_cast<int64_t *>(host) + front;
+                result->c.values = reinterpret_cast<float *>(host + ts_bytes) + front;
+                result->c.rows_per_segment = reinterpret_cast<uint32_t *>(host + ts_bytes + val_bytes);
+                result->c.n = total;
+                result->c.n_segments = in->n;
+                result->c.reserved_front = front;
+                std::memset(&result->c.metrics, 0, sizeof(result->c.metrics));
+                fill_metrics(plan.host_header, &result->c.metrics);
+                result->c.priv_ = result;
+                result->pool = ctx->pinned_pool;
+                result->block = block;
+                result->capacity = capacity;
+            }
+        }
+    }
+    mdb_segments_free(dev);
+    if (rc) return 1;
+    *out = &result->c;
+    return 0;
+}
+
 } // namespace
 
 extern "C" {
+
+int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, int32_t has_range, int64_t t_lo,
+                         int64_t t_hi, uint64_t reserve_front, mdb_grid_result **out) {
+    return grid_batch_owned_impl(ctx, in, TimeRange{t_lo, t_hi, has_range ? 1 : 0}, reserve_front, out);
+}
+
+void mdb_grid_result_free(mdb_grid_result *result) {
+    if (!result) return;
+    OwnedGridResult *owned = static_cast<OwnedGridResult *>(result->priv_);
+    if (!owned) return;
+    owned->pool->give(owned->block, owned->capacity);
+    delete owned;
+}
 
 int mdb_grid_count_dev(mdb_ctx *ctx, const mdb_segments *in, uint64_t *n_out) {
     return grid_count_dev_impl(ctx, in, NO_RANGE, n_out);

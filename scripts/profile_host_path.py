@@ -24,6 +24,12 @@ def main():
             out = ctx.grid_batch(part, cap)
         dt = (time.perf_counter() - t0) / reps
         print(f"grid host path: {len(part)} segments -> {cap} points: {dt*1e3:.2f} ms/batch, {cap/dt/1e9:.2f} Gpoints/s, {12*cap/dt/1e9:.1f} GB/s over PCIe")
+        ctx.grid_batch_owned(part, copy=False)[4]()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.grid_batch_owned(part, copy=False)[4]()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"grid owned/pinned: {len(part)} segments -> {cap} points: {dt*1e3:.2f} ms/batch, {cap/dt/1e9:.2f} Gpoints/s, {12*cap/dt/1e9:.1f} GB/s over PCIe")
         mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
         ctx.agg_batch(part, mask)
         t0 = time.perf_counter()

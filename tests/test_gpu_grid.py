@@ -313,3 +313,21 @@ def test_fuzzed_segments_never_crash_and_agree_with_the_oracle(hip):
         else:
             errors += got is None
     assert agree > 50 and errors > 20, (agree, errors)
+
+
+def test_owned_grid_results_in_page_locked_memory(hip):
+    eb = cases.error_bounds()["rel5"]
+    timestamps, _, batch = cases.mixed_batch(eb, True, seed=141)
+    expected = ora.grid_batch(batch)
+    for _ in range(3):   # the second and third call reuse the pooled page-locked block
+        got = hip.grid_batch_owned(batch)
+        cases.assert_grid_equal(got, expected)
+        assert np.array_equal(got[2], expected[2]) and got[3] == expected[3]
+    lo, hi = int(timestamps[500]), int(timestamps[9000])
+    ranged = hip.grid_batch_owned(batch, time_range=(lo, hi))
+    cases.assert_grid_equal(ranged, hip.grid_batch_range(batch, lo, hi))
+    ts, values, rows, metrics, release = hip.grid_batch_owned(batch, copy=False)
+    assert np.array_equal(ts, expected[0])
+    release()
+    empty = hip.grid_batch_owned(mdb.SegmentBatch.from_rows([]))
+    assert len(empty[0]) == 0 and len(empty[2]) == 0
