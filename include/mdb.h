@@ -106,12 +106,17 @@ int mdb_grid_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo,
 /* One-call form for host callers: sizes, reconstructs and copies back in one go (one upload of the
  * segments, one prepass, one copy from the device) into page-locked memory owned by the library,
  * which the caller wraps without copying and returns with mdb_grid_result_free() (allowed after
- * mdb_close()). has_range != 0 applies the predicate t_lo <= timestamp <= t_hi. Two to three times
+ * mdb_close()). flags: MDB_GRID_HAS_RANGE applies the predicate t_lo <= timestamp <= t_hi;
+ * MDB_GRID_VALUES_ONLY skips the timestamps (result->timestamps is NULL): the second and later
+ * field columns of a SortedJoinExec only contribute their values (sorted_join_exec.rs:268-275), so
+ * their timestamps need not cross PCIe. Two to three times
  * faster end to end than mdb_grid_count + mdb_grid_batch into pageable memory.
  * reserve_front asks for that many writable rows in front of the reconstructed points, so a
  * GridStream can put the leftovers of its previous batch there (grid_exec.rs:302-320) and hand
  * out slices of the block without copying the new points at all. */
-int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, int32_t has_range, int64_t t_lo,
+#define MDB_GRID_HAS_RANGE 1u
+#define MDB_GRID_VALUES_ONLY 2u
+int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, int64_t t_lo,
                          int64_t t_hi, uint64_t reserve_front, mdb_grid_result **out);
 void mdb_grid_result_free(mdb_grid_result *result);
 

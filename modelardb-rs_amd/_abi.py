@@ -154,7 +154,7 @@ _HIP_SYMBOLS = {
     "mdb_grid_batch_range_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.POINTER(C.c_uint64), C.POINTER(GridMetricsC)]),
-    "mdb_grid_batch_owned": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int32, C.c_int64,
+    "mdb_grid_batch_owned": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32, C.c_int64,
                                        C.c_int64, C.c_uint64, C.POINTER(C.POINTER(GridResultC))]),
     "mdb_grid_result_free": (None, [C.POINTER(GridResultC)]),
     "mdb_agg_batch": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,

@@ -137,17 +137,18 @@ class Context:
             C.byref(n_out), C.byref(metrics)))
         return out_ts[: n_out.value], out_val[: n_out.value], rows, metrics.as_dict()
 
-    def grid_batch_owned(self, batch, time_range=None, copy=True):
+    def grid_batch_owned(self, batch, time_range=None, copy=True, values_only=False):
         """One-call grid into page-locked memory owned by the library (mdb_grid_batch_owned).
         Returns (timestamps, values, rows_per_segment, metrics); the arrays are copies unless
         copy=False, in which case they alias the library's buffer and `release()` (5th item) must
-        be called when done."""
+        be called when done. values_only=True skips the timestamps (None is returned for them)."""
         seg = batch.as_c()
         out = C.POINTER(_abi.GridResultC)()
         has_range = time_range is not None
         t_lo, t_hi = time_range if has_range else (0, 0)
-        self._check(self.lib.mdb_grid_batch_owned(self.handle, C.byref(seg), int(has_range), t_lo,
-                                                  t_hi, 0, C.byref(out)))
+        flags = (1 if has_range else 0) | (2 if values_only else 0)
+        self._check(self.lib.mdb_grid_batch_owned(self.handle, C.byref(seg), flags, t_lo, t_hi, 0,
+                                                  C.byref(out)))
         result = out.contents
         n, n_segments = int(result.n), int(result.n_segments)
 
@@ -157,13 +158,14 @@ class Context:
             buffer = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(pointer)
             return np.frombuffer(buffer, dtype=dtype)
 
-        ts = view(result.timestamps, n, np.int64)
+        ts = None if values_only else view(result.timestamps, n, np.int64)
         values = view(result.values, n, np.float32)
         rows = view(result.rows_per_segment, n_segments, np.uint32)
         metrics = result.metrics.as_dict()
         release = lambda: self.lib.mdb_grid_result_free(out)
         if copy:
-            ts, values, rows = ts.copy(), values.copy(), rows.copy()
+            ts = None if ts is None else ts.copy()
+            values, rows = values.copy(), rows.copy()
             release()
             return ts, values, rows, metrics
         return ts, values, rows, metrics, release

@@ -449,7 +449,18 @@ std::shared_ptr<GridExec> GridExec::with_new_children(std::vector<std::shared_pt
 
 std::unique_ptr<GridStream> GridExec::execute(size_t partition, size_t batch_size) {
     return std::make_unique<GridStream>(ctx_, schema_, maybe_predicate_, limit_,
-                                        input_->execute_segments(partition), batch_size, metrics_);
+                                        input_->execute_segments(partition), batch_size, metrics_, values_only_);
+}
+
+std::unique_ptr<SegmentStream> GridExec::execute_stream(size_t partition, size_t batch_size) {
+    return execute(partition, batch_size);
+}
+
+std::shared_ptr<GridExec> GridExec::with_values_only() const {
+    auto exec = GridExec::make(ctx_, schema_, maybe_predicate_, limit_, input_);
+    exec->metrics_ = metrics_;
+    exec->values_only_ = true;
+    return exec;
 }
 
 std::string GridExec::fmt_as() const {
@@ -458,15 +469,19 @@ std::string GridExec::fmt_as() const {
 
 GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<TimestampPredicate> maybe_predicate,
                        std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
-                       std::shared_ptr<GridStreamMetrics> metrics)
+                       std::shared_ptr<GridStreamMetrics> metrics, bool values_only)
     : ctx_(ctx), schema_(std::move(schema)), maybe_predicate_(maybe_predicate), input_(std::move(input)),
       batch_size_(limit ? std::min(*limit, batch_size) : batch_size), // grid_exec.rs:239-246
-      current_batch_(RecordBatch::new_empty(schema_)), metrics_(std::move(metrics)) {}
+      metrics_(std::move(metrics)), values_only_(values_only) {
+    if (schema_.size() < 2) throw Error("GridStream should use a static schema.");
+    if (values_only_) schema_ = {schema_[1]};
+    current_batch_ = RecordBatch::new_empty(schema_);
+}
 
 void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch &batch) {
     const auto started = std::chrono::steady_clock::now();
-    const size_t n_tags = batch.columns.size() - query_compressed_schema().size();
-    if (schema_.size() != 2 + n_tags) throw Error("GridStream should use a static schema.");
+    const size_t n_tags = values_only_ ? 0 : batch.columns.size() - query_compressed_schema().size();
+    if (!values_only_ && schema_.size() != 2 + n_tags) throw Error("GridStream should use a static schema.");
     SegmentsView view;
     fill_segments_view(batch.columns, &view);
 
@@ -480,14 +495,17 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
     const int64_t t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
     const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
     mdb_grid_result *raw = nullptr;
-    check(mdb_grid_batch_owned(ctx_, &view.seg, pushdown ? 1 : 0, t_lo, t_hi, static_cast<uint64_t>(leftovers), &raw));
+    const uint32_t flags = (pushdown ? MDB_GRID_HAS_RANGE : 0u) | (values_only_ ? MDB_GRID_VALUES_ONLY : 0u);
+    check(mdb_grid_batch_owned(ctx_, &view.seg, flags, t_lo, t_hi, static_cast<uint64_t>(leftovers), &raw));
     std::shared_ptr<mdb_grid_result> result(raw, [](mdb_grid_result *r) { mdb_grid_result_free(r); });
     const int64_t total = leftovers + static_cast<int64_t>(result->n);
-    int64_t *timestamps = result->timestamps - leftovers;
+    int64_t *timestamps = values_only_ ? nullptr : result->timestamps - leftovers;
     float *values = result->values - leftovers;
     if (leftovers > 0) { // keep the batch sorted: leftovers first (grid_exec.rs:302-320)
-        std::memcpy(timestamps, current_batch_.columns[0]->as<int64_t>() + current_batch_offset_, 8 * leftovers);
-        std::memcpy(values, current_batch_.columns[1]->as<float>() + current_batch_offset_, 4 * leftovers);
+        const size_t value_column = values_only_ ? 0 : 1;
+        if (!values_only_)
+            std::memcpy(timestamps, current_batch_.columns[0]->as<int64_t>() + current_batch_offset_, 8 * leftovers);
+        std::memcpy(values, current_batch_.columns[value_column]->as<float>() + current_batch_offset_, 4 * leftovers);
     }
     const uint32_t *rows_per_segment = result->rows_per_segment;
     metrics_->add(result->metrics);
@@ -550,7 +568,7 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
     RecordBatch current;
     current.schema = schema_;
     current.num_rows = total;
-    current.columns.push_back(aliased(Type::Timestamp, timestamps));
+    if (!values_only_) current.columns.push_back(aliased(Type::Timestamp, timestamps));
     current.columns.push_back(aliased(Type::Float32, values));
     for (ColumnPtr &column : tag_columns) current.columns.push_back(column);
     current_batch_ = std::move(current);
@@ -577,6 +595,119 @@ PollState GridStream::poll_next(RecordBatch *out) {
     *out = current_batch_.slice(current_batch_offset_, length);
     current_batch_offset_ += length;
     metrics_->output_rows += static_cast<uint64_t>(length);
+    return PollState::ReadySome;
+}
+
+// ---- SortedJoinExec / SortedJoinStream ------------------------------------------------------------------------
+
+std::shared_ptr<SortedJoinExec> SortedJoinExec::make(std::vector<Field> schema,
+                                                     std::vector<SortedJoinColumnType> return_order,
+                                                     std::vector<std::shared_ptr<ExecutionPlan>> inputs) {
+    if (inputs.empty()) throw Error("At least one child must be provided SortedJoinExec.");
+    auto exec = std::make_shared<SortedJoinExec>();
+    exec->schema_ = std::move(schema);
+    exec->return_order_ = std::move(return_order);
+    for (size_t i = 1; i < inputs.size(); i++)
+        if (auto grid = std::dynamic_pointer_cast<GridExec>(inputs[i]))
+            if (!grid->values_only()) inputs[i] = grid->with_values_only();
+    exec->inputs_ = std::move(inputs);
+    return exec;
+}
+
+std::shared_ptr<SortedJoinExec>
+SortedJoinExec::with_new_children(std::vector<std::shared_ptr<ExecutionPlan>> children) const {
+    if (children.empty()) throw Error("At least one child must be provided SortedJoinExec.");
+    return SortedJoinExec::make(schema_, return_order_, std::move(children));
+}
+
+std::unique_ptr<SortedJoinStream> SortedJoinExec::execute(size_t partition, size_t batch_size) {
+    std::vector<std::unique_ptr<SegmentStream>> streams;
+    for (auto &input : inputs_) streams.push_back(input->execute_stream(partition, batch_size));
+    return std::make_unique<SortedJoinStream>(schema_, return_order_, std::move(streams), output_rows_);
+}
+
+std::unique_ptr<SegmentStream> SortedJoinExec::execute_stream(size_t partition, size_t batch_size) {
+    return execute(partition, batch_size);
+}
+
+SortedJoinStream::SortedJoinStream(std::vector<Field> schema, std::vector<SortedJoinColumnType> return_order,
+                                   std::vector<std::unique_ptr<SegmentStream>> inputs,
+                                   std::shared_ptr<uint64_t> output_rows)
+    : schema_(std::move(schema)), return_order_(std::move(return_order)), inputs_(std::move(inputs)),
+      batches_(inputs_.size()), output_rows_(std::move(output_rows)) {}
+
+std::optional<PollState> SortedJoinStream::poll_all_pending_inputs() {
+    // Every input without a batch is polled; the last poll that was not Ready(Some) is the reason
+    // returned, like the reference (a finished input ends the join, a pending one suspends it).
+    std::optional<PollState> reason_for_not_ok;
+    for (size_t index = 0; index < batches_.size(); index++) {
+        if (batches_[index]) continue;
+        RecordBatch batch;
+        PollState poll = inputs_[index]->poll_next(&batch);
+        if (poll == PollState::ReadySome)
+            batches_[index] = std::move(batch);
+        else
+            reason_for_not_ok = poll;
+    }
+    return reason_for_not_ok;
+}
+
+void SortedJoinStream::set_batch_num_rows_to_smallest() {
+    // Inputs can differ in length (sorted_join_exec.rs:248-272): a GridStream emits a short batch
+    // whenever a predicate leaves it with fewer than batch_size points (grid_exec.rs:419-423). The
+    // reference cuts every batch to the smallest and DROPS the surplus, which also shifts every later
+    // row of that input against the others. Here the surplus is kept for the next poll instead: the
+    // output is identical whenever the inputs are aligned and when one input simply ends early
+    // (the join then ends, surplus unread), and stays row-aligned where the reference would not.
+    int64_t smallest = INT64_MAX;
+    for (const auto &batch : batches_) smallest = std::min(smallest, batch->num_rows);
+    surplus_.assign(batches_.size(), std::nullopt);
+    for (size_t index = 0; index < batches_.size(); index++) {
+        if (batches_[index]->num_rows == smallest) continue;
+        surplus_[index] = batches_[index]->slice(smallest, batches_[index]->num_rows - smallest);
+        batches_[index] = batches_[index]->slice(0, smallest);
+    }
+}
+
+RecordBatch SortedJoinStream::sorted_join() const {
+    const RecordBatch &first = *batches_[0];
+    RecordBatch out;
+    out.schema = schema_;
+    out.num_rows = first.num_rows;
+    size_t field_index = 0;
+    for (const SortedJoinColumnType &element : return_order_) {
+        switch (element.kind) {
+        case SortedJoinColumnType::Kind::Timestamp:
+            out.columns.push_back(first.columns.at(0));
+            break;
+        case SortedJoinColumnType::Kind::Field: {
+            if (field_index >= batches_.size()) throw Error("SortedJoinStream has fewer inputs than field columns.");
+            const RecordBatch &batch = *batches_[field_index++];
+            // A values-only input has the value as its single column; a full one at index 1.
+            out.columns.push_back(batch.columns.at(batch.columns.size() == 1 ? 0 : 1));
+            break;
+        }
+        case SortedJoinColumnType::Kind::Tag: {
+            ColumnPtr found;
+            for (size_t c = 0; c < first.schema.size(); c++)
+                if (first.schema[c].name == element.tag_name) found = first.columns[c];
+            if (!found) throw Error("All tag columns should be in the schema.");
+            out.columns.push_back(found);
+            break;
+        }
+        }
+    }
+    if (out.columns.size() != schema_.size())
+        throw Error("SortedJoinStream should have ordered columns to match the schema.");
+    return out;
+}
+
+PollState SortedJoinStream::poll_next(RecordBatch *out) {
+    if (auto reason_for_not_ok = poll_all_pending_inputs()) return *reason_for_not_ok;
+    set_batch_num_rows_to_smallest();
+    *out = sorted_join();
+    for (size_t index = 0; index < batches_.size(); index++) batches_[index] = std::move(surplus_[index]);
+    *output_rows_ += static_cast<uint64_t>(out->num_rows);
     return PollState::ReadySome;
 }
 
@@ -966,6 +1097,12 @@ struct GridHandle {
     std::shared_ptr<mdbhost::GridExec> exec;
     std::unique_ptr<mdbhost::GridStream> stream;
 };
+
+struct JoinHandle {
+    std::vector<std::shared_ptr<mdbhost::QueueExec>> inputs;
+    std::shared_ptr<mdbhost::SortedJoinExec> exec;
+    std::unique_ptr<mdbhost::SortedJoinStream> stream;
+};
 } // namespace
 
 extern "C" {
@@ -1049,6 +1186,103 @@ int mdbh_grid_exec_describe(void *handle, char *out, uint64_t cap) {
 }
 
 void mdbh_grid_stream_free(void *handle) { delete static_cast<GridHandle *>(handle); }
+
+/* SortedJoinExec over one input per field column. use_grid != 0: every input is a GridExec over a
+ * hand-fed queue of segment batches (needs the GPU); use_grid == 0: the inputs are hand-fed queues of
+ * data point batches (timestamp, value, tags...), which exercises the join logic alone.
+ * return_kinds: 0 timestamp, 1 field, 2 tag (name in return_tag_names at the same position). */
+int mdbh_sorted_join_create(mdb_ctx *ctx, int32_t n_fields, const char *const *tag_names, int32_t n_tags,
+                            const int32_t *return_kinds, const char *const *return_tag_names, int32_t n_return,
+                            int32_t use_grid, int64_t limit, int32_t has_lower, int64_t lower, int32_t has_upper,
+                            int64_t upper, uint64_t batch_size, void **out) {
+    return guarded([&] {
+        using namespace mdbhost;
+        std::vector<std::string> tags(tag_names, tag_names + n_tags);
+        std::vector<Field> segment_schema = query_compressed_schema();
+        for (const std::string &tag : tags) segment_schema.push_back({tag, Type::Utf8View});
+        std::optional<TimestampPredicate> predicate;
+        if (has_lower || has_upper) {
+            predicate = TimestampPredicate{};
+            if (has_lower) predicate->lower = lower;
+            if (has_upper) predicate->upper = upper;
+        }
+        auto handle = std::make_unique<JoinHandle>();
+        std::vector<std::shared_ptr<ExecutionPlan>> inputs;
+        for (int32_t f = 0; f < n_fields; f++) {
+            auto queue = std::make_shared<QueueExec>(use_grid ? segment_schema : grid_schema(tags));
+            handle->inputs.push_back(queue);
+            if (use_grid)
+                inputs.push_back(GridExec::make(
+                    ctx, grid_schema(tags), predicate,
+                    limit >= 0 ? std::optional<size_t>(static_cast<size_t>(limit)) : std::nullopt, queue));
+            else
+                inputs.push_back(queue);
+        }
+        std::vector<Field> schema;
+        std::vector<SortedJoinColumnType> return_order;
+        int32_t field_index = 0;
+        for (int32_t r = 0; r < n_return; r++) {
+            if (return_kinds[r] == 0) {
+                schema.push_back({"timestamp", Type::Timestamp});
+                return_order.push_back(SortedJoinColumnType::timestamp());
+            } else if (return_kinds[r] == 1) {
+                schema.push_back({"field_" + std::to_string(field_index++), Type::Float32});
+                return_order.push_back(SortedJoinColumnType::field());
+            } else {
+                schema.push_back({return_tag_names[r], Type::Utf8View});
+                return_order.push_back(SortedJoinColumnType::tag(return_tag_names[r]));
+            }
+        }
+        handle->exec = SortedJoinExec::make(schema, return_order, inputs);
+        handle->stream = handle->exec->execute(0, batch_size);
+        *out = handle.release();
+    });
+}
+
+int mdbh_sorted_join_push(void *handle, int32_t input, ArrowArray *array, ArrowSchema *schema) {
+    return guarded([&] {
+        static_cast<JoinHandle *>(handle)->inputs.at(static_cast<size_t>(input))->push(
+            mdbhost::import_record_batch(array, schema));
+    });
+}
+
+int mdbh_sorted_join_finish_input(void *handle, int32_t input) {
+    return guarded([&] { static_cast<JoinHandle *>(handle)->inputs.at(static_cast<size_t>(input))->finish(); });
+}
+
+int mdbh_sorted_join_poll_next(void *handle, ArrowArray *out_array, ArrowSchema *out_schema, int32_t *state) {
+    return guarded([&] {
+        mdbhost::RecordBatch batch;
+        mdbhost::PollState poll = static_cast<JoinHandle *>(handle)->stream->poll_next(&batch);
+        *state = poll == mdbhost::PollState::ReadySome ? 0 : (poll == mdbhost::PollState::ReadyNone ? 1 : 2);
+        if (poll == mdbhost::PollState::ReadySome) mdbhost::export_record_batch(batch, out_array, out_schema);
+    });
+}
+
+int mdbh_sorted_join_describe(void *handle, char *out, uint64_t cap) {
+    return guarded([&] {
+        JoinHandle *h = static_cast<JoinHandle *>(handle);
+        std::string text = std::string(h->exec->name()) + "|" + h->exec->fmt_as() + "|children=" +
+                           std::to_string(h->exec->children().size()) + "|distribution=";
+        for (mdbhost::Distribution d : h->exec->required_input_distribution())
+            text += d == mdbhost::Distribution::SinglePartition ? "SinglePartition," : "Unspecified,";
+        text += "|values_only=";
+        for (auto &child : h->exec->children()) {
+            auto grid = std::dynamic_pointer_cast<mdbhost::GridExec>(child);
+            text += grid ? (grid->values_only() ? "1" : "0") : "-";
+        }
+        text += "|output_rows=" + std::to_string(h->exec->output_rows());
+        try {
+            h->exec->with_new_children({});
+        } catch (const mdbhost::Error &e) {
+            text += std::string("|with_new_children([])=Err(") + e.what() + ")";
+        }
+        std::strncpy(out, text.c_str(), cap - 1);
+        out[cap - 1] = 0;
+    });
+}
+
+void mdbh_sorted_join_free(void *handle) { delete static_cast<JoinHandle *>(handle); }
 
 /* kind: 0 count, 1 min, 2 max, 3 sum, 4 avg */
 int mdbh_accumulator_create(mdb_ctx *ctx, int32_t kind, void **out) {

@@ -105,6 +105,11 @@ struct ExecutionPlan { // the slice of datafusion's ExecutionPlan that GridExec 
     virtual std::vector<Field> schema() const = 0;
     virtual std::vector<std::shared_ptr<ExecutionPlan>> children() const = 0;
     virtual std::unique_ptr<SegmentStream> execute_segments(size_t partition) = 0;
+    // ExecutionPlan::execute as a parent operator sees it: a stream of RecordBatches (SegmentStream
+    // is just that). Plans that need the session's batch_size override it.
+    virtual std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t /*batch_size*/) {
+        return execute_segments(partition);
+    }
 };
 
 // A child plan fed by hand: batches are pushed, then the input is finished (used by tests and by
@@ -172,6 +177,12 @@ class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridE
     std::unique_ptr<SegmentStream> execute_segments(size_t) override {
         throw Error("GridExec produces data points, not segments.");
     }
+    std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t batch_size) override;
+    // A copy of this plan whose stream emits only the `value` column (same metrics object). Used by
+    // SortedJoinExec for every input but the first: only their values are read
+    // (sorted_join_exec.rs:268-275), so their timestamps and tags are never materialised.
+    std::shared_ptr<GridExec> with_values_only() const;
+    bool values_only() const { return values_only_; }
     std::vector<Distribution> required_input_distribution() const { return {Distribution::SinglePartition}; }
     std::string fmt_as() const; // "GridExec: limit=Some(5)" (:203-209)
     std::shared_ptr<GridStreamMetrics> metrics() const { return metrics_; }
@@ -184,15 +195,16 @@ class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridE
     std::optional<size_t> limit_;
     std::shared_ptr<ExecutionPlan> input_;
     std::shared_ptr<GridStreamMetrics> metrics_ = std::make_shared<GridStreamMetrics>();
+    bool values_only_ = false;
 };
 
-class GridStream { // grid_exec.rs:213-437
+class GridStream : public SegmentStream { // grid_exec.rs:213-437
   public:
     GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<TimestampPredicate> maybe_predicate,
                std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
-               std::shared_ptr<GridStreamMetrics> metrics);
+               std::shared_ptr<GridStreamMetrics> metrics, bool values_only = false);
     // Stream::poll_next (:402-429)
-    PollState poll_next(RecordBatch *out);
+    PollState poll_next(RecordBatch *out) override;
     std::vector<Field> schema() const { return schema_; }
     size_t batch_size() const { return batch_size_; }
 
@@ -206,6 +218,70 @@ class GridStream { // grid_exec.rs:213-437
     RecordBatch current_batch_;
     int64_t current_batch_offset_ = 0;
     std::shared_ptr<GridStreamMetrics> metrics_;
+    bool values_only_ = false;
+};
+
+// ---- SortedJoinExec (crates/modelardb_storage/src/query/sorted_join_exec.rs) ------------------------------------
+
+// Order of the columns SortedJoinStream returns (sorted_join_exec.rs:46-52).
+struct SortedJoinColumnType {
+    enum class Kind { Timestamp, Field, Tag } kind;
+    std::string tag_name; // Kind::Tag only
+    static SortedJoinColumnType timestamp() { return {Kind::Timestamp, {}}; }
+    static SortedJoinColumnType field() { return {Kind::Field, {}}; }
+    static SortedJoinColumnType tag(std::string name) { return {Kind::Tag, std::move(name)}; }
+};
+
+class SortedJoinStream;
+
+// Joins the sorted data points of one GridExec per field column into (timestamp, fields..., tags...)
+// rows. Timestamps and tags are taken from the first input only, so every later GridExec input is
+// switched to values-only: 4 instead of 12 bytes per point and field cross PCIe.
+class SortedJoinExec : public ExecutionPlan {
+  public:
+    // SortedJoinExec::new (sorted_join_exec.rs:75-101)
+    static std::shared_ptr<SortedJoinExec> make(std::vector<Field> schema,
+                                                std::vector<SortedJoinColumnType> return_order,
+                                                std::vector<std::shared_ptr<ExecutionPlan>> inputs);
+    const char *name() const override { return "SortedJoinExec"; }
+    std::vector<Field> schema() const override { return schema_; }
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return inputs_; }
+    // Err(Plan("At least one child must be provided ...")) if children is empty (:131-147).
+    std::shared_ptr<SortedJoinExec> with_new_children(std::vector<std::shared_ptr<ExecutionPlan>> children) const;
+    std::unique_ptr<SortedJoinStream> execute(size_t partition, size_t batch_size); // :151-168
+    std::unique_ptr<SegmentStream> execute_segments(size_t) override {
+        throw Error("SortedJoinExec produces data points, not segments.");
+    }
+    std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t batch_size) override;
+    std::vector<Distribution> required_input_distribution() const { // :173-175
+        return std::vector<Distribution>(inputs_.size(), Distribution::SinglePartition);
+    }
+    std::string fmt_as() const { return name(); } // :192-198
+    uint64_t output_rows() const { return *output_rows_; }
+
+  private:
+    std::vector<Field> schema_;
+    std::vector<SortedJoinColumnType> return_order_;
+    std::vector<std::shared_ptr<ExecutionPlan>> inputs_;
+    std::shared_ptr<uint64_t> output_rows_ = std::make_shared<uint64_t>(0); // BaselineMetrics
+};
+
+class SortedJoinStream : public SegmentStream { // sorted_join_exec.rs:200-336
+  public:
+    SortedJoinStream(std::vector<Field> schema, std::vector<SortedJoinColumnType> return_order,
+                     std::vector<std::unique_ptr<SegmentStream>> inputs, std::shared_ptr<uint64_t> output_rows);
+    PollState poll_next(RecordBatch *out) override; // :306-327
+
+  private:
+    std::optional<PollState> poll_all_pending_inputs(); // :228-246
+    void set_batch_num_rows_to_smallest();              // :251-272
+    RecordBatch sorted_join() const;                    // :277-311
+    std::vector<Field> schema_;
+    std::vector<SortedJoinColumnType> return_order_;
+    std::vector<std::unique_ptr<SegmentStream>> inputs_;
+    std::vector<std::optional<RecordBatch>> batches_;
+    std::vector<std::optional<RecordBatch>> surplus_; // rows beyond the smallest batch, kept for the next poll
+    std::shared_ptr<uint64_t> output_rows_;
 };
 
 // ---- accumulators (model_simple_aggregates.rs:336-618) -------------------------------------------------------

@@ -763,8 +763,8 @@ struct OwnedGridResult {
     uint64_t capacity;
 };
 
-int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t reserve_front,
-                          mdb_grid_result **out) {
+int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, bool values_only,
+                          uint64_t reserve_front, mdb_grid_result **out) {
     if (!ctx || !in || !out) return fail("ctx, in and out must not be NULL.");
     mdb_segments_owned *dev = nullptr;
     if (mdb_segments_upload(ctx, in, &dev)) return 1;
@@ -777,14 +777,15 @@ int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
         const uint64_t total = plan.host_header.total_points;
         // The device staging area mirrors the host block (same gaps), so one copy moves it all.
         const uint64_t front = align_up(reserve_front, 4); // keeps the 16-byte store alignment
-        const uint64_t ts_bytes = align_up((front + total) * 8, 256);
+        const uint64_t ts_bytes = values_only ? 0 : align_up((front + total) * 8, 256);
         const uint64_t val_bytes = align_up((front + total) * 4, 256);
         const uint64_t rows_bytes = align_up(in->n * 4, 256);
         void *stage = nullptr;
         if (!rc) rc = scratch_reserve(ctx, SCRATCH_STAGE_DEV, ts_bytes + val_bytes + rows_bytes, &stage);
         uint8_t *base = static_cast<uint8_t *>(stage);
         if (!rc)
-            rc = grid_launch(ctx, &dev->seg, range, plan, reinterpret_cast<int64_t *>(base) + front,
+            rc = grid_launch(ctx, &dev->seg, range, plan,
+                             values_only ? nullptr : reinterpret_cast<int64_t *>(base) + front,
                              reinterpret_cast<float *>(base + ts_bytes) + front,
                              reinterpret_cast<uint32_t *>(base + ts_bytes + val_bytes));
         void *block = nullptr;
@@ -802,7 +803,7 @@ int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
             } else {
                 result = new OwnedGridResult();
                 uint8_t *host = static_cast<uint8_t *>(block);
-                result->c.timestamps = reinterpret_cast<int64_t *>(host) + front;
+                result->c.timestamps = values_only ? nullptr : reinterpret_cast<int64_t *>(host) + front;
                 result->c.values = reinterpret_cast<float *>(host + ts_bytes) + front;
                 result->c.rows_per_segment = reinterpret_cast<uint32_t *>(host + ts_bytes + val_bytes);
                 result->c.n = total;
@@ -827,9 +828,10 @@ int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
 
 extern "C" {
 
-int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, int32_t has_range, int64_t t_lo,
+int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, int64_t t_lo,
                          int64_t t_hi, uint64_t reserve_front, mdb_grid_result **out) {
-    return grid_batch_owned_impl(ctx, in, TimeRange{t_lo, t_hi, has_range ? 1 : 0}, reserve_front, out);
+    return grid_batch_owned_impl(ctx, in, TimeRange{t_lo, t_hi, (flags & MDB_GRID_HAS_RANGE) ? 1 : 0},
+                                 (flags & MDB_GRID_VALUES_ONLY) != 0, reserve_front, out);
 }
 
 void mdb_grid_result_free(mdb_grid_result *result) {

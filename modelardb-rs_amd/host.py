@@ -43,6 +43,7 @@ def lib():
         _lib.mdbh_last_error.restype = C.c_char_p
         _lib.mdbh_accumulator_size.restype = C.c_uint64
         _lib.mdbh_grid_stream_free.restype = None
+        _lib.mdbh_sorted_join_free.restype = None
         _lib.mdbh_accumulator_free.restype = None
         _lib.mdbh_batches_free.restype = None
         _lib.mdbh_udm_free.restype = None
@@ -139,6 +140,85 @@ class GridStream:
     def close(self):
         if self.handle:
             lib().mdbh_grid_stream_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SortedJoinStream:
+    """SortedJoinExec::execute(...) of crates/modelardb_storage/src/query/sorted_join_exec.rs over
+    one hand-fed input per field column. With use_grid=True every input is a GridExec (segment
+    batches are pushed, the inputs after the first only reconstruct values); with use_grid=False
+    the inputs are plain streams of (timestamp, value, tags...) batches.
+
+    return_order: sequence of "timestamp", "field" or ("tag", name), the order of the columns
+    returned (SortedJoinColumnType, sorted_join_exec.rs:46-52)."""
+
+    READY_SOME, READY_NONE, PENDING = 0, 1, 2
+
+    def __init__(self, context, n_fields, return_order, tag_names=(), use_grid=True, limit=None,
+                 predicate=(None, None), batch_size=8192):
+        self._context = context
+        self.handle = C.c_void_p()
+        names, self._keep = _strings(tag_names)
+        kinds, tag_of = [], []
+        for element in return_order:
+            if element == "timestamp":
+                kinds.append(0), tag_of.append("")
+            elif element == "field":
+                kinds.append(1), tag_of.append("")
+            else:
+                kinds.append(2), tag_of.append(element[1])
+        return_names, self._keep_return = _strings(tag_of)
+        lower, upper = predicate
+        _check(lib().mdbh_sorted_join_create(
+            context.handle if context is not None else None, C.c_int32(n_fields), names,
+            C.c_int32(len(tag_names)), (C.c_int32 * max(len(kinds), 1))(*kinds), return_names,
+            C.c_int32(len(kinds)), C.c_int32(bool(use_grid)), C.c_int64(-1 if limit is None else limit),
+            C.c_int32(lower is not None), C.c_int64(lower or 0), C.c_int32(upper is not None),
+            C.c_int64(upper or 0), C.c_uint64(batch_size), C.byref(self.handle)))
+
+    def push(self, input_index, batch):
+        array, schema = _export(batch)
+        _check(lib().mdbh_sorted_join_push(self.handle, C.c_int32(input_index), C.byref(array),
+                                           C.byref(schema)))
+
+    def finish_input(self, input_index=None):
+        indices = range(self.n_inputs()) if input_index is None else [input_index]
+        for index in indices:
+            _check(lib().mdbh_sorted_join_finish_input(self.handle, C.c_int32(index)))
+
+    def n_inputs(self):
+        return int(self.describe().split("|children=")[1].split("|")[0])
+
+    def poll_next(self):
+        array, schema, state = ArrowArrayC(), ArrowSchemaC(), C.c_int32()
+        _check(lib().mdbh_sorted_join_poll_next(self.handle, C.byref(array), C.byref(schema),
+                                                C.byref(state)))
+        if state.value == self.READY_SOME:
+            return state.value, _import_batch(array, schema)
+        return state.value, None
+
+    def collect(self):
+        batches = []
+        while True:
+            state, batch = self.poll_next()
+            if state != self.READY_SOME:
+                return batches, state
+            batches.append(batch)
+
+    def describe(self):
+        out = C.create_string_buffer(1024)
+        _check(lib().mdbh_sorted_join_describe(self.handle, out, C.c_uint64(1024)))
+        return out.value.decode()
+
+    def close(self):
+        if self.handle:
+            lib().mdbh_sorted_join_free(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

@@ -318,3 +318,40 @@ def test_segment_files_to_device_and_grid(hip, tmp_path):
     hip.dev_free(out_ts)
     hip.dev_free(out_val)
     device_segments.free()
+
+
+@pytest.mark.parametrize("predicate", [(None, None), "middle"])
+def test_sorted_join_of_three_field_columns(hip, predicate):
+    # sorted_join_exec.rs:277-311 over one GridExec per field column: timestamps and
+    # tags come from the first field's GridExec, the other two only reconstruct values.
+    eb = cases.error_bounds()["rel5"]
+    timestamps, _ = cases.synthetic_series(40_000, True, (1.0, 1.05), 90)
+    if predicate == "middle":
+        predicate = (int(timestamps[5_000]), int(timestamps[31_234]))
+    fields = []
+    for seed in (91, 92, 93):
+        _, values = cases.synthetic_series(40_000, True, (1.0, 1.05), seed)
+        fields.append(ora.try_compress_univariate_time_series(timestamps, values, eb))
+    order = ["timestamp", "field", "field", ("tag", "tag"), "field"]
+    join = host.SortedJoinStream(hip, 3, order, tag_names=("tag",), predicate=predicate, batch_size=4096)
+    assert "values_only=011" in join.describe()
+    for index, batch in enumerate(fields):
+        for part in _segment_batches(batch, {"tag": "wind-turbine-1234567"}, 37 + index):  # ragged on purpose
+            join.push(index, part)
+    join.finish_input()
+    batches, state = join.collect()
+    assert state == host.SortedJoinStream.READY_NONE
+    table = pa.Table.from_batches(batches)
+    assert table.schema.names == ["timestamp", "field_0", "field_1", "tag", "field_2"]
+    expected = [ora.grid_batch(batch) for batch in fields]
+    keep = np.ones(len(expected[0][0]), dtype=bool)
+    if predicate != (None, None):
+        keep = (expected[0][0] >= predicate[0]) & (expected[0][0] <= predicate[1])
+    # The inputs emit batches of different sizes (ragged pushes, short batches under the predicate);
+    # the join keeps them row-aligned and returns every point.
+    n = table.num_rows
+    assert n == int(keep.sum())
+    assert np.array_equal(table.column("timestamp").cast(pa.int64()).to_numpy(), expected[0][0][keep][:n])
+    for column, (_, values, _, _) in zip(("field_0", "field_1", "field_2"), expected):
+        assert np.array_equal(table.column(column).to_numpy().view(np.uint32), values[keep][:n].view(np.uint32))
+    assert set(table.column("tag").to_pylist()) == {"wind-turbine-1234567"}

@@ -70,3 +70,60 @@ def test_uncompressed_data_manager_buffers_by_series_and_finishes_unused():
     assert manager.counts() == (1, 2)                      # A reached capacity 4 -> finished; new A buffer
     manager.flush()
     assert manager.counts() == (0, 3)
+
+
+def _points(timestamps, values, tag):
+    import pyarrow as pa
+    return pa.RecordBatch.from_arrays([
+        pa.array(timestamps, type=pa.int64()).cast(pa.timestamp("us")),
+        pa.array(values, type=pa.float32()),
+        pa.array([tag] * len(timestamps), type=pa.string_view())], names=["timestamp", "value", "tag"])
+
+
+def test_sorted_join_stream_zips_fields_in_return_order():
+    # sorted_join_exec.rs:277-311: timestamp and tags from input 0, one value column per input, in the
+    # order return_order asks for.
+    order = [("tag", "tag"), "field", "timestamp", "field"]
+    join = host.SortedJoinStream(None, 2, order, tag_names=("tag",), use_grid=False)
+    join.push(0, _points([100, 200, 300], [1.0, 2.0, 3.0], "A"))
+    join.push(1, _points([100, 200, 300], [10.0, 20.0, 30.0], "A"))
+    state, batch = join.poll_next()
+    assert state == host.SortedJoinStream.READY_SOME
+    assert batch.schema.names == ["tag", "field_0", "timestamp", "field_1"]
+    assert batch.column(0).to_pylist() == ["A", "A", "A"]
+    assert batch.column(1).to_pylist() == [1.0, 2.0, 3.0]
+    assert batch.column(2).cast("int64").to_pylist() == [100, 200, 300]
+    assert batch.column(3).to_pylist() == [10.0, 20.0, 30.0]
+    assert "output_rows=3" in join.describe()
+
+
+def test_sorted_join_stream_poll_protocol_and_smallest_batch():
+    join = host.SortedJoinStream(None, 2, ["timestamp", "field", "field"], tag_names=("tag",), use_grid=False)
+    assert join.poll_next() == (host.SortedJoinStream.PENDING, None)
+    join.push(0, _points([1, 2, 3, 4], [1.0, 2.0, 3.0, 4.0], "A"))
+    assert join.poll_next() == (host.SortedJoinStream.PENDING, None)   # input 1 has nothing yet; batch 0 kept
+    join.push(1, _points([1, 2], [5.0, 6.0], "A"))
+    state, batch = join.poll_next()
+    # Inputs of different length are cut to the smallest (sorted_join_exec.rs:248-272) ...
+    assert state == host.SortedJoinStream.READY_SOME and batch.num_rows == 2
+    assert batch.column(0).cast("int64").to_pylist() == [1, 2]
+    assert batch.column(2).to_pylist() == [5.0, 6.0]
+    # ... and the surplus of the longer one waits for the next poll, so the rows stay aligned.
+    join.push(1, _points([3], [7.0], "A"))
+    state, batch = join.poll_next()
+    assert state == host.SortedJoinStream.READY_SOME
+    assert batch.column(0).cast("int64").to_pylist() == [3] and batch.column(2).to_pylist() == [7.0]
+    join.finish_input(1)
+    assert join.poll_next() == (host.SortedJoinStream.READY_NONE, None)  # a finished input ends the join
+    join.close()
+
+
+def test_sorted_join_exec_plan_surface():
+    # sorted_join_exec.rs:104-198. GridExec inputs after the first only reconstruct values.
+    join = host.SortedJoinStream(_NullContext(), 3, ["timestamp", "field", "field", "field"], use_grid=True)
+    description = join.describe()
+    assert description.startswith("SortedJoinExec|SortedJoinExec|children=3|")
+    assert "distribution=SinglePartition,SinglePartition,SinglePartition," in description
+    assert "values_only=011" in description
+    assert "with_new_children([])=Err(At least one child must be provided" in description
+    assert join.n_inputs() == 3
