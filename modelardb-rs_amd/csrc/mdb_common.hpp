@@ -63,6 +63,7 @@ enum ScratchSlot {
     SCRATCH_FIT_D,
     SCRATCH_FIT_E,
     SCRATCH_FIT_F,
+    SCRATCH_FIT_SPLIT,
     SCRATCH_STAGE_DEV,
     SCRATCH_SLOT_COUNT
 };

@@ -496,6 +496,68 @@ struct RecordCapacity {
     }
 };
 
+// Segments implied by the gaps between accepted models (compression.rs:240-249, 310-362): a gap of
+// more than 255 points, or any gap in front of the first model, is a MacaqueV segment of its own.
+struct GapCounter {
+    bool have_previous = false;
+    uint32_t previous_end = 0;
+    uint32_t n_segments = 0;
+    __device__ __forceinline__ void on_model(uint32_t start, uint32_t end) {
+        if (have_previous) {
+            if (start - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
+        } else if (start > 0) {
+            n_segments += 1;
+        }
+        n_segments += 1;
+        have_previous = true;
+        previous_end = end;
+    }
+    __device__ __forceinline__ uint32_t finish(uint32_t n) {
+        if (have_previous) {
+            if (n - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
+        } else {
+            n_segments += 1;
+        }
+        return n_segments;
+    }
+};
+
+// Split mode (few chunks per call: an embedded-API series, a handful of ingest buffers). The greedy
+// loop is a pure function "model fitted from point c -> (accepted, end) or rejected", and the chain
+// of models of a chunk is that function iterated from point 0. With one lane per chunk a call with
+// few chunks leaves the GPU idle for chunk_length x ~1 us. Instead every chunk is cut into pieces of
+// `piece_points` and one lane starts the same greedy loop at the start of each piece, speculatively:
+// its first models are in general NOT models of the real chain, but greedy chains that start at
+// different points meet after a few models (as soon as two of them end a model at the same point)
+// and are identical from there on. Every lane records what it fitted from each start point it
+// visits in a per-point table and stops as soon as it reaches a point some lane has already been
+// at (normally the lane of the next piece, a few models into that piece): from there the recorded
+// chain is the one it would produce itself. k_fit_walk then follows the table from point 0 of every
+// chunk and copies the models on the real chain into the per-chunk record lists the non-split path
+// produces, so everything downstream is unchanged and the result is bit-identical.
+// Table entry per input point: 0 = not visited, 1 = no model accepted from here (the point becomes a
+// residual, compression.rs:258-262), otherwise (end + 2) | type << 31.
+struct SplitArgs {
+    const unsigned long long *piece_base; // exclusive scan of the pieces per chunk, n_chunks + 1
+    uint64_t n_pieces;
+    uint32_t piece_points;
+    unsigned int *entry; // indexed by chunk_offsets[chunk] + point
+    float *p0;
+    float *p1;
+};
+
+constexpr uint32_t ENTRY_REJECTED = 1u;
+constexpr uint32_t ENTRY_END_BIAS = 2u;
+
+struct PieceCount {
+    const unsigned long long *chunk_offsets;
+    uint32_t piece_points;
+    __device__ uint64_t operator()(uint64_t c) const {
+        const uint64_t length = chunk_offsets[c + 1] - chunk_offsets[c];
+        return length > COUNT_MASK - ENTRY_END_BIAS ? 0 : (length + piece_points - 1) / piece_points;
+    }
+};
+
 // One lane per chunk, one wave per workgroup. The greedy loop is flattened into a per-lane state
 // machine ("feed one point" or "finish the model") so that all 64 lanes can share wave-synchronous
 // prefetching: every lane keeps a ring of its next FIT_RING values (and timestamps, when they are
@@ -507,8 +569,8 @@ constexpr int FIT_RING = 32;
 constexpr int FIT_HISTORY = 8;
 constexpr int FIT_THREADS = MDB_WAVE;
 
-template <bool HAS_TS>
-__global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
+template <bool HAS_TS, bool SPLIT>
+__global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitArgs split,
                                                            const unsigned long long *__restrict__ record_base,
                                                            ModelRec *__restrict__ records,
                                                            ChunkPlan *__restrict__ plans,
@@ -516,14 +578,27 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
     __shared__ float ring_values[FIT_RING][MDB_WAVE];
     __shared__ long long ring_ts[HAS_TS ? FIT_RING : 1][MDB_WAVE];
     const int lane = threadIdx.x;
-    const uint64_t chunk = (uint64_t)blockIdx.x * FIT_THREADS + lane;
-    bool active = chunk < args.n_chunks;
+    const uint64_t unit = (uint64_t)blockIdx.x * FIT_THREADS + lane;
+    uint64_t chunk = unit;
+    bool active = unit < (SPLIT ? split.n_pieces : args.n_chunks);
+    uint32_t first_point = 0;
+    if (SPLIT && active) {
+        // The chunk of this piece: the last c with piece_base[c] <= unit.
+        uint64_t lo = 0, hi = args.n_chunks;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (split.piece_base[mid] <= unit) lo = mid;
+            else hi = mid;
+        }
+        chunk = lo;
+        first_point = (uint32_t)(unit - split.piece_base[chunk]) * split.piece_points;
+    }
     uint64_t base = 0;
     uint32_t n = 0;
     if (active) {
         base = args.chunk_offsets[chunk];
         const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
-        if (length64 > COUNT_MASK) {
+        if (length64 > COUNT_MASK - ENTRY_END_BIAS) { // (split mode gives such a chunk no pieces)
             atomicOr(error, ERR_TOO_LONG);
             plans[chunk] = {0, 0};
             active = false;
@@ -536,21 +611,20 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
     const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, active ? chunk : 0, base);
     const mdb_error_bound eb = args.eb;
     const DeviationFactor dev = deviation_factor(eb);
-    ModelRec *__restrict__ out = records + (active ? record_base[chunk] : 0);
+    ModelRec *__restrict__ out = records + ((active && !SPLIT) ? record_base[chunk] : 0);
 
-    uint32_t n_models = 0, n_segments = 0;
-    bool have_previous = false;
-    uint32_t previous_end = 0;
-    uint32_t current = 0; // first point of the model being fitted
-    uint32_t j = 0;       // next point to feed
-    uint32_t loaded = 0;  // the ring holds points [low, loaded) of the chunk, loaded - low <= FIT_RING
-    uint32_t low = 0;
+    uint32_t n_models = 0;
+    GapCounter gaps;
+    uint32_t current = first_point; // first point of the model being fitted
+    uint32_t j = first_point;       // next point to feed
+    uint32_t loaded = first_point;  // the ring holds points [low, loaded) of the chunk, loaded - low <= FIT_RING
+    uint32_t low = first_point;
     PmcDev pmc;
     SwingDev swing;
     pmc.reset();
     swing.reset();
     bool pmc_fits = true, swing_fits = true;
-    if (active && n == 0) {
+    if (!SPLIT && active && n == 0) {
         plans[chunk] = {0, 0};
         active = false;
     }
@@ -614,28 +688,29 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
                     rec.end = current + swing.length - 1;
                     swing.model(&rec.p0, &rec.p1);
                 }
-                // Segments implied by the gap before this model (compression.rs:240-249, 310-362).
-                if (have_previous) {
-                    if (current - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
-                } else if (current > 0) {
-                    n_segments += 1;
+                if (SPLIT) {
+                    split.p0[base + current] = rec.p0;
+                    split.p1[base + current] = rec.p1;
+                    __hip_atomic_store(&split.entry[base + current],
+                                       (rec.end + ENTRY_END_BIAS) | (rec.start_and_type & 0x80000000u),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    gaps.on_model(current, rec.end);
+                    out[n_models++] = rec;
                 }
-                out[n_models++] = rec;
-                n_segments += 1;
-                have_previous = true;
-                previous_end = rec.end;
                 current = rec.end + 1;
             } else {
+                if (SPLIT)
+                    __hip_atomic_store(&split.entry[base + current], ENTRY_REJECTED, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
                 current += 1; // the point becomes a residual (compression.rs:258-262)
             }
             if (current >= n) {
-                if (have_previous) {
-                    if (n - 1 - previous_end > MDB_RESIDUAL_VALUES_MAX_LENGTH) n_segments += 1;
-                } else {
-                    n_segments += 1;
-                }
-                plans[chunk] = {n_models, n_segments};
+                if (!SPLIT) plans[chunk] = {n_models, gaps.finish(n)};
                 active = false;
+            } else if (SPLIT && __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                active = false; // some lane has been here: the chain from this point on is recorded
             } else {
                 pmc.reset();
                 swing.reset();
@@ -645,6 +720,67 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args,
             }
         }
     }
+}
+
+// ---- k_fit_walk (split mode) ---------------------------------------------------------------------------------
+//
+// One wave per chunk follows the table from point 0. The wave keeps the entries of 64 consecutive
+// points in registers (one coalesced load) and steps through them with a uniform cursor, so a run of
+// rejected points costs a register read per point rather than a memory round trip.
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long *__restrict__ chunk_offsets,
+                                                       uint64_t n_chunks, SplitArgs split,
+                                                       const unsigned long long *__restrict__ record_base,
+                                                       ModelRec *__restrict__ records,
+                                                       ChunkPlan *__restrict__ plans,
+                                                       unsigned int *__restrict__ error) {
+    const uint64_t chunk = blockIdx.x;
+    if (chunk >= n_chunks) return;
+    const int lane = threadIdx.x;
+    const uint64_t base = chunk_offsets[chunk];
+    const uint64_t length64 = chunk_offsets[chunk + 1] - base;
+    if (length64 > COUNT_MASK - ENTRY_END_BIAS) {
+        if (lane == 0) {
+            atomicOr(error, ERR_TOO_LONG);
+            plans[chunk] = {0, 0};
+        }
+        return;
+    }
+    const uint32_t n = (uint32_t)length64;
+    ModelRec *__restrict__ out = records + record_base[chunk];
+    uint32_t n_models = 0;
+    GapCounter gaps;
+    uint32_t position = 0;
+    uint32_t window_first = 0;
+    uint32_t window = 0;
+    bool window_valid = false;
+    while (position < n) {
+        if (!window_valid || position - window_first >= MDB_WAVE) {
+            window_first = position;
+            window = (position + lane < n) ? split.entry[base + position + lane] : 0u;
+            window_valid = true;
+        }
+        const uint32_t entry = __shfl(window, (int)(position - window_first), MDB_WAVE);
+        if (entry == ENTRY_REJECTED) {
+            position += 1;
+        } else if (entry == 0u) { // cannot happen: every point on the chain was visited by some lane
+            if (lane == 0) atomicOr(error, ERR_SPLIT_CHAIN);
+            break;
+        } else {
+            const uint32_t end = (entry & COUNT_MASK) - ENTRY_END_BIAS;
+            if (lane == 0) {
+                ModelRec rec;
+                rec.start_and_type = position | (entry & 0x80000000u);
+                rec.end = end;
+                rec.p0 = split.p0[base + position];
+                rec.p1 = split.p1[base + position];
+                out[n_models] = rec;
+            }
+            gaps.on_model(position, end);
+            n_models += 1;
+            position = end + 1;
+        }
+    }
+    if (lane == 0) plans[chunk] = n == 0 ? ChunkPlan{0, 0} : ChunkPlan{n_models, gaps.finish(n)};
 }
 
 // ---- k_fit_plan --------------------------------------------------------------------------------------------
@@ -912,6 +1048,23 @@ static bool valid_error_bound(mdb_error_bound eb) { // crates/modelardb_types/sr
     return false;
 }
 
+// Points per piece for split mode, 0 = one lane per chunk. Split when the call has too few chunks
+// to give every SIMD a couple of waves and the chunks are long enough to be worth cutting.
+// MDB_FIT_PIECE_POINTS overrides: 1 = never split, N >= 64 = always split into pieces of N points.
+static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64_t total_points) {
+    if (const char *forced = std::getenv("MDB_FIT_PIECE_POINTS")) {
+        const long long value = std::atoll(forced);
+        if (value == 1) return 0;
+        if (value >= 64) return (uint32_t)std::min<long long>(value, 1 << 30);
+    }
+    const uint64_t target_lanes = (uint64_t)std::max(ctx->compute_units, 1) * 4 * MDB_WAVE * 2;
+    if (n_chunks == 0 || n_chunks >= target_lanes / 2) return 0;
+    if (total_points * 12 > (4ull << 30)) return 0; // the per-point table would be too large
+    const uint64_t piece = std::max<uint64_t>(512, align_up(total_points / target_lanes + 1, 64));
+    if (total_points / n_chunks < 2 * piece) return 0; // chunks too short to gain anything
+    return (uint32_t)piece;
+}
+
 int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *values,
                                const uint64_t *chunk_offsets, uint64_t n_chunks, mdb_error_bound eb,
                                int64_t regular_start, int64_t regular_interval,
@@ -964,11 +1117,15 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     unsigned long long total_records = 0;
     unsigned long long n_segments = 0;
     if (n_chunks > 0) {
+        unsigned long long points_end = 0;
         FIT_TRY(device_exclusive_scan(ctx, RecordCapacity{args.chunk_offsets}, n_chunks, record_base,
                                       block_sums, "k_fit_scan"));
         FIT_CHECK(hipMemcpyAsync(&total_records, record_base + n_chunks, 8, hipMemcpyDeviceToHost,
                                  ctx->stream));
+        FIT_CHECK(hipMemcpyAsync(&points_end, args.chunk_offsets + n_chunks, 8, hipMemcpyDeviceToHost,
+                                 ctx->stream));
         FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        const uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
         ModelRec *records = static_cast<ModelRec *>(p);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_C, n_chunks * sizeof(ChunkPlan), &p));
@@ -976,15 +1133,47 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_D, (n_chunks + 1) * 8, &p));
         unsigned long long *segment_base = static_cast<unsigned long long *>(p);
         const uint32_t chunk_blocks = (uint32_t)((n_chunks + 255) / 256);
-        {
+        if (piece_points == 0) {
             LaunchTimer timer(ctx, "k_fit_models");
             const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
             if (ts)
-                hipLaunchKernelGGL(k_fit_models<true>, dim3(fit_blocks), dim3(FIT_THREADS), 0, ctx->stream,
-                                   args, record_base, records, plans, error_flag);
+                hipLaunchKernelGGL((k_fit_models<true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
             else
-                hipLaunchKernelGGL(k_fit_models<false>, dim3(fit_blocks), dim3(FIT_THREADS), 0, ctx->stream,
-                                   args, record_base, records, plans, error_flag);
+                hipLaunchKernelGGL((k_fit_models<false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+        } else {
+            // Split mode: pieces of every chunk fitted speculatively, then the real chain is walked.
+            SplitArgs split{};
+            split.piece_points = piece_points;
+            const uint64_t table_points = points_end;
+            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_SPLIT, (n_chunks + 1) * 8 + 64 + table_points * 12, &p));
+            unsigned long long *piece_base = static_cast<unsigned long long *>(p);
+            split.piece_base = piece_base;
+            split.entry = reinterpret_cast<unsigned int *>(reinterpret_cast<uint8_t *>(p) +
+                                                           align_up((n_chunks + 1) * 8, 64));
+            split.p0 = reinterpret_cast<float *>(split.entry + table_points);
+            split.p1 = split.p0 + table_points;
+            FIT_CHECK(hipMemsetAsync(split.entry, 0, table_points * 4, ctx->stream));
+            FIT_TRY(device_exclusive_scan(ctx, PieceCount{args.chunk_offsets, piece_points}, n_chunks, piece_base,
+                                          block_sums, "k_fit_scan"));
+            unsigned long long n_pieces = 0;
+            FIT_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n_chunks, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            split.n_pieces = n_pieces;
+            if (n_pieces > 0) {
+                LaunchTimer timer(ctx, "k_fit_models_split");
+                const uint32_t fit_blocks = (uint32_t)((n_pieces + FIT_THREADS - 1) / FIT_THREADS);
+                if (ts)
+                    hipLaunchKernelGGL((k_fit_models<true, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else
+                    hipLaunchKernelGGL((k_fit_models<false, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+            }
+            LaunchTimer timer(ctx, "k_fit_walk");
+            hipLaunchKernelGGL(k_fit_walk, dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream,
+                               args.chunk_offsets, n_chunks, split, record_base, records, plans, error_flag);
         }
         FIT_TRY(device_exclusive_scan(ctx, SegmentCount{plans}, n_chunks, segment_base, block_sums,
                                       "k_fit_scan"));
@@ -994,9 +1183,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         FIT_CHECK(hipMemcpyAsync(&error, error_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         FIT_CHECK(hipStreamSynchronize(ctx->stream));
         FIT_CHECK(hipGetLastError());
+        if (error & ERR_SPLIT_CHAIN) {
+            release();
+            return fail("Internal error: the split fit left a gap in a chunk's model chain.");
+        }
         if (error) {
             release();
-            return fail("A chunk holds more than 2^31-1 data points.");
+            return fail("A chunk holds more than 2^31-3 data points.");
         }
         if (n_segments > 0x7ffffff0ull) {
             release();

@@ -24,6 +24,7 @@ enum : uint32_t {
     ERR_RESIDUALS = 1u << 3,
     ERR_BITSTREAM = 1u << 4,
     ERR_TOO_LONG = 1u << 5,
+    ERR_SPLIT_CHAIN = 1u << 6, // fit, split mode: the walk reached a point no lane visited (a bug)
 };
 
 struct SegDesc { // what one lane knows about a segment (registers only)

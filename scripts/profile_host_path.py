@@ -39,7 +39,25 @@ def main():
         print(f"agg  host path: {len(part)} segments: {dt*1e3:.3f} ms/batch, {len(part)/dt/1e6:.1f} Msegments/s")
     values = np.concatenate([datagen.sine_series(s, n)[1] for s in range(4)]); tss = np.tile(ts, 4)
     o = np.concatenate([offs[:-1] + s * n for s in range(4)] + [[4 * n]]).astype(np.uint64)
-    ctx.compress_chunks(tss, values, o, eb)
-    t0 = time.perf_counter(); got = ctx.compress_chunks(tss, values, o, eb); dt = time.perf_counter() - t0
-    print(f"fit  host path: {4*n} points in {len(o)-1} chunks: {dt*1e3:.1f} ms, {4*n/dt/1e6:.0f} Mpoints/s, {len(got)} segments")
+    one_ts, one_values = datagen.sine_series(9, 1_000_000)
+    lossless = mdb.error_bound("lossless")
+    for mode, label in (("1", "one lane per chunk"), (None, "split mode (auto)")):
+        if mode is None:
+            os.environ.pop("MDB_FIT_PIECE_POINTS", None)
+        else:
+            os.environ["MDB_FIT_PIECE_POINTS"] = mode
+        ctx.compress_chunks(tss, values, o, eb)
+        ctx.profile_enable(True); ctx.profile_reset()
+        t0 = time.perf_counter(); got = ctx.compress_chunks(tss, values, o, eb); dt = time.perf_counter() - t0
+        kernels = {k: round(v[1], 2) for k, v in ctx.profile().items() if v[1] >= 0.05}
+        ctx.profile_enable(False)
+        print(f"fit  host path, {label}: {4*n} points in {len(o)-1} chunks: {dt*1e3:.1f} ms, "
+              f"{4*n/dt/1e6:.0f} Mpoints/s, {len(got)} segments; kernels ms {kernels}")
+        for bound, name in ((eb, "rel 1 %"), (lossless, "lossless")):
+            ctx.try_compress_univariate_time_series(one_ts, one_values, bound)
+            t0 = time.perf_counter()
+            got = ctx.try_compress_univariate_time_series(one_ts, one_values, bound)
+            dt = time.perf_counter() - t0
+            print(f"fit  one series x 1M points in ONE call ({name}), {label}: {dt*1e3:.1f} ms, {len(got)} segments")
+
 main()

@@ -16,6 +16,18 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "1", "64", "1000"],
+                ids=["split-auto", "lane-per-chunk", "pieces-of-64", "pieces-of-1000"])
+def fit_mode(request, monkeypatch):
+    """Every fit test runs with the library choosing between one lane per chunk and split mode
+    (speculative pieces + chain walk, mdb_fit.hip), with split mode off, and with it forced."""
+    if request.param == "auto":
+        monkeypatch.delenv("MDB_FIT_PIECE_POINTS", raising=False)
+    else:
+        monkeypatch.setenv("MDB_FIT_PIECE_POINTS", request.param)
+    return request.param
+
+
 def assert_same_segments(got, expected):
     assert len(got) == len(expected)
     assert np.array_equal(got.model_type_id, expected.model_type_id)
@@ -170,3 +182,37 @@ def test_fit_pmc_chosen_while_swing_ran_far_ahead(hip):
     # the scenario really occurs: some PMC-Mean segment is followed by a model starting before
     # the point where Swing would have failed
     assert (expected.model_type_id == 0).any()
+
+
+def test_fit_split_mode_on_chains_that_converge_late_or_never(hip):
+    # Split mode relies on greedy chains from different start points meeting. Worst cases: one model
+    # spans the whole chunk (no piece ever meets another before the end), every point is rejected
+    # (every point is on every chain), and long models with a noisy stretch in the middle.
+    rng = np.random.default_rng(77)
+    n = 40_000
+    timestamps = np.arange(n, dtype=np.int64) * 1000 + 1_000_000
+    noisy = rng.normal(0.0, 1000.0, n).astype(np.float32)
+    ramp = (np.arange(n, dtype=np.float64) * 0.25 + 10.0).astype(np.float32)
+    mixed = np.full(n, 42.0, dtype=np.float32)
+    mixed[15_000:15_700] = noisy[:700]
+    mixed[30_000:] = ramp[30_000:]
+    for name, values in (("constant", np.full(n, 42.0, dtype=np.float32)), ("ramp", ramp), ("noise", noisy),
+                         ("mixed", mixed)):
+        for eb_name in ("lossless", "rel1"):
+            eb = cases.error_bounds()[eb_name]
+            expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
+            got = hip.try_compress_univariate_time_series(timestamps, values, eb)
+            assert_same_segments(got, expected)
+
+
+def test_fit_one_long_series_in_one_call(hip, fit_mode):
+    # The embedded API compresses a whole series in one call (data_folder.rs:214): BASELINE config 1
+    # is 1 series x 1 M points, lossless; here also with the benchmark's 1 % bound.
+    if fit_mode == "64":
+        pytest.skip("16 384 pieces of 64 points add nothing over the other modes here")
+    timestamps, values = datagen.sine_series(3, 1_000_000)
+    for eb_name in ("rel1", "lossless"):
+        eb = cases.error_bounds()[eb_name]
+        expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
+        got = hip.try_compress_univariate_time_series(timestamps, values, eb)
+        assert_same_segments(got, expected)
