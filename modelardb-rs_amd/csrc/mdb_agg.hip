@@ -306,10 +306,32 @@ __device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, 
         if (type == MDB_PMC_MEAN_ID) {
             acc.sum += (double)d.value * (double)n;
         } else {
-            // Sum of the line over n equally spaced points (f64 closed form of the f32 values).
-            double fa = d.slope * (double)ta + d.intercept;
-            double fb = d.slope * (double)tb + d.intercept;
-            acc.sum += (fa + fb) / 2.0 * (double)n;
+            // Sum of the line over n equally spaced points: the f64 closed form of the f32 values
+            // grid() would produce - unless it could miss their sum by more than a tenth of the
+            // 0.001 % the reference allows (integration_test.rs:1155-1171). That happens when
+            // slope * t + intercept cancels almost completely (epoch timestamps, a model that lasts
+            // microseconds, values near zero): every reconstructed point then carries rounding noise
+            // of ulp(slope * t), which averages out over the points but not over the two end points
+            // the closed form uses. The bound below is the worst case of that noise plus the f32
+            // rounding of the points; beyond it the points are summed one by one, which is exactly
+            // what the reference's plan (GridExec + filter + SUM) computes.
+            const double fa = d.slope * (double)ta + d.intercept;
+            const double fb = d.slope * (double)tb + d.intercept;
+            const double closed = (fa + fb) / 2.0 * (double)n;
+            const double magnitude = fmax(fabs(fa), fabs(fb));
+            const double cancelled = fmax(fmax(fabs(d.slope * (double)ta), fabs(d.slope * (double)tb)),
+                                          fabs(d.intercept));
+            const double worst = (double)n * (6.0e-8 * magnitude + 7.0e-46 + 2.3e-16 * cancelled);
+            if (worst <= 1.0e-6 * fabs(closed)) {
+                acc.sum += closed;
+            } else {
+                double pointwise = 0.0;
+                for (uint32_t k = a; k <= b; k++) {
+                    const int64_t t = d.start + (int64_t)((uint64_t)k * (uint64_t)d.delta);
+                    pointwise += (double)model_value_at(d, type, t);
+                }
+                acc.sum += pointwise;
+            }
         }
     }
     float seed = d.value;
