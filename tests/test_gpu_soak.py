@@ -141,3 +141,77 @@ def test_cases_that_once_failed(hip):
     # closed-form range SUM used two noisy end points and missed grid+filter+SUM by 0.09 %.
     for index in (506,):
         run_case(hip, index)
+
+
+# ---- the host operators under random batching ------------------------------------------------------------
+
+HOST_CASES = int(os.environ.get("MDB_SOAK_HOST_CASES", "24"))
+
+
+def run_host_case(hip, index):
+    import pyarrow as pa
+    from modelardb_rs_amd import host
+    rng = np.random.default_rng([0x484F5354, index])
+    n_fields = int(rng.choice([1, 1, 2, 3]))
+    n = int(rng.choice([50, 3000, 30_000]) * rng.uniform(0.5, 1.0)) + 1
+    timestamps = random_timestamps(rng, n)
+    eb = random_error_bound(rng)
+    tag = str(rng.choice(["a", "turbine-0123456789-long-tag-value"]))
+    fields = [ora.try_compress_univariate_time_series(timestamps, random_values(rng, n), eb)
+              for _ in range(n_fields)]
+    batch_size = int(rng.choice([1, 7, 100, 4096, 8192]))
+    predicate = (None, None)
+    if rng.random() < 0.5:
+        a, b = sorted(int(x) for x in rng.integers(0, n, 2))
+        predicate = (int(timestamps[a]) if rng.random() < 0.8 else None,
+                     int(timestamps[b]) if rng.random() < 0.8 else None)
+    keep = np.ones(n, dtype=bool)
+    if predicate[0] is not None:
+        keep &= timestamps >= predicate[0]
+    if predicate[1] is not None:
+        keep &= timestamps <= predicate[1]
+    expected = [ora.grid_batch(f) for f in fields]
+    where = f"host soak case {index}"
+
+    def pushes(batch):
+        arrow = host.segments_with_tags(batch.to_arrow(), {"tag": tag})
+        at = 0
+        while at < arrow.num_rows:
+            rows = int(rng.choice([1, 3, 50, 8192]))
+            yield arrow.slice(at, rows)
+            at += rows
+
+    if n_fields == 1:
+        stream = host.GridStream(hip, tag_names=("tag",), predicate=predicate, batch_size=batch_size)
+        for part in pushes(fields[0]):
+            stream.push(part)
+        stream.finish_input()
+        batches, state = stream.collect()
+        assert state == host.GridStream.READY_NONE, where
+        assert all(b.num_rows <= batch_size for b in batches), where
+        value_columns = ["value"]
+    else:
+        order = ["timestamp"] + ["field"] * n_fields + [("tag", "tag")]
+        stream = host.SortedJoinStream(hip, n_fields, order, tag_names=("tag",), predicate=predicate,
+                                       batch_size=batch_size)
+        for f, batch in enumerate(fields):
+            for part in pushes(batch):
+                stream.push(f, part)
+        stream.finish_input()
+        batches, state = stream.collect()
+        assert state == host.SortedJoinStream.READY_NONE, where
+        value_columns = [f"field_{f}" for f in range(n_fields)]
+    if not batches:
+        assert int(keep.sum()) == 0, where
+        return
+    table = pa.Table.from_batches(batches)
+    assert np.array_equal(table.column("timestamp").cast(pa.int64()).to_numpy(), expected[0][0][keep]), where
+    for column, (_, values, _, _) in zip(value_columns, expected):
+        assert np.array_equal(table.column(column).to_numpy().view(np.uint32), values[keep].view(np.uint32)), where
+    assert set(table.column("tag").to_pylist()) <= {tag}, where
+
+
+@pytest.mark.parametrize("block", range((HOST_CASES + 7) // 8))
+def test_random_batching_through_the_host_operators(hip, block):
+    for index in range(block * 8, min(HOST_CASES, (block + 1) * 8)):
+        run_host_case(hip, index)
