@@ -20,6 +20,8 @@
 //                    timestamps overwrite the placeholders.
 // Algorithmic bytes: 73 B/segment read + 12 B/point written (8 B timestamp + 4 B value).
 #include "mdb_segment_dev.hpp"
+#include "mdb_scan.hpp"
+#include "mdb_macaque_parallel.hpp"
 
 namespace mdb {
 
@@ -37,13 +39,14 @@ struct GridHeader {
     unsigned long long n_serial;
     unsigned int error;
     unsigned int pad;
-    unsigned long long metrics[10]; // mdb_grid_metrics minus rows_created (= total_points)
+    unsigned long long metrics[10]; // [0..8] mdb_grid_metrics minus rows_created (= total_points);
+                                    // [9] bytes of the MacaqueV streams the parallel decoder takes
 };
 
 __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
-    DevSegments s, TimeRange range, TileDesc *__restrict__ desc, uint32_t *__restrict__ counts,
-    unsigned long long *__restrict__ block_points, unsigned long long *__restrict__ block_serial,
-    GridHeader *__restrict__ header) {
+    DevSegments s, TimeRange range, uint32_t mv_min_values, TileDesc *__restrict__ desc,
+    uint32_t *__restrict__ counts, unsigned long long *__restrict__ block_points,
+    unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header) {
     __shared__ unsigned long long lds_metrics[12];
     if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
     __syncthreads();
@@ -72,12 +75,17 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         m[3] += (d.flags & FLAG_HAS_RESIDUALS) ? 1 : 0;
         m[7] += (d.flags & FLAG_REGULAR) ? 1 : 0;
         m[8] += (d.flags & FLAG_REGULAR) ? 0 : 1;
+        // Bytes of the MacaqueV streams long enough for the parallel decoder (bounds its scratch).
+        if (type == MDB_MACAQUE_V_ID && mv_min_values != 0xffffffffu) {
+            const uint32_t bytes = s.values.views[i].x;
+            if (mv_qualifies(info, bytes, mv_min_values)) m[9] += bytes;
+        }
     }
     // Block totals through LDS atomics (few per thread, once per block).
     atomicAdd(&lds_metrics[10], points);
     atomicAdd(&lds_metrics[11], serial);
 #pragma unroll
-    for (int k = 0; k < 9; k++)
+    for (int k = 0; k < 10; k++)
         if (m[k]) atomicAdd(&lds_metrics[k], m[k]);
     if (error) atomicOr(&header->error, error);
     __syncthreads();
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         block_points[blockIdx.x] = lds_metrics[10];
         block_serial[blockIdx.x] = lds_metrics[11];
     }
-    if (threadIdx.x < 9 && lds_metrics[threadIdx.x])
+    if (threadIdx.x < 10 && lds_metrics[threadIdx.x])
         atomicAdd(&header->metrics[threadIdx.x], lds_metrics[threadIdx.x]);
 }
 
@@ -377,8 +385,8 @@ struct MacaqueStream {
 
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
-    const uint32_t *__restrict__ serial_ids, uint64_t n_serial, int64_t *__restrict__ out_ts,
-    float *__restrict__ out_val, GridHeader *__restrict__ header) {
+    const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
+    int64_t *__restrict__ out_ts, float *__restrict__ out_val, GridHeader *__restrict__ header) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -427,6 +435,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint32_t values_to_decode = residuals_wanted ? d.n_model : min(d.n_model, visible_end);
     bool values_pending = present && type == MDB_MACAQUE_V_ID && d.n_model > 0 && d.n_visible > 0 &&
                           (residuals_wanted || d.first < d.n_model);
+    // Long streams may already have been decoded by the parallel decoder (mdb_macaque_parallel.hpp).
+    if (values_pending && mv_segs != nullptr && mv_segs[slot].done) values_pending = false;
     bool residuals_pending = residuals_wanted;
     RingBitReader reader;
     reader.begin(nullptr, 0);
@@ -549,7 +559,19 @@ struct GridPlan {
     GridHeader *header;
     GridHeader host_header;
     uint32_t n_blocks;
+    uint32_t mv_min_values; // MacaqueV streams at least this long go to the parallel decoder
 };
+
+// MDB_GRID_MV_MIN_VALUES: "off" disables the parallel MacaqueV decoder, a number sets the stream
+// length from which it is used (tests force it down so that short streams exercise it).
+static uint32_t mv_min_values_setting() {
+    if (const char *text = std::getenv("MDB_GRID_MV_MIN_VALUES")) {
+        if (std::strcmp(text, "off") == 0) return 0xffffffffu;
+        const long long value = std::atoll(text);
+        if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
+    }
+    return 0xffffffffu; // off by default until it beats one lane per stream (MV_DEFAULT_MIN_VALUES)
+}
 
 // Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
 // capacity_tiles bounds the tile map: if the batch needs more the caller gets an error before any
@@ -579,13 +601,14 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
 
     MDB_HIP_CHECK(hipMemsetAsync(plan->header, 0, sizeof(GridHeader), ctx->stream));
     std::memset(&plan->host_header, 0, sizeof(GridHeader));
+    plan->mv_min_values = mv_min_values_setting();
     if (n == 0) return 0;
     DevSegments s = to_dev(in);
     {
         LaunchTimer timer(ctx, "k_grid_prepass");
         hipLaunchKernelGGL(k_grid_prepass, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s,
-                           range, plan->desc, plan->counts, plan->block_points, plan->block_serial,
-                           plan->header);
+                           range, plan->mv_min_values, plan->desc, plan->counts, plan->block_points,
+                           plan->block_serial, plan->header);
     }
     {
         LaunchTimer timer(ctx, "k_scan_blocks");
@@ -625,6 +648,79 @@ void fill_metrics(const GridHeader &h, mdb_grid_metrics *m) {
     m->segments_irregular = h.metrics[8];
 }
 
+// The long MacaqueV streams of the batch through the parallel decoder (mdb_macaque_parallel.hpp);
+// runs after k_grid_tiles and before k_grid_serial, which skips the streams marked done.
+int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, GridPlan &plan, float *out_val,
+                          MvSeg **segs_out) {
+    const uint64_t n_serial = plan.host_header.n_serial;
+    // Every qualifying stream has ceil(bits / MV_PIECE_BITS) pieces and is on the serial list.
+    const uint64_t max_pieces = plan.host_header.metrics[9] * 8 / MV_PIECE_BITS + n_serial + 1;
+    if (max_pieces > 0x7fffff00ull) return 0; // absurdly large: leave it to the sequential decoder
+    const uint64_t sums_bytes = scan_block_sums_bytes(n_serial);
+    const uint64_t segs_bytes = align_up(n_serial * sizeof(MvSeg), 256);
+    const uint64_t base_bytes = align_up((n_serial + 1) * 8, 256) + align_up(sums_bytes, 256);
+    const uint64_t heads_bytes = align_up(max_pieces * MV_CHAINS * MV_HEAD * sizeof(MvRec), 256);
+    const uint64_t chains_bytes = align_up(max_pieces * MV_CHAINS * sizeof(MvChain), 256);
+    const uint64_t links_bytes = align_up(max_pieces * MV_CHAINS * sizeof(MvLink), 256);
+    const uint64_t starts_bytes = align_up(max_pieces * sizeof(MvStart), 256);
+    const uint64_t guesses_bytes = 2 * align_up(max_pieces * 4, 256); // guesses + tried
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_MV, segs_bytes + base_bytes + heads_bytes + chains_bytes + links_bytes +
+                                            starts_bytes + guesses_bytes, &p))
+        return 1;
+    uint8_t *at = static_cast<uint8_t *>(p);
+    MvSeg *segs = reinterpret_cast<MvSeg *>(at);
+    at += segs_bytes;
+    unsigned long long *piece_base = reinterpret_cast<unsigned long long *>(at);
+    unsigned long long *block_sums = reinterpret_cast<unsigned long long *>(at + align_up((n_serial + 1) * 8, 256));
+    at += base_bytes;
+    MvRec *heads = reinterpret_cast<MvRec *>(at);
+    at += heads_bytes;
+    MvChain *chains = reinterpret_cast<MvChain *>(at);
+    at += chains_bytes;
+    MvLink *links = reinterpret_cast<MvLink *>(at);
+    at += links_bytes;
+    MvStart *starts = reinterpret_cast<MvStart *>(at);
+    at += starts_bytes;
+    uint32_t *guesses = reinterpret_cast<uint32_t *>(at);
+    uint32_t *tried = reinterpret_cast<uint32_t *>(at + align_up(max_pieces * 4, 256));
+    MDB_HIP_CHECK(hipMemsetAsync(starts, 0, starts_bytes, ctx->stream));
+    {
+        LaunchTimer timer(ctx, "k_mv_select");
+        hipLaunchKernelGGL(k_mv_select, dim3((uint32_t)((n_serial + 255) / 256)), dim3(256), 0, ctx->stream, s,
+                           range, plan.offsets, plan.serial_ids, n_serial, plan.mv_min_values, segs);
+    }
+    if (device_exclusive_scan(ctx, MvPieceCount{segs}, n_serial, piece_base, block_sums, "k_mv_scan")) return 1;
+    const uint32_t piece_blocks = (uint32_t)((max_pieces + MDB_WAVE - 1) / MDB_WAVE);
+    for (int round = 0; round <= MV_ROUNDS; round++) {
+        if (round > 0) {
+            LaunchTimer timer(ctx, "k_mv_guess");
+            hipLaunchKernelGGL(k_mv_guess, dim3((uint32_t)n_serial), dim3(MDB_WAVE), 0, ctx->stream, segs,
+                               piece_base, chains, guesses);
+        }
+        LaunchTimer timer(ctx, "k_mv_chains");
+        hipLaunchKernelGGL(k_mv_chains, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
+                           n_serial, round, guesses, tried, heads, chains);
+    }
+    {
+        LaunchTimer timer(ctx, "k_mv_links");
+        hipLaunchKernelGGL(k_mv_links, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
+                           n_serial, heads, chains, links);
+    }
+    {
+        LaunchTimer timer(ctx, "k_mv_walk");
+        hipLaunchKernelGGL(k_mv_walk, dim3((uint32_t)n_serial), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
+                           chains, links, starts);
+    }
+    {
+        LaunchTimer timer(ctx, "k_mv_decode");
+        hipLaunchKernelGGL(k_mv_decode, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
+                           n_serial, starts, out_val, &plan.header->error);
+    }
+    *segs_out = segs;
+    return 0;
+}
+
 // Launch the reconstruction of a planned batch into device buffers (enqueue + final error check).
 int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan &plan, int64_t *out_ts,
                 float *out_val, uint32_t *out_rows) {
@@ -644,12 +740,18 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
                            out_val);
     }
     const uint64_t n_serial = plan.host_header.n_serial;
+    const MvSeg *mv_segs = nullptr;
+    if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
+        MvSeg *segs = nullptr;
+        if (grid_parallel_macaque(ctx, s, range, plan, out_val, &segs)) return 1;
+        mv_segs = segs;
+    }
     if (n_serial > 0) {
         LaunchTimer timer(ctx, "k_grid_serial");
         hipLaunchKernelGGL(k_grid_serial,
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
-                           plan.serial_ids, n_serial, out_ts, out_val, plan.header);
+                           plan.serial_ids, n_serial, mv_segs, out_ts, out_val, plan.header);
     }
     return 0;
 }

@@ -1,0 +1,642 @@
+// mdb_macaque_parallel.hpp - decoding ONE long MacaqueV value stream with many lanes.
+//
+// macaque_v::grid (crates/modelardb_compression/src/models/macaque_v.rs:272-323) is sequential by
+// construction: value i's position in the bit stream depends on every earlier code, and its bits
+// are XORed onto value i-1. One lane per stream (k_grid_serial) therefore runs at the latency of a
+// single wave, and lossless data (BASELINE config 1: every chunk becomes one 65 536-value MacaqueV
+// segment) leaves most of the GPU idle. This file cuts a stream into pieces of MV_PIECE_BITS bits and
+// decodes the pieces in parallel, still bit for bit the same values.
+//
+// What a parse needs from the past is small. Codes are `10` (repeat), `0` + n bits (n = "meaningful
+// bits" of the current window) and `11` + 5 bits leading zeros + 6 bits n + n bits (a new window).
+// WHERE the codes are therefore depends on (bit position, n) only; the leading zeros of the window
+// matter for the values (how far the n bits are shifted), not for the positions, and a `11` code
+// sets both from the stream itself.
+//
+//  * k_mv_chains: one lane per piece looks for places in its piece from which the stream parses
+//    cleanly to the end of the piece: speculative "chains". Candidates are `11` patterns near the
+//    start of the piece (they need nothing from the past) and, since real streams settle on one
+//    window and then consist of `0` and `10` codes only, the first 45 bits of the piece (the longest
+//    code) combined with a guess for n: the n at the end of the nearest earlier piece that has
+//    chains (k_mv_guess), refined over MV_ROUNDS rounds. Wrong candidates die within a few codes,
+//    with one exception: a parse that is a few bits late keeps reading the (almost always zero) top
+//    bits of the window as control bits; such late copies are recognised by their distance to a
+//    kept chain on the grid of code boundaries. Per chain a few boundaries are recorded with what
+//    the chain has accumulated there: values, `11` codes, XOR of the unshifted bits of its `0` codes
+//    before its first `11` (their shift is not known to the chain) and XOR of the shifted bits after.
+//  * k_mv_links: every chain is parsed on from the end of its piece until it stands on a boundary
+//    that a chain of a later piece recorded with the same n: from there on the two parses visit
+//    the same positions. The link notes that target and both chains' accumulators at the boundary.
+//  * k_mv_walk: one wave per stream follows the links from piece 0, whose chain starts at the real
+//    beginning. Every chain it visits is thereby proven to be on the real parse from the linked
+//    boundary on. Along the way it carries the real window (from the last real `11` code) and turns
+//    the accumulators into the index and the predecessor value each confirmed chain starts with.
+//    Chains it never visits are ignored. A broken link (no partner within MV_MAX_TAIL_BITS, a
+//    malformed stream) hands the whole stream back to k_grid_serial.
+//  * k_mv_decode: one lane per confirmed piece decodes its values from its confirmed start (position,
+//    real window, index, predecessor value) straight to their final positions.
+// Nothing is assumed about the data: a speculative chain is only ever used from a boundary the real
+// parse has been shown to pass with the same n, and every other situation falls back to the
+// sequential decoder. Included by mdb_grid.hip only.
+#pragma once
+
+#include "mdb_segment_dev.hpp"
+
+namespace mdb {
+
+#ifndef MDB_MV_PIECE_BITS
+#define MDB_MV_PIECE_BITS 4096
+#endif
+constexpr uint32_t MV_PIECE_BITS = MDB_MV_PIECE_BITS;
+constexpr int MV_CHAINS = 4; // speculative chains kept per piece
+constexpr int MV_HEAD = 4;   // boundaries recorded per chain
+constexpr uint32_t MV_SCAN_BITS = 256;    // `11` patterns are looked for this far into a piece
+constexpr uint32_t MV_MAX_CODE_BITS = 45; // 2 + 5 + 6 + 32
+constexpr int MV_ROUNDS = 3;              // rounds of guessed windows
+constexpr uint32_t MV_SHIFT_BITS = 8;     // how late a parse can be and still live on zero top bits
+constexpr uint32_t MV_SETTLE_CODES = 8;   // codes after which a guessed chain is recorded and compared
+constexpr uint32_t MV_NO_WINDOW = 0xffffu;
+constexpr uint32_t MV_NO_LENGTH = 0xffu;
+constexpr uint32_t MV_MAX_TAIL_BITS = 32 * MV_PIECE_BITS;
+constexpr uint32_t MV_MAX_STREAM_BYTES = 1u << 27; // bit positions stay below 2^30
+constexpr uint32_t MV_NONE = 0xffffffffu; // link: no partner found
+constexpr uint32_t MV_END = 0xfffffffeu;  // link: parsed to the end of the stream
+constexpr uint32_t MV_DEFAULT_MIN_VALUES = 1024;
+
+// One stream that qualifies (indexed like serial_ids).
+struct MvSeg {
+    const uint32_t *words;         // aligned base of the payload
+    unsigned long long out_offset; // of the segment's first visible point in out_val
+    uint32_t bias_bits;            // slack bits in front of the payload in words[0]
+    uint32_t total_bits;
+    uint32_t n_words;
+    uint32_t n_model;     // values in the stream
+    uint32_t first;       // first wanted value index
+    uint32_t visible_end; // one past the last wanted value index
+    uint32_t n_pieces;    // 0: the stream does not qualify
+    uint32_t done;        // set by k_mv_walk: k_mv_decode handles it, k_grid_serial skips it
+};
+
+// What a chain has accumulated at one of its code boundaries.
+struct MvRec {
+    uint32_t pos;    // bit position of the next code
+    uint32_t state;  // window: leading | meaningful << 8 (leading only valid once n11 > 0), or MV_NO_WINDOW
+    uint32_t count;  // values decoded since the chain's start
+    uint32_t n11;    // `11` codes since the chain's start
+    uint32_t raw_x;  // XOR of the unshifted bits of the `0` codes before the first `11`
+    uint32_t x;      // XOR of the (shifted) deltas from the first `11` on
+};
+
+struct MvChain { // chains[piece * MV_CHAINS + c], used ones first
+    uint32_t n_head; // recorded boundaries, 0: unused
+    MvRec end;       // the chain's first boundary at or beyond the end of its piece
+};
+
+struct MvLink { // links[piece * MV_CHAINS + c]
+    uint32_t target; // id (piece * MV_CHAINS + c) of the chain this parse joins, MV_END or MV_NONE
+    MvRec from;      // this parse at the shared boundary
+    MvRec into;      // the target chain at the shared boundary
+};
+
+struct MvStart {
+    uint32_t valid;
+    uint32_t pos, state;  // real window
+    uint32_t first_index; // index of the first value this piece decodes
+    uint32_t value_bits;  // the value before it
+    uint32_t n_values;
+};
+
+struct MvPieceCount {
+    const MvSeg *segs;
+    __device__ uint64_t operator()(uint64_t slot) const { return segs[slot].n_pieces; }
+};
+
+// Should this segment's values go through the parallel decoder? Evaluated identically by the
+// prepass (to bound the scratch memory) and by k_mv_select.
+__device__ __forceinline__ bool mv_qualifies(const SegInfo &info, uint32_t values_bytes, uint32_t min_values) {
+    const SegDesc &d = info.desc;
+    return min_values != 0xffffffffu && !info.error && (d.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID &&
+           !(d.flags & FLAG_HAS_RESIDUALS) && d.n_model >= min_values && d.n_visible > 0 &&
+           values_bytes > 12 && values_bytes < MV_MAX_STREAM_BYTES;
+}
+
+// Random-access reader: bits [pos, pos + count) of the stream, MSB first, zeros past the end.
+struct MvReader {
+    const uint32_t *words;
+    uint32_t n_words;
+    uint32_t bias_bits;
+    uint32_t total_bits;
+    uint32_t cached_word;
+    uint64_t cache;
+    __device__ __forceinline__ void open(const MvSeg &seg) {
+        words = seg.words;
+        n_words = seg.n_words;
+        bias_bits = seg.bias_bits;
+        total_bits = seg.total_bits;
+        cached_word = 0xfffffffeu; // never index - 1 of a real word
+        cache = 0;
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t index) const {
+        return index < n_words ? __builtin_bswap32(words[index]) : 0u;
+    }
+    // count in [0, 32]
+    __device__ __forceinline__ uint32_t peek(uint32_t pos, uint32_t count) {
+        if (count == 0) return 0;
+        const uint32_t at = bias_bits + pos;
+        const uint32_t index = at >> 5;
+        if (index != cached_word) {
+            // Moving one word forward is the common case: reuse the low half.
+            const uint32_t high = index == cached_word + 1 ? (uint32_t)cache : word(index);
+            cache = ((uint64_t)high << 32) | word(index + 1);
+            cached_word = index;
+        }
+        return (uint32_t)((cache << (at & 31u)) >> (64u - count));
+    }
+};
+
+enum : int { MV_OK = 0, MV_MALFORMED = 1, MV_OVERRUN = 2 };
+enum : uint32_t { MV_CODE_BITS = 0, MV_CODE_REPEAT = 1, MV_CODE_WINDOW = 2 };
+
+__device__ __forceinline__ bool mv_valid_window(uint32_t leading, uint32_t meaningful) {
+    // macaque_v.rs:305-313 as decode_macaque_v checks it: meaningful <= 32 and trailing <= 31.
+    return meaningful <= 32u && leading + meaningful <= 32u && leading + meaningful >= 1u;
+}
+
+__device__ __forceinline__ uint32_t mv_length(uint32_t state) { return state >> 8; }
+
+__device__ __forceinline__ uint32_t mv_shifted(uint32_t bits, uint32_t state) {
+    const uint32_t trailing = 32u - (state >> 8) - (state & 0xffu);
+    return bits << (trailing & 31u);
+}
+
+// Decodes the code at `pos` under window `state`; on MV_OK pos / state are advanced, `kind` says
+// which code it was and `bits` holds its unshifted payload. Nothing is changed otherwise.
+__device__ __forceinline__ int mv_step(MvReader &r, uint32_t &pos, uint32_t &state, uint32_t &kind,
+                                       uint32_t &bits) {
+    const uint32_t top = r.peek(pos, 13); // c0 c1 leading[5] meaningful[6]
+    uint32_t header, meaningful, next_state = state;
+    if ((top >> 12) == 0) { // `0`: the previous window again
+        if (state == MV_NO_WINDOW) return MV_MALFORMED;
+        header = 1;
+        meaningful = state >> 8;
+        kind = MV_CODE_BITS;
+    } else if ((top >> 11) == 2) { // `10`: the value repeats
+        if (pos + 2 > r.total_bits) return MV_OVERRUN;
+        pos += 2;
+        kind = MV_CODE_REPEAT;
+        bits = 0;
+        return MV_OK;
+    } else { // `11` + window
+        const uint32_t leading = (top >> 6) & 31u;
+        meaningful = top & 63u;
+        if (!mv_valid_window(leading, meaningful)) return MV_MALFORMED;
+        header = 13;
+        next_state = leading | (meaningful << 8);
+        kind = MV_CODE_WINDOW;
+    }
+    if (pos + header + meaningful > r.total_bits) return MV_OVERRUN;
+    bits = r.peek(pos + header, meaningful);
+    pos += header + meaningful;
+    state = next_state;
+    return MV_OK;
+}
+
+// One code of a speculative chain: like mv_step, plus the chain's accumulators.
+__device__ __forceinline__ int mv_chain_step(MvReader &r, MvRec &at) {
+    uint32_t kind = 0, bits = 0;
+    const int rc = mv_step(r, at.pos, at.state, kind, bits);
+    if (rc != MV_OK) return rc;
+    at.count += 1;
+    if (kind == MV_CODE_WINDOW) at.n11 += 1;
+    if (kind != MV_CODE_REPEAT) {
+        if (at.n11 > 0) at.x ^= mv_shifted(bits, at.state);
+        else at.raw_x ^= bits; // the chain does not know the leading zeros of a window it inherited
+    }
+    return MV_OK;
+}
+
+// Last slot whose first piece is <= piece (slots without pieces share the base of the next one).
+__device__ __forceinline__ uint32_t mv_slot_of(const unsigned long long *piece_base, uint64_t n_slots,
+                                               uint64_t piece) {
+    uint64_t lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (piece_base[mid] <= piece) lo = mid;
+        else hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
+// ---- k_mv_select: one lane per entry of the serial list -----------------------------------------------
+
+__global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange range,
+                                                   const unsigned long long *__restrict__ offsets,
+                                                   const uint32_t *__restrict__ serial_ids, uint64_t n_serial,
+                                                   uint32_t min_values, MvSeg *__restrict__ segs) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_serial) return;
+    const uint32_t i = serial_ids[slot];
+    SegInfo info = analyse_segment(s, i);
+    if (range.enabled) apply_time_range(s, i, info, range);
+    const uint4 view = s.values.views[i];
+    MvSeg seg;
+    seg.words = nullptr;
+    seg.out_offset = 0;
+    seg.bias_bits = seg.total_bits = seg.n_words = seg.n_model = seg.first = seg.visible_end = 0;
+    seg.n_pieces = 0;
+    seg.done = 0;
+    if (mv_qualifies(info, view.x, min_values)) {
+        const uint8_t *bytes = view_data(s.values, i, view);
+        const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        const uint32_t misalign = (uint32_t)(address & 3u);
+        seg.words = reinterpret_cast<const uint32_t *>(address - misalign);
+        seg.bias_bits = 8u * misalign;
+        seg.total_bits = 8u * view.x;
+        seg.n_words = (view.x + misalign + 3u) >> 2;
+        seg.n_model = info.desc.n_model;
+        seg.first = info.desc.first;
+        seg.visible_end = info.desc.first + info.desc.n_visible;
+        seg.out_offset = offsets[i];
+        seg.n_pieces = (seg.total_bits + MV_PIECE_BITS - 1) / MV_PIECE_BITS;
+    }
+    segs[slot] = seg;
+}
+
+// ---- k_mv_chains: one lane per piece ---------------------------------------------------------------------
+//
+// guesses[piece]: up to two candidate n (one per byte, MV_NO_LENGTH = none); tried[piece]: the n this
+// piece has already been searched with (one per byte).
+
+__device__ __forceinline__ bool mv_byte_listed(uint32_t list, uint32_t value) {
+    for (int k = 0; k < 4; k++)
+        if (((list >> (8 * k)) & 0xffu) == value) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict__ segs,
+                                                        const unsigned long long *__restrict__ piece_base,
+                                                        uint64_t n_slots, int round,
+                                                        const uint32_t *__restrict__ guesses,
+                                                        uint32_t *__restrict__ tried, MvRec *__restrict__ heads,
+                                                        MvChain *__restrict__ chains) {
+    const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (piece >= piece_base[n_slots]) return;
+    MvChain *__restrict__ mine = chains + piece * MV_CHAINS;
+    const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
+    const MvSeg seg = segs[slot];
+    const uint32_t p = (uint32_t)(piece - piece_base[slot]);
+    MvReader reader;
+    reader.open(seg);
+    const uint32_t piece_begin = p * MV_PIECE_BITS;
+    const uint32_t piece_end = min(piece_begin + MV_PIECE_BITS, seg.total_bits);
+    uint32_t n_chains = 0;
+    if (round > 0)
+        while (n_chains < MV_CHAINS && mine[n_chains].n_head > 0) n_chains++;
+
+    // Follows the stream from `at` to the first boundary at or beyond the end of the piece and keeps
+    // the chain unless it is malformed - or, for a guessed n, turns out to run on the grid of a
+    // kept chain or 1..MV_SHIFT_BITS bits behind it: while n stays the same, boundaries are a whole
+    // number of `0` codes apart (give or take `10` codes), so a chain on the same grid IS that
+    // chain from here on, and one slightly behind is a late copy living on the zero top bits of
+    // the window. A guessed chain may only fall in step with the real parse after a few codes, so
+    // its boundaries are recorded once it has settled.
+    auto follow = [&](MvRec at, uint32_t guessed_length) -> bool {
+        MvRec *__restrict__ head = heads + (piece * MV_CHAINS + n_chains) * MV_HEAD;
+        const bool guessed = guessed_length != MV_NO_LENGTH;
+        const uint32_t record_from = guessed ? MV_SETTLE_CODES : 0u;
+        uint32_t n_head = 0, steps = 0;
+        if (!guessed && at.state == MV_NO_WINDOW && at.pos == 32u) head[n_head++] = at; // the real start
+        while (at.pos < piece_end) {
+            const int rc = mv_chain_step(reader, at);
+            if (rc == MV_MALFORMED) return false;
+            if (rc == MV_OVERRUN) break; // only padding is left: the chain reaches the end
+            steps += 1;
+            if (steps >= record_from && n_head < MV_HEAD) head[n_head++] = at;
+            if (guessed && steps == MV_SETTLE_CODES && mv_length(at.state) == guessed_length) {
+                const uint32_t code_bits = 1u + guessed_length;
+                for (uint32_t c = 0; c < n_chains; c++) {
+                    if (mv_length(mine[c].end.state) != guessed_length) continue;
+                    const uint32_t lag = (at.pos + code_bits * 256u - mine[c].end.pos) % code_bits;
+                    if (lag <= MV_SHIFT_BITS) return false;
+                }
+            }
+        }
+        if (n_head == 0) return false;
+        mine[n_chains].n_head = n_head;
+        mine[n_chains].end = at;
+        n_chains += 1;
+        return true;
+    };
+
+    if (round == 0) {
+        tried[piece] = 0xffffffffu;
+        if (p == 0) {
+            // The real start: 32 raw bits of the first value, then codes, no window yet.
+            if (seg.total_bits >= 32) (void)follow({32u, MV_NO_WINDOW, 0u, 0u, 0u, 0u}, MV_NO_LENGTH);
+        } else {
+            const uint32_t scan_end = min(piece_begin + MV_SCAN_BITS, piece_end);
+            for (uint32_t o = piece_begin; o < scan_end && o + 13 <= seg.total_bits && n_chains < MV_CHAINS - 1; o++) {
+                const uint32_t top = reader.peek(o, 13);
+                if ((top >> 11) != 3u || !mv_valid_window((top >> 6) & 31u, top & 63u)) continue;
+                (void)follow({o, MV_NO_WINDOW, 0u, 0u, 0u, 0u}, MV_NO_LENGTH);
+            }
+        }
+    } else if (p > 0) {
+        uint32_t tried_here = tried[piece];
+        for (int g = 0; g < 2; g++) {
+            const uint32_t length = (guesses[piece] >> (8 * g)) & 0xffu;
+            if (length == MV_NO_LENGTH || length > 32u || mv_byte_listed(tried_here, length)) continue;
+            tried_here = (tried_here << 8) | length;
+            // Entry points a little before the piece are tried too, so that the real chain is usually
+            // met before its late copies. The leading zeros of the guessed window are unknown (and
+            // not needed: see MvRec::raw_x).
+            const uint32_t state = length << 8;
+            const uint32_t try_begin = piece_begin >= 32 + MV_SHIFT_BITS ? piece_begin - MV_SHIFT_BITS : piece_begin;
+            const uint32_t try_end = min(piece_begin + MV_MAX_CODE_BITS, piece_end);
+            const uint32_t first_new = n_chains;
+            for (uint32_t o = try_begin; o < try_end && n_chains < MV_CHAINS; o++)
+                (void)follow({o, state, 0u, 0u, 0u, 0u}, length);
+            // A chain that was found first can itself be the late copy of one found after it.
+            const uint32_t code_bits = 1u + length;
+            uint32_t kept = first_new;
+            for (uint32_t c = first_new; c < n_chains; c++) {
+                bool late_copy = false;
+                for (uint32_t b = 0; b < n_chains && !late_copy; b++) {
+                    if (b == c || mv_length(mine[b].end.state) != length || mv_length(mine[c].end.state) != length)
+                        continue;
+                    const uint32_t lag = (mine[c].end.pos + code_bits * 256u - mine[b].end.pos) % code_bits;
+                    late_copy = lag >= 1 && lag <= MV_SHIFT_BITS;
+                }
+                if (late_copy) continue;
+                if (kept != c) {
+                    for (uint32_t h = 0; h < mine[c].n_head; h++)
+                        heads[(piece * MV_CHAINS + kept) * MV_HEAD + h] = heads[(piece * MV_CHAINS + c) * MV_HEAD + h];
+                    mine[kept] = mine[c];
+                }
+                kept += 1;
+            }
+            n_chains = kept;
+        }
+        tried[piece] = tried_here;
+    }
+    for (uint32_t c = n_chains; c < MV_CHAINS; c++) mine[c].n_head = 0;
+}
+
+// ---- k_mv_guess: one wave per entry of the serial list ----------------------------------------------------
+//
+// guesses[piece] = the n at the end of the chains of the nearest earlier piece of the stream that
+// has chains (its first two chains, if they differ).
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_guess(const MvSeg *__restrict__ segs,
+                                                       const unsigned long long *__restrict__ piece_base,
+                                                       const MvChain *__restrict__ chains,
+                                                       uint32_t *__restrict__ guesses) {
+    const uint64_t slot = blockIdx.x;
+    const uint32_t n_pieces = segs[slot].n_pieces;
+    if (n_pieces == 0) return;
+    const int lane = threadIdx.x;
+    const uint64_t first_piece = piece_base[slot];
+    uint32_t carry = MV_NONE; // uniform: the answer of the last piece with chains in earlier groups of 64
+    for (uint32_t base = 0; base < n_pieces; base += MDB_WAVE) {
+        const uint32_t q = base + lane;
+        uint32_t seen = MV_NONE;
+        if (q < n_pieces) {
+            const MvChain *__restrict__ theirs = chains + (first_piece + q) * MV_CHAINS;
+            if (theirs[0].n_head > 0) {
+                const uint32_t a = mv_length(theirs[0].end.state) & 0xffu;
+                uint32_t b = MV_NO_LENGTH;
+                for (int c = 1; c < MV_CHAINS && b == MV_NO_LENGTH; c++)
+                    if (theirs[c].n_head > 0 && (mv_length(theirs[c].end.state) & 0xffu) != a)
+                        b = mv_length(theirs[c].end.state) & 0xffu;
+                seen = 0xffff0000u | (b << 8) | a;
+            }
+        }
+        // Inclusive "last one seen at or before this lane".
+        uint32_t inclusive = seen;
+#pragma unroll
+        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+            const uint32_t up = __shfl_up(inclusive, delta, MDB_WAVE);
+            if (lane >= delta && inclusive == MV_NONE) inclusive = up;
+        }
+        uint32_t before = __shfl_up(inclusive, 1, MDB_WAVE);
+        if (lane == 0 || before == MV_NONE) before = carry; // nothing earlier in this group of pieces
+        if (q < n_pieces) guesses[first_piece + q] = before;
+        const uint32_t last = __shfl(inclusive, MDB_WAVE - 1, MDB_WAVE);
+        if (last != MV_NONE) carry = last;
+    }
+}
+
+// ---- k_mv_links: one lane per piece -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_links(const MvSeg *__restrict__ segs,
+                                                       const unsigned long long *__restrict__ piece_base,
+                                                       uint64_t n_slots, const MvRec *__restrict__ heads,
+                                                       const MvChain *__restrict__ chains,
+                                                       MvLink *__restrict__ links) {
+    const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (piece >= piece_base[n_slots]) return;
+    const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
+    const MvSeg seg = segs[slot];
+    const uint64_t first_piece = piece_base[slot];
+    const uint32_t p = (uint32_t)(piece - first_piece);
+    MvReader reader;
+    reader.open(seg);
+    for (uint32_t c = 0; c < MV_CHAINS; c++) {
+        MvLink link;
+        link.target = MV_NONE;
+        link.from = {0, 0, 0, 0, 0, 0};
+        link.into = {0, 0, 0, 0, 0, 0};
+        const MvChain chain = chains[piece * MV_CHAINS + c];
+        if (chain.n_head > 0) {
+            MvRec at = chain.end;
+            const uint32_t tail_begin = at.pos;
+            uint32_t partner = 0xffffffffu, partner_last_pos = 0;
+            while (true) {
+                const uint32_t r = at.pos / MV_PIECE_BITS;
+                if (at.pos >= seg.total_bits || r >= seg.n_pieces) {
+                    link.target = MV_END;
+                    link.from = at;
+                    break;
+                }
+                if (r != partner) {
+                    // Only later pieces can be joined (a chain that ends in the padding of the last
+                    // piece still stands inside its own piece). Their recorded boundaries all lie near
+                    // the start of the piece: note where they end to stop looking early.
+                    partner = r;
+                    partner_last_pos = 0;
+                    if (r > p) {
+                        for (uint32_t k = 0; k < MV_CHAINS; k++) {
+                            const uint32_t n = chains[(first_piece + r) * MV_CHAINS + k].n_head;
+                            if (n == 0) break;
+                            const uint32_t last = heads[((first_piece + r) * MV_CHAINS + k) * MV_HEAD + n - 1].pos;
+                            partner_last_pos = max(partner_last_pos, last + 1);
+                        }
+                    }
+                }
+                bool joined = false;
+                if (at.pos < partner_last_pos) {
+                    for (uint32_t k = 0; k < MV_CHAINS && !joined; k++) {
+                        const uint64_t id = (first_piece + r) * MV_CHAINS + k;
+                        const uint32_t n = chains[id].n_head;
+                        if (n == 0) break;
+                        for (uint32_t h = 0; h < n; h++) {
+                            const MvRec rec = heads[id * MV_HEAD + h];
+                            if (rec.pos == at.pos && mv_length(rec.state) == mv_length(at.state)) {
+                                link.target = (uint32_t)id;
+                                link.from = at;
+                                link.into = rec;
+                                joined = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (joined) break;
+                if (at.pos - tail_begin > MV_MAX_TAIL_BITS) break; // MV_NONE: the sequential decoder takes over
+                const int rc = mv_chain_step(reader, at);
+                if (rc == MV_MALFORMED) break;
+                if (rc == MV_OVERRUN) {
+                    link.target = MV_END;
+                    link.from = at;
+                    break;
+                }
+            }
+        }
+        links[piece * MV_CHAINS + c] = link;
+    }
+}
+
+// ---- k_mv_walk: one wave per entry of the serial list -------------------------------------------------------
+
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_walk(MvSeg *__restrict__ segs,
+                                                      const unsigned long long *__restrict__ piece_base,
+                                                      const MvChain *__restrict__ chains,
+                                                      const MvLink *__restrict__ links,
+                                                      MvStart *__restrict__ starts) {
+    const uint64_t slot = blockIdx.x;
+    const MvSeg seg = segs[slot];
+    if (seg.n_pieces == 0) return;
+    const int lane = threadIdx.x;
+    const uint64_t first_piece = piece_base[slot];
+    const uint64_t first_chain = first_piece * MV_CHAINS;
+    const uint32_t n_ids = seg.n_pieces * MV_CHAINS;
+    MvReader reader;
+    reader.open(seg);
+    bool ok = seg.total_bits >= 32 && seg.n_model >= 1 && chains[first_chain].n_head > 0;
+    uint32_t q = 0;           // chain on the real parse, relative to first_chain (uniform)
+    uint32_t first_index = 1; // value 0 is the raw first value
+    uint32_t value_bits = reader.peek(0, 32);
+    // Where the real parse entered chain q, what that chain had accumulated there, the real window.
+    uint32_t pos = 32, state = MV_NO_WINDOW;
+    MvRec entered = {32u, MV_NO_WINDOW, 0u, 0u, 0u, 0u};
+    uint32_t window_first = 0;
+    bool window_valid = false;
+    MvLink window;
+    window.target = MV_NONE;
+    window.from = {0, 0, 0, 0, 0, 0};
+    window.into = {0, 0, 0, 0, 0, 0};
+    while (ok) {
+        if (!window_valid || q - window_first >= MDB_WAVE) {
+            window_first = q;
+            if (q + lane < n_ids) window = links[first_chain + q + lane];
+            window_valid = true;
+        }
+        const int source = (int)(q - window_first);
+        const uint32_t target = __shfl(window.target, source, MDB_WAVE);
+        MvRec from, into;
+        from.pos = __shfl(window.from.pos, source, MDB_WAVE);
+        from.state = __shfl(window.from.state, source, MDB_WAVE);
+        from.count = __shfl(window.from.count, source, MDB_WAVE);
+        from.n11 = __shfl(window.from.n11, source, MDB_WAVE);
+        from.raw_x = __shfl(window.from.raw_x, source, MDB_WAVE);
+        from.x = __shfl(window.from.x, source, MDB_WAVE);
+        into.pos = __shfl(window.into.pos, source, MDB_WAVE);
+        into.state = __shfl(window.into.state, source, MDB_WAVE);
+        into.count = __shfl(window.into.count, source, MDB_WAVE);
+        into.n11 = __shfl(window.into.n11, source, MDB_WAVE);
+        into.raw_x = __shfl(window.into.raw_x, source, MDB_WAVE);
+        into.x = __shfl(window.into.x, source, MDB_WAVE);
+        if (target == MV_NONE) {
+            ok = false;
+            break;
+        }
+        const uint32_t left = seg.n_model - first_index;
+        uint32_t n_values = target == MV_END ? left : from.count - entered.count;
+        const bool last = target == MV_END || n_values >= left;
+        if (n_values > left) n_values = left;
+        if (lane == 0) starts[first_piece + q / MV_CHAINS] = {1u, pos, state, first_index, value_bits, n_values};
+        if (last) break;
+        const uint32_t next = target - (uint32_t)first_chain;
+        if (next / MV_CHAINS <= q / MV_CHAINS || next >= n_ids) { // links only ever point to later pieces
+            ok = false;
+            break;
+        }
+        // The XOR of the values this chain decoded between the two boundaries. Until the first `11`
+        // after the real parse entered it the chain shifts with a window it did not get from the real
+        // parse: none at all (a guessed n: it kept the raw bits), or one from a `11` it read before
+        // it fell in step - same n, but possibly other leading zeros; then its bits are shifted back
+        // and forth, which is only possible if no `11` follows in this stretch.
+        uint32_t delta;
+        if (entered.n11 == 0) {
+            const uint32_t raw = from.raw_x ^ entered.raw_x;
+            if (raw != 0 && state == MV_NO_WINDOW) { // cannot happen: `0` codes need a window
+                ok = false;
+                break;
+            }
+            delta = (raw != 0 ? mv_shifted(raw, state) : 0u) ^ from.x ^ entered.x;
+        } else if ((entered.state & 0xffu) == (state & 0xffu)) {
+            delta = from.x ^ entered.x;
+        } else if (from.n11 == entered.n11) {
+            const uint32_t own_trailing = (32u - (entered.state >> 8) - (entered.state & 0xffu)) & 31u;
+            delta = mv_shifted((from.x ^ entered.x) >> own_trailing, state);
+        } else {
+            ok = false; // rare: leave the stream to the sequential decoder
+            break;
+        }
+        value_bits ^= delta;
+        first_index += n_values;
+        // The real window at the shared boundary: the chain's own if it has seen a `11` since the
+        // real parse entered it, otherwise still the one it was entered with.
+        if (from.n11 > entered.n11) state = from.state;
+        if (mv_length(state) != mv_length(into.state)) { // cannot happen: links compare n
+            ok = false;
+            break;
+        }
+        pos = from.pos;
+        entered = into;
+        q = next;
+    }
+    if (lane == 0) segs[slot].done = ok ? 1u : 0u;
+}
+
+// ---- k_mv_decode: one lane per piece -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_decode(const MvSeg *__restrict__ segs,
+                                                        const unsigned long long *__restrict__ piece_base,
+                                                        uint64_t n_slots, const MvStart *__restrict__ starts,
+                                                        float *__restrict__ out_val,
+                                                        unsigned int *__restrict__ error) {
+    const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (piece >= piece_base[n_slots]) return;
+    const MvStart start = starts[piece];
+    if (!start.valid) return;
+    const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
+    const MvSeg seg = segs[slot];
+    if (!seg.done) return; // the sequential decoder handles this stream
+    MvReader reader;
+    reader.open(seg);
+    float *__restrict__ out = out_val + seg.out_offset;
+    uint32_t value = start.value_bits;
+    if (piece == piece_base[slot] && seg.first == 0) out[0] = __uint_as_float(value); // the raw first value
+    uint32_t pos = start.pos, state = start.state, index = start.first_index;
+    for (uint32_t k = 0; k < start.n_values; k++, index++) {
+        uint32_t kind = 0, bits = 0;
+        if (mv_step(reader, pos, state, kind, bits) != MV_OK) {
+            atomicOr(error, ERR_BITSTREAM);
+            return;
+        }
+        if (kind != MV_CODE_REPEAT) value ^= mv_shifted(bits, state);
+        if (index >= seg.first && index < seg.visible_end) out[index - seg.first] = __uint_as_float(value);
+    }
+}
+
+} // namespace mdb

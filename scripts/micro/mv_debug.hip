@@ -1,0 +1,142 @@
+// Runs the parallel MacaqueV decoder's kernels on ONE stream read from a file and prints what every
+// stage produced (development tool for mdb_macaque_parallel.hpp).
+// usage: mv_debug stream.bin n_values
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../modelardb-rs_amd/csrc/mdb_common.hpp"
+#include "../../modelardb-rs_amd/csrc/mdb_macaque_parallel.hpp"
+namespace mdb { thread_local std::string g_last_error; }
+using namespace mdb;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 1;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { printf("cannot open %s\n", argv[1]); return 1; }
+    std::vector<uint8_t> bytes;
+    uint8_t buffer[4096];
+    size_t got;
+    while ((got = fread(buffer, 1, sizeof buffer, f)) > 0) bytes.insert(bytes.end(), buffer, buffer + got);
+    fclose(f);
+    const uint32_t n_values = (uint32_t)atoll(argv[2]);
+    uint8_t *dev_bytes;
+    CHECK(hipMalloc(&dev_bytes, bytes.size() + 8));
+    CHECK(hipMemcpy(dev_bytes, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    MvSeg seg{};
+    seg.words = reinterpret_cast<const uint32_t *>(dev_bytes);
+    seg.bias_bits = 0;
+    seg.total_bits = 8u * (uint32_t)bytes.size();
+    seg.n_words = ((uint32_t)bytes.size() + 3) / 4;
+    seg.n_model = n_values;
+    seg.first = 0;
+    seg.visible_end = n_values;
+    seg.n_pieces = (seg.total_bits + MV_PIECE_BITS - 1) / MV_PIECE_BITS;
+    const uint32_t P = seg.n_pieces;
+    MvSeg *segs; unsigned long long *piece_base; MvRec *heads; MvChain *chains; MvLink *links; MvStart *starts; uint32_t *guesses; uint32_t *tried;
+    float *out; unsigned int *error;
+    CHECK(hipMalloc(&segs, sizeof seg)); CHECK(hipMemcpy(segs, &seg, sizeof seg, hipMemcpyHostToDevice));
+    unsigned long long base_host[2] = {0, P};
+    CHECK(hipMalloc(&piece_base, 16)); CHECK(hipMemcpy(piece_base, base_host, 16, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&heads, (size_t)P * MV_CHAINS * MV_HEAD * sizeof(MvRec)));
+    CHECK(hipMalloc(&chains, (size_t)P * MV_CHAINS * sizeof(MvChain)));
+    CHECK(hipMalloc(&links, (size_t)P * MV_CHAINS * sizeof(MvLink)));
+    CHECK(hipMalloc(&starts, (size_t)P * sizeof(MvStart))); CHECK(hipMemset(starts, 0, (size_t)P * sizeof(MvStart)));
+    CHECK(hipMalloc(&guesses, (size_t)P * 4));
+    CHECK(hipMalloc(&tried, (size_t)P * 4));
+    CHECK(hipMalloc(&out, (size_t)n_values * 4)); CHECK(hipMemset(out, 0xff, (size_t)n_values * 4));
+    CHECK(hipMalloc(&error, 4)); CHECK(hipMemset(error, 0, 4));
+    const uint32_t blocks = (P + 63) / 64;
+    std::vector<MvChain> host_chains((size_t)P * MV_CHAINS);
+    for (int round = 0; round <= MV_ROUNDS; round++) {
+        if (round > 0) hipLaunchKernelGGL(k_mv_guess, dim3(1), dim3(64), 0, 0, segs, piece_base, chains, guesses);
+        hipLaunchKernelGGL(k_mv_chains, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, round, guesses, tried, heads, chains);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(host_chains.data(), chains, host_chains.size() * sizeof(MvChain), hipMemcpyDeviceToHost));
+        uint32_t with = 0, total = 0;
+        for (uint32_t q = 0; q < P; q++) {
+            with += host_chains[(size_t)q * MV_CHAINS].n_head > 0;
+            for (int c = 0; c < MV_CHAINS; c++) total += host_chains[(size_t)q * MV_CHAINS + c].n_head > 0;
+        }
+        printf("round %d: %u of %u pieces have a chain, %u chains\n", round, with, P, total);
+    }
+    hipLaunchKernelGGL(k_mv_links, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, heads, chains, links);
+    hipLaunchKernelGGL(k_mv_walk, dim3(1), dim3(64), 0, 0, segs, piece_base, chains, links, starts);
+    hipLaunchKernelGGL(k_mv_decode, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, starts, out, error);
+    CHECK(hipDeviceSynchronize());
+    std::vector<MvLink> host_links((size_t)P * MV_CHAINS);
+    std::vector<MvStart> host_starts(P);
+    std::vector<MvRec> host_heads((size_t)P * MV_CHAINS * MV_HEAD);
+    std::vector<uint32_t> host_guesses(P);
+    CHECK(hipMemcpy(host_links.data(), links, host_links.size() * sizeof(MvLink), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(host_starts.data(), starts, (size_t)P * sizeof(MvStart), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(host_heads.data(), heads, host_heads.size() * sizeof(MvRec), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(host_guesses.data(), guesses, (size_t)P * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(&seg, segs, sizeof seg, hipMemcpyDeviceToHost));
+    unsigned int host_error = 0;
+    CHECK(hipMemcpy(&host_error, error, 4, hipMemcpyDeviceToHost));
+    printf("done=%u error=%u pieces=%u bits=%u\n", seg.done, host_error, P, seg.total_bits);
+    for (uint32_t p = 0; p < P && p < 8; p++) {
+        const MvStart &st = host_starts[p];
+        printf("piece %u: guess %x | start valid %u pos %u state %x index %u n %u\n", p, host_guesses[p], st.valid, st.pos,
+               st.state, st.first_index, st.n_values);
+        for (int c = 0; c < MV_CHAINS; c++) {
+            const size_t id = (size_t)p * MV_CHAINS + c;
+            const MvChain &ch = host_chains[id];
+            if (ch.n_head == 0) break;
+            const MvLink &l = host_links[id];
+            printf("   chain %d: head0 (pos %u state %x count %u) end (pos %u state %x count %u n11 %u) link target %x (piece %u) pos %u\n",
+                   c, host_heads[id * MV_HEAD].pos, host_heads[id * MV_HEAD].state, host_heads[id * MV_HEAD].count, ch.end.pos,
+                   ch.end.state, ch.end.count, ch.end.n11, l.target, l.target < 0xfffffff0u ? l.target / MV_CHAINS : 0u, l.from.pos);
+        }
+    }
+    {   // replay the walk on the host to see where it ends
+        uint32_t q = 0, hops = 0;
+        while (true) {
+            const MvLink &l = host_links[q];
+            if (l.target == MV_END) { printf("walk: reached the end after %u hops (piece %u)\n", hops, q / MV_CHAINS); break; }
+            if (l.target == MV_NONE) {
+                const MvChain &ch = host_chains[q];
+                printf("walk: stuck after %u hops at piece %u chain %u: end (pos %u state %x)\n", hops, q / MV_CHAINS, q % MV_CHAINS,
+                       ch.end.pos, ch.end.state);
+                for (uint32_t r = q / MV_CHAINS + 1; r < q / MV_CHAINS + 4 && r < P; r++)
+                    for (int c = 0; c < MV_CHAINS; c++) {
+                        const size_t id = (size_t)r * MV_CHAINS + c;
+                        if (host_chains[id].n_head == 0) break;
+                        printf("   piece %u chain %d guess %x: heads", r, c, host_guesses[r]);
+                        for (uint32_t h = 0; h < host_chains[id].n_head; h++) printf(" (%u %x)", host_heads[id * MV_HEAD + h].pos, host_heads[id * MV_HEAD + h].state);
+                        printf(" end (%u %x)\n", host_chains[id].end.pos, host_chains[id].end.state);
+                    }
+                break;
+            }
+            q = l.target;
+            hops++;
+        }
+    }
+    if (argc >= 4) { // compare with the expected values
+        std::vector<uint32_t> expected(n_values), produced(n_values);
+        FILE *e = fopen(argv[3], "rb");
+        if (e && fread(expected.data(), 4, n_values, e) == n_values) {
+            CHECK(hipMemcpy(produced.data(), out, (size_t)n_values * 4, hipMemcpyDeviceToHost));
+            uint32_t bad = 0, first_bad = 0;
+            for (uint32_t i = 0; i < n_values; i++)
+                if (produced[i] != expected[i] && bad++ == 0) first_bad = i;
+            printf("values: %u of %u differ", bad, n_values);
+            if (bad) {
+                printf(", first at %u: got %08x want %08x; piece starts around it:", first_bad, produced[first_bad], expected[first_bad]);
+                for (uint32_t q = 0; q < P; q++)
+                    if (host_starts[q].valid && host_starts[q].first_index + host_starts[q].n_values > first_bad &&
+                        host_starts[q].first_index <= first_bad + 1)
+                        printf(" [piece %u index %u n %u pos %u state %x value %08x]", q, host_starts[q].first_index,
+                               host_starts[q].n_values, host_starts[q].pos, host_starts[q].state, host_starts[q].value_bits);
+            }
+            printf("\n");
+        }
+        if (e) fclose(e);
+    }
+    uint32_t valid = 0;
+    for (auto &s : host_starts) valid += s.valid;
+    printf("pieces on the real parse: %u\n", valid);
+    return 0;
+}

@@ -13,6 +13,18 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[None, "1024", "8"], ids=["mv-default", "mv-from-1024-values", "mv-from-8-values"])
+def macaque_decoder(request, monkeypatch):
+    """Every grid test runs with the parallel MacaqueV decoder (mdb_macaque_parallel.hpp) at its
+    default threshold, switched off (one lane per stream only) and forced onto every stream of at
+    least 8 values."""
+    if request.param is None:
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+    else:
+        monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("irregular", [False, True])
 @pytest.mark.parametrize("eb_name", ["lossless", "abs5", "rel5", "rel1"])
 def test_grid_matches_oracle_on_synthetic_series(hip, eb_name, irregular):
