@@ -560,6 +560,7 @@ struct GridPlan {
     GridHeader host_header;
     uint32_t n_blocks;
     uint32_t mv_min_values; // MacaqueV streams at least this long go to the parallel decoder
+    bool mv_forced;         // MDB_GRID_MV_MIN_VALUES is set: no upper limit on the number of pieces
 };
 
 // MDB_GRID_MV_MIN_VALUES: "off" disables the parallel MacaqueV decoder, a number sets the stream
@@ -570,7 +571,7 @@ static uint32_t mv_min_values_setting() {
         const long long value = std::atoll(text);
         if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
     }
-    return 0xffffffffu; // off by default until it beats one lane per stream (MV_DEFAULT_MIN_VALUES)
+    return MV_DEFAULT_MIN_VALUES;
 }
 
 // Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
@@ -602,6 +603,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     MDB_HIP_CHECK(hipMemsetAsync(plan->header, 0, sizeof(GridHeader), ctx->stream));
     std::memset(&plan->host_header, 0, sizeof(GridHeader));
     plan->mv_min_values = mv_min_values_setting();
+    plan->mv_forced = std::getenv("MDB_GRID_MV_MIN_VALUES") != nullptr;
     if (n == 0) return 0;
     DevSegments s = to_dev(in);
     {
@@ -655,7 +657,8 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     const uint64_t n_serial = plan.host_header.n_serial;
     // Every qualifying stream has ceil(bits / MV_PIECE_BITS) pieces and is on the serial list.
     const uint64_t max_pieces = plan.host_header.metrics[9] * 8 / MV_PIECE_BITS + n_serial + 1;
-    if (max_pieces > 0x7fffff00ull) return 0; // absurdly large: leave it to the sequential decoder
+    if (max_pieces > MV_MAX_PIECES && !plan.mv_forced) return 0; // enough streams for one lane per stream
+    if (max_pieces * MV_CHAINS > 0x7fffff00ull) return 0;
     const uint64_t sums_bytes = scan_block_sums_bytes(n_serial);
     const uint64_t segs_bytes = align_up(n_serial * sizeof(MvSeg), 256);
     const uint64_t base_bytes = align_up((n_serial + 1) * 8, 256) + align_up(sums_bytes, 256);
@@ -663,7 +666,7 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     const uint64_t chains_bytes = align_up(max_pieces * MV_CHAINS * sizeof(MvChain), 256);
     const uint64_t links_bytes = align_up(max_pieces * MV_CHAINS * sizeof(MvLink), 256);
     const uint64_t starts_bytes = align_up(max_pieces * sizeof(MvStart), 256);
-    const uint64_t guesses_bytes = 2 * align_up(max_pieces * 4, 256); // guesses + tried
+    const uint64_t guesses_bytes = 2 * align_up(max_pieces * 4, 256) + 256; // guesses + tried + pending
     void *p = nullptr;
     if (scratch_reserve(ctx, SCRATCH_MV, segs_bytes + base_bytes + heads_bytes + chains_bytes + links_bytes +
                                             starts_bytes + guesses_bytes, &p))
@@ -684,6 +687,8 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     at += starts_bytes;
     uint32_t *guesses = reinterpret_cast<uint32_t *>(at);
     uint32_t *tried = reinterpret_cast<uint32_t *>(at + align_up(max_pieces * 4, 256));
+    uint32_t *pending = reinterpret_cast<uint32_t *>(at + 2 * align_up(max_pieces * 4, 256));
+    MDB_HIP_CHECK(hipMemsetAsync(pending, 0, 256, ctx->stream));
     MDB_HIP_CHECK(hipMemsetAsync(starts, 0, starts_bytes, ctx->stream));
     {
         LaunchTimer timer(ctx, "k_mv_select");
@@ -692,19 +697,20 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     }
     if (device_exclusive_scan(ctx, MvPieceCount{segs}, n_serial, piece_base, block_sums, "k_mv_scan")) return 1;
     const uint32_t piece_blocks = (uint32_t)((max_pieces + MDB_WAVE - 1) / MDB_WAVE);
-    for (int round = 0; round <= MV_ROUNDS; round++) {
-        if (round > 0) {
+    for (int round = 0; round < MV_ROUNDS; round++) {
+        if (mv_round_kind(round) == MV_ROUND_GUESS) {
             LaunchTimer timer(ctx, "k_mv_guess");
             hipLaunchKernelGGL(k_mv_guess, dim3((uint32_t)n_serial), dim3(MDB_WAVE), 0, ctx->stream, segs,
                                piece_base, chains, guesses);
         }
-        LaunchTimer timer(ctx, "k_mv_chains");
+        LaunchTimer timer(ctx, round == 0 ? "k_mv_chains_start" : (round == 1 ? "k_mv_chains_first" : "k_mv_chains_more"));
         hipLaunchKernelGGL(k_mv_chains, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
-                           n_serial, round, guesses, tried, heads, chains);
+                           n_serial, round, guesses, tried, pending, heads, chains);
     }
     {
         LaunchTimer timer(ctx, "k_mv_links");
-        hipLaunchKernelGGL(k_mv_links, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
+        const uint32_t chain_blocks = (uint32_t)((max_pieces * MV_CHAINS + MDB_WAVE - 1) / MDB_WAVE);
+        hipLaunchKernelGGL(k_mv_links, dim3(chain_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
                            n_serial, heads, chains, links);
     }
     {

@@ -21,9 +21,8 @@
 //    chains (k_mv_guess), refined over MV_ROUNDS rounds. Wrong candidates die within a few codes,
 //    with one exception: a parse that is a few bits late keeps reading the (almost always zero) top
 //    bits of the window as control bits; such late copies are recognised by their distance to a
-//    kept chain on the grid of code boundaries. Per chain a few boundaries are recorded with what
-//    the chain has accumulated there: values, `11` codes, XOR of the unshifted bits of its `0` codes
-//    before its first `11` (their shift is not known to the chain) and XOR of the shifted bits after.
+//    kept chain on the grid of code boundaries. Per chain a few boundaries are recorded where the
+//    real parse may join it, and per such boundary what only the real parse can interpret (MvTrack).
 //  * k_mv_links: every chain is parsed on from the end of its piece until it stands on a boundary
 //    that a chain of a later piece recorded with the same n: from there on the two parses visit
 //    the same positions. The link notes that target and both chains' accumulators at the boundary.
@@ -52,16 +51,26 @@ constexpr int MV_CHAINS = 4; // speculative chains kept per piece
 constexpr int MV_HEAD = 4;   // boundaries recorded per chain
 constexpr uint32_t MV_SCAN_BITS = 256;    // `11` patterns are looked for this far into a piece
 constexpr uint32_t MV_MAX_CODE_BITS = 45; // 2 + 5 + 6 + 32
-constexpr int MV_ROUNDS = 3;              // rounds of guessed windows
+constexpr int MV_ROUNDS = 12;             // k_mv_chains launches at most (a round without work costs ~nothing)
+enum : int { MV_ROUND_START = 0, MV_ROUND_GUESS = 1, MV_ROUND_SCAN = 2 };
+// Piece 0 from the real start; guessed windows for everyone; `11` patterns for pieces that still have
+// no chain; then rounds of guesses, each of which carries the windows found so far past one more
+// change of n, until no piece is without a chain.
+__device__ __host__ inline int mv_round_kind(int round) {
+    return round == 0 ? MV_ROUND_START : (round == 2 ? MV_ROUND_SCAN : MV_ROUND_GUESS);
+}
 constexpr uint32_t MV_SHIFT_BITS = 8;     // how late a parse can be and still live on zero top bits
 constexpr uint32_t MV_SETTLE_CODES = 8;   // codes after which a guessed chain is recorded and compared
 constexpr uint32_t MV_NO_WINDOW = 0xffffu;
 constexpr uint32_t MV_NO_LENGTH = 0xffu;
-constexpr uint32_t MV_MAX_TAIL_BITS = 32 * MV_PIECE_BITS;
+constexpr uint32_t MV_MAX_TAIL_BITS = 16 * MV_PIECE_BITS;
 constexpr uint32_t MV_MAX_STREAM_BYTES = 1u << 27; // bit positions stay below 2^30
 constexpr uint32_t MV_NONE = 0xffffffffu; // link: no partner found
 constexpr uint32_t MV_END = 0xfffffffeu;  // link: parsed to the end of the stream
 constexpr uint32_t MV_DEFAULT_MIN_VALUES = 1024;
+// More pieces than this in one batch: there are enough streams to keep the GPU busy with one lane
+// per stream, which does a third of the work per value.
+constexpr uint64_t MV_MAX_PIECES = 131072;
 
 // One stream that qualifies (indexed like serial_ids).
 struct MvSeg {
@@ -77,25 +86,40 @@ struct MvSeg {
     uint32_t done;        // set by k_mv_walk: k_mv_decode handles it, k_grid_serial skips it
 };
 
-// What a chain has accumulated at one of its code boundaries.
+// A recorded code boundary of a chain: a place where the real parse may join it.
 struct MvRec {
-    uint32_t pos;    // bit position of the next code
-    uint32_t state;  // window: leading | meaningful << 8 (leading only valid once n11 > 0), or MV_NO_WINDOW
-    uint32_t count;  // values decoded since the chain's start
-    uint32_t n11;    // `11` codes since the chain's start
-    uint32_t raw_x;  // XOR of the unshifted bits of the `0` codes before the first `11`
-    uint32_t x;      // XOR of the (shifted) deltas from the first `11` on
+    uint32_t pos;   // bit position of the next code
+    uint32_t state; // window there: leading | meaningful << 8, or MV_NO_WINDOW
+    uint32_t count; // values the chain has decoded before it
+};
+
+// A chain while it is being followed, and what it has accumulated. A chain cannot know from where on
+// it coincides with the real parse, nor whether the leading zeros of its window are real before it
+// has read a `11` code AFTER that point. So for each of its recorded boundaries h it keeps apart:
+// raw[h], the XOR of the unshifted bits of the `0` codes between boundary h and the next `11` code
+// (only the real parse knows how far those are shifted), and snap[h], the value of x at that `11`
+// code; x is the XOR of everything the chain decoded, shifted with its own windows, which are real
+// from that `11` code on if the real parse joined at boundary h.
+struct MvTrack {
+    uint32_t pos;
+    uint32_t state;
+    uint32_t count;
+    uint32_t x;
+    uint32_t seen; // bit h: a `11` code has been read since boundary h
+    uint32_t raw[MV_HEAD];
+    uint32_t snap[MV_HEAD];
 };
 
 struct MvChain { // chains[piece * MV_CHAINS + c], used ones first
     uint32_t n_head; // recorded boundaries, 0: unused
-    MvRec end;       // the chain's first boundary at or beyond the end of its piece
+    MvTrack end;     // the chain at its first boundary at or beyond the end of its piece
 };
 
 struct MvLink { // links[piece * MV_CHAINS + c]
-    uint32_t target; // id (piece * MV_CHAINS + c) of the chain this parse joins, MV_END or MV_NONE
-    MvRec from;      // this parse at the shared boundary
-    MvRec into;      // the target chain at the shared boundary
+    uint32_t target;     // id (piece * MV_CHAINS + c) of the chain this parse joins, MV_END or MV_NONE
+    uint32_t into_head;  // which recorded boundary of the target it joins at
+    uint32_t into_count; // values the target had decoded there
+    MvTrack from;        // this parse at the shared boundary
 };
 
 struct MvStart {
@@ -121,6 +145,13 @@ __device__ __forceinline__ bool mv_qualifies(const SegInfo &info, uint32_t value
 }
 
 // Random-access reader: bits [pos, pos + count) of the stream, MSB first, zeros past the end.
+// A lane's 64 neighbours read pieces that lie MV_PIECE_BITS apart, so a word load per code would
+// touch 64 cache lines per instruction, over and over. Each lane therefore copies the words it is
+// going to walk over into LDS once, 16 bytes at a time (`stage`), laid out [word][lane] so that a
+// row is conflict free whatever word each lane is at; words outside that window (a parse that runs
+// on for several pieces) still come from global memory.
+constexpr uint32_t MV_STAGE_WORDS = MV_PIECE_BITS / 32 + 20; // a piece, 8 bits before it, ~600 bits after it
+
 struct MvReader {
     const uint32_t *words;
     uint32_t n_words;
@@ -128,6 +159,8 @@ struct MvReader {
     uint32_t total_bits;
     uint32_t cached_word;
     uint64_t cache;
+    const uint32_t *staged; // LDS, this lane's column, already byte swapped; nullptr: nothing staged
+    uint32_t staged_first;  // first staged word
     __device__ __forceinline__ void open(const MvSeg &seg) {
         words = seg.words;
         n_words = seg.n_words;
@@ -135,8 +168,42 @@ struct MvReader {
         total_bits = seg.total_bits;
         cached_word = 0xfffffffeu; // never index - 1 of a real word
         cache = 0;
+        staged = nullptr;
+        staged_first = 0;
+    }
+    // Copies words [first, first + MV_STAGE_WORDS) around bit position `from_pos` into `column`
+    // (this lane's column of a [MV_STAGE_WORDS][MDB_WAVE] LDS array). Only this lane reads it back.
+    __device__ __forceinline__ void stage(uint32_t *column, uint32_t from_pos) {
+        // First staged word: at or before the word of from_pos, on a 16-byte boundary of the ADDRESS
+        // (the payload itself is only byte aligned) so that the copy can use 16-byte loads.
+        const uint32_t skew = (uint32_t)((reinterpret_cast<uintptr_t>(words) >> 2) & 3u);
+        const uint32_t wanted = (bias_bits + from_pos) >> 5;
+        const uint32_t rounded = (wanted + skew) & ~3u;
+        const bool aligned = rounded >= skew;
+        const uint32_t first = aligned ? rounded - skew : 0u;
+#pragma unroll 4
+        for (uint32_t k = 0; k < MV_STAGE_WORDS / 4; k++) {
+            const uint32_t index = first + 4 * k;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (aligned && index + 3 < n_words) {
+                v = *reinterpret_cast<const uint4 *>(words + index);
+            } else {
+                if (index < n_words) v.x = words[index];
+                if (index + 1 < n_words) v.y = words[index + 1];
+                if (index + 2 < n_words) v.z = words[index + 2];
+                if (index + 3 < n_words) v.w = words[index + 3];
+            }
+            column[(4 * k + 0) * MDB_WAVE] = __builtin_bswap32(v.x);
+            column[(4 * k + 1) * MDB_WAVE] = __builtin_bswap32(v.y);
+            column[(4 * k + 2) * MDB_WAVE] = __builtin_bswap32(v.z);
+            column[(4 * k + 3) * MDB_WAVE] = __builtin_bswap32(v.w);
+        }
+        staged = column;
+        staged_first = first;
     }
     __device__ __forceinline__ uint32_t word(uint32_t index) const {
+        const uint32_t k = index - staged_first;
+        if (staged != nullptr && k < MV_STAGE_WORDS) return staged[k * MDB_WAVE];
         return index < n_words ? __builtin_bswap32(words[index]) : 0u;
     }
     // count in [0, 32]
@@ -201,18 +268,38 @@ __device__ __forceinline__ int mv_step(MvReader &r, uint32_t &pos, uint32_t &sta
     return MV_OK;
 }
 
-// One code of a speculative chain: like mv_step, plus the chain's accumulators.
-__device__ __forceinline__ int mv_chain_step(MvReader &r, MvRec &at) {
+// One code of a chain that has n_head recorded boundaries: like mv_step, plus the accumulators.
+__device__ __forceinline__ int mv_track_step(MvReader &r, MvTrack &t, uint32_t n_head) {
     uint32_t kind = 0, bits = 0;
-    const int rc = mv_step(r, at.pos, at.state, kind, bits);
+    const int rc = mv_step(r, t.pos, t.state, kind, bits);
     if (rc != MV_OK) return rc;
-    at.count += 1;
-    if (kind == MV_CODE_WINDOW) at.n11 += 1;
-    if (kind != MV_CODE_REPEAT) {
-        if (at.n11 > 0) at.x ^= mv_shifted(bits, at.state);
-        else at.raw_x ^= bits; // the chain does not know the leading zeros of a window it inherited
+    t.count += 1;
+    if (kind == MV_CODE_WINDOW) {
+#pragma unroll
+        for (uint32_t h = 0; h < MV_HEAD; h++)
+            if (h < n_head && !((t.seen >> h) & 1u)) {
+                t.snap[h] = t.x;
+                t.seen |= 1u << h;
+            }
+    } else if (kind == MV_CODE_BITS) {
+#pragma unroll
+        for (uint32_t h = 0; h < MV_HEAD; h++)
+            if (h < n_head && !((t.seen >> h) & 1u)) t.raw[h] ^= bits;
     }
+    if (kind != MV_CODE_REPEAT) t.x ^= mv_shifted(bits, t.state);
     return MV_OK;
+}
+
+__device__ __forceinline__ MvTrack mv_track_at(uint32_t pos, uint32_t state) {
+    MvTrack t;
+    t.pos = pos;
+    t.state = state;
+    t.count = 0;
+    t.x = 0;
+    t.seen = 0;
+#pragma unroll
+    for (int h = 0; h < MV_HEAD; h++) t.raw[h] = t.snap[h] = 0;
+    return t;
 }
 
 // Last slot whose first piece is <= piece (slots without pieces share the base of the next one).
@@ -262,6 +349,10 @@ __global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange rang
     segs[slot] = seg;
 }
 
+#ifdef MDB_MV_DEBUG
+__device__ unsigned long long mv_debug_counters[4]; // iterations, steps, max iterations of a lane, max ticks of a lane
+#endif
+
 // ---- k_mv_chains: one lane per piece ---------------------------------------------------------------------
 //
 // guesses[piece]: up to two candidate n (one per byte, MV_NO_LENGTH = none); tried[piece]: the n this
@@ -277,10 +368,14 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
                                                         const unsigned long long *__restrict__ piece_base,
                                                         uint64_t n_slots, int round,
                                                         const uint32_t *__restrict__ guesses,
-                                                        uint32_t *__restrict__ tried, MvRec *__restrict__ heads,
-                                                        MvChain *__restrict__ chains) {
+                                                        uint32_t *__restrict__ tried, uint32_t *__restrict__ pending,
+                                                        MvRec *__restrict__ heads, MvChain *__restrict__ chains) {
+    __shared__ uint32_t stage_lds[MV_STAGE_WORDS][MDB_WAVE];
     const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (piece >= piece_base[n_slots]) return;
+    // pending[r]: pieces that were still without a chain after round r. None left: nothing to do.
+    if (round > 1 && pending[round - 1] == 0) return;
+    const int kind = mv_round_kind(round);
     MvChain *__restrict__ mine = chains + piece * MV_CHAINS;
     const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
     const MvSeg seg = segs[slot];
@@ -290,102 +385,196 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
     const uint32_t piece_begin = p * MV_PIECE_BITS;
     const uint32_t piece_end = min(piece_begin + MV_PIECE_BITS, seg.total_bits);
     uint32_t n_chains = 0;
-    if (round > 0)
-        while (n_chains < MV_CHAINS && mine[n_chains].n_head > 0) n_chains++;
-
-    // Follows the stream from `at` to the first boundary at or beyond the end of the piece and keeps
-    // the chain unless it is malformed - or, for a guessed n, turns out to run on the grid of a
-    // kept chain or 1..MV_SHIFT_BITS bits behind it: while n stays the same, boundaries are a whole
-    // number of `0` codes apart (give or take `10` codes), so a chain on the same grid IS that
-    // chain from here on, and one slightly behind is a late copy living on the zero top bits of
-    // the window. A guessed chain may only fall in step with the real parse after a few codes, so
-    // its boundaries are recorded once it has settled.
-    auto follow = [&](MvRec at, uint32_t guessed_length) -> bool {
-        MvRec *__restrict__ head = heads + (piece * MV_CHAINS + n_chains) * MV_HEAD;
-        const bool guessed = guessed_length != MV_NO_LENGTH;
-        const uint32_t record_from = guessed ? MV_SETTLE_CODES : 0u;
-        uint32_t n_head = 0, steps = 0;
-        if (!guessed && at.state == MV_NO_WINDOW && at.pos == 32u) head[n_head++] = at; // the real start
-        while (at.pos < piece_end) {
-            const int rc = mv_chain_step(reader, at);
-            if (rc == MV_MALFORMED) return false;
-            if (rc == MV_OVERRUN) break; // only padding is left: the chain reaches the end
-            steps += 1;
-            if (steps >= record_from && n_head < MV_HEAD) head[n_head++] = at;
-            if (guessed && steps == MV_SETTLE_CODES && mv_length(at.state) == guessed_length) {
-                const uint32_t code_bits = 1u + guessed_length;
-                for (uint32_t c = 0; c < n_chains; c++) {
-                    if (mv_length(mine[c].end.state) != guessed_length) continue;
-                    const uint32_t lag = (at.pos + code_bits * 256u - mine[c].end.pos) % code_bits;
-                    if (lag <= MV_SHIFT_BITS) return false;
-                }
-            }
-        }
-        if (n_head == 0) return false;
-        mine[n_chains].n_head = n_head;
-        mine[n_chains].end = at;
-        n_chains += 1;
-        return true;
-    };
-
-    if (round == 0) {
+    if (kind == MV_ROUND_START) {
         tried[piece] = 0xffffffffu;
-        if (p == 0) {
-            // The real start: 32 raw bits of the first value, then codes, no window yet.
-            if (seg.total_bits >= 32) (void)follow({32u, MV_NO_WINDOW, 0u, 0u, 0u, 0u}, MV_NO_LENGTH);
+        for (uint32_t c = 0; c < MV_CHAINS; c++) mine[c].n_head = 0;
+        if (p > 0) {
+            atomicAdd(&pending[round], 1u);
+            return;
+        }
+    } else {
+        while (n_chains < MV_CHAINS && mine[n_chains].n_head > 0) n_chains++;
+        bool work = p > 0;
+        if (kind == MV_ROUND_SCAN) {
+            work = work && n_chains == 0;
         } else {
-            const uint32_t scan_end = min(piece_begin + MV_SCAN_BITS, piece_end);
-            for (uint32_t o = piece_begin; o < scan_end && o + 13 <= seg.total_bits && n_chains < MV_CHAINS - 1; o++) {
-                const uint32_t top = reader.peek(o, 13);
-                if ((top >> 11) != 3u || !mv_valid_window((top >> 6) & 31u, top & 63u)) continue;
-                (void)follow({o, MV_NO_WINDOW, 0u, 0u, 0u, 0u}, MV_NO_LENGTH);
+            // A guess this piece has not been searched with yet; after the first round of guesses only
+            // pieces without a chain from a guess keep searching.
+            bool untried = false;
+            for (int g = 0; g < 2; g++) {
+                const uint32_t candidate = (guesses[piece] >> (8 * g)) & 0xffu;
+                untried = untried || (candidate <= 32u && !mv_byte_listed(tried[piece] & 0x00ffffffu, candidate));
             }
+            const bool has_guessed_chain = (tried[piece] >> 24) == 0x01u;
+            work = work && untried && n_chains < MV_CHAINS && !has_guessed_chain;
         }
-    } else if (p > 0) {
-        uint32_t tried_here = tried[piece];
-        for (int g = 0; g < 2; g++) {
-            const uint32_t length = (guesses[piece] >> (8 * g)) & 0xffu;
-            if (length == MV_NO_LENGTH || length > 32u || mv_byte_listed(tried_here, length)) continue;
-            tried_here = (tried_here << 8) | length;
-            // Entry points a little before the piece are tried too, so that the real chain is usually
-            // met before its late copies. The leading zeros of the guessed window are unknown (and
-            // not needed: see MvRec::raw_x).
-            const uint32_t state = length << 8;
-            const uint32_t try_begin = piece_begin >= 32 + MV_SHIFT_BITS ? piece_begin - MV_SHIFT_BITS : piece_begin;
-            const uint32_t try_end = min(piece_begin + MV_MAX_CODE_BITS, piece_end);
-            const uint32_t first_new = n_chains;
-            for (uint32_t o = try_begin; o < try_end && n_chains < MV_CHAINS; o++)
-                (void)follow({o, state, 0u, 0u, 0u, 0u}, length);
-            // A chain that was found first can itself be the late copy of one found after it.
-            const uint32_t code_bits = 1u + length;
-            uint32_t kept = first_new;
-            for (uint32_t c = first_new; c < n_chains; c++) {
-                bool late_copy = false;
-                for (uint32_t b = 0; b < n_chains && !late_copy; b++) {
-                    if (b == c || mv_length(mine[b].end.state) != length || mv_length(mine[c].end.state) != length)
-                        continue;
-                    const uint32_t lag = (mine[c].end.pos + code_bits * 256u - mine[b].end.pos) % code_bits;
-                    late_copy = lag >= 1 && lag <= MV_SHIFT_BITS;
-                }
-                if (late_copy) continue;
-                if (kept != c) {
-                    for (uint32_t h = 0; h < mine[c].n_head; h++)
-                        heads[(piece * MV_CHAINS + kept) * MV_HEAD + h] = heads[(piece * MV_CHAINS + c) * MV_HEAD + h];
-                    mine[kept] = mine[c];
-                }
-                kept += 1;
-            }
-            n_chains = kept;
+        if (!work) {
+            if (n_chains == 0) atomicAdd(&pending[round], 1u);
+            return;
         }
-        tried[piece] = tried_here;
     }
+    reader.stage(&stage_lds[0][threadIdx.x], piece_begin);
+
+    // The candidates are tried one after the other, but as ONE loop in which every lane either picks
+    // its next candidate or advances its current one by a code: most candidates die within a few
+    // codes while a survivor runs through the whole piece, and lanes waiting for each other's
+    // candidates would cost the wave (candidates x longest chain) iterations instead of their sum.
+    //
+    // A candidate is followed to the first boundary at or beyond the end of the piece and kept
+    // unless it is malformed - or, for a guessed n, turns out to run on the grid of a kept chain or
+    // 1..MV_SHIFT_BITS bits behind it: while n stays the same, boundaries are a whole number of `0`
+    // codes apart (give or take `10` codes), so a chain on the same grid IS that chain from here on,
+    // and one slightly behind is a late copy living on the zero top bits of the window. A guessed
+    // chain may only fall in step with the real parse after a few codes, so its boundaries are
+    // recorded once it has settled.
+    int guess_index = -1;               // which guess is being searched (guess rounds)
+    uint32_t length = MV_NO_LENGTH;     // its n, MV_NO_LENGTH: candidates are `11` patterns / the real start
+    uint32_t o = 0, o_end = 0;          // next and last+1 entry point to try
+    uint32_t first_new = n_chains;      // chains [first_new, n_chains) were found with this guess
+    uint32_t tried_here = kind == MV_ROUND_START ? 0xffffffffu : tried[piece];
+    uint32_t chain_limit = MV_CHAINS;
+    bool searching = true, running = false, found_with_guess = false;
+    MvTrack at = mv_track_at(0u, 0u);
+    uint32_t steps = 0, n_head = 0;
+    if (kind == MV_ROUND_START) {
+        // The real start: 32 raw bits of the first value, then codes, no window yet.
+        if (seg.total_bits >= 32) {
+            at = mv_track_at(32u, MV_NO_WINDOW);
+            heads[(piece * MV_CHAINS) * MV_HEAD] = {32u, MV_NO_WINDOW, 0u};
+            n_head = 1;
+            running = true;
+        }
+    } else if (kind == MV_ROUND_SCAN) {
+        o = piece_begin;
+        o_end = min(piece_begin + MV_SCAN_BITS, piece_end);
+        chain_limit = 2; // survivors of a scan are rarely real; leave room for guessed chains
+    }
+#ifdef MDB_MV_DEBUG
+    unsigned long long debug_iterations = 0, debug_steps = 0;
+    const unsigned long long debug_t0 = wall_clock64();
+#endif
+    while (searching) {
+#ifdef MDB_MV_DEBUG
+        debug_iterations += 1;
+        debug_steps += running ? 1 : 0;
+#endif
+        if (!running) {
+            if (o >= o_end || n_chains >= chain_limit) {
+                if (length != MV_NO_LENGTH) {
+                    // A chain that was found first can itself be the late copy of one found after it.
+                    const uint32_t code_bits = 1u + length;
+                    uint32_t kept = first_new;
+                    for (uint32_t c = first_new; c < n_chains; c++) {
+                        bool late_copy = false;
+                        for (uint32_t b2 = 0; b2 < n_chains && !late_copy; b2++) {
+                            if (b2 == c || mv_length(mine[b2].end.state) != length ||
+                                mv_length(mine[c].end.state) != length)
+                                continue;
+                            const uint32_t lag = (mine[c].end.pos + code_bits * 256u - mine[b2].end.pos) % code_bits;
+                            late_copy = lag >= 1 && lag <= MV_SHIFT_BITS;
+                        }
+                        if (late_copy) continue;
+                        if (kept != c) {
+                            for (uint32_t h = 0; h < mine[c].n_head; h++)
+                                heads[(piece * MV_CHAINS + kept) * MV_HEAD + h] = heads[(piece * MV_CHAINS + c) * MV_HEAD + h];
+                            mine[kept] = mine[c];
+                        }
+                        kept += 1;
+                    }
+                    n_chains = kept;
+                }
+                // The next guess, if any.
+                length = MV_NO_LENGTH;
+                while (kind == MV_ROUND_GUESS && ++guess_index < 2) {
+                    const uint32_t candidate = (guesses[piece] >> (8 * guess_index)) & 0xffu;
+                    if (candidate > 32u || mv_byte_listed(tried_here & 0x00ffffffu, candidate)) continue;
+                    length = candidate;
+                    break;
+                }
+                if (length == MV_NO_LENGTH || n_chains >= MV_CHAINS) {
+                    searching = false;
+                } else {
+                    tried_here = (tried_here & 0xff000000u) | ((tried_here << 8) & 0x00ffff00u) | length;
+                    // The real parse enters the piece within its first 45 bits. The leading zeros of
+                    // the guessed window are unknown (and not needed: see MvTrack).
+                    o = piece_begin;
+                    o_end = min(piece_begin + MV_MAX_CODE_BITS, piece_end);
+                    first_new = n_chains;
+                    chain_limit = MV_CHAINS;
+                }
+            } else if (length == MV_NO_LENGTH) { // round 0: is there a plausible `11` code at o?
+                if (o + 13 <= seg.total_bits) {
+                    const uint32_t top = reader.peek(o, 13);
+                    if ((top >> 11) == 3u && mv_valid_window((top >> 6) & 31u, top & 63u)) {
+                        at = mv_track_at(o, MV_NO_WINDOW);
+                        steps = 0;
+                        n_head = 0;
+                        running = true;
+                    }
+                }
+                o += 1;
+            } else {
+                at = mv_track_at(o, length << 8);
+                steps = 0;
+                n_head = 0;
+                running = true;
+                o += 1;
+            }
+        } else {
+            MvRec *__restrict__ head = heads + (piece * MV_CHAINS + n_chains) * MV_HEAD;
+            bool finished = at.pos >= piece_end;
+            if (!finished) {
+                const int rc = mv_track_step(reader, at, n_head);
+                if (rc == MV_MALFORMED) {
+                    running = false;
+                } else if (rc == MV_OVERRUN) {
+                    finished = true; // only padding is left: the chain reaches the end
+                } else {
+                    steps += 1;
+                    const bool guessed = length != MV_NO_LENGTH;
+                    if ((!guessed || steps >= MV_SETTLE_CODES) && n_head < MV_HEAD)
+                        head[n_head++] = {at.pos, at.state, at.count};
+                    if (guessed && steps == MV_SETTLE_CODES && mv_length(at.state) == length) {
+                        const uint32_t code_bits = 1u + length;
+                        for (uint32_t c = 0; c < n_chains; c++) {
+                            if (mv_length(mine[c].end.state) != length) continue;
+                            const uint32_t lag = (at.pos + code_bits * 256u - mine[c].end.pos) % code_bits;
+                            if (lag <= MV_SHIFT_BITS) running = false;
+                        }
+                    }
+                    finished = running && at.pos >= piece_end;
+                }
+            }
+            if (finished) {
+                if (n_head > 0) {
+                    mine[n_chains].n_head = n_head;
+                    mine[n_chains].end = at;
+                    n_chains += 1;
+                    found_with_guess = found_with_guess || length != MV_NO_LENGTH;
+                }
+                running = false;
+            }
+        }
+    }
+#ifdef MDB_MV_DEBUG
+    atomicAdd(&mv_debug_counters[0], debug_iterations);
+    atomicAdd(&mv_debug_counters[1], debug_steps);
+    atomicMax(&mv_debug_counters[2], debug_iterations);
+    atomicMax(&mv_debug_counters[3], wall_clock64() - debug_t0);
+#endif
+    if (kind == MV_ROUND_GUESS) {
+        // Top byte 0x01: a chain found with a guessed window is kept.
+        const bool guessed_kept = (tried_here >> 24) == 0x01u || found_with_guess;
+        tried[piece] = (tried_here & 0x00ffffffu) | (guessed_kept ? 0x01000000u : 0xff000000u);
+    }
+    if (n_chains == 0) atomicAdd(&pending[round], 1u);
     for (uint32_t c = n_chains; c < MV_CHAINS; c++) mine[c].n_head = 0;
 }
 
 // ---- k_mv_guess: one wave per entry of the serial list ----------------------------------------------------
 //
 // guesses[piece] = the n at the end of the chains of the nearest earlier piece of the stream that
-// has chains (its first two chains, if they differ).
+// has chains (two of them, if its chains disagree).
 __global__ __launch_bounds__(MDB_WAVE) void k_mv_guess(const MvSeg *__restrict__ segs,
                                                        const unsigned long long *__restrict__ piece_base,
                                                        const MvChain *__restrict__ chains,
@@ -402,11 +591,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_guess(const MvSeg *__restrict__
         if (q < n_pieces) {
             const MvChain *__restrict__ theirs = chains + (first_piece + q) * MV_CHAINS;
             if (theirs[0].n_head > 0) {
-                const uint32_t a = mv_length(theirs[0].end.state) & 0xffu;
-                uint32_t b = MV_NO_LENGTH;
-                for (int c = 1; c < MV_CHAINS && b == MV_NO_LENGTH; c++)
-                    if (theirs[c].n_head > 0 && (mv_length(theirs[c].end.state) & 0xffu) != a)
-                        b = mv_length(theirs[c].end.state) & 0xffu;
+                // The chains found last first: those come from guessed windows, which are right more
+                // often than the survivors of a scan for `11` patterns.
+                uint32_t a = MV_NO_LENGTH, b = MV_NO_LENGTH;
+                for (int c = MV_CHAINS - 1; c >= 0; c--) {
+                    if (theirs[c].n_head == 0) continue;
+                    const uint32_t length = mv_length(theirs[c].end.state) & 0xffu;
+                    if (a == MV_NO_LENGTH) a = length;
+                    else if (b == MV_NO_LENGTH && length != a) b = length;
+                }
                 seen = 0xffff0000u | (b << 8) | a;
             }
         }
@@ -425,84 +618,82 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_guess(const MvSeg *__restrict__
     }
 }
 
-// ---- k_mv_links: one lane per piece -----------------------------------------------------------------------
+// ---- k_mv_links: one lane per chain ---------------------------------------------------------------------
 
 __global__ __launch_bounds__(MDB_WAVE) void k_mv_links(const MvSeg *__restrict__ segs,
                                                        const unsigned long long *__restrict__ piece_base,
                                                        uint64_t n_slots, const MvRec *__restrict__ heads,
                                                        const MvChain *__restrict__ chains,
                                                        MvLink *__restrict__ links) {
-    const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t piece = id / MV_CHAINS;
     if (piece >= piece_base[n_slots]) return;
-    const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
-    const MvSeg seg = segs[slot];
-    const uint64_t first_piece = piece_base[slot];
-    const uint32_t p = (uint32_t)(piece - first_piece);
-    MvReader reader;
-    reader.open(seg);
-    for (uint32_t c = 0; c < MV_CHAINS; c++) {
-        MvLink link;
-        link.target = MV_NONE;
-        link.from = {0, 0, 0, 0, 0, 0};
-        link.into = {0, 0, 0, 0, 0, 0};
-        const MvChain chain = chains[piece * MV_CHAINS + c];
-        if (chain.n_head > 0) {
-            MvRec at = chain.end;
-            const uint32_t tail_begin = at.pos;
-            uint32_t partner = 0xffffffffu, partner_last_pos = 0;
-            while (true) {
-                const uint32_t r = at.pos / MV_PIECE_BITS;
-                if (at.pos >= seg.total_bits || r >= seg.n_pieces) {
-                    link.target = MV_END;
-                    link.from = at;
-                    break;
-                }
-                if (r != partner) {
-                    // Only later pieces can be joined (a chain that ends in the padding of the last
-                    // piece still stands inside its own piece). Their recorded boundaries all lie near
-                    // the start of the piece: note where they end to stop looking early.
-                    partner = r;
-                    partner_last_pos = 0;
-                    if (r > p) {
-                        for (uint32_t k = 0; k < MV_CHAINS; k++) {
-                            const uint32_t n = chains[(first_piece + r) * MV_CHAINS + k].n_head;
-                            if (n == 0) break;
-                            const uint32_t last = heads[((first_piece + r) * MV_CHAINS + k) * MV_HEAD + n - 1].pos;
-                            partner_last_pos = max(partner_last_pos, last + 1);
-                        }
+    MvLink link;
+    link.target = MV_NONE;
+    link.into_head = 0;
+    link.into_count = 0;
+    link.from = mv_track_at(0u, 0u);
+    const uint32_t n_head = chains[id].n_head;
+    if (n_head > 0) {
+        const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
+        const MvSeg seg = segs[slot];
+        const uint64_t first_piece = piece_base[slot];
+        const uint32_t p = (uint32_t)(piece - first_piece);
+        MvReader reader;
+        reader.open(seg);
+        MvTrack at = chains[id].end;
+        const uint32_t tail_begin = at.pos;
+        uint32_t partner = 0xffffffffu, partner_last_pos = 0;
+        while (true) {
+            const uint32_t r = at.pos / MV_PIECE_BITS;
+            if (at.pos >= seg.total_bits || r >= seg.n_pieces) {
+                link.target = MV_END;
+                break;
+            }
+            if (r != partner) {
+                // Only later pieces can be joined (a chain that ends in the padding of the last piece
+                // still stands inside its own piece). Their recorded boundaries all lie near the start
+                // of the piece: note where they end to stop looking early.
+                partner = r;
+                partner_last_pos = 0;
+                if (r > p) {
+                    for (uint32_t k = 0; k < MV_CHAINS; k++) {
+                        const uint32_t n = chains[(first_piece + r) * MV_CHAINS + k].n_head;
+                        if (n == 0) break;
+                        const uint32_t last = heads[((first_piece + r) * MV_CHAINS + k) * MV_HEAD + n - 1].pos;
+                        partner_last_pos = max(partner_last_pos, last + 1);
                     }
                 }
+            }
+            if (at.pos < partner_last_pos) {
                 bool joined = false;
-                if (at.pos < partner_last_pos) {
-                    for (uint32_t k = 0; k < MV_CHAINS && !joined; k++) {
-                        const uint64_t id = (first_piece + r) * MV_CHAINS + k;
-                        const uint32_t n = chains[id].n_head;
-                        if (n == 0) break;
-                        for (uint32_t h = 0; h < n; h++) {
-                            const MvRec rec = heads[id * MV_HEAD + h];
-                            if (rec.pos == at.pos && mv_length(rec.state) == mv_length(at.state)) {
-                                link.target = (uint32_t)id;
-                                link.from = at;
-                                link.into = rec;
-                                joined = true;
-                                break;
-                            }
-                        }
+                for (uint32_t k = 0; k < MV_CHAINS && !joined; k++) {
+                    const uint64_t other = (first_piece + r) * MV_CHAINS + k;
+                    const uint32_t n = chains[other].n_head;
+                    if (n == 0) break;
+                    for (uint32_t h = 0; h < n; h++) {
+                        const MvRec rec = heads[other * MV_HEAD + h];
+                        if (rec.pos != at.pos || mv_length(rec.state) != mv_length(at.state)) continue;
+                        link.target = (uint32_t)other;
+                        link.into_head = h;
+                        link.into_count = rec.count;
+                        joined = true;
+                        break;
                     }
                 }
                 if (joined) break;
-                if (at.pos - tail_begin > MV_MAX_TAIL_BITS) break; // MV_NONE: the sequential decoder takes over
-                const int rc = mv_chain_step(reader, at);
-                if (rc == MV_MALFORMED) break;
-                if (rc == MV_OVERRUN) {
-                    link.target = MV_END;
-                    link.from = at;
-                    break;
-                }
+            }
+            if (at.pos - tail_begin > MV_MAX_TAIL_BITS) break; // MV_NONE: the sequential decoder takes over
+            const int rc = mv_track_step(reader, at, n_head);
+            if (rc == MV_MALFORMED) break;
+            if (rc == MV_OVERRUN) {
+                link.target = MV_END;
+                break;
             }
         }
-        links[piece * MV_CHAINS + c] = link;
+        link.from = at;
     }
+    links[id] = link;
 }
 
 // ---- k_mv_walk: one wave per entry of the serial list -------------------------------------------------------
@@ -525,15 +716,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_walk(MvSeg *__restrict__ segs,
     uint32_t q = 0;           // chain on the real parse, relative to first_chain (uniform)
     uint32_t first_index = 1; // value 0 is the raw first value
     uint32_t value_bits = reader.peek(0, 32);
-    // Where the real parse entered chain q, what that chain had accumulated there, the real window.
-    uint32_t pos = 32, state = MV_NO_WINDOW;
-    MvRec entered = {32u, MV_NO_WINDOW, 0u, 0u, 0u, 0u};
+    // Where the real parse entered chain q (position, real window, which recorded boundary of the
+    // chain that is, how many values the chain had decoded there).
+    uint32_t pos = 32, state = MV_NO_WINDOW, entered_head = 0, entered_count = 0;
     uint32_t window_first = 0;
     bool window_valid = false;
     MvLink window;
     window.target = MV_NONE;
-    window.from = {0, 0, 0, 0, 0, 0};
-    window.into = {0, 0, 0, 0, 0, 0};
+    window.into_head = window.into_count = 0;
+    window.from = mv_track_at(0u, 0u);
     while (ok) {
         if (!window_valid || q - window_first >= MDB_WAVE) {
             window_first = q;
@@ -542,25 +733,29 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_walk(MvSeg *__restrict__ segs,
         }
         const int source = (int)(q - window_first);
         const uint32_t target = __shfl(window.target, source, MDB_WAVE);
-        MvRec from, into;
-        from.pos = __shfl(window.from.pos, source, MDB_WAVE);
-        from.state = __shfl(window.from.state, source, MDB_WAVE);
-        from.count = __shfl(window.from.count, source, MDB_WAVE);
-        from.n11 = __shfl(window.from.n11, source, MDB_WAVE);
-        from.raw_x = __shfl(window.from.raw_x, source, MDB_WAVE);
-        from.x = __shfl(window.from.x, source, MDB_WAVE);
-        into.pos = __shfl(window.into.pos, source, MDB_WAVE);
-        into.state = __shfl(window.into.state, source, MDB_WAVE);
-        into.count = __shfl(window.into.count, source, MDB_WAVE);
-        into.n11 = __shfl(window.into.n11, source, MDB_WAVE);
-        into.raw_x = __shfl(window.into.raw_x, source, MDB_WAVE);
-        into.x = __shfl(window.into.x, source, MDB_WAVE);
+        const uint32_t into_head = __shfl(window.into_head, source, MDB_WAVE);
+        const uint32_t into_count = __shfl(window.into_count, source, MDB_WAVE);
+        const uint32_t from_pos = __shfl(window.from.pos, source, MDB_WAVE);
+        const uint32_t from_state = __shfl(window.from.state, source, MDB_WAVE);
+        const uint32_t from_count = __shfl(window.from.count, source, MDB_WAVE);
+        const uint32_t from_x = __shfl(window.from.x, source, MDB_WAVE);
+        const uint32_t from_seen = __shfl(window.from.seen, source, MDB_WAVE);
+        uint32_t from_raw = 0, from_snap = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < MV_HEAD; h++) {
+            const uint32_t raw_h = __shfl(window.from.raw[h], source, MDB_WAVE);
+            const uint32_t snap_h = __shfl(window.from.snap[h], source, MDB_WAVE);
+            if (h == entered_head) {
+                from_raw = raw_h;
+                from_snap = snap_h;
+            }
+        }
         if (target == MV_NONE) {
             ok = false;
             break;
         }
         const uint32_t left = seg.n_model - first_index;
-        uint32_t n_values = target == MV_END ? left : from.count - entered.count;
+        uint32_t n_values = target == MV_END ? left : from_count - entered_count;
         const bool last = target == MV_END || n_values >= left;
         if (n_values > left) n_values = left;
         if (lane == 0) starts[first_piece + q / MV_CHAINS] = {1u, pos, state, first_index, value_bits, n_values};
@@ -570,39 +765,31 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_walk(MvSeg *__restrict__ segs,
             ok = false;
             break;
         }
-        // The XOR of the values this chain decoded between the two boundaries. Until the first `11`
-        // after the real parse entered it the chain shifts with a window it did not get from the real
-        // parse: none at all (a guessed n: it kept the raw bits), or one from a `11` it read before
-        // it fell in step - same n, but possibly other leading zeros; then its bits are shifted back
-        // and forth, which is only possible if no `11` follows in this stretch.
-        uint32_t delta;
-        if (entered.n11 == 0) {
-            const uint32_t raw = from.raw_x ^ entered.raw_x;
-            if (raw != 0 && state == MV_NO_WINDOW) { // cannot happen: `0` codes need a window
+        // The XOR of the values decoded between the two boundaries (see MvTrack): the `0` codes up
+        // to the first `11` code carry bits that the REAL window at the entry shifts; from that `11`
+        // on the chain's own shifts were real.
+        const bool seen = (from_seen >> entered_head) & 1u;
+        uint32_t delta = 0;
+        if (from_raw != 0) {
+            if (state == MV_NO_WINDOW) { // cannot happen: `0` codes need a window
                 ok = false;
                 break;
             }
-            delta = (raw != 0 ? mv_shifted(raw, state) : 0u) ^ from.x ^ entered.x;
-        } else if ((entered.state & 0xffu) == (state & 0xffu)) {
-            delta = from.x ^ entered.x;
-        } else if (from.n11 == entered.n11) {
-            const uint32_t own_trailing = (32u - (entered.state >> 8) - (entered.state & 0xffu)) & 31u;
-            delta = mv_shifted((from.x ^ entered.x) >> own_trailing, state);
-        } else {
-            ok = false; // rare: leave the stream to the sequential decoder
+            delta = mv_shifted(from_raw, state);
+        }
+        if (seen) {
+            delta ^= from_x ^ from_snap;
+            state = from_state; // set by a `11` code the real parse has read too
+        }
+        if (mv_length(state) != mv_length(from_state)) { // cannot happen: same positions, same n
+            ok = false;
             break;
         }
         value_bits ^= delta;
         first_index += n_values;
-        // The real window at the shared boundary: the chain's own if it has seen a `11` since the
-        // real parse entered it, otherwise still the one it was entered with.
-        if (from.n11 > entered.n11) state = from.state;
-        if (mv_length(state) != mv_length(into.state)) { // cannot happen: links compare n
-            ok = false;
-            break;
-        }
-        pos = from.pos;
-        entered = into;
+        pos = from_pos;
+        entered_head = into_head;
+        entered_count = into_count;
         q = next;
     }
     if (lane == 0) segs[slot].done = ok ? 1u : 0u;
@@ -615,6 +802,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_decode(const MvSeg *__restrict_
                                                         uint64_t n_slots, const MvStart *__restrict__ starts,
                                                         float *__restrict__ out_val,
                                                         unsigned int *__restrict__ error) {
+    __shared__ uint32_t stage_lds[MV_STAGE_WORDS][MDB_WAVE];
     const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (piece >= piece_base[n_slots]) return;
     const MvStart start = starts[piece];
@@ -624,6 +812,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_decode(const MvSeg *__restrict_
     if (!seg.done) return; // the sequential decoder handles this stream
     MvReader reader;
     reader.open(seg);
+    reader.stage(&stage_lds[0][threadIdx.x], start.pos);
     float *__restrict__ out = out_val + seg.out_offset;
     uint32_t value = start.value_bits;
     if (piece == piece_base[slot] && seg.first == 0) out[0] = __uint_as_float(value); // the raw first value

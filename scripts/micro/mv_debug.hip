@@ -1,6 +1,7 @@
 // Runs the parallel MacaqueV decoder's kernels on ONE stream read from a file and prints what every
 // stage produced (development tool for mdb_macaque_parallel.hpp).
 // usage: mv_debug stream.bin n_values
+#define MDB_MV_DEBUG 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +35,7 @@ int main(int argc, char **argv) {
     seg.visible_end = n_values;
     seg.n_pieces = (seg.total_bits + MV_PIECE_BITS - 1) / MV_PIECE_BITS;
     const uint32_t P = seg.n_pieces;
-    MvSeg *segs; unsigned long long *piece_base; MvRec *heads; MvChain *chains; MvLink *links; MvStart *starts; uint32_t *guesses; uint32_t *tried;
+    MvSeg *segs; unsigned long long *piece_base; MvRec *heads; MvChain *chains; MvLink *links; MvStart *starts; uint32_t *guesses; uint32_t *tried; uint32_t *pending;
     float *out; unsigned int *error;
     CHECK(hipMalloc(&segs, sizeof seg)); CHECK(hipMemcpy(segs, &seg, sizeof seg, hipMemcpyHostToDevice));
     unsigned long long base_host[2] = {0, P};
@@ -45,14 +46,25 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&starts, (size_t)P * sizeof(MvStart))); CHECK(hipMemset(starts, 0, (size_t)P * sizeof(MvStart)));
     CHECK(hipMalloc(&guesses, (size_t)P * 4));
     CHECK(hipMalloc(&tried, (size_t)P * 4));
+    CHECK(hipMalloc(&pending, 256)); CHECK(hipMemset(pending, 0, 256));
     CHECK(hipMalloc(&out, (size_t)n_values * 4)); CHECK(hipMemset(out, 0xff, (size_t)n_values * 4));
     CHECK(hipMalloc(&error, 4)); CHECK(hipMemset(error, 0, 4));
     const uint32_t blocks = (P + 63) / 64;
     std::vector<MvChain> host_chains((size_t)P * MV_CHAINS);
-    for (int round = 0; round <= MV_ROUNDS; round++) {
-        if (round > 0) hipLaunchKernelGGL(k_mv_guess, dim3(1), dim3(64), 0, 0, segs, piece_base, chains, guesses);
-        hipLaunchKernelGGL(k_mv_chains, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, round, guesses, tried, heads, chains);
+    for (int round = 0; round < MV_ROUNDS; round++) {
+        if (mv_round_kind(round) == MV_ROUND_GUESS) hipLaunchKernelGGL(k_mv_guess, dim3(1), dim3(64), 0, 0, segs, piece_base, chains, guesses);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         CHECK(hipDeviceSynchronize());
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_mv_chains, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, round, guesses, tried, pending, heads, chains);
+        hipEventRecord(e1);
+        CHECK(hipDeviceSynchronize());
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long counters[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+        CHECK(hipMemcpyFromSymbol(counters, HIP_SYMBOL(mv_debug_counters), sizeof counters));
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mv_debug_counters), zero, sizeof zero));
+        printf("k_mv_chains round %d: %.3f ms (%u waves); iterations %llu (codes %llu), busiest lane %llu iterations, slowest lane %.3f ms\n",
+               round, ms, blocks, counters[0], counters[1], counters[2], counters[3] / 1e5);
         CHECK(hipMemcpy(host_chains.data(), chains, host_chains.size() * sizeof(MvChain), hipMemcpyDeviceToHost));
         uint32_t with = 0, total = 0;
         for (uint32_t q = 0; q < P; q++) {
@@ -61,7 +73,7 @@ int main(int argc, char **argv) {
         }
         printf("round %d: %u of %u pieces have a chain, %u chains\n", round, with, P, total);
     }
-    hipLaunchKernelGGL(k_mv_links, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, heads, chains, links);
+    hipLaunchKernelGGL(k_mv_links, dim3((P * MV_CHAINS + 63) / 64), dim3(64), 0, 0, segs, piece_base, 1ull, heads, chains, links);
     hipLaunchKernelGGL(k_mv_walk, dim3(1), dim3(64), 0, 0, segs, piece_base, chains, links, starts);
     hipLaunchKernelGGL(k_mv_decode, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, starts, out, error);
     CHECK(hipDeviceSynchronize());
@@ -77,7 +89,7 @@ int main(int argc, char **argv) {
     unsigned int host_error = 0;
     CHECK(hipMemcpy(&host_error, error, 4, hipMemcpyDeviceToHost));
     printf("done=%u error=%u pieces=%u bits=%u\n", seg.done, host_error, P, seg.total_bits);
-    for (uint32_t p = 0; p < P && p < 8; p++) {
+    for (uint32_t p = (argc >= 5 ? (uint32_t)atoi(argv[4]) : 0); p < P && p < (argc >= 5 ? (uint32_t)atoi(argv[4]) + 10 : 8); p++) {
         const MvStart &st = host_starts[p];
         printf("piece %u: guess %x | start valid %u pos %u state %x index %u n %u\n", p, host_guesses[p], st.valid, st.pos,
                st.state, st.first_index, st.n_values);
@@ -86,9 +98,9 @@ int main(int argc, char **argv) {
             const MvChain &ch = host_chains[id];
             if (ch.n_head == 0) break;
             const MvLink &l = host_links[id];
-            printf("   chain %d: head0 (pos %u state %x count %u) end (pos %u state %x count %u n11 %u) link target %x (piece %u) pos %u\n",
+            printf("   chain %d: head0 (pos %u state %x count %u) end (pos %u state %x count %u seen %x) link target %x (piece %u) pos %u\n",
                    c, host_heads[id * MV_HEAD].pos, host_heads[id * MV_HEAD].state, host_heads[id * MV_HEAD].count, ch.end.pos,
-                   ch.end.state, ch.end.count, ch.end.n11, l.target, l.target < 0xfffffff0u ? l.target / MV_CHAINS : 0u, l.from.pos);
+                   ch.end.state, ch.end.count, ch.end.seen, l.target, l.target < 0xfffffff0u ? l.target / MV_CHAINS : 0u, l.from.pos);
         }
     }
     {   // replay the walk on the host to see where it ends
