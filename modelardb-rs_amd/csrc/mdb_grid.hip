@@ -704,8 +704,9 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
                                piece_base, chains, guesses);
         }
         LaunchTimer timer(ctx, round == 0 ? "k_mv_chains_start" : (round == 1 ? "k_mv_chains_first" : "k_mv_chains_more"));
-        hipLaunchKernelGGL(k_mv_chains, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
-                           n_serial, round, guesses, tried, pending, heads, chains);
+        hipLaunchKernelGGL(k_mv_chains, dim3((uint32_t)((max_pieces * MV_CHAINS + MDB_WAVE - 1) / MDB_WAVE)),
+                           dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base, n_serial, round, guesses, tried,
+                           pending, heads, chains);
     }
     {
         LaunchTimer timer(ctx, "k_mv_links");

@@ -13,16 +13,18 @@
 // matter for the values (how far the n bits are shifted), not for the positions, and a `11` code
 // sets both from the stream itself.
 //
-//  * k_mv_chains: one lane per piece looks for places in its piece from which the stream parses
-//    cleanly to the end of the piece: speculative "chains". Candidates are `11` patterns near the
-//    start of the piece (they need nothing from the past) and, since real streams settle on one
-//    window and then consist of `0` and `10` codes only, the first 45 bits of the piece (the longest
-//    code) combined with a guess for n: the n at the end of the nearest earlier piece that has
-//    chains (k_mv_guess), refined over MV_ROUNDS rounds. Wrong candidates die within a few codes,
-//    with one exception: a parse that is a few bits late keeps reading the (almost always zero) top
-//    bits of the window as control bits; such late copies are recognised by their distance to a
-//    kept chain on the grid of code boundaries. Per chain a few boundaries are recorded where the
-//    real parse may join it, and per such boundary what only the real parse can interpret (MvTrack).
+//  * k_mv_chains: the lanes of a piece look for places in it from which the stream parses cleanly to
+//    the end of the piece: speculative "chains". Round 0 starts piece 0 at the real beginning. Then,
+//    since real streams settle on one window and consist of `0` and `10` codes only from there on,
+//    the candidates are the first 45 bits of the piece (the longest code) combined with a guess for
+//    n: the n at the end of the nearest earlier piece that has chains (k_mv_guess). Pieces that are
+//    still without a chain try the `11` patterns near their start (those need nothing from the
+//    past), and further rounds of guesses carry the windows found so far past one more change of n
+//    each, until no piece is without a chain. Wrong candidates die within a few codes, with one
+//    exception: a parse that is a few bits late keeps reading the (almost always zero) top bits of
+//    the window as control bits; such late copies are recognised by their distance to another
+//    chain on the grid of code boundaries. Per chain a few boundaries are recorded where the real
+//    parse may join it, and per such boundary what only the real parse can interpret (MvTrack).
 //  * k_mv_links: every chain is parsed on from the end of its piece until it stands on a boundary
 //    that a chain of a later piece recorded with the same n: from there on the two parses visit
 //    the same positions. The link notes that target and both chains' accumulators at the boundary.
@@ -110,7 +112,7 @@ struct MvTrack {
     uint32_t snap[MV_HEAD];
 };
 
-struct MvChain { // chains[piece * MV_CHAINS + c], used ones first
+struct MvChain { // chains[piece * MV_CHAINS + c]
     uint32_t n_head; // recorded boundaries, 0: unused
     MvTrack end;     // the chain at its first boundary at or beyond the end of its piece
 };
@@ -353,13 +355,22 @@ __global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange rang
 __device__ unsigned long long mv_debug_counters[4]; // iterations, steps, max iterations of a lane, max ticks of a lane
 #endif
 
-// ---- k_mv_chains: one lane per piece ---------------------------------------------------------------------
+// ---- k_mv_chains: MV_CHAINS lanes per piece -----------------------------------------------------------------
 //
 // guesses[piece]: up to two candidate n (one per byte, MV_NO_LENGTH = none); tried[piece]: the n this
-// piece has already been searched with (one per byte).
+// piece has already been searched with (one per byte, low three bytes) and, in the top byte, 0x01
+// once a chain found with a guessed n is kept; pending[r]: pieces without any chain after round r.
+//
+// Several chains can survive a piece: in a stream of `0` codes of one length a parse that is a few
+// bits late keeps reading the (almost always zero) top bits of the window as control bits and never
+// notices, and parses that start early can hop onto such a late grid through a `10` code. They
+// cannot be told apart for certain locally, so each of the MV_CHAINS lanes of a piece tries every
+// MV_CHAINS-th entry point and keeps the first chain that survives; the real parse is usually among
+// them, and k_mv_links / k_mv_walk find out which. A lane tries its candidates as ONE loop in which
+// it either picks the next candidate or advances the current one by a code.
 
 __device__ __forceinline__ bool mv_byte_listed(uint32_t list, uint32_t value) {
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 3; k++)
         if (((list >> (8 * k)) & 0xffu) == value) return true;
     return false;
 }
@@ -371,83 +382,67 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
                                                         uint32_t *__restrict__ tried, uint32_t *__restrict__ pending,
                                                         MvRec *__restrict__ heads, MvChain *__restrict__ chains) {
     __shared__ uint32_t stage_lds[MV_STAGE_WORDS][MDB_WAVE];
-    const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (piece >= piece_base[n_slots]) return;
-    // pending[r]: pieces that were still without a chain after round r. None left: nothing to do.
-    if (round > 1 && pending[round - 1] == 0) return;
+    const uint64_t lane_id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t piece = lane_id / MV_CHAINS;
+    const uint32_t sub = (uint32_t)(lane_id % MV_CHAINS);
     const int kind = mv_round_kind(round);
-    MvChain *__restrict__ mine = chains + piece * MV_CHAINS;
-    const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
-    const MvSeg seg = segs[slot];
-    const uint32_t p = (uint32_t)(piece - piece_base[slot]);
+    // No lane leaves before the ballot at the end; `present` lanes have a piece.
+    const bool present = piece < piece_base[n_slots] && !(round > 1 && pending[round - 1] == 0);
+    MvChain *__restrict__ mine = chains + piece * MV_CHAINS; // the piece's chains; this lane owns [sub]
+    MvRec *__restrict__ head = heads + (piece * MV_CHAINS + sub) * MV_HEAD;
+    bool work = false, slot_used = false, piece_has_chain = false;
+    uint32_t p = 0, piece_begin = 0, piece_end = 0;
+    MvSeg seg;
+    seg.total_bits = 0;
     MvReader reader;
-    reader.open(seg);
-    const uint32_t piece_begin = p * MV_PIECE_BITS;
-    const uint32_t piece_end = min(piece_begin + MV_PIECE_BITS, seg.total_bits);
-    uint32_t n_chains = 0;
-    if (kind == MV_ROUND_START) {
-        tried[piece] = 0xffffffffu;
-        for (uint32_t c = 0; c < MV_CHAINS; c++) mine[c].n_head = 0;
-        if (p > 0) {
-            atomicAdd(&pending[round], 1u);
-            return;
-        }
-    } else {
-        while (n_chains < MV_CHAINS && mine[n_chains].n_head > 0) n_chains++;
-        bool work = p > 0;
-        if (kind == MV_ROUND_SCAN) {
-            work = work && n_chains == 0;
+    uint32_t tried_here = 0xffffffffu;
+    if (present) {
+        const uint32_t slot = mv_slot_of(piece_base, n_slots, piece);
+        seg = segs[slot];
+        p = (uint32_t)(piece - piece_base[slot]);
+        reader.open(seg);
+        piece_begin = p * MV_PIECE_BITS;
+        piece_end = min(piece_begin + MV_PIECE_BITS, seg.total_bits);
+        if (kind == MV_ROUND_START) {
+            mine[sub].n_head = 0;
+            if (sub == 0) tried[piece] = 0xffffffffu;
+            work = p == 0 && sub == 0 && seg.total_bits >= 32;
         } else {
-            // A guess this piece has not been searched with yet; after the first round of guesses only
-            // pieces without a chain from a guess keep searching.
-            bool untried = false;
-            for (int g = 0; g < 2; g++) {
-                const uint32_t candidate = (guesses[piece] >> (8 * g)) & 0xffu;
-                untried = untried || (candidate <= 32u && !mv_byte_listed(tried[piece] & 0x00ffffffu, candidate));
+            for (uint32_t c = 0; c < MV_CHAINS; c++) piece_has_chain = piece_has_chain || mine[c].n_head > 0;
+            slot_used = mine[sub].n_head > 0;
+            tried_here = tried[piece];
+            if (kind == MV_ROUND_SCAN) {
+                work = p > 0 && !piece_has_chain;
+            } else {
+                // A guess this piece has not been searched with yet; once a chain found with a guessed
+                // window is kept the piece stops searching.
+                bool untried = false;
+                for (int g = 0; g < 2; g++) {
+                    const uint32_t candidate = (guesses[piece] >> (8 * g)) & 0xffu;
+                    untried = untried || (candidate <= 32u && !mv_byte_listed(tried_here, candidate));
+                }
+                work = p > 0 && untried && (tried_here >> 24) != 0x01u;
             }
-            const bool has_guessed_chain = (tried[piece] >> 24) == 0x01u;
-            work = work && untried && n_chains < MV_CHAINS && !has_guessed_chain;
-        }
-        if (!work) {
-            if (n_chains == 0) atomicAdd(&pending[round], 1u);
-            return;
         }
     }
-    reader.stage(&stage_lds[0][threadIdx.x], piece_begin);
+    // Every lane of a piece walks over the same bits: each keeps its own copy (a column of the array).
+    if (work) reader.stage(&stage_lds[0][threadIdx.x], piece_begin);
 
-    // The candidates are tried one after the other, but as ONE loop in which every lane either picks
-    // its next candidate or advances its current one by a code: most candidates die within a few
-    // codes while a survivor runs through the whole piece, and lanes waiting for each other's
-    // candidates would cost the wave (candidates x longest chain) iterations instead of their sum.
-    //
-    // A candidate is followed to the first boundary at or beyond the end of the piece and kept
-    // unless it is malformed - or, for a guessed n, turns out to run on the grid of a kept chain or
-    // 1..MV_SHIFT_BITS bits behind it: while n stays the same, boundaries are a whole number of `0`
-    // codes apart (give or take `10` codes), so a chain on the same grid IS that chain from here on,
-    // and one slightly behind is a late copy living on the zero top bits of the window. A guessed
-    // chain may only fall in step with the real parse after a few codes, so its boundaries are
-    // recorded once it has settled.
-    int guess_index = -1;               // which guess is being searched (guess rounds)
-    uint32_t length = MV_NO_LENGTH;     // its n, MV_NO_LENGTH: candidates are `11` patterns / the real start
-    uint32_t o = 0, o_end = 0;          // next and last+1 entry point to try
-    uint32_t first_new = n_chains;      // chains [first_new, n_chains) were found with this guess
-    uint32_t tried_here = kind == MV_ROUND_START ? 0xffffffffu : tried[piece];
-    uint32_t chain_limit = MV_CHAINS;
-    bool searching = true, running = false, found_with_guess = false;
+    int guess_index = -1;           // which guess is being searched (guess rounds)
+    uint32_t length = MV_NO_LENGTH; // its n, MV_NO_LENGTH: candidates are `11` patterns / the real start
+    uint32_t o = 0, o_end = 0;      // next and last+1 entry point of this lane
+    bool searching = work, running = false, found_with_guess = false;
     MvTrack at = mv_track_at(0u, 0u);
     uint32_t steps = 0, n_head = 0;
-    if (kind == MV_ROUND_START) {
+    if (work && kind == MV_ROUND_START) {
         // The real start: 32 raw bits of the first value, then codes, no window yet.
-        if (seg.total_bits >= 32) {
-            at = mv_track_at(32u, MV_NO_WINDOW);
-            heads[(piece * MV_CHAINS) * MV_HEAD] = {32u, MV_NO_WINDOW, 0u};
-            n_head = 1;
-            running = true;
-        }
-    } else if (kind == MV_ROUND_SCAN) {
-        o = piece_begin;
+        at = mv_track_at(32u, MV_NO_WINDOW);
+        head[0] = {32u, MV_NO_WINDOW, 0u};
+        n_head = 1;
+        running = true;
+    } else if (work && kind == MV_ROUND_SCAN) {
+        o = piece_begin + sub;
         o_end = min(piece_begin + MV_SCAN_BITS, piece_end);
-        chain_limit = 2; // survivors of a scan are rarely real; leave room for guessed chains
     }
 #ifdef MDB_MV_DEBUG
     unsigned long long debug_iterations = 0, debug_steps = 0;
@@ -459,50 +454,27 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
         debug_steps += running ? 1 : 0;
 #endif
         if (!running) {
-            if (o >= o_end || n_chains >= chain_limit) {
-                if (length != MV_NO_LENGTH) {
-                    // A chain that was found first can itself be the late copy of one found after it.
-                    const uint32_t code_bits = 1u + length;
-                    uint32_t kept = first_new;
-                    for (uint32_t c = first_new; c < n_chains; c++) {
-                        bool late_copy = false;
-                        for (uint32_t b2 = 0; b2 < n_chains && !late_copy; b2++) {
-                            if (b2 == c || mv_length(mine[b2].end.state) != length ||
-                                mv_length(mine[c].end.state) != length)
-                                continue;
-                            const uint32_t lag = (mine[c].end.pos + code_bits * 256u - mine[b2].end.pos) % code_bits;
-                            late_copy = lag >= 1 && lag <= MV_SHIFT_BITS;
-                        }
-                        if (late_copy) continue;
-                        if (kept != c) {
-                            for (uint32_t h = 0; h < mine[c].n_head; h++)
-                                heads[(piece * MV_CHAINS + kept) * MV_HEAD + h] = heads[(piece * MV_CHAINS + c) * MV_HEAD + h];
-                            mine[kept] = mine[c];
-                        }
-                        kept += 1;
-                    }
-                    n_chains = kept;
-                }
+            if (slot_used) {
+                searching = false; // this lane's slot is taken: one chain per lane
+            } else if (o >= o_end) {
                 // The next guess, if any.
                 length = MV_NO_LENGTH;
                 while (kind == MV_ROUND_GUESS && ++guess_index < 2) {
                     const uint32_t candidate = (guesses[piece] >> (8 * guess_index)) & 0xffu;
-                    if (candidate > 32u || mv_byte_listed(tried_here & 0x00ffffffu, candidate)) continue;
+                    if (candidate > 32u || mv_byte_listed(tried_here, candidate)) continue;
                     length = candidate;
                     break;
                 }
-                if (length == MV_NO_LENGTH || n_chains >= MV_CHAINS) {
+                if (length == MV_NO_LENGTH) {
                     searching = false;
                 } else {
                     tried_here = (tried_here & 0xff000000u) | ((tried_here << 8) & 0x00ffff00u) | length;
                     // The real parse enters the piece within its first 45 bits. The leading zeros of
                     // the guessed window are unknown (and not needed: see MvTrack).
-                    o = piece_begin;
+                    o = piece_begin + sub;
                     o_end = min(piece_begin + MV_MAX_CODE_BITS, piece_end);
-                    first_new = n_chains;
-                    chain_limit = MV_CHAINS;
                 }
-            } else if (length == MV_NO_LENGTH) { // round 0: is there a plausible `11` code at o?
+            } else if (length == MV_NO_LENGTH) { // a scan: is there a plausible `11` code at o?
                 if (o + 13 <= seg.total_bits) {
                     const uint32_t top = reader.peek(o, 13);
                     if ((top >> 11) == 3u && mv_valid_window((top >> 6) & 31u, top & 63u)) {
@@ -512,16 +484,18 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
                         running = true;
                     }
                 }
-                o += 1;
+                o += MV_CHAINS;
             } else {
                 at = mv_track_at(o, length << 8);
                 steps = 0;
                 n_head = 0;
                 running = true;
-                o += 1;
+                o += MV_CHAINS;
             }
         } else {
-            MvRec *__restrict__ head = heads + (piece * MV_CHAINS + n_chains) * MV_HEAD;
+            // A candidate is followed to the first boundary at or beyond the end of the piece and kept
+            // unless it is malformed. A guessed chain may only fall in step with the real parse after
+            // a few codes, so its boundaries are recorded once it has settled.
             bool finished = at.pos >= piece_end;
             if (!finished) {
                 const int rc = mv_track_step(reader, at, n_head);
@@ -534,23 +508,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
                     const bool guessed = length != MV_NO_LENGTH;
                     if ((!guessed || steps >= MV_SETTLE_CODES) && n_head < MV_HEAD)
                         head[n_head++] = {at.pos, at.state, at.count};
-                    if (guessed && steps == MV_SETTLE_CODES && mv_length(at.state) == length) {
-                        const uint32_t code_bits = 1u + length;
-                        for (uint32_t c = 0; c < n_chains; c++) {
-                            if (mv_length(mine[c].end.state) != length) continue;
-                            const uint32_t lag = (at.pos + code_bits * 256u - mine[c].end.pos) % code_bits;
-                            if (lag <= MV_SHIFT_BITS) running = false;
-                        }
-                    }
-                    finished = running && at.pos >= piece_end;
+                    finished = at.pos >= piece_end;
                 }
             }
             if (finished) {
                 if (n_head > 0) {
-                    mine[n_chains].n_head = n_head;
-                    mine[n_chains].end = at;
-                    n_chains += 1;
-                    found_with_guess = found_with_guess || length != MV_NO_LENGTH;
+                    mine[sub].n_head = n_head;
+                    mine[sub].end = at;
+                    slot_used = true;
+                    found_with_guess = length != MV_NO_LENGTH;
                 }
                 running = false;
             }
@@ -562,13 +528,40 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
     atomicMax(&mv_debug_counters[2], debug_iterations);
     atomicMax(&mv_debug_counters[3], wall_clock64() - debug_t0);
 #endif
-    if (kind == MV_ROUND_GUESS) {
-        // Top byte 0x01: a chain found with a guessed window is kept.
-        const bool guessed_kept = (tried_here >> 24) == 0x01u || found_with_guess;
-        tried[piece] = (tried_here & 0x00ffffffu) | (guessed_kept ? 0x01000000u : 0xff000000u);
+    // Bookkeeping per piece: its MV_CHAINS lanes sit next to each other in the wave.
+    const uint64_t group = 0xfull << (4u * (threadIdx.x / MV_CHAINS));
+    static_assert(MV_CHAINS == 4, "the group mask above assumes four lanes per piece");
+    // A chain that ends 1..MV_SHIFT_BITS bits behind another chain of the piece on the same grid
+    // (same n, a whole number of `0` codes apart) is a late copy of it: it lives on the zero top bits
+    // of the window, never meets the real parse and would only cost k_mv_links a long walk.
+    {
+        const bool kept_now = present && work && slot_used && n_head > 0 && found_with_guess;
+        const uint32_t my_pos = at.pos, my_state = at.state;
+        bool late_copy = false;
+        for (int other = 0; other < MV_CHAINS; other++) {
+            const int source = (int)(threadIdx.x / MV_CHAINS) * MV_CHAINS + other;
+            const uint32_t their_pos = __shfl(my_pos, source, MDB_WAVE);
+            const uint32_t their_state = __shfl(my_state, source, MDB_WAVE);
+            const bool their_kept = __shfl((int)kept_now, source, MDB_WAVE) != 0;
+            if (!kept_now || !their_kept || other == (int)sub) continue;
+            if (mv_length(their_state) != mv_length(my_state) || mv_length(my_state) > 32u) continue;
+            const uint32_t code_bits = 1u + mv_length(my_state);
+            const uint32_t lag = (my_pos + code_bits * 256u - their_pos) % code_bits;
+            late_copy = late_copy || (lag >= 1 && lag <= MV_SHIFT_BITS);
+        }
+        if (late_copy) {
+            mine[sub].n_head = 0;
+            slot_used = false;
+            found_with_guess = false;
+        }
     }
-    if (n_chains == 0) atomicAdd(&pending[round], 1u);
-    for (uint32_t c = n_chains; c < MV_CHAINS; c++) mine[c].n_head = 0;
+    const bool any_chain = (__ballot(present && slot_used) & group) != 0;
+    const bool any_guessed = (__ballot(found_with_guess) & group) != 0;
+    if (present && sub == 0) {
+        if (work && kind == MV_ROUND_GUESS)
+            tried[piece] = (tried_here & 0x00ffffffu) | (any_guessed || (tried_here >> 24) == 0x01u ? 0x01000000u : 0xff000000u);
+        if (!any_chain) atomicAdd(&pending[round], 1u);
+    }
 }
 
 // ---- k_mv_guess: one wave per entry of the serial list ----------------------------------------------------
@@ -590,7 +583,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_guess(const MvSeg *__restrict__
         uint32_t seen = MV_NONE;
         if (q < n_pieces) {
             const MvChain *__restrict__ theirs = chains + (first_piece + q) * MV_CHAINS;
-            if (theirs[0].n_head > 0) {
+            bool has_chain = false;
+            for (int c = 0; c < MV_CHAINS; c++) has_chain = has_chain || theirs[c].n_head > 0;
+            if (has_chain) {
                 // The chains found last first: those come from guessed windows, which are right more
                 // often than the survivors of a scan for `11` patterns.
                 uint32_t a = MV_NO_LENGTH, b = MV_NO_LENGTH;
@@ -659,7 +654,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_links(const MvSeg *__restrict__
                 if (r > p) {
                     for (uint32_t k = 0; k < MV_CHAINS; k++) {
                         const uint32_t n = chains[(first_piece + r) * MV_CHAINS + k].n_head;
-                        if (n == 0) break;
+                        if (n == 0) continue;
                         const uint32_t last = heads[((first_piece + r) * MV_CHAINS + k) * MV_HEAD + n - 1].pos;
                         partner_last_pos = max(partner_last_pos, last + 1);
                     }
@@ -670,7 +665,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_links(const MvSeg *__restrict__
                 for (uint32_t k = 0; k < MV_CHAINS && !joined; k++) {
                     const uint64_t other = (first_piece + r) * MV_CHAINS + k;
                     const uint32_t n = chains[other].n_head;
-                    if (n == 0) break;
+                    if (n == 0) continue;
                     for (uint32_t h = 0; h < n; h++) {
                         const MvRec rec = heads[other * MV_HEAD + h];
                         if (rec.pos != at.pos || mv_length(rec.state) != mv_length(at.state)) continue;

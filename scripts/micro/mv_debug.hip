@@ -56,7 +56,7 @@ int main(int argc, char **argv) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         CHECK(hipDeviceSynchronize());
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mv_chains, dim3(blocks), dim3(64), 0, 0, segs, piece_base, 1ull, round, guesses, tried, pending, heads, chains);
+        hipLaunchKernelGGL(k_mv_chains, dim3((P * MV_CHAINS + 63) / 64), dim3(64), 0, 0, segs, piece_base, 1ull, round, guesses, tried, pending, heads, chains);
         hipEventRecord(e1);
         CHECK(hipDeviceSynchronize());
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -68,8 +68,9 @@ int main(int argc, char **argv) {
         CHECK(hipMemcpy(host_chains.data(), chains, host_chains.size() * sizeof(MvChain), hipMemcpyDeviceToHost));
         uint32_t with = 0, total = 0;
         for (uint32_t q = 0; q < P; q++) {
-            with += host_chains[(size_t)q * MV_CHAINS].n_head > 0;
-            for (int c = 0; c < MV_CHAINS; c++) total += host_chains[(size_t)q * MV_CHAINS + c].n_head > 0;
+            bool any = false;
+            for (int c = 0; c < MV_CHAINS; c++) { any = any || host_chains[(size_t)q * MV_CHAINS + c].n_head > 0; total += host_chains[(size_t)q * MV_CHAINS + c].n_head > 0; }
+            with += any;
         }
         printf("round %d: %u of %u pieces have a chain, %u chains\n", round, with, P, total);
     }
@@ -96,7 +97,7 @@ int main(int argc, char **argv) {
         for (int c = 0; c < MV_CHAINS; c++) {
             const size_t id = (size_t)p * MV_CHAINS + c;
             const MvChain &ch = host_chains[id];
-            if (ch.n_head == 0) break;
+            if (ch.n_head == 0) continue;
             const MvLink &l = host_links[id];
             printf("   chain %d: head0 (pos %u state %x count %u) end (pos %u state %x count %u seen %x) link target %x (piece %u) pos %u\n",
                    c, host_heads[id * MV_HEAD].pos, host_heads[id * MV_HEAD].state, host_heads[id * MV_HEAD].count, ch.end.pos,

@@ -179,6 +179,16 @@ def test_config1_one_series_one_million_points_lossless(hip):
     assert np.array_equal(ts, timestamps)
     assert np.array_equal(reconstructed.view(np.uint32), values.view(np.uint32))  # lossless
     assert metrics["rows_created_by_macaque_v"] == n
+    # 16 streams of 65 536 values: the parallel MacaqueV decoder takes them unless it is switched off
+    # (k_mv_decode ran and decoded them: the one-lane decoder then has nothing left and the values
+    # above came from it).
+    hip.profile_enable(True)
+    hip.profile_reset()
+    again = hip.grid_batch(segments)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert np.array_equal(again[1].view(np.uint32), values.view(np.uint32))
+    assert "k_mv_decode" in kernels and "k_mv_walk" in kernels
     mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
     state, reference = hip.agg_batch(segments, mask), ora.agg_batch(segments, mask)
     assert (state.count, state.min, state.max) == (n, values.min(), values.max())
