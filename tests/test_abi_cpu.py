@@ -40,6 +40,7 @@ def test_struct_layouts():
     assert ctypes.sizeof(_abi.GridMetricsC) == 10 * 8
     assert ctypes.sizeof(_abi.AggStateC) == 24
     assert ctypes.sizeof(_abi.SegmentsOwnedC) == ctypes.sizeof(_abi.SegmentsC) + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_abi.GridResultC) == 3 * 8 + 3 * 8 + ctypes.sizeof(_abi.GridMetricsC) + 8
 
 
 def test_version_string():
