@@ -64,6 +64,7 @@ enum ScratchSlot {
     SCRATCH_FIT_E,
     SCRATCH_FIT_F,
     SCRATCH_FIT_SPLIT,
+    SCRATCH_FIT_GAP,
     SCRATCH_MV,
     SCRATCH_STAGE_DEV,
     SCRATCH_SLOT_COUNT

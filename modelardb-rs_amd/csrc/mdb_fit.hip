@@ -409,12 +409,13 @@ __device__ __forceinline__ void encode_irregular_timestamps(Sink &sink, const Ch
 }
 
 // Length in bytes of compress_residual_timestamps(ts[a..=b]) and whether it is the regular form.
+// `known_regular`: 1 / 0 if another kernel has already looked (k_fit_gap), -1 to find out here.
 __device__ __forceinline__ uint32_t timestamps_payload_length(const ChunkTimestamps &t, uint32_t a,
-                                                              uint32_t b, bool *regular) {
+                                                              uint32_t b, bool *regular, int known_regular = -1) {
     uint32_t count = b - a + 1;
     *regular = true;
     if (count <= 2) return 0;
-    if (chunk_range_regular(t, a, b)) return regular_length_bytes(count);
+    if (known_regular < 0 ? chunk_range_regular(t, a, b) : known_regular != 0) return regular_length_bytes(count);
     *regular = false;
     CountSink sink;
     encode_irregular_timestamps(sink, t, a, b);
@@ -485,6 +486,11 @@ struct FitArgs {
     const unsigned long long *chunk_offsets;
     uint64_t n_chunks;
     mdb_error_bound eb;
+    // Lossless MacaqueV-only segments of at least this many values are encoded by one WAVE each
+    // (k_fit_gap) instead of one lane; 0xffffffff: never. gap_results[segment] then holds what
+    // process_segment needs to know about them.
+    uint32_t gap_min_values;
+    const struct GapResult *gap_results;
 };
 
 __device__ __forceinline__ uint64_t chunk_record_capacity(uint64_t length) { return length / 8 + 1; }
@@ -761,7 +767,12 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
         }
         const uint32_t entry = __shfl(window, (int)(position - window_first), MDB_WAVE);
         if (entry == ENTRY_REJECTED) {
-            position += 1;
+            // A run of rejected points (noise under a lossless bound rejects every point) is skipped
+            // in one step: to the first entry of the window that is something else.
+            const unsigned long long others = __ballot(window != ENTRY_REJECTED && window_first + lane < n) &
+                                              (~0ull << (position - window_first));
+            position = others ? window_first + (uint32_t)__ffsll((long long)others) - 1u
+                              : min(n, window_first + (uint32_t)MDB_WAVE);
         } else if (entry == 0u) { // cannot happen: every point on the chain was visited by some lane
             if (lane == 0) atomicOr(error, ERR_SPLIT_CHAIN);
             break;
@@ -873,6 +884,18 @@ struct EncodeTargets {
     const unsigned long long *data_offsets[3];
 };
 
+struct GapResult { // of k_fit_gap<false>, indexed by segment
+    uint32_t values_bytes;
+    float min_value;
+    float max_value;
+    uint32_t regular; // are the timestamps of the segment equally spaced? (timestamps.rs:56-97)
+};
+
+__device__ __forceinline__ bool gap_goes_to_a_wave(const FitArgs &args, const SegItem &item) {
+    return args.eb.kind == MDB_EB_LOSSLESS && item.record == 0xffffffffu &&
+           item.last - item.first + 1 >= args.gap_min_values;
+}
+
 // Runs every encoder of one segment against `Sink`-typed sinks created by `make_sink(column, bytes)`.
 // With CountSink it sizes the payloads; with ByteSink it writes them.
 template <bool WRITE>
@@ -915,7 +938,8 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
     uint32_t ts_bytes;
     if (!WRITE) {
         bool regular;
-        ts_bytes = timestamps_payload_length(ts, item.first, item.last, &regular);
+        const int known_regular = gap_goes_to_a_wave(args, item) ? (int)args.gap_results[segment].regular : -1;
+        ts_bytes = timestamps_payload_length(ts, item.first, item.last, &regular, known_regular);
         sizes_io->pad = regular ? 1u : 0u;
     } else {
         ts_bytes = sizes_io->timestamps;
@@ -940,7 +964,15 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
         // compress_and_store_residuals_in_a_separate_segment (compression.rs:367-400)
         type = MDB_MACAQUE_V_ID;
         MacaqueState m;
-        if (!WRITE) {
+        if (gap_goes_to_a_wave(args, item) && (!WRITE || sizes_io->values > 12)) {
+            // k_fit_gap sized it before k_fit_size and wrote it before k_fit_encode (payloads of up to
+            // 12 bytes live inside the view, which this lane writes itself below).
+            const GapResult gap = args.gap_results[segment];
+            values_bytes = gap.values_bytes;
+            m.min_value = gap.min_value;
+            m.max_value = gap.max_value;
+            if (WRITE) finish_view(1, values_bytes);
+        } else if (!WRITE) {
             CountSink sink;
             macaque_encode(m, sink, eb, values + item.first, count, false, 0.0f);
             values_bytes = (uint32_t)sink.bytes();
@@ -1018,6 +1050,190 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
     }
 }
 
+// ---- k_fit_gap: one wave per long lossless MacaqueV-only segment ---------------------------------------------
+//
+// macaque_v.rs:76-164 with a lossless bound: value i is XORed with value i-1 (both known up front),
+// and the only thing carried from code to code is the window (leading / trailing zeros of the last
+// `11` code). A wave takes 64 values at a time: every lane computes its XOR, then the lanes whose
+// XOR does not fit the carried window are found with a ballot, one after the other - each of them
+// opens a new window for the lanes behind it. Code lengths are prefix-summed into bit offsets; in
+// write mode the codes are ORed into an LDS bit buffer and whole bytes flushed. Bit-identical to
+// the one-lane encoder, which for a 65 536-value chunk of noise needs 2 x 30 ms at the latency of a
+// single lane.
+
+constexpr uint32_t GAP_DEFAULT_MIN_VALUES = 256;
+constexpr int GAP_BUFFER_WORDS = 96; // 64 codes x 45 bits + a carried partial byte
+
+__global__ __launch_bounds__(256) void k_fit_gap_select(FitArgs args, const SegItem *__restrict__ items,
+                                                        uint64_t n_segments, uint32_t *__restrict__ gap_ids,
+                                                        uint32_t *__restrict__ n_gaps) {
+    const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (segment >= n_segments) return;
+    if (gap_goes_to_a_wave(args, items[segment])) gap_ids[atomicAdd(n_gaps, 1u)] = (uint32_t)segment;
+}
+
+// value (count <= 32 bits, right aligned) -> bits [at, at + count) of the big-endian bit buffer.
+__device__ __forceinline__ void gap_put(uint32_t *buffer, uint32_t at, uint32_t value, uint32_t count) {
+    if (count == 0) return;
+    const uint32_t word = at >> 5, offset = at & 31u;
+    if (offset + count <= 32u) {
+        atomicOr(&buffer[word], value << (32u - offset - count));
+    } else {
+        const uint32_t low_bits = offset + count - 32u; // bits that go to the next word
+        atomicOr(&buffer[word], value >> low_bits);
+        atomicOr(&buffer[word + 1], value << (32u - low_bits));
+    }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegItem *__restrict__ items,
+                                                      const uint32_t *__restrict__ gap_ids,
+                                                      const uint32_t *__restrict__ n_gaps,
+                                                      GapResult *__restrict__ results, EncodeTargets targets) {
+    __shared__ uint32_t buffer[GAP_BUFFER_WORDS];
+    if (blockIdx.x >= *n_gaps) return;
+    const uint32_t segment = gap_ids[blockIdx.x];
+    const SegItem item = items[segment];
+    const int lane = threadIdx.x;
+    const uint32_t n = item.last - item.first + 1;
+    const float *__restrict__ values = args.values + args.chunk_offsets[item.chunk] + item.first;
+    uint8_t *__restrict__ dst = nullptr;
+    if (WRITE) {
+        if (results[segment].values_bytes <= 12) return; // lives inside the view: k_fit_encode writes it
+        dst = targets.data[1] + targets.data_offsets[1][segment];
+    }
+
+    // The first value: 32 raw bits.
+    const uint32_t first_bits = __float_as_uint(values[0]);
+    float min_value = values[0], max_value = values[0]; // min_num / max_num of NaN and the first value
+    uint64_t total_bits = 32;
+    uint64_t written = 0; // bytes stored so far
+    uint32_t carry_bits = 0; // bits of a partial byte waiting at the front of the buffer
+    if (WRITE) {
+        if (lane < 4) dst[lane] = (uint8_t)(first_bits >> (24 - 8 * lane));
+        written = 4;
+        for (int k = lane; k < GAP_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
+    }
+    uint32_t window_leading = 255, window_trailing = 0; // uniform: macaque_v.rs:63-64
+    // While sizing, the wave also checks whether the timestamps are equally spaced, which the one-lane
+    // path (chunk_range_regular) would otherwise do point by point.
+    const ChunkTimestamps ts = chunk_timestamps(args.timestamps, item.chunk, args.chunk_offsets[item.chunk]);
+    bool regular = true;
+    const int64_t expected_delta = (!WRITE && ts.ts && n >= 2) ? ts.ts[item.first + 1] - ts.ts[item.first] : 0;
+    for (uint32_t base = 1; base < n; base += MDB_WAVE) {
+        const uint32_t i = base + lane;
+        const bool active = i < n;
+        if (!WRITE && ts.ts && active && ts.ts[item.first + i] - ts.ts[item.first + i - 1] != expected_delta)
+            regular = false;
+        const uint32_t current = active ? __float_as_uint(values[i]) : 0u;
+        const uint32_t previous = active ? __float_as_uint(values[i - 1]) : 0u;
+        const uint32_t x = current ^ previous;
+        const bool repeat = x == 0;
+        const uint32_t leading = repeat ? 32u : (uint32_t)__clz((int)x);
+        const uint32_t trailing = repeat ? 32u : (uint32_t)__ffs((int)x) - 1u;
+        // The window each lane's code is written with; lanes that open one get their own.
+        uint32_t my_leading = window_leading, my_trailing = window_trailing;
+        bool opens = false;
+        int cursor = 0;
+        while (true) {
+            const bool misfit = active && lane >= cursor && !repeat &&
+                                !(leading >= window_leading && trailing >= window_trailing);
+            const unsigned long long mask = __ballot(misfit);
+            if (mask == 0) {
+                if (lane >= cursor) {
+                    my_leading = window_leading;
+                    my_trailing = window_trailing;
+                }
+                break;
+            }
+            const int opener = __ffsll((long long)mask) - 1;
+            if (lane >= cursor && lane < opener) {
+                my_leading = window_leading;
+                my_trailing = window_trailing;
+            }
+            window_leading = __shfl(leading, opener, MDB_WAVE);
+            window_trailing = __shfl(trailing, opener, MDB_WAVE);
+            if (lane == opener) {
+                opens = true;
+                my_leading = window_leading;
+                my_trailing = window_trailing;
+            }
+            cursor = opener + 1;
+        }
+        const uint32_t meaningful = 32u - my_leading - my_trailing;
+        uint32_t code_bits = 0;
+        if (active) code_bits = repeat ? 2u : (opens ? 13u + meaningful : 1u + meaningful);
+        // Exclusive prefix sum of the code lengths: where each code goes.
+        uint32_t inclusive = code_bits;
+#pragma unroll
+        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+            const uint32_t up = __shfl_up(inclusive, delta, MDB_WAVE);
+            if (lane >= delta) inclusive += up;
+        }
+        const uint32_t batch_bits = __shfl(inclusive, MDB_WAVE - 1, MDB_WAVE);
+        // min / max with the first operand kept on ties, NaN as the neutral element (macaque_v.rs:199-204).
+        // The reduction keeps the order of the values (earlier blocks are the first operand), so that
+        // e.g. the sign of a zero minimum is the one the sequential encoder would report.
+        float low = active ? values[i] : __uint_as_float(0x7fc00000u);
+        float high = low;
+#pragma unroll
+        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+            const float low_before = __shfl_up(low, delta, MDB_WAVE);
+            const float high_before = __shfl_up(high, delta, MDB_WAVE);
+            if (lane >= delta) {
+                low = min_num(low_before, low);
+                high = max_num(high_before, high);
+            }
+        }
+        min_value = min_num(min_value, __shfl(low, MDB_WAVE - 1, MDB_WAVE));
+        max_value = max_num(max_value, __shfl(high, MDB_WAVE - 1, MDB_WAVE));
+        if (WRITE) {
+            if (active) {
+                const uint32_t at = carry_bits + inclusive - code_bits;
+                if (repeat) {
+                    gap_put(buffer, at, 0b10u, 2);
+                } else if (opens) {
+                    gap_put(buffer, at, (0b11u << 11) | (my_leading << 6) | meaningful, 13);
+                    gap_put(buffer, at + 13, x >> my_trailing, meaningful);
+                } else {
+                    gap_put(buffer, at, 0u, 1);
+                    gap_put(buffer, at + 1, x >> my_trailing, meaningful);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t buffered = carry_bits + batch_bits;
+            const uint32_t whole_bytes = buffered >> 3;
+            for (uint32_t b = lane; b < whole_bytes; b += MDB_WAVE)
+                dst[written + b] = (uint8_t)(buffer[b >> 2] >> (24u - 8u * (b & 3u)));
+            const uint32_t partial = (buffer[whole_bytes >> 2] >> (24u - 8u * (whole_bytes & 3u))) & 0xffu;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < GAP_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            carry_bits = buffered & 7u;
+            if (lane == 0 && carry_bits) buffer[0] = partial << 24;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            written += whole_bytes;
+        }
+        total_bits += batch_bits;
+    }
+    const bool all_regular = __all(regular);
+    if (WRITE) {
+        if (carry_bits && lane == 0) dst[written] = (uint8_t)(buffer[0] >> 24); // padded with zero bits
+    } else if (lane == 0) {
+        GapResult result;
+        result.values_bytes = (uint32_t)((total_bits + 7) >> 3);
+        result.min_value = min_value;
+        result.max_value = max_value;
+        result.regular = all_regular ? 1u : 0u;
+        results[segment] = result;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fit_size(FitArgs args, const unsigned long long *__restrict__ record_base,
                                                   const ModelRec *__restrict__ records,
                                                   const SegItem *__restrict__ items, uint64_t n_segments,
@@ -1046,6 +1262,17 @@ static bool valid_error_bound(mdb_error_bound eb) { // crates/modelardb_types/sr
     if (eb.kind == MDB_EB_ABSOLUTE) return std::isfinite(eb.value) && eb.value > 0.0f;
     if (eb.kind == MDB_EB_RELATIVE) return 0.0f < eb.value && eb.value <= 100.0f;
     return false;
+}
+
+// MDB_FIT_GAP_MIN_VALUES: "off" keeps one lane per MacaqueV-only segment, a number sets the length
+// from which a lossless one gets a wave of its own.
+static uint32_t gap_min_values_setting() {
+    if (const char *text = std::getenv("MDB_FIT_GAP_MIN_VALUES")) {
+        if (std::strcmp(text, "off") == 0) return 0xffffffffu;
+        const long long value = std::atoll(text);
+        if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
+    }
+    return GAP_DEFAULT_MIN_VALUES;
 }
 
 // Points per piece for split mode, 0 = one lane per chunk. Split when the call has too few chunks
@@ -1080,6 +1307,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     args.chunk_offsets = reinterpret_cast<const unsigned long long *>(chunk_offsets);
     args.n_chunks = n_chunks;
     args.eb = eb;
+    args.gap_min_values = 0xffffffffu;
+    args.gap_results = nullptr;
 
     OwnedSegments *owned = new OwnedSegments();
     owned->device = ctx->device;
@@ -1214,6 +1443,29 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                                items);
         }
         const uint32_t segment_blocks = (uint32_t)((n_segments + 255) / 256);
+        // Long lossless MacaqueV-only segments: one wave each (k_fit_gap), sized here, written below.
+        uint32_t *gap_ids = nullptr, *n_gaps = nullptr;
+        uint32_t gap_waves = 0;
+        const uint32_t gap_min_values = gap_min_values_setting();
+        if (n_segments > 0 && eb.kind == MDB_EB_LOSSLESS && gap_min_values != 0xffffffffu) {
+            const uint64_t most = std::min<uint64_t>(n_segments, points_end / gap_min_values + 1);
+            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP, n_segments * sizeof(GapResult) + most * 4 + 256, &p));
+            GapResult *gap_results = static_cast<GapResult *>(p);
+            gap_ids = reinterpret_cast<uint32_t *>(gap_results + n_segments);
+            n_gaps = gap_ids + align_up(most, 64);
+            gap_waves = (uint32_t)most;
+            args.gap_min_values = gap_min_values;
+            args.gap_results = gap_results;
+            FIT_CHECK(hipMemsetAsync(n_gaps, 0, 4, ctx->stream));
+            {
+                LaunchTimer timer(ctx, "k_fit_gap_select");
+                hipLaunchKernelGGL(k_fit_gap_select, dim3(segment_blocks), dim3(256), 0, ctx->stream, args, items,
+                                   (uint64_t)n_segments, gap_ids, n_gaps);
+            }
+            LaunchTimer timer(ctx, "k_fit_gap_size");
+            hipLaunchKernelGGL(k_fit_gap<false>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                               gap_ids, n_gaps, gap_results, EncodeTargets{});
+        }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_size");
             hipLaunchKernelGGL(k_fit_size, dim3(segment_blocks), dim3(256), 0, ctx->stream, args,
@@ -1269,6 +1521,11 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             tables[c][0] = reinterpret_cast<uint64_t>(dev + off_data[c]);
             tables[c][1] = 0;
             FIT_CHECK(hipMemcpyAsync(dev + off_table[c], tables[c], 16, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (gap_waves > 0) { // before k_fit_encode, which reads the first payload bytes for the views
+            LaunchTimer timer(ctx, "k_fit_gap_encode");
+            hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                               gap_ids, n_gaps, const_cast<GapResult *>(args.gap_results), targets);
         }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_encode");

@@ -16,16 +16,23 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "1", "64", "1000"],
-                ids=["split-auto", "lane-per-chunk", "pieces-of-64", "pieces-of-1000"])
+@pytest.fixture(autouse=True, params=[("auto", None), ("1", "off"), ("64", "8"), ("1000", None)],
+                ids=["split-auto", "lane-per-chunk+lane-per-gap", "pieces-of-64+gaps-from-8", "pieces-of-1000"])
 def fit_mode(request, monkeypatch):
     """Every fit test runs with the library choosing between one lane per chunk and split mode
-    (speculative pieces + chain walk, mdb_fit.hip), with split mode off, and with it forced."""
-    if request.param == "auto":
+    (speculative pieces + chain walk, mdb_fit.hip), with split mode off, and with it forced; and with
+    long lossless MacaqueV-only segments encoded by one wave each (k_fit_gap) from the default length,
+    never, and from 8 values."""
+    pieces, gaps = request.param
+    if pieces == "auto":
         monkeypatch.delenv("MDB_FIT_PIECE_POINTS", raising=False)
     else:
-        monkeypatch.setenv("MDB_FIT_PIECE_POINTS", request.param)
-    return request.param
+        monkeypatch.setenv("MDB_FIT_PIECE_POINTS", pieces)
+    if gaps is None:
+        monkeypatch.delenv("MDB_FIT_GAP_MIN_VALUES", raising=False)
+    else:
+        monkeypatch.setenv("MDB_FIT_GAP_MIN_VALUES", gaps)
+    return pieces
 
 
 def assert_same_segments(got, expected):
