@@ -44,6 +44,8 @@ def parse_args():
     parser.add_argument("--error-bound", type=float, default=1.0, help="relative bound in percent")
     parser.add_argument("--cpu-sample-series", type=int, default=48)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--settle-seconds", type=float, default=0.0,
+                        help="run the step untimed for this long before the warmup (lets clocks settle)")
     parser.add_argument("--fit-group-points", type=int, default=12_000_000_000,
                         help="at most this many raw points (4 B each) are resident per fit launch")
     return parser.parse_args()
@@ -165,6 +167,10 @@ def main():
                     metrics_total[key] += value
         return at, metrics_total
 
+    settle_until = time.perf_counter() + args.settle_seconds
+    while time.perf_counter() < settle_until:
+        step()
+        context.sync()
     for _ in range(args.warmup):
         step()
     barrier_and_sync(context, dist)
