@@ -65,6 +65,7 @@ enum ScratchSlot {
     SCRATCH_FIT_F,
     SCRATCH_FIT_SPLIT,
     SCRATCH_FIT_GAP,
+    SCRATCH_FIT_REGULAR,
     SCRATCH_MV,
     SCRATCH_STAGE_DEV,
     SCRATCH_SLOT_COUNT

@@ -92,6 +92,14 @@ struct TimestampSource {
     int64_t regular_start;
     int64_t regular_interval;
     const unsigned long long *series_first_index; // per chunk, may be nullptr
+    // Per chunk (first timestamp, interval), or nullptr. Set instead of `ts` when k_fit_regular has
+    // found the materialised timestamps of EVERY chunk equally spaced: nothing downstream has to
+    // load a timestamp then.
+    const long long *chunk_first;
+    const long long *chunk_interval;
+    // With `ts` set: per chunk, 1 if k_fit_regular found an irregularity in it (nullptr: not known).
+    // Segments of the other chunks are regular without looking.
+    const unsigned int *chunk_irregular;
 };
 
 struct ChunkTimestamps {
@@ -111,10 +119,46 @@ __device__ __forceinline__ ChunkTimestamps chunk_timestamps(const TimestampSourc
                                                             uint64_t chunk_base) {
     ChunkTimestamps t;
     t.ts = src.ts ? src.ts + chunk_base : nullptr;
+    if (!src.ts && src.chunk_first) {
+        t.first = src.chunk_first[chunk];
+        t.interval = src.chunk_interval[chunk];
+        return t;
+    }
     uint64_t first_index = src.series_first_index ? src.series_first_index[chunk] : 0;
     t.first = src.regular_start + (int64_t)(first_index * (uint64_t)src.regular_interval);
     t.interval = src.regular_interval;
     return t;
+}
+
+// One workgroup per chunk: are its timestamps equally spaced (timestamps.rs:56-97 asks that of every
+// segment)? Real ingest nearly always hands over timestamp arrays of regular series; knowing that the
+// whole call is regular lets every later kernel compute timestamps instead of loading them.
+__global__ __launch_bounds__(256) void k_fit_regular(const int64_t *__restrict__ ts,
+                                                     const unsigned long long *__restrict__ chunk_offsets,
+                                                     uint64_t n_chunks, long long *__restrict__ chunk_first,
+                                                     long long *__restrict__ chunk_interval,
+                                                     unsigned int *__restrict__ chunk_irregular,
+                                                     unsigned int *__restrict__ n_irregular) {
+    __shared__ int irregular;
+    const uint64_t chunk = blockIdx.x;
+    if (chunk >= n_chunks) return;
+    if (threadIdx.x == 0) irregular = 0;
+    __syncthreads();
+    const uint64_t base = chunk_offsets[chunk];
+    const uint64_t n = chunk_offsets[chunk + 1] - base;
+    const int64_t *__restrict__ t = ts + base;
+    const int64_t first = n > 0 ? t[0] : 0;
+    const int64_t interval = n > 1 ? t[1] - t[0] : 0;
+    bool mine = false;
+    for (uint64_t j = 2 + threadIdx.x; j < n; j += blockDim.x) mine = mine || (t[j] - t[j - 1] != interval);
+    if (mine) irregular = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        chunk_first[chunk] = first;
+        chunk_interval[chunk] = interval;
+        chunk_irregular[chunk] = irregular ? 1u : 0u;
+        if (irregular) atomicAdd(n_irregular, 1u);
+    }
 }
 
 // ---- PMC-Mean (models/pmc_mean.rs:31-93) ---------------------------------------------------------------
@@ -938,7 +982,10 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
     uint32_t ts_bytes;
     if (!WRITE) {
         bool regular;
-        const int known_regular = gap_goes_to_a_wave(args, item) ? (int)args.gap_results[segment].regular : -1;
+        int known_regular = gap_goes_to_a_wave(args, item) ? (int)args.gap_results[segment].regular : -1;
+        if (known_regular < 0 && args.timestamps.ts && args.timestamps.chunk_irregular &&
+            !args.timestamps.chunk_irregular[item.chunk])
+            known_regular = 1; // the whole chunk is equally spaced
         ts_bytes = timestamps_payload_length(ts, item.first, item.last, &regular, known_regular);
         sizes_io->pad = regular ? 1u : 0u;
     } else {
@@ -1303,7 +1350,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     FitArgs args;
     args.values = values;
     args.timestamps = {ts, regular_start, regular_interval,
-                       reinterpret_cast<const unsigned long long *>(series_first_index)};
+                       reinterpret_cast<const unsigned long long *>(series_first_index), nullptr, nullptr,
+                       nullptr};
     args.chunk_offsets = reinterpret_cast<const unsigned long long *>(chunk_offsets);
     args.n_chunks = n_chunks;
     args.eb = eb;
@@ -1347,6 +1395,25 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     unsigned long long n_segments = 0;
     if (n_chunks > 0) {
         unsigned long long points_end = 0;
+        // Materialised timestamps: are they all equally spaced? (answer read with the sync below)
+        unsigned int n_irregular_chunks = 1;
+        long long *chunk_first = nullptr, *chunk_interval = nullptr;
+        unsigned int *chunk_irregular = nullptr;
+        if (ts && n_chunks <= 0x7fffffffull) {
+            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_REGULAR, n_chunks * 20 + 64, &p));
+            chunk_first = static_cast<long long *>(p);
+            chunk_interval = chunk_first + n_chunks;
+            chunk_irregular = reinterpret_cast<unsigned int *>(chunk_interval + n_chunks);
+            unsigned int *counter = chunk_irregular + n_chunks;
+            FIT_CHECK(hipMemsetAsync(counter, 0, 4, ctx->stream));
+            {
+                LaunchTimer timer(ctx, "k_fit_regular");
+                hipLaunchKernelGGL(k_fit_regular, dim3((uint32_t)n_chunks), dim3(256), 0, ctx->stream, ts,
+                                   args.chunk_offsets, n_chunks, chunk_first, chunk_interval, chunk_irregular,
+                                   counter);
+            }
+            FIT_CHECK(hipMemcpyAsync(&n_irregular_chunks, counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         FIT_TRY(device_exclusive_scan(ctx, RecordCapacity{args.chunk_offsets}, n_chunks, record_base,
                                       block_sums, "k_fit_scan"));
         FIT_CHECK(hipMemcpyAsync(&total_records, record_base + n_chunks, 8, hipMemcpyDeviceToHost,
@@ -1354,6 +1421,15 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         FIT_CHECK(hipMemcpyAsync(&points_end, args.chunk_offsets + n_chunks, 8, hipMemcpyDeviceToHost,
                                  ctx->stream));
         FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ts && n_irregular_chunks == 0) {
+            // Every chunk is regular: from here on timestamps are computed, not loaded.
+            args.timestamps.ts = nullptr;
+            args.timestamps.chunk_first = chunk_first;
+            args.timestamps.chunk_interval = chunk_interval;
+            ts = nullptr;
+        } else if (ts) {
+            args.timestamps.chunk_irregular = chunk_irregular;
+        }
         const uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
         ModelRec *records = static_cast<ModelRec *>(p);
