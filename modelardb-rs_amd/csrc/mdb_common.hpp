@@ -182,23 +182,50 @@ inline DevSegments to_dev(const mdb_segments *s) {
     return d;
 }
 
-// MSB-first bit reader over global memory (models/bits.rs:25-83 semantics). Loads aligned 32-bit
-// words; a word that contains at least one payload byte never crosses a page, so touching the
-// slack bytes of the first/last word is safe.
+// MSB-first bit reader over global memory (models/bits.rs:25-83 semantics). Loads aligned 16-byte
+// chunks; a chunk that contains at least one payload byte never crosses a page, so touching the
+// slack bytes of the first/last chunk is safe.
 struct BitReaderDev {
-    const uint32_t *words; // aligned base
-    uint32_t next_word;
+    uint32_t next_word; // words consumed so far (of n_words)
     uint32_t n_words;
     uint64_t buffer; // MSB aligned
     int32_t available;
     uint64_t used_bits;
     uint64_t total_bits;
+    // The payload is fetched 16 bytes at a time, one such chunk ahead of use. With one lane per stream
+    // thousands of streams are open at once, far more than the caches hold a line for: a 4-byte load
+    // per word would pull the same 128-byte line from memory again and again.
+    const uint4 *chunks; // 16-byte aligned base
+    uint32_t n_chunks;
+    uint32_t next_chunk; // next one to load into `ahead`
+    uint32_t in_chunk;   // next word of `current` to hand out
+    uint4 current, ahead;
+
+    __device__ __forceinline__ uint4 load_chunk(uint32_t index) const {
+        return index < n_chunks ? chunks[index] : make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    __device__ __forceinline__ uint32_t take_word() {
+        const uint32_t w = in_chunk == 0 ? current.x : (in_chunk == 1 ? current.y : (in_chunk == 2 ? current.z : current.w));
+        if (++in_chunk == 4) {
+            current = ahead;
+            ahead = load_chunk(next_chunk++);
+            in_chunk = 0;
+        }
+        return w;
+    }
 
     __device__ __forceinline__ void init(const uint8_t *bytes, uint64_t nbytes) {
-        uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
-        uint32_t misalign = (uint32_t)(address & 3u);
-        words = reinterpret_cast<const uint32_t *>(address - misalign);
+        const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        const uint32_t misalign = (uint32_t)(address & 3u);
+        const uint32_t skipped_words = (uint32_t)((address & 15u) >> 2);
+        chunks = reinterpret_cast<const uint4 *>(address & ~(uintptr_t)15u);
         n_words = (uint32_t)((nbytes + misalign + 3u) >> 2);
+        n_chunks = (skipped_words + n_words + 3u) >> 2;
+        current = load_chunk(0);
+        ahead = load_chunk(1);
+        next_chunk = 2;
+        in_chunk = skipped_words;
         next_word = 0;
         buffer = 0;
         available = 0;
@@ -213,7 +240,8 @@ struct BitReaderDev {
 
     __device__ __forceinline__ void refill() {
         while (available <= 32 && next_word < n_words) {
-            uint32_t w = __builtin_bswap32(words[next_word++]);
+            uint32_t w = __builtin_bswap32(take_word());
+            next_word++;
             buffer |= (uint64_t)w << (32 - available);
             available += 32;
         }

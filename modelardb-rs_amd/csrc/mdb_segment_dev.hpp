@@ -120,19 +120,50 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
     uint64_t last_delta = 0;
     int64_t timestamp = start_time;
     while (!r.exhausted()) {
-        uint32_t ones = 0;
-        while (ones < 5 && !r.exhausted() && r.get(1)) ones++;
-        if (ones != 0 && r.remaining() < 7) break;
-        if (ones != 0) {
-            uint32_t width = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : ones == 4 ? 32u : 64u;
-            if (r.remaining() < width) {
-                *error |= ERR_TIMESTAMPS;
-                return count;
+        if (r.remaining() >= 80) {
+            // Far from the end of the stream (the longest code is 5 + 64 bits) nothing can go wrong,
+            // and the common codes (up to `1110` + 12 bits) are taken off the top of the bit buffer
+            // without a branch: 64 lanes decode 64 different codes per step, and every branch they
+            // disagree on is executed by all of them.
+            r.refill(); // >= 33 bits in the buffer
+            const uint32_t top = (uint32_t)(r.buffer >> 32);
+            const uint32_t ones = min((uint32_t)__clz((int)~top), 5u);
+            if (ones <= 3) {
+                const uint32_t header = ones + 1;                         // the run of ones and its zero
+                const uint32_t width = (0x0c090700u >> (8u * ones)) & 0xffu; // 0, 7, 9, 12
+                const uint64_t encoded = width ? (r.buffer << header) >> (64u - width) : 0ull;
+                const uint32_t consumed = header + width;
+                r.buffer <<= consumed;
+                r.available -= (int32_t)consumed;
+                r.used_bits += consumed;
+                const uint64_t negative = encoded | (~0ull << (width ? width : 1u));
+                last_delta += (width && encoded > (1ull << (width - 1))) ? negative : encoded;
+            } else {
+                const uint32_t header = 5u; // `11110` or `11111`
+                const uint32_t width = ones == 4 ? 32u : 64u;
+                r.buffer <<= header;
+                r.available -= (int32_t)header;
+                r.used_bits += header;
+                const uint64_t encoded = r.get64(width);
+                uint64_t dod = encoded;
+                if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
+                last_delta += dod;
             }
-            uint64_t encoded = r.get64(width);
-            uint64_t dod = encoded;
-            if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
-            last_delta += dod;
+        } else {
+            uint32_t ones = 0;
+            while (ones < 5 && !r.exhausted() && r.get(1)) ones++;
+            if (ones != 0 && r.remaining() < 7) break;
+            if (ones != 0) {
+                const uint32_t width = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : ones == 4 ? 32u : 64u;
+                if (r.remaining() < width) {
+                    *error |= ERR_TIMESTAMPS;
+                    return count;
+                }
+                uint64_t encoded = r.get64(width);
+                uint64_t dod = encoded;
+                if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
+                last_delta += dod;
+            }
         }
         timestamp = (int64_t)((uint64_t)timestamp + last_delta);
         if (count == COUNT_MASK) {

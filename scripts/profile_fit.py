@@ -13,6 +13,7 @@ def main():
     p.add_argument("--chunk", type=int, default=65536)
     p.add_argument("--error-bound", type=float, default=1.0)
     p.add_argument("--materialise-ts", action="store_true")
+    p.add_argument("--irregular", action="store_true", help="materialised timestamps with random gaps")
     a = p.parse_args()
     ctx = mdb.Context(0)
     eb = mdb.error_bound("relative", a.error_bound) if a.error_bound > 0 else mdb.error_bound("lossless")
@@ -24,7 +25,11 @@ def main():
     first = np.array([c * a.chunk for s in range(a.series) for c in range(cps)], dtype=np.uint64)
     off_dev, first_dev = ctx.upload_array(offsets), ctx.upload_array(first)
     ts_dev = 0
-    if a.materialise_ts:
+    if a.irregular:
+        rng = np.random.default_rng(5)
+        one = np.cumsum(rng.integers(900, 1100, a.points).astype(np.int64))
+        ts_dev = ctx.upload_array(np.tile(one, a.series))
+    elif a.materialise_ts:
         ts_dev = ctx.upload_array(np.tile(np.arange(a.points, dtype=np.int64) * 1000, a.series))
     for rep in range(2):
         ctx.profile_enable(True); ctx.profile_reset(); ctx.sync()
