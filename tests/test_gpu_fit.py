@@ -223,3 +223,34 @@ def test_fit_one_long_series_in_one_call(hip, fit_mode):
         expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
         got = hip.try_compress_univariate_time_series(timestamps, values, eb)
         assert_same_segments(got, expected)
+
+
+def test_fit_regular_and_irregular_chunks_in_one_call(hip):
+    # k_fit_regular decides per chunk whether its timestamps are equally spaced; only when ALL chunks
+    # are does the library stop loading timestamps. Mix both kinds (and chunks of 0, 1 and 2 points,
+    # and one whose only irregularity is its very last gap) in one call.
+    eb = cases.error_bounds()["rel1"]
+    rng = np.random.default_rng(53)
+    lengths = [5000, 3000, 0, 1, 2, 4000, 70_000, 2500, 6000]
+    kinds = ["regular", "irregular", "regular", "regular", "irregular", "last-gap", "regular", "irregular", "regular"]
+    timestamps, values = [], []
+    for s, (n, kind) in enumerate(zip(lengths, kinds)):
+        if kind == "regular":
+            ts = 1_000_000 * s + np.arange(n, dtype=np.int64) * (1000 + s)
+        elif kind == "irregular":
+            ts = 1_000_000 * s + np.cumsum(rng.integers(1, 2000, n)).astype(np.int64)
+        else:
+            ts = 1_000_000 * s + np.arange(n, dtype=np.int64) * 1000
+            ts[-1] += 7
+        timestamps.append(ts)
+        values.append(datagen.sine_series(s, n)[1] if n else np.zeros(0, np.float32))
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    timestamps, values = np.concatenate(timestamps), np.concatenate(values)
+    expected = ora.compress_chunks(timestamps, values, offsets, eb)
+    got = hip.compress_chunks(timestamps, values, offsets, eb)
+    assert_same_segments(got, expected)
+    # and all-regular with a different interval per chunk (the path that stops loading timestamps)
+    regular = [1_000_000 * s + np.arange(n, dtype=np.int64) * (1000 + 13 * s) for s, n in enumerate(lengths)]
+    regular = np.concatenate(regular)
+    assert_same_segments(hip.compress_chunks(regular, values, offsets, eb),
+                         ora.compress_chunks(regular, values, offsets, eb))
