@@ -353,3 +353,37 @@ def test_owned_grid_results_in_page_locked_memory(hip):
     release()
     empty = hip.grid_batch_owned(mdb.SegmentBatch.from_rows([]))
     assert len(empty[0]) == 0 and len(empty[2]) == 0
+
+
+def test_concurrent_calls_from_several_threads(hip):
+    # DataFusion polls GridStreams from tokio worker threads (SURVEY 8(b) "Threading"): calls on ONE
+    # context are serialised inside the library, separate contexts run side by side. ctypes releases
+    # the GIL during the calls, so these threads really overlap.
+    import threading
+    eb = cases.error_bounds()["rel5"]
+    batches = [cases.mixed_batch(eb, irregular, seed=140 + k, length=8000)[2] for k, irregular in
+               enumerate((False, True, False, True))]
+    expected = [ora.grid_batch(b) for b in batches]
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    own_contexts = [mdb.Context(0) for _ in batches]
+    failures = []
+
+    def worker(k, context):
+        try:
+            for _ in range(20):
+                got = context.grid_batch(batches[k])
+                cases.assert_grid_equal(got, expected[k])
+                assert context.agg_batch(batches[k], mask).count == len(expected[k][0])
+        except Exception as error:  # noqa: BLE001 - reported below
+            failures.append((k, repr(error)))
+
+    for contexts in ([hip] * len(batches), own_contexts):
+        threads = [threading.Thread(target=worker, args=(k, contexts[k])) for k in range(len(batches))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a call did not return"
+        assert not failures, failures
+    for context in own_contexts:
+        context.close()
