@@ -215,6 +215,22 @@ struct BitReaderDev {
         return w;
     }
 
+    // Positions the reader `start_bit` bits into the payload (init() = seek(bytes, nbytes, 0)).
+    __device__ __forceinline__ void seek(const uint8_t *bytes, uint64_t nbytes, uint64_t start_bit) {
+        const uint64_t skip_bytes = (start_bit >> 3) & ~(uint64_t)3u; // whole words that are skipped
+        init(bytes + skip_bytes, nbytes - skip_bytes);
+        // init() measured everything from the word it started at; put the bookkeeping back on the
+        // payload's own scale and drop the bits in front of start_bit.
+        total_bits = nbytes * 8u;
+        used_bits = skip_bytes * 8u;
+        uint32_t drop = (uint32_t)(start_bit - used_bits); // < 64
+        while (drop > 0) {
+            const uint32_t step = drop > 32u ? 32u : drop;
+            (void)get(step);
+            drop -= step;
+        }
+    }
+
     __device__ __forceinline__ void init(const uint8_t *bytes, uint64_t nbytes) {
         const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
         const uint32_t misalign = (uint32_t)(address & 3u);
@@ -268,6 +284,63 @@ struct BitReaderDev {
     }
 
     __device__ __forceinline__ bool overrun() const { return used_bits > total_bits; }
+};
+
+// A leaner reader for loops that take SHORT fields (<= 32 bits) off a long stream, one lane per
+// stream: a 128-bit window (two 64-bit registers) over 8-byte loads, one load ahead. No per-word
+// queue and no nested conditions - 64 lanes parsing 64 different streams execute every branch any
+// of them takes. The caller stops using it `slack` bits before the end (see far_from_end) and hands
+// over to BitReaderDev::seek for the tail, so it never has to think about the end of the payload.
+struct WindowReaderDev {
+    const uint64_t *words; // 8-byte aligned base
+    uint32_t n_words;
+    uint32_t next_word; // next one to load into `ahead`
+    uint64_t high, low; // bits [position, position + available) of the stream, MSB first
+    uint64_t ahead;
+    int32_t available;  // valid bits in (high, low): 65..128 whenever the caller looks
+    uint64_t position;  // bits of the payload consumed
+    uint64_t total_bits;
+
+    __device__ __forceinline__ uint64_t load(uint32_t index) const {
+        return index < n_words ? __builtin_bswap64(words[index]) : 0ull;
+    }
+    __device__ __forceinline__ void open(const uint8_t *bytes, uint64_t nbytes, uint32_t start_bit) {
+        const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        const uint32_t misalign = (uint32_t)(address & 7u);
+        words = reinterpret_cast<const uint64_t *>(address - misalign);
+        n_words = (uint32_t)((nbytes + misalign + 7u) >> 3);
+        high = load(0);
+        low = load(1);
+        ahead = load(2);
+        next_word = 3;
+        available = 128;
+        position = 0;
+        total_bits = nbytes * 8u;
+        uint32_t drop = 8u * misalign + start_bit; // < 64 + 64
+        position = 0 - (uint64_t)(8u * misalign);  // consume() adds it back
+        while (drop > 0) {
+            const uint32_t step = drop > 32u ? 32u : drop;
+            consume(step);
+            drop -= step;
+        }
+    }
+    __device__ __forceinline__ bool far_from_end(uint32_t slack) const { return position + slack <= total_bits; }
+    // The next 32 bits.
+    __device__ __forceinline__ uint32_t top() const { return (uint32_t)(high >> 32); }
+    // count in [1, 32]
+    __device__ __forceinline__ void consume(uint32_t count) {
+        high = (high << count) | (low >> (64u - count));
+        low <<= count;
+        available -= (int32_t)count;
+        position += count;
+        if (available <= 64) { // `low` is empty: the word loaded ahead becomes the low half
+            const uint32_t fill = (uint32_t)available; // 33..64 valid bits in `high`
+            high |= fill < 64u ? ahead >> fill : 0ull;
+            low = fill < 64u ? ahead << (64u - fill) : ahead;
+            ahead = load(next_word++);
+            available += 64;
+        }
+    }
 };
 
 // Rust f32::min / f32::max as the oracle defines them: minNum / maxNum, first operand kept on ties.

@@ -45,7 +45,8 @@ struct GridHeader {
 
 __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     DevSegments s, TimeRange range, uint32_t mv_min_values, TileDesc *__restrict__ desc,
-    uint32_t *__restrict__ counts, unsigned long long *__restrict__ block_points,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ irregular_totals,
+    uint32_t *__restrict__ irregular_first, unsigned long long *__restrict__ block_points,
     unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header) {
     __shared__ unsigned long long lds_metrics[12];
     if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
@@ -65,6 +66,10 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         desc[i] = make_tile_desc(d);
         bool is_serial = (d.flags & FLAG_SERIAL) != 0;
         counts[i] = d.n_visible | (is_serial ? SERIAL_BIT : 0u);
+        if (!(d.flags & FLAG_REGULAR)) { // k_grid_serial need not parse the timestamps to count again
+            irregular_totals[i] = d.n_total;
+            irregular_first[i] = d.first;
+        }
         points += d.n_visible;
         serial += is_serial ? 1 : 0;
         uint32_t type = d.flags & FLAG_TYPE_MASK;
@@ -386,7 +391,9 @@ struct MacaqueStream {
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
-    int64_t *__restrict__ out_ts, float *__restrict__ out_val, GridHeader *__restrict__ header) {
+    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ irregular_totals,
+    const uint32_t *__restrict__ irregular_first, int64_t *__restrict__ out_ts, float *__restrict__ out_val,
+    GridHeader *__restrict__ header) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -399,8 +406,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     if (present) {
         // The few segments with serial work are analysed again here rather than carrying the full
         // descriptor (first visible index, whole-segment counts) through memory for all of them.
-        SegInfo info = analyse_segment(s, i);
-        if (range.enabled) apply_time_range(s, i, info, range);
+        SegInfo info = analyse_segment(s, i, irregular_totals);
+        if (range.enabled) apply_time_range(s, i, info, range, irregular_first, counts);
         d = info.desc;
         error = info.error;
     }
@@ -551,6 +558,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
 struct GridPlan {
     TileDesc *desc;
     uint32_t *counts;
+    uint32_t *irregular_totals;
+    uint32_t *irregular_first;
     unsigned long long *offsets;
     unsigned long long *block_points;
     unsigned long long *block_serial;
@@ -587,8 +596,11 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     void *p;
     if (scratch_reserve(ctx, SCRATCH_DESC, n * sizeof(TileDesc), &p)) return 1;
     plan->desc = static_cast<TileDesc *>(p);
-    if (scratch_reserve(ctx, SCRATCH_COUNTS, (n + 4) * 4, &p)) return 1;
+    // counts, then (for segments with irregular timestamps only) their totals and first visible index
+    if (scratch_reserve(ctx, SCRATCH_COUNTS, 3 * (n + 4) * 4, &p)) return 1;
     plan->counts = static_cast<uint32_t *>(p);
+    plan->irregular_totals = plan->counts + n + 4;
+    plan->irregular_first = plan->irregular_totals + n + 4;
     if (scratch_reserve(ctx, SCRATCH_OFFSETS, (n + 1) * 8, &p)) return 1;
     plan->offsets = static_cast<unsigned long long *>(p);
     if (scratch_reserve(ctx, SCRATCH_BLOCK_SUMS, (uint64_t)(n_blocks + 1) * 16, &p)) return 1;
@@ -609,7 +621,8 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     {
         LaunchTimer timer(ctx, "k_grid_prepass");
         hipLaunchKernelGGL(k_grid_prepass, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s,
-                           range, plan->mv_min_values, plan->desc, plan->counts, plan->block_points,
+                           range, plan->mv_min_values, plan->desc, plan->counts, plan->irregular_totals,
+                           plan->irregular_first, plan->block_points,
                            plan->block_serial, plan->header);
     }
     {
@@ -758,7 +771,8 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
         hipLaunchKernelGGL(k_grid_serial,
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
-                           plan.serial_ids, n_serial, mv_segs, out_ts, out_val, plan.header);
+                           plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
+                           plan.irregular_first, out_ts, out_val, plan.header);
     }
     return 0;
 }

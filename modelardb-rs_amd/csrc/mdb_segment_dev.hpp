@@ -114,56 +114,61 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
     uint32_t count = 0;
     emit(count++, start_time);
     if (count >= limit) return count;
-    BitReaderDev r;
-    r.init(bytes, nbytes);
-    r.get(1);
     uint64_t last_delta = 0;
     int64_t timestamp = start_time;
-    while (!r.exhausted()) {
-        if (r.remaining() >= 80) {
-            // Far from the end of the stream (the longest code is 5 + 64 bits) nothing can go wrong,
-            // and the common codes (up to `1110` + 12 bits) are taken off the top of the bit buffer
-            // without a branch: 64 lanes decode 64 different codes per step, and every branch they
-            // disagree on is executed by all of them.
-            r.refill(); // >= 33 bits in the buffer
-            const uint32_t top = (uint32_t)(r.buffer >> 32);
-            const uint32_t ones = min((uint32_t)__clz((int)~top), 5u);
-            if (ones <= 3) {
-                const uint32_t header = ones + 1;                         // the run of ones and its zero
-                const uint32_t width = (0x0c090700u >> (8u * ones)) & 0xffu; // 0, 7, 9, 12
-                const uint64_t encoded = width ? (r.buffer << header) >> (64u - width) : 0ull;
-                const uint32_t consumed = header + width;
-                r.buffer <<= consumed;
-                r.available -= (int32_t)consumed;
-                r.used_bits += consumed;
-                const uint64_t negative = encoded | (~0ull << (width ? width : 1u));
-                last_delta += (width && encoded > (1ull << (width - 1))) ? negative : encoded;
-            } else {
-                const uint32_t header = 5u; // `11110` or `11111`
-                const uint32_t width = ones == 4 ? 32u : 64u;
-                r.buffer <<= header;
-                r.available -= (int32_t)header;
-                r.used_bits += header;
-                const uint64_t encoded = r.get64(width);
-                uint64_t dod = encoded;
-                if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
-                last_delta += dod;
-            }
+    // Far from the end of the stream (the longest code is 5 + 64 bits) nothing can go wrong, and the
+    // codes are taken off a 128-bit window with as few branches as possible: 64 lanes decode 64
+    // different codes per step, and every branch they disagree on is executed by all of them.
+    WindowReaderDev w;
+    w.open(bytes, nbytes, 1); // bit 0 is the flag "irregular" (timestamps.rs:116)
+    while (w.far_from_end(80)) {
+        const uint32_t top = w.top();
+        const uint32_t ones = min((uint32_t)__clz((int)~top), 5u);
+        if (ones <= 3) {
+            const uint32_t header = ones + 1;                            // the run of ones and its zero
+            const uint32_t width = (0x0c090700u >> (8u * ones)) & 0xffu; // 0, 7, 9, 12
+            const uint32_t encoded = width ? (top << header) >> (32u - width) : 0u;
+            w.consume(header + width);
+            // Two's complement of `width` bits, except that 2^(width-1) itself is positive (:139-155).
+            const uint64_t negative = (uint64_t)encoded | (~0ull << (width ? width : 1u));
+            last_delta += (width && encoded > (1u << (width - 1))) ? negative : (uint64_t)encoded;
         } else {
-            uint32_t ones = 0;
-            while (ones < 5 && !r.exhausted() && r.get(1)) ones++;
-            if (ones != 0 && r.remaining() < 7) break;
-            if (ones != 0) {
-                const uint32_t width = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : ones == 4 ? 32u : 64u;
-                if (r.remaining() < width) {
-                    *error |= ERR_TIMESTAMPS;
-                    return count;
-                }
-                uint64_t encoded = r.get64(width);
-                uint64_t dod = encoded;
-                if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
-                last_delta += dod;
+            w.consume(5); // `11110` or `11111`
+            uint64_t encoded = w.top();
+            w.consume(32);
+            if (ones == 5) {
+                encoded = (encoded << 32) | w.top();
+                w.consume(32);
+                last_delta += encoded;
+            } else {
+                last_delta += encoded > (1ull << 31) ? (encoded | (~0ull << 32)) : encoded;
             }
+        }
+        timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+        if (count == COUNT_MASK) {
+            *error |= ERR_TOO_LONG;
+            return count;
+        }
+        emit(count++, timestamp);
+        if (count >= limit) return count;
+    }
+    // The last few codes, where running out of bits has a meaning, with the careful reader.
+    BitReaderDev r;
+    r.seek(bytes, nbytes, w.position);
+    while (!r.exhausted()) {
+        uint32_t ones = 0;
+        while (ones < 5 && !r.exhausted() && r.get(1)) ones++;
+        if (ones != 0 && r.remaining() < 7) break;
+        if (ones != 0) {
+            const uint32_t width = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : ones == 4 ? 32u : 64u;
+            if (r.remaining() < width) {
+                *error |= ERR_TIMESTAMPS;
+                return count;
+            }
+            uint64_t encoded = r.get64(width);
+            uint64_t dod = encoded;
+            if (width < 64 && encoded > (1ull << (width - 1))) dod = encoded | (~0ull << width);
+            last_delta += dod;
         }
         timestamp = (int64_t)((uint64_t)timestamp + last_delta);
         if (count == COUNT_MASK) {
@@ -226,7 +231,11 @@ struct SegInfo {
     uint32_t regular_length; // len() of a regular stream = the stored big-endian integer
 };
 
-__device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i) {
+// `known_totals` (may be nullptr): per segment, the number of points of a segment with irregular
+// timestamps as an earlier analyse_segment of the same batch counted it - counting means parsing
+// the whole delta-of-delta stream, which the prepass has already done once.
+__device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i,
+                                                   const uint32_t *known_totals = nullptr) {
     SegInfo info;
     info.error = 0;
     info.swing_first = 0.0f;
@@ -290,8 +299,11 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
     } else if (ts_len > 0) {
         regular = false;
         ts_bytes = view_data(s.timestamps, i, vt);
-        n_total = decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, 0xffffffffu,
-                                              &info.error, [](uint32_t, int64_t) {});
+        if (known_totals)
+            n_total = known_totals[i];
+        else
+            n_total = decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, 0xffffffffu,
+                                                  &info.error, [](uint32_t, int64_t) {});
     }
     if (regular) flags |= FLAG_REGULAR;
 
@@ -350,14 +362,22 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
 
 // Restrict a segment to the points with lo <= timestamp <= hi: sets first / n_visible and drops
 // the serial flag when no serially decoded point remains visible.
+// `known_first` / `known_visible` (may be nullptr): what an earlier apply_time_range of the same batch
+// found for a segment with irregular timestamps (it has to decode them all to find out).
 __device__ __forceinline__ void apply_time_range(const DevSegments &s, uint64_t i, SegInfo &info,
-                                                 const TimeRange &range) {
+                                                 const TimeRange &range, const uint32_t *known_first = nullptr,
+                                                 const uint32_t *known_visible = nullptr) {
     SegDesc &d = info.desc;
     if (info.error) return;
     uint32_t k_lo = 0, k_hi = 0;
     bool any;
     if (d.flags & FLAG_REGULAR) {
         any = regular_index_interval(d.start, d.delta, d.n_total, range.lo, range.hi, &k_lo, &k_hi);
+    } else if (known_first && known_visible) {
+        const uint32_t visible = known_visible[i] & COUNT_MASK;
+        any = visible > 0;
+        k_lo = known_first[i];
+        k_hi = k_lo + visible - 1;
     } else {
         // Timestamps are sorted (the compressor requires it), so the in-range ones are an interval.
         any = false;
