@@ -417,20 +417,43 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
 
     if (present && !(d.flags & FLAG_REGULAR)) {
-        // Irregular timestamps, and the model values that depend on them.
+        // Irregular timestamps. Every lane writes into a region of its own, so a store instruction
+        // of the wave touches 64 different cache lines: two timestamps are paired into one aligned
+        // 16-byte store, and the values are not written here at all when the timestamps are (a
+        // PMC-Mean value does not depend on the timestamp and k_grid_tiles has written it already;
+        // Swing values are filled in from the stored timestamps by k_grid_swing_irregular, coalesced).
         const uint4 vt = s.timestamps.views[i];
         const uint8_t *bytes = view_data(s.timestamps, i, vt);
+        int64_t held = 0;      // timestamp of an even output position waiting for its neighbour
+        bool holding = false;
+        uint64_t held_at = 0;
         decode_irregular_timestamps(bytes, vt.x, d.start, s.end_time[i], visible_end, &error,
                                     [&](uint32_t k, int64_t t) {
                                         if (k < d.first || k >= visible_end) return;
                                         const uint64_t at = o + (k - d.first);
-                                        if (out_ts) out_ts[at] = t;
-                                        if (k < d.n_model) {
-                                            if (type == MDB_PMC_MEAN_ID) out_val[at] = d.value;
-                                            else if (type == MDB_SWING_ID)
-                                                out_val[at] = (float)(d.slope * (double)t + d.intercept);
+#ifdef MDB_EXPERIMENT_NO_IRREGULAR_STORES
+                                        if (t == 0x7fffffffffffffffll) out_ts[at] = t;
+                                        return;
+#endif
+                                        if (out_ts) {
+                                            if (at & 1ull) {
+                                                if (holding) {
+                                                    *reinterpret_cast<longlong2 *>(out_ts + at - 1) = make_longlong2(held, t);
+                                                    holding = false;
+                                                } else {
+                                                    out_ts[at] = t;
+                                                }
+                                            } else {
+                                                held = t;
+                                                held_at = at;
+                                                holding = true;
+                                            }
+                                        } else if (k < d.n_model && type == MDB_SWING_ID) {
+                                            // values only (a joined field column): nothing to read t from later
+                                            out_val[at] = (float)(d.slope * (double)t + d.intercept);
                                         }
                                     });
+        if (holding) out_ts[held_at] = held;
     }
 
     // Up to two MacaqueV streams per segment: the model's values (type 2) and the residual tail.
@@ -551,6 +574,30 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
         }
     }
     if (error) atomicOr(&header->error, error);
+}
+
+// Swing values of segments with irregular timestamps, from the timestamps k_grid_serial has just
+// stored: one wave per such segment, coalesced reads of out_ts and writes of out_val
+// (swing.rs:304-319: (slope * t + intercept) as f32, in f64).
+__global__ __launch_bounds__(256) void k_grid_swing_irregular(
+    DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const uint32_t *__restrict__ counts,
+    const uint32_t *__restrict__ irregular_totals, const uint32_t *__restrict__ irregular_first,
+    const int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    const uint64_t slot = (uint64_t)blockIdx.x * (blockDim.x / MDB_WAVE) + threadIdx.x / MDB_WAVE;
+    if (slot >= n_serial) return;
+    const int lane = threadIdx.x % MDB_WAVE;
+    const uint32_t i = serial_ids[slot];
+    if ((view_inline_byte(s.timestamps.views[i], 0) & 0x80u) == 0 || (int32_t)s.timestamps.views[i].x <= 0) return;
+    if (s.model_type_id[i] != MDB_SWING_ID) return;
+    SegInfo info = analyse_segment(s, i, irregular_totals);
+    if (range.enabled) apply_time_range(s, i, info, range, irregular_first, counts);
+    const SegDesc &d = info.desc;
+    if (info.error || (d.flags & FLAG_REGULAR) || d.first >= d.n_model) return;
+    const uint32_t model_points = min(d.n_model - d.first, d.n_visible);
+    const uint64_t o = offsets[i];
+    for (uint32_t k = lane; k < model_points; k += MDB_WAVE)
+        out_val[o + k] = (float)(d.slope * (double)out_ts[o + k] + d.intercept);
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -773,6 +820,12 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
                            plan.irregular_first, out_ts, out_val, plan.header);
+    }
+    if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
+        LaunchTimer timer(ctx, "k_grid_swing_irregular");
+        hipLaunchKernelGGL(k_grid_swing_irregular, dim3((uint32_t)((n_serial + 3) / 4)), dim3(256), 0, ctx->stream, s,
+                           range, plan.offsets, plan.serial_ids, n_serial, plan.counts, plan.irregular_totals,
+                           plan.irregular_first, out_ts, out_val);
     }
     return 0;
 }

@@ -337,6 +337,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
             int64_t model_end = start;
             if (regular) {
                 model_end = start + (int64_t)((uint64_t)(n_model - 1) * (uint64_t)d.delta);
+            } else if (n_res == 0) {
+                model_end = end; // the last timestamp is not stored in the stream: it is end_time
             } else {
                 decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, n_model,
                                             &info.error,
