@@ -9,6 +9,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 namespace mdbhost {
 
@@ -518,8 +519,16 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
         auto column = std::make_shared<Column>();
         column->type = Type::Utf8View;
         column->length = total;
-        column->data.assign(std::max<size_t>(static_cast<size_t>(total) * 16, 16), 0);
-        mdb_view16 *views = reinterpret_cast<mdb_view16 *>(column->data.data());
+        // 16 bytes per created row: not zero-filled first, and written by several threads when large
+        // (this is the StringView append per row of grid_exec.rs:341-346, the host-side cost of a tag).
+        struct TagStorage {
+            std::unique_ptr<mdb_view16[]> views;
+            ColumnPtr input;
+        };
+        auto storage = std::make_shared<TagStorage>();
+        storage->views.reset(new mdb_view16[std::max<size_t>(static_cast<size_t>(total), 1)]);
+        storage->input = batch.columns[query_compressed_schema().size() + t];
+        mdb_view16 *views = storage->views.get();
         // buffer 0: long leftover strings, copied so old inputs can be dropped.
         column->owned_buffers.emplace_back();
         std::vector<uint8_t> &leftover_payload = column->owned_buffers[0];
@@ -538,22 +547,38 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
                 }
             }
         }
-        int64_t at = leftovers;
         const mdb_view16 *input_views = input_tags.as<mdb_view16>();
-        for (int64_t row = 0; row < batch.num_rows; row++) {
-            mdb_view16 tag = input_views[row];
-            if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
-            for (uint32_t k = 0; k < rows_per_segment[row]; k++) views[at++] = tag;
+        auto replicate = [&](int64_t first_row, int64_t last_row, int64_t at) {
+            for (int64_t row = first_row; row < last_row; row++) {
+                mdb_view16 tag = input_views[row];
+                if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
+                for (uint32_t k = 0; k < rows_per_segment[row]; k++) views[at++] = tag;
+            }
+        };
+        const int64_t new_rows = total - leftovers;
+        const unsigned n_threads = new_rows >= (1 << 18) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (n_threads == 1) {
+            replicate(0, batch.num_rows, leftovers);
+        } else {
+            // Equal shares of the segment rows; every thread starts where the rows before it end.
+            std::vector<std::thread> workers;
+            int64_t at = leftovers, row = 0;
+            for (unsigned w = 0; w < n_threads; w++) {
+                const int64_t last_row = batch.num_rows * static_cast<int64_t>(w + 1) / n_threads;
+                workers.emplace_back(replicate, row, last_row, at);
+                for (; row < last_row; row++) at += rows_per_segment[row];
+            }
+            for (std::thread &worker : workers) worker.join();
         }
-        column->values = column->data.data();
-        column->buffer_ptrs.push_back(leftover_payload.empty() ? reinterpret_cast<const uint8_t *>(column->data.data())
+        column->values = views;
+        column->buffer_ptrs.push_back(leftover_payload.empty() ? reinterpret_cast<const uint8_t *>(views)
                                                                : leftover_payload.data());
         column->buffer_sizes.push_back(static_cast<int64_t>(leftover_payload.size()));
         for (size_t b = 0; b < input_tags.buffer_ptrs.size(); b++) {
             column->buffer_ptrs.push_back(input_tags.buffer_ptrs[b]);
             column->buffer_sizes.push_back(input_tags.buffer_sizes[b]);
         }
-        column->keep_alive = batch.columns[query_compressed_schema().size() + t];
+        column->keep_alive = storage;
         tag_columns.push_back(column);
     }
 

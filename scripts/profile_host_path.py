@@ -39,6 +39,21 @@ def main():
         print(f"agg  host path: {len(part)} segments: {dt*1e3:.3f} ms/batch, {len(part)/dt/1e6:.1f} Msegments/s")
     values = np.concatenate([datagen.sine_series(s, n)[1] for s in range(4)]); tss = np.tile(ts, 4)
     o = np.concatenate([offs[:-1] + s * n for s in range(4)] + [[4 * n]]).astype(np.uint64)
+    # The C++ GridStream (leftovers, tag replication, slicing into DataFusion-sized batches) on top.
+    from modelardb_rs_amd import host
+    arrow = host.segments_with_tags(batch.slice(0, 8192).to_arrow(), {"tag": "turbine-0001"})
+    for tags in ((), ("tag",)):
+        source = arrow if tags else batch.slice(0, 8192).to_arrow()
+        stream = host.GridStream(ctx, tag_names=tags, batch_size=8192)
+        t0 = time.perf_counter(); rows = 0
+        for _ in range(5):
+            stream.push(source)
+        stream.finish_input()
+        batches, _ = stream.collect()
+        rows = sum(b.num_rows for b in batches)
+        dt = (time.perf_counter() - t0) / 5
+        print(f"GridStream ({len(tags)} tag columns): 8192 segments -> {rows // 5} points per input batch: {dt*1e3:.2f} ms, "
+              f"{rows / 5 / dt / 1e9:.2f} Gpoints/s, {len(batches) // 5} output batches")
     one_ts, one_values = datagen.sine_series(9, 1_000_000)
     lossless = mdb.error_bound("lossless")
     for mode, label in (("1", "one lane per chunk"), (None, "split mode (auto)")):
