@@ -1333,7 +1333,7 @@ static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64
     }
     const uint64_t target_lanes = (uint64_t)std::max(ctx->compute_units, 1) * 4 * MDB_WAVE * 2;
     if (n_chunks == 0 || n_chunks >= target_lanes / 2) return 0;
-    if (total_points * 12 > (4ull << 30)) return 0; // the per-point table would be too large
+    if (total_points * 12 > (48ull << 30)) return 0; // the per-point table would be too large
     const uint64_t piece = std::max<uint64_t>(512, align_up(total_points / target_lanes + 1, 64));
     if (total_points / n_chunks < 2 * piece) return 0; // chunks too short to gain anything
     return (uint32_t)piece;
