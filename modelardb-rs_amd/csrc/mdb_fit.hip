@@ -618,6 +618,7 @@ struct PieceCount {
 constexpr int FIT_RING = 32;
 constexpr int FIT_HISTORY = 8;
 constexpr int FIT_THREADS = MDB_WAVE;
+constexpr int FIT_QUICK_REJECTS = 16; // rejected points skipped per trip (lossless bound only)
 
 template <bool HAS_TS, bool SPLIT>
 __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitArgs split,
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
 
     uint32_t n_models = 0;
     GapCounter gaps;
+    const uint32_t piece_end = SPLIT ? first_point + split.piece_points : 0u; // (split mode) of this lane's piece
     uint32_t current = first_point; // first point of the model being fitted
     uint32_t j = first_point;       // next point to feed
     uint32_t loaded = first_point;  // the ring holds points [low, loaded) of the chunk, loaded - low <= FIT_RING
@@ -680,6 +682,48 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
     }
 
     while (__any(active)) {
+        // Lossless bound, noisy data: nearly every point is rejected (PMC-Mean ends at the second
+        // point because the values differ, Swing at the third because the points are not exactly
+        // collinear, and neither reaches the 8 points a model needs). Feeding three points and
+        // finishing costs four trips through this loop per point; the same verdict follows from the
+        // first three points directly (pmc_mean.rs:58-76 and swing.rs:101-198 with a zero deviation),
+        // so runs of such points are skipped here, a few per trip.
+        if (args.eb.kind == MDB_EB_LOSSLESS) {
+            for (int skipped = 0; skipped < FIT_QUICK_REJECTS; skipped++) {
+                bool reject = false;
+                // (only on points that are in the lane's LDS ring already: a load per point would cost
+                // more than the trips it saves)
+                if (active && j == current && current + 2 < n && current >= low && current + 2 < loaded) {
+                    const float v0 = ring_values[current % FIT_RING][lane];
+                    const float v1 = ring_values[(current + 1) % FIT_RING][lane];
+                    const float v2 = ring_values[(current + 2) % FIT_RING][lane];
+                    if (isfinite(v0) && isfinite(v1) && isfinite(v2) && v0 != v1) {
+                        const int64_t t0 = HAS_TS ? (int64_t)ring_ts[current % FIT_RING][lane] : regular_ts.regular_at(current);
+                        const int64_t t1 = HAS_TS ? (int64_t)ring_ts[(current + 1) % FIT_RING][lane]
+                                                  : regular_ts.regular_at(current + 1);
+                        const int64_t t2 = HAS_TS ? (int64_t)ring_ts[(current + 2) % FIT_RING][lane]
+                                                  : regular_ts.regular_at(current + 2);
+                        const LineDev line = line_through(t0, (double)v0, t1, (double)v1);
+                        const double approximation = line.slope * (double)t2 + line.intercept;
+                        reject = approximation < (double)v2 || approximation > (double)v2;
+                    }
+                }
+                if (!__any(reject)) break;
+                if (reject) {
+                    if (SPLIT)
+                        __hip_atomic_store(&split.entry[base + current], ENTRY_REJECTED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    current += 1;
+                    j = current;
+                    // Inside its own piece a lane is normally the first one there: it only has to look
+                    // for another lane's tracks once it is past the end of its piece.
+                    if (SPLIT && current >= piece_end &&
+                        __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                        active = false; // some lane has been here already
+                }
+            }
+        }
         const bool feeding = active && j < n && (pmc_fits || swing_fits);
         // Wave-synchronous top-up: triggered by any lane whose next point is not in its ring.
         if (__any(feeding && (j >= loaded || j < low))) {
@@ -688,7 +732,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
             // Normally the ring is extended at `loaded`. A lane whose next point fell out of the
             // back of its ring (PMC-Mean chosen although Swing had reached > 8 points further,
             // types.rs:84-101) restarts its ring at j; points before j are never needed again.
-            if (active && j < low) {
+            if (active && (j < low || j > loaded)) { // (j > loaded: after a run of quick rejects)
                 loaded = j;
                 low = j;
             }
@@ -758,8 +802,9 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
             if (current >= n) {
                 if (!SPLIT) plans[chunk] = {n_models, gaps.finish(n)};
                 active = false;
-            } else if (SPLIT && __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            } else if (SPLIT && current >= piece_end &&
+                       __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 active = false; // some lane has been here: the chain from this point on is recorded
             } else {
                 pmc.reset();
