@@ -981,8 +981,7 @@ struct GapResult { // of k_fit_gap<false>, indexed by segment
 };
 
 __device__ __forceinline__ bool gap_goes_to_a_wave(const FitArgs &args, const SegItem &item) {
-    return args.eb.kind == MDB_EB_LOSSLESS && item.record == 0xffffffffu &&
-           item.last - item.first + 1 >= args.gap_min_values;
+    return item.record == 0xffffffffu && item.last - item.first + 1 >= args.gap_min_values;
 }
 
 // Runs every encoder of one segment against `Sink`-typed sinks created by `make_sink(column, bytes)`.
@@ -1142,10 +1141,10 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
     }
 }
 
-// ---- k_fit_gap: one wave per long lossless MacaqueV-only segment ---------------------------------------------
+// ---- k_fit_gap: one wave per long MacaqueV-only segment -----------------------------------------------------
 //
-// macaque_v.rs:76-164 with a lossless bound: value i is XORed with value i-1 (both known up front),
-// and the only thing carried from code to code is the window (leading / trailing zeros of the last
+// macaque_v.rs:76-164: what is stored for value i is XORed with what was stored for value i-1, and
+// the only other thing carried from code to code is the window (leading / trailing zeros of the last
 // `11` code). A wave takes 64 values at a time: every lane computes its XOR, then the lanes whose
 // XOR does not fit the carried window are found with a ballot, one after the other - each of them
 // opens a new window for the lanes behind it. Code lengths are prefix-summed into bit offsets; in
@@ -1207,6 +1206,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         for (int k = lane; k < GAP_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
     }
     uint32_t window_leading = 255, window_trailing = 0; // uniform: macaque_v.rs:63-64
+    const mdb_error_bound eb = args.eb;
+    float carried_in = values[0];  // uniform: the value stored last (the first one is stored as it is)
+    float last_stored = values[0];
     // While sizing, the wave also checks whether the timestamps are equally spaced, which the one-lane
     // path (chunk_range_regular) would otherwise do point by point.
     const ChunkTimestamps ts = chunk_timestamps(args.timestamps, item.chunk, args.chunk_offsets[item.chunk]);
@@ -1217,8 +1219,36 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         const bool active = i < n;
         if (!WRITE && ts.ts && active && ts.ts[item.first + i] - ts.ts[item.first + i - 1] != expected_delta)
             regular = false;
-        const uint32_t current = active ? __float_as_uint(values[i]) : 0u;
-        const uint32_t previous = active ? __float_as_uint(values[i - 1]) : 0u;
+        // What is stored for value i (macaque_v.rs:100-118). Lossless: the value. Otherwise the value
+        // stored before it if that is within the bound of value i, else value i with its least
+        // mantissa bits rewritten - which every lane can work out for its own value up front; who
+        // keeps the carried value and who starts a new one is again settled with ballots.
+        float stored = active ? values[i] : 0.0f;
+        if (eb.kind != MDB_EB_LOSSLESS) {
+            const float raw = stored;
+            const float rewritten = active ? rewrite_least_mantissa_bits(eb, raw) : 0.0f;
+            int cursor = 0;
+            while (true) {
+                const bool breaks = active && lane >= cursor && !within_error_bound(eb, raw, last_stored);
+                const unsigned long long mask = __ballot(breaks);
+                if (mask == 0) {
+                    if (lane >= cursor) stored = last_stored;
+                    break;
+                }
+                const int breaker = __ffsll((long long)mask) - 1;
+                if (lane >= cursor && lane < breaker) stored = last_stored;
+                last_stored = __shfl(rewritten, breaker, MDB_WAVE);
+                if (lane == breaker) stored = last_stored;
+                cursor = breaker + 1;
+            }
+        }
+        const float before = __shfl_up(stored, 1, MDB_WAVE);
+        const uint32_t current = active ? __float_as_uint(stored) : 0u;
+        const uint32_t previous = active ? __float_as_uint(lane == 0 ? carried_in : before) : 0u;
+        // The value stored last in this batch is what the next batch starts from.
+        const int last_lane = (int)min((uint32_t)MDB_WAVE, n - base) - 1;
+        carried_in = __shfl(stored, last_lane, MDB_WAVE);
+        last_stored = carried_in;
         const uint32_t x = current ^ previous;
         const bool repeat = x == 0;
         const uint32_t leading = repeat ? 32u : (uint32_t)__clz((int)x);
@@ -1266,7 +1296,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         // min / max with the first operand kept on ties, NaN as the neutral element (macaque_v.rs:199-204).
         // The reduction keeps the order of the values (earlier blocks are the first operand), so that
         // e.g. the sign of a zero minimum is the one the sequential encoder would report.
-        float low = active ? values[i] : __uint_as_float(0x7fc00000u);
+        float low = active ? stored : __uint_as_float(0x7fc00000u);
         float high = low;
 #pragma unroll
         for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
@@ -1568,7 +1598,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         uint32_t *gap_ids = nullptr, *n_gaps = nullptr;
         uint32_t gap_waves = 0;
         const uint32_t gap_min_values = gap_min_values_setting();
-        if (n_segments > 0 && eb.kind == MDB_EB_LOSSLESS && gap_min_values != 0xffffffffu) {
+        if (n_segments > 0 && gap_min_values != 0xffffffffu) {
             const uint64_t most = std::min<uint64_t>(n_segments, points_end / gap_min_values + 1);
             FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP, n_segments * sizeof(GapResult) + most * 4 + 256, &p));
             GapResult *gap_results = static_cast<GapResult *>(p);
@@ -1583,9 +1613,16 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 hipLaunchKernelGGL(k_fit_gap_select, dim3(segment_blocks), dim3(256), 0, ctx->stream, args, items,
                                    (uint64_t)n_segments, gap_ids, n_gaps);
             }
-            LaunchTimer timer(ctx, "k_fit_gap_size");
-            hipLaunchKernelGGL(k_fit_gap<false>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
-                               gap_ids, n_gaps, gap_results, EncodeTargets{});
+            // How many there are decides the launch (usually none, and then nothing is launched).
+            uint32_t found = 0;
+            FIT_CHECK(hipMemcpyAsync(&found, n_gaps, 4, hipMemcpyDeviceToHost, ctx->stream));
+            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            gap_waves = found;
+            if (gap_waves > 0) {
+                LaunchTimer timer(ctx, "k_fit_gap_size");
+                hipLaunchKernelGGL(k_fit_gap<false>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                                   gap_ids, n_gaps, gap_results, EncodeTargets{});
+            }
         }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_size");
