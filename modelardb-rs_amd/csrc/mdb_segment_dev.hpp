@@ -411,19 +411,61 @@ __device__ __forceinline__ void decode_macaque_v(const uint8_t *bytes, uint32_t 
         if (count > 0 || !seeded) *error |= ERR_BITSTREAM;
         return;
     }
-    BitReaderDev r;
-    r.init(bytes, nbytes);
     uint32_t leading = 255, trailing = 0;
-    uint32_t last;
+    uint32_t last = seed_bits;
     uint32_t emitted = 0;
-    if (seeded) {
-        last = seed_bits;
-    } else {
-        last = r.get(32);
-        if (count == 0) {
-            *error |= ERR_BITSTREAM;
-            return;
+    if (!seeded && count == 0) {
+        *error |= ERR_BITSTREAM;
+        return;
+    }
+    // Far from the end of the stream the codes are taken off a 128-bit window (see WindowReaderDev):
+    // one lane per stream, so every branch the lanes disagree on costs all of them.
+    WindowReaderDev w;
+    w.open(bytes, nbytes, 0);
+    bool first_pending = !seeded;
+    while (emitted < count && w.far_from_end(96)) {
+        if (first_pending) { // the first value: 32 raw bits
+            last = w.top();
+            w.consume(32);
+            first_pending = false;
+            emit(emitted++, last);
+            continue;
         }
+        const uint32_t top = w.top(); // c0 c1 leading[5] meaningful[6] ...
+        if ((top >> 30) == 2u) {      // `10`: the value repeats
+            w.consume(2);
+        } else {
+            uint32_t meaningful;
+            if ((top >> 31) == 0u) { // `0`: the previous window
+                meaningful = 32u - leading - trailing;
+                if (meaningful > 32u || trailing > 31u) {
+                    *error |= ERR_BITSTREAM;
+                    return;
+                }
+                w.consume(1);
+            } else { // `11` + 5 bits leading zeros + 6 bits length
+                leading = (top >> 25) & 31u;
+                meaningful = (top >> 19) & 63u;
+                trailing = 32u - meaningful - leading;
+                if (meaningful > 32u || trailing > 31u) {
+                    *error |= ERR_BITSTREAM;
+                    return;
+                }
+                w.consume(13);
+            }
+            if (meaningful > 0) {
+                const uint32_t value = w.top() >> (32u - meaningful);
+                w.consume(meaningful);
+                last ^= value << trailing;
+            }
+        }
+        emit(emitted++, last);
+    }
+    // The rest (or all of a short stream) with the careful reader, where running out of bits counts.
+    BitReaderDev r;
+    r.seek(bytes, nbytes, w.position);
+    if (first_pending) {
+        last = r.get(32);
         emit(emitted++, last);
     }
     while (emitted < count) {
