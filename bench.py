@@ -232,9 +232,9 @@ def main():
     context.sync()
     agg_seconds = time.perf_counter() - t0
     t0 = time.perf_counter()
-    ranged = None
+    range_state = None
     for part in parts:
-        ranged = context.agg_batch_range_dev(part, t_lo, t_hi, mask, ranged)
+        range_state = context.agg_batch_range_dev(part, t_lo, t_hi, mask, range_state)
     context.sync()
     range_seconds = time.perf_counter() - t0
     agg_profile = context.profile()
@@ -244,7 +244,7 @@ def main():
         from modelardb_rs_amd import sharding
         t0 = time.perf_counter()
         state = sharding.all_reduce_state(state, dist, device=f"cuda:{local_rank}")
-        ranged = sharding.all_reduce_state(ranged, dist, device=f"cuda:{local_rank}")
+        range_state = sharding.all_reduce_state(range_state, dist, device=f"cuda:{local_rank}")
         reduce_seconds = time.perf_counter() - t0
     else:
         reduce_seconds = 0.0
@@ -258,7 +258,7 @@ def main():
         "range": {"t_lo": t_lo, "t_hi": t_hi, "seconds": range_seconds,
                   "segments_per_s": n_segments / range_seconds,
                   "kernel_ms": agg_profile.get("k_agg_range", (1, 0.0))[1] / max(agg_profile.get("k_agg_range", (1, 0.0))[0], 1),
-                  "count": ranged.count, "min": ranged.min, "max": ranged.max, "sum": ranged.sum},
+                  "count": range_state.count, "min": range_state.min, "max": range_state.max, "sum": range_state.sum},
         "final_reduce_seconds": reduce_seconds,
         "note": "COUNT/MIN/MAX/SUM on the resident segments (BASELINE config 3: no grid); the range "
                 "variant clips to the middle half of the time axis; with N > 1 the partials of all "

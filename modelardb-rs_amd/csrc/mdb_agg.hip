@@ -26,7 +26,9 @@ struct AggPartial {
     float min;
     float max;
     unsigned int error;
-    unsigned int pad;
+    unsigned int deferred;                // MacaqueV streams left to the parallel decoder ...
+    unsigned long long deferred_values;   // ... the values in them ...
+    unsigned long long deferred_bytes;    // ... and their bytes
 };
 
 __device__ __forceinline__ double shfl_down_f64(double v, int delta) {
@@ -51,6 +53,9 @@ __device__ __forceinline__ void block_reduce(AggPartial &p, AggPartial *lds) {
         p.min = min_num(p.min, __shfl_down(p.min, delta, MDB_WAVE));
         p.max = max_num(p.max, __shfl_down(p.max, delta, MDB_WAVE));
         p.error |= __shfl_down(p.error, delta, MDB_WAVE);
+        p.deferred += __shfl_down(p.deferred, delta, MDB_WAVE);
+        p.deferred_values += (unsigned long long)shfl_down_i64((long long)p.deferred_values, delta);
+        p.deferred_bytes += (unsigned long long)shfl_down_i64((long long)p.deferred_bytes, delta);
     }
     const int lane = threadIdx.x & (MDB_WAVE - 1);
     const int wave = threadIdx.x / MDB_WAVE;
@@ -64,6 +69,9 @@ __device__ __forceinline__ void block_reduce(AggPartial &p, AggPartial *lds) {
             p.min = min_num(p.min, lds[w].min);
             p.max = max_num(p.max, lds[w].max);
             p.error |= lds[w].error;
+            p.deferred += lds[w].deferred;
+            p.deferred_values += lds[w].deferred_values;
+            p.deferred_bytes += lds[w].deferred_bytes;
         }
     }
 }
@@ -75,7 +83,9 @@ __device__ __forceinline__ AggPartial empty_partial() {
     p.min = FLT_MAX;   // f32::MAX (model_simple_aggregates.rs:413)
     p.max = -FLT_MAX;  // f32::MIN (model_simple_aggregates.rs:456)
     p.error = 0;
-    p.pad = 0;
+    p.deferred = 0;
+    p.deferred_values = 0;
+    p.deferred_bytes = 0;
     return p;
 }
 
@@ -136,13 +146,28 @@ __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, c
     return model_sum + residuals_sum;
 }
 
-__global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uint32_t which_mask,
+// How k_agg_segments treats the MacaqueV streams that qualify for the parallel decoder: add them up
+// like any other (ALL), leave them aside and count them (DEFER), or add up nothing but them, and
+// only their sums (ONLY_DEFERRED - what is run when leaving them aside turned out to be pointless).
+enum : uint32_t { AGG_SUM_ALL = 0, AGG_SUM_DEFER = 1, AGG_SUM_ONLY_DEFERRED = 2 };
+
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uint32_t which_mask, uint32_t mode,
+                                                              uint32_t mv_min_values,
                                                               AggPartial *__restrict__ partials) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
     const bool need_len = which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM);
     for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
          i += (uint64_t)gridDim.x * AGG_THREADS) {
+        if (mode == AGG_SUM_ONLY_DEFERRED) {
+            if (s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
+            SegInfo info = analyse_segment(s, i);
+            if (!mv_qualifies_for_sum(info, s.values.views[i].x, mv_min_values)) continue;
+            uint32_t error = 0;
+            p.sum += (double)segment_sum(s, i, info, info.desc.n_model, &error);
+            p.error |= error;
+            continue;
+        }
         if (which_mask & MDB_AGG_MIN) p.min = min_num(p.min, s.min_value[i]);
         if (which_mask & MDB_AGG_MAX) p.max = max_num(p.max, s.max_value[i]);
         if (!need_len) continue;
@@ -155,7 +180,13 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
         if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) p.count += length;
         if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) {
             error |= info.error;
-            if (!error) p.sum += (double)segment_sum(s, i, info, length, &error);
+            if (mode == AGG_SUM_DEFER && !error && mv_qualifies_for_sum(info, s.values.views[i].x, mv_min_values)) {
+                p.deferred += 1;
+                p.deferred_values += length;
+                p.deferred_bytes += s.values.views[i].x;
+            } else if (!error) {
+                p.sum += (double)segment_sum(s, i, info, length, &error);
+            }
         }
         p.error |= error;
     }
@@ -175,6 +206,9 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_finish(const AggPartial *__
         p.min = min_num(p.min, q.min);
         p.max = max_num(p.max, q.max);
         p.error |= q.error;
+        p.deferred += q.deferred;
+        p.deferred_values += q.deferred_values;
+        p.deferred_bytes += q.deferred_bytes;
     }
     block_reduce(p, lds);
     if (threadIdx.x == 0) *result = p;
@@ -397,6 +431,9 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     AggPartial *partials = static_cast<AggPartial *>(p);
     AggPartial *result = partials + n_blocks;
     DevSegments s = to_dev(in);
+    const bool sums_wanted = !range && (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG));
+    bool mv_forced = false;
+    const uint32_t mv_min_values = macaque_parallel_min_values(&mv_forced);
     if (range) {
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
@@ -404,7 +441,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     } else {
         LaunchTimer timer(ctx, "k_agg_segments");
         hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
-                           which_mask, partials);
+                           which_mask, sums_wanted ? AGG_SUM_DEFER : AGG_SUM_ALL, mv_min_values, partials);
     }
     {
         LaunchTimer timer(ctx, "k_agg_finish");
@@ -417,6 +454,34 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MDB_HIP_CHECK(hipGetLastError());
     if (host.error) return fail(describe_error(host.error));
+    if (host.deferred > 0) {
+        // Long MacaqueV streams were left aside: through the parallel decoder if that pays off ...
+        bool handled = false;
+        double sum = 0.0;
+        if (macaque_deferred_sum(ctx, s, mv_min_values, mv_forced, host.deferred, host.deferred_values,
+                                 host.deferred_bytes, &handled, &sum))
+            return 1;
+        if (!handled) { // ... or one lane per stream after all
+            {
+                LaunchTimer timer(ctx, "k_agg_segments");
+                hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
+                                   which_mask, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials);
+            }
+            {
+                LaunchTimer timer(ctx, "k_agg_finish");
+                hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(AGG_THREADS), 0, ctx->stream, partials,
+                                   n_blocks, result);
+            }
+            AggPartial late;
+            MDB_HIP_CHECK(hipMemcpyAsync(&late, result, sizeof(AggPartial), hipMemcpyDeviceToHost,
+                                         ctx->stream));
+            MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            MDB_HIP_CHECK(hipGetLastError());
+            if (late.error) return fail(describe_error(late.error));
+            sum = late.sum;
+        }
+        host.sum += sum;
+    }
     // Fold into the caller's running state exactly as update_batch would continue it.
     if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) inout->count += host.count;
     if (which_mask & MDB_AGG_MIN) inout->min = (inout->min != inout->min) ? host.min

@@ -67,6 +67,7 @@ enum ScratchSlot {
     SCRATCH_FIT_GAP,
     SCRATCH_FIT_REGULAR,
     SCRATCH_MV,
+    SCRATCH_AGG_MV,
     SCRATCH_STAGE_DEV,
     SCRATCH_SLOT_COUNT
 };
@@ -167,6 +168,11 @@ struct DevSegments {
     DevCol values;
     DevCol residuals;
 };
+
+// mdb_grid.hip, for mdb_agg.hip: the parallel MacaqueV decoder as a service to SUM (see there).
+uint32_t macaque_parallel_min_values(bool *forced);
+int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values, bool forced, uint64_t n_streams,
+                         uint64_t n_values, uint64_t n_bytes, bool *handled, double *sum);
 
 inline DevSegments to_dev(const mdb_segments *s) {
     DevSegments d;

@@ -710,14 +710,16 @@ void fill_metrics(const GridHeader &h, mdb_grid_metrics *m) {
     m->segments_irregular = h.metrics[8];
 }
 
-// The long MacaqueV streams of the batch through the parallel decoder (mdb_macaque_parallel.hpp);
-// runs after k_grid_tiles and before k_grid_serial, which skips the streams marked done.
-int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, GridPlan &plan, float *out_val,
-                          MvSeg **segs_out) {
-    const uint64_t n_serial = plan.host_header.n_serial;
-    // Every qualifying stream has ceil(bits / MV_PIECE_BITS) pieces and is on the serial list.
-    const uint64_t max_pieces = plan.host_header.metrics[9] * 8 / MV_PIECE_BITS + n_serial + 1;
-    if (max_pieces > MV_MAX_PIECES && !plan.mv_forced) return 0; // enough streams for one lane per stream
+// The parallel decoder (mdb_macaque_parallel.hpp) over n_serial candidate streams holding stream_bytes
+// bytes between them: `select` launches the kernel that fills segs[0..n_serial), the decoded values go
+// to out_val + MvSeg::out_offset and MvSeg::done says which streams were decoded. *segs_out stays
+// nullptr when the batch has so many streams that one lane per stream is the better plan.
+template <typename Select>
+int mv_pipeline(mdb_ctx *ctx, uint64_t n_serial, uint64_t stream_bytes, bool forced, Select select, float *out_val,
+                unsigned int *error, MvSeg **segs_out) {
+    // Every qualifying stream has ceil(bits / MV_PIECE_BITS) pieces.
+    const uint64_t max_pieces = stream_bytes * 8 / MV_PIECE_BITS + n_serial + 1;
+    if (max_pieces > MV_MAX_PIECES && !forced) return 0; // enough streams for one lane per stream
     if (max_pieces * MV_CHAINS > 0x7fffff00ull) return 0;
     const uint64_t sums_bytes = scan_block_sums_bytes(n_serial);
     const uint64_t segs_bytes = align_up(n_serial * sizeof(MvSeg), 256);
@@ -750,11 +752,7 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     uint32_t *pending = reinterpret_cast<uint32_t *>(at + 2 * align_up(max_pieces * 4, 256));
     MDB_HIP_CHECK(hipMemsetAsync(pending, 0, 256, ctx->stream));
     MDB_HIP_CHECK(hipMemsetAsync(starts, 0, starts_bytes, ctx->stream));
-    {
-        LaunchTimer timer(ctx, "k_mv_select");
-        hipLaunchKernelGGL(k_mv_select, dim3((uint32_t)((n_serial + 255) / 256)), dim3(256), 0, ctx->stream, s,
-                           range, plan.offsets, plan.serial_ids, n_serial, plan.mv_min_values, segs);
-    }
+    select(segs);
     if (device_exclusive_scan(ctx, MvPieceCount{segs}, n_serial, piece_base, block_sums, "k_mv_scan")) return 1;
     const uint32_t piece_blocks = (uint32_t)((max_pieces + MDB_WAVE - 1) / MDB_WAVE);
     for (int round = 0; round < MV_ROUNDS; round++) {
@@ -782,9 +780,206 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     {
         LaunchTimer timer(ctx, "k_mv_decode");
         hipLaunchKernelGGL(k_mv_decode, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
-                           n_serial, starts, out_val, &plan.header->error);
+                           n_serial, starts, out_val, error);
     }
     *segs_out = segs;
+    return 0;
+}
+
+// The long MacaqueV streams of a grid batch; runs after k_grid_tiles and before k_grid_serial, which
+// skips the streams marked done.
+int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, GridPlan &plan, float *out_val,
+                          MvSeg **segs_out) {
+    const uint64_t n_serial = plan.host_header.n_serial;
+    auto select = [&](MvSeg *segs) {
+        LaunchTimer timer(ctx, "k_mv_select");
+        hipLaunchKernelGGL(k_mv_select, dim3((uint32_t)((n_serial + 255) / 256)), dim3(256), 0, ctx->stream, s,
+                           range, plan.offsets, plan.serial_ids, n_serial, plan.mv_min_values, segs);
+    };
+    return mv_pipeline(ctx, n_serial, plan.host_header.metrics[9], plan.mv_forced, select, out_val,
+                       &plan.header->error, segs_out);
+}
+
+// ---- SUM over long MacaqueV streams (for mdb_agg.hip) ------------------------------------------------
+//
+// macaque_v::sum (macaque_v.rs:220-265) adds the values of a stream one after the other in f32, and
+// f32 addition does not associate, so the additions stay with one lane per stream. What need not stay
+// there is the decoding, which is a hundred times the work: k_agg_segments leaves the streams that
+// qualify for the parallel decoder aside, they are decoded into scratch memory here, and k_mv_sums
+// then only has to add floats.
+
+constexpr unsigned long long DEFERRED_ONE = 1ull << 40; // scan item: streams above bit 40, their values below
+
+struct DeferredItem {
+    DevSegments s;
+    uint32_t min_values;
+    __device__ uint64_t operator()(uint64_t i) const {
+        if (s.model_type_id[i] != MDB_MACAQUE_V_ID) return 0;
+        const SegInfo info = analyse_segment(s, i);
+        return mv_qualifies_for_sum(info, s.values.views[i].x, min_values) ? (DEFERRED_ONE | info.desc.n_model) : 0;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_mv_select_scanned(DevSegments s, const unsigned long long *__restrict__ scan,
+                                                           uint32_t min_values, MvSeg *__restrict__ segs) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    const unsigned long long mine = scan[i];
+    if ((scan[i + 1] >> 40) == (mine >> 40)) return; // not one of the streams left aside
+    const SegInfo info = analyse_segment(s, i);
+    segs[mine >> 40] = mv_describe(s, i, info, min_values, mine & (DEFERRED_ONE - 1));
+}
+
+struct DeferredResult {
+    double sum;
+    unsigned int error;
+    unsigned int pad;
+};
+
+// One wave per stream. The additions are a dependent chain that only one lane can walk, so the wave's
+// job is to keep that lane fed: all lanes fetch the next MV_SUM_CHUNK values (coalesced, in flight
+// while lane 0 adds up the chunk before) and hand them over through LDS.
+constexpr uint32_t MV_SUM_CHUNK = 1024;
+
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_sums(const MvSeg *__restrict__ segs, uint64_t n_slots,
+                                                      const float *__restrict__ values, float *__restrict__ sums,
+                                                      DeferredResult *__restrict__ result) {
+    __shared__ float4 chunk_lds[2][MV_SUM_CHUNK / 4];
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const MvSeg seg = segs[slot];
+    if (!seg.done) {
+        // The parallel decoder gave this stream up: decode it here, one lane.
+        if (lane != 0) return;
+        float sum = 0.0f;
+        uint32_t error = 0;
+        decode_macaque_v(reinterpret_cast<const uint8_t *>(seg.words) + seg.bias_bits / 8, seg.total_bits / 8,
+                         seg.n_model, false, 0, &error, [&](uint32_t k, uint32_t bits) {
+                             if (k == 0) sum = __uint_as_float(bits);
+                             else sum += __uint_as_float(bits);
+                         });
+        if (error) atomicOr(&result->error, error);
+        sums[slot] = sum;
+        return;
+    }
+    constexpr uint32_t PER_LANE = MV_SUM_CHUNK / MDB_WAVE;
+    const float *__restrict__ v = values + seg.out_offset;
+    const uint32_t n = seg.n_model;
+    float fetched[PER_LANE];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (uint32_t j = 0; j < PER_LANE; j++) {
+            const uint32_t k = base + j * MDB_WAVE + lane;
+            fetched[j] = k < n ? v[k] : 0.0f;
+        }
+    };
+    auto hand_over = [&](uint32_t buffer) {
+        float *to = reinterpret_cast<float *>(chunk_lds[buffer]);
+#pragma unroll
+        for (uint32_t j = 0; j < PER_LANE; j++) to[j * MDB_WAVE + lane] = fetched[j];
+    };
+    fetch(0);
+    hand_over(0);
+    __syncthreads();
+    float sum = 0.0f;
+    uint32_t buffer = 0;
+    for (uint32_t base = 0; base < n; base += MV_SUM_CHUNK, buffer ^= 1u) {
+        const bool more = base + MV_SUM_CHUNK < n;
+        if (more) fetch(base + MV_SUM_CHUNK);
+        if (lane == 0) {
+            const uint32_t count = min(MV_SUM_CHUNK, n - base);
+            const float4 *from = chunk_lds[buffer];
+            uint32_t k = 0;
+            if (base == 0) { // the sum starts AS the first value (macaque_v.rs:228-235)
+                const float *first = reinterpret_cast<const float *>(from);
+                sum = first[0];
+                for (k = 1; k < 4 && k < count; k++) sum += first[k];
+            }
+#pragma unroll 4
+            for (; k + 4 <= count; k += 4) {
+                const float4 q = from[k / 4];
+                sum += q.x;
+                sum += q.y;
+                sum += q.z;
+                sum += q.w;
+            }
+            const float *rest = reinterpret_cast<const float *>(from);
+            for (; k < count; k++) sum += rest[k];
+        }
+        if (more) hand_over(buffer ^ 1u);
+        __syncthreads();
+    }
+    if (lane == 0) sums[slot] = sum;
+}
+
+// One wave, fixed order: the result does not depend on how the work was scheduled.
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_sums_finish(const float *__restrict__ sums, uint64_t n_slots,
+                                                             DeferredResult *__restrict__ result) {
+    __shared__ double lanes[MDB_WAVE];
+    double sum = 0.0;
+    for (uint64_t slot = threadIdx.x; slot < n_slots; slot += MDB_WAVE) sum += (double)sums[slot];
+    lanes[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int lane = 0; lane < MDB_WAVE; lane++) total += lanes[lane];
+        result->sum = total;
+    }
+}
+
+uint32_t macaque_parallel_min_values(bool *forced) {
+    *forced = std::getenv("MDB_GRID_MV_MIN_VALUES") != nullptr;
+    return mv_min_values_setting();
+}
+
+// Adds up, per stream in f32 and then across streams in f64, the MacaqueV segments of the batch that
+// mv_qualifies() for min_values - the caller has counted them: n_streams streams, n_values values,
+// n_bytes bytes. *handled stays false when there are too many for the parallel decoder to pay off.
+int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values, bool forced, uint64_t n_streams,
+                         uint64_t n_values, uint64_t n_bytes, bool *handled, double *sum) {
+    *handled = false;
+    if (n_streams == 0 || n_values >= DEFERRED_ONE) return 0;
+    if (n_bytes * 8 / MV_PIECE_BITS + n_streams + 1 > MV_MAX_PIECES && !forced) return 0;
+    const uint64_t scan_bytes = align_up((s.n + 1) * 8, 256);
+    const uint64_t block_sums_bytes = align_up(scan_block_sums_bytes(s.n), 256);
+    const uint64_t values_bytes = align_up(n_values * 4, 256);
+    const uint64_t sums_bytes = align_up(n_streams * 4, 256);
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_AGG_MV, scan_bytes + block_sums_bytes + values_bytes + sums_bytes + 256, &p))
+        return 1;
+    uint8_t *at = static_cast<uint8_t *>(p);
+    unsigned long long *scan = reinterpret_cast<unsigned long long *>(at);
+    at += scan_bytes;
+    unsigned long long *block_sums = reinterpret_cast<unsigned long long *>(at);
+    at += block_sums_bytes;
+    float *values = reinterpret_cast<float *>(at);
+    at += values_bytes;
+    float *sums = reinterpret_cast<float *>(at);
+    at += sums_bytes;
+    DeferredResult *result = reinterpret_cast<DeferredResult *>(at);
+    MDB_HIP_CHECK(hipMemsetAsync(result, 0, sizeof(DeferredResult), ctx->stream));
+    if (device_exclusive_scan(ctx, DeferredItem{s, min_values}, s.n, scan, block_sums, "k_mv_deferred_scan")) return 1;
+    auto select = [&](MvSeg *segs) {
+        LaunchTimer timer(ctx, "k_mv_select");
+        hipLaunchKernelGGL(k_mv_select_scanned, dim3((uint32_t)((s.n + 255) / 256)), dim3(256), 0, ctx->stream, s,
+                           scan, min_values, segs);
+    };
+    MvSeg *segs = nullptr;
+    if (mv_pipeline(ctx, n_streams, n_bytes, forced, select, values, &result->error, &segs)) return 1;
+    if (!segs) return 0;
+    {
+        LaunchTimer timer(ctx, "k_mv_sums");
+        hipLaunchKernelGGL(k_mv_sums, dim3((uint32_t)n_streams), dim3(MDB_WAVE), 0, ctx->stream, segs, n_streams,
+                           values, sums, result);
+        hipLaunchKernelGGL(k_mv_sums_finish, dim3(1), dim3(MDB_WAVE), 0, ctx->stream, sums, n_streams, result);
+    }
+    DeferredResult host;
+    MDB_HIP_CHECK(hipMemcpyAsync(&host, result, sizeof(DeferredResult), hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipGetLastError());
+    if (host.error) return fail(describe_error(host.error));
+    *handled = true;
+    *sum = host.sum;
     return 0;
 }
 

@@ -45,10 +45,6 @@
 
 namespace mdb {
 
-#ifndef MDB_MV_PIECE_BITS
-#define MDB_MV_PIECE_BITS 4096
-#endif
-constexpr uint32_t MV_PIECE_BITS = MDB_MV_PIECE_BITS;
 constexpr int MV_CHAINS = 4; // speculative chains kept per piece
 constexpr int MV_HEAD = 4;   // boundaries recorded per chain
 constexpr uint32_t MV_SCAN_BITS = 256;    // `11` patterns are looked for this far into a piece
@@ -66,13 +62,8 @@ constexpr uint32_t MV_SETTLE_CODES = 8;   // codes after which a guessed chain i
 constexpr uint32_t MV_NO_WINDOW = 0xffffu;
 constexpr uint32_t MV_NO_LENGTH = 0xffu;
 constexpr uint32_t MV_MAX_TAIL_BITS = 16 * MV_PIECE_BITS;
-constexpr uint32_t MV_MAX_STREAM_BYTES = 1u << 27; // bit positions stay below 2^30
 constexpr uint32_t MV_NONE = 0xffffffffu; // link: no partner found
 constexpr uint32_t MV_END = 0xfffffffeu;  // link: parsed to the end of the stream
-constexpr uint32_t MV_DEFAULT_MIN_VALUES = 1024;
-// More pieces than this in one batch: there are enough streams to keep the GPU busy with one lane
-// per stream, which does a third of the work per value.
-constexpr uint64_t MV_MAX_PIECES = 131072;
 
 // One stream that qualifies (indexed like serial_ids).
 struct MvSeg {
@@ -136,15 +127,6 @@ struct MvPieceCount {
     const MvSeg *segs;
     __device__ uint64_t operator()(uint64_t slot) const { return segs[slot].n_pieces; }
 };
-
-// Should this segment's values go through the parallel decoder? Evaluated identically by the
-// prepass (to bound the scratch memory) and by k_mv_select.
-__device__ __forceinline__ bool mv_qualifies(const SegInfo &info, uint32_t values_bytes, uint32_t min_values) {
-    const SegDesc &d = info.desc;
-    return min_values != 0xffffffffu && !info.error && (d.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID &&
-           !(d.flags & FLAG_HAS_RESIDUALS) && d.n_model >= min_values && d.n_visible > 0 &&
-           values_bytes > 12 && values_bytes < MV_MAX_STREAM_BYTES;
-}
 
 // Random-access reader: bits [pos, pos + count) of the stream, MSB first, zeros past the end.
 // A lane's 64 neighbours read pieces that lie MV_PIECE_BITS apart, so a word load per code would
@@ -316,17 +298,10 @@ __device__ __forceinline__ uint32_t mv_slot_of(const unsigned long long *piece_b
     return (uint32_t)lo;
 }
 
-// ---- k_mv_select: one lane per entry of the serial list -----------------------------------------------
-
-__global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange range,
-                                                   const unsigned long long *__restrict__ offsets,
-                                                   const uint32_t *__restrict__ serial_ids, uint64_t n_serial,
-                                                   uint32_t min_values, MvSeg *__restrict__ segs) {
-    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_serial) return;
-    const uint32_t i = serial_ids[slot];
-    SegInfo info = analyse_segment(s, i);
-    if (range.enabled) apply_time_range(s, i, info, range);
+// What the decoder needs to know about the stream of segment i: nothing (n_pieces 0) unless it
+// qualifies. out_offset: where the value of its first visible point goes.
+__device__ __forceinline__ MvSeg mv_describe(const DevSegments &s, uint64_t i, const SegInfo &info, uint32_t min_values,
+                                             unsigned long long out_offset) {
     const uint4 view = s.values.views[i];
     MvSeg seg;
     seg.words = nullptr;
@@ -345,10 +320,24 @@ __global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange rang
         seg.n_model = info.desc.n_model;
         seg.first = info.desc.first;
         seg.visible_end = info.desc.first + info.desc.n_visible;
-        seg.out_offset = offsets[i];
+        seg.out_offset = out_offset;
         seg.n_pieces = (seg.total_bits + MV_PIECE_BITS - 1) / MV_PIECE_BITS;
     }
-    segs[slot] = seg;
+    return seg;
+}
+
+// ---- k_mv_select: one lane per entry of the serial list -----------------------------------------------
+
+__global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange range,
+                                                   const unsigned long long *__restrict__ offsets,
+                                                   const uint32_t *__restrict__ serial_ids, uint64_t n_serial,
+                                                   uint32_t min_values, MvSeg *__restrict__ segs) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_serial) return;
+    const uint32_t i = serial_ids[slot];
+    SegInfo info = analyse_segment(s, i);
+    if (range.enabled) apply_time_range(s, i, info, range);
+    segs[slot] = mv_describe(s, i, info, min_values, offsets[i]);
 }
 
 #ifdef MDB_MV_DEBUG

@@ -506,4 +506,32 @@ inline std::string describe_error(uint32_t error) {
     return message;
 }
 
+// ---- which MacaqueV streams go through the parallel decoder (mdb_macaque_parallel.hpp) ----------------
+
+#ifndef MDB_MV_PIECE_BITS
+#define MDB_MV_PIECE_BITS 4096
+#endif
+constexpr uint32_t MV_PIECE_BITS = MDB_MV_PIECE_BITS; // a stream is cut into pieces of this many bits
+constexpr uint32_t MV_MAX_STREAM_BYTES = 1u << 27; // bit positions stay below 2^30
+constexpr uint32_t MV_DEFAULT_MIN_VALUES = 1024;
+// More pieces than this in one batch: there are enough streams to keep the GPU busy with one lane
+// per stream, which does a third of the work per value.
+constexpr uint64_t MV_MAX_PIECES = 131072;
+
+// Should this segment's values go through the parallel decoder? Evaluated identically by whoever
+// bounds the scratch memory (k_grid_prepass, k_agg_segments) and by the kernels that select streams.
+__device__ __forceinline__ bool mv_qualifies(const SegInfo &info, uint32_t values_bytes, uint32_t min_values) {
+    const SegDesc &d = info.desc;
+    return min_values != 0xffffffffu && !info.error && (d.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID &&
+           !(d.flags & FLAG_HAS_RESIDUALS) && d.n_model >= min_values && d.n_visible > 0 &&
+           values_bytes > 12 && values_bytes < MV_MAX_STREAM_BYTES;
+}
+
+// The same for SUM, whose length is len()'s (models/mod.rs:98-124: a regular stream reports its STORED
+// length): only streams for which that is also the number of values grid() would produce.
+__device__ __forceinline__ bool mv_qualifies_for_sum(const SegInfo &info, uint32_t values_bytes, uint32_t min_values) {
+    const uint32_t length = (info.desc.flags & FLAG_REGULAR) ? info.regular_length : info.desc.n_total;
+    return mv_qualifies(info, values_bytes, min_values) && length == info.desc.n_model;
+}
+
 } // namespace mdb

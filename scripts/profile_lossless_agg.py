@@ -7,9 +7,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import modelardb_rs_amd as mdb  # noqa: E402
 
+def config_1(ctx, eb):
+    """BASELINE configs[0] as an aggregate query: one series, 16 streams of 65 536 values."""
+    import datagen
+    n = 1_000_000
+    ts, v = datagen.sine_series(0, n)
+    offsets = np.arange(0, n + 65536, 65536, dtype=np.uint64)
+    offsets[-1] = n
+    dev = ctx.upload_segments(ctx.compress_chunks(ts, v, offsets, eb))
+    for setting in ("off", None):
+        if setting is None:
+            os.environ.pop("MDB_GRID_MV_MIN_VALUES", None)
+        else:
+            os.environ["MDB_GRID_MV_MIN_VALUES"] = setting
+        ctx.agg_batch_dev(dev, 15)
+        ctx.profile_enable(True); ctx.profile_reset(); ctx.sync(); t0 = time.perf_counter()
+        for _ in range(5):
+            state = ctx.agg_batch_dev(dev, 15)
+        ctx.sync(); dt = (time.perf_counter() - t0) / 5
+        kernels = {k: round(x[1] / x[0], 3) for k, x in ctx.profile().items() if x[1] / x[0] > 0.05}
+        ctx.profile_enable(False)
+        print(f"config 1 SUM, parallel decoder {setting or 'default'}: {dt*1e3:.2f} ms, sum {state.sum!r} {kernels}", flush=True)
+    dev.free()
+
+
 def main():
     ctx = mdb.Context(0)
     eb = mdb.error_bound("lossless")
+    config_1(ctx, eb)
     for series, points, chunk in ((20000, 20000, 2000), (2000, 200_000, 65536)):
         total = series * points
         values = ctx.dev_alloc(4 * total)

@@ -18,6 +18,18 @@ ALL = MDB_AGG_COUNT | MDB_AGG_MIN | MDB_AGG_MAX | MDB_AGG_SUM
 SUM_TOLERANCE = 1e-5  # 0.001 %
 
 
+@pytest.fixture(autouse=True, params=[None, "off", "8"], ids=["mv-default", "mv-off", "mv-from-8-values"])
+def macaque_decoder(request, monkeypatch):
+    """SUM leaves long MacaqueV streams to the parallel decoder (macaque_deferred_sum in mdb_grid.hip):
+    every test runs with its default threshold, with it switched off and with every stream of at
+    least 8 values going that way."""
+    if request.param is None:
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+    else:
+        monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
+    return request.param
+
+
 def _assert_state(got, expected):
     assert got.count == expected.count
     assert np.float32(got.min) == np.float32(expected.min)
@@ -48,6 +60,34 @@ def test_aggregates_continue_a_running_state(hip):
     state = hip.agg_batch(first, ALL)
     state = hip.agg_batch(second, ALL, state)
     _assert_state(state, ora.agg_batch(batch, ALL))
+
+
+def test_sum_of_long_lossless_streams(hip, macaque_decoder, monkeypatch):
+    # BASELINE configs[0] as an aggregate query: 16 MacaqueV streams of 65 536 values. Each stream is
+    # added up in f32 in stream order whoever decodes it (macaque_v.rs:220-265), so the two ways must
+    # agree to the rounding of a handful of f64 additions.
+    import datagen
+    n = 1_000_000
+    timestamps, values = datagen.sine_series(3, n)
+    offsets = np.arange(0, n + 65536, 65536, dtype=np.uint64)
+    offsets[-1] = n
+    segments = hip.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
+    assert set(segments.model_type_id.tolist()) == {2}
+    hip.profile_enable(True)
+    hip.profile_reset()
+    state = hip.agg_batch(segments, ALL)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert ("k_mv_sums" in kernels) == (macaque_decoder != "off")
+    _assert_state(state, ora.agg_batch(segments, ALL))
+    per_stream = 0.0
+    for k in range(len(offsets) - 1):
+        per_stream += float(np.add.accumulate(values[int(offsets[k]):int(offsets[k + 1])], dtype=np.float32)[-1])
+    assert abs(state.sum - per_stream) <= 1e-12 * abs(per_stream)
+    monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", "off")
+    serial = hip.agg_batch(segments, ALL)
+    assert abs(state.sum - serial.sum) <= 1e-12 * abs(serial.sum)
+    assert (state.count, state.min, state.max) == (serial.count, serial.min, serial.max)
 
 
 def test_aggregates_three_point_series(hip):
