@@ -46,6 +46,13 @@ const char *mdb_last_error(void);
 const char *mdb_version(void);
 /* Use an externally created hipStream_t (e.g. torch's current stream) instead of the context's. */
 int mdb_set_stream(mdb_ctx *ctx, void *hip_stream);
+/* Give back the working memory the context has grown for the batches seen so far (device scratch,
+ * page-locked staging and the recycled result blocks); the next call grows what it needs again.
+ * A context keeps this memory between calls because allocating is slow - a fit of 10^10 points
+ * leaves tens of GB behind - so a long-lived owner calls this after an unusually large batch.
+ * released_bytes (may be NULL): device bytes given back. Results and segments already handed out
+ * stay valid. */
+int mdb_trim(mdb_ctx *ctx, uint64_t *released_bytes);
 /* Name, CU count, HBM bytes of the context's device. */
 int mdb_device_info(mdb_ctx *ctx, char *name, uint64_t name_cap, int32_t *compute_units,
                     uint64_t *hbm_bytes);

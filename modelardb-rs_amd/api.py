@@ -80,6 +80,12 @@ class Context:
     def set_stream(self, hip_stream):
         self._check(self.lib.mdb_set_stream(self.handle, C.c_void_p(hip_stream)))
 
+    def trim(self):
+        """Give back the scratch / staging memory the context has grown; returns the device bytes."""
+        released = C.c_uint64()
+        self._check(self.lib.mdb_trim(self.handle, C.byref(released)))
+        return released.value
+
     # ---- device memory -----------------------------------------------------------------------
 
     def dev_alloc(self, nbytes):

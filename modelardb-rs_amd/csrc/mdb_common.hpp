@@ -80,6 +80,7 @@ struct PinnedPool {
     std::vector<std::pair<void *, uint64_t>> blocks;
     int take(uint64_t bytes, void **out, uint64_t *capacity);
     void give(void *block, uint64_t capacity);
+    void trim();  // frees the recycled blocks
     void close();
 };
 

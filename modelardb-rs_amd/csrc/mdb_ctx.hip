@@ -85,6 +85,12 @@ void PinnedPool::give(void *block, uint64_t capacity) {
     blocks.push_back({block, capacity});
 }
 
+void PinnedPool::trim() {
+    std::lock_guard<std::mutex> lock(mutex);
+    for (auto &block : blocks) (void)hipHostFree(block.first);
+    blocks.clear();
+}
+
 void PinnedPool::close() {
     std::lock_guard<std::mutex> lock(mutex);
     closed = true;
@@ -178,6 +184,29 @@ int mdb_close(mdb_ctx *ctx) {
     ctx->pinned_pool->close();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return 0;
+}
+
+int mdb_trim(mdb_ctx *ctx, uint64_t *released_bytes) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    uint64_t released = 0;
+    for (int i = 0; i < SCRATCH_SLOT_COUNT; i++) {
+        if (!ctx->scratch[i]) continue;
+        MDB_HIP_CHECK(hipFree(ctx->scratch[i]));
+        released += ctx->scratch_bytes[i];
+        ctx->scratch[i] = nullptr;
+        ctx->scratch_bytes[i] = 0;
+    }
+    if (ctx->pinned) {
+        MDB_HIP_CHECK(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    ctx->pinned_pool->trim();
+    if (released_bytes) *released_bytes = released;
     return 0;
 }
 

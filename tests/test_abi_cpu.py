@@ -60,6 +60,7 @@ def test_null_arguments_are_errors_not_crashes():
     assert library.mdb_grid_count(None, None, None) == 1
     assert b"NULL" in library.mdb_last_error()
     assert library.mdb_init(0, None) == 1
+    assert library.mdb_trim(None, None) == 1
     assert library.mdb_close(None) == 0
 
 

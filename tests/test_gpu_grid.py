@@ -355,6 +355,23 @@ def test_owned_grid_results_in_page_locked_memory(hip):
     assert len(empty[0]) == 0 and len(empty[2]) == 0
 
 
+def test_trim_gives_memory_back_and_the_context_keeps_working(hip):
+    eb = cases.error_bounds()["rel5"]
+    _, _, batch = cases.mixed_batch(eb, False, seed=31)
+    before = hip.grid_batch(batch)
+    owned = hip.grid_batch_owned(batch, copy=False)  # a result handed out before the trim stays valid
+    state = hip.agg_batch(batch, mdb.MDB_AGG_SUM | mdb.MDB_AGG_COUNT)
+    assert hip.trim() > 0
+    assert hip.trim() == 0
+    assert np.array_equal(owned[1].view(np.uint32), before[1].view(np.uint32))
+    owned[4]()
+    after = hip.grid_batch(batch)
+    assert np.array_equal(after[0], before[0])
+    assert np.array_equal(after[1].view(np.uint32), before[1].view(np.uint32))
+    again = hip.agg_batch(batch, mdb.MDB_AGG_SUM | mdb.MDB_AGG_COUNT)
+    assert (again.sum, again.count) == (state.sum, state.count)
+
+
 def test_concurrent_calls_from_several_threads(hip):
     # DataFusion polls GridStreams from tokio worker threads (SURVEY 8(b) "Threading"): calls on ONE
     # context are serialised inside the library, separate contexts run side by side. ctypes releases
