@@ -339,6 +339,7 @@ struct RingBitReader {
     uint32_t skip_bits; // slack bits in front of the first payload byte
     uint64_t used_bits;
     uint64_t total_bits;
+    uint32_t ahead;     // refill(): ring word next_word, byte swapped
 
     __device__ __forceinline__ void begin(const uint8_t *bytes, uint64_t nbytes) {
         uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
@@ -352,6 +353,7 @@ struct RingBitReader {
         skip_bits = 8u * misalign;
         used_bits = 0;
         total_bits = nbytes * 8u;
+        ahead = 0;
     }
     __device__ __forceinline__ bool hungry() const { return loaded < n_words && loaded - next_word < 3; }
     __device__ __forceinline__ void pull(const uint32_t (*ring)[MDB_WAVE], int lane) {
@@ -377,6 +379,32 @@ struct RingBitReader {
         used_bits += count;
         return value;
     }
+    // The same without branches (64 lanes that each stand somewhere else in a code execute both sides
+    // of every branch anyway): at most one word, so a caller that needs up to 45 bits refills before
+    // the control bits and again before the payload. Needs 0 <= available while words remain, which
+    // holds from the second refill of a stream on (the first word may bring as few as 8 bits).
+    // The word comes out of a register (`ahead` = ring word next_word, see look_ahead) so that no LDS
+    // latency sits on the chain from one code to the next.
+    __device__ __forceinline__ void refill(const uint32_t (*ring)[MDB_WAVE], int lane) {
+        const bool want = available <= 32 && next_word < loaded;
+        const uint64_t placed = (((uint64_t)ahead << 32) << skip_bits) >> (available & 63);
+        buffer |= want ? placed : 0ull;
+        available += want ? 32 - (int32_t)skip_bits : 0;
+        skip_bits = want ? 0u : skip_bits;
+        next_word += want ? 1u : 0u;
+        look_ahead(ring, lane);
+    }
+    // Ring slot of next_word, read whether or not it has been filled yet: it is not used before it has
+    // (refill() tests next_word < loaded), and a stream that starts calls this again after its first
+    // top-up. A top-up never overwrites the slots [next_word, loaded).
+    __device__ __forceinline__ void look_ahead(const uint32_t (*ring)[MDB_WAVE], int lane) {
+        ahead = __builtin_bswap32(ring[next_word % SERIAL_RING_WORDS][lane]);
+    }
+    __device__ __forceinline__ void consume(uint32_t count) {
+        buffer <<= count;
+        available -= (int32_t)count;
+        used_bits += count;
+    }
     __device__ __forceinline__ bool overrun() const { return used_bits > total_bits; }
 };
 
@@ -386,6 +414,7 @@ struct MacaqueStream {
     uint32_t last;       // bits of the previous value
     uint32_t leading, trailing;
     bool first_is_raw;   // the next value is stored as 32 raw bits (macaque_v.rs:289-293)
+    bool fresh;          // nothing has been read from the stream yet
 };
 
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
@@ -472,7 +501,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     reader.begin(nullptr, 0);
     MacaqueStream stream;
     stream.remaining = 0; stream.position = 0; stream.last = __float_as_uint(d.value);
-    stream.leading = 255; stream.trailing = 0; stream.first_is_raw = false;
+    stream.leading = 255; stream.trailing = 0; stream.first_is_raw = false; stream.fresh = false;
     bool active = false;
     auto open_next_stream = [&]() {
         if (values_pending) {
@@ -481,6 +510,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
             if (vv.x == 0) error |= ERR_BITSTREAM;
             stream.remaining = values_to_decode; stream.position = 0; stream.leading = 255; stream.trailing = 0;
             stream.first_is_raw = true;
+            stream.fresh = true;
             values_pending = false;
             active = vv.x != 0;
         } else if (residuals_pending) {
@@ -492,6 +522,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
             stream.remaining = visible_end - d.n_model; stream.position = d.n_model;
             stream.leading = 255; stream.trailing = 0;
             stream.first_is_raw = false;
+            stream.fresh = true;
             residuals_pending = false;
             active = vr.x >= 2;
         } else {
@@ -518,50 +549,43 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
             reader.loaded = min(reader.n_words, first + min(room, (uint32_t)SERIAL_TOPUP_WORDS));
         }
         if (active) {
-            // One value (macaque_v.rs:297-322) is at most 2 + 5 + 6 + 32 = 45 bits. After pull() the
-            // bit buffer holds > 32 bits and the ring >= 64 more, so control bits, window and payload
-            // are peeled off the top of the 64-bit buffer with one refill per field group instead of
-            // one reader call per field.
-            uint32_t bits;
-            reader.pull(ring, lane);
-            if (stream.first_is_raw) {
-                bits = reader.get(32, ring, lane);
-                stream.first_is_raw = false;
-            } else {
-                const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
-                bits = stream.last;
-                uint32_t header_bits, meaningful;
-                bool decode_value = true;
-                if ((top >> 12) == 0) {          // `0`: reuse the previous window
-                    header_bits = 1;
-                    meaningful = 32u - stream.leading - stream.trailing;
-                } else if ((top >> 11) == 2) {   // `10`: the value repeats
-                    header_bits = 2;
-                    meaningful = 0;
-                    decode_value = false;
-                } else {                         // `11` + 5 bits leading zeros + 6 bits length
-                    header_bits = 13;
-                    stream.leading = (top >> 6) & 31u;
-                    meaningful = top & 63u;
-                    stream.trailing = 32u - meaningful - stream.leading;
-                }
-                if (decode_value && (meaningful > 32u || stream.trailing > 31u)) {
-                    error |= ERR_BITSTREAM; // malformed stream: stop after this value
-                    meaningful = 0;
-                    decode_value = false;
-                    stream.remaining = 1;
-                    values_pending = false;
-                    residuals_pending = false;
-                }
-                reader.buffer <<= header_bits;
-                reader.available -= (int32_t)header_bits;
-                reader.used_bits += header_bits;
-                if (decode_value) {
-                    uint32_t value = reader.get(meaningful, ring, lane);
-                    value <<= (stream.trailing & 31u);
-                    bits = value ^ stream.last;
-                }
+            // One value (macaque_v.rs:297-322): `10` it repeats, `0` + the bits of the previous window,
+            // `11` + 5 bits leading zeros + 6 bits length + the bits - at most 45 bits, of which the
+            // control bits come off the top of the 64-bit buffer after one refill and the payload after
+            // another. Every lane of the wave stands at a different kind of code, so the three cases
+            // are computed with selects rather than branched to; only a malformed stream branches.
+            if (stream.fresh) {
+                reader.look_ahead(ring, lane);
+                reader.refill(ring, lane);
+                stream.fresh = false;
             }
+            reader.refill(ring, lane);
+            const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
+            const bool raw = stream.first_is_raw;                 // 32 raw bits, no control bits
+            const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
+            const bool opens = !raw && c0 && c1;
+            const bool repeats = !raw && c0 && !c1;
+            const uint32_t header_bits = raw ? 0u : (c0 ? (c1 ? 13u : 2u) : 1u);
+            const uint32_t leading = opens ? ((top >> 6) & 31u) : stream.leading;
+            const uint32_t trailing = opens ? 32u - (top & 63u) - leading : stream.trailing;
+            uint32_t meaningful = 32u - leading - trailing;
+            bool silent = repeats; // no payload: the value is the previous one
+            if (!raw && !repeats && (meaningful > 32u || trailing > 31u)) {
+                error |= ERR_BITSTREAM; // malformed stream: stop after this value
+                silent = true;
+                stream.remaining = 1;
+                values_pending = false;
+                residuals_pending = false;
+            }
+            stream.leading = leading;
+            stream.trailing = trailing;
+            stream.first_is_raw = false;
+            meaningful = raw ? 32u : (silent ? 0u : meaningful);
+            reader.consume(header_bits);
+            reader.refill(ring, lane);
+            const uint32_t payload = (uint32_t)((reader.buffer >> 1) >> (63u - meaningful)); // 0 bits: 0
+            reader.consume(meaningful);
+            const uint32_t bits = raw ? payload : (stream.last ^ (payload << (trailing & 31u)));
             stream.last = bits;
             if (stream.position >= d.first && stream.position < visible_end)
                 out_val[o + (stream.position - d.first)] = __uint_as_float(bits);
