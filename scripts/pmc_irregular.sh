@@ -1,15 +1,17 @@
 #!/bin/bash
 # Hardware counters of the irregular-timestamp grid path (development tool; run via gpurun).
+# One counter group per pass, each under its own timeout: a pass with FETCH_SIZE and WRITE_SIZE
+# together once aborted and then sat there until gpurun killed it.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_irr_a -o a -- python3 $ROOT/scripts/profile_irregular.py > $OUT/pmc_irr_a.log 2>&1
+timeout 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_irr_a -o a -- python3 $ROOT/scripts/profile_irregular.py > $OUT/pmc_irr_a.log 2>&1
 echo "a rc=$?"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_irr_b -o b -- python3 $ROOT/scripts/profile_irregular.py > $OUT/pmc_irr_b.log 2>&1
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_irr_b -o b -- python3 $ROOT/scripts/profile_irregular.py > $OUT/pmc_irr_b.log 2>&1
 echo "b rc=$?"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_irr_c -o c -- python3 $ROOT/scripts/profile_irregular.py > $OUT/pmc_irr_c.log 2>&1
+timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_irr_c -o c -- python3 $ROOT/scripts/profile_irregular.py > $OUT/pmc_irr_c.log 2>&1
 echo "c rc=$?"
 python3 - <<'PY'
 import csv, collections, os
