@@ -8,11 +8,11 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o trace -- python3 $ROOT/bench.py $BENCH_ARGS > $OUT/prof_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -o trace -- python3 $ROOT/bench.py $BENCH_ARGS > $OUT/prof_trace.log 2>&1
 echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o fetch -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o fetch -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
 echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write.log 2>&1
 echo "write rc=$?"
 ls -R $OUT | head -50
 # keep only the small summaries (the per-dispatch trace of 3 steps is small too)
