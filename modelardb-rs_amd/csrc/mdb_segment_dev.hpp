@@ -282,8 +282,12 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
             for (int32_t k = 0; k < ts_len; k++) length = (length << 8) | view_inline_byte(vt, k);
             info.regular_length = (uint32_t)(length > COUNT_MASK ? COUNT_MASK : length);
             uint64_t span = (uint64_t)(end - start);
-            if (length < 2 || end < start) {
-                info.error |= ERR_TIMESTAMPS;
+            if (length < 2) {
+                info.error |= ERR_TIMESTAMPS; // the interval is a division by length - 1 (timestamps.rs:218-219)
+            } else if (end < start) {
+                // (start..=end).step_by(..) is an empty range: grid() produces no point for such a
+                // segment while len() still reports the stored length.
+                n_total = 0;
             } else {
                 uint64_t interval = span / (length - 1);
                 if (interval == 0) {
@@ -469,6 +473,9 @@ __device__ __forceinline__ void decode_macaque_v(const uint8_t *bytes, uint32_t 
         emit(emitted++, last);
     }
     while (emitted < count) {
+        // A stream shorter than its segment claims (a corrupted length can claim 2^31 values): every
+        // value takes at least one bit, so stopping here bounds the loop by the size of the stream.
+        if (r.overrun()) break;
         bool decode_value = true;
         if (r.get(1)) {
             if (r.get(1)) {

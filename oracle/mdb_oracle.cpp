@@ -569,6 +569,7 @@ bool macaque_v_decode(const uint8_t *bytes, uint64_t nbytes, uint64_t count, boo
         remaining_values -= 1;
     }
     for (uint64_t i = 0; i < remaining_values; i++) {
+        if (r.overrun) return false; /* the reference panics at the first bit past the end (bits.rs:61-82) */
         bool decode_value = true;
         if (r.bit()) {
             if (r.bit()) {

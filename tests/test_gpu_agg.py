@@ -105,6 +105,91 @@ def test_aggregates_edge_cases(hip):
         _assert_state(hip.agg_batch(batch, ALL), ora.agg_batch(batch, ALL))
 
 
+def test_fuzzed_segments_never_hang_and_agree_with_the_oracle(hip):
+    """Valid segments with random corruptions (truncated or random payloads, shifted times, wrong
+    model type), as in the grid test of the same name: an error or a result, never a crash or a
+    hang - a corrupted length can claim 2^31 values for a 12-byte stream - and whenever the oracle
+    accepts a batch (for aggregates and for grid) the GPU accepts it too and agrees."""
+    rng = np.random.default_rng(231)
+    pool = []
+    for eb_name in ("lossless", "rel5"):
+        pool += cases.edge_case_batch(cases.error_bounds()[eb_name]).rows()
+        for irregular in (False, True):
+            pool += cases.mixed_batch(cases.error_bounds()[eb_name], irregular, seed=232, length=3000)[2].rows()
+    agree = errors = 0
+    for trial in range(300):
+        rows = []
+        for _ in range(int(rng.integers(1, 6))):
+            row = list(pool[int(rng.integers(0, len(pool)))])
+            if rng.random() < 0.35:
+                field = int(rng.choice([0, 1, 2, 3, 6, 7]))
+                if field == 0:
+                    row[0] = int(rng.integers(0, 4))
+                elif field in (1, 2):
+                    row[field] = int(row[field] + rng.integers(-500, 500))
+                else:
+                    payload = bytearray(row[field])
+                    action = rng.integers(0, 3)
+                    if action == 0 and payload:
+                        payload = payload[: int(rng.integers(0, len(payload)))]
+                    elif action == 1 and payload:
+                        payload[int(rng.integers(0, len(payload)))] ^= 1 << int(rng.integers(0, 8))
+                    else:
+                        payload = bytearray(rng.integers(0, 256, size=int(rng.integers(0, 20)), dtype=np.uint8).tobytes())
+                    row[field] = bytes(payload)
+            rows.append(tuple(row))
+        batch = mdb.SegmentBatch.from_rows(rows)
+        try:
+            expected = ora.agg_batch(batch, ALL)
+            # len() and sum() look at less of a segment than grid() does (a regular segment whose
+            # length does not fit its time span counts and sums fine in the reference and panics in
+            # grid()); the library validates a segment the same way for both, so only batches that
+            # grid() accepts as well have to be accepted here.
+            if expected.count > 200_000:
+                continue
+            ora.grid_batch(batch)
+        except ora.OracleError:
+            expected = None
+        try:
+            got = hip.agg_batch(batch, ALL)
+        except mdb.HipError:
+            got = None
+        if expected is not None:
+            assert got is not None, rows
+            _assert_state(got, expected)
+            agree += 1
+        else:
+            errors += got is None
+    assert agree > 50 and errors > 20, (agree, errors)
+
+
+def test_a_stream_shorter_than_its_segment_claims_is_an_error_not_a_hang(hip):
+    # 2^31 - 1 values according to the timestamps column, 8 bytes of MacaqueV values.
+    good = ora.try_compress_univariate_time_series([100, 200, 300, 400, 500], [73.0, 37.0, 37.0, 37.0, 73.0], cases.LOSSLESS)
+    row = list(good.rows()[0])
+    assert row[0] == 2
+    count = (1 << 31) - 1
+    row[2] = row[1] + (count - 1) * 100
+    row[3] = count.to_bytes(4, "big")
+    batch = mdb.SegmentBatch.from_rows([tuple(row)])
+    with pytest.raises(ora.OracleError):
+        ora.agg_batch(batch, ALL)
+    with pytest.raises(mdb.HipError, match="MacaqueV"):
+        hip.agg_batch(batch, ALL)
+    assert hip.agg_batch(batch, MDB_AGG_COUNT).count == count  # len() never looks at the values
+
+
+def test_a_regular_segment_that_ends_before_it_starts(hip):
+    # (start..=end).step_by(..) is empty (timestamps.rs:218-222), so grid() yields nothing, while len()
+    # reports the stored length and pmc_mean::sum multiplies by it: the library follows both.
+    batch = mdb.SegmentBatch.from_rows([(0, 280, 70, b"\x08", 5.0, 5.0, b"", b"")])
+    expected = ora.agg_batch(batch, ALL)
+    assert (expected.count, expected.sum) == (8, 40.0)
+    _assert_state(hip.agg_batch(batch, ALL), expected)
+    assert len(ora.grid_batch(batch)[0]) == 0
+    assert len(hip.grid_batch(batch)[0]) == 0
+
+
 def test_aggregates_empty_batch(hip):
     state = hip.agg_batch(mdb.SegmentBatch.from_rows([]), ALL)
     fresh = mdb._abi.AggStateC.fresh()
