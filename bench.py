@@ -89,9 +89,13 @@ def eb_for(args, mdb):
 
 
 def barrier_and_sync(context, dist):
+    """Both sides of the timed region: this rank's launch stream drained, every rank arrived, and
+    (the barrier is a collective on torch's stream) torch's streams drained too."""
     context.sync()
     if dist is not None:
+        import torch
         dist.barrier()
+        torch.cuda.synchronize()
     context.sync()
 
 
