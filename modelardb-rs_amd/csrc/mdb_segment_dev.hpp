@@ -523,7 +523,7 @@ constexpr uint32_t MV_MAX_STREAM_BYTES = 1u << 27; // bit positions stay below 2
 constexpr uint32_t MV_DEFAULT_MIN_VALUES = 1024;
 // More pieces than this in one batch: there are enough streams to keep the GPU busy with one lane
 // per stream, which does a third of the work per value.
-constexpr uint64_t MV_MAX_PIECES = 131072;
+constexpr uint64_t MV_MAX_PIECES = (1ull << 29) / MV_PIECE_BITS; // 2^29 bits of streams
 
 // Should this segment's values go through the parallel decoder? Evaluated identically by whoever
 // bounds the scratch memory (k_grid_prepass, k_agg_segments) and by the kernels that select streams.
