@@ -279,10 +279,13 @@ struct CountSink {
     __device__ __forceinline__ uint64_t bytes() const { return (bits + 7) >> 3; }
 };
 
+// Writes whole 4-byte words once the destination is 4-byte aligned (a payload starts at any byte):
+// every lane writes a stream of its own, so each store instruction of a wave touches 64 cache lines
+// whatever its width, and a byte at a time is four times as many of them.
 struct ByteSink {
     uint8_t *dst;
     uint64_t acc = 0;
-    uint32_t pending = 0; // < 8 between calls
+    uint32_t pending = 0; // < 32 between calls
     uint64_t written = 0;
     __device__ __forceinline__ explicit ByteSink(uint8_t *d) : dst(d) {}
     // count in [0, 32]
@@ -291,12 +294,24 @@ struct ByteSink {
         uint64_t masked = count == 32 ? (uint64_t)value : ((uint64_t)value & ((1ull << count) - 1ull));
         acc = (acc << count) | masked;
         pending += count;
+        while (pending >= 32) {
+            uint8_t *at = dst + written;
+            if ((reinterpret_cast<uintptr_t>(at) & 3u) == 0) {
+                *reinterpret_cast<uint32_t *>(at) = __builtin_bswap32((uint32_t)(acc >> (pending - 32)));
+                written += 4;
+                pending -= 32;
+            } else {
+                *at = (uint8_t)(acc >> (pending - 8));
+                written += 1;
+                pending -= 8;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(bool pad_with_ones) {
         while (pending >= 8) {
             dst[written++] = (uint8_t)(acc >> (pending - 8));
             pending -= 8;
         }
-    }
-    __device__ __forceinline__ void finish(bool pad_with_ones) {
         if (pending == 0) return;
         uint32_t pad = 8 - pending;
         uint32_t byte = (uint32_t)(acc << pad) & 0xffu;
@@ -428,8 +443,7 @@ __device__ __forceinline__ void encode_irregular_timestamps(Sink &sink, const Ch
     sink.put(1, 1);
     uint64_t last_timestamp = (uint64_t)t.at(a);
     uint64_t last_delta = 0;
-    for (uint32_t j = a + 1; j < b; j++) {
-        uint64_t current = (uint64_t)t.at(j);
+    auto encode = [&](uint64_t current) {
         uint64_t delta = current - last_timestamp;
         int64_t dod = (int64_t)(delta - last_delta);
         if (dod == 0) {
@@ -449,7 +463,19 @@ __device__ __forceinline__ void encode_irregular_timestamps(Sink &sink, const Ch
         }
         last_delta = delta;
         last_timestamp = current;
+    };
+    // Every lane walks a segment of its own, so a load is a trip to memory for the whole wave: AHEAD
+    // timestamps are fetched before any of them is encoded.
+    constexpr uint32_t AHEAD = 8;
+    uint32_t j = a + 1;
+    for (; j + AHEAD <= b; j += AHEAD) {
+        uint64_t fetched[AHEAD];
+#pragma unroll
+        for (uint32_t k = 0; k < AHEAD; k++) fetched[k] = (uint64_t)t.at(j + k);
+#pragma unroll
+        for (uint32_t k = 0; k < AHEAD; k++) encode(fetched[k]);
     }
+    for (; j < b; j++) encode((uint64_t)t.at(j));
 }
 
 // Length in bytes of compress_residual_timestamps(ts[a..=b]) and whether it is the regular form.
