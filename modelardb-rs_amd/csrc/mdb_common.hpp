@@ -303,21 +303,23 @@ struct WindowReaderDev {
     uint32_t n_words;
     uint32_t next_word; // next one to load into `ahead`
     uint64_t high, low; // bits [position, position + available) of the stream, MSB first
-    uint64_t ahead;
+    uint64_t ahead;     // the word after them, not byte swapped yet
     int32_t available;  // valid bits in (high, low): 65..128 whenever the caller looks
     uint64_t position;  // bits of the payload consumed
     uint64_t total_bits;
 
+    // As stored (little endian): the byte swap happens where the word is used, a few codes later, so
+    // that nothing has to wait for the load right behind it.
     __device__ __forceinline__ uint64_t load(uint32_t index) const {
-        return index < n_words ? __builtin_bswap64(words[index]) : 0ull;
+        return index < n_words ? words[index] : 0ull;
     }
     __device__ __forceinline__ void open(const uint8_t *bytes, uint64_t nbytes, uint32_t start_bit) {
         const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
         const uint32_t misalign = (uint32_t)(address & 7u);
         words = reinterpret_cast<const uint64_t *>(address - misalign);
         n_words = (uint32_t)((nbytes + misalign + 7u) >> 3);
-        high = load(0);
-        low = load(1);
+        high = __builtin_bswap64(load(0));
+        low = __builtin_bswap64(load(1));
         ahead = load(2);
         next_word = 3;
         available = 128;
@@ -342,8 +344,9 @@ struct WindowReaderDev {
         position += count;
         if (available <= 64) { // `low` is empty: the word loaded ahead becomes the low half
             const uint32_t fill = (uint32_t)available; // 33..64 valid bits in `high`
-            high |= fill < 64u ? ahead >> fill : 0ull;
-            low = fill < 64u ? ahead << (64u - fill) : ahead;
+            const uint64_t next = __builtin_bswap64(ahead);
+            high |= fill < 64u ? next >> fill : 0ull;
+            low = fill < 64u ? next << (64u - fill) : next;
             ahead = load(next_word++);
             available += 64;
         }
