@@ -604,24 +604,20 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
 // stored: one wave per such segment, coalesced reads of out_ts and writes of out_val
 // (swing.rs:304-319: (slope * t + intercept) as f32, in f64).
 __global__ __launch_bounds__(256) void k_grid_swing_irregular(
-    DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
-    const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const uint32_t *__restrict__ counts,
-    const uint32_t *__restrict__ irregular_totals, const uint32_t *__restrict__ irregular_first,
-    const int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const int64_t *__restrict__ out_ts,
+    float *__restrict__ out_val) {
     const uint64_t slot = (uint64_t)blockIdx.x * (blockDim.x / MDB_WAVE) + threadIdx.x / MDB_WAVE;
     if (slot >= n_serial) return;
     const int lane = threadIdx.x % MDB_WAVE;
     const uint32_t i = serial_ids[slot];
-    if ((view_inline_byte(s.timestamps.views[i], 0) & 0x80u) == 0 || (int32_t)s.timestamps.views[i].x <= 0) return;
-    if (s.model_type_id[i] != MDB_SWING_ID) return;
-    SegInfo info = analyse_segment(s, i, irregular_totals);
-    if (range.enabled) apply_time_range(s, i, info, range, irregular_first, counts);
-    const SegDesc &d = info.desc;
-    if (info.error || (d.flags & FLAG_REGULAR) || d.first >= d.n_model) return;
-    const uint32_t model_points = min(d.n_model - d.first, d.n_visible);
+    // The prepass has left what is needed in the segment's descriptor: the line, and how many of the
+    // visible points the model stands for.
+    const TileDesc t = desc[i];
+    if ((t.flags & FLAG_REGULAR) || (t.flags & FLAG_TYPE_MASK) != MDB_SWING_ID) return;
     const uint64_t o = offsets[i];
-    for (uint32_t k = lane; k < model_points; k += MDB_WAVE)
-        out_val[o + k] = (float)(d.slope * (double)out_ts[o + k] + d.intercept);
+    for (uint32_t k = lane; k < t.n_model; k += MDB_WAVE)
+        out_val[o + k] = (float)(t.slope * (double)out_ts[o + k] + t.intercept);
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -1042,9 +1038,8 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
     }
     if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
         LaunchTimer timer(ctx, "k_grid_swing_irregular");
-        hipLaunchKernelGGL(k_grid_swing_irregular, dim3((uint32_t)((n_serial + 3) / 4)), dim3(256), 0, ctx->stream, s,
-                           range, plan.offsets, plan.serial_ids, n_serial, plan.counts, plan.irregular_totals,
-                           plan.irregular_first, out_ts, out_val);
+        hipLaunchKernelGGL(k_grid_swing_irregular, dim3((uint32_t)((n_serial + 3) / 4)), dim3(256), 0, ctx->stream,
+                           plan.desc, plan.offsets, plan.serial_ids, n_serial, out_ts, out_val);
     }
     return 0;
 }
