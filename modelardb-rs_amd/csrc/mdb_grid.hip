@@ -417,6 +417,63 @@ struct MacaqueStream {
     bool fresh;          // nothing has been read from the stream yet
 };
 
+// Tops the ring of every lane of the wave up at once (the caller has found a hungry lane): independent
+// predicated loads first, then the LDS writes.
+__device__ __forceinline__ void ring_top_up(RingBitReader &reader, uint32_t (*ring)[MDB_WAVE], int lane, bool active) {
+    uint32_t fetched[SERIAL_TOPUP_WORDS];
+    const uint32_t first = reader.loaded;
+    const uint32_t room = active ? SERIAL_RING_WORDS - (reader.loaded - reader.next_word) : 0u;
+#pragma unroll
+    for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
+        const uint32_t index = first + k;
+        fetched[k] = ((uint32_t)k < room && index < reader.n_words) ? reader.words[index] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
+        const uint32_t index = first + k;
+        if ((uint32_t)k < room && index < reader.n_words) ring[index % SERIAL_RING_WORDS][lane] = fetched[k];
+    }
+    reader.loaded = min(reader.n_words, first + min(room, (uint32_t)SERIAL_TOPUP_WORDS));
+}
+
+// One value (macaque_v.rs:297-322): `10` it repeats, `0` + the bits of the previous window, `11` + 5
+// bits leading zeros + 6 bits length + the bits - at most 45 bits, of which the control bits come off
+// the top of the 64-bit buffer after one refill and the payload after another. Every lane of the wave
+// stands at a different kind of code, so the three cases are computed with selects rather than
+// branched to. Returns the bits of the value (stream.last is updated); *malformed: the window is
+// impossible, the value returned is the previous one and the caller stops.
+__device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, MacaqueStream &stream,
+                                                      const uint32_t (*ring)[MDB_WAVE], int lane, bool *malformed) {
+    if (stream.fresh) {
+        reader.look_ahead(ring, lane);
+        reader.refill(ring, lane);
+        stream.fresh = false;
+    }
+    reader.refill(ring, lane);
+    const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
+    const bool raw = stream.first_is_raw;                 // 32 raw bits, no control bits
+    const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
+    const bool opens = !raw && c0 && c1;
+    const bool repeats = !raw && c0 && !c1;
+    const uint32_t header_bits = raw ? 0u : (c0 ? (c1 ? 13u : 2u) : 1u);
+    const uint32_t leading = opens ? ((top >> 6) & 31u) : stream.leading;
+    const uint32_t trailing = opens ? 32u - (top & 63u) - leading : stream.trailing;
+    uint32_t meaningful = 32u - leading - trailing;
+    *malformed = !raw && !repeats && (meaningful > 32u || trailing > 31u);
+    const bool silent = repeats || *malformed; // no payload: the value is the previous one
+    stream.leading = leading;
+    stream.trailing = trailing;
+    stream.first_is_raw = false;
+    meaningful = raw ? 32u : (silent ? 0u : meaningful);
+    reader.consume(header_bits);
+    reader.refill(ring, lane);
+    const uint32_t payload = (uint32_t)((reader.buffer >> 1) >> (63u - meaningful)); // 0 bits: 0
+    reader.consume(meaningful);
+    const uint32_t bits = raw ? payload : (stream.last ^ (payload << (trailing & 31u)));
+    stream.last = bits;
+    return bits;
+}
+
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
@@ -532,61 +589,16 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     open_next_stream();
 
     while (__any(active)) {
-        if (__any(active && reader.hungry())) {
-            uint32_t fetched[SERIAL_TOPUP_WORDS];
-            const uint32_t first = reader.loaded;
-            const uint32_t room = active ? SERIAL_RING_WORDS - (reader.loaded - reader.next_word) : 0u;
-#pragma unroll
-            for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
-                const uint32_t index = first + k;
-                fetched[k] = ((uint32_t)k < room && index < reader.n_words) ? reader.words[index] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
-                const uint32_t index = first + k;
-                if ((uint32_t)k < room && index < reader.n_words) ring[index % SERIAL_RING_WORDS][lane] = fetched[k];
-            }
-            reader.loaded = min(reader.n_words, first + min(room, (uint32_t)SERIAL_TOPUP_WORDS));
-        }
+        if (__any(active && reader.hungry())) ring_top_up(reader, ring, lane, active);
         if (active) {
-            // One value (macaque_v.rs:297-322): `10` it repeats, `0` + the bits of the previous window,
-            // `11` + 5 bits leading zeros + 6 bits length + the bits - at most 45 bits, of which the
-            // control bits come off the top of the 64-bit buffer after one refill and the payload after
-            // another. Every lane of the wave stands at a different kind of code, so the three cases
-            // are computed with selects rather than branched to; only a malformed stream branches.
-            if (stream.fresh) {
-                reader.look_ahead(ring, lane);
-                reader.refill(ring, lane);
-                stream.fresh = false;
-            }
-            reader.refill(ring, lane);
-            const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
-            const bool raw = stream.first_is_raw;                 // 32 raw bits, no control bits
-            const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
-            const bool opens = !raw && c0 && c1;
-            const bool repeats = !raw && c0 && !c1;
-            const uint32_t header_bits = raw ? 0u : (c0 ? (c1 ? 13u : 2u) : 1u);
-            const uint32_t leading = opens ? ((top >> 6) & 31u) : stream.leading;
-            const uint32_t trailing = opens ? 32u - (top & 63u) - leading : stream.trailing;
-            uint32_t meaningful = 32u - leading - trailing;
-            bool silent = repeats; // no payload: the value is the previous one
-            if (!raw && !repeats && (meaningful > 32u || trailing > 31u)) {
-                error |= ERR_BITSTREAM; // malformed stream: stop after this value
-                silent = true;
+            bool malformed;
+            const uint32_t bits = ring_decode_value(reader, stream, ring, lane, &malformed);
+            if (malformed) {
+                error |= ERR_BITSTREAM; // stop after this value
                 stream.remaining = 1;
                 values_pending = false;
                 residuals_pending = false;
             }
-            stream.leading = leading;
-            stream.trailing = trailing;
-            stream.first_is_raw = false;
-            meaningful = raw ? 32u : (silent ? 0u : meaningful);
-            reader.consume(header_bits);
-            reader.refill(ring, lane);
-            const uint32_t payload = (uint32_t)((reader.buffer >> 1) >> (63u - meaningful)); // 0 bits: 0
-            reader.consume(meaningful);
-            const uint32_t bits = raw ? payload : (stream.last ^ (payload << (trailing & 31u)));
-            stream.last = bits;
             if (stream.position >= d.first && stream.position < visible_end)
                 out_val[o + (stream.position - d.first)] = __uint_as_float(bits);
             stream.position += 1;
@@ -932,19 +944,62 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_sums(const MvSeg *__restrict__ 
     if (lane == 0) sums[slot] = sum;
 }
 
-// One wave, fixed order: the result does not depend on how the work was scheduled.
-__global__ __launch_bounds__(MDB_WAVE) void k_mv_sums_finish(const float *__restrict__ sums, uint64_t n_slots,
-                                                             DeferredResult *__restrict__ result) {
-    __shared__ double lanes[MDB_WAVE];
-    double sum = 0.0;
-    for (uint64_t slot = threadIdx.x; slot < n_slots; slot += MDB_WAVE) sum += (double)sums[slot];
-    lanes[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double total = 0.0;
-        for (int lane = 0; lane < MDB_WAVE; lane++) total += lanes[lane];
-        result->sum = total;
+// The same sums when there are too many streams for the parallel decoder to pay off: one lane per
+// stream decodes (LDS ring, as k_grid_serial) and adds as it goes.
+__global__ __launch_bounds__(SERIAL_THREADS) void k_mv_serial_sums(const MvSeg *__restrict__ segs, uint64_t n_slots,
+                                                                  float *__restrict__ sums,
+                                                                  DeferredResult *__restrict__ result) {
+    __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    bool active = slot < n_slots;
+    RingBitReader reader;
+    reader.begin(nullptr, 0);
+    MacaqueStream stream;
+    stream.remaining = 0; stream.position = 0; stream.last = 0;
+    stream.leading = 255; stream.trailing = 0; stream.first_is_raw = true; stream.fresh = true;
+    if (active) {
+        const MvSeg seg = segs[slot];
+        reader.begin(reinterpret_cast<const uint8_t *>(seg.words) + seg.bias_bits / 8, seg.total_bits / 8);
+        stream.remaining = seg.n_model;
+        active = seg.n_model > 0 && seg.total_bits > 0;
     }
+    float sum = 0.0f;
+    uint32_t error = 0;
+    while (__any(active)) {
+        if (__any(active && reader.hungry())) ring_top_up(reader, ring, lane, active);
+        if (active) {
+            const bool first = stream.first_is_raw;
+            bool malformed;
+            const float value = __uint_as_float(ring_decode_value(reader, stream, ring, lane, &malformed));
+            sum = first ? value : sum + value; // the sum starts AS the first value (macaque_v.rs:228-235)
+            stream.remaining -= 1;
+            // A stream shorter than its segment claims ends the loop too: it is bounded by the bits
+            // there are, not by a (possibly corrupted) count.
+            if (malformed || reader.overrun()) error |= ERR_BITSTREAM;
+            if (malformed || reader.overrun() || stream.remaining == 0) active = false;
+        }
+    }
+    if (slot < n_slots) sums[slot] = sum;
+    if (error) atomicOr(&result->error, error);
+}
+
+// One workgroup, fixed order (strided partial sums, then a fixed tree): the result does not depend
+// on how the work was scheduled.
+constexpr int MV_FINISH_THREADS = 1024;
+
+__global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_sums_finish(const float *__restrict__ sums, uint64_t n_slots,
+                                                                      DeferredResult *__restrict__ result) {
+    __shared__ double partial[MV_FINISH_THREADS];
+    double sum = 0.0;
+    for (uint64_t slot = threadIdx.x; slot < n_slots; slot += MV_FINISH_THREADS) sum += (double)sums[slot];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int width = MV_FINISH_THREADS / 2; width > 0; width >>= 1) {
+        if ((int)threadIdx.x < width) partial[threadIdx.x] += partial[threadIdx.x + width];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) result->sum = partial[0];
 }
 
 uint32_t macaque_parallel_min_values(bool *forced) {
@@ -959,10 +1014,12 @@ int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values
                          uint64_t n_values, uint64_t n_bytes, bool *handled, double *sum) {
     *handled = false;
     if (n_streams == 0 || n_values >= DEFERRED_ONE) return 0;
-    if (n_bytes * 8 / MV_PIECE_BITS + n_streams + 1 > MV_MAX_PIECES && !forced) return 0;
+    // Few enough streams for the parallel decoder (the gate of mv_pipeline)? Then their values go to
+    // scratch memory first; otherwise a lane per stream decodes and adds in one go.
+    const bool parallel = n_bytes * 8 / MV_PIECE_BITS + n_streams + 1 <= MV_MAX_PIECES || forced;
     const uint64_t scan_bytes = align_up((s.n + 1) * 8, 256);
     const uint64_t block_sums_bytes = align_up(scan_block_sums_bytes(s.n), 256);
-    const uint64_t values_bytes = align_up(n_values * 4, 256);
+    const uint64_t values_bytes = parallel ? align_up(n_values * 4, 256) : 256;
     const uint64_t sums_bytes = align_up(n_streams * 4, 256);
     void *p = nullptr;
     if (scratch_reserve(ctx, SCRATCH_AGG_MV, scan_bytes + block_sums_bytes + values_bytes + sums_bytes + 256, &p))
@@ -985,13 +1042,23 @@ int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values
                            scan, min_values, segs);
     };
     MvSeg *segs = nullptr;
-    if (mv_pipeline(ctx, n_streams, n_bytes, forced, select, values, &result->error, &segs)) return 1;
-    if (!segs) return 0;
-    {
+    if (parallel && mv_pipeline(ctx, n_streams, n_bytes, forced, select, values, &result->error, &segs)) return 1;
+    if (segs) {
         LaunchTimer timer(ctx, "k_mv_sums");
         hipLaunchKernelGGL(k_mv_sums, dim3((uint32_t)n_streams), dim3(MDB_WAVE), 0, ctx->stream, segs, n_streams,
                            values, sums, result);
-        hipLaunchKernelGGL(k_mv_sums_finish, dim3(1), dim3(MDB_WAVE), 0, ctx->stream, sums, n_streams, result);
+    } else {
+        void *q = nullptr;
+        if (scratch_reserve(ctx, SCRATCH_MV, n_streams * sizeof(MvSeg), &q)) return 1;
+        segs = static_cast<MvSeg *>(q);
+        select(segs);
+        LaunchTimer timer(ctx, "k_mv_serial_sums");
+        hipLaunchKernelGGL(k_mv_serial_sums, dim3((uint32_t)((n_streams + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+                           dim3(SERIAL_THREADS), 0, ctx->stream, segs, n_streams, sums, result);
+    }
+    {
+        LaunchTimer timer(ctx, "k_mv_sums_finish");
+        hipLaunchKernelGGL(k_mv_sums_finish, dim3(1), dim3(MV_FINISH_THREADS), 0, ctx->stream, sums, n_streams, result);
     }
     DeferredResult host;
     MDB_HIP_CHECK(hipMemcpyAsync(&host, result, sizeof(DeferredResult), hipMemcpyDeviceToHost, ctx->stream));
