@@ -146,9 +146,10 @@ __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, c
     return model_sum + residuals_sum;
 }
 
-// How k_agg_segments treats the MacaqueV streams that qualify for the parallel decoder: add them up
-// like any other (ALL), leave them aside and count them (DEFER), or add up nothing but them, and
-// only their sums (ONLY_DEFERRED - what is run when leaving them aside turned out to be pointless).
+// How k_agg_segments treats the long MacaqueV streams (mv_qualifies_for_sum): add them up like any
+// other (ALL), leave them aside and count them for macaque_deferred_sum (DEFER), or add up nothing
+// but them, and only their sums (ONLY_DEFERRED - the way out when macaque_deferred_sum declines,
+// which it only does beyond 2^40 values).
 enum : uint32_t { AGG_SUM_ALL = 0, AGG_SUM_DEFER = 1, AGG_SUM_ONLY_DEFERRED = 2 };
 
 __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uint32_t which_mask, uint32_t mode,
@@ -455,13 +456,13 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     MDB_HIP_CHECK(hipGetLastError());
     if (host.error) return fail(describe_error(host.error));
     if (host.deferred > 0) {
-        // Long MacaqueV streams were left aside: through the parallel decoder if that pays off ...
+        // Long MacaqueV streams were left aside for the decoders of mdb_grid.hip ...
         bool handled = false;
         double sum = 0.0;
         if (macaque_deferred_sum(ctx, s, mv_min_values, mv_forced, host.deferred, host.deferred_values,
                                  host.deferred_bytes, &handled, &sum))
             return 1;
-        if (!handled) { // ... or one lane per stream after all
+        if (!handled) { // ... or, if those decline, one lane per stream here after all
             {
                 LaunchTimer timer(ctx, "k_agg_segments");
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,

@@ -1009,7 +1009,7 @@ uint32_t macaque_parallel_min_values(bool *forced) {
 
 // Adds up, per stream in f32 and then across streams in f64, the MacaqueV segments of the batch that
 // mv_qualifies() for min_values - the caller has counted them: n_streams streams, n_values values,
-// n_bytes bytes. *handled stays false when there are too many for the parallel decoder to pay off.
+// n_bytes bytes. *handled stays false only when the counts are beyond what the scan item can carry.
 int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values, bool forced, uint64_t n_streams,
                          uint64_t n_values, uint64_t n_bytes, bool *handled, double *sum) {
     *handled = false;
