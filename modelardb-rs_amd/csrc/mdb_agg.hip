@@ -163,7 +163,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
         if (mode == AGG_SUM_ONLY_DEFERRED) {
             if (s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
             SegInfo info = analyse_segment(s, i);
-            if (!mv_qualifies_for_sum(info, s.values.views[i].x, mv_min_values)) continue;
+            if (mv_deferred_values(s, i, info, mv_min_values, TimeRange{0, 0, 0}) == 0) continue;
             uint32_t error = 0;
             p.sum += (double)segment_sum(s, i, info, info.desc.n_model, &error);
             p.error |= error;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
         if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) p.count += length;
         if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) {
             error |= info.error;
-            if (mode == AGG_SUM_DEFER && !error && mv_qualifies_for_sum(info, s.values.views[i].x, mv_min_values)) {
+            if (mode == AGG_SUM_DEFER && !error && mv_deferred_values(s, i, info, mv_min_values, TimeRange{0, 0, 0}) != 0) {
                 p.deferred += 1;
                 p.deferred_values += length;
                 p.deferred_bytes += s.values.views[i].x;
@@ -396,16 +396,30 @@ __device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, 
     }
 }
 
-__global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_t t_lo, int64_t t_hi,
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_t t_lo, int64_t t_hi, uint32_t mode,
+                                                           uint32_t mv_min_values,
                                                            AggPartial *__restrict__ partials) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
+    const TimeRange range = {t_lo, t_hi, 1};
     for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
          i += (uint64_t)gridDim.x * AGG_THREADS) {
         // Cheap rejection on the two columns the reference prunes on (start_time / end_time).
         if (s.end_time[i] < t_lo || s.start_time[i] > t_hi) continue;
+        if (mode == AGG_SUM_ONLY_DEFERRED && s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
         SegInfo info = analyse_segment(s, i);
         uint32_t error = info.error;
+        // Long MacaqueV streams are left to the decoders of mdb_grid.hip (see AGG_SUM_DEFER).
+        const uint32_t deferred_values =
+            (mode != AGG_SUM_ALL && !error && s.model_type_id[i] == MDB_MACAQUE_V_ID)
+                ? mv_deferred_values(s, i, info, mv_min_values, range) : 0u;
+        if (mode == AGG_SUM_ONLY_DEFERRED && deferred_values == 0) continue;
+        if (mode == AGG_SUM_DEFER && deferred_values != 0) {
+            p.deferred += 1;
+            p.deferred_values += deferred_values;
+            p.deferred_bytes += s.values.views[i].x;
+            continue;
+        }
         if (!error) {
             RangeAcc acc;
             segment_range(s, i, info, t_lo, t_hi, acc, &error);
@@ -438,7 +452,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     if (range) {
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
-                           t_hi, partials);
+                           t_hi, AGG_SUM_DEFER, mv_min_values, partials);
     } else {
         LaunchTimer timer(ctx, "k_agg_segments");
         hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
@@ -458,12 +472,17 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     if (host.deferred > 0) {
         // Long MacaqueV streams were left aside for the decoders of mdb_grid.hip ...
         bool handled = false;
-        double sum = 0.0;
-        if (macaque_deferred_sum(ctx, s, mv_min_values, mv_forced, host.deferred, host.deferred_values,
-                                 host.deferred_bytes, &handled, &sum))
+        DeferredTotals totals;
+        const TimeRange time_range = {t_lo, t_hi, range ? 1 : 0};
+        if (macaque_deferred(ctx, s, time_range, mv_min_values, mv_forced, host.deferred, host.deferred_values,
+                             host.deferred_bytes, &handled, &totals))
             return 1;
         if (!handled) { // ... or, if those decline, one lane per stream here after all
-            {
+            if (range) {
+                LaunchTimer timer(ctx, "k_agg_range");
+                hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
+                                   t_hi, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials);
+            } else {
                 LaunchTimer timer(ctx, "k_agg_segments");
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
                                    which_mask, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials);
@@ -479,9 +498,17 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
             MDB_HIP_CHECK(hipGetLastError());
             if (late.error) return fail(describe_error(late.error));
-            sum = late.sum;
+            totals.sum = late.sum;
+            totals.count = late.count;
+            totals.min = late.min;
+            totals.max = late.max;
         }
-        host.sum += sum;
+        host.sum += totals.sum;
+        if (range) { // without one, COUNT / MIN / MAX of these segments came from their metadata
+            host.count += totals.count;
+            host.min = totals.min < host.min ? totals.min : host.min;
+            host.max = totals.max > host.max ? totals.max : host.max;
+        }
     }
     // Fold into the caller's running state exactly as update_batch would continue it.
     if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) inout->count += host.count;

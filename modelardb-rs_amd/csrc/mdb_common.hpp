@@ -170,10 +170,14 @@ struct DevSegments {
     DevCol residuals;
 };
 
-// mdb_grid.hip, for mdb_agg.hip: the parallel MacaqueV decoder as a service to SUM (see there).
+// mdb_grid.hip, for mdb_agg.hip: the MacaqueV decoders as a service to the aggregates (see there).
+struct DeferredTotals {
+    double sum = 0.0;
+    long long count = 0;
+    float min = 0.0f;
+    float max = 0.0f;
+};
 uint32_t macaque_parallel_min_values(bool *forced);
-int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values, bool forced, uint64_t n_streams,
-                         uint64_t n_values, uint64_t n_bytes, bool *handled, double *sum);
 
 inline DevSegments to_dev(const mdb_segments *s) {
     DevSegments d;

@@ -23,6 +23,8 @@
 #include "mdb_scan.hpp"
 #include "mdb_macaque_parallel.hpp"
 
+#include <cfloat>
+
 namespace mdb {
 
 constexpr int PREPASS_THREADS = 256;
@@ -845,27 +847,59 @@ constexpr unsigned long long DEFERRED_ONE = 1ull << 40; // scan item: streams ab
 struct DeferredItem {
     DevSegments s;
     uint32_t min_values;
+    TimeRange range;
     __device__ uint64_t operator()(uint64_t i) const {
         if (s.model_type_id[i] != MDB_MACAQUE_V_ID) return 0;
-        const SegInfo info = analyse_segment(s, i);
-        return mv_qualifies_for_sum(info, s.values.views[i].x, min_values) ? (DEFERRED_ONE | info.desc.n_model) : 0;
+        const uint32_t values = mv_deferred_values(s, i, analyse_segment(s, i), min_values, range);
+        return values ? (DEFERRED_ONE | values) : 0;
     }
 };
 
-__global__ __launch_bounds__(256) void k_mv_select_scanned(DevSegments s, const unsigned long long *__restrict__ scan,
+__global__ __launch_bounds__(256) void k_mv_select_scanned(DevSegments s, TimeRange range,
+                                                           const unsigned long long *__restrict__ scan,
                                                            uint32_t min_values, MvSeg *__restrict__ segs) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     const unsigned long long mine = scan[i];
     if ((scan[i + 1] >> 40) == (mine >> 40)) return; // not one of the streams left aside
-    const SegInfo info = analyse_segment(s, i);
+    SegInfo info = analyse_segment(s, i);
+    if (range.enabled) apply_time_range(s, i, info, range);
     segs[mine >> 40] = mv_describe(s, i, info, min_values, mine & (DEFERRED_ONE - 1));
 }
 
 struct DeferredResult {
     double sum;
+    long long count; // the three below: time-range aggregates only
+    float min;
+    float max;
     unsigned int error;
     unsigned int pad;
+};
+
+// What one stream contributes to a time-range aggregate.
+struct RangePartial {
+    double sum;
+    long long count;
+    float min;
+    float max;
+    __device__ __forceinline__ void clear() {
+        sum = 0.0;
+        count = 0;
+        min = FLT_MAX;
+        max = -FLT_MAX;
+    }
+    __device__ __forceinline__ void point(float v) {
+        sum += (double)v;
+        count += 1;
+        min = min_num(min, v);
+        max = max_num(max, v);
+    }
+    __device__ __forceinline__ void merge(const RangePartial &other) {
+        sum += other.sum;
+        count += other.count;
+        min = min_num(min, other.min);
+        max = max_num(max, other.max);
+    }
 };
 
 // One wave per stream. The additions are a dependent chain that only one lane can walk, so the wave's
@@ -984,10 +1018,119 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_mv_serial_sums(const MvSeg *
     if (error) atomicOr(&result->error, error);
 }
 
-// One workgroup, fixed order (strided partial sums, then a fixed tree): the result does not depend
-// on how the work was scheduled.
 constexpr int MV_FINISH_THREADS = 1024;
 
+// ---- the same for aggregates under a time range: SUM (f64), COUNT, MIN, MAX of the visible values ----------
+
+__device__ __forceinline__ RangePartial shfl_down_partial(const RangePartial &p, int delta) {
+    RangePartial q;
+    const unsigned long long sum_bits = (unsigned long long)__double_as_longlong(p.sum);
+    q.sum = __longlong_as_double((long long)(((unsigned long long)__shfl_down((uint32_t)(sum_bits >> 32), delta, MDB_WAVE) << 32) |
+                                             __shfl_down((uint32_t)sum_bits, delta, MDB_WAVE)));
+    q.count = (long long)(((unsigned long long)__shfl_down((uint32_t)((unsigned long long)p.count >> 32), delta, MDB_WAVE) << 32) |
+                          __shfl_down((uint32_t)p.count, delta, MDB_WAVE));
+    q.min = __shfl_down(p.min, delta, MDB_WAVE);
+    q.max = __shfl_down(p.max, delta, MDB_WAVE);
+    return q;
+}
+
+// One wave per stream the parallel decoder has put into `values` (its visible values only).
+__global__ __launch_bounds__(MDB_WAVE) void k_mv_range_partials(const MvSeg *__restrict__ segs, uint64_t n_slots,
+                                                                const float *__restrict__ values,
+                                                                RangePartial *__restrict__ partials,
+                                                                DeferredResult *__restrict__ result) {
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const MvSeg seg = segs[slot];
+    RangePartial mine;
+    mine.clear();
+    if (!seg.done) {
+        // The parallel decoder gave this stream up: decode it here, one lane.
+        if (lane != 0) return;
+        uint32_t error = 0;
+        decode_macaque_v(reinterpret_cast<const uint8_t *>(seg.words) + seg.bias_bits / 8, seg.total_bits / 8,
+                         seg.visible_end, false, 0, &error, [&](uint32_t k, uint32_t bits) {
+                             if (k >= seg.first) mine.point(__uint_as_float(bits));
+                         });
+        if (error) atomicOr(&result->error, error);
+        partials[slot] = mine;
+        return;
+    }
+    const float *__restrict__ v = values + seg.out_offset;
+    const uint32_t n = seg.visible_end - seg.first;
+    for (uint32_t k = lane; k < n; k += MDB_WAVE) mine.point(v[k]);
+#pragma unroll
+    for (int delta = MDB_WAVE / 2; delta > 0; delta >>= 1) mine.merge(shfl_down_partial(mine, delta));
+    if (lane == 0) partials[slot] = mine;
+}
+
+// One lane per stream, out of the LDS ring (too many streams for the parallel decoder to pay off).
+__global__ __launch_bounds__(SERIAL_THREADS) void k_mv_serial_range(const MvSeg *__restrict__ segs, uint64_t n_slots,
+                                                                   RangePartial *__restrict__ partials,
+                                                                   DeferredResult *__restrict__ result) {
+    __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    bool active = slot < n_slots;
+    RingBitReader reader;
+    reader.begin(nullptr, 0);
+    MacaqueStream stream;
+    stream.remaining = 0; stream.position = 0; stream.last = 0;
+    stream.leading = 255; stream.trailing = 0; stream.first_is_raw = true; stream.fresh = true;
+    uint32_t first = 0;
+    if (active) {
+        const MvSeg seg = segs[slot];
+        reader.begin(reinterpret_cast<const uint8_t *>(seg.words) + seg.bias_bits / 8, seg.total_bits / 8);
+        stream.remaining = seg.visible_end; // the format has no random access: from the beginning
+        first = seg.first;
+        active = seg.visible_end > 0 && seg.total_bits > 0;
+    }
+    RangePartial mine;
+    mine.clear();
+    uint32_t error = 0;
+    while (__any(active)) {
+        if (__any(active && reader.hungry())) ring_top_up(reader, ring, lane, active);
+        if (active) {
+            bool malformed;
+            const float value = __uint_as_float(ring_decode_value(reader, stream, ring, lane, &malformed));
+            if (stream.position >= first) mine.point(value);
+            stream.position += 1;
+            stream.remaining -= 1;
+            if (malformed || reader.overrun()) error |= ERR_BITSTREAM;
+            if (malformed || reader.overrun() || stream.remaining == 0) active = false;
+        }
+    }
+    if (slot < n_slots) partials[slot] = mine;
+    if (error) atomicOr(&result->error, error);
+}
+
+__global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_range_finish(const RangePartial *__restrict__ partials,
+                                                                       uint64_t n_slots,
+                                                                       DeferredResult *__restrict__ result) {
+    __shared__ RangePartial lds[MV_FINISH_THREADS];
+    RangePartial mine;
+    mine.clear();
+    for (uint64_t slot = threadIdx.x; slot < n_slots; slot += MV_FINISH_THREADS) mine.merge(partials[slot]);
+    lds[threadIdx.x] = mine;
+    __syncthreads();
+    for (int width = MV_FINISH_THREADS / 2; width > 0; width >>= 1) {
+        if ((int)threadIdx.x < width) {
+            RangePartial a = lds[threadIdx.x];
+            a.merge(lds[threadIdx.x + width]);
+            lds[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        result->sum = lds[0].sum;
+        result->count = lds[0].count;
+        result->min = lds[0].min;
+        result->max = lds[0].max;
+    }
+}
+
+// One workgroup, fixed order (strided partial sums, then a fixed tree): the result does not depend
+// on how the work was scheduled.
 __global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_sums_finish(const float *__restrict__ sums, uint64_t n_slots,
                                                                       DeferredResult *__restrict__ result) {
     __shared__ double partial[MV_FINISH_THREADS];
@@ -1007,22 +1150,25 @@ uint32_t macaque_parallel_min_values(bool *forced) {
     return mv_min_values_setting();
 }
 
-// Adds up, per stream in f32 and then across streams in f64, the MacaqueV segments of the batch that
-// mv_qualifies() for min_values - the caller has counted them: n_streams streams, n_values values,
-// n_bytes bytes. *handled stays false only when the counts are beyond what the scan item can carry.
-int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values, bool forced, uint64_t n_streams,
-                         uint64_t n_values, uint64_t n_bytes, bool *handled, double *sum) {
+// The long MacaqueV streams k_agg_segments / k_agg_range left aside (mv_deferred_values; the caller has
+// counted them: n_streams streams, n_values values to decode into scratch memory at most, n_bytes
+// bytes). Without a range: each stream added up in f32 in stream order, the streams in f64
+// (totals->sum). With one: SUM (f64), COUNT, MIN and MAX of the values inside it. *handled stays
+// false only when the counts are beyond what the scan item can carry.
+int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,
+                     uint64_t n_streams, uint64_t n_values, uint64_t n_bytes, bool *handled,
+                     DeferredTotals *totals) {
     *handled = false;
     if (n_streams == 0 || n_values >= DEFERRED_ONE) return 0;
     // Few enough streams for the parallel decoder (the gate of mv_pipeline)? Then their values go to
-    // scratch memory first; otherwise a lane per stream decodes and adds in one go.
+    // scratch memory first; otherwise a lane per stream decodes and accumulates in one go.
     const bool parallel = n_bytes * 8 / MV_PIECE_BITS + n_streams + 1 <= MV_MAX_PIECES || forced;
     const uint64_t scan_bytes = align_up((s.n + 1) * 8, 256);
     const uint64_t block_sums_bytes = align_up(scan_block_sums_bytes(s.n), 256);
     const uint64_t values_bytes = parallel ? align_up(n_values * 4, 256) : 256;
-    const uint64_t sums_bytes = align_up(n_streams * 4, 256);
+    const uint64_t per_stream_bytes = align_up(n_streams * sizeof(RangePartial), 256); // or one float each
     void *p = nullptr;
-    if (scratch_reserve(ctx, SCRATCH_AGG_MV, scan_bytes + block_sums_bytes + values_bytes + sums_bytes + 256, &p))
+    if (scratch_reserve(ctx, SCRATCH_AGG_MV, scan_bytes + block_sums_bytes + values_bytes + per_stream_bytes + 256, &p))
         return 1;
     uint8_t *at = static_cast<uint8_t *>(p);
     unsigned long long *scan = reinterpret_cast<unsigned long long *>(at);
@@ -1032,31 +1178,50 @@ int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values
     float *values = reinterpret_cast<float *>(at);
     at += values_bytes;
     float *sums = reinterpret_cast<float *>(at);
-    at += sums_bytes;
+    RangePartial *partials = reinterpret_cast<RangePartial *>(at);
+    at += per_stream_bytes;
     DeferredResult *result = reinterpret_cast<DeferredResult *>(at);
     MDB_HIP_CHECK(hipMemsetAsync(result, 0, sizeof(DeferredResult), ctx->stream));
-    if (device_exclusive_scan(ctx, DeferredItem{s, min_values}, s.n, scan, block_sums, "k_mv_deferred_scan")) return 1;
+    if (device_exclusive_scan(ctx, DeferredItem{s, min_values, range}, s.n, scan, block_sums, "k_mv_deferred_scan"))
+        return 1;
     auto select = [&](MvSeg *segs) {
         LaunchTimer timer(ctx, "k_mv_select");
         hipLaunchKernelGGL(k_mv_select_scanned, dim3((uint32_t)((s.n + 255) / 256)), dim3(256), 0, ctx->stream, s,
-                           scan, min_values, segs);
+                           range, scan, min_values, segs);
     };
     MvSeg *segs = nullptr;
     if (parallel && mv_pipeline(ctx, n_streams, n_bytes, forced, select, values, &result->error, &segs)) return 1;
-    if (segs) {
-        LaunchTimer timer(ctx, "k_mv_sums");
-        hipLaunchKernelGGL(k_mv_sums, dim3((uint32_t)n_streams), dim3(MDB_WAVE), 0, ctx->stream, segs, n_streams,
-                           values, sums, result);
-    } else {
+    const bool decoded = segs != nullptr;
+    if (!decoded) {
         void *q = nullptr;
         if (scratch_reserve(ctx, SCRATCH_MV, n_streams * sizeof(MvSeg), &q)) return 1;
         segs = static_cast<MvSeg *>(q);
         select(segs);
-        LaunchTimer timer(ctx, "k_mv_serial_sums");
-        hipLaunchKernelGGL(k_mv_serial_sums, dim3((uint32_t)((n_streams + SERIAL_THREADS - 1) / SERIAL_THREADS)),
-                           dim3(SERIAL_THREADS), 0, ctx->stream, segs, n_streams, sums, result);
     }
-    {
+    const uint32_t lane_blocks = (uint32_t)((n_streams + SERIAL_THREADS - 1) / SERIAL_THREADS);
+    if (range.enabled) {
+        if (decoded) {
+            LaunchTimer timer(ctx, "k_mv_range_partials");
+            hipLaunchKernelGGL(k_mv_range_partials, dim3((uint32_t)n_streams), dim3(MDB_WAVE), 0, ctx->stream, segs,
+                               n_streams, values, partials, result);
+        } else {
+            LaunchTimer timer(ctx, "k_mv_serial_range");
+            hipLaunchKernelGGL(k_mv_serial_range, dim3(lane_blocks), dim3(SERIAL_THREADS), 0, ctx->stream, segs,
+                               n_streams, partials, result);
+        }
+        LaunchTimer timer(ctx, "k_mv_range_finish");
+        hipLaunchKernelGGL(k_mv_range_finish, dim3(1), dim3(MV_FINISH_THREADS), 0, ctx->stream, partials, n_streams,
+                           result);
+    } else {
+        if (decoded) {
+            LaunchTimer timer(ctx, "k_mv_sums");
+            hipLaunchKernelGGL(k_mv_sums, dim3((uint32_t)n_streams), dim3(MDB_WAVE), 0, ctx->stream, segs, n_streams,
+                               values, sums, result);
+        } else {
+            LaunchTimer timer(ctx, "k_mv_serial_sums");
+            hipLaunchKernelGGL(k_mv_serial_sums, dim3(lane_blocks), dim3(SERIAL_THREADS), 0, ctx->stream, segs,
+                               n_streams, sums, result);
+        }
         LaunchTimer timer(ctx, "k_mv_sums_finish");
         hipLaunchKernelGGL(k_mv_sums_finish, dim3(1), dim3(MV_FINISH_THREADS), 0, ctx->stream, sums, n_streams, result);
     }
@@ -1066,7 +1231,10 @@ int macaque_deferred_sum(mdb_ctx *ctx, const DevSegments &s, uint32_t min_values
     MDB_HIP_CHECK(hipGetLastError());
     if (host.error) return fail(describe_error(host.error));
     *handled = true;
-    *sum = host.sum;
+    totals->sum = host.sum;
+    totals->count = host.count;
+    totals->min = host.min;
+    totals->max = host.max;
     return 0;
 }
 

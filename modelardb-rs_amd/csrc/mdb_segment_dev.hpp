@@ -541,4 +541,22 @@ __device__ __forceinline__ bool mv_qualifies_for_sum(const SegInfo &info, uint32
     return mv_qualifies(info, values_bytes, min_values) && length == info.desc.n_model;
 }
 
+// Aggregates leave long MacaqueV streams to the decoders of mdb_grid.hip (macaque_deferred_sum): how
+// many values of segment i that would be - none if it does not qualify. `info` is what
+// analyse_segment() said about it. With a time range: the values up to the last one inside it
+// (regular timestamps only; what is summed there is what grid() would produce, so grid()'s length
+// counts); without: the whole stream, if len() and grid() agree on its length.
+__device__ __forceinline__ uint32_t mv_deferred_values(const DevSegments &s, uint64_t i, SegInfo info,
+                                                       uint32_t min_values, const TimeRange &range) {
+    const uint32_t bytes = s.values.views[i].x;
+    if (!range.enabled) return mv_qualifies_for_sum(info, bytes, min_values) ? info.desc.n_model : 0u;
+    if (!(info.desc.flags & FLAG_REGULAR)) return 0u;
+    apply_time_range(s, i, info, range);
+    return mv_qualifies(info, bytes, min_values) ? info.desc.n_visible : 0u;
+}
+
+int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,
+                     uint64_t n_streams, uint64_t n_values, uint64_t n_bytes, bool *handled,
+                     DeferredTotals *totals);
+
 } // namespace mdb

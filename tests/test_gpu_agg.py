@@ -84,6 +84,18 @@ def test_sum_of_long_lossless_streams(hip, macaque_decoder, monkeypatch):
     for k in range(len(offsets) - 1):
         per_stream += float(np.add.accumulate(values[int(offsets[k]):int(offsets[k + 1])], dtype=np.float32)[-1])
     assert abs(state.sum - per_stream) <= 1e-12 * abs(per_stream)
+    # The same under a time range (what the reference computes with GridExec + filter + aggregate):
+    # the values with index 300 000 .. 700 000, which lie in 8 of the 16 streams.
+    lo, hi = 300_000, 700_000
+    hip.profile_enable(True)
+    hip.profile_reset()
+    ranged = hip.agg_batch_range(segments, int(timestamps[lo]), int(timestamps[hi]), ALL)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert ("k_mv_range_finish" in kernels) == (macaque_decoder != "off")
+    inside = values[lo:hi + 1]
+    assert (ranged.count, ranged.min, ranged.max) == (len(inside), inside.min(), inside.max())
+    assert abs(ranged.sum - float(inside.astype(np.float64).sum())) <= 1e-9 * abs(float(inside.astype(np.float64).sum()))
     monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", "off")
     serial = hip.agg_batch(segments, ALL)
     assert abs(state.sum - serial.sum) <= 1e-12 * abs(serial.sum)
