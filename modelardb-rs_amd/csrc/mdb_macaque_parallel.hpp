@@ -61,7 +61,10 @@ constexpr uint32_t MV_SHIFT_BITS = 8;     // how late a parse can be and still l
 constexpr uint32_t MV_SETTLE_CODES = 8;   // codes after which a guessed chain is recorded and compared
 constexpr uint32_t MV_NO_WINDOW = 0xffffu;
 constexpr uint32_t MV_NO_LENGTH = 0xffu;
-constexpr uint32_t MV_MAX_TAIL_BITS = 1u << 16;
+#ifndef MDB_MV_MAX_TAIL_BITS
+#define MDB_MV_MAX_TAIL_BITS (1u << 16)
+#endif
+constexpr uint32_t MV_MAX_TAIL_BITS = MDB_MV_MAX_TAIL_BITS;
 constexpr uint32_t MV_NONE = 0xffffffffu; // link: no partner found
 constexpr uint32_t MV_END = 0xfffffffeu;  // link: parsed to the end of the stream
 
