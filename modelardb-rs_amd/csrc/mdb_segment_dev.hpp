@@ -123,6 +123,24 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
     w.open(bytes, nbytes, 1); // bit 0 is the flag "irregular" (timestamps.rs:116)
     while (w.far_from_end(80)) {
         const uint32_t top = w.top();
+        if ((top >> 31) == 0u) {
+            // A run of `0` codes - the delta repeats: what a series sampled at a fixed rate with the
+            // odd gap or jitter consists of almost entirely (one irregularity makes the whole segment
+            // "irregular", timestamps.rs:77-96). The whole run is taken off the stream at once.
+            uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
+            run = min(run, min(limit - count, COUNT_MASK - count));
+            if (run == 0) { // count == COUNT_MASK: as below
+                *error |= ERR_TOO_LONG;
+                return count;
+            }
+            w.consume(run);
+            for (uint32_t j = 0; j < run; j++) {
+                timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+                emit(count++, timestamp);
+            }
+            if (count >= limit) return count;
+            continue;
+        }
         const uint32_t ones = min((uint32_t)__clz((int)~top), 5u);
         if (ones <= 3) {
             const uint32_t header = ones + 1;                            // the run of ones and its zero

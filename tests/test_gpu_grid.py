@@ -271,6 +271,36 @@ def test_grid_with_pushed_down_time_range(hip, eb_name, irregular):
         assert metrics["rows_created"] == len(exp_ts)
 
 
+@pytest.mark.parametrize("gap_probability", [0.0005, 0.02, 0.5])
+def test_mostly_regular_timestamps_with_gaps(hip, gap_probability):
+    # What irregular timestamps usually are: a fixed sampling interval with a sample missing now and
+    # then. One gap makes a whole segment irregular (timestamps.rs:77-96) and its stream then consists
+    # of long runs of `0` codes, which the decoder takes off the stream up to 32 at a time.
+    rng = np.random.default_rng(171)
+    n = 60_000
+    timestamps = 1_700_000_000_000_000 + np.cumsum(np.where(rng.random(n) < gap_probability, 3000, 1000).astype(np.int64))
+    values = (50 + 5 * np.sin(np.arange(n) / 700.0) + rng.uniform(-0.02, 0.02, n)).astype(np.float32)
+    offsets = np.array([0, 7, 7 + 40_000, n], dtype=np.uint64)
+    for eb_name in ("rel1", "lossless"):
+        eb = cases.error_bounds()[eb_name]
+        expected_segments = ora.compress_chunks(timestamps, values, offsets, eb)
+        segments = hip.compress_chunks(timestamps, values, offsets, eb)
+        assert segments.rows() == expected_segments.rows()
+        cases.assert_grid_equal(hip.grid_batch(segments), ora.grid_batch(segments))
+        assert np.array_equal(hip.grid_batch(segments)[0], timestamps)
+        for t_lo, t_hi in ((int(timestamps[1000]), int(timestamps[1031])), (int(timestamps[33]) + 1, int(timestamps[50_000]) - 1),
+                           (int(timestamps[-1]), int(timestamps[-1]) + 5)):
+            exp_ts, exp_values, exp_rows = _expected_range(segments, t_lo, t_hi)
+            ts, reconstructed, rows, _ = hip.grid_batch_range(segments, t_lo, t_hi)
+            assert np.array_equal(ts, exp_ts), (t_lo, t_hi)
+            assert np.array_equal(reconstructed.view(np.uint32), exp_values.view(np.uint32)), (t_lo, t_hi)
+            assert np.array_equal(rows, exp_rows)
+        mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+        got, expected = hip.agg_batch(segments, mask), ora.agg_batch(segments, mask)
+        assert (got.count, got.min, got.max) == (expected.count, expected.min, expected.max)
+        assert abs(got.sum - expected.sum) <= 1e-5 * abs(expected.sum)
+
+
 def test_grid_time_range_edge_cases(hip):
     for eb_name in ("lossless", "rel5"):
         batch = cases.edge_case_batch(cases.error_bounds()[eb_name])
