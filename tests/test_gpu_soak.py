@@ -98,11 +98,24 @@ def check_state(got, expected, magnitude, where):
     assert close_sum(got.sum, expected.sum, magnitude), (where, got.sum, expected.sum)
 
 
-def run_case(hip, index):
+def gap_shaped_timestamps(index, n):
+    """A fixed sampling interval with a sample (or a few) missing now and then: what irregular
+    timestamps usually are, and long runs of the one-bit "same delta" code in the compressed stream.
+    Its own generator, so that the cases of run_case() stay what they were."""
+    rng = np.random.default_rng([0x474150, index])
+    interval = int(rng.choice([1, 1000, 60_000_000]))
+    probability = float(rng.choice([0.0005, 0.01, 0.2]))
+    missing = np.where(rng.random(n) < probability, rng.integers(1, 4, n), 0).astype(np.int64)
+    return int(rng.choice([0, 1658671178037000])) + np.cumsum(interval * (1 + missing))
+
+
+def run_case(hip, index, gaps=False):
     rng = np.random.default_rng([0x50414B, index])
     n = int(rng.choice([1, 2, 7, 8, 60, 700, 5000, 20_000, 70_000]))
     n = max(1, int(n * rng.uniform(0.5, 1.0)))
     timestamps, values, eb = random_timestamps(rng, n), random_values(rng, n), random_error_bound(rng)
+    if gaps:
+        timestamps = gap_shaped_timestamps(index, n)
     n_chunks = int(rng.choice([1, 1, 2, 5]))
     cuts = np.sort(rng.integers(0, n + 1, n_chunks - 1)) if n_chunks > 1 else np.zeros(0, dtype=np.int64)
     offsets = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
@@ -134,6 +147,12 @@ def run_case(hip, index):
 def test_random_series_through_fit_grid_and_aggregates(hip, block):
     for index in range(block * BLOCK, min(N_CASES, (block + 1) * BLOCK)):
         run_case(hip, index)
+
+
+@pytest.mark.parametrize("block", range((N_CASES // 3 + BLOCK - 1) // BLOCK))
+def test_random_series_with_gap_shaped_timestamps(hip, block):
+    for index in range(block * BLOCK, min(N_CASES // 3, (block + 1) * BLOCK)):
+        run_case(hip, 1_000_000 + index, gaps=True)
 
 
 def test_cases_that_once_failed(hip):
