@@ -641,7 +641,14 @@ struct PieceCount {
 // runs dry the WHOLE wave tops its rings up with independent, predicated loads issued back to back
 // and waits once - one HBM/L2 latency per ~FIT_RING-8 points instead of one per point. The ring
 // always keeps the 8 most recent points, because a rejected model restarts at most 7 points back.
-constexpr int FIT_RING = 32;
+#ifndef MDB_FIT_RING
+#define MDB_FIT_RING 32
+#endif
+constexpr int FIT_RING = MDB_FIT_RING;
+#ifndef MDB_FIT_RING_WITH_TIMESTAMPS
+#define MDB_FIT_RING_WITH_TIMESTAMPS 16
+#endif
+constexpr int FIT_RING_WITH_TIMESTAMPS = MDB_FIT_RING_WITH_TIMESTAMPS;
 constexpr int FIT_HISTORY = 8;
 constexpr int FIT_THREADS = MDB_WAVE;
 constexpr int FIT_QUICK_REJECTS = 16; // rejected points skipped per trip (lossless bound only)
@@ -652,8 +659,11 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
                                                            ModelRec *__restrict__ records,
                                                            ChunkPlan *__restrict__ plans,
                                                            unsigned int *__restrict__ error) {
-    __shared__ float ring_values[FIT_RING][MDB_WAVE];
-    __shared__ long long ring_ts[HAS_TS ? FIT_RING : 1][MDB_WAVE];
+    // With timestamps a ring slot is 12 bytes per lane instead of 4: fewer slots, so that as many
+    // waves fit into a CU's LDS as without (what the kernel lives on is waves in flight).
+    constexpr int RING = HAS_TS ? FIT_RING_WITH_TIMESTAMPS : FIT_RING;
+    __shared__ float ring_values[RING][MDB_WAVE];
+    __shared__ long long ring_ts[HAS_TS ? RING : 1][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t unit = (uint64_t)blockIdx.x * FIT_THREADS + lane;
     uint64_t chunk = unit;
@@ -695,7 +705,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
     const uint32_t piece_end = SPLIT ? first_point + split.piece_points : 0u; // (split mode) of this lane's piece
     uint32_t current = first_point; // first point of the model being fitted
     uint32_t j = first_point;       // next point to feed
-    uint32_t loaded = first_point;  // the ring holds points [low, loaded) of the chunk, loaded - low <= FIT_RING
+    uint32_t loaded = first_point;  // the ring holds points [low, loaded) of the chunk, loaded - low <= RING
     uint32_t low = first_point;
     PmcDev pmc;
     SwingDev swing;
@@ -720,14 +730,14 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
                 // (only on points that are in the lane's LDS ring already: a load per point would cost
                 // more than the trips it saves)
                 if (active && j == current && current + 2 < n && current >= low && current + 2 < loaded) {
-                    const float v0 = ring_values[current % FIT_RING][lane];
-                    const float v1 = ring_values[(current + 1) % FIT_RING][lane];
-                    const float v2 = ring_values[(current + 2) % FIT_RING][lane];
+                    const float v0 = ring_values[current % RING][lane];
+                    const float v1 = ring_values[(current + 1) % RING][lane];
+                    const float v2 = ring_values[(current + 2) % RING][lane];
                     if (isfinite(v0) && isfinite(v1) && isfinite(v2) && v0 != v1) {
-                        const int64_t t0 = HAS_TS ? (int64_t)ring_ts[current % FIT_RING][lane] : regular_ts.regular_at(current);
-                        const int64_t t1 = HAS_TS ? (int64_t)ring_ts[(current + 1) % FIT_RING][lane]
+                        const int64_t t0 = HAS_TS ? (int64_t)ring_ts[current % RING][lane] : regular_ts.regular_at(current);
+                        const int64_t t1 = HAS_TS ? (int64_t)ring_ts[(current + 1) % RING][lane]
                                                   : regular_ts.regular_at(current + 1);
-                        const int64_t t2 = HAS_TS ? (int64_t)ring_ts[(current + 2) % FIT_RING][lane]
+                        const int64_t t2 = HAS_TS ? (int64_t)ring_ts[(current + 2) % RING][lane]
                                                   : regular_ts.regular_at(current + 2);
                         const LineDev line = line_through(t0, (double)v0, t1, (double)v1);
                         const double approximation = line.slope * (double)t2 + line.intercept;
@@ -753,8 +763,8 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
         const bool feeding = active && j < n && (pmc_fits || swing_fits);
         // Wave-synchronous top-up: triggered by any lane whose next point is not in its ring.
         if (__any(feeding && (j >= loaded || j < low))) {
-            float fetched_values[FIT_RING - FIT_HISTORY];
-            long long fetched_ts[HAS_TS ? FIT_RING - FIT_HISTORY : 1];
+            float fetched_values[RING - FIT_HISTORY];
+            long long fetched_ts[HAS_TS ? RING - FIT_HISTORY : 1];
             // Normally the ring is extended at `loaded`. A lane whose next point fell out of the
             // back of its ring (PMC-Mean chosen although Swing had reached > 8 points further,
             // types.rs:84-101) restarts its ring at j; points before j are never needed again.
@@ -763,29 +773,29 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
                 low = j;
             }
             const uint32_t first = loaded;
-            const uint32_t room = active ? (uint32_t)max(0, (int)(j + FIT_RING - FIT_HISTORY) - (int)first) : 0u;
+            const uint32_t room = active ? (uint32_t)max(0, (int)(j + RING - FIT_HISTORY) - (int)first) : 0u;
 #pragma unroll
-            for (int k = 0; k < FIT_RING - FIT_HISTORY; k++) {
+            for (int k = 0; k < RING - FIT_HISTORY; k++) {
                 const uint32_t index = first + k;
                 const bool wanted = (uint32_t)k < room && index < n;
                 fetched_values[k] = wanted ? values[index] : 0.0f;
                 if (HAS_TS) fetched_ts[k] = wanted ? timestamps[index] : 0;
             }
 #pragma unroll
-            for (int k = 0; k < FIT_RING - FIT_HISTORY; k++) {
+            for (int k = 0; k < RING - FIT_HISTORY; k++) {
                 const uint32_t index = first + k;
                 if ((uint32_t)k < room && index < n) {
-                    ring_values[index % FIT_RING][lane] = fetched_values[k];
-                    if (HAS_TS) ring_ts[index % FIT_RING][lane] = fetched_ts[k];
+                    ring_values[index % RING][lane] = fetched_values[k];
+                    if (HAS_TS) ring_ts[index % RING][lane] = fetched_ts[k];
                 }
             }
-            loaded = min(n, first + min(room, (uint32_t)(FIT_RING - FIT_HISTORY)));
-            if (loaded > low + FIT_RING) low = loaded - FIT_RING;
+            loaded = min(n, first + min(room, (uint32_t)(RING - FIT_HISTORY)));
+            if (loaded > low + RING) low = loaded - RING;
             // Only this lane reads its own column: no cross-lane hazard, just LDS program order.
         }
         if (feeding) {
-            const float v = ring_values[j % FIT_RING][lane];
-            const int64_t t = HAS_TS ? (int64_t)ring_ts[j % FIT_RING][lane] : regular_ts.regular_at(j);
+            const float v = ring_values[j % RING][lane];
+            const int64_t t = HAS_TS ? (int64_t)ring_ts[j % RING][lane] : regular_ts.regular_at(j);
             // try_to_update_models (types.rs:74-81): a model that failed once is never fed again.
             if (pmc_fits) pmc_fits = pmc.fit(eb, v);
             if (swing_fits) swing_fits = swing.fit(dev, t, v);

@@ -14,6 +14,7 @@ def main():
     p.add_argument("--error-bound", type=float, default=1.0)
     p.add_argument("--materialise-ts", action="store_true")
     p.add_argument("--irregular", action="store_true", help="materialised timestamps with random gaps")
+    p.add_argument("--gaps", action="store_true", help="materialised timestamps: a fixed interval, 1 %% of the samples missing")
     a = p.parse_args()
     ctx = mdb.Context(0)
     eb = mdb.error_bound("relative", a.error_bound) if a.error_bound > 0 else mdb.error_bound("lossless")
@@ -28,6 +29,10 @@ def main():
     if a.irregular:
         rng = np.random.default_rng(5)
         one = np.cumsum(rng.integers(900, 1100, a.points).astype(np.int64))
+        ts_dev = ctx.upload_array(np.tile(one, a.series))
+    elif a.gaps:
+        rng = np.random.default_rng(5)
+        one = np.cumsum(np.where(rng.random(a.points) < 0.01, 2000, 1000).astype(np.int64))
         ts_dev = ctx.upload_array(np.tile(one, a.series))
     elif a.materialise_ts:
         ts_dev = ctx.upload_array(np.tile(np.arange(a.points, dtype=np.int64) * 1000, a.series))
