@@ -789,6 +789,11 @@ int mv_pipeline(mdb_ctx *ctx, uint64_t n_serial, uint64_t stream_bytes, bool for
     select(segs);
     if (device_exclusive_scan(ctx, MvPieceCount{segs}, n_serial, piece_base, block_sums, "k_mv_scan")) return 1;
     const uint32_t piece_blocks = (uint32_t)((max_pieces + MDB_WAVE - 1) / MDB_WAVE);
+    // A wave that stages whole pieces takes 38 KB of LDS, so four of them fill a CU: beyond the
+    // 1 024 waves that are resident at once, less staging and more waves is the better trade
+    // (16 streams of 65 536 values: 5.8 / 5.95 / 6.0 ms with whole / half / quarter pieces staged;
+    // 64 streams: 7.3 / 6.85 / 6.95 ms; 256 streams: 17.0 / 14.7 / 13.8 ms).
+    const int staging = max_pieces <= 12288 ? 0 : (max_pieces <= 49152 ? 1 : 2);
     for (int round = 0; round < MV_ROUNDS; round++) {
         if (mv_round_kind(round) == MV_ROUND_GUESS) {
             LaunchTimer timer(ctx, "k_mv_guess");
@@ -796,9 +801,16 @@ int mv_pipeline(mdb_ctx *ctx, uint64_t n_serial, uint64_t stream_bytes, bool for
                                piece_base, chains, guesses);
         }
         LaunchTimer timer(ctx, round == 0 ? "k_mv_chains_start" : (round == 1 ? "k_mv_chains_first" : "k_mv_chains_more"));
-        hipLaunchKernelGGL(k_mv_chains, dim3((uint32_t)((max_pieces * MV_CHAINS + MDB_WAVE - 1) / MDB_WAVE)),
-                           dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base, n_serial, round, guesses, tried,
-                           pending, heads, chains);
+        const dim3 chain_grid((uint32_t)((max_pieces * MV_CHAINS + MDB_WAVE - 1) / MDB_WAVE));
+        if (staging == 0)
+            hipLaunchKernelGGL(k_mv_chains<MV_STAGE_WORDS>, chain_grid, dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
+                               n_serial, round, guesses, tried, pending, heads, chains);
+        else if (staging == 1)
+            hipLaunchKernelGGL(k_mv_chains<MV_STAGE_WORDS_HALF>, chain_grid, dim3(MDB_WAVE), 0, ctx->stream, segs,
+                               piece_base, n_serial, round, guesses, tried, pending, heads, chains);
+        else
+            hipLaunchKernelGGL(k_mv_chains<MV_STAGE_WORDS_QUARTER>, chain_grid, dim3(MDB_WAVE), 0, ctx->stream, segs,
+                               piece_base, n_serial, round, guesses, tried, pending, heads, chains);
     }
     {
         LaunchTimer timer(ctx, "k_mv_links");
@@ -813,8 +825,15 @@ int mv_pipeline(mdb_ctx *ctx, uint64_t n_serial, uint64_t stream_bytes, bool for
     }
     {
         LaunchTimer timer(ctx, "k_mv_decode");
-        hipLaunchKernelGGL(k_mv_decode, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs, piece_base,
-                           n_serial, starts, out_val, error);
+        if (staging == 0)
+            hipLaunchKernelGGL(k_mv_decode<MV_STAGE_WORDS>, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs,
+                               piece_base, n_serial, starts, out_val, error);
+        else if (staging == 1)
+            hipLaunchKernelGGL(k_mv_decode<MV_STAGE_WORDS_HALF>, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream, segs,
+                               piece_base, n_serial, starts, out_val, error);
+        else
+            hipLaunchKernelGGL(k_mv_decode<MV_STAGE_WORDS_QUARTER>, dim3(piece_blocks), dim3(MDB_WAVE), 0, ctx->stream,
+                               segs, piece_base, n_serial, starts, out_val, error);
     }
     *segs_out = segs;
     return 0;

@@ -137,7 +137,12 @@ struct MvPieceCount {
 // going to walk over into LDS once, 16 bytes at a time (`stage`), laid out [word][lane] so that a
 // row is conflict free whatever word each lane is at; words outside that window (a parse that runs
 // on for several pieces) still come from global memory.
+// How much of a piece a lane copies: all of it when the batch is small (few waves, each as fast as it
+// can be), half or a quarter when there are more waves than fit next to each other with 38 KB of LDS
+// each (what does not get staged comes from global memory as before).
 constexpr uint32_t MV_STAGE_WORDS = MV_PIECE_BITS / 32 + 20; // a piece, 8 bits before it, ~600 bits after it
+constexpr uint32_t MV_STAGE_WORDS_HALF = MV_PIECE_BITS / 64 + 20;
+constexpr uint32_t MV_STAGE_WORDS_QUARTER = MV_PIECE_BITS / 128 + 20;
 
 struct MvReader {
     const uint32_t *words;
@@ -148,6 +153,7 @@ struct MvReader {
     uint64_t cache;
     const uint32_t *staged; // LDS, this lane's column, already byte swapped; nullptr: nothing staged
     uint32_t staged_first;  // first staged word
+    uint32_t staged_words;  // how many
     __device__ __forceinline__ void open(const MvSeg &seg) {
         words = seg.words;
         n_words = seg.n_words;
@@ -157,10 +163,11 @@ struct MvReader {
         cache = 0;
         staged = nullptr;
         staged_first = 0;
+        staged_words = 0;
     }
-    // Copies words [first, first + MV_STAGE_WORDS) around bit position `from_pos` into `column`
-    // (this lane's column of a [MV_STAGE_WORDS][MDB_WAVE] LDS array). Only this lane reads it back.
-    __device__ __forceinline__ void stage(uint32_t *column, uint32_t from_pos) {
+    // Copies words [first, first + WORDS) around bit position `from_pos` into `column` (this lane's
+    // column of a [WORDS][MDB_WAVE] LDS array). Only this lane reads it back.
+    template <uint32_t WORDS> __device__ __forceinline__ void stage(uint32_t *column, uint32_t from_pos) {
         // First staged word: at or before the word of from_pos, on a 16-byte boundary of the ADDRESS
         // (the payload itself is only byte aligned) so that the copy can use 16-byte loads.
         const uint32_t skew = (uint32_t)((reinterpret_cast<uintptr_t>(words) >> 2) & 3u);
@@ -169,7 +176,7 @@ struct MvReader {
         const bool aligned = rounded >= skew;
         const uint32_t first = aligned ? rounded - skew : 0u;
 #pragma unroll 4
-        for (uint32_t k = 0; k < MV_STAGE_WORDS / 4; k++) {
+        for (uint32_t k = 0; k < WORDS / 4; k++) {
             const uint32_t index = first + 4 * k;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (aligned && index + 3 < n_words) {
@@ -187,10 +194,11 @@ struct MvReader {
         }
         staged = column;
         staged_first = first;
+        staged_words = WORDS / 4 * 4;
     }
     __device__ __forceinline__ uint32_t word(uint32_t index) const {
         const uint32_t k = index - staged_first;
-        if (staged != nullptr && k < MV_STAGE_WORDS) return staged[k * MDB_WAVE];
+        if (k < staged_words) return staged[k * MDB_WAVE];
         return index < n_words ? __builtin_bswap32(words[index]) : 0u;
     }
     // count in [0, 32]
@@ -367,13 +375,14 @@ __device__ __forceinline__ bool mv_byte_listed(uint32_t list, uint32_t value) {
     return false;
 }
 
+template <uint32_t STAGE_WORDS>
 __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict__ segs,
                                                         const unsigned long long *__restrict__ piece_base,
                                                         uint64_t n_slots, int round,
                                                         const uint32_t *__restrict__ guesses,
                                                         uint32_t *__restrict__ tried, uint32_t *__restrict__ pending,
                                                         MvRec *__restrict__ heads, MvChain *__restrict__ chains) {
-    __shared__ uint32_t stage_lds[MV_STAGE_WORDS][MDB_WAVE];
+    __shared__ uint32_t stage_lds[STAGE_WORDS][MDB_WAVE];
     const uint64_t lane_id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t piece = lane_id / MV_CHAINS;
     const uint32_t sub = (uint32_t)(lane_id % MV_CHAINS);
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_chains(const MvSeg *__restrict_
         }
     }
     // Every lane of a piece walks over the same bits: each keeps its own copy (a column of the array).
-    if (work) reader.stage(&stage_lds[0][threadIdx.x], piece_begin);
+    if (work) reader.template stage<STAGE_WORDS>(&stage_lds[0][threadIdx.x], piece_begin);
 
     int guess_index = -1;           // which guess is being searched (guess rounds)
     uint32_t length = MV_NO_LENGTH; // its n, MV_NO_LENGTH: candidates are `11` patterns / the real start
@@ -784,12 +793,13 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_walk(MvSeg *__restrict__ segs,
 
 // ---- k_mv_decode: one lane per piece -----------------------------------------------------------------------
 
+template <uint32_t STAGE_WORDS>
 __global__ __launch_bounds__(MDB_WAVE) void k_mv_decode(const MvSeg *__restrict__ segs,
                                                         const unsigned long long *__restrict__ piece_base,
                                                         uint64_t n_slots, const MvStart *__restrict__ starts,
                                                         float *__restrict__ out_val,
                                                         unsigned int *__restrict__ error) {
-    __shared__ uint32_t stage_lds[MV_STAGE_WORDS][MDB_WAVE];
+    __shared__ uint32_t stage_lds[STAGE_WORDS][MDB_WAVE];
     const uint64_t piece = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (piece >= piece_base[n_slots]) return;
     const MvStart start = starts[piece];
@@ -799,7 +809,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_mv_decode(const MvSeg *__restrict_
     if (!seg.done) return; // the sequential decoder handles this stream
     MvReader reader;
     reader.open(seg);
-    reader.stage(&stage_lds[0][threadIdx.x], start.pos);
+    reader.template stage<STAGE_WORDS>(&stage_lds[0][threadIdx.x], start.pos);
     float *__restrict__ out = out_val + seg.out_offset;
     uint32_t value = start.value_bits;
     if (piece == piece_base[slot] && seg.first == 0) out[0] = __uint_as_float(value); // the raw first value

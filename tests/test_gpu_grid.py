@@ -195,6 +195,35 @@ def test_config1_one_series_one_million_points_lossless(hip):
     assert abs(state.sum - reference.sum) <= 1e-5 * abs(reference.sum)
 
 
+@pytest.mark.parametrize("streams", [40, 130])
+def test_many_long_lossless_streams(hip, streams, macaque_decoder):
+    # The parallel MacaqueV decoder stages half (above 12 288 pieces of 4 096 bits) or a quarter (above
+    # 49 152) of each piece in LDS instead of all of it; 40 and 130 streams of 65 536 values are 15 600
+    # and 50 700 pieces. Still bit for bit what one lane per stream produces.
+    import datagen
+    n = 65536
+    distinct = [datagen.sine_series(100 + k, n)[1] for k in range(5)]
+    values = np.concatenate([distinct[k % 5] for k in range(streams)])
+    timestamps = np.tile(np.arange(n, dtype=np.int64) * 1000, streams)
+    offsets = (np.arange(streams + 1, dtype=np.uint64) * n)
+    segments = hip.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
+    assert len(segments) == streams and set(segments.model_type_id.tolist()) == {2}
+    hip.profile_enable(True)
+    hip.profile_reset()
+    ts, reconstructed, rows, metrics = hip.grid_batch(segments)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert "k_mv_decode" in kernels  # every mode of this file's fixture leaves the decoder on for such streams
+    assert np.array_equal(ts, timestamps)
+    assert np.array_equal(reconstructed.view(np.uint32), values.view(np.uint32))
+    assert metrics["rows_created_by_macaque_v"] == streams * n
+    t_lo, t_hi = 20_000_000, 40_000_000
+    ts, reconstructed, rows, _ = hip.grid_batch_range(segments, t_lo, t_hi)
+    keep = (timestamps >= t_lo) & (timestamps <= t_hi)
+    assert np.array_equal(ts, timestamps[keep])
+    assert np.array_equal(reconstructed.view(np.uint32), values[keep].view(np.uint32))
+
+
 def test_random_bit_patterns_survive_lossless_round_trip(hip):
     # Any f32 bit pattern (NaN payloads, subnormals, infinities) must come back bit for bit
     # (the reference's proptests use ProptestValue::ANY: macaque_v.rs:436-475, pmc_mean.rs:141-152).
