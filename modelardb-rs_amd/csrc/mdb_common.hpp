@@ -66,6 +66,7 @@ enum ScratchSlot {
     SCRATCH_FIT_SPLIT,
     SCRATCH_FIT_GAP,
     SCRATCH_FIT_REGULAR,
+    SCRATCH_FIT_TS,
     SCRATCH_MV,
     SCRATCH_AGG_MV,
     SCRATCH_STAGE_DEV,

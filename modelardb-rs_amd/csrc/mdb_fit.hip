@@ -561,6 +561,9 @@ struct FitArgs {
     // process_segment needs to know about them.
     uint32_t gap_min_values;
     const struct GapResult *gap_results;
+    // Timestamps of segments inside irregular chunks are sized and written by one WAVE each
+    // (k_fit_timestamps); ts_results[segment].bytes == 0xffffffff: not this one. May be nullptr.
+    const struct TsResult *ts_results;
 };
 
 __device__ __forceinline__ uint64_t chunk_record_capacity(uint64_t length) { return length / 8 + 1; }
@@ -1009,6 +1012,11 @@ struct EncodeTargets {
     const unsigned long long *data_offsets[3];
 };
 
+struct TsResult { // of k_fit_timestamps<false>, indexed by segment
+    uint32_t bytes; // length of compress_residual_timestamps(); 0xffffffff: the one-lane path does it
+    uint32_t regular;
+};
+
 struct GapResult { // of k_fit_gap<false>, indexed by segment
     uint32_t values_bytes;
     float min_value;
@@ -1060,7 +1068,11 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
     // -- timestamps (timestamps.rs:56-155) over [first, last]
     const uint32_t count = item.last - item.first + 1;
     uint32_t ts_bytes;
-    if (!WRITE) {
+    const bool ts_by_wave = args.ts_results != nullptr && args.ts_results[segment].bytes != 0xffffffffu;
+    if (!WRITE && ts_by_wave) {
+        ts_bytes = args.ts_results[segment].bytes;
+        sizes_io->pad = args.ts_results[segment].regular;
+    } else if (!WRITE) {
         bool regular;
         int known_regular = gap_goes_to_a_wave(args, item) ? (int)args.gap_results[segment].regular : -1;
         if (known_regular < 0 && args.timestamps.ts && args.timestamps.chunk_irregular &&
@@ -1075,6 +1087,8 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
             if (sizes_io->pad) { // regular: the length, big endian
                 for (uint32_t k = 0; k < ts_bytes; k++)
                     dst[k] = (uint8_t)((uint64_t)count >> (8 * (ts_bytes - 1 - k)));
+            } else if (ts_by_wave && ts_bytes > 12) {
+                // k_fit_timestamps<true> has written it (before this kernel: the view reads its prefix)
             } else {
                 ByteSink sink(dst);
                 encode_irregular_timestamps(sink, ts, item.first, item.last);
@@ -1392,6 +1406,138 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
     }
 }
 
+// ---- k_fit_timestamps: one wave per segment of an irregular chunk -----------------------------------------
+//
+// compress_residual_timestamps (timestamps.rs:56-155) has no state that runs from code to code: the
+// delta-of-delta of point j needs timestamps j-2, j-1 and j, nothing else. So the lanes of a wave take
+// 64 points at a time - coalesced loads instead of one trip to memory per lane and point -, the code
+// lengths add up to the size (and to bit offsets, in write mode, where the codes are ORed into an LDS
+// bit buffer whose whole bytes are flushed, as k_fit_gap does for values). The same pass finds out
+// whether the segment is equally spaced after all. Bit-identical to encode_irregular_timestamps.
+
+constexpr uint32_t TS_WAVE_MIN_POINTS = 32;
+constexpr int TS_BUFFER_WORDS = 144; // 64 codes x 69 bits + a carried partial byte
+
+// Bits of the code for one delta-of-delta: `prefix` (prefix_bits <= 5... 16 for the short codes, which
+// carry their payload with them) followed by `payload_bits` in {0, 32, 64} bits of payload.
+__device__ __forceinline__ uint32_t delta_of_delta_code(int64_t dod, uint32_t *prefix, uint32_t *prefix_bits) {
+    if (dod == 0) { *prefix = 0; *prefix_bits = 1; return 0; }
+    if (dod >= -63 && dod <= 64) { *prefix = (0b10u << 7) | ((uint32_t)dod & 0x7fu); *prefix_bits = 9; return 0; }
+    if (dod >= -255 && dod <= 256) { *prefix = (0b110u << 9) | ((uint32_t)dod & 0x1ffu); *prefix_bits = 12; return 0; }
+    if (dod >= -2047 && dod <= 2048) { *prefix = (0b1110u << 12) | ((uint32_t)dod & 0xfffu); *prefix_bits = 16; return 0; }
+    *prefix_bits = 5;
+    if (dod >= -2147483647ll && dod <= 2147483648ll) { *prefix = 0b11110u; return 32; }
+    *prefix = 0b11111u;
+    return 64;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_timestamps(FitArgs args, const SegItem *__restrict__ items,
+                                                             TsResult *__restrict__ results, EncodeTargets targets) {
+    __shared__ uint32_t buffer[TS_BUFFER_WORDS];
+    const uint32_t segment = blockIdx.x;
+    const SegItem item = items[segment];
+    const uint32_t count = item.last - item.first + 1;
+    if (count < TS_WAVE_MIN_POINTS) return;
+    if (args.timestamps.chunk_irregular && !args.timestamps.chunk_irregular[item.chunk]) return; // O(1) elsewhere
+    const int lane = threadIdx.x;
+    const int64_t *__restrict__ t = args.timestamps.ts + args.chunk_offsets[item.chunk];
+    const uint32_t a = item.first, b = item.last;
+    // Point j (a < j < b) is stored as the code of (t[j] - t[j-1]) - (t[j-1] - t[j-2]); the first delta is
+    // compared with zero (timestamps.rs:118-137).
+    auto delta_of_delta = [&](uint32_t j) -> int64_t {
+        const uint64_t current = (uint64_t)t[j], before = (uint64_t)t[j - 1];
+        const uint64_t last_delta = j == a + 1 ? 0ull : before - (uint64_t)t[j - 2];
+        return (int64_t)((current - before) - last_delta);
+    };
+    if (!WRITE) {
+        const int64_t expected = t[a + 1] - t[a];
+        bool regular = true;
+        unsigned long long bits = 0;
+        for (uint32_t j = a + 1 + lane; j <= b; j += MDB_WAVE) {
+            if (t[j] - t[j - 1] != expected) regular = false;
+            if (j < b) {
+                uint32_t prefix, prefix_bits;
+                bits += delta_of_delta_code(delta_of_delta(j), &prefix, &prefix_bits) + prefix_bits;
+            }
+        }
+#pragma unroll
+        for (int delta = MDB_WAVE / 2; delta > 0; delta >>= 1) {
+            const uint32_t low = __shfl_down((uint32_t)bits, delta, MDB_WAVE);
+            const uint32_t high = __shfl_down((uint32_t)(bits >> 32), delta, MDB_WAVE);
+            bits += ((unsigned long long)high << 32) | low;
+        }
+        const bool all_regular = __all(regular);
+        if (lane == 0) {
+            TsResult result;
+            result.regular = all_regular ? 1u : 0u;
+            result.bytes = all_regular ? regular_length_bytes(count) : (uint32_t)((bits + 1 + 7) >> 3);
+            results[segment] = result;
+        }
+        return;
+    }
+    const TsResult mine = results[segment];
+    if (mine.bytes == 0xffffffffu || mine.regular || mine.bytes <= 12) return; // k_fit_encode writes those
+    uint8_t *__restrict__ dst = targets.data[0] + targets.data_offsets[0][segment];
+    for (int k = lane; k < TS_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) buffer[0] = 0x80000000u; // the flag "irregular" (timestamps.rs:116)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t carry_bits = 1;
+    uint64_t written = 0;
+    for (uint32_t base = a + 1; base < b; base += MDB_WAVE) {
+        const uint32_t j = base + lane;
+        const bool active = j < b;
+        uint32_t prefix = 0, prefix_bits = 0, payload_bits = 0;
+        int64_t dod = 0;
+        if (active) {
+            dod = delta_of_delta(j);
+            payload_bits = delta_of_delta_code(dod, &prefix, &prefix_bits);
+        }
+        const uint32_t code_bits = prefix_bits + payload_bits;
+        uint32_t inclusive = code_bits;
+#pragma unroll
+        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+            const uint32_t up = __shfl_up(inclusive, delta, MDB_WAVE);
+            if (lane >= delta) inclusive += up;
+        }
+        const uint32_t batch_bits = __shfl(inclusive, MDB_WAVE - 1, MDB_WAVE);
+        if (active) {
+            uint32_t at = carry_bits + inclusive - code_bits;
+            gap_put(buffer, at, prefix, prefix_bits);
+            at += prefix_bits;
+            if (payload_bits == 64) {
+                gap_put(buffer, at, (uint32_t)((uint64_t)dod >> 32), 32);
+                at += 32;
+            }
+            if (payload_bits != 0) gap_put(buffer, at, (uint32_t)dod, 32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t buffered = carry_bits + batch_bits;
+        const uint32_t whole_bytes = buffered >> 3;
+        for (uint32_t k = lane; k < whole_bytes; k += MDB_WAVE)
+            dst[written + k] = (uint8_t)(buffer[k >> 2] >> (24u - 8u * (k & 3u)));
+        const uint32_t partial = (buffer[whole_bytes >> 2] >> (24u - 8u * (whole_bytes & 3u))) & 0xffu;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < TS_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        carry_bits = buffered & 7u;
+        if (lane == 0 && carry_bits) buffer[0] = partial << 24;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        written += whole_bytes;
+    }
+    // finish_with_one_bits (bits.rs:159-166): the last byte is filled up with ones.
+    if (carry_bits && lane == 0) dst[written] = (uint8_t)((buffer[0] >> 24) | ((1u << (8u - carry_bits)) - 1u));
+}
+
 __global__ __launch_bounds__(256) void k_fit_size(FitArgs args, const unsigned long long *__restrict__ record_base,
                                                   const ModelRec *__restrict__ records,
                                                   const SegItem *__restrict__ items, uint64_t n_segments,
@@ -1468,6 +1614,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     args.eb = eb;
     args.gap_min_values = 0xffffffffu;
     args.gap_results = nullptr;
+    args.ts_results = nullptr;
 
     OwnedSegments *owned = new OwnedSegments();
     owned->device = ctx->device;
@@ -1660,6 +1807,17 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                                    gap_ids, n_gaps, gap_results, EncodeTargets{});
             }
         }
+        // Segments of irregular chunks: their timestamps are sized (and below, written) by a wave each.
+        const bool ts_by_wave = ts != nullptr && n_segments > 0 && n_segments <= 0x7fffffffull;
+        if (ts_by_wave) {
+            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_TS, n_segments * sizeof(TsResult), &p));
+            TsResult *ts_results = static_cast<TsResult *>(p);
+            FIT_CHECK(hipMemsetAsync(ts_results, 0xff, n_segments * sizeof(TsResult), ctx->stream));
+            args.ts_results = ts_results;
+            LaunchTimer timer(ctx, "k_fit_timestamps_size");
+            hipLaunchKernelGGL(k_fit_timestamps<false>, dim3((uint32_t)n_segments), dim3(MDB_WAVE), 0, ctx->stream, args,
+                               items, ts_results, EncodeTargets{});
+        }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_size");
             hipLaunchKernelGGL(k_fit_size, dim3(segment_blocks), dim3(256), 0, ctx->stream, args,
@@ -1720,6 +1878,11 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             LaunchTimer timer(ctx, "k_fit_gap_encode");
             hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                gap_ids, n_gaps, const_cast<GapResult *>(args.gap_results), targets);
+        }
+        if (ts_by_wave) { // before k_fit_encode as well
+            LaunchTimer timer(ctx, "k_fit_timestamps_encode");
+            hipLaunchKernelGGL(k_fit_timestamps<true>, dim3((uint32_t)n_segments), dim3(MDB_WAVE), 0, ctx->stream, args,
+                               items, const_cast<TsResult *>(args.ts_results), targets);
         }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_encode");
