@@ -162,7 +162,10 @@ int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, ui
 
 /* Compress many independent series chunks in one launch: chunk c is
  * [chunk_offsets[c], chunk_offsets[c + 1]) of ts/values. Segments come out grouped by chunk in
- * chunk order, each chunk's segments in time order; out->chunk_index names the chunk. */
+ * chunk order, each chunk's segments in time order; out->chunk_index names the chunk.
+ * Each BinaryView column of the result has ONE data buffer, which Arrow limits to 2 GiB: a call whose
+ * timestamps, values or residuals payloads add up to more fails and asks for fewer chunks per call
+ * (irregular timestamps: about 10^9 points; regular ones: no practical limit, 3 bytes per segment). */
 int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
                         const uint64_t *chunk_offsets, uint64_t n_chunks,
                         mdb_error_bound error_bound, mdb_segments_owned **out);
