@@ -1226,6 +1226,31 @@ __device__ __forceinline__ void gap_put(uint32_t *buffer, uint32_t at, uint32_t 
     }
 }
 
+// The LDS bit buffer of a wave holds `buffered` bits (the codes of one batch behind a carried partial
+// byte, all lanes' atomicOr's done): its whole bytes go to dst + *written, the partial byte moves to the
+// front of the cleared buffer. Returns how many bits that partial byte has.
+__device__ __forceinline__ uint32_t wave_flush_bits(uint32_t *buffer, int buffer_words, uint8_t *__restrict__ dst,
+                                                    uint64_t *written, uint32_t buffered, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t whole_bytes = buffered >> 3;
+    for (uint32_t b = lane; b < whole_bytes; b += MDB_WAVE)
+        dst[*written + b] = (uint8_t)(buffer[b >> 2] >> (24u - 8u * (b & 3u)));
+    const uint32_t partial = (buffer[whole_bytes >> 2] >> (24u - 8u * (whole_bytes & 3u))) & 0xffu;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < buffer_words; k += MDB_WAVE) buffer[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t carry_bits = buffered & 7u;
+    if (lane == 0 && carry_bits) buffer[0] = partial << 24;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    *written += whole_bytes;
+    return carry_bits;
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegItem *__restrict__ items,
                                                       const uint32_t *__restrict__ gap_ids,
@@ -1372,24 +1397,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
                     gap_put(buffer, at + 1, x >> my_trailing, meaningful);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t buffered = carry_bits + batch_bits;
-            const uint32_t whole_bytes = buffered >> 3;
-            for (uint32_t b = lane; b < whole_bytes; b += MDB_WAVE)
-                dst[written + b] = (uint8_t)(buffer[b >> 2] >> (24u - 8u * (b & 3u)));
-            const uint32_t partial = (buffer[whole_bytes >> 2] >> (24u - 8u * (whole_bytes & 3u))) & 0xffu;
-            __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < GAP_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            carry_bits = buffered & 7u;
-            if (lane == 0 && carry_bits) buffer[0] = partial << 24;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            written += whole_bytes;
+            carry_bits = wave_flush_bits(buffer, GAP_BUFFER_WORDS, dst, &written, carry_bits + batch_bits, lane);
         }
         total_bits += batch_bits;
     }
@@ -1515,24 +1523,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_timestamps(FitArgs args, const
             }
             if (payload_bits != 0) gap_put(buffer, at, (uint32_t)dod, 32);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t buffered = carry_bits + batch_bits;
-        const uint32_t whole_bytes = buffered >> 3;
-        for (uint32_t k = lane; k < whole_bytes; k += MDB_WAVE)
-            dst[written + k] = (uint8_t)(buffer[k >> 2] >> (24u - 8u * (k & 3u)));
-        const uint32_t partial = (buffer[whole_bytes >> 2] >> (24u - 8u * (whole_bytes & 3u))) & 0xffu;
-        __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < TS_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        carry_bits = buffered & 7u;
-        if (lane == 0 && carry_bits) buffer[0] = partial << 24;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        written += whole_bytes;
+        carry_bits = wave_flush_bits(buffer, TS_BUFFER_WORDS, dst, &written, carry_bits + batch_bits, lane);
     }
     // finish_with_one_bits (bits.rs:159-166): the last byte is filled up with ones.
     if (carry_bits && lane == 0) dst[written] = (uint8_t)((buffer[0] >> 24) | ((1u << (8u - carry_bits)) - 1u));
