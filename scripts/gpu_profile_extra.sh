@@ -14,3 +14,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_lo
 echo "lossless fit rc=$?"
 find $OUT -name "*.csv" -size +20M -delete
 for f in fit lossless lossless_fit; do tail -n 2 $OUT/prof_$f.log; done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_irregular -o irregular -- python3 $ROOT/scripts/profile_irregular.py > $OUT/prof_irregular.log 2>&1
+echo "irregular rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_lossless_agg -o lossless_agg -- python3 $ROOT/scripts/profile_lossless_agg.py > $OUT/prof_lossless_agg.log 2>&1
+echo "lossless agg rc=$?"
+find $OUT -name "*.csv" -size +20M -delete
+for f in irregular lossless_agg; do tail -n 3 $OUT/prof_$f.log; done
