@@ -1270,9 +1270,12 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
     const uint64_t n_tiles = (total + TILE_POINTS - 1) / TILE_POINTS;
     if (n_tiles > 0x7fffffffull) return fail("Too many output tiles for one launch.");
     {
+        // When no segment of the batch has regular timestamps, every timestamp comes from
+        // k_grid_serial and the tiles need not store 8 placeholder bytes per point.
+        int64_t *tile_ts = plan.host_header.metrics[7] == 0 ? nullptr : out_ts;
         LaunchTimer timer(ctx, "k_grid_tiles");
         hipLaunchKernelGGL(k_grid_tiles, dim3((uint32_t)n_tiles), dim3(TILE_THREADS), 0, ctx->stream,
-                           plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, out_ts,
+                           plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, tile_ts,
                            out_val);
     }
     const uint64_t n_serial = plan.host_header.n_serial;
