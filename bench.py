@@ -7,21 +7,31 @@ sine + noise compressed with a 1 % relative error bound, per GPU (weak scaling: 
 own 1k x 10M shard; series shard embarrassingly, no data-path collective). Segments are resident in
 HBM before the timed region and the reconstructed (timestamp, value) columns are written to HBM.
 
+`python bench.py --gpus N` starts the N ranks itself when it is not already one of them (a child
+`python -m torch.distributed.run`, started before this process touches a GPU; its JSON line is
+relayed and its exit code returned). With N = 1 the single rank still joins a 1-rank process group
+and an RCCL communicator of the C ABI (mdb_comm_init), so the final aggregate merge - the one
+exchange step of the path - runs over RCCL on every box.
+
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
-kernel (k_grid_tiles: algorithmic bytes / HIP-event time measured on the launch stream) and
-`cpu_baseline` (the CPU oracle, a port of the reference's per-row GridStream loop, timed on the
-host cores on a bounded sample of the same segments).
+kernel (k_grid_tiles: algorithmic bytes / HIP-event time measured on the launch stream),
+`cpu_baseline` (the CPU oracle, a port of the reference's per-row GridStream loop, timed on the host
+cores on a bounded sample of the same segments) and `verified`: what the run compared with the
+oracle AFTER the timed region (the fitted segments of the sample series byte for byte, the
+reconstructed columns of the sample bit for bit).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--series S] [--points P]
 """
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
 for _path in (REPO_ROOT, os.path.join(REPO_ROOT, "tests")):
@@ -32,6 +42,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s 
 CHUNK_POINTS = 65536    # ingest buffer of the reference server (storage/mod.rs:58)
 SEED = 0x4D44425F52454631
 INTERVAL_US = 1000
+GRID_KERNEL_SOURCES = ("mdb_grid.hip", "mdb_segment_dev.hpp", "mdb_common.hpp")
 
 
 def parse_args():
@@ -43,7 +54,11 @@ def parse_args():
     parser.add_argument("--points", type=int, default=10_000_000)
     parser.add_argument("--error-bound", type=float, default=1.0, help="relative bound in percent")
     parser.add_argument("--cpu-sample-series", type=int, default=48)
-    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--fit-sample-series", type=int, default=4)
+    parser.add_argument("--no-cpu-baseline", action="store_true",
+                        help="skip the CPU legs AND the in-run verification against the oracle")
+    parser.add_argument("--no-host-path", action="store_true",
+                        help="skip the end-to-end GridStream (PCIe-inclusive) measurement")
     parser.add_argument("--range-middle", type=float, default=0.0,
                         help="BASELINE config 5: the timed step is a point-range GridExec query over this "
                              "fraction of the time axis (centred), e.g. 0.5; 0 = the whole series (config 2)")
@@ -54,109 +69,182 @@ def parse_args():
     return parser.parse_args()
 
 
-def init_distributed(n_gpus):
-    rank = int(os.environ.get("RANK", "0"))
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks_if_needed(args):
+    """`bench.py --gpus N` with N > 1 outside a launcher: start the N ranks as a CHILD process - this
+    process has made no GPU call yet and never will - relay its output and leave with its code."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    environment = dict(os.environ)
+    environment.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(command, env=environment, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(child.stdout)
+    sys.stdout.flush()
+    sys.exit(child.returncode)
+
+
+def init_distributed(args):
+    """Every run is a torch.distributed job over RCCL, the single-GPU one included (a process group
+    of one rank), so the collective path is exercised wherever the bench runs."""
+    launched = "WORLD_SIZE" in os.environ
+    if not launched:
+        os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port())})
+    rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # Launched by torch.distributed.run (any world size, so the 1-GPU box exercises the RCCL path too).
-    if world > 1 or os.environ.get("TORCHELASTIC_RUN_ID") is not None:
-        import torch
-        import torch.distributed as dist_module
-        torch.cuda.set_device(local_rank)
-        dist_module.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_module
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     return rank, local_rank, world, dist
+
+
+def source_hash(names):
+    digest = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(REPO_ROOT, "modelardb-rs_amd", "csrc", name), "rb") as f:
+            digest.update(f.read())
+    return digest.hexdigest()[:16]
 
 
 def pmc_traffic(args, points_per_launch, segments_per_launch):
     """HBM bytes per launch of k_grid_tiles from the committed rocprofv3 PMC passes (bench.py cannot
     collect counters itself): WRITE_SIZE and FETCH_SIZE in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950. Only reported for the workload the passes ran on."""
+    MI355X_MICROARCH.md prescribes for gfx950. Only reported for the workload the passes ran on AND
+    while the kernel sources are the ones the passes measured (scripts/gpu_profile.sh stores their
+    hash next to the counters): otherwise null and the reason."""
     path = os.path.join(REPO_ROOT, "profiles", "pmc_grid_tiles.json")
     if not os.path.exists(path):
-        return None
+        return None, "profiles/pmc_grid_tiles.json is missing"
     with open(path) as f:
         pmc = json.load(f)
     if (pmc.get("series"), pmc.get("points")) != (args.series, args.points):
-        return None
+        return None, "the PMC passes ran on another workload"
+    if pmc.get("source_hash") != source_hash(GRID_KERNEL_SOURCES):
+        return None, ("the grid kernel sources changed since the PMC passes "
+                      f"(measured {pmc.get('source_hash')}, now {source_hash(GRID_KERNEL_SOURCES)}): "
+                      "rerun scripts/gpu_profile.sh")
     return (pmc["write_bytes_per_point"] * points_per_launch
-            + pmc["fetch_bytes_per_segment_corrected"] * segments_per_launch)
-
-
-def eb_for(args, mdb):
-    return mdb.error_bound("relative", args.error_bound)
+            + pmc["fetch_bytes_per_segment_corrected"] * segments_per_launch), None
 
 
 def barrier_and_sync(context, dist):
     """Both sides of the timed region: this rank's launch stream drained, every rank arrived, and
     (the barrier is a collective on torch's stream) torch's streams drained too."""
+    import torch
     context.sync()
-    if dist is not None:
-        import torch
-        dist.barrier()
-        torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
     context.sync()
 
 
-def fit_on_gpu(context, mdb, args, rank):
+def summary(seconds, units):
+    """{median, min, max} rates of a repeated timing."""
+    rates = sorted(units / s for s in seconds)
+    return {"median": statistics.median(rates), "min": rates[0], "max": rates[-1], "repetitions": len(rates)}
+
+
+def fit_on_gpu(context, mdb, np, args, rank, keep_series):
     """Generate this rank's series on the device and compress them with the HIP fitter, in groups of
-    series so that raw values never need more than a few GB of HBM at once."""
-    import ctypes as C
+    series so that raw values never need more than a few GB of HBM at once. Returns the device
+    batches, the timing of the (second, warm) fit call of every group with its k_fit_models kernel
+    time, and the raw values of the first `keep_series` series exactly as the fitter read them."""
     eb = mdb.error_bound("relative", args.error_bound)
     chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
     # All series of the rank in one launch when they fit (one lane per chunk: occupancy = chunks).
     group = max(1, min(args.series, args.fit_group_points // max(args.points, 1)))
-    parts, fit_seconds, fit_points = [], 0.0, 0
+    parts, fit_seconds, fit_points, kernel_ms, kept = [], 0.0, 0, {}, None
     first_series_of_rank = rank * args.series
     for first in range(0, args.series, group):
         n_series = min(group, args.series - first)
         total = n_series * args.points
         values = context.dev_alloc(4 * total)
         context.synth_values_dev(values, first_series_of_rank + first, n_series, args.points, SEED)
-        offsets = np.zeros(n_series * chunks_per_series + 1, dtype=np.uint64)
-        first_index = np.zeros(n_series * chunks_per_series, dtype=np.uint64)
-        k = 0
-        for s in range(n_series):
-            for c in range(chunks_per_series):
-                start = c * CHUNK_POINTS
-                offsets[k] = s * args.points + start
-                first_index[k] = start
-                k += 1
-        offsets[k] = total
+        starts = np.arange(0, args.points, CHUNK_POINTS, dtype=np.uint64)
+        offsets = (np.arange(n_series, dtype=np.uint64)[:, None] * np.uint64(args.points) + starts[None, :]).reshape(-1)
+        offsets = np.concatenate([offsets, np.array([total], dtype=np.uint64)])
+        first_index = np.tile(starts, n_series)
+        k = n_series * chunks_per_series
         offsets_dev = context.upload_array(offsets)
         first_index_dev = context.upload_array(first_index)
         # The first call grows the context's scratch (tens of GB of hipMalloc); time the second.
         context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US, first_index_dev).free()
         context.sync()
+        context.profile_enable(True)
+        context.profile_reset()
         t0 = time.perf_counter()
         parts.append(context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US,
                                                  first_index_dev))
         context.sync()
         fit_seconds += time.perf_counter() - t0
+        for name, (launches, ms) in context.profile().items():
+            if name.startswith("k_fit"):
+                kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
+        context.profile_enable(False)
         fit_points += total
+        if first == 0 and keep_series > 0:
+            kept = context.download_array(values, min(keep_series, n_series) * args.points, np.float32)
         for pointer in (values, offsets_dev, first_index_dev):
             context.dev_free(pointer)
-    return parts, fit_seconds, fit_points
+    return parts, fit_seconds, fit_points, kernel_ms, kept
+
+
+def host_path(context, mdb, np, part, args):
+    """The drop-in path end to end: the C++ GridExec / GridStream of libmdb_host over HOST segment
+    batches (what DataFusion would hand it), PCIe included: upload of the segments, kernels, copy of
+    the reconstructed columns back into page-locked memory. Not the headline (`value` is
+    device-resident); reported so the integrated number is on the record."""
+    from modelardb_rs_amd import host
+    chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
+    sample_series = max(1, min(args.series, 1_000_000_000 // max(args.points, 1)))
+    sample = part.download()
+    sample = sample.take(np.nonzero(sample.chunk_index < sample_series * chunks_per_series)[0])
+    out = {}
+    for batch_size in (8192, 65536):
+        if not hasattr(host, "measure_grid_stream"):
+            return None
+        points, seconds, bytes_down = host.measure_grid_stream(context, sample, batch_size)
+        out[f"batch_{batch_size}"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
+                                      "points": points, "segments": len(sample)}
+    return out
 
 
 def main():
     args = parse_args()
-    rank, local_rank, world, dist = init_distributed(args.gpus)
+    launch_ranks_if_needed(args)
+    rank, local_rank, world, dist = init_distributed(args)
+    import numpy as np
+    import torch
+
     import modelardb_rs_amd as mdb
+    from modelardb_rs_amd import sharding
 
     context = mdb.Context(local_rank)
     info = context.device_info()
+    sharding.init_comm(context, dist)  # the C ABI's own RCCL communicator (mdb_comm_init)
+    verify = rank == 0 and not args.no_cpu_baseline
 
     # ---- build the workload: fit on the GPU, keep the segments in HBM ---------------------------
-    parts, fit_seconds, fit_points = fit_on_gpu(context, mdb, args, rank)
+    n_fit_sample = min(args.fit_sample_series, args.series) if verify else 0
+    parts, fit_seconds, fit_points, fit_kernel_ms, fit_sample_values = fit_on_gpu(
+        context, mdb, np, args, rank, n_fit_sample)
     n_segments = sum(len(p) for p in parts)
 
     total_points = 0
     for part in parts:
         total_points += context.grid_count_dev(part)
     assert total_points == args.series * args.points, (total_points, args.series * args.points)
-    largest = max(context.grid_count_dev(p) for p in parts)
     out_ts = context.dev_alloc(8 * total_points)
     out_val = context.dev_alloc(4 * total_points)
 
@@ -193,15 +281,16 @@ def main():
     for _ in range(args.steps):
         produced, metrics = step()
     barrier_and_sync(context, dist)
-    elapsed = time.perf_counter() - t0
+    own_elapsed = time.perf_counter() - t0
     assert ranged or produced == total_points
     points_per_step = produced
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # MAX over ranks (and every rank's own time, for the min/max on the line).
+    t = torch.tensor([own_elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    per_rank_seconds = [float(x.item()) for x in gathered]
+    elapsed = max(per_rank_seconds)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream ------------------------
     context.profile_enable(True)
@@ -220,6 +309,7 @@ def main():
     segments_per_launch = n_segments / len(parts)
     algorithmic_bytes = 73.0 * segments_per_launch + 12.0 * points_per_launch
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, traffic_note = pmc_traffic(args, points_per_launch, segments_per_launch)
 
     # ---- secondary measurements on the same resident segments (not the headline) ----------------
     mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
@@ -243,15 +333,15 @@ def main():
     range_seconds = time.perf_counter() - t0
     agg_profile = context.profile()
     context.profile_enable(False)
-    if dist is not None:
-        # The one exchange step of the path: merge the per-GPU aggregate partials over RCCL/xGMI.
-        from modelardb_rs_amd import sharding
-        t0 = time.perf_counter()
-        state = sharding.all_reduce_state(state, dist, device=f"cuda:{local_rank}")
-        range_state = sharding.all_reduce_state(range_state, dist, device=f"cuda:{local_rank}")
-        reduce_seconds = time.perf_counter() - t0
-    else:
-        reduce_seconds = 0.0
+    # The one exchange step of the path: merge the per-GPU aggregate partials with the C ABI's
+    # mdb_agg_all_reduce (one 32-byte ncclAllGather over RCCL / xGMI + a rank-ordered fold).
+    local_state = mdb._abi.AggStateC(state.sum, state.count, state.min, state.max)
+    context.agg_all_reduce(state)  # first collective on the communicator: connection set-up
+    t0 = time.perf_counter()
+    state, ranks_seen = context.agg_all_reduce(local_state)
+    range_state, _ = context.agg_all_reduce(range_state)
+    reduce_seconds = (time.perf_counter() - t0) / 2
+    assert ranks_seen == world, (ranks_seen, world)
     assert state.count == world * total_points, (state.count, world * total_points)
     aggregates = {
         "segments_per_s": n_segments / agg_seconds,
@@ -265,55 +355,94 @@ def main():
                   "count": range_state.count, "min": range_state.min, "max": range_state.max, "sum": range_state.sum},
         "final_reduce_seconds": reduce_seconds,
         "note": "COUNT/MIN/MAX/SUM on the resident segments (BASELINE config 3: no grid); the range "
-                "variant clips to the middle half of the time axis; with N > 1 the partials of all "
-                "ranks are merged by one all-gather over RCCL",
+                "variant clips to the middle half of the time axis; the partials of all ranks are merged "
+                "by mdb_agg_all_reduce (C ABI): one 32-byte all-gather over RCCL per merge",
     }
 
-    # ---- CPU baseline: the oracle's per-row grid loop on a bounded sample -------------------------
+    # ---- in-run verification + CPU baseline: the oracle on a bounded sample -----------------------
     cpu_baseline = None
     fit_cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    verified = None
+    host_path_result = None
+    if verify:
         import oracle_lib as ora
-        sample = parts[0].download()
+        cores = os.cpu_count() or 1
+        eb = mdb.error_bound("relative", args.error_bound)
         chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
+        downloaded = parts[0].download()
         n_sample = min(args.cpu_sample_series, args.series)
         # Whole leading series: segments are ordered by chunk, chunks by series.
-        sample = sample.take(np.nonzero(sample.chunk_index < n_sample * chunks_per_series)[0])
-        cores = os.cpu_count() or 1
-        timing = {}
-        ts_cpu = ora.grid_batch(sample, n_threads=cores, timing=timing)[0]
-        cpu_seconds = timing["seconds"]
-        single = sample.take(np.nonzero(sample.chunk_index < chunks_per_series)[0])
-        ts_single = ora.grid_batch(single, n_threads=1, timing=timing)[0]
+        sample = downloaded.take(np.nonzero(downloaded.chunk_index < n_sample * chunks_per_series)[0])
+        ts_cpu, val_cpu, cpu_seconds = ora.grid_batch_timed(sample, cores, repetitions=3)
+        single = downloaded.take(np.nonzero(downloaded.chunk_index < chunks_per_series)[0])
+        ts_single, _, single_seconds = ora.grid_batch_timed(single, 1, repetitions=3)
+        rates = summary(cpu_seconds, len(ts_cpu))
         cpu_baseline = {
-            "value": len(ts_cpu) / cpu_seconds,
+            "value": rates["median"], "min": rates["min"], "max": rates["max"],
+            "repetitions": rates["repetitions"],
             "unit": "values/s",
             "cores": cores,
             "kind": "port",
             "sample": f"grid() of the first {n_sample} series ({len(ts_cpu)} points, {len(sample)} "
                       f"segments) of the same workload, segment ranges sharded over {cores} host "
-                      f"threads, output buffers pre-touched",
-            "single_thread_value": len(ts_single) / timing["seconds"],
+                      f"threads; median of 3 timed passes after one untimed pass",
+            "threads": f"{cores} worker threads, worker w pinned to the w-th allowed CPU; NUMA: Linux "
+                       "first-touch, every worker first-touches (untimed pass) the output pages it writes",
+            "single_thread_value": summary(single_seconds, len(ts_single))["median"],
         }
-        # The fitter's CPU baseline: the oracle's greedy compression of a few of the same series.
-        n_fit = min(4, args.series)
-        raw = context.dev_alloc(4 * n_fit * args.points)
-        context.synth_values_dev(raw, rank * args.series, n_fit, args.points, SEED)
-        host_values = context.download_array(raw, n_fit * args.points, np.float32)
-        context.dev_free(raw)
+        # grid verification: the device columns of the timed step against the oracle's, bit for bit.
+        if ranged:
+            keep = (ts_cpu >= step_lo) & (ts_cpu <= step_hi)
+            ts_cpu, val_cpu = ts_cpu[keep], val_cpu[keep]
+        grid_points_verified = 0
+        piece = 1 << 26
+        for at in range(0, len(ts_cpu), piece):
+            n_piece = min(piece, len(ts_cpu) - at)
+            got_ts = context.download_array(out_ts, n_piece, np.int64, offset_elements=at)
+            got_val = context.download_array(out_val, n_piece, np.float32, offset_elements=at)
+            if not np.array_equal(got_ts, ts_cpu[at:at + n_piece]):
+                raise SystemExit("VERIFICATION FAILED: grid timestamps differ from the oracle")
+            if not np.array_equal(got_val.view(np.uint32), val_cpu[at:at + n_piece].view(np.uint32)):
+                raise SystemExit("VERIFICATION FAILED: grid values differ from the oracle")
+            grid_points_verified += n_piece
+        del ts_cpu, val_cpu
+        # fit verification: the oracle's greedy compression of the very bytes the GPU fitted.
+        n_fit = n_fit_sample
         host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
         offsets = np.array([s * args.points + c for s in range(n_fit)
                             for c in range(0, args.points, CHUNK_POINTS)] + [n_fit * args.points],
                            dtype=np.uint64)
-        t0 = time.perf_counter()
-        fitted = ora.compress_chunks(host_ts, host_values, offsets, eb_for(args, mdb), n_threads=cores)
-        fit_cpu_seconds = time.perf_counter() - t0
-        fit_cpu = {"points_per_s": n_fit * args.points / fit_cpu_seconds,
-                   "segments_per_s": len(fitted) / fit_cpu_seconds, "cores": cores, "kind": "port",
-                   "sample": f"{n_fit} series x {args.points} points, chunks sharded over {cores} threads"}
+        import datagen
+        host_defined = np.concatenate([datagen.bench_series(rank * args.series + s, min(args.points, 1 << 20), SEED)
+                                       for s in range(n_fit)])
+        device_made = np.concatenate([fit_sample_values[s * args.points: s * args.points + min(args.points, 1 << 20)]
+                                      for s in range(n_fit)])
+        if not np.array_equal(host_defined.view(np.uint32), device_made.view(np.uint32)):
+            raise SystemExit("VERIFICATION FAILED: the device generator differs from tests/datagen.bench_series")
+        fitted, fit_cpu_seconds = ora.compress_chunks_timed(host_ts, fit_sample_values, offsets, eb, cores,
+                                                            repetitions=3)
+        gpu_fitted = downloaded.take(np.nonzero(downloaded.chunk_index < n_fit * chunks_per_series)[0])
+        if fitted.rows() != gpu_fitted.rows():
+            raise SystemExit("VERIFICATION FAILED: GPU segments differ from the oracle's")
+        fit_rates = summary(fit_cpu_seconds, n_fit * args.points)
+        fit_cpu = {"points_per_s": fit_rates["median"], "min": fit_rates["min"], "max": fit_rates["max"],
+                   "repetitions": fit_rates["repetitions"],
+                   "segments_per_s": len(fitted) / statistics.median(fit_cpu_seconds), "cores": cores,
+                   "kind": "port",
+                   "sample": f"{n_fit} series x {args.points} points, chunks sharded over {cores} pinned threads"}
+        verified = {"fit_segments": len(fitted), "fit_points": n_fit * args.points,
+                    "grid_points": grid_points_verified, "generator_points": len(host_defined),
+                    "how": "after the timed region: oracle fit of the sample series' exact bytes == GPU "
+                           "segments (all columns, byte for byte); oracle grid of the sample == the device "
+                           "columns the timed step wrote (bit for bit); device generator == host definition"}
+        del downloaded
+        if not args.no_host_path:
+            host_path_result = host_path(context, mdb, np, parts[0], args)
 
     if rank == 0:
         value = world * points_per_step * args.steps / elapsed
+        fit_models_ms = fit_kernel_ms.get("k_fit_models", 0.0) + fit_kernel_ms.get("k_fit_models_split", 0.0)
+        fit_gbps = 4.0 * fit_points / (fit_models_ms * 1e-3) / 1e9 if fit_models_ms > 0 else 0.0
         result = {
             "metric": "gridded values/sec",
             "value": value,
@@ -327,6 +456,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "rccl_ranks_seen": ranks_seen,
+            "ms_per_step_per_rank": {"min": 1e3 * min(per_rank_seconds) / args.steps,
+                                     "max": 1e3 * max(per_rank_seconds) / args.steps},
             "config": {
                 "workload": f"{args.series} series x {args.points} points sine+noise, "
                             f"relative error bound {args.error_bound} %, grid() decode of the "
@@ -338,6 +470,8 @@ def main():
                 "segments_per_gpu": n_segments,
                 "segment_mix": metrics,
                 "parallelism": f"series-sharded x{world}, no data-path collective",
+                "arithmetic": "Swing values as (f64 slope * f64 t + f64 intercept) -> f32, timestamps i64; "
+                              "output columns i64 + f32 (12 B/point)",
                 "device": info["name"],
             },
             "roofline": {
@@ -347,32 +481,43 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(args, points_per_launch, segments_per_launch),
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": algorithmic_bytes,
                 "other_kernels_ms": {name: ms / max(n, 1) for name, (n, ms) in profile.items()
                                      if name != "k_grid_tiles"},
             },
             "cpu_baseline": cpu_baseline,
+            "verified": verified,
             "aggregates": aggregates,
+            "host_path": host_path_result,
             "fit": {
                 "cpu_baseline": fit_cpu,
                 "points_per_s": fit_points / fit_seconds if fit_seconds > 0 else None,
                 "segments_per_s": n_segments / fit_seconds if fit_seconds > 0 else None,
                 "seconds": fit_seconds,
+                "roofline": {"bound": "hbm", "kernel": "k_fit_models", "achieved": fit_gbps,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fit_gbps / HBM_PEAK_GBPS,
+                             "kernel_ms": fit_models_ms,
+                             "algorithmic_bytes_per_launch": 4.0 * fit_points,
+                             "note": "4 B/point read (regular timestamps are synthesised, not loaded); the "
+                                     "greedy fit is a sequential dependency per chunk, so this kernel is "
+                                     "latency/issue-bound, far from the HBM roofline by nature"},
+                "kernels_ms": fit_kernel_ms,
                 "note": "PMC-Mean/Swing/MacaqueV fit of this rank's series on the GPU (setup, not "
                         "in the timed region), regular timestamps synthesised on the fly",
             },
         }
         print(json.dumps(result))
+        sys.stdout.flush()
 
     for part in parts:
         part.free()
     context.dev_free(out_ts)
     context.dev_free(out_val)
     context.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

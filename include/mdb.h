@@ -69,6 +69,12 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
 /* Copy a device batch back; the result has on_device = 0 and one data buffer per column. */
 int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **host);
 void mdb_segments_free(mdb_segments_owned *segments);
+/* mdb_segments_upload checks every out-of-line view of a HOST batch against the column's data buffers
+ * (a view that points outside them is an error, never a wild device read). A batch that is ALREADY on
+ * the device and was not made by this library (mdb_segments_upload / mdb_compress_chunks*) must be
+ * well formed: the "_dev" entry points follow buffer_index and offset without looking. This runs the
+ * same check on such a batch (views in device memory, buffer_sizes a host array as everywhere). */
+int mdb_segments_validate_dev(mdb_ctx *ctx, const mdb_segments *dev);
 
 /* ---- grid: replaces the per-row loop of GridStream::grid_and_append_to_leftovers_in_current_batch
  *      (crates/modelardb_storage/src/query/grid_exec.rs:323-356) which calls
@@ -178,6 +184,47 @@ int mdb_compress_chunks_dev(mdb_ctx *ctx, const int64_t *ts, const float *values
                             mdb_error_bound error_bound, int64_t regular_start,
                             int64_t regular_interval, const uint64_t *series_first_index,
                             mdb_segments_owned **out);
+
+/* try_split_and_compress_univariate_time_series (compression.rs:147-179): ONE sorted series with
+ * n_fields field columns that share its timestamps, field f compressed within error_bounds[f].
+ * out[f] receives field f's segments (host memory, as mdb_compress_series); on failure nothing is
+ * returned. The timestamps cross PCIe once. */
+int mdb_split_and_compress_univariate(mdb_ctx *ctx, const int64_t *ts, const float *const *field_values,
+                                      const mdb_error_bound *error_bounds, uint32_t n_fields, uint64_t n,
+                                      mdb_segments_owned **out);
+
+/* ---- the crate's two remaining public helpers (crates/modelardb_compression/src/lib.rs:30-33):
+ *      plain host arithmetic, no context, no GPU ------------------------------------------------- */
+
+/* is_value_within_error_bound (models/mod.rs:53-77; used by tests of the callers, e.g.
+ * crates/modelardb_server/tests/integration_test.rs:1232): *within = 1 or 0. */
+int mdb_is_value_within_error_bound(mdb_error_bound error_bound, float real_value, float approximate_value,
+                                    int32_t *within);
+/* are_compressed_timestamps_regular (models/timestamps.rs:199-202; grid_exec.rs:352 feeds the
+ * GridStreamMetrics with it): empty, or the top bit of the first byte is 0. */
+int mdb_are_compressed_timestamps_regular(const uint8_t *compressed_timestamps, uint64_t n_bytes,
+                                          int32_t *regular);
+
+/* ---- multi-GPU: the final aggregate merge over RCCL / xGMI -----------------------
+ * One process and one context per GPU; series are sharded over the GPUs and fit / grid / the
+ * per-segment aggregates never exchange anything. The single exchange step is the merge of the
+ * accumulators' partial states, which the reference hands to DataFusion's final aggregate
+ * (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:362-378, 517-534, 591-612). */
+
+#define MDB_COMM_ID_BYTES 128
+/* ncclGetUniqueId: called by ONE rank, which hands the 128 bytes to the others by whatever channel
+ * the host has (the reference's cluster already talks Arrow Flight; the bench uses torch's store). */
+int mdb_comm_unique_id(void *id_out);
+/* ncclCommInitRank on the context's device; collective over all `world` ranks. */
+int mdb_comm_init(mdb_ctx *ctx, int32_t rank, int32_t world, const void *unique_id);
+int mdb_comm_close(mdb_ctx *ctx); /* also done by mdb_close */
+/* Merge the partial states of all ranks: one ncclAllGather of 32 bytes per rank on the context's
+ * stream, then a fold in RANK ORDER with the accumulators' own rules, so that the f64 SUM is
+ * reproducible run to run and identical on every rank (an all-reduce leaves the order of the
+ * additions to the ring). Collective. ranks_seen (may be NULL): how many states arrived. */
+int mdb_agg_all_reduce(mdb_ctx *ctx, mdb_agg_state *inout, int32_t *ranks_seen);
+/* The fold itself, for hosts that move the states themselves: into = merge(into, from). */
+int mdb_agg_merge(mdb_agg_state *into, const mdb_agg_state *from);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

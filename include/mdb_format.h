@@ -143,4 +143,53 @@ typedef struct mdb_grid_result {
 }
 #endif
 
+/* The layouts above are the ABI: pinned here for C and C++ and, with the same numbers, as `const`
+ * assertions in rust/modelardb_hip/src/sys.rs and in tests/test_abi_cpu.py (ctypes). */
+#include <stddef.h>
+#ifdef __cplusplus
+#define MDB_LAYOUT_ASSERT(condition) static_assert(condition, #condition)
+#else
+#define MDB_LAYOUT_ASSERT(condition) _Static_assert(condition, #condition)
+#endif
+MDB_LAYOUT_ASSERT(sizeof(mdb_error_bound) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_error_bound, value) == 4);
+MDB_LAYOUT_ASSERT(sizeof(mdb_view16) == 16);
+MDB_LAYOUT_ASSERT(offsetof(mdb_view16, u) == 4);
+MDB_LAYOUT_ASSERT(sizeof(mdb_binview_col) == 32);
+MDB_LAYOUT_ASSERT(offsetof(mdb_binview_col, buffers) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_binview_col, buffer_sizes) == 16);
+MDB_LAYOUT_ASSERT(offsetof(mdb_binview_col, n_buffers) == 24);
+MDB_LAYOUT_ASSERT(sizeof(mdb_segments) == 144);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, model_type_id) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, start_time) == 16);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, end_time) == 24);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, timestamps) == 32);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, min_value) == 64);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, max_value) == 72);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, values) == 80);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments, residuals) == 112);
+MDB_LAYOUT_ASSERT(sizeof(mdb_grid_metrics) == 80);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_metrics, rows_created_by_model_type) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_metrics, segments_with_residuals) == 32);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_metrics, segments_with_model_type) == 40);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_metrics, segments_regular) == 64);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_metrics, segments_irregular) == 72);
+MDB_LAYOUT_ASSERT(sizeof(mdb_agg_state) == 24);
+MDB_LAYOUT_ASSERT(offsetof(mdb_agg_state, count) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_agg_state, min) == 16);
+MDB_LAYOUT_ASSERT(offsetof(mdb_agg_state, max) == 20);
+MDB_LAYOUT_ASSERT(sizeof(mdb_segments_owned) == 176);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments_owned, error) == 144);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments_owned, chunk_index) == 152);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments_owned, on_device) == 160);
+MDB_LAYOUT_ASSERT(offsetof(mdb_segments_owned, priv_) == 168);
+MDB_LAYOUT_ASSERT(sizeof(mdb_grid_result) == 136);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, values) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, rows_per_segment) == 16);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, n) == 24);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, n_segments) == 32);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, reserved_front) == 40);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, metrics) == 48);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, priv_) == 128);
+
 #endif /* MDB_FORMAT_H */

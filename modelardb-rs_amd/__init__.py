@@ -11,4 +11,7 @@ from ._abi import (  # noqa: F401
     MDB_PMC_MEAN_ID, MDB_SWING_ID, MODEL_TYPE_NAMES, load_hip_library,
 )
 from .segments import BinaryViewColumn, SegmentBatch, error_bound  # noqa: F401
-from .api import Context, DeviceSegments, HipError  # noqa: F401
+from .api import (  # noqa: F401
+    Context, DeviceSegments, HipError, are_compressed_timestamps_regular, comm_unique_id,
+    is_value_within_error_bound,
+)

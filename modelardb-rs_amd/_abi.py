@@ -28,6 +28,8 @@ MDB_AGG_MAX = 4
 MDB_AGG_SUM = 8
 MDB_AGG_AVG = 16
 
+MDB_COMM_ID_BYTES = 128
+
 F32_MAX = 3.4028234663852886e38
 
 
@@ -173,6 +175,19 @@ _HIP_SYMBOLS = {
     "mdb_compress_chunks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_uint64, ErrorBoundC, C.c_int64, C.c_int64,
                                           C.c_void_p, C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_segments_validate_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC)]),
+    "mdb_split_and_compress_univariate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                                    C.POINTER(ErrorBoundC), C.c_uint32, C.c_uint64,
+                                                    C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_is_value_within_error_bound": (C.c_int, [ErrorBoundC, C.c_float, C.c_float,
+                                                  C.POINTER(C.c_int32)]),
+    "mdb_are_compressed_timestamps_regular": (C.c_int, [C.c_void_p, C.c_uint64,
+                                                        C.POINTER(C.c_int32)]),
+    "mdb_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mdb_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mdb_comm_close": (C.c_int, [C.c_void_p]),
+    "mdb_agg_all_reduce": (C.c_int, [C.c_void_p, C.POINTER(AggStateC), C.POINTER(C.c_int32)]),
+    "mdb_agg_merge": (C.c_int, [C.POINTER(AggStateC), C.POINTER(AggStateC)]),
     "mdb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mdb_profile_reset": (C.c_int, [C.c_void_p]),
     "mdb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64),

@@ -54,6 +54,34 @@ class DeviceSegments:
             pass
 
 
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 bytes, made by one rank."""
+    lib = _abi.load_hip_library()
+    buffer = C.create_string_buffer(_abi.MDB_COMM_ID_BYTES)
+    if lib.mdb_comm_unique_id(buffer) != 0:
+        raise HipError(lib.mdb_last_error().decode())
+    return buffer.raw
+
+
+def is_value_within_error_bound(eb, real_value, approximate_value):
+    """models/mod.rs:53-77 through the C ABI (host arithmetic, no GPU)."""
+    lib = _abi.load_hip_library()
+    within = C.c_int32()
+    if lib.mdb_is_value_within_error_bound(eb, real_value, approximate_value, C.byref(within)) != 0:
+        raise HipError(lib.mdb_last_error().decode())
+    return bool(within.value)
+
+
+def are_compressed_timestamps_regular(data):
+    """models/timestamps.rs:199-202 through the C ABI (host arithmetic, no GPU)."""
+    lib = _abi.load_hip_library()
+    data = bytes(data)
+    regular = C.c_int32()
+    if lib.mdb_are_compressed_timestamps_regular(data, len(data), C.byref(regular)) != 0:
+        raise HipError(lib.mdb_last_error().decode())
+    return bool(regular.value)
+
+
 class Context:
     def __init__(self, device=0):
         self.lib = _abi.load_hip_library()
@@ -280,6 +308,53 @@ class Context:
             n_chunks, eb, regular_start, regular_interval, C.c_void_p(series_first_index_ptr),
             C.byref(out)))
         return DeviceSegments(self, out)
+
+    def try_split_and_compress_univariate_time_series(self, timestamps, field_values, error_bounds):
+        """compression.rs:147-179: one sorted series, several field columns sharing its timestamps,
+        one error bound per field. Returns one SegmentBatch per field."""
+        ts = np.ascontiguousarray(timestamps, dtype=np.int64)
+        fields = [np.ascontiguousarray(v, dtype=np.float32) for v in field_values]
+        for v in fields:
+            if len(v) != len(ts):
+                raise HipError(
+                    "Uncompressed timestamps and uncompressed values have different lengths.")
+        n_fields = len(fields)
+        pointers = (C.c_void_p * max(n_fields, 1))(*[v.ctypes.data for v in fields])
+        bounds = (_abi.ErrorBoundC * max(n_fields, 1))(*error_bounds)
+        out = (C.POINTER(_abi.SegmentsOwnedC) * max(n_fields, 1))()
+        self._check(self.lib.mdb_split_and_compress_univariate(
+            self.handle, ts.ctypes.data_as(C.c_void_p), pointers, bounds, n_fields, len(ts), out))
+        batches = []
+        for f in range(n_fields):
+            try:
+                batches.append(SegmentBatch.from_owned(out[f]))
+            finally:
+                self.lib.mdb_segments_free(out[f])
+        return batches
+
+    def validate_segments_dev(self, dev_segments):
+        """Raises HipError if an out-of-line view of a device batch points outside its buffers."""
+        seg = dev_segments.seg if hasattr(dev_segments, "seg") else dev_segments
+        self._check(self.lib.mdb_segments_validate_dev(self.handle, C.byref(seg)))
+
+    # ---- multi-GPU: the final aggregate merge over RCCL ------------------------------------------
+
+    def comm_init(self, rank, world, unique_id):
+        """ncclCommInitRank on this context's device (collective). `unique_id`: the 128 bytes of
+        `comm_unique_id()` made by ONE rank and handed to the others."""
+        buffer = C.create_string_buffer(bytes(unique_id), _abi.MDB_COMM_ID_BYTES)
+        self._check(self.lib.mdb_comm_init(self.handle, rank, world, buffer))
+
+    def comm_close(self):
+        self._check(self.lib.mdb_comm_close(self.handle))
+
+    def agg_all_reduce(self, state):
+        """Merge the partial aggregate states of all ranks (one 32-byte all-gather over RCCL + a
+        rank-ordered fold). Returns (merged state, ranks seen)."""
+        merged = _abi.AggStateC(state.sum, state.count, state.min, state.max)
+        seen = C.c_int32()
+        self._check(self.lib.mdb_agg_all_reduce(self.handle, C.byref(merged), C.byref(seen)))
+        return merged, seen.value
 
     def synth_values_dev(self, out_ptr, first_series, n_series, n_per_series,
                          seed=0x4D44425F52454631):

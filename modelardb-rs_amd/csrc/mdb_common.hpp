@@ -70,6 +70,7 @@ enum ScratchSlot {
     SCRATCH_MV,
     SCRATCH_AGG_MV,
     SCRATCH_STAGE_DEV,
+    SCRATCH_COMM,
     SCRATCH_SLOT_COUNT
 };
 
@@ -101,6 +102,11 @@ struct mdb_ctx {
 
     std::shared_ptr<mdb::PinnedPool> pinned_pool = std::make_shared<mdb::PinnedPool>();
 
+    // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).
+    void *comm = nullptr;
+    int comm_rank = 0;
+    int comm_world = 0;
+
     bool profiling = false;
     std::map<std::string, mdb::KernelTime> kernel_times;
     std::vector<mdb::PendingEvent> pending_events;
@@ -108,6 +114,9 @@ struct mdb_ctx {
 };
 
 namespace mdb {
+
+int validate_views_host(const mdb_binview_col &col, uint64_t n);
+void merge_agg_state(mdb_agg_state *into, const mdb_agg_state &from);
 
 // Grow-only device scratch, one allocation per slot.
 int scratch_reserve(mdb_ctx *ctx, ScratchSlot slot, uint64_t bytes, void **out);

@@ -138,6 +138,45 @@ int profile_collect(mdb_ctx *ctx) {
     return 0;
 }
 
+// Every out-of-line view must point into one of the column's data buffers: the kernels follow
+// buffer_index and offset without looking (view_data, mdb_common.hpp), so a view that does not is a
+// wild device read. The reference cannot build such a column (arrow validates it); a foreign or
+// corrupted batch gets an error here instead of a GPU memory fault.
+int validate_views_host(const mdb_binview_col &col, uint64_t n) {
+    for (int32_t b = 0; b < col.n_buffers; b++)
+        if (col.buffer_sizes[b] < 0) return fail("Malformed BinaryView: negative buffer size.");
+    for (uint64_t i = 0; i < n; i++) {
+        const mdb_view16 &view = col.views[i];
+        if (view.length < 0) return fail("Malformed BinaryView: negative length.");
+        if (view.length <= 12) continue;
+        const int32_t buffer = view.u.ref.buffer_index;
+        const int64_t offset = view.u.ref.offset;
+        if (buffer < 0 || buffer >= col.n_buffers || offset < 0 ||
+            offset + (int64_t)view.length > col.buffer_sizes[buffer])
+            return fail("Malformed BinaryView: row " + std::to_string(i) +
+                        " points outside the column's data buffers.");
+    }
+    return 0;
+}
+
+// The same check for a batch whose views are already in device memory (buffer_sizes stays a host
+// array, as everywhere in mdb_segments): flag[0] counts the offending views.
+__global__ __launch_bounds__(256) void k_validate_views(const uint4 *__restrict__ views, uint64_t n,
+                                                        const long long *__restrict__ buffer_sizes,
+                                                        int32_t n_buffers, unsigned int *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 view = views[i];
+    const int32_t length = (int32_t)view.x;
+    bool bad = length < 0;
+    if (!bad && length > 12) {
+        const int32_t buffer = (int32_t)view.z;
+        const int64_t offset = (int32_t)view.w;
+        bad = buffer < 0 || buffer >= n_buffers || offset < 0 || offset + length > buffer_sizes[buffer];
+    }
+    if (bad) atomicAdd(flag, 1u);
+}
+
 } // namespace mdb
 
 using namespace mdb;
@@ -171,6 +210,7 @@ int mdb_init(int device, mdb_ctx **out) {
 
 int mdb_close(mdb_ctx *ctx) {
     if (!ctx) return 0;
+    (void)mdb_comm_close(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->pending_events) {
@@ -213,6 +253,7 @@ int mdb_trim(mdb_ctx *ctx, uint64_t *released_bytes) {
 int mdb_set_stream(mdb_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail("ctx must not be NULL.");
     std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = static_cast<hipStream_t>(hip_stream);
@@ -244,6 +285,7 @@ int mdb_dev_alloc(mdb_ctx *ctx, uint64_t bytes, void **dev_ptr) {
 
 int mdb_dev_free(mdb_ctx *ctx, void *dev_ptr) {
     if (!ctx) return fail("ctx must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MDB_HIP_CHECK(hipFree(dev_ptr));
@@ -253,6 +295,8 @@ int mdb_dev_free(mdb_ctx *ctx, void *dev_ptr) {
 int mdb_dev_upload(mdb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes) {
     if (!ctx) return fail("ctx must not be NULL.");
     if (bytes == 0) return 0;
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -261,6 +305,8 @@ int mdb_dev_upload(mdb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t b
 int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes) {
     if (!ctx) return fail("ctx must not be NULL.");
     if (bytes == 0) return 0;
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -268,6 +314,8 @@ int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t
 
 int mdb_dev_sync(mdb_ctx *ctx) {
     if (!ctx) return fail("ctx must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -284,7 +332,12 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
         if (cols[c]->n_buffers < 0) return fail("n_buffers must not be negative.");
         if (cols[c]->n_buffers > 0 && (!cols[c]->buffers || !cols[c]->buffer_sizes))
             return fail("buffers and buffer_sizes must be given when n_buffers > 0.");
+        if (n > 0 && !cols[c]->views) return fail("views must not be NULL.");
+        if (validate_views_host(*cols[c], n)) return 1;
     }
+    if (n > 0 && (!host->model_type_id || !host->start_time || !host->end_time || !host->min_value ||
+                  !host->max_value))
+        return fail("The primitive columns must not be NULL.");
 
     struct Piece {
         const void *src;
@@ -417,7 +470,10 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
             base[b] = total;
             total += (uint64_t)cols[c]->buffer_sizes[b];
         }
-        if (total > 0x7fffffffull) rc = fail("A downloaded column exceeds 2 GiB of payload.");
+        if (total > 0x7fffffffull) {
+            rc = fail("A downloaded column exceeds 2 GiB of payload.");
+            break;
+        }
         owned->host_allocs[8 + c].resize(total);
         for (int b = 0; b < cols[c]->n_buffers && !rc; b++) {
             uint64_t bytes = (uint64_t)cols[c]->buffer_sizes[b];
@@ -430,7 +486,13 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
             mdb_view16 *views = reinterpret_cast<mdb_view16 *>(owned->host_allocs[5 + c].data());
             for (uint64_t i = 0; i < n; i++) {
                 if (views[i].length > 12) {
-                    views[i].u.ref.offset += (int32_t)base[views[i].u.ref.buffer_index];
+                    const int32_t buffer = views[i].u.ref.buffer_index;
+                    if (buffer < 0 || buffer >= cols[c]->n_buffers) {
+                        rc = fail("Malformed BinaryView: buffer index out of range.");
+                        break;
+                    }
+                    // (total <= 2 GiB was checked above, so the rebased offset fits)
+                    views[i].u.ref.offset = (int32_t)((int64_t)views[i].u.ref.offset + (int64_t)base[(size_t)buffer]);
                     views[i].u.ref.buffer_index = 0;
                 }
             }
@@ -468,6 +530,38 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
     return 0;
 }
 
+int mdb_segments_validate_dev(mdb_ctx *ctx, const mdb_segments *dev) {
+    if (!ctx || !dev) return fail("ctx and dev must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    const mdb_binview_col *cols[3] = {&dev->timestamps, &dev->values, &dev->residuals};
+    if (dev->n == 0) return 0;
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_HEADER, sizeof(unsigned int) * 64, &p)) return 1;
+    unsigned int *flag = static_cast<unsigned int *>(p);
+    MDB_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+    for (int c = 0; c < 3; c++) {
+        const int32_t n_buffers = cols[c]->n_buffers;
+        if (n_buffers < 0) return fail("n_buffers must not be negative.");
+        if (n_buffers > 0 && !cols[c]->buffer_sizes) return fail("buffer_sizes must be given when n_buffers > 0.");
+        if (scratch_reserve(ctx, SCRATCH_STAGE_DEV, 8 * (uint64_t)(n_buffers + 1), &p)) return 1;
+        long long *sizes = static_cast<long long *>(p);
+        if (n_buffers > 0)
+            MDB_HIP_CHECK(hipMemcpyAsync(sizes, cols[c]->buffer_sizes, 8 * (size_t)n_buffers, hipMemcpyHostToDevice,
+                                         ctx->stream));
+        hipLaunchKernelGGL(k_validate_views, dim3((uint32_t)((dev->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const uint4 *>(cols[c]->views), dev->n, sizes, n_buffers, flag);
+        // (the pageable copy above has completed on return; the kernel reads `sizes` before the next
+        // column overwrites it because everything is in stream order)
+    }
+    unsigned int bad = 0;
+    MDB_HIP_CHECK(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipGetLastError());
+    if (bad) return fail("Malformed BinaryView: " + std::to_string(bad) + " views point outside the data buffers.");
+    return 0;
+}
+
 void mdb_segments_free(mdb_segments_owned *segments) {
     if (!segments) return;
     OwnedSegments *owned = static_cast<OwnedSegments *>(segments->priv_);
@@ -478,6 +572,39 @@ void mdb_segments_free(mdb_segments_owned *segments) {
         for (void *p : owned->device_allocs) (void)hipFree(p);
     }
     delete owned;
+}
+
+int mdb_is_value_within_error_bound(mdb_error_bound eb, float real_value, float approximate_value,
+                                    int32_t *within) {
+    if (!within) return fail("within must not be NULL.");
+    // models/mod.rs:53-77, the arithmetic of within_error_bound in mdb_fit.hip on the host: equal (or
+    // both NaN) first, then the f32 comparison of the bound's kind.
+    const double real = (double)real_value, approximate = (double)approximate_value;
+    bool result;
+    if (real == approximate || (real != real && approximate != approximate)) {
+        result = true;
+    } else if (eb.kind == MDB_EB_ABSOLUTE) {
+        result = fabsf(real_value - approximate_value) <= eb.value;
+    } else if (eb.kind == MDB_EB_RELATIVE) {
+        const float difference = real_value - approximate_value;
+        const float ratio = fabsf(difference / real_value);
+        result = (ratio * 100.0f) <= eb.value;
+    } else if (eb.kind == MDB_EB_LOSSLESS) {
+        result = false;
+    } else {
+        return fail("Invalid error bound.");
+    }
+    *within = result ? 1 : 0;
+    return 0;
+}
+
+int mdb_are_compressed_timestamps_regular(const uint8_t *compressed_timestamps, uint64_t n_bytes,
+                                          int32_t *regular) {
+    if (!regular || (n_bytes > 0 && !compressed_timestamps))
+        return fail("regular and compressed_timestamps must not be NULL.");
+    // timestamps.rs:199-202
+    *regular = (n_bytes == 0 || (compressed_timestamps[0] & 128u) == 0) ? 1 : 0;
+    return 0;
 }
 
 int mdb_profile_enable(mdb_ctx *ctx, int enabled) {

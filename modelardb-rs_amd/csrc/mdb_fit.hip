@@ -1616,9 +1616,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     };
 #define FIT_CHECK(expr)                                                                            \
     do {                                                                                           \
-        if ((expr) != hipSuccess) {                                                                \
+        const hipError_t fit_err_ = (expr);                                                        \
+        if (fit_err_ != hipSuccess) {                                                              \
             release();                                                                             \
-            return fail(std::string(#expr) + " failed: " + hipGetErrorString(hipGetLastError()));  \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(fit_err_));           \
         }                                                                                          \
     } while (0)
 #define FIT_TRY(expr)                                                                              \
@@ -1982,6 +1983,59 @@ int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, ui
                         mdb_error_bound error_bound, mdb_segments_owned **out) {
     const uint64_t offsets[2] = {0, n};
     return mdb_compress_chunks(ctx, ts, values, offsets, 1, error_bound, out);
+}
+
+int mdb_split_and_compress_univariate(mdb_ctx *ctx, const int64_t *ts, const float *const *field_values,
+                                      const mdb_error_bound *error_bounds, uint32_t n_fields, uint64_t n,
+                                      mdb_segments_owned **out) {
+    if (!ctx || !out) return fail("ctx and out must not be NULL.");
+    if (n_fields > 0 && (!field_values || !error_bounds)) return fail("field_values and error_bounds must not be NULL.");
+    if (n > 0 && !ts) return fail("ts must not be NULL.");
+    for (uint32_t f = 0; f < n_fields; f++) {
+        out[f] = nullptr;
+        if (n > 0 && !field_values[f]) return fail("field_values[f] must not be NULL.");
+    }
+    // The fields share the timestamps (compression.rs:153-157): uploaded once, every field fitted
+    // against the same device array.
+    std::vector<mdb_segments_owned *> on_device(n_fields, nullptr);
+    void *dev_ts = nullptr, *dev_values = nullptr, *dev_offsets = nullptr;
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        MDB_HIP_CHECK(hipSetDevice(ctx->device));
+        const uint64_t offsets[2] = {0, n};
+        if (hipMalloc(&dev_ts, n ? 8 * n : 256) != hipSuccess || hipMalloc(&dev_values, n ? 4 * n : 256) != hipSuccess ||
+            hipMalloc(&dev_offsets, 16) != hipSuccess)
+            rc = fail("hipMalloc failed.");
+        if (!rc && n && hipMemcpyAsync(dev_ts, ts, 8 * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            rc = fail("hipMemcpy host to device failed.");
+        if (!rc && hipMemcpyAsync(dev_offsets, offsets, 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            rc = fail("hipMemcpy host to device failed.");
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+        for (uint32_t f = 0; f < n_fields && !rc; f++) {
+            if (n && hipMemcpyAsync(dev_values, field_values[f], 4 * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy host to device failed.");
+            if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+            if (!rc)
+                rc = compress_chunks_dev_locked(ctx, static_cast<const int64_t *>(dev_ts),
+                                                static_cast<const float *>(dev_values),
+                                                static_cast<const uint64_t *>(dev_offsets), n ? 1 : 0, error_bounds[f],
+                                                0, 0, nullptr, &on_device[f]);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        if (dev_ts) (void)hipFree(dev_ts);
+        if (dev_values) (void)hipFree(dev_values);
+        if (dev_offsets) (void)hipFree(dev_offsets);
+    }
+    for (uint32_t f = 0; f < n_fields && !rc; f++) rc = mdb_segments_download(ctx, on_device[f], &out[f]);
+    for (uint32_t f = 0; f < n_fields; f++) {
+        if (on_device[f]) mdb_segments_free(on_device[f]);
+        if (rc && out[f]) {
+            mdb_segments_free(out[f]);
+            out[f] = nullptr;
+        }
+    }
+    return rc ? 1 : 0;
 }
 
 } // extern "C"

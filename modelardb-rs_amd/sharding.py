@@ -43,21 +43,37 @@ def unpack_state(data):
 
 def merge_states(states):
     """Fold partial states in the given order with the accumulators' own rules
-    (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:355, 398, 441, 501)."""
+    (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:355, 398, 441, 501): the
+    fold of the C ABI (mdb_agg_merge, csrc/mdb_comm.hip), the same one mdb_agg_all_reduce applies to
+    what its all-gather returns."""
+    import ctypes as C
+    lib = _abi.load_hip_library()
     out = _abi.AggStateC.fresh()
     for state in states:
-        out.sum += state.sum
-        out.count += state.count
-        if not (state.min != state.min) and (out.min != out.min or state.min < out.min):
-            out.min = state.min
-        if not (state.max != state.max) and (out.max != out.max or state.max > out.max):
-            out.max = state.max
+        part = _abi.AggStateC(state.sum, state.count, state.min, state.max)
+        if lib.mdb_agg_merge(C.byref(out), C.byref(part)) != 0:
+            raise RuntimeError(lib.mdb_last_error().decode())
     return out
 
 
-def all_reduce_state(state, dist, device=None):
+def init_comm(context, dist):
+    """Give `context` its RCCL communicator (mdb_comm_init): rank 0 makes the unique id through the
+    C ABI and the process group that launched the ranks hands it round (any channel would do - a
+    Rust host would use its own)."""
+    from . import api
+    rank, world = dist.get_rank(), dist.get_world_size()
+    payload = [api.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(payload, src=0)
+    context.comm_init(rank, world, payload[0])
+
+
+def all_reduce_state(state, dist=None, device=None, context=None):
     """Merge every rank's partial aggregate state; every rank gets the same result.
-    `dist` is torch.distributed (backend nccl = RCCL over xGMI on the GPU box, gloo on CPU)."""
+    With `context` (a Context after init_comm) the exchange is the C ABI's mdb_agg_all_reduce: one
+    ncclAllGather over RCCL / xGMI on the context's stream. Without, `dist` (torch.distributed) moves
+    the bytes - gloo in the CPU tests - and the same fold is applied."""
+    if context is not None:
+        return context.agg_all_reduce(state)[0]
     import torch
     world = dist.get_world_size()
     payload = torch.frombuffer(bytearray(pack_state(state)), dtype=torch.uint8).clone()

@@ -24,6 +24,8 @@
 #include <limits>
 #include <string>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include <vector>
 
 namespace {
@@ -1321,6 +1323,31 @@ int ora_model_finish(const ora_model *model, mdb_error_bound eb, uint64_t residu
     return 0;
 }
 
+/* Baseline hygiene for the timed legs (bench.py's cpu_baseline): with pinning on, worker w of the
+ * threaded entry points runs on the w-th CPU the process is allowed on and stays there, so a page a
+ * worker touches first is and remains local to it (Linux first-touch NUMA policy). */
+static int g_pin_threads = 0;
+static void pin_worker(uint64_t w) {
+    if (!g_pin_threads) return;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int count = CPU_COUNT(&allowed);
+    if (count <= 0) return;
+    int want = (int)(w % (uint64_t)count), seen = 0;
+    for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
+        if (!CPU_ISSET(cpu, &allowed)) continue;
+        if (seen++ == want) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpu, &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            return;
+        }
+    }
+}
+void ora_set_thread_pinning(int enabled) { g_pin_threads = enabled != 0; }
+
 int ora_compress_chunks(const int64_t *ts, const float *v, const uint64_t *chunk_offsets,
                         uint64_t n_chunks, mdb_error_bound eb, int n_threads,
                         mdb_segments_owned **out) {
@@ -1336,6 +1363,7 @@ int ora_compress_chunks(const int64_t *ts, const float *v, const uint64_t *chunk
         std::vector<std::thread> threads;
         for (uint64_t w = 0; w < workers; w++) {
             threads.emplace_back([&, w]() {
+                pin_worker(w);
                 uint64_t begin = n_chunks * w / workers;
                 uint64_t end = n_chunks * (w + 1) / workers;
                 for (uint64_t c = begin; c < end; c++)
@@ -1419,6 +1447,7 @@ int ora_grid_batch_mt(const mdb_segments *in, int64_t *out_ts, float *out_val, u
         std::vector<std::thread> threads;
         for (uint64_t w = 0; w < workers; w++) {
             threads.emplace_back([&, w]() {
+                pin_worker(w);
                 uint64_t begin, end;
                 range(w, &begin, &end);
                 for (uint64_t row = begin; row < end; row++) {
@@ -1448,6 +1477,7 @@ int ora_grid_batch_mt(const mdb_segments *in, int64_t *out_ts, float *out_val, u
         std::vector<std::thread> threads;
         for (uint64_t w = 0; w < workers; w++) {
             threads.emplace_back([&, w]() {
+                pin_worker(w);
                 uint64_t begin, end;
                 range(w, &begin, &end);
                 std::vector<int64_t> ts_builder;

@@ -119,6 +119,9 @@ int ora_grid_batch(const mdb_segments *in, int64_t *out_ts, float *out_val,
 /* Same loop sharded over n_threads host threads by contiguous segment ranges (CPU baseline). */
 int ora_grid_batch_mt(const mdb_segments *in, int64_t *out_ts, float *out_val, uint64_t cap,
                       uint64_t *n_out, int n_threads);
+/* Timed legs only (bench.py cpu_baseline): pin worker w of the threaded entry points to the w-th CPU
+ * the process may run on, so first-touched pages stay local to their worker. Off by default. */
+void ora_set_thread_pinning(int enabled);
 /* optimizer/model_simple_aggregates.rs:345-358,395-401,438-444,481-513,553-587 */
 int ora_agg_batch(const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout);
 /* Oracle of the time-range extension: grid + filter t_lo <= ts <= t_hi + aggregate, which is what

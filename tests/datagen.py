@@ -82,3 +82,50 @@ def sine_series(series_index, n_points, seed=0x4D44425F52454631, t0=0, delta=100
     values = (100.0 + 10.0 * np.sin(2.0 * np.pi * i / period + phase) + noise).astype(np.float32)
     timestamps = t0 + np.arange(n_points, dtype=np.int64) * delta
     return timestamps, values
+
+
+_BENCH_SEED = 0x4D44425F52454631
+
+
+def _splitmix64(x):
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _sine_of_turns(turns):
+    """sin(2 pi turns), turns in [0, 1): the fixed polynomial of mdb_synth.hip, the same IEEE
+    operations in the same order (numpy never fuses a * b + c)."""
+    quarters = turns * 4.0
+    quadrant = np.floor(quarters)
+    x = (quarters - quadrant) * 1.5707963267948966
+    x2 = x * x
+    s = np.full_like(x, -7.6471637318198164759e-13)
+    for coefficient in (1.6059043836821614599e-10, -2.5052108385441718775e-08,
+                        2.7557319223985890653e-06, -1.9841269841269841270e-04,
+                        8.3333333333333333333e-03, -1.6666666666666666667e-01, 1.0):
+        s = s * x2 + coefficient
+    s = s * x
+    c = np.full_like(x, 4.7794773323873852974e-14)
+    for coefficient in (-1.1470745597729724714e-11, 2.0876756987868098979e-09,
+                        -2.7557319223985890653e-07, 2.4801587301587301587e-05,
+                        -1.3888888888888888889e-03, 4.1666666666666666667e-02, -0.5, 1.0):
+        c = c * x2 + coefficient
+    return np.where(quadrant == 0.0, s, np.where(quadrant == 1.0, c, np.where(quadrant == 2.0, -s, -c)))
+
+
+def bench_series(series_index, n_points, seed=_BENCH_SEED, first_point=0):
+    """The benchmark workload of SURVEY 8(d) / bench.py, defined on the host: bit for bit what the
+    device generator (mdb_synth_values_dev, csrc/mdb_synth.hip) writes for series `series_index`,
+    points [first_point, first_point + n_points). Returns f32 values."""
+    with np.errstate(over="ignore"):
+        i = np.arange(first_point, first_point + n_points, dtype=np.uint64)
+        period = 2000.0 + 37.0 * float(series_index % 64)
+        fraction = float(series_index) * 0.61803
+        fraction -= np.floor(fraction)
+        turns = i.astype(np.float64) / period + fraction
+        turns -= np.floor(turns)
+        h = _splitmix64(np.uint64(seed) ^ (np.uint64(series_index) << np.uint64(40)) ^ i)
+        u = ((h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) - 0.5) * 0.1
+        return (100.0 + 10.0 * _sine_of_turns(turns) + u).astype(np.float32)

@@ -365,6 +365,46 @@ def grid_batch(batch, n_threads=1, timing=None):
     return out_ts[: n_out.value], out_val[: n_out.value], rows, metrics.as_dict()
 
 
+def grid_batch_timed(batch, n_threads, repetitions=3, pin=True):
+    """The timed CPU-baseline leg: the per-row GridStream loop sharded over `n_threads` workers, each
+    pinned to a CPU of its own (ora_set_thread_pinning). The outputs are allocated untouched; one
+    untimed pass lets every worker first-touch the pages it writes (NUMA-local under Linux's default
+    first-touch policy), then `repetitions` passes are timed. Returns (timestamps, values, seconds[])."""
+    import time
+    seg = batch.as_c()
+    cap = grid_count(batch)
+    out_ts = np.empty(cap, dtype=np.int64)
+    out_val = np.empty(cap, dtype=np.float32)
+    n_out = C.c_uint64()
+    lib().ora_set_thread_pinning(1 if pin else 0)
+    try:
+        seconds = []
+        for repetition in range(repetitions + 1):
+            started = time.perf_counter()
+            _check(lib().ora_grid_batch_mt(C.byref(seg), _ptr(out_ts), _ptr(out_val), C.c_uint64(cap),
+                                           C.byref(n_out), C.c_int(max(n_threads, 1))))
+            if repetition > 0:
+                seconds.append(time.perf_counter() - started)
+    finally:
+        lib().ora_set_thread_pinning(0)
+    return out_ts[: n_out.value], out_val[: n_out.value], seconds
+
+
+def compress_chunks_timed(timestamps, values, chunk_offsets, eb, n_threads, repetitions=3, pin=True):
+    """The timed CPU-baseline leg of the fitter: returns (segments of the last pass, seconds[])."""
+    import time
+    lib().ora_set_thread_pinning(1 if pin else 0)
+    try:
+        seconds, fitted = [], None
+        for _ in range(repetitions):
+            started = time.perf_counter()
+            fitted = compress_chunks(timestamps, values, chunk_offsets, eb, n_threads=n_threads)
+            seconds.append(time.perf_counter() - started)
+    finally:
+        lib().ora_set_thread_pinning(0)
+    return fitted, seconds
+
+
 def agg_batch(batch, which_mask, state=None):
     seg = batch.as_c()
     state = state or _abi.AggStateC.fresh()

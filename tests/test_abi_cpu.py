@@ -43,6 +43,86 @@ def test_struct_layouts():
     assert ctypes.sizeof(_abi.GridResultC) == 3 * 8 + 3 * 8 + ctypes.sizeof(_abi.GridMetricsC) + 8
 
 
+def test_struct_layouts_match_the_pinned_numbers_of_the_header():
+    """include/mdb_format.h pins sizeof/offsetof of every ABI struct with static assertions; the
+    same numbers are asserted in rust/modelardb_hip/src/sys.rs. The ctypes mirror must agree."""
+    text = open(os.path.join(REPO_ROOT, "include", "mdb_format.h")).read()
+    mirror = {"mdb_error_bound": _abi.ErrorBoundC, "mdb_binview_col": _abi.BinViewColC,
+              "mdb_segments": _abi.SegmentsC, "mdb_grid_metrics": _abi.GridMetricsC,
+              "mdb_agg_state": _abi.AggStateC, "mdb_segments_owned": _abi.SegmentsOwnedC,
+              "mdb_grid_result": _abi.GridResultC}
+    sizes = dict(re.findall(r"MDB_LAYOUT_ASSERT\(sizeof\((\w+)\) == (\d+)\)", text))
+    offsets = re.findall(r"MDB_LAYOUT_ASSERT\(offsetof\((\w+), (\w+)\) == (\d+)\)", text)
+    assert set(mirror) <= set(sizes) and len(offsets) >= 30
+    for name, struct in mirror.items():
+        assert ctypes.sizeof(struct) == int(sizes[name]), name
+    for name, field, offset in offsets:
+        if name in mirror:
+            assert getattr(mirror[name], field).offset == int(offset), (name, field)
+    rust = open(os.path.join(REPO_ROOT, "rust", "modelardb_hip", "src", "sys.rs")).read()
+    for name, size in sizes.items():
+        assert re.search(rf"size_of::<{name}>\(\) == {size}\b", rust), f"sys.rs does not pin sizeof({name})"
+    for name, field, offset in offsets:
+        assert re.search(rf"offset_of!\({name}, {field}\) == {offset}\b", rust), (name, field)
+
+
+def test_crate_helpers_through_the_c_abi_match_the_oracle():
+    """is_value_within_error_bound / are_compressed_timestamps_regular (lib.rs:30-33) are plain host
+    arithmetic behind the C ABI; the reference's own cases (models/mod.rs:298-405,
+    timestamps.rs:457-478) and a random sweep against the oracle."""
+    import oracle_lib as ora
+    absolute, relative, lossless = (mdb.error_bound("absolute", 1.0), mdb.error_bound("relative", 10.0),
+                                    mdb.error_bound("lossless"))
+    assert mdb.is_value_within_error_bound(absolute, 10.0, 11.0)
+    assert mdb.is_value_within_error_bound(relative, 10.0, 11.0)
+    assert not mdb.is_value_within_error_bound(lossless, 10.0, 11.0)
+    nan, inf = float("nan"), float("inf")
+    for eb in (absolute, relative, lossless):
+        assert mdb.is_value_within_error_bound(eb, nan, nan)
+        assert mdb.is_value_within_error_bound(eb, inf, inf)
+        for a, b in ((inf, -inf), (nan, 1.0), (1.0, nan), (inf, 1.0), (1.0, -inf)):
+            assert not mdb.is_value_within_error_bound(eb, a, b)
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        eb = (mdb.error_bound("absolute", float(10.0 ** rng.uniform(-6, 3))) if rng.random() < 0.5
+              else mdb.error_bound("relative", float(rng.uniform(1e-3, 100.0))))
+        real = float(np.float32(rng.normal() * 10.0 ** rng.integers(-3, 6)))
+        approximate = float(np.float32(real * (1.0 + rng.normal() * 0.05)))
+        assert mdb.is_value_within_error_bound(eb, real, approximate) == \
+            bool(ora.is_value_within_error_bound(eb, real, approximate))
+    assert mdb.are_compressed_timestamps_regular(b"")
+    assert mdb.are_compressed_timestamps_regular(bytes([0x05]))
+    assert mdb.are_compressed_timestamps_regular(bytes([0x00, 0x80]))
+    assert not mdb.are_compressed_timestamps_regular(bytes([0x80, 0x01]))
+    for data in (ora.compress_residual_timestamps(np.arange(5) * 100),
+                 ora.compress_residual_timestamps(np.array([0, 100, 250, 300, 470, 600]))):
+        assert mdb.are_compressed_timestamps_regular(data) == bool(ora.are_compressed_timestamps_regular(data))
+
+
+def test_rust_binding_declares_every_symbol():
+    rust = open(os.path.join(REPO_ROOT, "rust", "modelardb_hip", "src", "sys.rs")).read()
+    for name in _declared_in_header():
+        assert re.search(rf"pub fn {name}\(", rust), f"sys.rs does not declare {name}"
+
+
+def test_rust_patches_apply_to_the_reference():
+    """The three call-site patches apply cleanly to the reference tree (present in the authoring
+    container only; nothing at run time reads it)."""
+    import glob
+    import subprocess
+    reference = "/root/reference"
+    if not os.path.isdir(os.path.join(reference, "crates")):
+        pytest.skip("the reference tree is not present")
+    patches = sorted(glob.glob(os.path.join(REPO_ROOT, "rust", "patches", "*.patch")))
+    assert len(patches) == 3
+    for patch in patches:
+        with open(patch) as f:
+            done = subprocess.run(["patch", "-p1", "--dry-run", "--force", "-d", reference], stdin=f,
+                                  capture_output=True, text=True)
+        assert done.returncode == 0, done.stdout + done.stderr
+        assert "FAILED" not in done.stdout and "fuzz" not in done.stdout, done.stdout
+
+
 def test_version_string():
     assert b"gfx950" in mdb.load_hip_library().mdb_version()
 
@@ -62,6 +142,14 @@ def test_null_arguments_are_errors_not_crashes():
     assert library.mdb_init(0, None) == 1
     assert library.mdb_trim(None, None) == 1
     assert library.mdb_close(None) == 0
+    assert library.mdb_comm_init(None, 0, 1, None) == 1
+    assert library.mdb_agg_all_reduce(None, None, None) == 1
+    assert library.mdb_comm_unique_id(None) == 1
+    assert library.mdb_agg_merge(None, None) == 1
+    assert library.mdb_is_value_within_error_bound(mdb.error_bound("lossless"), 1.0, 1.0, None) == 1
+    assert library.mdb_are_compressed_timestamps_regular(None, 4, None) == 1
+    assert library.mdb_split_and_compress_univariate(None, None, None, None, 0, 0, None) == 1
+    assert library.mdb_segments_validate_dev(None, None) == 1
 
 
 def test_segment_batch_arrow_round_trip():

@@ -168,6 +168,74 @@ def test_synthetic_generator_statistics(hip):
         assert np.abs(values[s] - clean).max() <= 0.0501
 
 
+def test_synthetic_generator_is_the_host_definition_bit_for_bit(hip):
+    """The bench fits what mdb_synth_values_dev writes; tests/datagen.bench_series is the same
+    recipe on the host (fixed polynomial sine, splitmix64 noise, IEEE +, *, /, floor only), so the
+    oracle can be run on exactly the bytes the bench fits."""
+    n_points = 300_001  # not a multiple of 4: the kernel's scalar tail too
+    for first_series, n_series in ((0, 3), (63, 2), (999, 1), (12_499, 1)):
+        pointer = hip.dev_alloc(4 * n_series * n_points + 16)
+        hip.synth_values_dev(pointer, first_series, n_series, n_points)
+        got = hip.download_array(pointer, n_series * n_points, np.float32).reshape(n_series, n_points)
+        hip.dev_free(pointer)
+        for s in range(n_series):
+            expected = datagen.bench_series(first_series + s, n_points)
+            assert np.array_equal(got[s].view(np.uint32), expected.view(np.uint32)), (first_series + s)
+
+
+def test_bench_workload_fit_and_grid_match_the_oracle_on_the_generated_bytes(hip):
+    """Two series of the benchmark workload exactly as bench.py builds them (device generator,
+    65 536-point chunks, regular timestamps synthesised by the fitter): the oracle fits the host
+    definition of the same series into the same segments, and grids them to the same points."""
+    n_series, n_points, chunk = 2, 400_000, 65536
+    eb = mdb.error_bound("relative", 1.0)
+    values_dev = hip.dev_alloc(4 * n_series * n_points)
+    hip.synth_values_dev(values_dev, 5, n_series, n_points)
+    starts = np.arange(0, n_points, chunk, dtype=np.uint64)
+    offsets = np.concatenate([(np.arange(n_series, dtype=np.uint64)[:, None] * np.uint64(n_points) + starts).reshape(-1),
+                              np.array([n_series * n_points], dtype=np.uint64)])
+    first_index = np.tile(starts, n_series)
+    offsets_dev, first_dev = hip.upload_array(offsets), hip.upload_array(first_index)
+    dev = hip.compress_chunks_dev(0, values_dev, offsets_dev, len(offsets) - 1, eb, 0, 1000, first_dev)
+    host_values = np.concatenate([datagen.bench_series(5 + s, n_points) for s in range(n_series)])
+    host_ts = np.tile(np.arange(n_points, dtype=np.int64) * 1000, n_series)
+    expected = ora.compress_chunks(host_ts, host_values, offsets, eb)
+    got = dev.download()
+    assert_same_segments(got, expected)
+    total = hip.grid_count_dev(dev)
+    out_ts, out_val = hip.dev_alloc(8 * total), hip.dev_alloc(4 * total)
+    hip.grid_batch_dev(dev, out_ts, out_val, total)
+    oracle_ts, oracle_values = ora.grid_batch(expected)[:2]
+    assert np.array_equal(hip.download_array(out_ts, total, np.int64), oracle_ts)
+    assert np.array_equal(hip.download_array(out_val, total, np.float32).view(np.uint32),
+                          oracle_values.view(np.uint32))
+    for pointer in (values_dev, offsets_dev, first_dev, out_ts, out_val):
+        hip.dev_free(pointer)
+    dev.free()
+
+
+def test_split_and_compress_univariate_time_series(hip):
+    """try_split_and_compress_univariate_time_series (compression.rs:147-179): several field columns
+    of one series, one error bound per field, the timestamps shared."""
+    for irregular in (False, True):
+        timestamps, first = cases.synthetic_series(20_000, irregular, (1.0, 1.05), seed=211)
+        _, second = cases.synthetic_series(20_000, irregular, None, seed=212)
+        third = datagen.sine_series(3, 20_000)[1]
+        bounds = [cases.error_bounds()[name] for name in ("rel5", "lossless", "abs0.01")]
+        fields = [first, second, third]
+        got = hip.try_split_and_compress_univariate_time_series(timestamps, fields, bounds)
+        assert len(got) == 3
+        for batch, values, eb in zip(got, fields, bounds):
+            expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
+            expected.chunk_index = None
+            assert_same_segments(batch, expected)
+    assert hip.try_split_and_compress_univariate_time_series(np.arange(5) * 100, [], []) == []
+    empty = hip.try_split_and_compress_univariate_time_series([], [[]], [cases.LOSSLESS])
+    assert len(empty) == 1 and len(empty[0]) == 0
+    with pytest.raises(mdb.HipError, match="different lengths"):
+        hip.try_split_and_compress_univariate_time_series([1, 2, 3], [[1.0, 2.0]], [cases.LOSSLESS])
+
+
 def test_fit_pmc_chosen_while_swing_ran_far_ahead(hip):
     # PMC-Mean wins ties (types.rs:84-101) even when Swing accepted up to ~3 % more points, so the
     # next model starts well behind the last point that was fed. Long near-constant runs with a

@@ -343,6 +343,50 @@ def test_grid_time_range_edge_cases(hip):
             assert np.array_equal(rows, exp_rows)
 
 
+def test_views_that_point_outside_their_buffers_are_errors(hip):
+    """A BinaryView whose buffer index or offset leaves the column's data buffers must be an error
+    from every host entry point (the kernels follow views without looking); arrow cannot build such
+    a column, a foreign or corrupted batch can."""
+    import ctypes as C
+    timestamps, values = cases.synthetic_series(4000, True, None, seed=77)
+    good = ora.try_compress_univariate_time_series(timestamps, values, cases.LOSSLESS)
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_SUM
+    assert len(hip.grid_batch(good)[0]) == 4000
+
+    def corrupted(column_name, field, value):
+        batch = good.take(np.arange(len(good)))
+        column = getattr(batch, column_name)
+        lengths = column.views[:, 0:4].copy().view(np.int32).reshape(-1)
+        row = int(np.nonzero(lengths > 12)[0][0])
+        column.views[row, field:field + 4] = np.frombuffer(np.int32(value).tobytes(), dtype=np.uint8)
+        return batch
+
+    rng = np.random.default_rng(9)
+    for column_name in ("timestamps", "values"):
+        size = len(getattr(good, column_name).buffers[0])
+        for field, value in ((8, 1), (8, 7), (8, -1), (12, -4), (12, size - 3), (12, size + 100),
+                             (12, 2**31 - 1), (0, -5), (8, int(rng.integers(2, 2**31 - 1)))):
+            bad = corrupted(column_name, field, value)
+            for call in (lambda: hip.grid_batch(bad), lambda: hip.grid_count(bad),
+                         lambda: hip.grid_batch_owned(bad), lambda: hip.agg_batch(bad, mask),
+                         lambda: hip.agg_batch_range(bad, 0, 10**9, mask), lambda: hip.upload_segments(bad)):
+                with pytest.raises(mdb.HipError, match="Malformed BinaryView|negative"):
+                    call()
+    # a device batch that did not come from this library: mdb_segments_validate_dev finds the same
+    dev = hip.upload_segments(good)
+    hip.validate_segments_dev(dev)
+    views = good.values.views.copy()
+    lengths = views[:, 0:4].copy().view(np.int32).reshape(-1)
+    row = int(np.nonzero(lengths > 12)[0][0])
+    views[row, 12:16] = np.frombuffer(np.int32(len(good.values.buffers[0]) - 1).tobytes(), dtype=np.uint8)
+    address = C.cast(dev.seg.values.views, C.c_void_p).value
+    hip._check(hip.lib.mdb_dev_upload(hip.handle, C.c_void_p(address), views.ctypes.data_as(C.c_void_p), views.nbytes))
+    with pytest.raises(mdb.HipError, match="Malformed BinaryView"):
+        hip.validate_segments_dev(dev)
+    dev.free()
+    assert len(hip.grid_batch(good)[0]) == 4000  # the context is fine afterwards
+
+
 def test_fuzzed_segments_never_crash_and_agree_with_the_oracle(hip):
     """Valid segments with random corruptions (truncated or random payloads, swapped times, wrong
     model type): the reference would panic on many of them; the C ABI must return an error or a
