@@ -23,6 +23,8 @@
 //                  <= 12 bytes inline, larger payloads in one data buffer per column).
 // Output is bit-identical to the CPU oracle: same segment boundaries, same bytes.
 // Algorithmic bytes: 4 B/point read (12 B/point when timestamps are materialised) + segments written.
+#include <type_traits>
+
 #include "mdb_scan.hpp"
 #include "mdb_segment_dev.hpp"
 
@@ -266,6 +268,179 @@ struct SwingDev {
         double projected = numerator / denominator;
         double slope = max_num(lower.slope, min_num(projected, upper.slope));
         double last_value = slope * (double)(end_time - start_time) + first_value;
+        *first = (float)first_value;
+        *last = (float)last_value;
+    }
+};
+
+// ---- the same two fitters, cheaper, for the kernel's main path -------------------------------------------
+//
+// k_fit_models runs 64 greedy loops in lockstep, each at a different place of its model, so whatever
+// ANY lane needs the wave executes: PMC-Mean's acceptance test (a correctly rounded f64 division for
+// the average and two f32 divisions for the relative bound) runs at nearly every step although each
+// lane's PMC-Mean model is alive for a few percent of its points, and Swing converts 64-bit
+// timestamps to f64 several times per point. Both are replaced by forms that decide the same thing
+// with the same bits:
+//
+// PmcDev::fit_fast   The reference accepts the point iff min and max are within the bound of
+//                    avg = (f32)(sum / len). An approximate average (f32 reciprocal, error below 16
+//                    ulp) decides that with margins that cover its error and every rounding of the
+//                    reference's test; only a point that falls between the margins (about one in 10^5
+//                    for a 1 % bound), NaNs and magnitudes near the f32 limits take the exact test. The
+//                    model's value itself is computed exactly when the model is finished.
+// SwingFast          With regular timestamps t(j) = first + j * interval that stay below 2^53 in
+//                    magnitude (checked per call by k_fit_exact_double_timestamps) every timestamp and
+//                    every difference of two timestamps IS an f64, so (f64)t, (f64)(t1 - t0) of
+//                    swing.rs:150, 215, 335, 338 are computed as such: the same numbers, no 64-bit
+//                    integer arithmetic or conversions on the way.
+
+struct PmcFast {
+    int32_t kind;    // MDB_EB_*; lossless: always the exact test
+    float pass_bound; // relative: eps (1 - 2^-17) / 100; absolute: eps (1 - 2^-17)
+    float fail_bound; // relative: eps (1 + 2^-17) / 100; absolute: eps (1 + 2^-17)
+    bool enabled;
+};
+
+__device__ __forceinline__ PmcFast pmc_fast_constants(mdb_error_bound eb) {
+    PmcFast f;
+    f.kind = eb.kind;
+    const double scale = eb.kind == MDB_EB_RELATIVE ? 0.01 : 1.0;
+    f.pass_bound = (float)((double)eb.value * (1.0 - 0x1p-17) * scale);
+    f.fail_bound = (float)((double)eb.value * (1.0 + 0x1p-17) * scale);
+    // (an absolute bound in the subnormal range leaves no room for the margins)
+    f.enabled = eb.kind == MDB_EB_RELATIVE || (eb.kind == MDB_EB_ABSOLUTE && eb.value >= 0x1p-60f);
+    return f;
+}
+
+// 1: certainly within the bound, -1: certainly not, 0: too close to call (or not a case for the
+// margins). `approximate_average` is within `average_error` of the f32 the reference compares with.
+__device__ __forceinline__ int pmc_fast_within(const PmcFast &f, float real_value, float approximate_average,
+                                               float average_error) {
+    const float difference = fabsf(real_value - approximate_average);
+    float pass_bound = f.pass_bound, fail_bound = f.fail_bound;
+    bool usable = true;
+    if (f.kind == MDB_EB_RELATIVE) {
+        const float magnitude = fabsf(real_value);
+        pass_bound *= magnitude;
+        fail_bound *= magnitude;
+        usable = magnitude >= 0x1p-60f; // (false for NaN) products far from the subnormal range
+    }
+    if (usable && difference <= pass_bound - average_error) return 1;
+    if (usable && difference > fail_bound + average_error) return -1;
+    return 0;
+}
+
+// PMCMean::fit_value (pmc_mean.rs:58-76) with the decision taken as described above.
+__device__ __forceinline__ bool pmc_fit_fast(PmcDev &pmc, const PmcFast &fast, mdb_error_bound eb, float value) {
+    const float next_min = min_num(pmc.min_value, value);
+    const float next_max = max_num(pmc.max_value, value);
+    const double next_sum = pmc.sum + (double)value;
+    const uint32_t next_length = pmc.length + 1;
+    int verdict = 0;
+    if (fast.enabled) {
+        const float approximate = (float)next_sum * __builtin_amdgcn_rcpf((float)next_length);
+        const float error = fmaxf(fabsf(approximate) * 0x1p-20f, 0x1p-120f);
+        const int low = pmc_fast_within(fast, next_min, approximate, error);
+        const int high = pmc_fast_within(fast, next_max, approximate, error);
+        verdict = (low < 0 || high < 0) ? -1 : ((low > 0 && high > 0) ? 1 : 0);
+    }
+    bool accepted = verdict > 0;
+    if (verdict == 0) {
+        const float average = (float)(next_sum / (double)next_length);
+        accepted = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
+    }
+    if (accepted) {
+        pmc.min_value = next_min;
+        pmc.max_value = next_max;
+        pmc.sum = next_sum;
+        pmc.length = next_length;
+    }
+    return accepted;
+}
+
+__device__ __forceinline__ LineDev line_through_exact(double t0, double v0, double t1, double v1) {
+    if (equal_or_nan(v0, v1)) return {0.0, v0};
+    const double slope = (v1 - v0) / (t1 - t0);
+    const double intercept = v0 - slope * t0;
+    return {slope, intercept};
+}
+
+struct SwingFast {
+    double start_time; // (f64)start_time, exact
+    double first_value;
+    LineDev upper, lower;
+    double numerator, denominator;
+    uint32_t length;
+    bool all_finite;
+    __device__ __forceinline__ void reset() {
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        all_finite = false;
+        start_time = 0.0;
+        first_value = nan;
+        upper = {nan, nan};
+        lower = {nan, nan};
+        numerator = 0.0;
+        denominator = 0.0;
+        length = 0;
+    }
+    // SwingDev::fit with `t` = (f64)timestamp. The model's end is not kept: points are fed one after
+    // the other, so it is the start plus length - 1 intervals.
+    __device__ __forceinline__ bool fit(const DeviationFactor &dev, double t, float value32) {
+        const double value = (double)value32;
+        const double deviation = dev.of(value);
+        if (length >= 2 && all_finite) {
+            if (!isfinite(value)) return false;
+            const double upper_approximation = upper.slope * t + upper.intercept;
+            const double lower_approximation = lower.slope * t + lower.intercept;
+            if (upper_approximation + deviation < value || lower_approximation - deviation > value)
+                return false;
+            // One line per step for the two bounds: the corridor narrows from above or from below,
+            // both at the same point only when it is about as wide as the deviation.
+            const bool lowers_upper = upper_approximation - deviation > value;
+            const bool raises_lower = lower_approximation + deviation < value;
+            if (lowers_upper || raises_lower) {
+                const LineDev line = line_through_exact(start_time, first_value, t,
+                                                        lowers_upper ? value + deviation : value - deviation);
+                if (lowers_upper) upper = line;
+                else lower = line;
+                if (lowers_upper && raises_lower)
+                    lower = line_through_exact(start_time, first_value, t, value - deviation);
+            }
+            if (first_value != value) {
+                const double dt = t - start_time;
+                numerator += (value - first_value) * dt;
+                denominator += dt * dt;
+            } else {
+                numerator += 0.0;
+                denominator += 0.0;
+            }
+            length += 1;
+            return true;
+        }
+        if (length == 0) {
+            start_time = t;
+            first_value = value;
+            all_finite = isfinite(value);
+            length = 1;
+            return true;
+        }
+        if (!all_finite || !isfinite(value)) {
+            if (!equal_or_nan(first_value, value)) return false;
+            upper = {value, value};
+            lower = {value, value};
+            length += 1;
+            return true;
+        }
+        upper = line_through_exact(start_time, first_value, t, value + deviation);
+        lower = line_through_exact(start_time, first_value, t, value - deviation);
+        length += 1;
+        return true;
+    }
+    // `interval`: (f64) of the sampling interval; end_time - start_time is length - 1 of them.
+    __device__ __forceinline__ void model(double interval, float *first, float *last) const {
+        double projected = numerator / denominator;
+        double slope = max_num(lower.slope, min_num(projected, upper.slope));
+        double last_value = slope * ((double)(length - 1) * interval) + first_value;
         *first = (float)first_value;
         *last = (float)last_value;
     }
@@ -656,7 +831,26 @@ constexpr int FIT_HISTORY = 8;
 constexpr int FIT_THREADS = MDB_WAVE;
 constexpr int FIT_QUICK_REJECTS = 16; // rejected points skipped per trip (lossless bound only)
 
-template <bool HAS_TS, bool SPLIT>
+// Can every timestamp of the call be held exactly in an f64, differences included (SwingFast)? Regular
+// timestamps only: |first| <= 2^52 and |interval| * length <= 2^52 for every chunk.
+__global__ __launch_bounds__(256) void k_fit_exact_double_timestamps(TimestampSource timestamps,
+                                                                     const unsigned long long *__restrict__ chunk_offsets,
+                                                                     uint64_t n_chunks, unsigned int *__restrict__ inexact) {
+
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= n_chunks) return;
+    const uint64_t base = chunk_offsets[chunk];
+    const uint64_t n = chunk_offsets[chunk + 1] - base;
+    const ChunkTimestamps t = chunk_timestamps(timestamps, chunk, base);
+    const uint64_t limit = 1ull << 52;
+    const uint64_t first = t.first < 0 ? 0ull - (uint64_t)t.first : (uint64_t)t.first;
+    const uint64_t interval = t.interval < 0 ? 0ull - (uint64_t)t.interval : (uint64_t)t.interval;
+    const bool fits = first <= limit && n <= limit && (interval == 0 || n <= limit / interval);
+    if (!fits) atomicOr(inexact, 1u);
+}
+
+// FAST (regular timestamps that are exact in f64 only): PmcDev::fit_fast and SwingFast above.
+template <bool HAS_TS, bool SPLIT, bool FAST>
 __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitArgs split,
                                                            const unsigned long long *__restrict__ record_base,
                                                            ModelRec *__restrict__ records,
@@ -710,10 +904,13 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
     uint32_t j = first_point;       // next point to feed
     uint32_t loaded = first_point;  // the ring holds points [low, loaded) of the chunk, loaded - low <= RING
     uint32_t low = first_point;
+    static_assert(!(FAST && HAS_TS), "the fast path computes its timestamps");
     PmcDev pmc;
-    SwingDev swing;
+    typename std::conditional<FAST, SwingFast, SwingDev>::type swing;
     pmc.reset();
     swing.reset();
+    const PmcFast pmc_fast = pmc_fast_constants(eb);
+    const double first_time = (double)regular_ts.first, interval_time = (double)regular_ts.interval; // exact if FAST
     bool pmc_fits = true, swing_fits = true;
     if (!SPLIT && active && n == 0) {
         plans[chunk] = {0, 0};
@@ -798,10 +995,18 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
         }
         if (feeding) {
             const float v = ring_values[j % RING][lane];
-            const int64_t t = HAS_TS ? (int64_t)ring_ts[j % RING][lane] : regular_ts.regular_at(j);
             // try_to_update_models (types.rs:74-81): a model that failed once is never fed again.
-            if (pmc_fits) pmc_fits = pmc.fit(eb, v);
-            if (swing_fits) swing_fits = swing.fit(dev, t, v);
+            if constexpr (FAST) {
+                // first + j * interval: the product and the sum are integers below 2^53, hence exact
+                // whether fused or not.
+                const double t = __builtin_fma((double)j, interval_time, first_time);
+                if (pmc_fits) pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v);
+                if (swing_fits) swing_fits = swing.fit(dev, t, v);
+            } else {
+                const int64_t t = HAS_TS ? (int64_t)ring_ts[j % RING][lane] : regular_ts.regular_at(j);
+                if (pmc_fits) pmc_fits = pmc.fit(eb, v);
+                if (swing_fits) swing_fits = swing.fit(dev, t, v);
+            }
             j += 1;
         } else if (active) {
             // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
@@ -819,7 +1024,8 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
                 } else {
                     rec.start_and_type = current | 0x80000000u;
                     rec.end = current + swing.length - 1;
-                    swing.model(&rec.p0, &rec.p1);
+                    if constexpr (FAST) swing.model(interval_time, &rec.p0, &rec.p1);
+                    else swing.model(&rec.p0, &rec.p1);
                 }
                 if (SPLIT) {
                     split.p0[base + current] = rec.p0;
@@ -851,6 +1057,330 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
                 pmc_fits = true;
                 swing_fits = true;
                 j = current;
+            }
+        }
+    }
+}
+
+// ---- k_fit_models_lean --------------------------------------------------------------------------------------
+//
+// The same greedy loop for the case that matters most - regular timestamps that are exact in f64
+// (k_fit_exact_double_timestamps) under an absolute or relative bound - written for how a wave
+// executes it. Counters of k_fit_models on the benchmark workload (scripts/pmc_fit_modes.sh): per
+// point 161 vector, 131 SCALAR and 28 branch instructions - every `if` on a per-lane condition costs
+// the wave a handful of scalar instructions to split and rejoin its lanes whether or not a lane
+// takes it, and with 64 models at 64 different places nearly every `if` of the two fitters is taken
+// by somebody. Here one step of PMC-Mean and one step of Swing are straight-line code: every lane
+// computes the step, conditions select what is kept. What stays behind a branch is what is rare for
+// the whole wave: the exact PMC-Mean test (pmc_fit_fast), the second line of a Swing step that
+// moves both bounds, non-finite values, finishing a model, and topping up the ring.
+// The ring holds 16-byte groups (one global_load_dwordx4 per 4 points instead of 4 loads; a chunk
+// may start at any float, so groups are counted from the 16-byte boundary below its first value).
+// Same records, same bytes as k_fit_models: every fit test runs both (MDB_FIT_LEAN=0 selects the
+// other).
+constexpr int LEAN_GROUPS = 8;        // 16-byte groups per lane in the ring (32 points)
+constexpr int LEAN_LOADS = 6;         // groups fetched per top-up at most; 2 groups of history stay
+constexpr int LEAN_TRASH = LEAN_GROUPS; // ring row that takes the stores nobody wants
+
+template <int KIND> __device__ __forceinline__ double lean_deviation(double factor, double value) {
+    return KIND == MDB_EB_RELATIVE ? fabs(value * factor) : factor; // DeviationFactor::of
+}
+
+// certainly within the bound (the first half of pmc_fast_within, without branches)
+template <int KIND>
+__device__ __forceinline__ bool lean_passes(const PmcFast &f, float real_value, float approximate_average,
+                                            float average_error) {
+    const float difference = fabsf(real_value - approximate_average);
+    float pass_bound = f.pass_bound;
+    bool usable = true;
+    if (KIND == MDB_EB_RELATIVE) {
+        const float magnitude = fabsf(real_value);
+        pass_bound *= magnitude;
+        usable = magnitude >= 0x1p-60f;
+    }
+    return usable & (difference <= pass_bound - average_error);
+}
+
+__device__ __forceinline__ float ring_value(const float4 (*ring)[MDB_WAVE], int lane, uint32_t position) {
+    return reinterpret_cast<const float *>(&ring[(position >> 2) % LEAN_GROUPS][lane])[position & 3u];
+}
+
+template <bool SPLIT, int KIND>
+__global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, SplitArgs split,
+                                                                const unsigned long long *__restrict__ record_base,
+                                                                ModelRec *__restrict__ records,
+                                                                ChunkPlan *__restrict__ plans,
+                                                                unsigned int *__restrict__ error) {
+    static_assert(KIND == MDB_EB_RELATIVE || KIND == MDB_EB_ABSOLUTE, "lossless data has its own shortcuts");
+    __shared__ float4 ring[LEAN_GROUPS + 1][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t unit = (uint64_t)blockIdx.x * FIT_THREADS + lane;
+    uint64_t chunk = unit;
+    bool active = unit < (SPLIT ? split.n_pieces : args.n_chunks);
+    uint32_t first_point = 0;
+    if (SPLIT && active) {
+        uint64_t lo = 0, hi = args.n_chunks;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (split.piece_base[mid] <= unit) lo = mid;
+            else hi = mid;
+        }
+        chunk = lo;
+        first_point = (uint32_t)(unit - split.piece_base[chunk]) * split.piece_points;
+    }
+    uint64_t base = 0;
+    uint32_t n = 0;
+    if (active) {
+        base = args.chunk_offsets[chunk];
+        const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
+        if (length64 > COUNT_MASK - ENTRY_END_BIAS) {
+            atomicOr(error, ERR_TOO_LONG);
+            plans[chunk] = {0, 0};
+            active = false;
+        } else {
+            n = (uint32_t)length64;
+        }
+    }
+    if (!SPLIT && active && n == 0) {
+        plans[chunk] = {0, 0};
+        active = false;
+    }
+    // Lanes without points read (and ignore) the first group of the call's values.
+    const float *chunk_values = args.values + (active ? base : 0);
+    const uint32_t misalign = (uint32_t)((reinterpret_cast<uintptr_t>(chunk_values) >> 2) & 3u);
+    const float4 *__restrict__ groups = reinterpret_cast<const float4 *>(chunk_values - misalign);
+    const uint32_t last_group = active ? (n - 1 + misalign) >> 2 : 0u;
+    const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, active ? chunk : 0, base);
+    const double first_time = (double)regular_ts.first, interval_time = (double)regular_ts.interval; // exact
+    const mdb_error_bound eb = args.eb;
+    const PmcFast pmc_fast = pmc_fast_constants(eb);
+    const double deviation_factor_value = deviation_factor(eb).factor;
+    const double nan64 = __longlong_as_double(0x7ff8000000000000ll);
+    const float nan32 = __uint_as_float(0x7fc00000u);
+    ModelRec *__restrict__ out = records + ((active && !SPLIT) ? record_base[chunk] : 0);
+
+    uint32_t n_models = 0;
+    GapCounter gaps;
+    const uint32_t piece_end = SPLIT ? first_point + split.piece_points : 0u;
+    uint32_t current = first_point; // first point of the model being fitted
+    uint32_t j = first_point;       // next point to feed
+    // The ring holds groups [low_group, loaded_group) of the chunk, at most LEAN_GROUPS of them.
+    uint32_t loaded_group = (first_point + misalign) >> 2, low_group = loaded_group;
+    // PMC-Mean (PmcDev) and Swing (SwingFast) of the model being fitted, in registers.
+    float pmc_min = nan32, pmc_max = nan32;
+    double pmc_sum = 0.0;
+    uint32_t pmc_length = 0;
+    double swing_start = 0.0, swing_first = nan64;
+    double upper_slope = nan64, upper_intercept = nan64, lower_slope = nan64, lower_intercept = nan64;
+    double numerator = 0.0, denominator = 0.0;
+    uint32_t swing_length = 0;
+    bool swing_finite = false;
+    bool pmc_fits = true, swing_fits = true;
+
+    while (__any(active)) {
+        const bool feeding = active & (j < n) & (pmc_fits | swing_fits);
+        const uint32_t position = j + misalign; // of point j, counted from the 16-byte boundary
+        const uint32_t group = position >> 2;
+        if (__any(feeding & ((group >= loaded_group) | (group < low_group)))) {
+            // Normally the ring is extended at loaded_group. A lane whose next point fell out of the back
+            // of its ring (PMC-Mean chosen although Swing had run far ahead, types.rs:84-101) or lies
+            // beyond it restarts the ring at that point's group.
+            if (active & ((group < low_group) | (group > loaded_group))) {
+                loaded_group = group;
+                low_group = group;
+            }
+            const uint32_t first_group = loaded_group;
+            // Two groups behind the current one stay (a rejected model restarts at most 7 points back).
+            const uint32_t end_group = active ? min(group + (uint32_t)LEAN_LOADS, last_group + 1u) : first_group;
+            float4 fetched[LEAN_LOADS];
+#pragma unroll
+            for (int k = 0; k < LEAN_LOADS; k++) fetched[k] = groups[min(first_group + (uint32_t)k, last_group)];
+#pragma unroll
+            for (int k = 0; k < LEAN_LOADS; k++) {
+                const uint32_t g = first_group + (uint32_t)k;
+                ring[g < end_group ? g % LEAN_GROUPS : (uint32_t)LEAN_TRASH][lane] = fetched[k];
+            }
+            loaded_group = max(first_group, end_group);
+            if (loaded_group > low_group + LEAN_GROUPS) low_group = loaded_group - LEAN_GROUPS;
+        }
+        const float value32 = ring_value(ring, lane, position);
+        const double value = (double)value32;
+
+        // ---- PMC-Mean: PMCMean::fit_value (pmc_mean.rs:58-76), decided as in pmc_fit_fast ----
+        const bool pmc_steps = feeding & pmc_fits;
+        const float next_min = min_num(pmc_min, value32);
+        const float next_max = max_num(pmc_max, value32);
+        const double next_sum = pmc_sum + value;
+        const uint32_t next_length = pmc_length + 1;
+        bool pmc_accepts;
+        {
+            const float approximate = (float)next_sum * __builtin_amdgcn_rcpf((float)next_length);
+            const float average_error = fmaxf(fabsf(approximate) * 0x1p-20f, 0x1p-120f);
+            const bool passes_low = lean_passes<KIND>(pmc_fast, next_min, approximate, average_error);
+            const bool passes_high = lean_passes<KIND>(pmc_fast, next_max, approximate, average_error);
+            pmc_accepts = pmc_fast.enabled & passes_low & passes_high;
+            // Not certainly within the bound: certainly outside it (the step that ends a PMC-Mean model,
+            // once per model), or too close to call and decided by the exact test.
+            const bool doubtful = pmc_steps & !pmc_accepts;
+            if (__any(doubtful)) {
+                if (doubtful) {
+                    const int low = pmc_fast.enabled ? pmc_fast_within(pmc_fast, next_min, approximate, average_error) : 0;
+                    const int high = pmc_fast.enabled ? pmc_fast_within(pmc_fast, next_max, approximate, average_error) : 0;
+                    if (low >= 0 && high >= 0) {
+                        const float average = (float)(next_sum / (double)next_length);
+                        pmc_accepts = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
+                    }
+                }
+            }
+        }
+        const bool pmc_keeps = pmc_steps & pmc_accepts;
+        if (pmc_keeps) { // (kept under the lanes' mask: no select per register)
+            pmc_min = next_min;
+            pmc_max = next_max;
+            pmc_sum = next_sum;
+            pmc_length = next_length;
+        }
+        pmc_fits = pmc_fits & (!pmc_steps | pmc_accepts);
+
+        // ---- Swing: Swing::fit_data_point (swing.rs:101-198) on exact f64 timestamps (SwingFast) ----
+        const bool swing_steps = feeding & swing_fits;
+        // first + j * interval: integers below 2^53, exact whether fused or not.
+        const double time = __builtin_fma((double)j, interval_time, first_time);
+        const double deviation = lean_deviation<KIND>(deviation_factor_value, value);
+        const bool is_first = swing_length == 0, is_second = swing_length == 1, later = swing_length >= 2;
+        const bool value_finite = isfinite(value);
+        // A non-finite first value only accepts copies of itself, a finite one no non-finite value
+        // (swing.rs:113-125): rare, behind a branch below.
+        const bool special = !is_first & (!swing_finite | !value_finite);
+        const double upper_approximation = upper_slope * time + upper_intercept;
+        const double lower_approximation = lower_slope * time + lower_intercept;
+        const bool outside = later & ((upper_approximation + deviation < value) | (lower_approximation - deviation > value));
+        const bool lowers_upper = is_second | (later & (upper_approximation - deviation > value));
+        const bool raises_lower = is_second | (later & (lower_approximation + deviation < value));
+        // One line per step serves whichever bound moves (line_through_exact, start and first value of
+        // the model); a step that moves both gets its second line behind the branch.
+        const double target = lowers_upper ? value + deviation : value - deviation;
+        const double elapsed = time - swing_start;
+        double line_slope = (target - swing_first) / elapsed;
+        double line_intercept = swing_first - line_slope * swing_start;
+        bool swing_accepts = is_first | !outside;
+        double second_slope = lower_slope, second_intercept = lower_intercept;
+        const bool moves_both = swing_steps & !special & lowers_upper & raises_lower & !outside;
+        // (a line to a value equal to the model's first one is flat, swing.rs:331-333; and such a value
+        // adds nothing to the sums of swing.rs:212-228)
+        const bool level = swing_steps & ((swing_first == target) | (swing_first == value));
+        double weighted = (value - swing_first) * elapsed, squared = elapsed * elapsed;
+        if (__any(moves_both | level | (swing_steps & special))) {
+            if (moves_both) {
+                const LineDev line = line_through_exact(swing_start, swing_first, time, value - deviation);
+                second_slope = line.slope;
+                second_intercept = line.intercept;
+            }
+            if (level) {
+                if (swing_first == target) {
+                    line_slope = 0.0;
+                    line_intercept = swing_first;
+                }
+                if (swing_first == value) {
+                    weighted = 0.0;
+                    squared = 0.0;
+                }
+            }
+            if (swing_steps & special) swing_accepts = equal_or_nan(swing_first, value);
+        }
+        const bool swing_keeps = swing_steps & swing_accepts;
+        const bool plain = swing_keeps & !special & !is_first;
+        const bool new_upper = plain & lowers_upper;
+        const bool new_lower = plain & raises_lower;
+        if (new_upper) {
+            upper_slope = line_slope;
+            upper_intercept = line_intercept;
+        }
+        if (new_lower) {
+            lower_slope = lowers_upper ? second_slope : line_slope;
+            lower_intercept = lowers_upper ? second_intercept : line_intercept;
+        }
+        if (plain & later) { // swing.rs:212-228: only from the third point on
+            numerator += weighted;
+            denominator += squared;
+        }
+        if (swing_keeps & (special | is_first)) {
+            if (special) { // upper = lower = {value, value} (swing.rs:121-123)
+                upper_slope = upper_intercept = lower_slope = lower_intercept = value;
+            } else {
+                swing_start = time;
+                swing_first = value;
+                swing_finite = value_finite;
+            }
+        }
+        swing_length += swing_keeps ? 1u : 0u;
+        swing_fits = swing_fits & (!swing_steps | swing_accepts);
+        j += feeding ? 1u : 0u;
+
+        const bool finishing = active & !feeding;
+        if (__any(finishing)) {
+            if (finishing) {
+                // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
+                const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc_length;
+                const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing_length;
+                const bool choose_pmc = pmc_bpv <= swing_bpv;
+                const float bpv = choose_pmc ? pmc_bpv : swing_bpv;
+                if (bpv <= (float)MDB_VALUE_SIZE_IN_BYTES) { // compression.rs:238
+                    ModelRec rec;
+                    if (choose_pmc) {
+                        rec.start_and_type = current;
+                        rec.end = current + pmc_length - 1;
+                        rec.p0 = (float)(pmc_sum / (double)pmc_length); // pmc_mean.rs:91-93
+                        rec.p1 = rec.p0;
+                    } else { // swing.rs:246-259
+                        rec.start_and_type = current | 0x80000000u;
+                        rec.end = current + swing_length - 1;
+                        const double projected = numerator / denominator;
+                        const double slope = max_num(lower_slope, min_num(projected, upper_slope));
+                        const double last_value = slope * ((double)(swing_length - 1) * interval_time) + swing_first;
+                        rec.p0 = (float)swing_first;
+                        rec.p1 = (float)last_value;
+                    }
+                    if (SPLIT) {
+                        split.p0[base + current] = rec.p0;
+                        split.p1[base + current] = rec.p1;
+                        __hip_atomic_store(&split.entry[base + current],
+                                           (rec.end + ENTRY_END_BIAS) | (rec.start_and_type & 0x80000000u),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        gaps.on_model(current, rec.end);
+                        out[n_models++] = rec;
+                    }
+                    current = rec.end + 1;
+                } else {
+                    if (SPLIT)
+                        __hip_atomic_store(&split.entry[base + current], ENTRY_REJECTED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    current += 1; // the point becomes a residual (compression.rs:258-262)
+                }
+                if (current >= n) {
+                    if (!SPLIT) plans[chunk] = {n_models, gaps.finish(n)};
+                    active = false;
+                } else if (SPLIT && current >= piece_end &&
+                           __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    active = false; // some lane has been here: the chain from this point on is recorded
+                } else {
+                    pmc_min = nan32;
+                    pmc_max = nan32;
+                    pmc_sum = 0.0;
+                    pmc_length = 0;
+                    swing_start = 0.0;
+                    swing_first = nan64;
+                    upper_slope = upper_intercept = lower_slope = lower_intercept = nan64;
+                    numerator = 0.0;
+                    denominator = 0.0;
+                    swing_length = 0;
+                    swing_finite = false;
+                    pmc_fits = true;
+                    swing_fits = true;
+                    j = current;
+                }
             }
         }
     }
@@ -1570,6 +2100,18 @@ static uint32_t gap_min_values_setting() {
     return GAP_DEFAULT_MIN_VALUES;
 }
 
+// MDB_FIT_FAST=0: the plain forms of PMC-Mean and Swing in k_fit_models even where the fast ones apply.
+static bool fit_fast_setting() {
+    const char *text = std::getenv("MDB_FIT_FAST");
+    return !(text && std::strcmp(text, "0") == 0);
+}
+
+// MDB_FIT_LEAN=0: k_fit_models (its fast form) even where k_fit_models_lean applies.
+static bool fit_lean_setting() {
+    const char *text = std::getenv("MDB_FIT_LEAN");
+    return !(text && std::strcmp(text, "0") == 0);
+}
+
 // Points per piece for split mode, 0 = one lane per chunk. Split when the call has too few chunks
 // to give every SIMD a couple of waves and the chunks are long enough to be worth cutting.
 // MDB_FIT_PIECE_POINTS overrides: 1 = never split, N >= 64 = always split into pieces of N points.
@@ -1680,6 +2222,19 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         } else if (ts) {
             args.timestamps.chunk_irregular = chunk_irregular;
         }
+        // Regular timestamps (given as such, or found to be): are they all exact as f64? Then the
+        // fast forms of the two fitters apply (MDB_FIT_FAST=0 keeps the plain ones: A/B and tests).
+        bool fast = false;
+        if (!ts && fit_fast_setting()) {
+            unsigned int inexact = 0;
+            FIT_CHECK(hipMemsetAsync(error_flag + 1, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_fit_exact_double_timestamps, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0,
+                               ctx->stream, args.timestamps, args.chunk_offsets, n_chunks, error_flag + 1);
+            FIT_CHECK(hipMemcpyAsync(&inexact, error_flag + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            fast = inexact == 0;
+        }
+        const bool lean = fast && fit_lean_setting() && eb.kind != MDB_EB_LOSSLESS;
         const uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
         ModelRec *records = static_cast<ModelRec *>(p);
@@ -1692,10 +2247,19 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             LaunchTimer timer(ctx, "k_fit_models");
             const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
             if (ts)
-                hipLaunchKernelGGL((k_fit_models<true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                hipLaunchKernelGGL((k_fit_models<true, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+            else if (lean && eb.kind == MDB_EB_RELATIVE)
+                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_RELATIVE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+            else if (lean && eb.kind == MDB_EB_ABSOLUTE)
+                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_ABSOLUTE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+            else if (fast)
+                hipLaunchKernelGGL((k_fit_models<false, false, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
             else
-                hipLaunchKernelGGL((k_fit_models<false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                hipLaunchKernelGGL((k_fit_models<false, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
         } else {
             // Split mode: pieces of every chunk fitted speculatively, then the real chain is walked.
@@ -1720,10 +2284,19 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 LaunchTimer timer(ctx, "k_fit_models_split");
                 const uint32_t fit_blocks = (uint32_t)((n_pieces + FIT_THREADS - 1) / FIT_THREADS);
                 if (ts)
-                    hipLaunchKernelGGL((k_fit_models<true, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                    hipLaunchKernelGGL((k_fit_models<true, true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else if (lean && eb.kind == MDB_EB_RELATIVE)
+                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_RELATIVE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else if (lean && eb.kind == MDB_EB_ABSOLUTE)
+                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_ABSOLUTE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else if (fast)
+                    hipLaunchKernelGGL((k_fit_models<false, true, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                        ctx->stream, args, split, record_base, records, plans, error_flag);
                 else
-                    hipLaunchKernelGGL((k_fit_models<false, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                    hipLaunchKernelGGL((k_fit_models<false, true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                        ctx->stream, args, split, record_base, records, plans, error_flag);
             }
             LaunchTimer timer(ctx, "k_fit_walk");

@@ -16,14 +16,24 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[("auto", None), ("1", "off"), ("64", "8"), ("1000", None)],
-                ids=["split-auto", "lane-per-chunk+lane-per-gap", "pieces-of-64+gaps-from-8", "pieces-of-1000"])
+@pytest.fixture(autouse=True, params=[("auto", None, None), ("1", "off", None), ("64", "8", None),
+                                      ("1000", None, "lean-off"), ("1", None, "plain")],
+                ids=["split-auto", "lane-per-chunk+lane-per-gap", "pieces-of-64+gaps-from-8",
+                     "pieces-of-1000+k_fit_models-fast", "lane-per-chunk+k_fit_models-plain"])
 def fit_mode(request, monkeypatch):
     """Every fit test runs with the library choosing between one lane per chunk and split mode
-    (speculative pieces + chain walk, mdb_fit.hip), with split mode off, and with it forced; and with
+    (speculative pieces + chain walk, mdb_fit.hip), with split mode off, and with it forced; with
     long lossless MacaqueV-only segments encoded by one wave each (k_fit_gap) from the default length,
-    never, and from 8 values."""
-    pieces, gaps = request.param
+    never, and from 8 values; and with each of the three forms of the greedy loop (k_fit_models_lean
+    where it applies, k_fit_models with the fast forms of the fitters, k_fit_models plain)."""
+    pieces, gaps, loop = request.param
+    for name in ("MDB_FIT_LEAN", "MDB_FIT_FAST"):
+        monkeypatch.delenv(name, raising=False)
+    if loop in ("lean-off", "plain"):
+        monkeypatch.setenv("MDB_FIT_LEAN", "0")
+    if loop == "plain":
+        monkeypatch.setenv("MDB_FIT_FAST", "0")
+
     if pieces == "auto":
         monkeypatch.delenv("MDB_FIT_PIECE_POINTS", raising=False)
     else:
