@@ -71,6 +71,8 @@ enum ScratchSlot {
     SCRATCH_AGG_MV,
     SCRATCH_STAGE_DEV,
     SCRATCH_COMM,
+    SCRATCH_TS_BASE,
+    SCRATCH_TS_SLOTS,
     SCRATCH_SLOT_COUNT
 };
 
@@ -155,6 +157,21 @@ __device__ __forceinline__ uint32_t view_inline_byte(const uint4 &view, uint32_t
     return (word >> (8u * (k & 3u))) & 0xffu;
 }
 
+// A pointer the compiler has lost track of - read from the table of data buffers, or put together from
+// an aligned address - is a "flat" one to it, and every load through a flat pointer makes the wave
+// wait for ALL its outstanding memory operations (flat loads may come back out of order), which turns
+// "one chunk loaded ahead" into a full trip to memory per chunk. Everything these readers touch is
+// device (global) memory: saying so gives global_load instructions and counted waits.
+template <typename T> __device__ __forceinline__ T load_global(const T *pointer) {
+    typedef const __attribute__((address_space(1))) T *global_pointer;
+    return *(global_pointer)(uintptr_t)pointer;
+}
+__device__ __forceinline__ uint4 load_global(const uint4 *pointer) { // (uint4 is a class: load the plain vector)
+    typedef unsigned int plain4 __attribute__((ext_vector_type(4)));
+    const plain4 v = load_global(reinterpret_cast<const plain4 *>(pointer));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct DevCol {
     const uint4 *views;
     const uint8_t *const *buffers;
@@ -223,7 +240,7 @@ struct BitReaderDev {
     uint4 current, ahead;
 
     __device__ __forceinline__ uint4 load_chunk(uint32_t index) const {
-        return index < n_chunks ? chunks[index] : make_uint4(0u, 0u, 0u, 0u);
+        return index < n_chunks ? load_global(chunks + index) : make_uint4(0u, 0u, 0u, 0u);
     }
 
     __device__ __forceinline__ uint32_t take_word() {
@@ -324,23 +341,28 @@ struct WindowReaderDev {
 
     // As stored (little endian): the byte swap happens where the word is used, a few codes later, so
     // that nothing has to wait for the load right behind it.
+    // (always a load, see LeanReaderDev::load: behind the end the last word repeats, and the caller does
+    // not look at those bits)
     __device__ __forceinline__ uint64_t load(uint32_t index) const {
-        return index < n_words ? words[index] : 0ull;
+        return load_global(words + min(index, n_words > 0 ? n_words - 1 : 0u));
     }
+    // Any start_bit: whole 8-byte words in front of it are skipped, not read.
     __device__ __forceinline__ void open(const uint8_t *bytes, uint64_t nbytes, uint32_t start_bit) {
         const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
         const uint32_t misalign = (uint32_t)(address & 7u);
-        words = reinterpret_cast<const uint64_t *>(address - misalign);
-        n_words = (uint32_t)((nbytes + misalign + 7u) >> 3);
+        const uint64_t first_bit = 8ull * misalign + start_bit; // counted from the aligned base
+        const uint64_t skipped = first_bit >> 6;
+        const uint64_t all_words = (nbytes + misalign + 7u) >> 3;
+        words = reinterpret_cast<const uint64_t *>(address - misalign) + skipped;
+        n_words = (uint32_t)(all_words > skipped ? all_words - skipped : 0u);
         high = __builtin_bswap64(load(0));
         low = __builtin_bswap64(load(1));
         ahead = load(2);
         next_word = 3;
         available = 128;
-        position = 0;
         total_bits = nbytes * 8u;
-        uint32_t drop = 8u * misalign + start_bit; // < 64 + 64
-        position = 0 - (uint64_t)(8u * misalign);  // consume() adds it back
+        uint32_t drop = (uint32_t)(first_bit & 63u);
+        position = (uint64_t)start_bit - drop; // consume() adds it back
         while (drop > 0) {
             const uint32_t step = drop > 32u ? 32u : drop;
             consume(step);
@@ -364,6 +386,80 @@ struct WindowReaderDev {
             ahead = load(next_word++);
             available += 64;
         }
+    }
+};
+
+// The leanest of the readers, for the delta-of-delta timestamp codes (1 to 16 bits almost always): a
+// 64-bit buffer refilled 32 bits at a time, without a branch except around the fetch of the word.
+// Words come out of 16-byte chunks, one chunk loaded AHEAD of the one in use: a lane that walks a
+// stream of its own needs a word every three codes or so, in lockstep with 63 others that is a load in
+// nearly every step of the wave, and a load that is needed in the next step costs the whole wave a
+// trip to memory - a chunk ahead is some ten steps of lead. (A chunk that holds at least one byte of
+// the payload never crosses a page, so the slack bytes of the first and last chunk are safe to touch.)
+// The caller stops `slack` bits before the end (far_from_end) and hands over to BitReaderDev::seek.
+struct LeanReaderDev {
+    const uint4 *chunks; // 16-byte aligned base (of the first chunk that is read)
+    uint32_t last_chunk; // index of the last chunk that holds payload
+    uint32_t next_chunk; // next one to load into `ahead`
+    uint32_t left;       // words of `current` not handed out yet (1..4)
+    uint4 current, ahead; // current.x is the next word
+    uint64_t buffer;     // bits [position, position + available) of the stream, MSB first
+    int32_t available;
+    uint64_t position;   // bits of the payload consumed
+    uint64_t total_bits;
+
+    // Always a load of a chunk of the stream, never a choice between a load and a constant: a value
+    // that is "the loaded chunk or zeros" has to be put together right behind the load, and the wave
+    // would wait for the memory there instead of a chunk later. Behind the end the last chunk repeats;
+    // the caller does not look at those bits (far_from_end).
+    __device__ __forceinline__ uint4 load(uint32_t index) const { return load_global(chunks + min(index, last_chunk)); }
+    __device__ __forceinline__ uint32_t take_word() {
+        const uint32_t w = current.x;
+        current.x = current.y;
+        current.y = current.z;
+        current.z = current.w;
+        if (--left == 0) {
+            current = ahead;
+            ahead = load(next_chunk++);
+            left = 4;
+        }
+        return __builtin_bswap32(w);
+    }
+    // nbytes > 0
+    __device__ __forceinline__ void open(const uint8_t *bytes, uint64_t nbytes, uint64_t start_bit) {
+        const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        const uint32_t misalign = (uint32_t)(address & 15u);
+        const uint64_t first_bit = 8ull * misalign + start_bit; // counted from the aligned base
+        const uint64_t skipped = first_bit >> 7;                // whole chunks in front of it
+        const uint64_t all_chunks = (nbytes + misalign + 15u) >> 4;
+        chunks = reinterpret_cast<const uint4 *>(address - misalign) + skipped;
+        last_chunk = (uint32_t)(all_chunks > skipped ? all_chunks - skipped - 1 : 0u);
+        current = load(0);
+        ahead = load(1);
+        next_chunk = 2;
+        left = 4;
+        for (uint32_t k = (uint32_t)((first_bit >> 5) & 3u); k > 0; k--) (void)take_word();
+        const uint32_t drop = (uint32_t)(first_bit & 31u);
+        const uint64_t high = take_word();
+        buffer = ((high << 32) | take_word()) << drop;
+        available = 64 - (int32_t)drop;
+        position = start_bit;
+        total_bits = nbytes * 8u;
+    }
+    __device__ __forceinline__ bool far_from_end(uint32_t slack) const { return position + slack <= total_bits; }
+    // At least 33 valid bits afterwards.
+    __device__ __forceinline__ void refill() {
+        if (available <= 32) {
+            buffer |= (uint64_t)take_word() << (32 - available);
+            available += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t top() const { return (uint32_t)(buffer >> 32); }
+    // count in [0, 32], after refill()
+    __device__ __forceinline__ void consume(uint32_t count) {
+        buffer <<= count;
+        available -= (int32_t)count;
+        position += count;
     }
 };
 

@@ -15,9 +15,12 @@
 //                    points; every wave-level store instruction writes 1 KiB contiguous (timestamps
 //                    are transposed through LDS for that). Writes placeholders for points it cannot
 //                    reconstruct.
+//   k_grid_timestamps 1 lane / 256-bit piece of a delta-of-delta timestamp stream, from the cursor the
+//                    prepass left in front of the piece's first code: timestamps and the Swing values
+//                    that follow from them overwrite the placeholders, each lane a contiguous run.
 //   k_grid_serial    1 lane / segment with a serial dependency, always after k_grid_tiles: MacaqueV
-//                    value streams, residual tails (<= 255 values) and irregular (delta-of-delta)
-//                    timestamps overwrite the placeholders.
+//                    value streams, residual tails (<= 255 values) and the few irregular timestamp
+//                    streams short enough to live inside their view overwrite the placeholders.
 // Algorithmic bytes: 73 B/segment read + 12 B/point written (8 B timestamp + 4 B value).
 #include "mdb_segment_dev.hpp"
 #include "mdb_scan.hpp"
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     DevSegments s, TimeRange range, uint32_t mv_min_values, TileDesc *__restrict__ desc,
     uint32_t *__restrict__ counts, uint32_t *__restrict__ irregular_totals,
     uint32_t *__restrict__ irregular_first, unsigned long long *__restrict__ block_points,
-    unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header) {
+    unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header, TsCheckpoints checkpoints,
+    const uint32_t *__restrict__ known_totals) {
     __shared__ unsigned long long lds_metrics[12];
     if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
     __syncthreads();
@@ -61,8 +65,8 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     for (int k = 0; k < PREPASS_ITEMS; k++) {
         uint64_t i = base + (uint64_t)k * PREPASS_THREADS + threadIdx.x;
         if (i >= s.n) break;
-        SegInfo info = analyse_segment(s, i);
-        if (range.enabled) apply_time_range(s, i, info, range);
+        SegInfo info = analyse_segment(s, i, known_totals, &checkpoints);
+        if (range.enabled) apply_time_range(s, i, info, range, nullptr, nullptr, &checkpoints);
         error |= info.error;
         const SegDesc &d = info.desc;
         desc[i] = make_tile_desc(d);
@@ -317,6 +321,28 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     }
 }
 
+// ---- irregular timestamps, one lane per piece of a stream ---------------------------------------------------
+//
+// timestamps.rs:228-292 decodes a delta-of-delta stream code by code; what it carries from one code to
+// the next is a TsCursor, and the prepass - which has to walk every such stream once anyway, because
+// the number of points of a segment is the number of its codes - has left the cursor in front of the
+// first code of every 256-bit piece. So the second walk is not one: every piece is decoded by a lane
+// of its own (about 22 codes of a randomly sampled series, up to 256 of a fixed-rate series with gaps),
+// lanes next to each other decode pieces next to each other and write runs of points next to each
+// other. Swing values are (slope * t + intercept) of the timestamps just decoded (swing.rs:304-319, the
+// line is in the descriptor); PMC-Mean values do not depend on the timestamp (k_grid_tiles has written
+// them); MacaqueV values and residual tails are k_grid_serial's.
+
+struct TsPieceCount { // pieces of the stream of segment i, 0 if it has no checkpoints
+    DevSegments s;
+    __device__ uint64_t operator()(uint64_t i) const {
+        const uint4 view = s.timestamps.views[i];
+        const int32_t length = (int32_t)view.x;
+        const bool irregular = length > 0 && (view_inline_byte(view, 0) & 0x80u) != 0;
+        return irregular && ts_has_checkpoints(length) ? ts_pieces((uint32_t)length) : 0u;
+    }
+};
+
 // ---- the serial kernel -------------------------------------------------------------------------------
 //
 // One lane per segment that carries a serial dependency, one wave per workgroup. MacaqueV streams
@@ -428,7 +454,7 @@ __device__ __forceinline__ void ring_top_up(RingBitReader &reader, uint32_t (*ri
 #pragma unroll
     for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
         const uint32_t index = first + k;
-        fetched[k] = ((uint32_t)k < room && index < reader.n_words) ? reader.words[index] : 0u;
+        fetched[k] = ((uint32_t)k < room && index < reader.n_words) ? load_global(reader.words + index) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < SERIAL_TOPUP_WORDS; k++) {
@@ -476,12 +502,369 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
     return bits;
 }
 
+// ---- k_grid_ts_count: the one sequential walk over every delta-of-delta stream ---------------------------
+//
+// len() of a segment with irregular timestamps is the number of codes of its stream (models/mod.rs:
+// 98-124), so every such stream has to be walked once before anything can be placed. One lane per
+// segment, one wave per workgroup, the streams read through the LDS ring of k_grid_serial (a wave
+// that walks 64 streams needs a word of some stream in nearly every step: fetched one by one that is a
+// trip to memory per step, fetched 24 words per lane at a time it is one per seventy). On the way the
+// lane leaves the cursor in front of the first code of every 256-bit piece (TsCursor): from there on
+// the pieces are independent. The last 80 bits of a stream, where running out of bits has a meaning,
+// are left to the careful decoder. The step carries nothing it does not need: no per-point callback,
+// one branch for the rare 32- and 64-bit codes, one for a run of `0` codes (counted and skipped at
+// once: a series sampled at a fixed rate with the odd gap is such runs almost entirely), one for the
+// checkpoint.
+__global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s, TsCheckpoints checkpoints,
+                                                                 uint32_t *__restrict__ totals,
+                                                                 GridHeader *__restrict__ header) {
+    __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    uint4 view = make_uint4(0u, 0u, 0u, 0u);
+    if (i < s.n) view = s.timestamps.views[i];
+    const int32_t length = (int32_t)view.x;
+    const bool irregular = i < s.n && length > 0 && (view_inline_byte(view, 0) & 0x80u) != 0;
+    if (!__any(irregular)) return;
+    const uint8_t *bytes = irregular ? view_data(s.timestamps, i, view) : nullptr;
+    const uint32_t nbytes = irregular ? (uint32_t)length : 0u;
+    const bool keeps = irregular && checkpoints.piece_base != nullptr && ts_has_checkpoints(length);
+    TsCursor *slots = keeps ? checkpoints.slots + checkpoints.piece_base[i] : nullptr;
+    const uint32_t n_slots = keeps ? ts_pieces(nbytes) : 0u;
+    TsCursor at = ts_stream_start(irregular ? s.start_time[i] : 0, bytes);
+    if (keeps) {
+        uint2 *owner = checkpoints.piece_segment + checkpoints.piece_base[i];
+        for (uint32_t k = 0; k < n_slots; k++) owner[k] = make_uint2((uint32_t)i, nbytes);
+        slots[0] = at;
+    }
+    uint32_t piece = 0;
+    uint32_t error = 0;
+    // (streams of 2^28 bytes and more have no checkpoints and go through the careful decoder whole)
+    const uint32_t fast_end = nbytes < (1u << 28) && nbytes * 8u >= 80u ? nbytes * 8u - 80u : 0u;
+    RingBitReader reader;
+    reader.begin(bytes, nbytes);
+    bool active = irregular && at.bit <= fast_end;
+    bool fresh = true;
+    while (__any(active)) {
+        if (__any(active && reader.hungry())) {
+            ring_top_up(reader, ring, lane, active);
+            // (a step that took three words off the ring - a 64-bit code - has looked ahead at a slot
+            // that was not filled yet)
+            reader.look_ahead(ring, lane);
+        }
+        if (active) {
+            if (fresh) { // the flag "irregular" (timestamps.rs:116) is bit 0
+                reader.look_ahead(ring, lane);
+                reader.refill(ring, lane);
+                reader.refill(ring, lane);
+                reader.consume(1);
+                fresh = false;
+            }
+            if (keeps && (at.bit >> 8) != piece) {
+                piece = at.bit >> 8;
+                slots[piece] = at;
+            }
+            reader.refill(ring, lane);
+            const uint32_t top = (uint32_t)(reader.buffer >> 32);
+            uint32_t length_of_code;
+            if (top < 0x08000000u) { // five `0` codes or more
+                uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
+                run = min(run, ((piece + 1u) << 8) - at.bit); // (the next piece's cursor is met)
+                at.timestamp = (int64_t)((uint64_t)at.timestamp + (uint64_t)run * at.last_delta);
+                at.count += run;
+                length_of_code = run;
+            } else {
+                const uint32_t ones = (uint32_t)__clz((int)~top);
+                if (ones >= 4) {
+                    reader.consume(5); // `11110` + 32 bits or `11111` + 64 bits
+                    reader.refill(ring, lane);
+                    uint64_t encoded = (uint32_t)(reader.buffer >> 32);
+                    reader.consume(32);
+                    at.bit += 37;
+                    if (ones >= 5) {
+                        reader.refill(ring, lane);
+                        encoded = (encoded << 32) | (uint32_t)(reader.buffer >> 32);
+                        reader.consume(32);
+                        at.bit += 32;
+                        at.last_delta += encoded;
+                    } else {
+                        at.last_delta += encoded > (1ull << 31) ? (encoded | (~0ull << 32)) : encoded;
+                    }
+                    length_of_code = 0;
+                } else {
+                    int32_t delta_of_delta;
+                    length_of_code = ts_short_code(top, ones, &delta_of_delta);
+                    at.last_delta += (uint64_t)(int64_t)delta_of_delta;
+                }
+                at.timestamp = (int64_t)((uint64_t)at.timestamp + at.last_delta);
+                at.count += 1;
+            }
+            reader.consume(length_of_code);
+            at.bit += length_of_code;
+            active = at.bit <= fast_end;
+        }
+    }
+    if (irregular) {
+        if (keeps && (at.bit >> 8) != piece && at.bit < nbytes * 8u) {
+            piece = at.bit >> 8;
+            slots[piece] = at;
+        }
+        // The last codes with the careful decoder (it meets the cursors of the pieces it enters itself).
+        uint32_t last_piece = piece;
+        bool finished = false;
+        at = decode_irregular_span(bytes, nbytes, s.end_time[i], 0xffffffffu, &error, at, 0xffffffffu, &finished,
+                                   [](uint32_t, int64_t) {},
+                                   [&](const TsCursor &c) {
+                                       if (!keeps) return;
+                                       last_piece = c.bit / TS_PIECE_BITS;
+                                       slots[last_piece] = c;
+                                   });
+        for (uint32_t k = last_piece + 1; k < n_slots; k++)
+            slots[k] = TsCursor{nbytes * 8u, TS_NO_CODE, s.end_time[i], 0ull, bytes};
+        totals[i] = at.count;
+    }
+    if (error) atomicOr(&header->error, error);
+}
+
+// ---- k_grid_timestamps: the second walk is not one -----------------------------------------------------------
+//
+// One lane per piece of a stream, from the cursor k_grid_ts_count left in front of the piece's first
+// code: about 22 codes of a randomly sampled series, up to 256 of a fixed-rate series with gaps. How
+// many codes it is the next piece's cursor says, so they are simply taken off the stream (the careful
+// decoder has been over the last bits of every stream already). The bytes of the piece - at most 80,
+// counted from the 16-byte boundary below its first one - are fetched at once and parked in LDS; the
+// points go to LDS too, as 32-bit offsets from the first timestamp of the wave, because the 64 pieces
+// of a wave are usually pieces of one stream that follow each other, and so do the points they decode
+// to: the wave then writes them out together, every store instruction a contiguous run (a lane storing
+// its own points one by one is a request per point to the memory system, and that is what bounds the
+// kernel then). A wave whose pieces hold more points than the buffer has room for (long runs of `0`
+// codes: hundreds of points per piece), whose points do not follow each other in the output or span
+// more than 2^32 microseconds stores directly, two timestamps per store.
+// Swing values are (slope * t + intercept) of the timestamps just decoded (swing.rs:304-319, the line
+// is in the descriptor), a PMC-Mean value does not depend on the timestamp, MacaqueV values and
+// residuals are written later by k_grid_serial.
+constexpr uint32_t TS_STAGE_POINTS = 1536;
+constexpr int TS_THREADS = 128;
+constexpr int TS_PIECE_CHUNKS = 4; // 16-byte chunks parked per piece: 127 + 255 + 69 + 32 bits at most
+
+__global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
+    DevSegments s, const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ irregular_totals, const uint32_t *__restrict__ irregular_first,
+    const uint32_t *__restrict__ counts, TsCheckpoints checkpoints, uint64_t n_pieces,
+    int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    __shared__ uint32_t stage_ts[TS_THREADS / MDB_WAVE][TS_STAGE_POINTS];
+    __shared__ float stage_val[TS_THREADS / MDB_WAVE][TS_STAGE_POINTS];
+    __shared__ uint4 parked[TS_THREADS / MDB_WAVE][TS_PIECE_CHUNKS][MDB_WAVE];
+    const int lane = threadIdx.x % MDB_WAVE, wave = threadIdx.x / MDB_WAVE;
+    const uint64_t slot = (uint64_t)blockIdx.x * TS_THREADS + threadIdx.x;
+    const bool present = slot < n_pieces;
+    // What the lane needs to know arrives in two rounds of loads: the piece's cursor (with the address
+    // of the stream), its segment and the next piece's; then everything about the segment, together
+    // with the bytes of the piece.
+    TsCursor from = TsCursor{0u, TS_NO_CODE, 0, 0ull, nullptr};
+    uint32_t i = 0, stream_bytes = 0, next_count = TS_NO_CODE;
+    bool next_is_mine = false; // the next piece belongs to the same stream
+    if (present) {
+        from = checkpoints.slots[slot];
+        const uint2 owner = checkpoints.piece_segment[slot];
+        i = owner.x;
+        stream_bytes = owner.y;
+        if (slot + 1 < n_pieces) {
+            next_is_mine = checkpoints.piece_segment[slot + 1].x == i;
+            next_count = checkpoints.slots[slot + 1].count;
+        }
+    }
+    const bool has_code = from.count != TS_NO_CODE;
+    const uint32_t piece = from.bit >> 8; // (a piece without a code is never the first of its stream)
+    const uint32_t visible = present ? counts[i] & COUNT_MASK : 0u;
+    const uint32_t first = present ? irregular_first[i] : 0u; // index of the first visible point
+    const uint32_t visible_end = first + visible;              // (and behind the last)
+    const uint32_t n_total = present ? irregular_totals[i] : 0u;
+    const int64_t end_time = present ? s.end_time[i] : 0;
+    // The bytes of the piece: at most 16-byte chunks 0..3 from the boundary below its first code.
+    uint32_t first_bit = 0; // of the piece's first code, counted from the first parked chunk
+    uint4 fetched[TS_PIECE_CHUNKS];
+    if (present && has_code) {
+        const uintptr_t address = reinterpret_cast<uintptr_t>(from.stream) + (from.bit >> 3);
+        const uint4 *chunk = reinterpret_cast<const uint4 *>(address & ~(uintptr_t)15u);
+        // (a chunk that holds a byte of the stream never crosses a page; behind the last one it repeats)
+        const uintptr_t last_byte = reinterpret_cast<uintptr_t>(from.stream) + stream_bytes - 1;
+        const uint4 *last_chunk = reinterpret_cast<const uint4 *>(last_byte & ~(uintptr_t)15u);
+        first_bit = (uint32_t)(address & 15u) * 8u + (from.bit & 7u);
+#pragma unroll
+        for (int c = 0; c < TS_PIECE_CHUNKS; c++) fetched[c] = load_global(min(chunk + c, last_chunk));
+    }
+    // The points this lane decodes: from the one its first code produces (piece 0: from point 0, the
+    // start time) up to where the next piece takes over, or to the end of the segment.
+    uint32_t run_first = 0, run_end = 0;
+    const bool last_of_stream = !next_is_mine || next_count == TS_NO_CODE; // no code starts in a later piece
+    if (present && visible > 0 && has_code) {
+        run_first = piece == 0 ? 0u : from.count;
+        run_end = last_of_stream ? n_total : next_count;
+        run_first = max(run_first, first);
+        run_end = min(run_end, visible_end);
+        if (run_end < run_first) run_end = run_first;
+    }
+    const uint32_t mine = run_end - run_first;
+    const uint64_t o = present ? (uint64_t)offsets[i] : 0;
+    const uint64_t out_first = o + (run_first - first);
+    // Where the lane's points go inside the wave's: an exclusive prefix sum over the lanes.
+    uint32_t before = mine;
+#pragma unroll
+    for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+        const uint32_t up = __shfl_up(before, delta, MDB_WAVE);
+        if (lane >= delta) before += up;
+    }
+    const uint32_t wave_total = __shfl(before, MDB_WAVE - 1, MDB_WAVE);
+    before -= mine;
+    if (wave_total == 0) return;
+
+    // The bytes of the piece, parked in LDS: chunk c of the lane is parked[wave][c][lane].
+    if (present && has_code) {
+#pragma unroll
+        for (int c = 0; c < TS_PIECE_CHUNKS; c++) parked[wave][c][lane] = fetched[c];
+    }
+    const uint32_t *my_words = reinterpret_cast<const uint32_t *>(&parked[wave][0][0]);
+    auto word = [&](uint32_t k) { // word k of the lane's parked bytes, most significant byte first
+        k = min(k, (uint32_t)(4 * TS_PIECE_CHUNKS - 1));
+        return __builtin_bswap32(my_words[((k >> 2) * MDB_WAVE + lane) * 4 + (k & 3u)]);
+    };
+
+    // All the lanes' runs one after the other in the output, and close enough in time?
+    const unsigned long long producing = __ballot(mine > 0);
+    const int leader = __ffsll((long long)producing) - 1;
+    const uint64_t wave_first = __shfl((uint32_t)(out_first >> 32), leader, MDB_WAVE) * 0x100000000ull +
+                                __shfl((uint32_t)out_first, leader, MDB_WAVE);
+    const int64_t lane_base = from.timestamp; // (piece 0: the start time)
+    const int64_t base_time = (int64_t)(__shfl((uint32_t)((uint64_t)lane_base >> 32), leader, MDB_WAVE) * 0x100000000ull +
+                                        __shfl((uint32_t)lane_base, leader, MDB_WAVE));
+    bool staged = wave_total <= TS_STAGE_POINTS && !__any(mine > 0 && out_first != wave_first + before);
+
+    const TileDesc d = present ? desc[i] : TileDesc{};
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    // d.n_model counts the VISIBLE points the model stands for; they are the first ones.
+    const uint32_t model_end = first + d.n_model;
+    uint32_t *my_ts = stage_ts[wave];
+    float *my_val = stage_val[wave];
+    bool too_far = false;  // a timestamp does not fit into 32 bits from base_time: the wave stores directly
+    int64_t held = 0;      // (direct stores) timestamp of an even output position waiting for its neighbour
+    bool holding = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        auto emit = [&](uint32_t k, int64_t t) {
+            if (k < run_first || k >= run_end) return;
+            // swing.rs:304-319 on the timestamp just decoded; a PMC-Mean value is what k_grid_tiles has
+            // written already; MacaqueV values and residuals are written later (placeholder, as there).
+            float value = 0.0f;
+            if (k < model_end) value = type == MDB_SWING_ID ? (float)(d.slope * (double)t + d.intercept) : d.value;
+            if (staged) {
+                const uint64_t distance = (uint64_t)(t - base_time);
+                too_far |= distance > 0xffffffffull;
+                my_ts[before + (k - run_first)] = (uint32_t)distance;
+                my_val[before + (k - run_first)] = value;
+                return;
+            }
+            const uint64_t at = out_first + (k - run_first);
+            if (type == MDB_SWING_ID && k < model_end) out_val[at] = value;
+            if (!out_ts) return;
+            if (at & 1ull) {
+                if (holding) {
+                    *reinterpret_cast<longlong2 *>(out_ts + at - 1) = make_longlong2(held, t);
+                    holding = false;
+                } else {
+                    out_ts[at] = t;
+                }
+            } else {
+                held = t;
+                holding = true;
+            }
+        };
+        if (mine > 0) {
+            if (piece == 0) emit(0u, from.timestamp); // point 0 is the start time
+            if (has_code && from.count < run_end) {
+                // The codes of this piece produce the points from.count .. codes_end - 1. The last point
+                // of a segment is not a code: it is end_time (timestamps.rs:108-113).
+                const uint32_t codes_end = min(run_end, last_of_stream ? n_total - 1u : next_count);
+                uint32_t next_word = first_bit >> 5;
+                uint64_t buffer = (((uint64_t)word(next_word) << 32) | word(next_word + 1)) << (first_bit & 31u);
+                int32_t available = 64 - (int32_t)(first_bit & 31u);
+                next_word += 2;
+                auto refill = [&]() { // at least 33 bits afterwards, without a branch
+                    const bool want = available <= 32;
+                    const uint64_t placed = (uint64_t)word(next_word) << ((32 - available) & 63);
+                    buffer |= want ? placed : 0ull;
+                    available += want ? 32 : 0;
+                    next_word += want ? 1u : 0u;
+                };
+                auto consume = [&](uint32_t bits) {
+                    buffer <<= bits;
+                    available -= (int32_t)bits;
+                };
+                int64_t timestamp = from.timestamp;
+                uint64_t last_delta = from.last_delta;
+                uint32_t k = from.count;
+                while (k < codes_end) {
+                    refill();
+                    const uint32_t top = (uint32_t)(buffer >> 32);
+                    if (top < 0x00800000u) { // nine `0` codes or more: the delta repeats
+                        uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
+                        run = min(run, codes_end - k);
+                        consume(run);
+                        for (uint32_t j = 0; j < run; j++) {
+                            timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+                            emit(k++, timestamp);
+                        }
+                        continue;
+                    }
+                    const uint32_t ones = (uint32_t)__clz((int)~top);
+                    uint32_t length = 0;
+                    if (ones >= 4) {
+                        consume(5); // `11110` + 32 bits or `11111` + 64 bits
+                        refill();
+                        uint64_t encoded = (uint32_t)(buffer >> 32);
+                        consume(32);
+                        if (ones >= 5) {
+                            refill();
+                            encoded = (encoded << 32) | (uint32_t)(buffer >> 32);
+                            consume(32);
+                            last_delta += encoded;
+                        } else {
+                            last_delta += encoded > (1ull << 31) ? (encoded | (~0ull << 32)) : encoded;
+                        }
+                    } else {
+                        int32_t delta_of_delta;
+                        length = ts_short_code(top, ones, &delta_of_delta);
+                        last_delta += (uint64_t)(int64_t)delta_of_delta;
+                    }
+                    consume(length);
+                    timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+                    emit(k++, timestamp);
+                }
+                if (last_of_stream && run_end == n_total) emit(n_total - 1u, end_time);
+            }
+            if (holding) {
+                out_ts[out_first + (run_end - 1 - run_first)] = held;
+                holding = false;
+            }
+        }
+        if (!staged || !__any(too_far)) break;
+        staged = false; // once more, with direct stores
+    }
+    if (!staged) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t k = lane; k < wave_total; k += MDB_WAVE) {
+        if (out_ts) out_ts[wave_first + k] = base_time + (int64_t)(uint64_t)my_ts[k];
+        out_val[wave_first + k] = my_val[k];
+    }
+}
+
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     DevSegments s, TimeRange range, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ irregular_totals,
     const uint32_t *__restrict__ irregular_first, int64_t *__restrict__ out_ts, float *__restrict__ out_val,
-    GridHeader *__restrict__ header) {
+    GridHeader *__restrict__ header, TsCheckpoints checkpoints) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -494,8 +877,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     if (present) {
         // The few segments with serial work are analysed again here rather than carrying the full
         // descriptor (first visible index, whole-segment counts) through memory for all of them.
-        SegInfo info = analyse_segment(s, i, irregular_totals);
-        if (range.enabled) apply_time_range(s, i, info, range, irregular_first, counts);
+        SegInfo info = analyse_segment(s, i, irregular_totals, &checkpoints);
+        if (range.enabled) apply_time_range(s, i, info, range, irregular_first, counts, &checkpoints);
         d = info.desc;
         error = info.error;
     }
@@ -504,8 +887,9 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint64_t o = present ? (uint64_t)offsets[i] : 0;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
 
-    if (present && !(d.flags & FLAG_REGULAR)) {
-        // Irregular timestamps. Every lane writes into a region of its own, so a store instruction
+    if (present && !(d.flags & (FLAG_REGULAR | FLAG_CHECKPOINTS))) {
+        // Irregular timestamps short enough to live inside their view (k_grid_timestamps has the
+        // others). Every lane writes into a region of its own, so a store instruction
         // of the wave touches 64 different cache lines: two timestamps are paired into one aligned
         // 16-byte store, and the values are not written here at all when the timestamps are (a
         // PMC-Mean value does not depend on the timestamp and k_grid_tiles has written it already;
@@ -628,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_grid_swing_irregular(
     // The prepass has left what is needed in the segment's descriptor: the line, and how many of the
     // visible points the model stands for.
     const TileDesc t = desc[i];
-    if ((t.flags & FLAG_REGULAR) || (t.flags & FLAG_TYPE_MASK) != MDB_SWING_ID) return;
+    if ((t.flags & (FLAG_REGULAR | FLAG_CHECKPOINTS)) || (t.flags & FLAG_TYPE_MASK) != MDB_SWING_ID) return;
     const uint64_t o = offsets[i];
     for (uint32_t k = lane; k < t.n_model; k += MDB_WAVE)
         out_val[o + k] = (float)(t.slope * (double)out_ts[o + k] + t.intercept);
@@ -651,6 +1035,8 @@ struct GridPlan {
     uint32_t n_blocks;
     uint32_t mv_min_values; // MacaqueV streams at least this long go to the parallel decoder
     bool mv_forced;         // MDB_GRID_MV_MIN_VALUES is set: no upper limit on the number of pieces
+    TsCheckpoints checkpoints; // of the batch's irregular timestamp streams (piece_base == nullptr: none)
+    uint64_t n_ts_pieces;
 };
 
 // MDB_GRID_MV_MIN_VALUES: "off" disables the parallel MacaqueV decoder, a number sets the stream
@@ -697,14 +1083,49 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     std::memset(&plan->host_header, 0, sizeof(GridHeader));
     plan->mv_min_values = mv_min_values_setting();
     plan->mv_forced = std::getenv("MDB_GRID_MV_MIN_VALUES") != nullptr;
+    plan->checkpoints = TsCheckpoints{nullptr, nullptr, nullptr};
+    plan->n_ts_pieces = 0;
     if (n == 0) return 0;
     DevSegments s = to_dev(in);
+    // Timestamp streams that do not fit into their views (irregular timestamps of more than a handful
+    // of points): a slot per 256-bit piece for the cursors the prepass leaves behind. The column's data
+    // buffers say whether there are any (MDB_GRID_TS_PIECES=off: decode them one lane per segment).
+    uint64_t ts_payload = 0;
+    for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
+        ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
+    const char *pieces_setting = std::getenv("MDB_GRID_TS_PIECES");
+    if (pieces_setting && std::strcmp(pieces_setting, "off") == 0) ts_payload = 0;
+    if (ts_payload > 0) {
+        if (scratch_reserve(ctx, SCRATCH_TS_BASE, (n + 1) * 8 + scan_block_sums_bytes(n) + 64, &p)) return 1;
+        unsigned long long *piece_base = static_cast<unsigned long long *>(p);
+        if (device_exclusive_scan(ctx, TsPieceCount{s}, n, piece_base, piece_base + n + 1, "k_grid_ts_scan")) return 1;
+        unsigned long long n_pieces = 0;
+        MDB_HIP_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n_pieces > 0) {
+            if (scratch_reserve(ctx, SCRATCH_TS_SLOTS, n_pieces * (sizeof(TsCursor) + sizeof(uint2)) + 64, &p)) return 1;
+            plan->checkpoints.piece_base = piece_base;
+            plan->checkpoints.slots = static_cast<TsCursor *>(p);
+            plan->checkpoints.piece_segment = reinterpret_cast<uint2 *>(plan->checkpoints.slots + n_pieces);
+            plan->n_ts_pieces = n_pieces;
+        }
+    }
+    // The lengths of the irregular timestamp streams (and the cursors of their pieces) first: a walk of
+    // its own, so that it can be a wave-synchronous one.
+    const uint32_t *known_totals = nullptr;
+    if (ts_payload > 0) {
+        LaunchTimer timer(ctx, "k_grid_ts_count");
+        hipLaunchKernelGGL(k_grid_ts_count, dim3((uint32_t)((n + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+                           dim3(SERIAL_THREADS), 0, ctx->stream, s, plan->checkpoints, plan->irregular_totals,
+                           plan->header);
+        known_totals = plan->irregular_totals;
+    }
     {
         LaunchTimer timer(ctx, "k_grid_prepass");
         hipLaunchKernelGGL(k_grid_prepass, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s,
                            range, plan->mv_min_values, plan->desc, plan->counts, plan->irregular_totals,
                            plan->irregular_first, plan->block_points,
-                           plan->block_serial, plan->header);
+                           plan->block_serial, plan->header, plan->checkpoints, known_totals);
     }
     {
         LaunchTimer timer(ctx, "k_scan_blocks");
@@ -1278,6 +1699,13 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
                            plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, tile_ts,
                            out_val);
     }
+    if (plan.n_ts_pieces > 0) {
+        LaunchTimer timer(ctx, "k_grid_timestamps");
+        hipLaunchKernelGGL(k_grid_timestamps, dim3((uint32_t)((plan.n_ts_pieces + TS_THREADS - 1) / TS_THREADS)),
+                           dim3(TS_THREADS), 0, ctx->stream,
+                           s, plan.desc, plan.offsets, plan.irregular_totals, plan.irregular_first, plan.counts,
+                           plan.checkpoints, plan.n_ts_pieces, out_ts, out_val);
+    }
     const uint64_t n_serial = plan.host_header.n_serial;
     const MvSeg *mv_segs = nullptr;
     if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
@@ -1291,7 +1719,7 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
-                           plan.irregular_first, out_ts, out_val, plan.header);
+                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints);
     }
     if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
         LaunchTimer timer(ctx, "k_grid_swing_irregular");

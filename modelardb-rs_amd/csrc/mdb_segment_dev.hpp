@@ -15,6 +15,7 @@ enum : uint32_t {
     FLAG_REGULAR = 1u << 2,
     FLAG_HAS_RESIDUALS = 1u << 3,
     FLAG_SERIAL = 1u << 4,
+    FLAG_CHECKPOINTS = 1u << 5, // irregular timestamps with checkpoints: k_grid_timestamps writes them
 };
 
 enum : uint32_t {
@@ -105,56 +106,94 @@ __device__ __forceinline__ bool regular_index_interval(int64_t start, int64_t de
 
 // ---- MacaqueTS irregular decode (models/timestamps.rs:228-292) ---------------------------------
 
-// Calls emit(index, timestamp) for every timestamp; returns the count. `limit` stops early.
-template <typename Emit>
-__device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *bytes, uint32_t nbytes,
-                                                              int64_t start_time, int64_t end_time,
-                                                              uint32_t limit, uint32_t *error,
-                                                              Emit emit) {
-    uint32_t count = 0;
-    emit(count++, start_time);
-    if (count >= limit) return count;
-    uint64_t last_delta = 0;
-    int64_t timestamp = start_time;
+// Where a delta-of-delta stream stands in front of one of its codes: everything the decoder carries
+// from code to code. The stream of a long segment is cut into pieces of TS_PIECE_BITS bits; the one
+// sequential parse every such stream needs anyway (len() is the number of codes) leaves the cursor of
+// the first code that starts in each piece behind (a "checkpoint"), and from there on the pieces
+// are independent: k_grid_timestamps decodes them one lane per piece, and whoever needs the
+// timestamp of one point, or the points inside a time range, decodes one piece instead of the stream.
+struct TsCursor {
+    uint32_t bit;        // of the code, from the start of the payload (bit 0 is the flag "irregular")
+    uint32_t count;      // index of the point the code produces
+    int64_t timestamp;   // of the point before
+    uint64_t last_delta; // delta of the point before
+    const uint8_t *stream; // (checkpoints only) the payload, so that a piece can be fetched without its segment
+};
+static_assert(sizeof(TsCursor) == 32, "32 bytes per piece of a stream");
+
+constexpr uint32_t TS_PIECE_BITS = 256;
+constexpr uint32_t TS_NO_CODE = 0xffffffffu; // TsCursor::count of a piece in which no code starts (the last one)
+__device__ __forceinline__ uint32_t ts_pieces(uint32_t nbytes) { return (nbytes * 8u + TS_PIECE_BITS - 1) / TS_PIECE_BITS; }
+// Streams that live inside their view (at most 12 bytes, a handful of points) have no checkpoints.
+__device__ __forceinline__ bool ts_has_checkpoints(int32_t nbytes) { return nbytes > 12 && nbytes < (1 << 28); }
+
+// Decodes the codes that start at `at` and before bit `stop_bit`: emit(index, timestamp) for every
+// point, at most up to index limit - 1; cross(cursor) in front of the first code of every piece after
+// the one `at` lies in. Returns the cursor it stopped at; *finished: the stream is exhausted and its
+// last point (end_time, which is not stored, timestamps.rs:108-113) has been emitted.
+template <typename Emit, typename Cross>
+__device__ __forceinline__ TsCursor decode_irregular_span(const uint8_t *bytes, uint32_t nbytes, int64_t end_time,
+                                                        uint32_t limit, uint32_t *error, TsCursor at,
+                                                        uint32_t stop_bit, bool *finished, Emit emit, Cross cross) {
+    *finished = false;
+    uint32_t count = at.count;
+    uint64_t last_delta = at.last_delta;
+    int64_t timestamp = at.timestamp;
+    uint32_t piece = at.bit / TS_PIECE_BITS;
+    if (count >= limit) return at;
+    auto cursor = [&](uint64_t bit) { return TsCursor{(uint32_t)bit, count, timestamp, last_delta, bytes}; };
     // Far from the end of the stream (the longest code is 5 + 64 bits) nothing can go wrong, and the
-    // codes are taken off a 128-bit window with as few branches as possible: 64 lanes decode 64
-    // different codes per step, and every branch they disagree on is executed by all of them.
-    WindowReaderDev w;
-    w.open(bytes, nbytes, 1); // bit 0 is the flag "irregular" (timestamps.rs:116)
+    // codes are taken off the top of a 64-bit buffer with as few branches as possible: 64 lanes decode
+    // 64 different codes per step, and every branch they disagree on is executed by all of them.
+    LeanReaderDev w;
+    w.open(bytes, nbytes, at.bit);
     while (w.far_from_end(80)) {
+        if (w.position >= stop_bit) return cursor(w.position);
+        if ((uint32_t)(w.position / TS_PIECE_BITS) != piece) {
+            piece = (uint32_t)(w.position / TS_PIECE_BITS);
+            cross(cursor(w.position));
+        }
+        w.refill();
         const uint32_t top = w.top();
         if ((top >> 31) == 0u) {
             // A run of `0` codes - the delta repeats: what a series sampled at a fixed rate with the
             // odd gap or jitter consists of almost entirely (one irregularity makes the whole segment
-            // "irregular", timestamps.rs:77-96). The whole run is taken off the stream at once.
+            // "irregular", timestamps.rs:77-96). The whole run is taken off the stream at once, as far
+            // as it stays inside the piece.
             uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
             run = min(run, min(limit - count, COUNT_MASK - count));
+            run = min(run, (piece + 1u) * TS_PIECE_BITS - (uint32_t)w.position);
+            run = min(run, stop_bit - (uint32_t)w.position);
             if (run == 0) { // count == COUNT_MASK: as below
                 *error |= ERR_TOO_LONG;
-                return count;
+                return cursor(w.position);
             }
             w.consume(run);
             for (uint32_t j = 0; j < run; j++) {
                 timestamp = (int64_t)((uint64_t)timestamp + last_delta);
                 emit(count++, timestamp);
             }
-            if (count >= limit) return count;
+            if (count >= limit) return cursor(w.position);
             continue;
         }
         const uint32_t ones = min((uint32_t)__clz((int)~top), 5u);
         if (ones <= 3) {
-            const uint32_t header = ones + 1;                            // the run of ones and its zero
-            const uint32_t width = (0x0c090700u >> (8u * ones)) & 0xffu; // 0, 7, 9, 12
-            const uint32_t encoded = width ? (top << header) >> (32u - width) : 0u;
-            w.consume(header + width);
-            // Two's complement of `width` bits, except that 2^(width-1) itself is positive (:139-155).
-            const uint64_t negative = (uint64_t)encoded | (~0ull << (width ? width : 1u));
-            last_delta += (width && encoded > (1u << (width - 1))) ? negative : (uint64_t)encoded;
+            // `10` + 7, `110` + 9 or `1110` + 12 bits: two's complement of `width` bits, except that
+            // 2^(width-1) itself is positive (timestamps.rs:139-155).
+            const uint32_t width = (0x0c090700u >> (8u * ones)) & 0xffu; // (0,) 7, 9, 12
+            const uint32_t length = ones + 1u + width;
+            const uint32_t encoded = __builtin_amdgcn_ubfe(top, 32u - length, width);
+            w.consume(length);
+            const uint32_t half = (1u << width) >> 1;
+            const int32_t delta_of_delta = encoded > half ? (int32_t)(encoded - (half << 1)) : (int32_t)encoded;
+            last_delta += (uint64_t)(int64_t)delta_of_delta;
         } else {
             w.consume(5); // `11110` or `11111`
+            w.refill();
             uint64_t encoded = w.top();
             w.consume(32);
             if (ones == 5) {
+                w.refill();
                 encoded = (encoded << 32) | w.top();
                 w.consume(32);
                 last_delta += encoded;
@@ -165,15 +204,20 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
         timestamp = (int64_t)((uint64_t)timestamp + last_delta);
         if (count == COUNT_MASK) {
             *error |= ERR_TOO_LONG;
-            return count;
+            return cursor(w.position);
         }
         emit(count++, timestamp);
-        if (count >= limit) return count;
+        if (count >= limit) return cursor(w.position);
     }
     // The last few codes, where running out of bits has a meaning, with the careful reader.
     BitReaderDev r;
     r.seek(bytes, nbytes, w.position);
     while (!r.exhausted()) {
+        if (r.used_bits >= stop_bit) return cursor(r.used_bits);
+        if ((uint32_t)(r.used_bits / TS_PIECE_BITS) != piece) {
+            piece = (uint32_t)(r.used_bits / TS_PIECE_BITS);
+            cross(cursor(r.used_bits));
+        }
         uint32_t ones = 0;
         while (ones < 5 && !r.exhausted() && r.get(1)) ones++;
         if (ones != 0 && r.remaining() < 7) break;
@@ -181,7 +225,7 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
             const uint32_t width = ones == 1 ? 7u : ones == 2 ? 9u : ones == 3 ? 12u : ones == 4 ? 32u : 64u;
             if (r.remaining() < width) {
                 *error |= ERR_TIMESTAMPS;
-                return count;
+                return cursor(r.used_bits);
             }
             uint64_t encoded = r.get64(width);
             uint64_t dod = encoded;
@@ -191,13 +235,102 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
         timestamp = (int64_t)((uint64_t)timestamp + last_delta);
         if (count == COUNT_MASK) {
             *error |= ERR_TOO_LONG;
-            return count;
+            return cursor(r.used_bits);
         }
         emit(count++, timestamp);
-        if (count >= limit) return count;
+        if (count >= limit) return cursor(r.used_bits);
     }
     emit(count++, end_time);
-    return count;
+    *finished = true;
+    return cursor(nbytes * 8ull);
+}
+
+// The cursor in front of the first code of a stream: point 0 is start_time, bit 0 the flag.
+__device__ __forceinline__ TsCursor ts_stream_start(int64_t start_time, const uint8_t *stream = nullptr) {
+    return TsCursor{1u, 1u, start_time, 0ull, stream};
+}
+
+// One code of at most 16 bits off the top of `top` (the next 32 bits of the stream): `0`, `10` + 7,
+// `110` + 9 or `1110` + 12 bits, two's complement of `width` bits except that 2^(width-1) itself is
+// positive (timestamps.rs:139-155). Returns the length of the code; `ones` = 4 or 5 (a 32- or 64-bit
+// payload) is the caller's. No branch: lanes that stand at different kinds of code stay together.
+__device__ __forceinline__ uint32_t ts_short_code(uint32_t top, uint32_t ones, int32_t *delta_of_delta) {
+    const uint32_t width = (0x0c090700u >> (8u * ones)) & 0xffu; // 0, 7, 9, 12
+    const uint32_t length = ones + 1u + width;
+    const uint32_t encoded = __builtin_amdgcn_ubfe(top, 32u - length, width);
+    const uint32_t half = (1u << width) >> 1;
+    *delta_of_delta = encoded > half ? (int32_t)(encoded - (half << 1)) : (int32_t)encoded;
+    return length;
+}
+
+// Calls emit(index, timestamp) for every timestamp; returns the count. `limit` stops early.
+template <typename Emit>
+__device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *bytes, uint32_t nbytes,
+                                                              int64_t start_time, int64_t end_time,
+                                                              uint32_t limit, uint32_t *error,
+                                                              Emit emit) {
+    emit(0u, start_time);
+    if (limit <= 1) return 1;
+    bool finished;
+    return decode_irregular_span(bytes, nbytes, end_time, limit, error, ts_stream_start(start_time), 0xffffffffu,
+                                 &finished, emit, [](const TsCursor &) {})
+        .count;
+}
+
+// The checkpoints of a batch (or none: piece_base == nullptr). Segment i owns the slots
+// [piece_base[i], piece_base[i + 1]): ts_pieces(length of its stream) of them if the stream has
+// checkpoints (irregular, out of line), none otherwise.
+struct TsCheckpoints {
+    const unsigned long long *piece_base;
+    TsCursor *slots;
+    uint2 *piece_segment; // slot -> {segment, bytes of its stream}
+};
+
+// How many of a stream's pieces have a code starting in them: all, or all but the last.
+__device__ __forceinline__ uint32_t ts_valid_pieces(const TsCursor *slots, uint32_t n_pieces) {
+    while (n_pieces > 1 && slots[n_pieces - 1].count == TS_NO_CODE) n_pieces -= 1;
+    return n_pieces;
+}
+
+// Timestamp of point `index` (>= 1) of a stream with checkpoints: one piece is decoded.
+__device__ __forceinline__ int64_t ts_point_at(const TsCursor *slots, uint32_t n_pieces, const uint8_t *bytes,
+                                               uint32_t nbytes, int64_t end_time, uint32_t index, uint32_t *error) {
+    n_pieces = ts_valid_pieces(slots, n_pieces);
+    uint32_t lo = 0, hi = n_pieces; // the last piece whose first code produces a point <= index
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (slots[mid].count <= index) lo = mid;
+        else hi = mid;
+    }
+    int64_t found = slots[lo].timestamp;
+    bool finished;
+    decode_irregular_span(bytes, nbytes, end_time, index + 1, error, slots[lo], 0xffffffffu, &finished,
+                          [&](uint32_t, int64_t t) { found = t; }, [](const TsCursor &) {});
+    return found;
+}
+
+// Index of the first point with timestamp >= bound (or > bound if `beyond`), n_total if there is none;
+// timestamps ascend (the compressor requires it). Point 0 is start_time. One piece is decoded.
+__device__ __forceinline__ uint32_t ts_first_index(const TsCursor *slots, uint32_t n_pieces, const uint8_t *bytes,
+                                                   uint32_t nbytes, int64_t start_time, int64_t end_time,
+                                                   uint32_t n_total, int64_t bound, bool beyond, uint32_t *error) {
+    auto reached = [&](int64_t t) { return beyond ? t > bound : t >= bound; };
+    if (reached(start_time)) return 0;
+    n_pieces = ts_valid_pieces(slots, n_pieces);
+    uint32_t lo = 0, hi = n_pieces; // the last piece that begins behind a point not yet at the bound
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (!reached(slots[mid].timestamp)) lo = mid;
+        else hi = mid;
+    }
+    uint32_t found = n_total;
+    bool finished;
+    decode_irregular_span(bytes, nbytes, end_time, 0xffffffffu, error, slots[lo], (lo + 1) * TS_PIECE_BITS, &finished,
+                          [&](uint32_t k, int64_t t) {
+                              if (found == n_total && reached(t)) found = k;
+                          },
+                          [](const TsCursor &) {});
+    return found;
 }
 
 // ---- prepass -----------------------------------------------------------------------------------
@@ -252,8 +385,11 @@ struct SegInfo {
 // `known_totals` (may be nullptr): per segment, the number of points of a segment with irregular
 // timestamps as an earlier analyse_segment of the same batch counted it - counting means parsing
 // the whole delta-of-delta stream, which the prepass has already done once.
+// `checkpoints` (may be nullptr): the batch's timestamp checkpoints, made by k_grid_ts_count (which has
+// also left the streams' lengths in known_totals).
 __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i,
-                                                   const uint32_t *known_totals = nullptr) {
+                                                   const uint32_t *known_totals = nullptr,
+                                                   const TsCheckpoints *checkpoints = nullptr) {
     SegInfo info;
     info.error = 0;
     info.swing_first = 0.0f;
@@ -280,6 +416,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
     uint32_t n_total = 0;
     bool regular = true;
     const uint8_t *ts_bytes = nullptr;
+    TsCursor *slots = nullptr; // the stream's checkpoints, if it has any
+    uint32_t n_slots = 0;
     info.regular_length = 0;
     if (ts_len < 0) {
         info.error |= ERR_TIMESTAMPS;
@@ -321,11 +459,17 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
     } else if (ts_len > 0) {
         regular = false;
         ts_bytes = view_data(s.timestamps, i, vt);
-        if (known_totals)
+        if (checkpoints && checkpoints->piece_base && ts_has_checkpoints(ts_len)) {
+            flags |= FLAG_CHECKPOINTS;
+            slots = checkpoints->slots + checkpoints->piece_base[i];
+            n_slots = ts_pieces((uint32_t)ts_len);
+        }
+        if (known_totals) {
             n_total = known_totals[i];
-        else
+        } else {
             n_total = decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, 0xffffffffu,
                                                   &info.error, [](uint32_t, int64_t) {});
+        }
     }
     if (regular) flags |= FLAG_REGULAR;
 
@@ -361,6 +505,9 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
                 model_end = start + (int64_t)((uint64_t)(n_model - 1) * (uint64_t)d.delta);
             } else if (n_res == 0) {
                 model_end = end; // the last timestamp is not stored in the stream: it is end_time
+            } else if (slots) {
+                model_end = n_model == 1 ? start
+                                         : ts_point_at(slots, n_slots, ts_bytes, (uint32_t)ts_len, end, n_model - 1, &info.error);
             } else {
                 decode_irregular_timestamps(ts_bytes, (uint32_t)ts_len, start, end, n_model,
                                             &info.error,
@@ -377,7 +524,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
     } else if (type == MDB_MACAQUE_V_ID) {
         if ((int32_t)vv.x <= 0 || n_model == 0) info.error |= ERR_VALUES;
     }
-    if (!regular || type == MDB_MACAQUE_V_ID || n_res > 0) flags |= FLAG_SERIAL;
+    // (irregular timestamps with checkpoints are k_grid_timestamps' work, not the serial kernel's)
+    if ((!regular && !(flags & FLAG_CHECKPOINTS)) || type == MDB_MACAQUE_V_ID || n_res > 0) flags |= FLAG_SERIAL;
     d.flags = flags;
     d.first = 0;
     d.n_visible = n_total;
@@ -390,7 +538,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
 // found for a segment with irregular timestamps (it has to decode them all to find out).
 __device__ __forceinline__ void apply_time_range(const DevSegments &s, uint64_t i, SegInfo &info,
                                                  const TimeRange &range, const uint32_t *known_first = nullptr,
-                                                 const uint32_t *known_visible = nullptr) {
+                                                 const uint32_t *known_visible = nullptr,
+                                                 const TsCheckpoints *checkpoints = nullptr) {
     SegDesc &d = info.desc;
     if (info.error) return;
     uint32_t k_lo = 0, k_hi = 0;
@@ -402,6 +551,19 @@ __device__ __forceinline__ void apply_time_range(const DevSegments &s, uint64_t 
         any = visible > 0;
         k_lo = known_first[i];
         k_hi = k_lo + visible - 1;
+    } else if ((d.flags & FLAG_CHECKPOINTS) && checkpoints && checkpoints->piece_base) {
+        // Timestamps are sorted (the compressor requires it): the first point at or behind lo and the
+        // first one behind hi, each found in one piece of the stream.
+        const uint4 vt = s.timestamps.views[i];
+        const uint8_t *bytes = view_data(s.timestamps, i, vt);
+        const TsCursor *slots = checkpoints->slots + checkpoints->piece_base[i];
+        const uint32_t n_slots = ts_pieces(vt.x);
+        const int64_t end = s.end_time[i];
+        k_lo = ts_first_index(slots, n_slots, bytes, vt.x, d.start, end, d.n_total, range.lo, false, &info.error);
+        const uint32_t behind = ts_first_index(slots, n_slots, bytes, vt.x, d.start, end, d.n_total, range.hi, true,
+                                               &info.error);
+        any = k_lo < behind;
+        k_hi = any ? behind - 1 : 0;
     } else {
         // Timestamps are sorted (the compressor requires it), so the in-range ones are an interval.
         any = false;
@@ -419,8 +581,8 @@ __device__ __forceinline__ void apply_time_range(const DevSegments &s, uint64_t 
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     const bool model_visible = any && d.first < d.n_model;
     const bool residuals_visible = any && d.first + d.n_visible > d.n_model;
-    const bool serial = any && (!(d.flags & FLAG_REGULAR) || (type == MDB_MACAQUE_V_ID && model_visible) ||
-                                residuals_visible);
+    const bool serial = any && (!(d.flags & (FLAG_REGULAR | FLAG_CHECKPOINTS)) ||
+                                (type == MDB_MACAQUE_V_ID && model_visible) || residuals_visible);
     d.flags = (d.flags & ~FLAG_SERIAL) | (serial ? FLAG_SERIAL : 0u);
 }
 

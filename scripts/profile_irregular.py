@@ -21,8 +21,11 @@ def main():
     one = np.cumsum(rng.integers(900, 1100, points).astype(np.int64))
     # What irregular usually means in practice: a fixed sampling rate with a sample missing now and then.
     gaps = np.cumsum(np.where(rng.random(points) < 0.01, 2000, 1000).astype(np.int64))
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     for label, ts in (("regular", np.tile(np.arange(points, dtype=np.int64) * 1000, series)), ("irregular", np.tile(one, series)),
                       ("1 % gaps", np.tile(gaps, series))):
+        if only and only != label.split()[0]:
+            continue
         ts_dev = ctx.upload_array(ts)
         ctx.compress_chunks_dev(ts_dev, values, off_dev, len(offsets) - 1, eb, 0, 0, 0).free()
         ctx.sync(); t0 = time.perf_counter()

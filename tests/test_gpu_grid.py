@@ -13,13 +13,19 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[None, "1024", "8"], ids=["mv-default", "mv-from-1024-values", "mv-from-8-values"])
+@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane"],
+                ids=["mv-default", "mv-from-1024-values", "mv-from-8-values", "timestamps-one-lane-per-segment"])
 def macaque_decoder(request, monkeypatch):
     """Every grid test runs with the parallel MacaqueV decoder (mdb_macaque_parallel.hpp) at its
     default threshold, switched off (one lane per stream only) and forced onto every stream of at
-    least 8 values."""
+    least 8 values; and with irregular timestamps decoded one lane per 256-bit piece of a stream
+    (k_grid_timestamps, the default) and one lane per segment (k_grid_serial)."""
+    monkeypatch.delenv("MDB_GRID_TS_PIECES", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+    elif request.param == "ts-one-lane":
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+        monkeypatch.setenv("MDB_GRID_TS_PIECES", "off")
     else:
         monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
     return request.param
