@@ -66,7 +66,8 @@ int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t
 int mdb_dev_sync(mdb_ctx *ctx);
 /* Copy a host batch of segments (Arrow buffers) to the device; the result has on_device = 1. */
 int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_owned **dev);
-/* Copy a device batch back; the result has on_device = 0 and one data buffer per column. */
+/* Copy a device batch back; the result has on_device = 0 and one data buffer per column (several if the
+ * column's payloads exceed 2 GiB). */
 int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **host);
 void mdb_segments_free(mdb_segments_owned *segments);
 /* mdb_segments_upload checks every out-of-line view of a HOST batch against the column's data buffers
@@ -169,9 +170,10 @@ int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, ui
 /* Compress many independent series chunks in one launch: chunk c is
  * [chunk_offsets[c], chunk_offsets[c + 1]) of ts/values. Segments come out grouped by chunk in
  * chunk order, each chunk's segments in time order; out->chunk_index names the chunk.
- * Each BinaryView column of the result has ONE data buffer, which Arrow limits to 2 GiB: a call whose
- * timestamps, values or residuals payloads add up to more fails and asks for fewer chunks per call
- * (irregular timestamps: about 10^9 points; regular ones: no practical limit, 3 bytes per segment). */
+ * A BinaryView column whose payloads (irregular timestamps, MacaqueV values, residuals) add up to more
+ * than 1 GiB comes back with several data buffers, as arrow's builders produce them (types.rs:444-516):
+ * the views carry the buffer index, mdb_grid_* / mdb_agg_* read such columns, and mdb_segments_download
+ * keeps the buffers apart when they do not fit into one. */
 int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
                         const uint64_t *chunk_offsets, uint64_t n_chunks,
                         mdb_error_bound error_bound, mdb_segments_owned **out);

@@ -73,6 +73,7 @@ enum ScratchSlot {
     SCRATCH_COMM,
     SCRATCH_TS_BASE,
     SCRATCH_TS_SLOTS,
+    SCRATCH_FIT_BASES,
     SCRATCH_SLOT_COUNT
 };
 
@@ -141,8 +142,9 @@ struct OwnedSegments {
     int device = -1;                   // -1: host memory
     std::vector<void *> device_allocs; // hipFree'd on release
     std::vector<std::vector<uint8_t>> host_allocs;
-    const uint8_t *buffer_ptrs[3] = {nullptr, nullptr, nullptr}; // host view of per-column data ptr
-    int64_t buffer_sizes[3] = {0, 0, 0};
+    // host batches: per column, the data buffers (pointers into host_allocs) and their sizes
+    std::vector<const uint8_t *> buffer_ptrs[3];
+    std::vector<int64_t> buffer_sizes[3];
 };
 
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }

@@ -1,5 +1,8 @@
 // mdb_ctx.hip - context lifetime, device memory, segment upload/download and launch profiling of
 // libmdb_hip.so (see include/mdb.h for the contract of every entry point).
+#include <algorithm>
+#include <cstdlib>
+
 #include "mdb_common.hpp"
 
 namespace mdb {
@@ -462,7 +465,10 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
             rc = fail("hipMemcpy of the buffer table failed.");
     }
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
-    // Concatenate the variadic buffers of each column into one host buffer and rebase the views.
+    // The data buffers of each column: one host buffer with the views rebased onto it while everything
+    // fits below 2 GiB (what most consumers prefer), else buffer by buffer as they are on the device.
+    // host_allocs[8 + c] is the single buffer, or the first of several; further ones go to the end.
+    std::vector<size_t> buffer_slots[3];
     for (int c = 0; c < 3 && !rc; c++) {
         uint64_t total = 0;
         std::vector<uint64_t> base((size_t)cols[c]->n_buffers);
@@ -470,19 +476,35 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
             base[b] = total;
             total += (uint64_t)cols[c]->buffer_sizes[b];
         }
-        if (total > 0x7fffffffull) {
-            rc = fail("A downloaded column exceeds 2 GiB of payload.");
-            break;
+        // (MDB_SEGMENTS_MERGE_LIMIT: tests of the several-buffers path without 2 GiB of payloads)
+        uint64_t merge_limit = 0x7fffffffull;
+        if (const char *text = std::getenv("MDB_SEGMENTS_MERGE_LIMIT"))
+            merge_limit = std::min<uint64_t>(merge_limit, (uint64_t)std::max(0ll, std::atoll(text)));
+        const bool merged = total <= merge_limit;
+        if (merged) {
+            owned->host_allocs[8 + c].resize(total);
+            buffer_slots[c].push_back(8 + (size_t)c);
         }
-        owned->host_allocs[8 + c].resize(total);
         for (int b = 0; b < cols[c]->n_buffers && !rc; b++) {
-            uint64_t bytes = (uint64_t)cols[c]->buffer_sizes[b];
-            if (bytes && hipMemcpyAsync(owned->host_allocs[8 + c].data() + base[b],
-                                        reinterpret_cast<const void *>(tables[c][b]), bytes,
-                                        hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            const uint64_t bytes = (uint64_t)cols[c]->buffer_sizes[b];
+            uint8_t *to;
+            if (merged) {
+                to = owned->host_allocs[8 + c].data() + base[b];
+            } else {
+                size_t slot = 8 + (size_t)c;
+                if (b > 0) {
+                    owned->host_allocs.emplace_back();
+                    slot = owned->host_allocs.size() - 1;
+                }
+                owned->host_allocs[slot].resize(bytes);
+                buffer_slots[c].push_back(slot);
+                to = owned->host_allocs[slot].data();
+            }
+            if (bytes && hipMemcpyAsync(to, reinterpret_cast<const void *>(tables[c][b]), bytes, hipMemcpyDeviceToHost,
+                                        ctx->stream) != hipSuccess)
                 rc = fail("hipMemcpy of a data buffer failed.");
         }
-        if (!rc && cols[c]->n_buffers > 1) {
+        if (!rc) {
             mdb_view16 *views = reinterpret_cast<mdb_view16 *>(owned->host_allocs[5 + c].data());
             for (uint64_t i = 0; i < n; i++) {
                 if (views[i].length > 12) {
@@ -491,9 +513,11 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
                         rc = fail("Malformed BinaryView: buffer index out of range.");
                         break;
                     }
-                    // (total <= 2 GiB was checked above, so the rebased offset fits)
-                    views[i].u.ref.offset = (int32_t)((int64_t)views[i].u.ref.offset + (int64_t)base[(size_t)buffer]);
-                    views[i].u.ref.buffer_index = 0;
+                    if (merged && cols[c]->n_buffers > 1) {
+                        // (total <= 2 GiB here, so the rebased offset fits)
+                        views[i].u.ref.offset = (int32_t)((int64_t)views[i].u.ref.offset + (int64_t)base[(size_t)buffer]);
+                        views[i].u.ref.buffer_index = 0;
+                    }
                 }
             }
         }
@@ -514,12 +538,14 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
     s.max_value = reinterpret_cast<const float *>(owned->host_allocs[4].data());
     mdb_binview_col *out_cols[3] = {&s.timestamps, &s.values, &s.residuals};
     for (int c = 0; c < 3; c++) {
-        owned->buffer_ptrs[c] = owned->host_allocs[8 + c].data();
-        owned->buffer_sizes[c] = (int64_t)owned->host_allocs[8 + c].size();
+        for (size_t slot : buffer_slots[c]) { // (host_allocs no longer grows: the pointers stay)
+            owned->buffer_ptrs[c].push_back(owned->host_allocs[slot].data());
+            owned->buffer_sizes[c].push_back((int64_t)owned->host_allocs[slot].size());
+        }
         out_cols[c]->views = reinterpret_cast<const mdb_view16 *>(owned->host_allocs[5 + c].data());
-        out_cols[c]->buffers = &owned->buffer_ptrs[c];
-        out_cols[c]->buffer_sizes = &owned->buffer_sizes[c];
-        out_cols[c]->n_buffers = 1;
+        out_cols[c]->buffers = owned->buffer_ptrs[c].data();
+        out_cols[c]->buffer_sizes = owned->buffer_sizes[c].data();
+        out_cols[c]->n_buffers = (int32_t)owned->buffer_ptrs[c].size();
     }
     owned->c.error = dev->error ? reinterpret_cast<const float *>(owned->host_allocs[11].data()) : nullptr;
     owned->c.chunk_index =

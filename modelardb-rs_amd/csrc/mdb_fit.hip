@@ -1538,9 +1538,45 @@ struct EncodeTargets {
     float *error;
     uint32_t *chunk_index;
     uint4 *views[3];
-    uint8_t *data[3];
+    uint8_t *data[3]; // the column's payloads, one after the other
     const unsigned long long *data_offsets[3];
+    // The payloads of a column are ONE run of device memory presented as several Arrow data buffers (a
+    // view addresses at most 2 GiB of one buffer): buffer k begins at the payload that begins at or
+    // behind k x MDB_FIT_DATA_BUFFER_BYTES, data_bases[c][k] is where.
+    const unsigned long long *data_bases[3];
+    uint32_t n_data_buffers[3];
 };
+
+// Which data buffer the payload at `offset` of a column lies in, and where inside it (the view's
+// buffer_index and offset, types.rs:444-516 leaves the same to arrow's BinaryViewBuilder).
+__device__ __forceinline__ void data_buffer_of(const unsigned long long *bases, uint32_t n_buffers, uint64_t offset,
+                                               uint32_t *buffer, uint32_t *offset_in_buffer) {
+    uint32_t lo = 0, hi = n_buffers; // the last buffer that begins at or in front of the payload
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (bases[mid] <= offset) lo = mid;
+        else hi = mid;
+    }
+    *buffer = lo;
+    *offset_in_buffer = (uint32_t)(offset - bases[lo]);
+}
+
+// data_bases of one column: buffer k begins at the first payload at or behind k x buffer_bytes.
+// data_offsets is the exclusive scan of the out-of-line payload sizes over the segments (n + 1 entries).
+__global__ __launch_bounds__(64) void k_fit_data_bases(const unsigned long long *__restrict__ data_offsets,
+                                                       uint64_t n_segments, uint64_t buffer_bytes, uint32_t n_buffers,
+                                                       unsigned long long *__restrict__ bases) {
+    for (uint32_t k = threadIdx.x; k < n_buffers; k += blockDim.x) {
+        const uint64_t wanted = (uint64_t)k * buffer_bytes;
+        uint64_t lo = 0, hi = n_segments; // the first segment whose payload begins at or behind `wanted`
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (data_offsets[mid] >= wanted) hi = mid;
+            else lo = mid + 1;
+        }
+        bases[k] = data_offsets[lo];
+    }
+}
 
 struct TsResult { // of k_fit_timestamps<false>, indexed by segment
     uint32_t bytes; // length of compress_residual_timestamps(); 0xffffffff: the one-lane path does it
@@ -1578,14 +1614,13 @@ __device__ __forceinline__ void process_segment(const FitArgs &args, const unsig
     };
     auto finish_view = [&](int column, uint32_t bytes) {
         if (!WRITE || bytes <= 12) return;
-        // Out-of-line view: length, 4-byte prefix, buffer index 0, offset (Arrow BinaryView).
+        // Out-of-line view: length, 4-byte prefix, buffer index, offset in that buffer (Arrow BinaryView).
         const uint64_t offset = targets->data_offsets[column][segment];
         const uint8_t *p = targets->data[column] + offset;
         uint4 view;
         view.x = bytes;
         view.y = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-        view.z = 0;
-        view.w = (uint32_t)offset;
+        data_buffer_of(targets->data_bases[column], targets->n_data_buffers[column], offset, &view.z, &view.w);
         targets->views[column][segment] = view;
     };
     if (WRITE) {
@@ -2106,6 +2141,17 @@ static bool fit_fast_setting() {
     return !(text && std::strcmp(text, "0") == 0);
 }
 
+// From how many bytes of payloads on a BinaryView column begins another data buffer (at most 1 GiB, so
+// that a buffer with the payload that ends it stays below the 2 GiB a view can address).
+constexpr uint64_t MAX_DATA_BUFFERS = 4096;
+static uint64_t data_buffer_bytes_setting() {
+    if (const char *text = std::getenv("MDB_FIT_DATA_BUFFER_BYTES")) {
+        const long long value = std::atoll(text);
+        if (value >= 16) return (uint64_t)std::min<long long>(value, 1ll << 30);
+    }
+    return 1ull << 30;
+}
+
 // MDB_FIT_LEAN=0: k_fit_models (its fast form) even where k_fit_models_lean applies.
 static bool fit_lean_setting() {
     const char *text = std::getenv("MDB_FIT_LEAN");
@@ -2396,11 +2442,39 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                                      hipMemcpyDeviceToHost, ctx->stream));
             FIT_CHECK(hipStreamSynchronize(ctx->stream)); // seg_block_sums is reused by the next scan
         }
-        for (int c = 0; c < 3; c++)
-            if (data_bytes[c] > 0x7fffffffull) {
+        // A column's payloads become several data buffers when they add up to more than one buffer may
+        // hold (arrow's builders roll over the same way, types.rs:444-516). MDB_FIT_DATA_BUFFER_BYTES: the
+        // size from which a new buffer is begun (tests force it down); a buffer ends with the payload that
+        // begins in it, so it stays below 2 GiB as long as no single payload is larger than the rest.
+        const uint64_t buffer_bytes = data_buffer_bytes_setting();
+        uint32_t n_data_buffers[3];
+        std::vector<unsigned long long> data_bases[3];
+        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_BASES, 3 * 8 * (uint64_t)MAX_DATA_BUFFERS + 64, &p));
+        unsigned long long *bases_dev = static_cast<unsigned long long *>(p);
+        for (int c = 0; c < 3; c++) {
+            const uint64_t wanted = data_bytes[c] <= buffer_bytes ? 1 : (data_bytes[c] + buffer_bytes - 1) / buffer_bytes;
+            if (wanted > MAX_DATA_BUFFERS) {
                 release();
-                return fail("A BinaryView data buffer would exceed 2 GiB; compress fewer chunks per call.");
+                return fail("Too many BinaryView data buffers for one batch; compress fewer chunks per call.");
             }
+            n_data_buffers[c] = (uint32_t)wanted;
+            data_bases[c].assign(wanted + 1, 0);
+            if (wanted > 1) {
+                hipLaunchKernelGGL(k_fit_data_bases, dim3(1), dim3(64), 0, ctx->stream, data_offsets[c],
+                                   (uint64_t)n_segments, buffer_bytes, n_data_buffers[c], bases_dev + c * MAX_DATA_BUFFERS);
+                FIT_CHECK(hipMemcpyAsync(data_bases[c].data(), bases_dev + c * MAX_DATA_BUFFERS, 8 * wanted,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            } else {
+                FIT_CHECK(hipMemsetAsync(bases_dev + c * MAX_DATA_BUFFERS, 0, 8, ctx->stream));
+            }
+            data_bases[c][wanted] = data_bytes[c];
+            for (uint64_t k = 0; k < wanted; k++)
+                if (data_bases[c][k + 1] - data_bases[c][k] > 0x7fffffffull) {
+                    release();
+                    return fail("A BinaryView data buffer would exceed 2 GiB: one payload is too large.");
+                }
+        }
 
         // One device blob for the output batch.
         const uint64_t n = n_segments;
@@ -2416,7 +2490,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         uint64_t off_views[3], off_data[3], off_table[3];
         for (int c = 0; c < 3; c++) off_views[c] = carve(16 * n);
         for (int c = 0; c < 3; c++) off_data[c] = carve(data_bytes[c]);
-        for (int c = 0; c < 3; c++) off_table[c] = carve(16);
+        for (int c = 0; c < 3; c++) off_table[c] = carve(8 * (uint64_t)(n_data_buffers[c] + 1));
         void *blob = nullptr;
         FIT_CHECK(hipMalloc(&blob, cursor ? cursor : 256));
         owned->device_allocs.push_back(blob);
@@ -2430,15 +2504,20 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         targets.max_value = reinterpret_cast<float *>(dev + off_max);
         targets.error = reinterpret_cast<float *>(dev + off_error);
         targets.chunk_index = reinterpret_cast<uint32_t *>(dev + off_chunk);
-        uint64_t tables[3][2];
+        std::vector<uint64_t> tables[3];
         for (int c = 0; c < 3; c++) {
             targets.views[c] = reinterpret_cast<uint4 *>(dev + off_views[c]);
             targets.data[c] = dev + off_data[c];
             targets.data_offsets[c] = data_offsets[c];
-            tables[c][0] = reinterpret_cast<uint64_t>(dev + off_data[c]);
-            tables[c][1] = 0;
-            FIT_CHECK(hipMemcpyAsync(dev + off_table[c], tables[c], 16, hipMemcpyHostToDevice, ctx->stream));
+            targets.data_bases[c] = bases_dev + c * MAX_DATA_BUFFERS;
+            targets.n_data_buffers[c] = n_data_buffers[c];
+            tables[c].assign(n_data_buffers[c] + 1, 0);
+            for (uint32_t k = 0; k < n_data_buffers[c]; k++)
+                tables[c][k] = reinterpret_cast<uint64_t>(dev + off_data[c] + data_bases[c][k]);
+            FIT_CHECK(hipMemcpyAsync(dev + off_table[c], tables[c].data(), 8 * tables[c].size(), hipMemcpyHostToDevice,
+                                     ctx->stream));
         }
+        FIT_CHECK(hipStreamSynchronize(ctx->stream)); // (`tables` is pageable memory of this frame)
         if (gap_waves > 0) { // before k_fit_encode, which reads the first payload bytes for the views
             LaunchTimer timer(ctx, "k_fit_gap_encode");
             hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
@@ -2466,13 +2545,14 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         s.max_value = targets.max_value;
         mdb_binview_col *cols[3] = {&s.timestamps, &s.values, &s.residuals};
         for (int c = 0; c < 3; c++) {
-            owned->host_allocs[c].resize(16);
-            int64_t *size_slot = reinterpret_cast<int64_t *>(owned->host_allocs[c].data());
-            size_slot[0] = (int64_t)data_bytes[c];
+            owned->host_allocs[c].resize(8 * (size_t)n_data_buffers[c]);
+            int64_t *size_slots = reinterpret_cast<int64_t *>(owned->host_allocs[c].data());
+            for (uint32_t k = 0; k < n_data_buffers[c]; k++)
+                size_slots[k] = (int64_t)(data_bases[c][k + 1] - data_bases[c][k]);
             cols[c]->views = reinterpret_cast<const mdb_view16 *>(targets.views[c]);
             cols[c]->buffers = reinterpret_cast<const uint8_t *const *>(dev + off_table[c]);
-            cols[c]->buffer_sizes = size_slot;
-            cols[c]->n_buffers = 1;
+            cols[c]->buffer_sizes = size_slots;
+            cols[c]->n_buffers = (int32_t)n_data_buffers[c];
         }
         owned->c.error = targets.error;
         owned->c.chunk_index = targets.chunk_index;

@@ -246,6 +246,57 @@ def test_split_and_compress_univariate_time_series(hip):
         hip.try_split_and_compress_univariate_time_series([1, 2, 3], [[1.0, 2.0]], [cases.LOSSLESS])
 
 
+def test_payload_columns_roll_over_into_several_data_buffers(hip, monkeypatch):
+    """A BinaryView column whose payloads exceed what one data buffer may hold (2 GiB for arrow; the
+    library begins a new buffer every GiB) comes back with several buffers, as arrow's builders make
+    them (types.rs:444-516). Forced here with a buffer size of a few hundred bytes: same rows as the
+    oracle's, several buffers per column, on the device and after the download, and grid() reads them."""
+    rng = np.random.default_rng(17)
+    n_chunks, n_points = 6, 4000
+    timestamps = np.concatenate([np.cumsum(rng.integers(100, 900, n_points)).astype(np.int64) for _ in range(n_chunks)])
+    values = rng.uniform(-1e6, 1e6, n_chunks * n_points).astype(np.float32)
+    values[: n_points] = np.repeat(rng.uniform(1, 2, n_points // 400), 400)[:n_points]  # models with residual tails
+    offsets = np.arange(0, n_chunks * n_points + 1, n_points, dtype=np.uint64)
+    for eb in (cases.LOSSLESS, cases.error_bounds()["rel1"]):
+        expected = ora.compress_chunks(timestamps, values, offsets, eb)
+        for buffer_bytes in ("300", "5000", None):
+            if buffer_bytes is None:
+                monkeypatch.delenv("MDB_FIT_DATA_BUFFER_BYTES", raising=False)
+            else:
+                monkeypatch.setenv("MDB_FIT_DATA_BUFFER_BYTES", buffer_bytes)
+            ts_dev, values_dev, offsets_dev = (hip.upload_array(a) for a in (timestamps, values, offsets))
+            dev = hip.compress_chunks_dev(ts_dev, values_dev, offsets_dev, n_chunks, eb)
+            if buffer_bytes is not None:
+                assert dev.seg.timestamps.n_buffers > 3 and dev.seg.values.n_buffers > 3
+                limit = int(buffer_bytes)
+                longest = max(len(p) for p in expected.timestamps.to_bytes_list())
+                assert all(dev.seg.timestamps.buffer_sizes[k] <= limit + longest for k in range(dev.seg.timestamps.n_buffers))
+            else:
+                assert dev.seg.timestamps.n_buffers == 1
+            hip.validate_segments_dev(dev)
+            got = dev.download()
+            assert_same_segments(got, expected)
+            assert len(got.timestamps.buffers) == 1  # merged on the way down while it all fits into one
+            if buffer_bytes is not None:
+                monkeypatch.setenv("MDB_SEGMENTS_MERGE_LIMIT", "1000")  # as if it did not
+                apart = dev.download()
+                monkeypatch.delenv("MDB_SEGMENTS_MERGE_LIMIT")
+                assert len(apart.timestamps.buffers) == dev.seg.timestamps.n_buffers > 3
+                assert_same_segments(apart, expected)
+                cases.assert_grid_equal(hip.grid_batch(apart), ora.grid_batch(expected))
+            total = hip.grid_count_dev(dev)
+            out_ts, out_val = hip.dev_alloc(8 * total), hip.dev_alloc(4 * total)
+            hip.grid_batch_dev(dev, out_ts, out_val, total)
+            assert np.array_equal(hip.download_array(out_ts, total, np.int64), timestamps)
+            oracle_values = ora.grid_batch(expected)[1]
+            assert np.array_equal(hip.download_array(out_val, total, np.float32).view(np.uint32), oracle_values.view(np.uint32))
+            for pointer in (ts_dev, values_dev, offsets_dev, out_ts, out_val):
+                hip.dev_free(pointer)
+            dev.free()
+            # and through the host entry point (upload, fit, download in one call)
+            assert_same_segments(hip.compress_chunks(timestamps, values, offsets, eb), expected)
+
+
 def test_fit_pmc_chosen_while_swing_ran_far_ahead(hip):
     # PMC-Mean wins ties (types.rs:84-101) even when Swing accepted up to ~3 % more points, so the
     # next model starts well behind the last point that was fed. Long near-constant runs with a
