@@ -123,6 +123,7 @@ _HIP_SYMBOLS = {
     # name: (restype, argtypes)
     "mdb_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mdb_close": (C.c_int, [C.c_void_p]),
+    "mdb_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mdb_last_error": (C.c_char_p, []),
     "mdb_version": (C.c_char_p, []),
     "mdb_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

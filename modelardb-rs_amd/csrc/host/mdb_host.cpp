@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -477,27 +478,59 @@ GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<Ti
     if (schema_.size() < 2) throw Error("GridStream should use a static schema.");
     if (values_only_) schema_ = {schema_[1]};
     current_batch_ = RecordBatch::new_empty(schema_);
+    // MDB_HOST_GRID_PREFETCH=0: grid a batch when it is polled for and not before (A/B, tests).
+    const char *setting = std::getenv("MDB_HOST_GRID_PREFETCH");
+    prefetch_ = !(setting && std::string(setting) == "0");
 }
 
-void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch &batch) {
-    const auto started = std::chrono::steady_clock::now();
-    const size_t n_tags = values_only_ ? 0 : batch.columns.size() - query_compressed_schema().size();
-    if (!values_only_ && schema_.size() != 2 + n_tags) throw Error("GridStream should use a static schema.");
-    SegmentsView view;
-    fill_segments_view(batch.columns, &view);
+GridStream::~GridStream() {
+    if (ahead_ && ahead_->result.valid()) {
+        try {
+            mdb_grid_result_free(ahead_->result.get());
+        } catch (...) {
+        }
+    }
+    if (second_ctx_) mdb_close(second_ctx_);
+}
 
+GridStream::InFlight GridStream::start_grid(RecordBatch batch) {
+    InFlight flight;
+    flight.batch = std::make_shared<RecordBatch>(std::move(batch));
+    mdb_ctx *ctx = ctx_;
+    if (prefetch_ && (started_ & 1u)) {
+        if (!second_ctx_) check(mdb_clone(ctx_, &second_ctx_));
+        ctx = second_ctx_;
+    }
+    started_ += 1;
     // One library call replaces the per-row loop of grid_exec.rs:323-356. A timestamp predicate is
     // pushed down so out-of-range points are neither reconstructed nor copied over PCIe (the
     // leftovers were filtered when they were created), which makes the filter step of
     // grid_exec.rs:366-387 a no-op here. The points arrive in page-locked memory owned by the
-    // library with room in front for the leftovers; the columns below alias it.
+    // library with room in front for the leftovers (fewer than batch_size of them); the columns alias it.
     const bool pushdown = maybe_predicate_.has_value();
     const int64_t t_lo = pushdown && maybe_predicate_->lower ? *maybe_predicate_->lower : INT64_MIN;
     const int64_t t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
-    const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
-    mdb_grid_result *raw = nullptr;
     const uint32_t flags = (pushdown ? MDB_GRID_HAS_RANGE : 0u) | (values_only_ ? MDB_GRID_VALUES_ONLY : 0u);
-    check(mdb_grid_batch_owned(ctx_, &view.seg, flags, t_lo, t_hi, static_cast<uint64_t>(leftovers), &raw));
+    const uint64_t reserve_front = batch_size_;
+    std::shared_ptr<RecordBatch> held = flight.batch;
+    auto call = [held, ctx, flags, t_lo, t_hi, reserve_front]() {
+        SegmentsView view;
+        fill_segments_view(held->columns, &view);
+        mdb_grid_result *raw = nullptr;
+        check(mdb_grid_batch_owned(ctx, &view.seg, flags, t_lo, t_hi, reserve_front, &raw));
+        return raw;
+    };
+    flight.result = std::async(prefetch_ ? std::launch::async : std::launch::deferred, call);
+    return flight;
+}
+
+void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) {
+    const auto started = std::chrono::steady_clock::now();
+    const RecordBatch &batch = *flight.batch;
+    const size_t n_tags = values_only_ ? 0 : batch.columns.size() - query_compressed_schema().size();
+    if (!values_only_ && schema_.size() != 2 + n_tags) throw Error("GridStream should use a static schema.");
+    const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
+    mdb_grid_result *raw = flight.result.get(); // (rethrows what the call threw)
     std::shared_ptr<mdb_grid_result> result(raw, [](mdb_grid_result *r) { mdb_grid_result_free(r); });
     const int64_t total = leftovers + static_cast<int64_t>(result->n);
     int64_t *timestamps = values_only_ ? nullptr : result->timestamps - leftovers;
@@ -528,6 +561,7 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
         auto storage = std::make_shared<TagStorage>();
         storage->views.reset(new mdb_view16[std::max<size_t>(static_cast<size_t>(total), 1)]);
         storage->input = batch.columns[query_compressed_schema().size() + t];
+        (void)flight.batch; // (the tag columns keep the input's buffers alive themselves)
         mdb_view16 *views = storage->views.get();
         // buffer 0: long leftover strings, copied so old inputs can be dropped.
         column->owned_buffers.emplace_back();
@@ -605,10 +639,24 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(const RecordBatch
 PollState GridStream::poll_next(RecordBatch *out) {
     // grid_exec.rs:402-429
     if (static_cast<size_t>(current_batch_.num_rows - current_batch_offset_) < batch_size_) {
-        RecordBatch batch;
-        PollState state = input_->poll_next(&batch);
-        if (state == PollState::ReadySome) {
-            grid_and_append_to_leftovers_in_current_batch(batch);
+        std::optional<InFlight> flight = std::move(ahead_);
+        ahead_.reset();
+        PollState state = PollState::ReadySome;
+        if (!flight) {
+            RecordBatch batch;
+            state = input_finished_ ? PollState::ReadyNone : input_->poll_next(&batch);
+            if (state == PollState::ReadySome) flight = start_grid(std::move(batch));
+            if (state == PollState::ReadyNone) input_finished_ = true;
+        }
+        if (flight) {
+            // The batch after this one starts now, so that it is on the GPU while this one comes down.
+            if (prefetch_ && !input_finished_) {
+                RecordBatch next;
+                const PollState next_state = input_->poll_next(&next);
+                if (next_state == PollState::ReadySome) ahead_ = start_grid(std::move(next));
+                if (next_state == PollState::ReadyNone) input_finished_ = true;
+            }
+            grid_and_append_to_leftovers_in_current_batch(std::move(*flight));
         } else if (state == PollState::ReadyNone && current_batch_offset_ < current_batch_.num_rows) {
             // Ignore Ready(None): there are data points left in the current batch.
         } else {
@@ -1207,6 +1255,31 @@ int mdbh_grid_exec_describe(void *handle, char *out, uint64_t cap) {
         }
         std::strncpy(out, text.c_str(), cap - 1);
         out[cap - 1] = 0;
+    });
+}
+
+/* Polls the stream to its end without exporting the batches (the measurement of bench.py's host_path:
+ * the operator itself, not the cost of moving every 8 192-row batch into Python). rows / batches:
+ * what came out; checksum: the sum of the first timestamp (or value bits) of every batch. */
+int mdbh_grid_stream_drain(void *handle, uint64_t *rows, uint64_t *batches, uint64_t *checksum) {
+    return guarded([&] {
+        mdbhost::GridStream &stream = *static_cast<GridHandle *>(handle)->stream;
+        uint64_t n_rows = 0, n_batches = 0, sum = 0;
+        while (true) {
+            mdbhost::RecordBatch batch;
+            const mdbhost::PollState state = stream.poll_next(&batch);
+            if (state != mdbhost::PollState::ReadySome) break;
+            n_rows += static_cast<uint64_t>(batch.num_rows);
+            n_batches += 1;
+            if (batch.num_rows > 0 && !batch.columns.empty()) {
+                uint64_t first = 0;
+                std::memcpy(&first, batch.columns[0]->values, batch.columns[0]->type == mdbhost::Type::Float32 ? 4 : 8);
+                sum += first;
+            }
+        }
+        *rows = n_rows;
+        *batches = n_batches;
+        *checksum = sum;
     });
 }
 

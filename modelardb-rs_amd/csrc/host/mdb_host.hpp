@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <deque>
 #include <functional>
+#include <future>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -208,9 +209,25 @@ class GridStream : public SegmentStream { // grid_exec.rs:213-437
     std::vector<Field> schema() const { return schema_; }
     size_t batch_size() const { return batch_size_; }
 
+    ~GridStream();
+
   private:
-    void grid_and_append_to_leftovers_in_current_batch(const RecordBatch &batch); // :261-391
+    // One batch of segments on its way through the GPU: mdb_grid_batch_owned runs on a thread of its
+    // own and on one of two contexts, so that the copy of one batch's data points to the host overlaps
+    // the upload and the kernels of the next (the reference grids a batch when it is polled for,
+    // grid_exec.rs:402-412; the stream returns the same rows in the same order).
+    struct InFlight {
+        std::shared_ptr<RecordBatch> batch;
+        std::future<mdb_grid_result *> result;
+    };
+    InFlight start_grid(RecordBatch batch);
+    void grid_and_append_to_leftovers_in_current_batch(InFlight flight); // :261-391
     mdb_ctx *ctx_;
+    mdb_ctx *second_ctx_ = nullptr; // created with the first batch that is started ahead
+    unsigned started_ = 0;
+    std::optional<InFlight> ahead_;
+    bool input_finished_ = false;
+    bool prefetch_ = true;
     std::vector<Field> schema_;
     std::optional<TimestampPredicate> maybe_predicate_;
     std::unique_ptr<SegmentStream> input_;

@@ -211,6 +211,11 @@ int mdb_init(int device, mdb_ctx **out) {
     return 0;
 }
 
+int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
+    if (!ctx || !out) return fail("ctx and out must not be NULL.");
+    return mdb_init(ctx->device, out);
+}
+
 int mdb_close(mdb_ctx *ctx) {
     if (!ctx) return 0;
     (void)mdb_comm_close(ctx);

@@ -124,6 +124,13 @@ class GridStream:
                 return batches, state
             batches.append(batch)
 
+    def drain(self):
+        """Poll the stream to its end inside the library (no batch crosses into Python). Returns
+        (rows, batches, checksum of the batches' first timestamps)."""
+        rows, batches, checksum = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().mdbh_grid_stream_drain(self.handle, C.byref(rows), C.byref(batches), C.byref(checksum)))
+        return rows.value, batches.value, checksum.value
+
     def metrics(self):
         out = (C.c_uint64 * 12)()
         _check(lib().mdbh_grid_stream_metrics(self.handle, out))
@@ -147,6 +154,25 @@ class GridStream:
             self.close()
         except Exception:
             pass
+
+
+def measure_grid_stream(context, segments, batch_size, segments_per_batch=8192):
+    """The host operator end to end, for bench.py's host_path: `segments` (a SegmentBatch in host
+    memory) handed to a GridStream `segments_per_batch` rows at a time - what the Parquet scan below a
+    GridExec delivers - and the stream polled to its end in slices of `batch_size` data points. Every
+    byte crosses PCIe: the segment columns up, 12 bytes per data point down into page-locked memory.
+    Returns (data points, seconds, bytes copied down)."""
+    import time
+    arrow = segments.to_arrow()
+    stream = GridStream(context, batch_size=batch_size)
+    for first in range(0, arrow.num_rows, segments_per_batch):
+        stream.push(arrow.slice(first, min(segments_per_batch, arrow.num_rows - first)))
+    stream.finish_input()
+    started = time.perf_counter()
+    rows, _, _ = stream.drain()
+    seconds = time.perf_counter() - started
+    stream.close()
+    return rows, seconds, 12 * rows
 
 
 class SortedJoinStream:

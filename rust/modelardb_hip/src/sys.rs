@@ -131,6 +131,7 @@ unsafe extern "C" {
     // ---- lifetime ----------------------------------------------------------------------------
     pub fn mdb_init(device: c_int, ctx: *mut *mut mdb_ctx) -> c_int;
     pub fn mdb_close(ctx: *mut mdb_ctx) -> c_int;
+    pub fn mdb_clone(ctx: *mut mdb_ctx, out: *mut *mut mdb_ctx) -> c_int;
     pub fn mdb_last_error() -> *const c_char;
     pub fn mdb_version() -> *const c_char;
     pub fn mdb_set_stream(ctx: *mut mdb_ctx, hip_stream: *mut c_void) -> c_int;

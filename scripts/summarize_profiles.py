@@ -25,7 +25,7 @@ def counters(name):
 
 
 def main():
-    round_dir = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
+    round_dir = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r02")
     os.makedirs(round_dir, exist_ok=True)
     shutil.copy(os.path.join(OUT, "prof_trace", "trace_kernel_stats.csv"),
                 os.path.join(round_dir, "bench_kernel_stats.csv"))
@@ -57,6 +57,7 @@ def main():
         "fetch_bytes_per_segment_reported": fetch_bytes * dispatches_per_step / segments,
         "fetch_bytes_per_segment_corrected": 2.0 * fetch_bytes * dispatches_per_step / segments,
         "source": f"profiles/{os.path.basename(round_dir)}/bench_pmc_fetch_write.json (rocprofv3 --pmc, separate passes)",
+        "source_hash": open(os.path.join(OUT, "prof_source_hash.txt")).read().strip(),
     }
     json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_grid_tiles.json"), "w"), indent=1)
     print(json.dumps(pmc, indent=1))

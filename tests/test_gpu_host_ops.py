@@ -17,6 +17,18 @@ from modelardb_rs_amd import host
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[None, "0"], ids=["one-batch-ahead", "grid-when-polled"])
+def grid_prefetch(request, monkeypatch):
+    """Every test runs with GridStream keeping one batch of segments ahead on a second context (the
+    copy of one batch overlapping the kernels of the next) and with it gridding a batch when it is
+    polled for, as the reference does (grid_exec.rs:402-412): the same rows in the same order."""
+    if request.param is None:
+        monkeypatch.delenv("MDB_HOST_GRID_PREFETCH", raising=False)
+    else:
+        monkeypatch.setenv("MDB_HOST_GRID_PREFETCH", request.param)
+    return request.param
+
+
 def _series(seed, length=30_000, irregular=False):
     eb = cases.error_bounds()["rel5"]
     timestamps, values = cases.synthetic_series(length, irregular, (1.0, 1.05), seed)
@@ -62,6 +74,31 @@ def test_grid_stream_reconstructs_two_series_with_tags(hip, batch_size):
     assert metrics["rows_created"] == metrics["output_rows"] == len(ts)
     assert metrics["regular_segments"] + metrics["irregular_segments"] == total_segments
     assert metrics["elapsed_compute_ns"] > 0
+
+
+def test_grid_stream_drained_inside_the_library_returns_every_row(hip):
+    """bench.py's host_path polls the stream to its end in C++ (mdbh_grid_stream_drain): the rows and
+    the first timestamp of every batch must be those the same stream yields batch by batch."""
+    timestamps, _, batch = _series(5, length=60_000, irregular=True)
+    for batch_size in (8192, 777):
+        polled = host.GridStream(hip, batch_size=batch_size)
+        drained = host.GridStream(hip, batch_size=batch_size)
+        for piece in _segment_batches(batch, {}, 50):
+            polled.push(piece)
+            drained.push(piece)
+        polled.finish_input()
+        drained.finish_input()
+        batches, state = polled.collect()
+        assert state == host.GridStream.READY_NONE
+        rows, n_batches, checksum = drained.drain()
+        got_ts, _, _ = _concat(batches)
+        assert np.array_equal(got_ts, timestamps)
+        assert (rows, n_batches) == (len(timestamps), len(batches))
+        firsts = sum(int(b.column("timestamp").cast(pa.int64())[0].as_py()) for b in batches)
+        assert checksum == firsts % (1 << 64)
+        assert polled.metrics()["output_rows"] == drained.metrics()["output_rows"] == len(timestamps)
+    points, seconds, bytes_down = host.measure_grid_stream(hip, batch, 8192, segments_per_batch=64)
+    assert points == len(timestamps) and bytes_down == 12 * points and seconds > 0
 
 
 def test_grid_stream_limit_caps_the_batch_size(hip):  # grid_exec.rs:239-246
