@@ -200,7 +200,7 @@ def fit_on_gpu(context, mdb, np, args, rank, keep_series):
     return parts, fit_seconds, fit_points, kernel_ms, kept
 
 
-def host_path(context, mdb, np, part, args):
+def host_path(context, mdb, np, sample, args):
     """The drop-in path end to end: the C++ GridExec / GridStream of libmdb_host over HOST segment
     batches (what DataFusion would hand it), PCIe included: upload of the segments, kernels, copy of
     the reconstructed columns back into page-locked memory. Not the headline (`value` is
@@ -208,7 +208,6 @@ def host_path(context, mdb, np, part, args):
     from modelardb_rs_amd import host
     chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
     sample_series = max(1, min(args.series, 1_000_000_000 // max(args.points, 1)))
-    sample = part.download()
     sample = sample.take(np.nonzero(sample.chunk_index < sample_series * chunks_per_series)[0])
     out = {"note": "C++ GridExec/GridStream of libmdb_host over host segment batches (8 192 segment rows per "
                    "input batch), polled to the end in slices of batch_size data points; upload of the segments, "
@@ -220,6 +219,23 @@ def host_path(context, mdb, np, part, args):
         out[f"batch_{batch_size}"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
                                       "points": points, "segments": len(sample), "seconds": seconds}
     return out
+
+
+PHASES = {}
+
+
+class phase:
+    """Wall time of one part of the run, into the line's `phases_s` and onto stderr as it ends."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.started = time.perf_counter()
+
+    def __exit__(self, *exc):
+        PHASES[self.name] = PHASES.get(self.name, 0.0) + time.perf_counter() - self.started
+        print(f"[bench] {self.name}: {PHASES[self.name]:.2f} s", file=sys.stderr, flush=True)
 
 
 def claim_stdout():
@@ -236,7 +252,8 @@ def main():
     args = parse_args()
     launch_ranks_if_needed(args)
     result_fd = claim_stdout()
-    rank, local_rank, world, dist = init_distributed(args)
+    with phase("init_distributed"):
+        rank, local_rank, world, dist = init_distributed(args)
     import numpy as np
     import torch
 
@@ -245,13 +262,15 @@ def main():
 
     context = mdb.Context(local_rank)
     info = context.device_info()
-    sharding.init_comm(context, dist)  # the C ABI's own RCCL communicator (mdb_comm_init)
+    with phase("comm_init"):
+        sharding.init_comm(context, dist)  # the C ABI's own RCCL communicator (mdb_comm_init)
     verify = rank == 0 and not args.no_cpu_baseline
 
     # ---- build the workload: fit on the GPU, keep the segments in HBM ---------------------------
     n_fit_sample = min(args.fit_sample_series, args.series) if verify else 0
-    parts, fit_seconds, fit_points, fit_kernel_ms, fit_sample_values = fit_on_gpu(
-        context, mdb, np, args, rank, n_fit_sample)
+    with phase("generate_and_fit"):
+        parts, fit_seconds, fit_points, fit_kernel_ms, fit_sample_values = fit_on_gpu(
+            context, mdb, np, args, rank, n_fit_sample)
     n_segments = sum(len(p) for p in parts)
 
     total_points = 0
@@ -382,13 +401,15 @@ def main():
         cores = os.cpu_count() or 1
         eb = mdb.error_bound("relative", args.error_bound)
         chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
-        downloaded = parts[0].download()
+        with phase("download_segments"):
+            downloaded = parts[0].download()
         n_sample = min(args.cpu_sample_series, args.series)
         # Whole leading series: segments are ordered by chunk, chunks by series.
         sample = downloaded.take(np.nonzero(downloaded.chunk_index < n_sample * chunks_per_series)[0])
-        ts_cpu, val_cpu, cpu_seconds = ora.grid_batch_timed(sample, cores, repetitions=3)
-        single = downloaded.take(np.nonzero(downloaded.chunk_index < chunks_per_series)[0])
-        ts_single, _, single_seconds = ora.grid_batch_timed(single, 1, repetitions=3)
+        with phase("cpu_baseline_grid"):
+            ts_cpu, val_cpu, cpu_seconds = ora.grid_batch_timed(sample, cores, repetitions=3)
+            single = downloaded.take(np.nonzero(downloaded.chunk_index < chunks_per_series)[0])
+            ts_single, _, single_seconds = ora.grid_batch_timed(single, 1, repetitions=3)
         rates = summary(cpu_seconds, len(ts_cpu))
         cpu_baseline = {
             "value": rates["median"], "min": rates["min"], "max": rates["max"],
@@ -409,6 +430,7 @@ def main():
             ts_cpu, val_cpu = ts_cpu[keep], val_cpu[keep]
         grid_points_verified = 0
         piece = 1 << 26
+        verify_started = time.perf_counter()
         for at in range(0, len(ts_cpu), piece):
             n_piece = min(piece, len(ts_cpu) - at)
             got_ts = context.download_array(out_ts, n_piece, np.int64, offset_elements=at)
@@ -419,6 +441,9 @@ def main():
                 raise SystemExit("VERIFICATION FAILED: grid values differ from the oracle")
             grid_points_verified += n_piece
         del ts_cpu, val_cpu
+        PHASES["verify_grid"] = time.perf_counter() - verify_started
+        print(f"[bench] verify_grid: {PHASES['verify_grid']:.2f} s", file=sys.stderr, flush=True)
+        verify_started = time.perf_counter()
         # fit verification: the oracle's greedy compression of the very bytes the GPU fitted.
         n_fit = n_fit_sample
         host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
@@ -448,9 +473,12 @@ def main():
                     "how": "after the timed region: oracle fit of the sample series' exact bytes == GPU "
                            "segments (all columns, byte for byte); oracle grid of the sample == the device "
                            "columns the timed step wrote (bit for bit); device generator == host definition"}
-        del downloaded
+        PHASES["verify_fit_and_cpu_baseline_fit"] = time.perf_counter() - verify_started
+        print(f"[bench] verify_fit_and_cpu_baseline_fit: {PHASES['verify_fit_and_cpu_baseline_fit']:.2f} s", file=sys.stderr, flush=True)
         if not args.no_host_path:
-            host_path_result = host_path(context, mdb, np, parts[0], args)
+            with phase("host_path"):
+                host_path_result = host_path(context, mdb, np, downloaded, args)
+        del downloaded
 
     if rank == 0:
         value = world * points_per_step * args.steps / elapsed
@@ -503,6 +531,7 @@ def main():
             },
             "cpu_baseline": cpu_baseline,
             "verified": verified,
+            "phases_s": {name: round(seconds, 2) for name, seconds in PHASES.items()},
             "aggregates": aggregates,
             "host_path": host_path_result,
             "fit": {

@@ -52,15 +52,17 @@ class BinaryViewColumn:
         return self.views[:, 0:4].copy().view(np.int32).reshape(-1)
 
     def value(self, i):
-        length = int(self.lengths()[i])
+        length, _, index, offset = (int(word) for word in self.views[i].view(np.int32))
         if length <= 12:
             return self.views[i, 4:4 + length].tobytes()
-        index = int(self.views[i, 8:12].copy().view(np.int32)[0])
-        offset = int(self.views[i, 12:16].copy().view(np.int32)[0])
         return self.buffers[index][offset:offset + length].tobytes()
 
     def to_bytes_list(self):
-        return [self.value(i) for i in range(len(self))]
+        words = self.views.view(np.int32).reshape(-1, 4).tolist()
+        inline = self.views[:, 4:16].tobytes()
+        buffers = [memoryview(b) for b in self.buffers]
+        return [inline[12 * i:12 * i + length] if length <= 12 else bytes(buffers[index][offset:offset + length])
+                for i, (length, _, index, offset) in enumerate(words)]
 
     def take(self, indices):
         return BinaryViewColumn(self.views[indices], self.buffers)
