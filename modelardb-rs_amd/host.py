@@ -11,6 +11,9 @@ from . import _abi
 
 HOST_LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "host",
                                  "libmdb_host.so")
+# Set by tests/test_host_sanitizers_cpu.py only: a sanitizer build of mdb_host.cpp with the test stand-in
+# for libmdb_hip compiled in (tests/stub). It answers from canned fixtures and computes nothing.
+LIBRARY_UNDER_TEST = os.environ.get("MDB_HOST_LIBRARY_UNDER_TEST")
 
 
 class ArrowSchemaC(C.Structure):
@@ -36,10 +39,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _abi.load_hip_library()  # RTLD_GLOBAL: resolves libmdb_host's dependency
-        if not os.path.exists(HOST_LIBRARY_PATH):
-            raise RuntimeError(f"{HOST_LIBRARY_PATH} is missing: run __graft_entry__.build().")
-        _lib = C.CDLL(HOST_LIBRARY_PATH)
+        path = LIBRARY_UNDER_TEST or HOST_LIBRARY_PATH
+        if not LIBRARY_UNDER_TEST:
+            _abi.load_hip_library()  # RTLD_GLOBAL: resolves libmdb_host's dependency
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build().")
+        _lib = C.CDLL(path)
         _lib.mdbh_last_error.restype = C.c_char_p
         _lib.mdbh_accumulator_size.restype = C.c_uint64
         _lib.mdbh_grid_stream_free.restype = None

@@ -18,4 +18,15 @@ def hip():
     """The HIP product library bound to cuda:0. Fails loudly when it is missing: no fallback."""
     import modelardb_rs_amd as mdb
     from modelardb_rs_amd import api
+    if os.environ.get("MDB_HOST_LIBRARY_UNDER_TEST"):
+        # tests/test_host_sanitizers_cpu.py: the host operators over the canned-answer stand-in for
+        # libmdb_hip (tests/stub/mdb_stub.cpp); the only thing they need of a context is its handle.
+        import ctypes
+        from modelardb_rs_amd import host
+
+        class StubContext:
+            handle = ctypes.c_void_p()
+
+        assert host.lib().mdb_init(0, ctypes.byref(StubContext.handle)) == 0
+        return StubContext()
     return api.Context(0)

@@ -4,6 +4,8 @@ crates/modelardb_embedded/src/operations/data_folder.rs:1087-1234 (3-point serie
 crates/modelardb_server/tests/integration_test.rs:1128-1246 (segment vs grid aggregates),
 crates/modelardb_compression/src/compression.rs:422-434, 932-978 (compress)."""
 
+import os
+
 import numpy as np
 import pyarrow as pa
 import pytest
@@ -14,7 +16,15 @@ import oracle_lib as ora
 import modelardb_rs_amd as mdb
 from modelardb_rs_amd import host
 
-pytestmark = pytest.mark.gpu
+# tests/test_host_sanitizers_cpu.py runs this very file without a GPU against the host library built
+# with the CPU sanitizers and the canned-answer stand-in for libmdb_hip (tests/stub): the grid-heavy
+# cases shrink tenfold there so that the fixture file of canned answers stays small.
+UNDER_STUB = bool(os.environ.get("MDB_HOST_LIBRARY_UNDER_TEST"))
+pytestmark = [] if UNDER_STUB else pytest.mark.gpu
+
+
+def _n(points):
+    return points // 10 if UNDER_STUB else points
 
 
 @pytest.fixture(autouse=True, params=[None, "0"], ids=["one-batch-ahead", "grid-when-polled"])
@@ -29,7 +39,8 @@ def grid_prefetch(request, monkeypatch):
     return request.param
 
 
-def _series(seed, length=30_000, irregular=False):
+def _series(seed, length=None, irregular=False):
+    length = _n(30_000) if length is None else length
     eb = cases.error_bounds()["rel5"]
     timestamps, values = cases.synthetic_series(length, irregular, (1.0, 1.05), seed)
     return timestamps, values, ora.try_compress_univariate_time_series(timestamps, values, eb)
@@ -64,7 +75,8 @@ def test_grid_stream_reconstructs_two_series_with_tags(hip, batch_size):
     batches, state = stream.collect()
     assert state == host.GridStream.READY_NONE
     assert all(b.num_rows <= batch_size for b in batches)
-    assert all(b.num_rows == batch_size for b in batches[:-1])
+    # (one input batch per poll, grid_exec.rs:407-417: full batches only while an input batch holds enough points)
+    assert UNDER_STUB or all(b.num_rows == batch_size for b in batches[:-1])
     ts, values, table = _concat(batches)
     assert table.schema.names == ["timestamp", "value", "tag"]
     assert np.array_equal(ts, np.concatenate(expected_ts))
@@ -79,7 +91,7 @@ def test_grid_stream_reconstructs_two_series_with_tags(hip, batch_size):
 def test_grid_stream_drained_inside_the_library_returns_every_row(hip):
     """bench.py's host_path polls the stream to its end in C++ (mdbh_grid_stream_drain): the rows and
     the first timestamp of every batch must be those the same stream yields batch by batch."""
-    timestamps, _, batch = _series(5, length=60_000, irregular=True)
+    timestamps, _, batch = _series(5, length=_n(60_000), irregular=True)
     for batch_size in (8192, 777):
         polled = host.GridStream(hip, batch_size=batch_size)
         drained = host.GridStream(hip, batch_size=batch_size)
@@ -114,7 +126,7 @@ def test_grid_stream_limit_caps_the_batch_size(hip):  # grid_exec.rs:239-246
 
 def test_grid_stream_predicate_prunes_after_reconstruction(hip):  # grid_exec.rs:366-387
     timestamps, _, batch = _series(64, irregular=True)
-    lower, upper = int(timestamps[1234]), int(timestamps[20_000])
+    lower, upper = int(timestamps[_n(1230)]), int(timestamps[_n(20_000)])
     stream = host.GridStream(hip, tag_names=("tag",), predicate=(lower, upper), batch_size=4096)
     for part in _segment_batches(batch, {"tag": "x"}, 100):
         stream.push(part)
@@ -336,6 +348,7 @@ def test_uncompressed_data_manager_compresses_finished_buffers_in_one_launch(hip
             assert mdb.SegmentBatch.from_arrow(b).rows() == oracle.rows()
 
 
+@pytest.mark.skipif(UNDER_STUB, reason="device-resident path: needs the GPU")
 def test_segment_files_to_device_and_grid(hip, tmp_path):
     # N2: whole Parquet segment files -> one device batch -> grid, equal to the oracle.
     from modelardb_rs_amd import segment_files
@@ -362,15 +375,15 @@ def test_sorted_join_of_three_field_columns(hip, predicate):
     # sorted_join_exec.rs:277-311 over one GridExec per field column: timestamps and
     # tags come from the first field's GridExec, the other two only reconstruct values.
     eb = cases.error_bounds()["rel5"]
-    timestamps, _ = cases.synthetic_series(40_000, True, (1.0, 1.05), 90)
+    timestamps, _ = cases.synthetic_series(_n(40_000), True, (1.0, 1.05), 90)
     if predicate == "middle":
-        predicate = (int(timestamps[5_000]), int(timestamps[31_234]))
+        predicate = (int(timestamps[_n(5_000)]), int(timestamps[_n(31_230)]))
     fields = []
     for seed in (91, 92, 93):
-        _, values = cases.synthetic_series(40_000, True, (1.0, 1.05), seed)
+        _, values = cases.synthetic_series(_n(40_000), True, (1.0, 1.05), seed)
         fields.append(ora.try_compress_univariate_time_series(timestamps, values, eb))
     order = ["timestamp", "field", "field", ("tag", "tag"), "field"]
-    join = host.SortedJoinStream(hip, 3, order, tag_names=("tag",), predicate=predicate, batch_size=4096)
+    join = host.SortedJoinStream(hip, 3, order, tag_names=("tag",), predicate=predicate, batch_size=_n(4096))
     assert "values_only=011" in join.describe()
     for index, batch in enumerate(fields):
         for part in _segment_batches(batch, {"tag": "wind-turbine-1234567"}, 37 + index):  # ragged on purpose
