@@ -544,9 +544,11 @@ int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, 
 
 int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
-    if (mdb_segments_upload(ctx, in, &dev)) return 1;
-    int rc = mdb_agg_batch_dev(ctx, &dev->seg, which_mask, inout);
+    if (upload_segments_locked(ctx, in, true, &dev)) return 1;
+    int rc = agg_run(ctx, &dev->seg, false, 0, 0, which_mask, inout);
     mdb_segments_free(dev);
     return rc;
 }
@@ -554,9 +556,11 @@ int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb
 int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                         uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
-    if (mdb_segments_upload(ctx, in, &dev)) return 1;
-    int rc = mdb_agg_batch_range_dev(ctx, &dev->seg, t_lo, t_hi, which_mask, inout);
+    if (upload_segments_locked(ctx, in, true, &dev)) return 1;
+    int rc = agg_run(ctx, &dev->seg, true, t_lo, t_hi, which_mask, inout);
     mdb_segments_free(dev);
     return rc;
 }

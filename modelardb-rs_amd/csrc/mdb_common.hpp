@@ -74,6 +74,7 @@ enum ScratchSlot {
     SCRATCH_TS_BASE,
     SCRATCH_TS_SLOTS,
     SCRATCH_FIT_BASES,
+    SCRATCH_UPLOAD,
     SCRATCH_SLOT_COUNT
 };
 
@@ -104,6 +105,7 @@ struct mdb_ctx {
     uint64_t pinned_bytes = 0;
 
     std::shared_ptr<mdb::PinnedPool> pinned_pool = std::make_shared<mdb::PinnedPool>();
+    bool owns_pinned_pool = true; // false for a clone: it shares the pool of the context it was made from
 
     // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).
     void *comm = nullptr;
@@ -124,6 +126,8 @@ void merge_agg_state(mdb_agg_state *into, const mdb_agg_state &from);
 // Grow-only device scratch, one allocation per slot.
 int scratch_reserve(mdb_ctx *ctx, ScratchSlot slot, uint64_t bytes, void **out);
 int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out);
+// mdb_segments_upload with ctx->mutex held; transient = into the context's upload scratch (mdb_ctx.hip).
+int upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool transient, mdb_segments_owned **out);
 int profile_collect(mdb_ctx *ctx);
 
 // Brackets a launch with events when profiling is on.

@@ -46,12 +46,14 @@ int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out) {
 int PinnedPool::take(uint64_t bytes, void **out, uint64_t *capacity) {
     if (bytes == 0) bytes = 256;
     {
-        // Best fit among the recycled blocks that are not wastefully large.
+        // Best fit among the recycled blocks that are not wastefully large. The bounds are loose on
+        // purpose: the batches of one query differ in size by the data they decode to, and a block that
+        // does not fit costs a hipHostMalloc (13 ms for 70 MB, ten batches' worth of copying).
         std::lock_guard<std::mutex> lock(mutex);
         int best = -1;
         for (size_t i = 0; i < blocks.size(); i++) {
             uint64_t cap = blocks[i].second;
-            if (cap >= bytes && cap <= 2 * bytes + (1 << 20) && (best < 0 || cap < blocks[(size_t)best].second))
+            if (cap >= bytes && cap <= 4 * bytes + (16 << 20) && (best < 0 || cap < blocks[(size_t)best].second))
                 best = (int)i;
         }
         if (best >= 0) {
@@ -61,7 +63,12 @@ int PinnedPool::take(uint64_t bytes, void **out, uint64_t *capacity) {
             return 0;
         }
     }
-    uint64_t grown = align_up(bytes + bytes / 8, 1 << 16);
+    // Size classes a quarter of a power of two apart, so that blocks made for one batch fit the next.
+    uint64_t grown = 1 << 16;
+    while (grown < bytes) grown <<= 1;
+    for (uint64_t quarter = grown >> 3, smaller = grown - quarter; quarter >= (1 << 14) && smaller >= bytes;
+         smaller -= quarter)
+        grown = smaller;
     MDB_HIP_CHECK(hipHostMalloc(out, grown, hipHostMallocDefault));
     *capacity = grown;
     return 0;
@@ -213,7 +220,12 @@ int mdb_init(int device, mdb_ctx **out) {
 
 int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
     if (!ctx || !out) return fail("ctx and out must not be NULL.");
-    return mdb_init(ctx->device, out);
+    if (mdb_init(ctx->device, out)) return 1;
+    // One pool of page-locked blocks for the context and its clones: an operator makes its second context
+    // per query, and a pool that died with it would pay hipHostMalloc for every block again.
+    (*out)->pinned_pool = ctx->pinned_pool;
+    (*out)->owns_pinned_pool = false;
+    return 0;
 }
 
 int mdb_close(mdb_ctx *ctx) {
@@ -229,7 +241,7 @@ int mdb_close(mdb_ctx *ctx) {
     for (int i = 0; i < SCRATCH_SLOT_COUNT; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    ctx->pinned_pool->close();
+    if (ctx->owns_pinned_pool) ctx->pinned_pool->close();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -334,6 +346,17 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
     if (!ctx || !host || !out) return fail("ctx, host and out must not be NULL.");
     std::lock_guard<std::mutex> lock(ctx->mutex);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    return mdb::upload_segments_locked(ctx, host, false, out);
+}
+
+} // extern "C"
+
+// transient: the blob is the context's SCRATCH_UPLOAD slot instead of an allocation of its own, valid
+// until the next transient upload on this context (the caller holds ctx->mutex from the upload to the
+// end of the launch that reads it). hipMalloc + hipFree per batch would cost more than the kernels of a
+// small batch, and hipFree waits for the WHOLE device: with it, two contexts could never overlap the copy
+// of one batch with the kernels of the next (36 GB/s instead of the 56 GB/s the link gives).
+int mdb::upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool transient, mdb_segments_owned **out) {
     const uint64_t n = host->n;
     const mdb_binview_col *cols[3] = {&host->timestamps, &host->values, &host->residuals};
     for (int c = 0; c < 3; c++) {
@@ -378,17 +401,24 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
 
     OwnedSegments *owned = new OwnedSegments();
     void *blob = nullptr;
-    if (hipMalloc(&blob, total) != hipSuccess) {
-        delete owned;
-        return fail("hipMalloc of " + std::to_string(total) + " bytes failed.");
+    if (transient) {
+        if (scratch_reserve(ctx, SCRATCH_UPLOAD, total, &blob)) {
+            delete owned;
+            return 1;
+        }
+    } else {
+        if (hipMalloc(&blob, total) != hipSuccess) {
+            delete owned;
+            return fail("hipMalloc of " + std::to_string(total) + " bytes failed.");
+        }
+        owned->device_allocs.push_back(blob);
     }
     owned->device = ctx->device;
-    owned->device_allocs.push_back(blob);
     uint8_t *dev = static_cast<uint8_t *>(blob);
 
     void *stage_v = nullptr;
     if (pinned_reserve(ctx, total, &stage_v)) {
-        (void)hipFree(blob);
+        if (!transient) (void)hipFree(blob);
         delete owned;
         return 1;
     }
@@ -403,7 +433,7 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
     }
     if (hipMemcpyAsync(dev, stage, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        (void)hipFree(blob);
+        if (!transient) (void)hipFree(blob);
         delete owned;
         return fail("hipMemcpy host to device failed.");
     }
@@ -434,6 +464,8 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
     *out = &owned->c;
     return 0;
 }
+
+extern "C" {
 
 int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **out) {
     if (!ctx || !dev || !out) return fail("ctx, dev and out must not be NULL.");
@@ -597,7 +629,7 @@ void mdb_segments_free(mdb_segments_owned *segments) {
     if (!segments) return;
     OwnedSegments *owned = static_cast<OwnedSegments *>(segments->priv_);
     if (!owned) return;
-    if (owned->device >= 0) {
+    if (owned->device >= 0 && !owned->device_allocs.empty()) {
         (void)hipSetDevice(owned->device);
         (void)hipDeviceSynchronize();
         for (void *p : owned->device_allocs) (void)hipFree(p);

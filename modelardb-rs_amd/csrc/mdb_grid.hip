@@ -1763,14 +1763,18 @@ namespace {
 
 const TimeRange NO_RANGE = {0, 0, 0};
 
-int grid_count_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
-    if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
-    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+int grid_count_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
     GridPlan plan;
     if (grid_plan(ctx, in, range, &plan)) return 1;
     *n_out = plan.host_header.total_points;
     return 0;
+}
+
+int grid_count_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
+    if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    return grid_count_dev_locked(ctx, in, range, n_out);
 }
 
 int grid_batch_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
@@ -1786,9 +1790,11 @@ int grid_batch_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, i
 
 int grid_count_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
     if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
-    if (mdb_segments_upload(ctx, in, &dev)) return 1;
-    int rc = grid_count_dev_impl(ctx, &dev->seg, range, n_out);
+    if (upload_segments_locked(ctx, in, true, &dev)) return 1;
+    int rc = grid_count_dev_locked(ctx, &dev->seg, range, n_out);
     mdb_segments_free(dev);
     return rc;
 }
@@ -1798,11 +1804,12 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
                          mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
     if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
-    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    if (upload_segments_locked(ctx, in, true, &dev)) return 1;
     int rc = 0;
     {
-        std::lock_guard<std::mutex> lock(ctx->mutex);
         void *stage = nullptr;
         // Device staging for the outputs: timestamps, values, rows-per-segment (256 B aligned).
         const uint64_t ts_bytes = align_up(cap * 8, 256), val_bytes = align_up(cap * 4, 256);
@@ -1841,12 +1848,13 @@ struct OwnedGridResult {
 int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, bool values_only,
                           uint64_t reserve_front, mdb_grid_result **out) {
     if (!ctx || !in || !out) return fail("ctx, in and out must not be NULL.");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
-    if (mdb_segments_upload(ctx, in, &dev)) return 1;
+    if (upload_segments_locked(ctx, in, true, &dev)) return 1;
     int rc = 0;
     OwnedGridResult *result = nullptr;
     {
-        std::lock_guard<std::mutex> lock(ctx->mutex);
         GridPlan plan;
         rc = grid_plan(ctx, &dev->seg, range, &plan);
         const uint64_t total = plan.host_header.total_points;
