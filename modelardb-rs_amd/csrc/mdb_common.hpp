@@ -75,6 +75,7 @@ enum ScratchSlot {
     SCRATCH_TS_SLOTS,
     SCRATCH_FIT_BASES,
     SCRATCH_UPLOAD,
+    SCRATCH_PENDING,
     SCRATCH_SLOT_COUNT
 };
 

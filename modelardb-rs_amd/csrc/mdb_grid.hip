@@ -48,31 +48,55 @@ struct GridHeader {
                                     // [9] bytes of the MacaqueV streams the parallel decoder takes
 };
 
+// MODE 0: every segment through the generic analysis (a time range is given).
+// MODE 1: the simple segments (segment_is_simple) through the trimmed analysis; the others are left to a
+//         MODE 2 launch behind it: one bit per segment in `pending`, one flag per block in `block_pending`.
+// MODE 2: the segments MODE 1 left, through the generic analysis; a block without any returns at once.
+template <int MODE>
 __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     DevSegments s, TimeRange range, uint32_t mv_min_values, TileDesc *__restrict__ desc,
     uint32_t *__restrict__ counts, uint32_t *__restrict__ irregular_totals,
     uint32_t *__restrict__ irregular_first, unsigned long long *__restrict__ block_points,
     unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header, TsCheckpoints checkpoints,
-    const uint32_t *__restrict__ known_totals) {
-    __shared__ unsigned long long lds_metrics[12];
-    if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
+    const uint32_t *__restrict__ known_totals, unsigned long long *__restrict__ pending,
+    uint32_t *__restrict__ block_pending, uint32_t n_blocks) {
+    __shared__ unsigned long long lds_metrics[13];
+    // MODE 2 is launched with few workgroups that walk the blocks of the MODE 1 launch: a batch of simple
+    // segments only costs a look at its block flags (32 k workgroups that return at once cost 0.16 ms).
+    for (uint32_t block = blockIdx.x; block < n_blocks; block += gridDim.x) {
+    if (MODE == 2 && block_pending[block] == 0) continue;
+    if (MODE == 2) __syncthreads();
+    if (threadIdx.x < 13) lds_metrics[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * SEGS_PER_BLOCK;
+    const uint64_t base = (uint64_t)block * SEGS_PER_BLOCK;
     unsigned long long points = 0, serial = 0;
     unsigned long long m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t error = 0;
+    bool left_any = false;
 #pragma unroll 1
     for (int k = 0; k < PREPASS_ITEMS; k++) {
         uint64_t i = base + (uint64_t)k * PREPASS_THREADS + threadIdx.x;
-        if (i >= s.n) break;
-        SegInfo info = analyse_segment(s, i, known_totals, &checkpoints);
-        if (range.enabled) apply_time_range(s, i, info, range, nullptr, nullptr, &checkpoints);
+        if (MODE == 1) {
+            // The 64 segments of a wave's iteration are one word of `pending` (base and k * 256 are
+            // multiples of 64).
+            const bool simple = i < s.n && segment_is_simple(s, i);
+            const unsigned long long left = __ballot(i < s.n && !simple);
+            if ((threadIdx.x & (MDB_WAVE - 1)) == 0 && (base + (uint64_t)k * PREPASS_THREADS + (threadIdx.x & ~(MDB_WAVE - 1))) < s.n)
+                pending[i >> 6] = left;
+            left_any |= left != 0;
+            if (!simple) continue;
+        } else {
+            if (i >= s.n) break;
+            if (MODE == 2 && !((pending[i >> 6] >> (i & 63)) & 1ull)) continue;
+        }
+        SegInfo info = MODE == 1 ? analyse_segment<true>(s, i) : analyse_segment<false>(s, i, known_totals, &checkpoints);
+        if (MODE != 1 && range.enabled) apply_time_range(s, i, info, range, nullptr, nullptr, &checkpoints);
         error |= info.error;
         const SegDesc &d = info.desc;
         desc[i] = make_tile_desc(d);
         bool is_serial = (d.flags & FLAG_SERIAL) != 0;
         counts[i] = d.n_visible | (is_serial ? SERIAL_BIT : 0u);
-        if (!(d.flags & FLAG_REGULAR)) { // k_grid_serial need not parse the timestamps to count again
+        if (MODE != 1 && !(d.flags & FLAG_REGULAR)) { // k_grid_serial need not parse the timestamps to count again
             irregular_totals[i] = d.n_total;
             irregular_first[i] = d.first;
         }
@@ -87,7 +111,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         m[7] += (d.flags & FLAG_REGULAR) ? 1 : 0;
         m[8] += (d.flags & FLAG_REGULAR) ? 0 : 1;
         // Bytes of the MacaqueV streams long enough for the parallel decoder (bounds its scratch).
-        if (type == MDB_MACAQUE_V_ID && mv_min_values != 0xffffffffu) {
+        if (MODE != 1 && type == MDB_MACAQUE_V_ID && mv_min_values != 0xffffffffu) {
             const uint32_t bytes = s.values.views[i].x;
             if (mv_qualifies(info, bytes, mv_min_values)) m[9] += bytes;
         }
@@ -95,17 +119,25 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     // Block totals through LDS atomics (few per thread, once per block).
     atomicAdd(&lds_metrics[10], points);
     atomicAdd(&lds_metrics[11], serial);
+    if (MODE == 1 && left_any && (threadIdx.x & (MDB_WAVE - 1)) == 0) atomicAdd(&lds_metrics[12], 1ull);
 #pragma unroll
     for (int k = 0; k < 10; k++)
         if (m[k]) atomicAdd(&lds_metrics[k], m[k]);
     if (error) atomicOr(&header->error, error);
     __syncthreads();
     if (threadIdx.x == 0) {
-        block_points[blockIdx.x] = lds_metrics[10];
-        block_serial[blockIdx.x] = lds_metrics[11];
+        if (MODE == 2) {
+            block_points[block] += lds_metrics[10];
+            block_serial[block] += lds_metrics[11];
+        } else {
+            block_points[block] = lds_metrics[10];
+            block_serial[block] = lds_metrics[11];
+        }
+        if (MODE == 1) block_pending[block] = (uint32_t)lds_metrics[12];
     }
     if (threadIdx.x < 10 && lds_metrics[threadIdx.x])
         atomicAdd(&header->metrics[threadIdx.x], lds_metrics[threadIdx.x]);
+    }
 }
 
 // One block: exclusive scan of the per-block totals (in place), totals into the header.
@@ -1120,12 +1152,29 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
                            plan->header);
         known_totals = plan->irregular_totals;
     }
-    {
-        LaunchTimer timer(ctx, "k_grid_prepass");
-        hipLaunchKernelGGL(k_grid_prepass, dim3(n_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s,
-                           range, plan->mv_min_values, plan->desc, plan->counts, plan->irregular_totals,
-                           plan->irregular_first, plan->block_points,
-                           plan->block_serial, plan->header, plan->checkpoints, known_totals);
+    // Simple segments (PMC-Mean / Swing, regular timestamps, no residuals) first, through the trimmed
+    // analysis; what that leaves, through the generic one (MDB_GRID_PREPASS_SPLIT=0: everything generic).
+    const char *split_setting = std::getenv("MDB_GRID_PREPASS_SPLIT");
+    const bool split = !range.enabled && !(split_setting && std::strcmp(split_setting, "0") == 0);
+    unsigned long long *pending = nullptr;
+    uint32_t *block_pending = nullptr;
+    if (split) {
+        if (scratch_reserve(ctx, SCRATCH_PENDING, (n / 64 + 2) * 8 + (uint64_t)n_blocks * 4, &p)) return 1;
+        pending = static_cast<unsigned long long *>(p);
+        block_pending = reinterpret_cast<uint32_t *>(pending + n / 64 + 2);
+    }
+    auto prepass = [&](auto kernel, const char *name, uint32_t workgroups) {
+        LaunchTimer timer(ctx, name);
+        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(PREPASS_THREADS), 0, ctx->stream, s, range,
+                           plan->mv_min_values, plan->desc, plan->counts, plan->irregular_totals,
+                           plan->irregular_first, plan->block_points, plan->block_serial, plan->header,
+                           plan->checkpoints, known_totals, pending, block_pending, n_blocks);
+    };
+    if (split) {
+        prepass(k_grid_prepass<1>, "k_grid_prepass_simple", n_blocks);
+        prepass(k_grid_prepass<2>, "k_grid_prepass", std::min<uint32_t>(n_blocks, 3 * 256 * 4));
+    } else {
+        prepass(k_grid_prepass<0>, "k_grid_prepass", n_blocks);
     }
     {
         LaunchTimer timer(ctx, "k_scan_blocks");

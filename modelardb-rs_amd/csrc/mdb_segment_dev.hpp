@@ -382,11 +382,28 @@ struct SegInfo {
     uint32_t regular_length; // len() of a regular stream = the stored big-endian integer
 };
 
+// PMC-Mean or Swing, timestamps regular (or the empty stream of one or two points), no residuals: nothing
+// about such a segment needs a bit stream walked.
+__device__ __forceinline__ bool segment_is_simple(const DevSegments &s, uint64_t i) {
+    const int32_t type = s.model_type_id[i];
+    const uint4 vt = s.timestamps.views[i];
+    const int32_t ts_len = (int32_t)vt.x;
+    const int32_t res_len = (int32_t)s.residuals.views[i].x;
+    const bool regular = ts_len == 0 || (ts_len > 0 && (view_inline_byte(vt, 0) & 0x80u) == 0);
+    return (type == MDB_PMC_MEAN_ID || type == MDB_SWING_ID) && regular && res_len == 0;
+}
+
 // `known_totals` (may be nullptr): per segment, the number of points of a segment with irregular
 // timestamps as an earlier analyse_segment of the same batch counted it - counting means parsing
 // the whole delta-of-delta stream, which the prepass has already done once.
 // `checkpoints` (may be nullptr): the batch's timestamp checkpoints, made by k_grid_ts_count (which has
 // also left the streams' lengths in known_totals).
+//
+// SIMPLE = true is the same analysis for a segment the caller has found to be "simple"
+// (segment_is_simple(): PMC-Mean or Swing, regular timestamps, no residuals): the branches such a
+// segment cannot take are not compiled, which is what lets the prepass run them at three times the
+// occupancy (the delta-of-delta decoders are most of the generic version's 132 registers).
+template <bool SIMPLE = false>
 __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i,
                                                    const uint32_t *known_totals = nullptr,
                                                    const TsCheckpoints *checkpoints = nullptr) {
@@ -456,6 +473,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
                 }
             }
         }
+    } else if (SIMPLE) {
+        if (ts_len > 0) info.error |= ERR_TIMESTAMPS; // (not a simple segment: the caller's mistake)
     } else if (ts_len > 0) {
         regular = false;
         ts_bytes = view_data(s.timestamps, i, vt);
@@ -476,7 +495,9 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
     // residuals_length() (models/mod.rs:277-284)
     const int32_t res_len = (int32_t)vr.x;
     uint32_t n_res = 0;
-    if (res_len < 0) {
+    if (SIMPLE) {
+        if (res_len != 0) info.error |= ERR_RESIDUALS; // (not a simple segment)
+    } else if (res_len < 0) {
         info.error |= ERR_RESIDUALS;
     } else if (res_len > 0) {
         flags |= FLAG_HAS_RESIDUALS;
@@ -501,7 +522,7 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
             info.error |= ERR_VALUES; // expect("Model should represent at least one value.")
         } else if (!info.error) {
             int64_t model_end = start;
-            if (regular) {
+            if (regular || SIMPLE) {
                 model_end = start + (int64_t)((uint64_t)(n_model - 1) * (uint64_t)d.delta);
             } else if (n_res == 0) {
                 model_end = end; // the last timestamp is not stored in the stream: it is end_time
@@ -525,7 +546,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
         if ((int32_t)vv.x <= 0 || n_model == 0) info.error |= ERR_VALUES;
     }
     // (irregular timestamps with checkpoints are k_grid_timestamps' work, not the serial kernel's)
-    if ((!regular && !(flags & FLAG_CHECKPOINTS)) || type == MDB_MACAQUE_V_ID || n_res > 0) flags |= FLAG_SERIAL;
+    if (!SIMPLE && ((!regular && !(flags & FLAG_CHECKPOINTS)) || type == MDB_MACAQUE_V_ID || n_res > 0))
+        flags |= FLAG_SERIAL;
     d.flags = flags;
     d.first = 0;
     d.n_visible = n_total;
