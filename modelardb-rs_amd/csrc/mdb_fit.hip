@@ -1082,23 +1082,33 @@ constexpr int LEAN_GROUPS = 8;        // 16-byte groups per lane in the ring (32
 constexpr int LEAN_LOADS = 6;         // groups fetched per top-up at most; 2 groups of history stay
 constexpr int LEAN_TRASH = LEAN_GROUPS; // ring row that takes the stores nobody wants
 
+// One bit per lane of the wave, the same value in every lane (so: scalar registers).
+using LaneMask = unsigned long long;
+__device__ __forceinline__ LaneMask lanes_where(bool condition) { return __builtin_amdgcn_ballot_w64(condition); }
+__device__ __forceinline__ bool in_lanes(LaneMask mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// First statement of an `if (in_lanes(m)) { a = b; ... }` whose assignments should run under the lanes' mask
+// (one move per register, one per DOUBLE register pair) rather than be turned into a select per 32 bits.
+__device__ __forceinline__ void keep_under_mask() { asm volatile(""); }
+
 template <int KIND> __device__ __forceinline__ double lean_deviation(double factor, double value) {
     return KIND == MDB_EB_RELATIVE ? fabs(value * factor) : factor; // DeviationFactor::of
 }
 
-// certainly within the bound (the first half of pmc_fast_within, without branches)
+// The lanes whose value is certainly within the bound (the first half of pmc_fast_within, without branches).
+// (lanes_where of ONE comparison is the comparison's own result; of an expression it is a detour through a
+// vector register.)
 template <int KIND>
-__device__ __forceinline__ bool lean_passes(const PmcFast &f, float real_value, float approximate_average,
-                                            float average_error) {
+__device__ __forceinline__ LaneMask lean_passes(const PmcFast &f, float real_value, float approximate_average,
+                                                float average_error) {
     const float difference = fabsf(real_value - approximate_average);
     float pass_bound = f.pass_bound;
-    bool usable = true;
+    LaneMask usable = ~0ull;
     if (KIND == MDB_EB_RELATIVE) {
         const float magnitude = fabsf(real_value);
         pass_bound *= magnitude;
-        usable = magnitude >= 0x1p-60f;
+        usable = lanes_where(magnitude >= 0x1p-60f);
     }
-    return usable & (difference <= pass_bound - average_error);
+    return usable & lanes_where(difference <= pass_bound - average_error);
 }
 
 __device__ __forceinline__ float ring_value(const float4 (*ring)[MDB_WAVE], int lane, uint32_t position) {
@@ -1174,24 +1184,30 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     double upper_slope = nan64, upper_intercept = nan64, lower_slope = nan64, lower_intercept = nan64;
     double numerator = 0.0, denominator = 0.0;
     uint32_t swing_length = 0;
-    bool swing_finite = false;
-    bool pmc_fits = true, swing_fits = true;
+    // What is true of which lane is kept as 64-bit lane masks: they are the same for the whole wave, so
+    // they live in scalar registers and `and`, `or`, `not` of conditions are scalar instructions. (As
+    // `bool` variables that survive an iteration the compiler keeps them as 0 / 1 in vector registers
+    // and converts to and fro: some forty vector instructions of a step, a fifth of it.)
+    LaneMask active_m = lanes_where(active);
+    LaneMask pmc_fits_m = ~0ull, swing_fits_m = ~0ull, swing_finite_m = 0;
+    const LaneMask pmc_fast_m = pmc_fast.enabled ? ~0ull : 0ull;
 
-    while (__any(active)) {
-        const bool feeding = active & (j < n) & (pmc_fits | swing_fits);
+    while (active_m != 0) {
+        const LaneMask feeding_m = active_m & lanes_where(j < n) & (pmc_fits_m | swing_fits_m);
         const uint32_t position = j + misalign; // of point j, counted from the 16-byte boundary
         const uint32_t group = position >> 2;
-        if (__any(feeding & ((group >= loaded_group) | (group < low_group)))) {
+        if (feeding_m & (lanes_where(group >= loaded_group) | lanes_where(group < low_group))) {
             // Normally the ring is extended at loaded_group. A lane whose next point fell out of the back
             // of its ring (PMC-Mean chosen although Swing had run far ahead, types.rs:84-101) or lies
             // beyond it restarts the ring at that point's group.
-            if (active & ((group < low_group) | (group > loaded_group))) {
+            const bool lane_active = in_lanes(active_m);
+            if (lane_active & ((group < low_group) | (group > loaded_group))) {
                 loaded_group = group;
                 low_group = group;
             }
             const uint32_t first_group = loaded_group;
             // Two groups behind the current one stay (a rejected model restarts at most 7 points back).
-            const uint32_t end_group = active ? min(group + (uint32_t)LEAN_LOADS, last_group + 1u) : first_group;
+            const uint32_t end_group = lane_active ? min(group + (uint32_t)LEAN_LOADS, last_group + 1u) : first_group;
             float4 fetched[LEAN_LOADS];
 #pragma unroll
             for (int k = 0; k < LEAN_LOADS; k++) fetched[k] = groups[min(first_group + (uint32_t)k, last_group)];
@@ -1207,76 +1223,81 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         const double value = (double)value32;
 
         // ---- PMC-Mean: PMCMean::fit_value (pmc_mean.rs:58-76), decided as in pmc_fit_fast ----
-        const bool pmc_steps = feeding & pmc_fits;
+        const LaneMask pmc_steps_m = feeding_m & pmc_fits_m;
         const float next_min = min_num(pmc_min, value32);
         const float next_max = max_num(pmc_max, value32);
         const double next_sum = pmc_sum + value;
         const uint32_t next_length = pmc_length + 1;
-        bool pmc_accepts;
+        LaneMask pmc_accepts_m;
         {
             const float approximate = (float)next_sum * __builtin_amdgcn_rcpf((float)next_length);
             const float average_error = fmaxf(fabsf(approximate) * 0x1p-20f, 0x1p-120f);
-            const bool passes_low = lean_passes<KIND>(pmc_fast, next_min, approximate, average_error);
-            const bool passes_high = lean_passes<KIND>(pmc_fast, next_max, approximate, average_error);
-            pmc_accepts = pmc_fast.enabled & passes_low & passes_high;
+            pmc_accepts_m = pmc_fast_m & lean_passes<KIND>(pmc_fast, next_min, approximate, average_error) &
+                            lean_passes<KIND>(pmc_fast, next_max, approximate, average_error);
             // Not certainly within the bound: certainly outside it (the step that ends a PMC-Mean model,
             // once per model), or too close to call and decided by the exact test.
-            const bool doubtful = pmc_steps & !pmc_accepts;
-            if (__any(doubtful)) {
-                if (doubtful) {
+            const LaneMask doubtful_m = pmc_steps_m & ~pmc_accepts_m;
+            if (doubtful_m) {
+                bool exactly_within = false;
+                if (in_lanes(doubtful_m)) {
                     const int low = pmc_fast.enabled ? pmc_fast_within(pmc_fast, next_min, approximate, average_error) : 0;
                     const int high = pmc_fast.enabled ? pmc_fast_within(pmc_fast, next_max, approximate, average_error) : 0;
                     if (low >= 0 && high >= 0) {
                         const float average = (float)(next_sum / (double)next_length);
-                        pmc_accepts = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
+                        exactly_within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
                     }
                 }
+                pmc_accepts_m |= lanes_where(exactly_within);
             }
         }
-        const bool pmc_keeps = pmc_steps & pmc_accepts;
-        if (pmc_keeps) { // (kept under the lanes' mask: no select per register)
+        if (in_lanes(pmc_steps_m & pmc_accepts_m)) { // (kept under the lanes' mask: no select per register)
+            keep_under_mask();
             pmc_min = next_min;
             pmc_max = next_max;
             pmc_sum = next_sum;
             pmc_length = next_length;
         }
-        pmc_fits = pmc_fits & (!pmc_steps | pmc_accepts);
+        pmc_fits_m &= ~pmc_steps_m | pmc_accepts_m;
 
         // ---- Swing: Swing::fit_data_point (swing.rs:101-198) on exact f64 timestamps (SwingFast) ----
-        const bool swing_steps = feeding & swing_fits;
+        const LaneMask swing_steps_m = feeding_m & swing_fits_m;
         // first + j * interval: integers below 2^53, exact whether fused or not.
         const double time = __builtin_fma((double)j, interval_time, first_time);
         const double deviation = lean_deviation<KIND>(deviation_factor_value, value);
-        const bool is_first = swing_length == 0, is_second = swing_length == 1, later = swing_length >= 2;
-        const bool value_finite = isfinite(value);
+        const LaneMask first_m = lanes_where(swing_length == 0), second_m = lanes_where(swing_length == 1);
+        const LaneMask later_m = ~(first_m | second_m);
+        const LaneMask value_finite_m = lanes_where(__builtin_amdgcn_classf(value32, 0x1f8)); // isfinite: +-normal, +-subnormal, +-0
         // A non-finite first value only accepts copies of itself, a finite one no non-finite value
         // (swing.rs:113-125): rare, behind a branch below.
-        const bool special = !is_first & (!swing_finite | !value_finite);
+        const LaneMask special_m = ~first_m & ~(swing_finite_m & value_finite_m);
         const double upper_approximation = upper_slope * time + upper_intercept;
         const double lower_approximation = lower_slope * time + lower_intercept;
-        const bool outside = later & ((upper_approximation + deviation < value) | (lower_approximation - deviation > value));
-        const bool lowers_upper = is_second | (later & (upper_approximation - deviation > value));
-        const bool raises_lower = is_second | (later & (lower_approximation + deviation < value));
+        const LaneMask outside_m = later_m & (lanes_where(upper_approximation + deviation < value) |
+                                              lanes_where(lower_approximation - deviation > value));
+        const LaneMask lowers_upper_m = second_m | (later_m & lanes_where(upper_approximation - deviation > value));
+        const LaneMask raises_lower_m = second_m | (later_m & lanes_where(lower_approximation + deviation < value));
+        const bool lowers_upper = in_lanes(lowers_upper_m);
         // One line per step serves whichever bound moves (line_through_exact, start and first value of
         // the model); a step that moves both gets its second line behind the branch.
         const double target = lowers_upper ? value + deviation : value - deviation;
         const double elapsed = time - swing_start;
         double line_slope = (target - swing_first) / elapsed;
         double line_intercept = swing_first - line_slope * swing_start;
-        bool swing_accepts = is_first | !outside;
+        LaneMask swing_accepts_m = first_m | ~outside_m;
         double second_slope = lower_slope, second_intercept = lower_intercept;
-        const bool moves_both = swing_steps & !special & lowers_upper & raises_lower & !outside;
+        const LaneMask moves_both_m = swing_steps_m & ~special_m & lowers_upper_m & raises_lower_m & ~outside_m;
         // (a line to a value equal to the model's first one is flat, swing.rs:331-333; and such a value
         // adds nothing to the sums of swing.rs:212-228)
-        const bool level = swing_steps & ((swing_first == target) | (swing_first == value));
+        const LaneMask level_m = swing_steps_m & (lanes_where(swing_first == target) | lanes_where(swing_first == value));
+        const LaneMask special_steps_m = swing_steps_m & special_m;
         double weighted = (value - swing_first) * elapsed, squared = elapsed * elapsed;
-        if (__any(moves_both | level | (swing_steps & special))) {
-            if (moves_both) {
+        if (moves_both_m | level_m | special_steps_m) {
+            if (in_lanes(moves_both_m)) {
                 const LineDev line = line_through_exact(swing_start, swing_first, time, value - deviation);
                 second_slope = line.slope;
                 second_intercept = line.intercept;
             }
-            if (level) {
+            if (in_lanes(level_m)) {
                 if (swing_first == target) {
                     line_slope = 0.0;
                     line_intercept = swing_first;
@@ -1286,40 +1307,45 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
                     squared = 0.0;
                 }
             }
-            if (swing_steps & special) swing_accepts = equal_or_nan(swing_first, value);
+            if (special_steps_m)
+                swing_accepts_m = (swing_accepts_m & ~special_steps_m) | (special_steps_m & lanes_where(equal_or_nan(swing_first, value)));
         }
-        const bool swing_keeps = swing_steps & swing_accepts;
-        const bool plain = swing_keeps & !special & !is_first;
-        const bool new_upper = plain & lowers_upper;
-        const bool new_lower = plain & raises_lower;
-        if (new_upper) {
+        const LaneMask swing_keeps_m = swing_steps_m & swing_accepts_m;
+        const LaneMask plain_m = swing_keeps_m & ~special_m & ~first_m;
+        if (in_lanes(plain_m & lowers_upper_m)) {
+            keep_under_mask();
             upper_slope = line_slope;
             upper_intercept = line_intercept;
         }
-        if (new_lower) {
+        if (in_lanes(plain_m & raises_lower_m)) {
+            keep_under_mask();
             lower_slope = lowers_upper ? second_slope : line_slope;
             lower_intercept = lowers_upper ? second_intercept : line_intercept;
         }
-        if (plain & later) { // swing.rs:212-228: only from the third point on
+        if (in_lanes(plain_m & later_m)) { // swing.rs:212-228: only from the third point on
+            keep_under_mask();
             numerator += weighted;
             denominator += squared;
         }
-        if (swing_keeps & (special | is_first)) {
-            if (special) { // upper = lower = {value, value} (swing.rs:121-123)
+        const LaneMask opens_m = swing_keeps_m & (special_m | first_m); // (once per model, or never finite)
+        if (opens_m) {
+            if (in_lanes(opens_m & special_m)) // upper = lower = {value, value} (swing.rs:121-123)
                 upper_slope = upper_intercept = lower_slope = lower_intercept = value;
-            } else {
+            const LaneMask starts_m = opens_m & ~special_m;
+            if (in_lanes(starts_m)) {
                 swing_start = time;
                 swing_first = value;
-                swing_finite = value_finite;
             }
+            swing_finite_m = (swing_finite_m & ~starts_m) | (starts_m & value_finite_m);
         }
-        swing_length += swing_keeps ? 1u : 0u;
-        swing_fits = swing_fits & (!swing_steps | swing_accepts);
-        j += feeding ? 1u : 0u;
+        swing_length += in_lanes(swing_keeps_m) ? 1u : 0u;
+        swing_fits_m &= ~swing_steps_m | swing_accepts_m;
+        j += in_lanes(feeding_m) ? 1u : 0u;
 
-        const bool finishing = active & !feeding;
-        if (__any(finishing)) {
-            if (finishing) {
+        const LaneMask finishing_m = active_m & ~feeding_m;
+        if (finishing_m) {
+            bool ends = false; // this lane has no model left to fit
+            if (in_lanes(finishing_m)) {
                 // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
                 const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc_length;
                 const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing_length;
@@ -1360,11 +1386,11 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
                 }
                 if (current >= n) {
                     if (!SPLIT) plans[chunk] = {n_models, gaps.finish(n)};
-                    active = false;
+                    ends = true;
                 } else if (SPLIT && current >= piece_end &&
                            __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    active = false; // some lane has been here: the chain from this point on is recorded
+                    ends = true; // some lane has been here: the chain from this point on is recorded
                 } else {
                     pmc_min = nan32;
                     pmc_max = nan32;
@@ -1376,12 +1402,15 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
                     numerator = 0.0;
                     denominator = 0.0;
                     swing_length = 0;
-                    swing_finite = false;
-                    pmc_fits = true;
-                    swing_fits = true;
                     j = current;
                 }
             }
+            const LaneMask ended_m = lanes_where(ends);
+            const LaneMask next_model_m = finishing_m & ~ended_m;
+            active_m &= ~ended_m;
+            pmc_fits_m |= next_model_m;
+            swing_fits_m |= next_model_m;
+            swing_finite_m &= ~next_model_m;
         }
     }
 }
