@@ -676,6 +676,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
 // is in the descriptor), a PMC-Mean value does not depend on the timestamp, MacaqueV values and
 // residuals are written later by k_grid_serial.
 constexpr uint32_t TS_STAGE_POINTS = 1536;
+constexpr uint32_t TS_MAX_RUNS = 2 * TS_STAGE_POINTS / (3 * MDB_WAVE); // arithmetic runs of a piece that fit into the wave's buffer (16)
 constexpr int TS_THREADS = 128;
 constexpr int TS_PIECE_CHUNKS = 4; // 16-byte chunks parked per piece: 127 + 255 + 69 + 32 bits at most
 
@@ -684,8 +685,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
     const uint32_t *__restrict__ irregular_totals, const uint32_t *__restrict__ irregular_first,
     const uint32_t *__restrict__ counts, TsCheckpoints checkpoints, uint64_t n_pieces,
     int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
-    __shared__ uint32_t stage_ts[TS_THREADS / MDB_WAVE][TS_STAGE_POINTS];
-    __shared__ float stage_val[TS_THREADS / MDB_WAVE][TS_STAGE_POINTS];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[TS_THREADS / MDB_WAVE][2 * TS_STAGE_POINTS]; // timestamps, then values; or the runs
     __shared__ uint4 parked[TS_THREADS / MDB_WAVE][TS_PIECE_CHUNKS][MDB_WAVE];
     const int lane = threadIdx.x % MDB_WAVE, wave = threadIdx.x / MDB_WAVE;
     const uint64_t slot = (uint64_t)blockIdx.x * TS_THREADS + threadIdx.x;
@@ -770,14 +770,164 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
     const int64_t lane_base = from.timestamp; // (piece 0: the start time)
     const int64_t base_time = (int64_t)(__shfl((uint32_t)((uint64_t)lane_base >> 32), leader, MDB_WAVE) * 0x100000000ull +
                                         __shfl((uint32_t)lane_base, leader, MDB_WAVE));
-    bool staged = wave_total <= TS_STAGE_POINTS && !__any(mine > 0 && out_first != wave_first + before);
+    const bool consecutive = !__any(mine > 0 && out_first != wave_first + before);
+    bool staged = wave_total <= TS_STAGE_POINTS && consecutive;
 
     const TileDesc d = present ? desc[i] : TileDesc{};
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     // d.n_model counts the VISIBLE points the model stands for; they are the first ones.
     const uint32_t model_end = first + d.n_model;
-    uint32_t *my_ts = stage_ts[wave];
-    float *my_val = stage_val[wave];
+    uint32_t *my_ts = stage[wave];
+    float *my_val = reinterpret_cast<float *>(stage[wave] + TS_STAGE_POINTS);
+    // A wave with more points than its buffer holds has long runs of `0` codes in its pieces (hundreds of
+    // points per piece). A `0` code repeats the delta, so the points between two other codes are an
+    // arithmetic run: the lanes decode their pieces into (first index, first timestamp, delta) triples, a
+    // handful per piece, and then the whole wave writes the points of all the runs, 64 consecutive ones
+    // per store instruction, each lane computing its point from the run it lies in. (A timestamp or a
+    // delta that does not fit into 32 bits, or more than TS_MAX_RUNS runs in a piece: direct stores.)
+    if (wave_total > TS_STAGE_POINTS) {
+        // run r of the lane is runs[(lane * TS_MAX_RUNS + r) * 3 ..]: the index of its first point in the
+        // stream, that point's distance from the lane's base time, the delta.
+        uint32_t *runs = stage[wave];
+        uint32_t n_runs = 0;
+        bool unfit = false;
+        auto open_run = [&](uint32_t k_first, int64_t t, uint64_t delta) {
+            const uint64_t distance = (uint64_t)(t - lane_base);
+            unfit |= distance > 0xffffffffull || delta > 0xffffffffull || n_runs >= TS_MAX_RUNS;
+            if (unfit) return;
+            uint32_t *run = runs + ((uint32_t)lane * TS_MAX_RUNS + n_runs) * 3u;
+            run[0] = k_first;
+            run[1] = (uint32_t)distance;
+            run[2] = (uint32_t)delta;
+            n_runs += 1;
+        };
+        if (mine > 0) {
+            if (piece == 0) open_run(0u, from.timestamp, 0ull); // point 0 is the start time
+            if (has_code && from.count < run_end) {
+                const uint32_t codes_end = min(run_end, last_of_stream ? n_total - 1u : next_count);
+                uint32_t next_word = first_bit >> 5;
+                uint64_t buffer = (((uint64_t)word(next_word) << 32) | word(next_word + 1)) << (first_bit & 31u);
+                int32_t available = 64 - (int32_t)(first_bit & 31u);
+                next_word += 2;
+                auto refill = [&]() { // at least 33 bits afterwards, without a branch
+                    const bool want = available <= 32;
+                    const uint64_t placed = (uint64_t)word(next_word) << ((32 - available) & 63);
+                    buffer |= want ? placed : 0ull;
+                    available += want ? 32 : 0;
+                    next_word += want ? 1u : 0u;
+                };
+                auto consume = [&](uint32_t bits) {
+                    buffer <<= bits;
+                    available -= (int32_t)bits;
+                };
+                int64_t timestamp = from.timestamp;
+                uint64_t last_delta = from.last_delta;
+                uint32_t k = from.count;
+                bool in_run = false; // the points being produced belong to the run opened last
+                while (k < codes_end) {
+                    refill();
+                    const uint32_t top = (uint32_t)(buffer >> 32);
+                    if (top < 0x00800000u) { // nine `0` codes or more: the delta repeats
+                        uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
+                        run = min(run, codes_end - k);
+                        consume(run);
+                        if (!in_run) open_run(k, (int64_t)((uint64_t)timestamp + last_delta), last_delta);
+                        in_run = true;
+                        timestamp = (int64_t)((uint64_t)timestamp + (uint64_t)run * last_delta);
+                        k += run;
+                        continue;
+                    }
+                    const uint32_t ones = (uint32_t)__clz((int)~top);
+                    uint32_t length = 0;
+                    bool repeats = false; // a single `0` code
+                    if (ones >= 4) {
+                        consume(5); // `11110` + 32 bits or `11111` + 64 bits
+                        refill();
+                        uint64_t encoded = (uint32_t)(buffer >> 32);
+                        consume(32);
+                        if (ones >= 5) {
+                            refill();
+                            encoded = (encoded << 32) | (uint32_t)(buffer >> 32);
+                            consume(32);
+                            last_delta += encoded;
+                        } else {
+                            last_delta += encoded > (1ull << 31) ? (encoded | (~0ull << 32)) : encoded;
+                        }
+                    } else {
+                        int32_t delta_of_delta;
+                        length = ts_short_code(top, ones, &delta_of_delta);
+                        last_delta += (uint64_t)(int64_t)delta_of_delta;
+                        repeats = ones == 0;
+                    }
+                    consume(length);
+                    timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+                    if (!(repeats && in_run)) open_run(k, timestamp, last_delta);
+                    in_run = true;
+                    k += 1;
+                }
+                if (last_of_stream && run_end == n_total) open_run(n_total - 1u, end_time, 0ull);
+            }
+        }
+        if (!__any(unfit)) {
+            // What the other lanes have to know about a piece takes the place of the parked bytes (16 words
+            // per piece, word w of piece q at meta[w * 64 + q]); then every lane walks the wave's points 64
+            // apart.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t *meta = reinterpret_cast<uint32_t *>(&parked[wave][0][0]);
+            auto put = [&](int w, uint32_t value) { meta[w * MDB_WAVE + lane] = value; };
+            auto put64 = [&](int w, uint64_t value) {
+                put(w, (uint32_t)value);
+                put(w + 1, (uint32_t)(value >> 32));
+            };
+            put(0, before);
+            put(1, n_runs);
+            put(2, run_first);
+            put(3, type == MDB_SWING_ID ? model_end : 0u); // (up to where a Swing value is computed)
+            put(4, model_end);                             // (and up to where the value is d.value otherwise)
+            put(5, __float_as_uint(d.value));
+            put64(6, out_first);
+            put64(8, (uint64_t)lane_base);
+            put64(10, (uint64_t)__double_as_longlong(d.slope));
+            put64(12, (uint64_t)__double_as_longlong(d.intercept));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            auto get = [&](int w, uint32_t q) { return meta[w * MDB_WAVE + q]; };
+            auto get64 = [&](int w, uint32_t q) { return (uint64_t)get(w, q) | ((uint64_t)get(w + 1, q) << 32); };
+            // (Four consecutive points per lane share the search for their run, but a lane storing its own
+            // four writes a quarter of a cache line per instruction: 7.4 ms instead of 5.0 for 10^9 points;
+            // through a slab in LDS the stores are as here, but the slab's room leaves 12 runs per piece
+            // instead of 16, and a wave with a 13-run piece - nearly every wave at one gap per 100 points -
+            // stores directly.)
+            uint32_t q = 0; // the piece point p lies in: the last one that starts at or before it
+            for (uint32_t p = (uint32_t)lane; p < wave_total; p += MDB_WAVE) {
+                while (q + 1 < MDB_WAVE && get(0, q + 1) <= p) q += 1;
+                const uint32_t k = get(2, q) + (p - get(0, q)); // index of the point in its stream
+                // The last run of the piece that starts at or before k.
+                const uint32_t *piece_runs = runs + q * TS_MAX_RUNS * 3u;
+                uint32_t lo = 0, hi = get(1, q);
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (piece_runs[mid * 3u] <= k) lo = mid;
+                    else hi = mid;
+                }
+                const uint32_t *run = piece_runs + lo * 3u;
+                const int64_t t = (int64_t)(get64(8, q) + run[1] + (uint64_t)(k - run[0]) * run[2]);
+                float value = 0.0f;
+                if (k < get(3, q))
+                    value = (float)(__longlong_as_double((long long)get64(10, q)) * (double)t +
+                                    __longlong_as_double((long long)get64(12, q)));
+                else if (k < get(4, q))
+                    value = __uint_as_float(get(5, q));
+                const uint64_t at = get64(6, q) + (p - get(0, q));
+                if (out_ts) out_ts[at] = t;
+                out_val[at] = value;
+            }
+            return;
+        }
+    }
     bool too_far = false;  // a timestamp does not fit into 32 bits from base_time: the wave stores directly
     int64_t held = 0;      // (direct stores) timestamp of an even output position waiting for its neighbour
     bool holding = false;

@@ -306,7 +306,7 @@ def test_grid_with_pushed_down_time_range(hip, eb_name, irregular):
         assert metrics["rows_created"] == len(exp_ts)
 
 
-@pytest.mark.parametrize("gap_probability", [0.0005, 0.02, 0.5])
+@pytest.mark.parametrize("gap_probability", [0.0005, 0.005, 0.01, 0.02, 0.5])
 def test_mostly_regular_timestamps_with_gaps(hip, gap_probability):
     # What irregular timestamps usually are: a fixed sampling interval with a sample missing now and
     # then. One gap makes a whole segment irregular (timestamps.rs:77-96) and its stream then consists
@@ -334,6 +334,31 @@ def test_mostly_regular_timestamps_with_gaps(hip, gap_probability):
         got, expected = hip.agg_batch(segments, mask), ora.agg_batch(segments, mask)
         assert (got.count, got.min, got.max) == (expected.count, expected.min, expected.max)
         assert abs(got.sum - expected.sum) <= 1e-5 * abs(expected.sum)
+
+
+def test_fixed_rate_series_with_a_few_very_long_gaps(hip):
+    # Long runs of `0` codes are written as arithmetic runs by the whole wave (k_grid_timestamps), staged as
+    # 32-bit distances and deltas: a gap of hours (a delta beyond 2^32 microseconds) or a piece that starts
+    # more than 2^32 microseconds behind its stream's checkpoint must fall back to stores of 64-bit values.
+    rng = np.random.default_rng(172)
+    n = 200_000
+    deltas = np.full(n, 1000, dtype=np.int64)
+    deltas[rng.integers(1000, n - 1000, 6)] = 7_200_000_000        # two hours
+    deltas[rng.integers(1000, n - 1000, 40)] = 4_294_967_296 + 7   # just beyond 32 bits
+    deltas[rng.integers(1000, n - 1000, 200)] = 5000
+    timestamps = 1_600_000_000_000_000 + np.cumsum(deltas)
+    values = (20 + 3 * np.sin(np.arange(n) / 900.0) + rng.uniform(-0.01, 0.01, n)).astype(np.float32)
+    offsets = np.arange(0, n + 1, 50_000, dtype=np.uint64)
+    for eb_name in ("rel1", "lossless"):
+        segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()[eb_name])
+        got = hip.grid_batch(segments)
+        cases.assert_grid_equal(got, ora.grid_batch(segments))
+        assert np.array_equal(got[0], timestamps)
+        t_lo, t_hi = int(timestamps[70_001]), int(timestamps[160_000])
+        exp_ts, exp_values, exp_rows = _expected_range(segments, t_lo, t_hi)
+        ts, reconstructed, rows, _ = hip.grid_batch_range(segments, t_lo, t_hi)
+        assert np.array_equal(ts, exp_ts) and np.array_equal(rows, exp_rows)
+        assert np.array_equal(reconstructed.view(np.uint32), exp_values.view(np.uint32))
 
 
 def test_grid_time_range_edge_cases(hip):
