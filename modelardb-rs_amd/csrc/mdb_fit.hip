@@ -1078,8 +1078,15 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
 // may start at any float, so groups are counted from the 16-byte boundary below its first value).
 // Same records, same bytes as k_fit_models: every fit test runs both (MDB_FIT_LEAN=0 selects the
 // other).
-constexpr int LEAN_GROUPS = 8;        // 16-byte groups per lane in the ring (32 points)
-constexpr int LEAN_LOADS = 6;         // groups fetched per top-up at most; 2 groups of history stay
+#ifndef MDB_LEAN_GROUPS
+#define MDB_LEAN_GROUPS 8
+#endif
+#ifndef MDB_LEAN_LOADS
+#define MDB_LEAN_LOADS 6
+#endif
+constexpr int LEAN_GROUPS = MDB_LEAN_GROUPS; // 16-byte groups per lane in the ring (32 points)
+constexpr int LEAN_LOADS = MDB_LEAN_LOADS;   // groups fetched per top-up at most; 2 groups of history stay
+static_assert(LEAN_LOADS + 2 <= LEAN_GROUPS, "a top-up must leave two groups of history in the ring");
 constexpr int LEAN_TRASH = LEAN_GROUPS; // ring row that takes the stores nobody wants
 
 // One bit per lane of the wave, the same value in every lane (so: scalar registers).
