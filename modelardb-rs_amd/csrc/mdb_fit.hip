@@ -141,25 +141,37 @@ __global__ __launch_bounds__(256) void k_fit_regular(const int64_t *__restrict__
                                                      long long *__restrict__ chunk_interval,
                                                      unsigned int *__restrict__ chunk_irregular,
                                                      unsigned int *__restrict__ n_irregular) {
-    __shared__ int irregular;
+    // n_irregular[1] counts the chunks with a timestamp beyond +-2^52: below that every timestamp and every
+    // difference of two is exactly an f64, which the straight-line fitter relies on (SwingFast).
+    __shared__ int irregular, beyond;
     const uint64_t chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
-    if (threadIdx.x == 0) irregular = 0;
+    if (threadIdx.x == 0) {
+        irregular = 0;
+        beyond = 0;
+    }
     __syncthreads();
     const uint64_t base = chunk_offsets[chunk];
     const uint64_t n = chunk_offsets[chunk + 1] - base;
     const int64_t *__restrict__ t = ts + base;
     const int64_t first = n > 0 ? t[0] : 0;
     const int64_t interval = n > 1 ? t[1] - t[0] : 0;
-    bool mine = false;
-    for (uint64_t j = 2 + threadIdx.x; j < n; j += blockDim.x) mine = mine || (t[j] - t[j - 1] != interval);
+    const int64_t exact_limit = 1ll << 52;
+    bool mine = false, far = false;
+    for (uint64_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const int64_t here = t[j];
+        far = far || here > exact_limit || here < -exact_limit;
+        if (j >= 2) mine = mine || (here - t[j - 1] != interval);
+    }
     if (mine) irregular = 1;
+    if (far) beyond = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         chunk_first[chunk] = first;
         chunk_interval[chunk] = interval;
         chunk_irregular[chunk] = irregular ? 1u : 0u;
         if (irregular) atomicAdd(n_irregular, 1u);
+        if (beyond) atomicAdd(n_irregular + 1, 1u);
     }
 }
 
@@ -1087,7 +1099,6 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
 constexpr int LEAN_GROUPS = MDB_LEAN_GROUPS; // 16-byte groups per lane in the ring (32 points)
 constexpr int LEAN_LOADS = MDB_LEAN_LOADS;   // groups fetched per top-up at most; 2 groups of history stay
 static_assert(LEAN_LOADS + 2 <= LEAN_GROUPS, "a top-up must leave two groups of history in the ring");
-constexpr int LEAN_TRASH = LEAN_GROUPS; // ring row that takes the stores nobody wants
 
 // One bit per lane of the wave, the same value in every lane (so: scalar registers).
 using LaneMask = unsigned long long;
@@ -1118,18 +1129,28 @@ __device__ __forceinline__ LaneMask lean_passes(const PmcFast &f, float real_val
     return usable & lanes_where(difference <= pass_bound - average_error);
 }
 
+template <int GROUPS>
 __device__ __forceinline__ float ring_value(const float4 (*ring)[MDB_WAVE], int lane, uint32_t position) {
-    return reinterpret_cast<const float *>(&ring[(position >> 2) % LEAN_GROUPS][lane])[position & 3u];
+    return reinterpret_cast<const float *>(&ring[(position >> 2) % GROUPS][lane])[position & 3u];
 }
 
-template <bool SPLIT, int KIND>
+// HAS_TS: timestamps are loaded (irregular series, k_fit_regular has found all of them within +-2^52, so that
+// (f64)t and differences of such are exact: SwingFast's arithmetic on SwingDev's inputs). Their ring holds
+// pairs; with 24 bytes per point and lane instead of 4 the rings are half as long, so that as many waves
+// fit into a CU.
+template <bool SPLIT, int KIND, bool HAS_TS = false>
 __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, SplitArgs split,
                                                                 const unsigned long long *__restrict__ record_base,
                                                                 ModelRec *__restrict__ records,
                                                                 ChunkPlan *__restrict__ plans,
                                                                 unsigned int *__restrict__ error) {
     static_assert(KIND == MDB_EB_RELATIVE || KIND == MDB_EB_ABSOLUTE, "lossless data has its own shortcuts");
+    constexpr int LEAN_GROUPS = HAS_TS ? 4 : mdb::LEAN_GROUPS; // (shadow the constants of the values-only form)
+    constexpr int LEAN_LOADS = HAS_TS ? 2 : mdb::LEAN_LOADS;
+    constexpr int LEAN_TRASH = LEAN_GROUPS;
     __shared__ float4 ring[LEAN_GROUPS + 1][MDB_WAVE];
+    // Timestamps of the points of value group g: pairs 2g and 2g + 1 (row 2 * LEAN_GROUPS and the one behind it: trash).
+    __shared__ longlong2 ring_ts[HAS_TS ? 2 * LEAN_GROUPS + 2 : 1][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t unit = (uint64_t)blockIdx.x * FIT_THREADS + lane;
     uint64_t chunk = unit;
@@ -1169,6 +1190,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     const uint32_t last_group = active ? (n - 1 + misalign) >> 2 : 0u;
     const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, active ? chunk : 0, base);
     const double first_time = (double)regular_ts.first, interval_time = (double)regular_ts.interval; // exact
+    const int64_t *__restrict__ chunk_ts = HAS_TS ? args.timestamps.ts + (active ? base : 0) : nullptr;
     const mdb_error_bound eb = args.eb;
     const PmcFast pmc_fast = pmc_fast_constants(eb);
     const double deviation_factor_value = deviation_factor(eb).factor;
@@ -1190,6 +1212,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     double swing_start = 0.0, swing_first = nan64;
     double upper_slope = nan64, upper_intercept = nan64, lower_slope = nan64, lower_intercept = nan64;
     double numerator = 0.0, denominator = 0.0;
+    double swing_end = 0.0; // (HAS_TS) time of the last point the model has accepted
     uint32_t swing_length = 0;
     // What is true of which lane is kept as 64-bit lane masks: they are the same for the whole wave, so
     // they live in scalar registers and `and`, `or`, `not` of conditions are scalar instructions. (As
@@ -1216,17 +1239,36 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             // Two groups behind the current one stay (a rejected model restarts at most 7 points back).
             const uint32_t end_group = lane_active ? min(group + (uint32_t)LEAN_LOADS, last_group + 1u) : first_group;
             float4 fetched[LEAN_LOADS];
+            long long fetched_ts[HAS_TS ? LEAN_LOADS : 1][4];
 #pragma unroll
-            for (int k = 0; k < LEAN_LOADS; k++) fetched[k] = groups[min(first_group + (uint32_t)k, last_group)];
+            for (int k = 0; k < LEAN_LOADS; k++) {
+                const uint32_t g = min(first_group + (uint32_t)k, last_group);
+                fetched[k] = groups[g];
+                if (HAS_TS) {
+                    // The four points of the group, the chunk's first or last one where the group reaches
+                    // beyond it (a chunk may start and end anywhere in its first and last group).
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t slot = 4u * g + (uint32_t)q;
+                        const uint32_t index = slot < misalign ? 0u : min(slot - misalign, n - 1u);
+                        fetched_ts[k][q] = (active && n > 0) ? chunk_ts[index] : 0ll;
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < LEAN_LOADS; k++) {
                 const uint32_t g = first_group + (uint32_t)k;
                 ring[g < end_group ? g % LEAN_GROUPS : (uint32_t)LEAN_TRASH][lane] = fetched[k];
+                if (HAS_TS) {
+                    const uint32_t row = g < end_group ? 2u * (g % LEAN_GROUPS) : 2u * (uint32_t)LEAN_GROUPS;
+                    ring_ts[row][lane] = make_longlong2(fetched_ts[k][0], fetched_ts[k][1]);
+                    ring_ts[row + 1][lane] = make_longlong2(fetched_ts[k][2], fetched_ts[k][3]);
+                }
             }
             loaded_group = max(first_group, end_group);
             if (loaded_group > low_group + LEAN_GROUPS) low_group = loaded_group - LEAN_GROUPS;
         }
-        const float value32 = ring_value(ring, lane, position);
+        const float value32 = ring_value<LEAN_GROUPS>(ring, lane, position);
         const double value = (double)value32;
 
         // ---- PMC-Mean: PMCMean::fit_value (pmc_mean.rs:58-76), decided as in pmc_fit_fast ----
@@ -1268,8 +1310,15 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
 
         // ---- Swing: Swing::fit_data_point (swing.rs:101-198) on exact f64 timestamps (SwingFast) ----
         const LaneMask swing_steps_m = feeding_m & swing_fits_m;
-        // first + j * interval: integers below 2^53, exact whether fused or not.
-        const double time = __builtin_fma((double)j, interval_time, first_time);
+        // first + j * interval: integers below 2^53, exact whether fused or not. (HAS_TS: the timestamp
+        // itself, exact for the same reason.)
+        double time;
+        if (HAS_TS) {
+            const longlong2 pair = ring_ts[(position >> 1) % (2 * LEAN_GROUPS)][lane];
+            time = (double)((position & 1u) ? pair.y : pair.x);
+        } else {
+            time = __builtin_fma((double)j, interval_time, first_time);
+        }
         const double deviation = lean_deviation<KIND>(deviation_factor_value, value);
         const LaneMask first_m = lanes_where(swing_length == 0), second_m = lanes_where(swing_length == 1);
         const LaneMask later_m = ~(first_m | second_m);
@@ -1345,6 +1394,12 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             }
             swing_finite_m = (swing_finite_m & ~starts_m) | (starts_m & value_finite_m);
         }
+        if (HAS_TS) { // SwingDev::end_time: the model's last point is no longer (length - 1) intervals from its first
+            if (in_lanes(swing_keeps_m)) {
+                keep_under_mask();
+                swing_end = time;
+            }
+        }
         swing_length += in_lanes(swing_keeps_m) ? 1u : 0u;
         swing_fits_m &= ~swing_steps_m | swing_accepts_m;
         j += in_lanes(feeding_m) ? 1u : 0u;
@@ -1370,7 +1425,8 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
                         rec.end = current + swing_length - 1;
                         const double projected = numerator / denominator;
                         const double slope = max_num(lower_slope, min_num(projected, upper_slope));
-                        const double last_value = slope * ((double)(swing_length - 1) * interval_time) + swing_first;
+                        const double span = HAS_TS ? swing_end - swing_start : (double)(swing_length - 1) * interval_time;
+                        const double last_value = slope * span + swing_first;
                         rec.p0 = (float)swing_first;
                         rec.p1 = (float)last_value;
                     }
@@ -2270,23 +2326,23 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     if (n_chunks > 0) {
         unsigned long long points_end = 0;
         // Materialised timestamps: are they all equally spaced? (answer read with the sync below)
-        unsigned int n_irregular_chunks = 1;
+        unsigned int regular_verdict[2] = {1u, 1u}; // irregular chunks, chunks with a timestamp beyond +-2^52
         long long *chunk_first = nullptr, *chunk_interval = nullptr;
         unsigned int *chunk_irregular = nullptr;
         if (ts && n_chunks <= 0x7fffffffull) {
-            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_REGULAR, n_chunks * 20 + 64, &p));
+            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_REGULAR, n_chunks * 20 + 128, &p));
             chunk_first = static_cast<long long *>(p);
             chunk_interval = chunk_first + n_chunks;
             chunk_irregular = reinterpret_cast<unsigned int *>(chunk_interval + n_chunks);
-            unsigned int *counter = chunk_irregular + n_chunks;
-            FIT_CHECK(hipMemsetAsync(counter, 0, 4, ctx->stream));
+            unsigned int *counter = chunk_irregular + n_chunks; // [0] irregular chunks, [1] chunks beyond +-2^52
+            FIT_CHECK(hipMemsetAsync(counter, 0, 8, ctx->stream));
             {
                 LaunchTimer timer(ctx, "k_fit_regular");
                 hipLaunchKernelGGL(k_fit_regular, dim3((uint32_t)n_chunks), dim3(256), 0, ctx->stream, ts,
                                    args.chunk_offsets, n_chunks, chunk_first, chunk_interval, chunk_irregular,
                                    counter);
             }
-            FIT_CHECK(hipMemcpyAsync(&n_irregular_chunks, counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+            FIT_CHECK(hipMemcpyAsync(regular_verdict, counter, 8, hipMemcpyDeviceToHost, ctx->stream));
         }
         FIT_TRY(device_exclusive_scan(ctx, RecordCapacity{args.chunk_offsets}, n_chunks, record_base,
                                       block_sums, "k_fit_scan"));
@@ -2295,6 +2351,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         FIT_CHECK(hipMemcpyAsync(&points_end, args.chunk_offsets + n_chunks, 8, hipMemcpyDeviceToHost,
                                  ctx->stream));
         FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        const unsigned int n_irregular_chunks = regular_verdict[0];
         if (ts && n_irregular_chunks == 0) {
             // Every chunk is regular: from here on timestamps are computed, not loaded.
             args.timestamps.ts = nullptr;
@@ -2317,6 +2374,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             fast = inexact == 0;
         }
         const bool lean = fast && fit_lean_setting() && eb.kind != MDB_EB_LOSSLESS;
+        // Timestamps that have to be loaded (some chunk is irregular), all of them exact as f64: the
+        // straight-line fitter with a ring of timestamps.
+        const bool lean_ts = ts && chunk_irregular && regular_verdict[1] == 0 && fit_fast_setting() &&
+                             fit_lean_setting() && eb.kind != MDB_EB_LOSSLESS;
         const uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
         ModelRec *records = static_cast<ModelRec *>(p);
@@ -2328,7 +2389,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         if (piece_points == 0) {
             LaunchTimer timer(ctx, "k_fit_models");
             const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
-            if (ts)
+            if (lean_ts && eb.kind == MDB_EB_RELATIVE)
+                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_RELATIVE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+            else if (lean_ts)
+                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_ABSOLUTE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+            else if (ts)
                 hipLaunchKernelGGL((k_fit_models<true, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
             else if (lean && eb.kind == MDB_EB_RELATIVE)
@@ -2365,7 +2432,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             if (n_pieces > 0) {
                 LaunchTimer timer(ctx, "k_fit_models_split");
                 const uint32_t fit_blocks = (uint32_t)((n_pieces + FIT_THREADS - 1) / FIT_THREADS);
-                if (ts)
+                if (lean_ts && eb.kind == MDB_EB_RELATIVE)
+                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_RELATIVE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else if (lean_ts)
+                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_ABSOLUTE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
+                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else if (ts)
                     hipLaunchKernelGGL((k_fit_models<true, true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                        ctx->stream, args, split, record_base, records, plans, error_flag);
                 else if (lean && eb.kind == MDB_EB_RELATIVE)
