@@ -383,3 +383,21 @@ def test_fit_regular_and_irregular_chunks_in_one_call(hip):
     regular = np.concatenate(regular)
     assert_same_segments(hip.compress_chunks(regular, values, offsets, eb),
                          ora.compress_chunks(regular, values, offsets, eb))
+
+
+@pytest.mark.parametrize("origin", [(1 << 52) - 3_000_000, -(1 << 52) - 40_000, 1 << 60, -(1 << 62)])
+def test_fit_irregular_timestamps_around_and_beyond_the_exact_f64_range(hip, origin):
+    # The straight-line fitter computes with (f64)timestamp, which is the timestamp itself only up to 2^52 in
+    # magnitude (k_fit_regular checks every one); a series that crosses that line, or lies far beyond it,
+    # must take the general kernel and still produce the oracle's segments. Chunks of odd lengths and
+    # starts, so that the timestamp ring's first and last groups are partial.
+    rng = np.random.default_rng(91)
+    lengths = [7001, 1, 2, 3, 4999, 13, 20_000]
+    n = sum(lengths)
+    timestamps = origin + np.cumsum(rng.integers(1, 3000, n)).astype(np.int64)
+    values = (10 + np.sin(np.arange(n) / 400.0) + rng.normal(0, 0.01, n)).astype(np.float32)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    for eb_name in ("rel1", "abs0.01"):
+        eb = cases.error_bounds()[eb_name]
+        assert_same_segments(hip.compress_chunks(timestamps, values, offsets, eb),
+                             ora.compress_chunks(timestamps, values, offsets, eb))
