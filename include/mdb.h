@@ -56,6 +56,11 @@ int mdb_set_stream(mdb_ctx *ctx, void *hip_stream);
  * released_bytes (may be NULL): device bytes given back. Results and segments already handed out
  * stay valid. */
 int mdb_trim(mdb_ctx *ctx, uint64_t *released_bytes);
+/* The same, automatically: after every call on this context, device scratch beyond `bytes` is given back
+ * (largest allocations first; 0, the default, keeps everything). For owners of many contexts - one
+ * GridStream per field column - each of which would otherwise keep what its largest batch needed. A clone
+ * (mdb_clone) starts with the limit of the context it was made from. */
+int mdb_set_scratch_limit(mdb_ctx *ctx, uint64_t bytes);
 /* Name, CU count, HBM bytes of the context's device. */
 int mdb_device_info(mdb_ctx *ctx, char *name, uint64_t name_cap, int32_t *compute_units,
                     uint64_t *hbm_bytes);

@@ -128,6 +128,7 @@ _HIP_SYMBOLS = {
     "mdb_version": (C.c_char_p, []),
     "mdb_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdb_trim": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mdb_set_scratch_limit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mdb_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_uint64)]),
     "mdb_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -114,6 +114,10 @@ class Context:
         self._check(self.lib.mdb_trim(self.handle, C.byref(released)))
         return released.value
 
+    def set_scratch_limit(self, nbytes):
+        """Device scratch beyond `nbytes` is given back after every call (0: keep everything)."""
+        self._check(self.lib.mdb_set_scratch_limit(self.handle, C.c_uint64(nbytes)))
+
     # ---- device memory -----------------------------------------------------------------------
 
     def dev_alloc(self, nbytes):

@@ -529,7 +529,7 @@ extern "C" {
 int mdb_agg_batch_dev(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask,
                       mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return agg_run(ctx, in, false, 0, 0, which_mask, inout);
 }
@@ -537,14 +537,14 @@ int mdb_agg_batch_dev(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask,
 int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                             uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return agg_run(ctx, in, true, t_lo, t_hi, which_mask, inout);
 }
 
 int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
@@ -556,7 +556,7 @@ int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb
 int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                         uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;

@@ -112,7 +112,7 @@ int mdb_comm_unique_id(void *id_out) {
 int mdb_comm_init(mdb_ctx *ctx, int32_t rank, int32_t world, const void *unique_id) {
     if (!ctx || !unique_id) return fail("ctx and unique_id must not be NULL.");
     if (world < 1 || rank < 0 || rank >= world) return fail("rank must be in [0, world).");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (ctx->comm) return fail("The context already has a communicator.");
     const Rccl *nccl = rccl();
     if (!nccl) return 1;
@@ -129,7 +129,7 @@ int mdb_comm_init(mdb_ctx *ctx, int32_t rank, int32_t world, const void *unique_
 
 int mdb_comm_close(mdb_ctx *ctx) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (!ctx->comm) return 0;
     const Rccl *nccl = rccl();
     if (!nccl) return 1;
@@ -144,7 +144,7 @@ int mdb_comm_close(mdb_ctx *ctx) {
 
 int mdb_agg_all_reduce(mdb_ctx *ctx, mdb_agg_state *inout, int32_t *ranks_seen) {
     if (!ctx || !inout) return fail("ctx and inout must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (!ctx->comm) return fail("mdb_comm_init has not been called on this context.");
     const Rccl *nccl = rccl();
     if (!nccl) return 1;

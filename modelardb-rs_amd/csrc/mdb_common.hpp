@@ -107,6 +107,7 @@ struct mdb_ctx {
 
     std::shared_ptr<mdb::PinnedPool> pinned_pool = std::make_shared<mdb::PinnedPool>();
     bool owns_pinned_pool = true; // false for a clone: it shares the pool of the context it was made from
+    uint64_t scratch_limit = 0;   // mdb_set_scratch_limit: device scratch kept between calls (0: all of it)
 
     // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).
     void *comm = nullptr;
@@ -127,6 +128,19 @@ void merge_agg_state(mdb_agg_state *into, const mdb_agg_state &from);
 // Grow-only device scratch, one allocation per slot.
 int scratch_reserve(mdb_ctx *ctx, ScratchSlot slot, uint64_t bytes, void **out);
 int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out);
+// The lock every entry point takes on its context. When the call is over it gives back device scratch beyond
+// the context's limit (mdb_set_scratch_limit), largest allocations first.
+void scratch_enforce_limit(mdb_ctx *ctx);
+struct CallGuard {
+    mdb_ctx *ctx;
+    explicit CallGuard(mdb_ctx *c) : ctx(c) { ctx->mutex.lock(); }
+    ~CallGuard() {
+        if (ctx->scratch_limit) scratch_enforce_limit(ctx);
+        ctx->mutex.unlock();
+    }
+    CallGuard(const CallGuard &) = delete;
+    CallGuard &operator=(const CallGuard &) = delete;
+};
 // mdb_segments_upload with ctx->mutex held; transient = into the context's upload scratch (mdb_ctx.hip).
 int upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool transient, mdb_segments_owned **out);
 int profile_collect(mdb_ctx *ctx);

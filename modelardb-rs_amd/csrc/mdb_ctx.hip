@@ -43,6 +43,23 @@ int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out) {
     return 0;
 }
 
+void scratch_enforce_limit(mdb_ctx *ctx) {
+    uint64_t total = 0;
+    for (int i = 0; i < SCRATCH_SLOT_COUNT; i++) total += ctx->scratch[i] ? ctx->scratch_bytes[i] : 0;
+    if (total <= ctx->scratch_limit) return;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+    while (total > ctx->scratch_limit) {
+        int largest = -1;
+        for (int i = 0; i < SCRATCH_SLOT_COUNT; i++)
+            if (ctx->scratch[i] && (largest < 0 || ctx->scratch_bytes[i] > ctx->scratch_bytes[largest])) largest = i;
+        if (largest < 0) break;
+        (void)hipFree(ctx->scratch[largest]);
+        total -= ctx->scratch_bytes[largest];
+        ctx->scratch[largest] = nullptr;
+        ctx->scratch_bytes[largest] = 0;
+    }
+}
+
 int PinnedPool::take(uint64_t bytes, void **out, uint64_t *capacity) {
     if (bytes == 0) bytes = 256;
     {
@@ -225,6 +242,7 @@ int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
     // per query, and a pool that died with it would pay hipHostMalloc for every block again.
     (*out)->pinned_pool = ctx->pinned_pool;
     (*out)->owns_pinned_pool = false;
+    (*out)->scratch_limit = ctx->scratch_limit;
     return 0;
 }
 
@@ -247,9 +265,16 @@ int mdb_close(mdb_ctx *ctx) {
     return 0;
 }
 
+int mdb_set_scratch_limit(mdb_ctx *ctx, uint64_t bytes) {
+    if (!ctx) return fail("ctx must not be NULL.");
+    mdb::CallGuard lock(ctx);
+    ctx->scratch_limit = bytes;
+    return 0;
+}
+
 int mdb_trim(mdb_ctx *ctx, uint64_t *released_bytes) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     uint64_t released = 0;
@@ -272,7 +297,7 @@ int mdb_trim(mdb_ctx *ctx, uint64_t *released_bytes) {
 
 int mdb_set_stream(mdb_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -305,7 +330,7 @@ int mdb_dev_alloc(mdb_ctx *ctx, uint64_t bytes, void **dev_ptr) {
 
 int mdb_dev_free(mdb_ctx *ctx, void *dev_ptr) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MDB_HIP_CHECK(hipFree(dev_ptr));
@@ -315,7 +340,7 @@ int mdb_dev_free(mdb_ctx *ctx, void *dev_ptr) {
 int mdb_dev_upload(mdb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes) {
     if (!ctx) return fail("ctx must not be NULL.");
     if (bytes == 0) return 0;
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -325,7 +350,7 @@ int mdb_dev_upload(mdb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t b
 int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes) {
     if (!ctx) return fail("ctx must not be NULL.");
     if (bytes == 0) return 0;
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -334,7 +359,7 @@ int mdb_dev_download(mdb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t
 
 int mdb_dev_sync(mdb_ctx *ctx) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -344,7 +369,7 @@ int mdb_dev_sync(mdb_ctx *ctx) {
 // columns, the three view arrays, every variadic data buffer, and three pointer tables.
 int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_owned **out) {
     if (!ctx || !host || !out) return fail("ctx, host and out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return mdb::upload_segments_locked(ctx, host, false, out);
 }
@@ -470,7 +495,7 @@ extern "C" {
 int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **out) {
     if (!ctx || !dev || !out) return fail("ctx, dev and out must not be NULL.");
     if (!dev->on_device) return fail("The batch is already in host memory.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     const mdb_segments &d = dev->seg;
     const uint64_t n = d.n;
@@ -595,7 +620,7 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
 
 int mdb_segments_validate_dev(mdb_ctx *ctx, const mdb_segments *dev) {
     if (!ctx || !dev) return fail("ctx and dev must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     const mdb_binview_col *cols[3] = {&dev->timestamps, &dev->values, &dev->residuals};
     if (dev->n == 0) return 0;
@@ -672,7 +697,7 @@ int mdb_are_compressed_timestamps_regular(const uint8_t *compressed_timestamps, 
 
 int mdb_profile_enable(mdb_ctx *ctx, int enabled) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (profile_collect(ctx)) return 1;
     ctx->profiling = enabled != 0;
     return 0;
@@ -680,7 +705,7 @@ int mdb_profile_enable(mdb_ctx *ctx, int enabled) {
 
 int mdb_profile_reset(mdb_ctx *ctx) {
     if (!ctx) return fail("ctx must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (profile_collect(ctx)) return 1;
     ctx->kernel_times.clear();
     return 0;
@@ -688,7 +713,7 @@ int mdb_profile_reset(mdb_ctx *ctx) {
 
 int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *total_ms) {
     if (!ctx || !name) return fail("ctx and name must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (profile_collect(ctx)) return 1;
     auto it = ctx->kernel_times.find(name);
     if (launches) *launches = it == ctx->kernel_times.end() ? 0 : it->second.launches;
@@ -698,7 +723,7 @@ int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *
 
 int mdb_profile_names(mdb_ctx *ctx, char *out, uint64_t cap) {
     if (!ctx || !out || cap == 0) return fail("ctx and out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     if (profile_collect(ctx)) return 1;
     std::string joined;
     for (auto &kv : ctx->kernel_times) {

@@ -2691,7 +2691,7 @@ int mdb_compress_chunks_dev(mdb_ctx *ctx, const int64_t *ts, const float *values
                             mdb_segments_owned **out) {
     if (!ctx || !out) return fail("ctx and out must not be NULL.");
     if (n_chunks > 0 && (!values || !chunk_offsets)) return fail("values and chunk_offsets must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return compress_chunks_dev_locked(ctx, ts, values, chunk_offsets, n_chunks, error_bound,
                                       regular_start, regular_interval, series_first_index, out);
@@ -2710,7 +2710,7 @@ int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
     int rc = 0;
     void *dev_ts = nullptr, *dev_values = nullptr, *dev_offsets = nullptr;
     {
-        std::lock_guard<std::mutex> lock(ctx->mutex);
+        mdb::CallGuard lock(ctx);
         MDB_HIP_CHECK(hipSetDevice(ctx->device));
         auto upload = [&](void **dst, const void *src, uint64_t bytes) {
             if (rc) return;
@@ -2763,7 +2763,7 @@ int mdb_split_and_compress_univariate(mdb_ctx *ctx, const int64_t *ts, const flo
     void *dev_ts = nullptr, *dev_values = nullptr, *dev_offsets = nullptr;
     int rc = 0;
     {
-        std::lock_guard<std::mutex> lock(ctx->mutex);
+        mdb::CallGuard lock(ctx);
         MDB_HIP_CHECK(hipSetDevice(ctx->device));
         const uint64_t offsets[2] = {0, n};
         if (hipMalloc(&dev_ts, n ? 8 * n : 256) != hipSuccess || hipMalloc(&dev_values, n ? 4 * n : 256) != hipSuccess ||

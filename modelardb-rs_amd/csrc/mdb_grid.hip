@@ -1971,7 +1971,7 @@ int grid_count_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
 
 int grid_count_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
     if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return grid_count_dev_locked(ctx, in, range, n_out);
 }
@@ -1981,7 +1981,7 @@ int grid_batch_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, i
                         mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
     if (cap > 0 && !out_val) return fail("out_val must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     return grid_batch_dev_locked(ctx, in, range, out_ts, out_val, out_rows_per_segment, cap, n_out,
                                  metrics);
@@ -1989,7 +1989,7 @@ int grid_batch_dev_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, i
 
 int grid_count_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, uint64_t *n_out) {
     if (!ctx || !in || !n_out) return fail("ctx, in and n_out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
@@ -2003,7 +2003,7 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
                          mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
     if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
@@ -2047,7 +2047,7 @@ struct OwnedGridResult {
 int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, bool values_only,
                           uint64_t reserve_front, mdb_grid_result **out) {
     if (!ctx || !in || !out) return fail("ctx, in and out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;

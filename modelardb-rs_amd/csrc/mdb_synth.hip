@@ -89,7 +89,7 @@ using namespace mdb;
 extern "C" int mdb_synth_values_dev(mdb_ctx *ctx, float *out, uint64_t first_series,
                                     uint64_t n_series, uint64_t n_per_series, uint64_t seed) {
     if (!ctx || !out) return fail("ctx and out must not be NULL.");
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     const uint64_t total = n_series * n_per_series;
     if (total == 0) return 0;

@@ -78,6 +78,12 @@ impl Context {
         Ok(released)
     }
 
+    /// Device scratch beyond `bytes` is given back after every call on this context (0 keeps everything):
+    /// for owners of many contexts, e.g. one `GridStream` per field column.
+    pub fn set_scratch_limit(&self, bytes: u64) -> Result<()> {
+        check(unsafe { sys::mdb_set_scratch_limit(self.raw(), bytes) })
+    }
+
     /// `ncclCommInitRank` for the final aggregate merge; `unique_id` comes from
     /// [`comm_unique_id`] on one rank.
     pub fn comm_init(&self, rank: i32, world: i32, unique_id: &[u8; sys::MDB_COMM_ID_BYTES]) -> Result<()> {

@@ -136,6 +136,7 @@ unsafe extern "C" {
     pub fn mdb_version() -> *const c_char;
     pub fn mdb_set_stream(ctx: *mut mdb_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn mdb_trim(ctx: *mut mdb_ctx, released_bytes: *mut u64) -> c_int;
+    pub fn mdb_set_scratch_limit(ctx: *mut mdb_ctx, bytes: u64) -> c_int;
     pub fn mdb_device_info(ctx: *mut mdb_ctx, name: *mut c_char, name_cap: u64, compute_units: *mut i32,
                            hbm_bytes: *mut u64) -> c_int;
 

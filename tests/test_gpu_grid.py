@@ -538,3 +538,26 @@ def test_concurrent_calls_from_several_threads(hip):
         assert not failures, failures
     for context in own_contexts:
         context.close()
+
+
+def test_scratch_limit_gives_memory_back_after_every_call():
+    # mdb_set_scratch_limit: a context keeps at most that much device scratch between calls (an owner of
+    # many contexts - one GridStream per field column - would otherwise keep what each one's largest
+    # batch needed until it calls mdb_trim). Results are what they are without the limit.
+    from modelardb_rs_amd import api
+    timestamps, values = cases.synthetic_series(400_000, False, (1.0, 1.05), seed=5)
+    batch = ora.try_compress_univariate_time_series(timestamps, values, cases.error_bounds()["rel1"])
+    expected = ora.grid_batch(batch)
+    unlimited, limited = api.Context(0), api.Context(0)
+    limited.set_scratch_limit(1 << 20)
+    for context in (unlimited, limited):
+        for _ in range(2):
+            cases.assert_grid_equal(context.grid_batch(batch), expected)
+    kept_unlimited, kept_limited = unlimited.trim(), limited.trim()
+    assert kept_unlimited > 4 * len(timestamps)          # the output staging alone is 12 bytes per point
+    assert kept_limited <= 1 << 20
+    limited.set_scratch_limit(0)
+    cases.assert_grid_equal(limited.grid_batch(batch), expected)
+    assert limited.trim() > 4 * len(timestamps)
+    unlimited.close()
+    limited.close()
