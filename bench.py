@@ -444,6 +444,19 @@ def main():
                 raise SystemExit("VERIFICATION FAILED: grid values differ from the oracle")
             grid_points_verified += n_piece
         del ts_cpu, val_cpu
+        # ... and at full size, a property that does not need the oracle: every one of the rank's series occupies
+        # exactly its block of the output, from its first to its last (visible) timestamp.
+        first_us = -(-step_lo // INTERVAL_US) * INTERVAL_US if ranged else 0
+        last_us = min(step_hi // INTERVAL_US, args.points - 1) * INTERVAL_US if ranged else (args.points - 1) * INTERVAL_US
+        per_series = (last_us - first_us) // INTERVAL_US + 1
+        if points_per_step != args.series * per_series:
+            raise SystemExit(f"VERIFICATION FAILED: {points_per_step} points per step, expected {args.series * per_series}")
+        for series_index in range(args.series):
+            block = series_index * per_series
+            edge = (int(context.download_array(out_ts, 1, np.int64, offset_elements=block)[0]),
+                    int(context.download_array(out_ts, 1, np.int64, offset_elements=block + per_series - 1)[0]))
+            if edge != (first_us, last_us):
+                raise SystemExit(f"VERIFICATION FAILED: series {series_index} starts / ends at {edge}")
         PHASES["verify_grid"] = time.perf_counter() - verify_started
         print(f"[bench] verify_grid: {PHASES['verify_grid']:.2f} s", file=sys.stderr, flush=True)
         verify_started = time.perf_counter()
@@ -473,9 +486,11 @@ def main():
                    "sample": f"{n_fit} series x {args.points} points, chunks sharded over {cores} pinned threads"}
         verified = {"fit_segments": len(fitted), "fit_points": n_fit * args.points,
                     "grid_points": grid_points_verified, "generator_points": len(host_defined),
+                    "series_blocks": args.series,
                     "how": "after the timed region: oracle fit of the sample series' exact bytes == GPU "
                            "segments (all columns, byte for byte); oracle grid of the sample == the device "
-                           "columns the timed step wrote (bit for bit); device generator == host definition"}
+                           "columns the timed step wrote (bit for bit); device generator == host definition; "
+                           "every series of the rank starts and ends its block of the output columns where it must"}
         PHASES["verify_fit_and_cpu_baseline_fit"] = time.perf_counter() - verify_started
         print(f"[bench] verify_fit_and_cpu_baseline_fit: {PHASES['verify_fit_and_cpu_baseline_fit']:.2f} s", file=sys.stderr, flush=True)
         if not args.no_host_path:
