@@ -254,9 +254,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     if (use_lds)
         for (uint32_t k = 1 + threadIdx.x; k < n_in_tile; k += TILE_THREADS)
             rel[k] = (uint32_t)(offsets[s0 + k] - tile_start);
-    for (uint32_t k = threadIdx.x; k < min(n_in_tile, (uint32_t)TILE_LDS_DESCS); k += TILE_THREADS)
-        lds_desc[k] = desc[s0 + k];
-    __syncthreads();
+    // A tile all of whose segments have their timestamps decoded by k_grid_timestamps is written there,
+    // values included: nothing to do here.
+    bool mine_are_left = n_in_tile <= (uint32_t)TILE_LDS_DESCS;
+    for (uint32_t k = threadIdx.x; k < min(n_in_tile, (uint32_t)TILE_LDS_DESCS); k += TILE_THREADS) {
+        const TileDesc d = desc[s0 + k];
+        lds_desc[k] = d;
+        mine_are_left = mine_are_left && (d.flags & FLAG_CHECKPOINTS) != 0;
+    }
+    if (__syncthreads_and(mine_are_left)) return;
     auto descriptor = [&](uint32_t k) -> TileDesc { // k relative to s0
         return k < TILE_LDS_DESCS ? lds_desc[k] : desc[s0 + k];
     };
@@ -271,6 +277,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
         const uint64_t p = wave_base + (uint64_t)lane * 4;
         int64_t t[4] = {0, 0, 0, 0};
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // Points of a segment whose timestamps k_grid_timestamps decodes are written by it, values included:
+        // where all 256 points of the wave's iteration are such points nothing is stored here.
+        bool left_to_timestamps = p >= tile_end;
         if (p < tile_end) {
             const uint32_t local = (uint32_t)(p - tile_start);
             // Largest k in [0, n_in_tile) with offsets[s0 + k] <= p.
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
             const uint32_t index = (uint32_t)(p - segment_offset);
             if (index + 4 <= d.n_points) {
                 // All four points in one segment: the common case.
+                left_to_timestamps = (d.flags & FLAG_CHECKPOINTS) != 0;
                 PointValue q0 = reconstruct_point(d, index);
                 t[0] = q0.t; t[1] = q0.t + d.delta; t[2] = t[1] + d.delta; t[3] = t[2] + d.delta;
                 if ((d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) {
@@ -322,6 +332,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
                 }
                 v = make_float4(values[0], values[1], values[2], values[3]);
             }
+        }
+        if (__all(left_to_timestamps)) continue; // (the same for the whole wave)
+        if (p < tile_end) {
             if (p + 4 <= tile_end) {
                 *reinterpret_cast<float4 *>(out_val + p) = v;
             } else {
@@ -946,7 +959,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
                 return;
             }
             const uint64_t at = out_first + (k - run_first);
-            if (type == MDB_SWING_ID && k < model_end) out_val[at] = value;
+            out_val[at] = value; // (k_grid_tiles leaves these points alone)
             if (!out_ts) return;
             if (at & 1ull) {
                 if (holding) {
