@@ -76,6 +76,7 @@ enum ScratchSlot {
     SCRATCH_FIT_BASES,
     SCRATCH_UPLOAD,
     SCRATCH_PENDING,
+    SCRATCH_TS_LEFT,
     SCRATCH_SLOT_COUNT
 };
 

@@ -46,6 +46,7 @@ struct GridHeader {
     unsigned int pad;
     unsigned long long metrics[10]; // [0..8] mdb_grid_metrics minus rows_created (= total_points);
                                     // [9] bytes of the MacaqueV streams the parallel decoder takes
+    unsigned long long checkpointed_points; // visible points of the segments k_grid_timestamps decodes
 };
 
 // MODE 0: every segment through the generic analysis (a time range is given).
@@ -60,16 +61,16 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header, TsCheckpoints checkpoints,
     const uint32_t *__restrict__ known_totals, unsigned long long *__restrict__ pending,
     uint32_t *__restrict__ block_pending, uint32_t n_blocks) {
-    __shared__ unsigned long long lds_metrics[13];
+    __shared__ unsigned long long lds_metrics[14];
     // MODE 2 is launched with few workgroups that walk the blocks of the MODE 1 launch: a batch of simple
     // segments only costs a look at its block flags (32 k workgroups that return at once cost 0.16 ms).
     for (uint32_t block = blockIdx.x; block < n_blocks; block += gridDim.x) {
     if (MODE == 2 && block_pending[block] == 0) continue;
     if (MODE == 2) __syncthreads();
-    if (threadIdx.x < 13) lds_metrics[threadIdx.x] = 0;
+    if (threadIdx.x < 14) lds_metrics[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)block * SEGS_PER_BLOCK;
-    unsigned long long points = 0, serial = 0;
+    unsigned long long points = 0, serial = 0, checkpointed = 0;
     unsigned long long m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t error = 0;
     bool left_any = false;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         m[3] += (d.flags & FLAG_HAS_RESIDUALS) ? 1 : 0;
         m[7] += (d.flags & FLAG_REGULAR) ? 1 : 0;
         m[8] += (d.flags & FLAG_REGULAR) ? 0 : 1;
+        if (MODE != 1 && (d.flags & FLAG_CHECKPOINTS)) checkpointed += d.n_visible;
         // Bytes of the MacaqueV streams long enough for the parallel decoder (bounds its scratch).
         if (MODE != 1 && type == MDB_MACAQUE_V_ID && mv_min_values != 0xffffffffu) {
             const uint32_t bytes = s.values.views[i].x;
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     // Block totals through LDS atomics (few per thread, once per block).
     atomicAdd(&lds_metrics[10], points);
     atomicAdd(&lds_metrics[11], serial);
+    if (checkpointed) atomicAdd(&lds_metrics[13], checkpointed);
     if (MODE == 1 && left_any && (threadIdx.x & (MDB_WAVE - 1)) == 0) atomicAdd(&lds_metrics[12], 1ull);
 #pragma unroll
     for (int k = 0; k < 10; k++)
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     }
     if (threadIdx.x < 10 && lds_metrics[threadIdx.x])
         atomicAdd(&header->metrics[threadIdx.x], lds_metrics[threadIdx.x]);
+    if (threadIdx.x == 13 && lds_metrics[13]) atomicAdd(&header->checkpointed_points, lds_metrics[13]);
     }
 }
 
@@ -684,24 +688,49 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
 // its own points one by one is a request per point to the memory system, and that is what bounds the
 // kernel then). A wave whose pieces hold more points than the buffer has room for (long runs of `0`
 // codes: hundreds of points per piece), whose points do not follow each other in the output or span
-// more than 2^32 microseconds stores directly, two timestamps per store.
+// more than 2^32 microseconds stores directly, two timestamps per store. (The buffer holds 2 048 points: at 1 536,
+// half the waves of a series sampled at random intervals - 24.4 points per piece on average - did not fit,
+// decoded their pieces into runs in vain and then stored directly: 7.9 instead of 5.0 ms per 10^9 points.)
 // Swing values are (slope * t + intercept) of the timestamps just decoded (swing.rs:304-319, the line
 // is in the descriptor), a PMC-Mean value does not depend on the timestamp, MacaqueV values and
 // residuals are written later by k_grid_serial.
-constexpr uint32_t TS_STAGE_POINTS = 1536;
+constexpr uint32_t TS_STAGE_POINTS = 2048;
 constexpr uint32_t TS_MAX_RUNS = 2 * TS_STAGE_POINTS / (3 * MDB_WAVE); // arithmetic runs of a piece that fit into the wave's buffer (16)
 constexpr int TS_THREADS = 128;
 constexpr int TS_PIECE_CHUNKS = 4; // 16-byte chunks parked per piece: 127 + 255 + 69 + 32 bits at most
 
-__global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
-    DevSegments s, const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
-    const uint32_t *__restrict__ irregular_totals, const uint32_t *__restrict__ irregular_first,
-    const uint32_t *__restrict__ counts, TsCheckpoints checkpoints, uint64_t n_pieces,
-    int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[TS_THREADS / MDB_WAVE][2 * TS_STAGE_POINTS]; // timestamps, then values; or the runs
-    __shared__ uint4 parked[TS_THREADS / MDB_WAVE][TS_PIECE_CHUNKS][MDB_WAVE];
-    const int lane = threadIdx.x % MDB_WAVE, wave = threadIdx.x / MDB_WAVE;
-    const uint64_t slot = (uint64_t)blockIdx.x * TS_THREADS + threadIdx.x;
+struct TsWaveArgs {
+    DevSegments s;
+    const TileDesc *desc;
+    const unsigned long long *offsets;
+    const uint32_t *irregular_totals, *irregular_first, *counts;
+    TsCheckpoints checkpoints;
+    uint64_t n_pieces;
+    int64_t *out_ts;
+    float *out_val;
+    // (sparse flavour) waves it leaves to the general one: their numbers, and how many there are
+    uint32_t *left_waves;
+    unsigned int *n_left_waves;
+};
+
+// The 64 pieces `wave_index * 64 ...` of the batch, by one wave. SPARSE: only the first of the three ways
+// out below, as a loop without the other two's branches and stores (they are most of what a wave executes
+// per code otherwise); a wave that needs another way is noted in args.left_waves for the general flavour.
+template <bool SPARSE>
+__device__ __forceinline__ void ts_wave(const TsWaveArgs &args, uint64_t wave_index, uint32_t *stage_words,
+                                        uint4 (*parked_chunks)[MDB_WAVE]) {
+    const DevSegments &s = args.s;
+    const TileDesc *__restrict__ desc = args.desc;
+    const unsigned long long *__restrict__ offsets = args.offsets;
+    const uint32_t *__restrict__ irregular_totals = args.irregular_totals;
+    const uint32_t *__restrict__ irregular_first = args.irregular_first;
+    const uint32_t *__restrict__ counts = args.counts;
+    const TsCheckpoints &checkpoints = args.checkpoints;
+    const uint64_t n_pieces = args.n_pieces;
+    int64_t *__restrict__ out_ts = args.out_ts;
+    float *__restrict__ out_val = args.out_val;
+    const int lane = threadIdx.x % MDB_WAVE;
+    const uint64_t slot = wave_index * MDB_WAVE + (uint64_t)lane;
     const bool present = slot < n_pieces;
     // What the lane needs to know arrives in two rounds of loads: the piece's cursor (with the address
     // of the stream), its segment and the next piece's; then everything about the segment, together
@@ -767,9 +796,9 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
     // The bytes of the piece, parked in LDS: chunk c of the lane is parked[wave][c][lane].
     if (present && has_code) {
 #pragma unroll
-        for (int c = 0; c < TS_PIECE_CHUNKS; c++) parked[wave][c][lane] = fetched[c];
+        for (int c = 0; c < TS_PIECE_CHUNKS; c++) parked_chunks[c][lane] = fetched[c];
     }
-    const uint32_t *my_words = reinterpret_cast<const uint32_t *>(&parked[wave][0][0]);
+    const uint32_t *my_words = reinterpret_cast<const uint32_t *>(&parked_chunks[0][0]);
     auto word = [&](uint32_t k) { // word k of the lane's parked bytes, most significant byte first
         k = min(k, (uint32_t)(4 * TS_PIECE_CHUNKS - 1));
         return __builtin_bswap32(my_words[((k >> 2) * MDB_WAVE + lane) * 4 + (k & 3u)]);
@@ -790,8 +819,89 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     // d.n_model counts the VISIBLE points the model stands for; they are the first ones.
     const uint32_t model_end = first + d.n_model;
-    uint32_t *my_ts = stage[wave];
-    float *my_val = reinterpret_cast<float *>(stage[wave] + TS_STAGE_POINTS);
+    uint32_t *my_ts = stage_words;
+    float *my_val = reinterpret_cast<float *>(stage_words + TS_STAGE_POINTS);
+    if constexpr (SPARSE) {
+        // The wave's points as one contiguous run, or not at all here.
+        bool leaves = !staged;
+        if (staged) {
+            bool too_far = false;
+            auto emit = [&](uint32_t k, int64_t t) {
+                if (k < run_first || k >= run_end) return;
+                float value = 0.0f;
+                if (k < model_end) value = type == MDB_SWING_ID ? (float)(d.slope * (double)t + d.intercept) : d.value;
+                const uint64_t distance = (uint64_t)(t - base_time);
+                too_far |= distance > 0xffffffffull;
+                my_ts[before + (k - run_first)] = (uint32_t)distance;
+                my_val[before + (k - run_first)] = value;
+            };
+            if (mine > 0) {
+                if (piece == 0) emit(0u, from.timestamp); // point 0 is the start time
+                if (has_code && from.count < run_end) {
+                    const uint32_t codes_end = min(run_end, last_of_stream ? n_total - 1u : next_count);
+                    uint32_t next_word = first_bit >> 5;
+                    uint64_t buffer = (((uint64_t)word(next_word) << 32) | word(next_word + 1)) << (first_bit & 31u);
+                    int32_t available = 64 - (int32_t)(first_bit & 31u);
+                    next_word += 2;
+                    auto refill = [&]() { // at least 33 bits afterwards, without a branch
+                        const bool want = available <= 32;
+                        const uint64_t placed = (uint64_t)word(next_word) << ((32 - available) & 63);
+                        buffer |= want ? placed : 0ull;
+                        available += want ? 32 : 0;
+                        next_word += want ? 1u : 0u;
+                    };
+                    auto consume = [&](uint32_t bits) {
+                        buffer <<= bits;
+                        available -= (int32_t)bits;
+                    };
+                    int64_t timestamp = from.timestamp;
+                    uint64_t last_delta = from.last_delta;
+                    uint32_t k = from.count;
+                    while (k < codes_end) {
+                        refill();
+                        const uint32_t top = (uint32_t)(buffer >> 32);
+                        const uint32_t ones = (uint32_t)__clz((int)~top);
+                        uint32_t length = 0;
+                        if (ones >= 4) { // `11110` + 32 bits or `11111` + 64 bits: rare
+                            consume(5);
+                            refill();
+                            uint64_t encoded = (uint32_t)(buffer >> 32);
+                            consume(32);
+                            if (ones >= 5) {
+                                refill();
+                                encoded = (encoded << 32) | (uint32_t)(buffer >> 32);
+                                consume(32);
+                                last_delta += encoded;
+                            } else {
+                                last_delta += encoded > (1ull << 31) ? (encoded | (~0ull << 32)) : encoded;
+                            }
+                        } else { // (a `0` code is a short code with a delta of delta of zero)
+                            int32_t delta_of_delta;
+                            length = ts_short_code(top, ones, &delta_of_delta);
+                            last_delta += (uint64_t)(int64_t)delta_of_delta;
+                        }
+                        consume(length);
+                        timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+                        emit(k++, timestamp);
+                    }
+                    if (last_of_stream && run_end == n_total) emit(n_total - 1u, end_time);
+                }
+            }
+            leaves = __any(too_far);
+        }
+        if (leaves) {
+            if (lane == 0) args.left_waves[atomicAdd(args.n_left_waves, 1u)] = (uint32_t)wave_index;
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t k = lane; k < wave_total; k += MDB_WAVE) {
+            if (out_ts) out_ts[wave_first + k] = base_time + (int64_t)(uint64_t)my_ts[k];
+            out_val[wave_first + k] = my_val[k];
+        }
+        return;
+    }
     // A wave with more points than its buffer holds has long runs of `0` codes in its pieces (hundreds of
     // points per piece). A `0` code repeats the delta, so the points between two other codes are an
     // arithmetic run: the lanes decode their pieces into (first index, first timestamp, delta) triples, a
@@ -801,7 +911,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
     if (wave_total > TS_STAGE_POINTS) {
         // run r of the lane is runs[(lane * TS_MAX_RUNS + r) * 3 ..]: the index of its first point in the
         // stream, that point's distance from the lane's base time, the delta.
-        uint32_t *runs = stage[wave];
+        uint32_t *runs = stage_words;
         uint32_t n_runs = 0;
         bool unfit = false;
         auto open_run = [&](uint32_t k_first, int64_t t, uint64_t delta) {
@@ -888,7 +998,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t *meta = reinterpret_cast<uint32_t *>(&parked[wave][0][0]);
+            uint32_t *meta = reinterpret_cast<uint32_t *>(&parked_chunks[0][0]);
             auto put = [&](int w, uint32_t value) { meta[w * MDB_WAVE + lane] = value; };
             auto put64 = [&](int w, uint64_t value) {
                 put(w, (uint32_t)value);
@@ -1051,6 +1161,36 @@ __global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(
     for (uint32_t k = lane; k < wave_total; k += MDB_WAVE) {
         if (out_ts) out_ts[wave_first + k] = base_time + (int64_t)(uint64_t)my_ts[k];
         out_val[wave_first + k] = my_val[k];
+    }
+}
+
+// Every wave of the batch, each in whichever way it needs.
+__global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps(TsWaveArgs args) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[TS_THREADS / MDB_WAVE][2 * TS_STAGE_POINTS]; // timestamps, then values; or the runs
+    __shared__ uint4 parked[TS_THREADS / MDB_WAVE][TS_PIECE_CHUNKS][MDB_WAVE];
+    const int wave = threadIdx.x / MDB_WAVE;
+    ts_wave<false>(args, (uint64_t)blockIdx.x * (TS_THREADS / MDB_WAVE) + wave, stage[wave], parked[wave]);
+}
+
+// Every wave of the batch the sparse way (randomly sampled series: some twenty codes per piece, all different);
+// the few that cannot go that way are listed for k_grid_timestamps_left.
+__global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps_sparse(TsWaveArgs args) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[TS_THREADS / MDB_WAVE][2 * TS_STAGE_POINTS];
+    __shared__ uint4 parked[TS_THREADS / MDB_WAVE][TS_PIECE_CHUNKS][MDB_WAVE];
+    const int wave = threadIdx.x / MDB_WAVE;
+    ts_wave<true>(args, (uint64_t)blockIdx.x * (TS_THREADS / MDB_WAVE) + wave, stage[wave], parked[wave]);
+}
+
+// The waves k_grid_timestamps_sparse has listed, by a fixed number of workgroups (usually there are none).
+__global__ __launch_bounds__(TS_THREADS) void k_grid_timestamps_left(TsWaveArgs args) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[TS_THREADS / MDB_WAVE][2 * TS_STAGE_POINTS];
+    __shared__ uint4 parked[TS_THREADS / MDB_WAVE][TS_PIECE_CHUNKS][MDB_WAVE];
+    const int wave = threadIdx.x / MDB_WAVE;
+    const uint32_t n_left = *args.n_left_waves;
+    const uint32_t stride = gridDim.x * (TS_THREADS / MDB_WAVE);
+    for (uint32_t k = blockIdx.x * (TS_THREADS / MDB_WAVE) + wave; k < n_left; k += stride) {
+        ts_wave<false>(args, args.left_waves[k], stage[wave], parked[wave]);
+        __builtin_amdgcn_wave_barrier(); // (the next round reuses the wave's LDS)
     }
 }
 
@@ -1912,11 +2052,33 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
                            out_val);
     }
     if (plan.n_ts_pieces > 0) {
-        LaunchTimer timer(ctx, "k_grid_timestamps");
-        hipLaunchKernelGGL(k_grid_timestamps, dim3((uint32_t)((plan.n_ts_pieces + TS_THREADS - 1) / TS_THREADS)),
-                           dim3(TS_THREADS), 0, ctx->stream,
-                           s, plan.desc, plan.offsets, plan.irregular_totals, plan.irregular_first, plan.counts,
-                           plan.checkpoints, plan.n_ts_pieces, out_ts, out_val);
+        TsWaveArgs ts_args{s, plan.desc, plan.offsets, plan.irregular_totals, plan.irregular_first, plan.counts,
+                           plan.checkpoints, plan.n_ts_pieces, out_ts, out_val, nullptr, nullptr};
+        const uint64_t n_waves = (plan.n_ts_pieces + MDB_WAVE - 1) / MDB_WAVE;
+        const uint32_t ts_blocks = (uint32_t)((plan.n_ts_pieces + TS_THREADS - 1) / TS_THREADS);
+        // Few points per piece (randomly sampled series): the sparse flavour, then the general one for the
+        // waves it has listed. Many (a fixed rate with gaps), or MDB_GRID_TS_SPARSE=0: the general one.
+        const char *sparse_setting = std::getenv("MDB_GRID_TS_SPARSE");
+        const bool sparse = !(sparse_setting && std::strcmp(sparse_setting, "0") == 0) &&
+                            plan.host_header.checkpointed_points <= (uint64_t)(TS_STAGE_POINTS / MDB_WAVE) * plan.n_ts_pieces &&
+                            n_waves < 0xffffffffull;
+        if (sparse) {
+            void *p;
+            if (scratch_reserve(ctx, SCRATCH_TS_LEFT, (n_waves + 16) * 4, &p)) return 1;
+            ts_args.n_left_waves = static_cast<unsigned int *>(p);
+            ts_args.left_waves = ts_args.n_left_waves + 16;
+            MDB_HIP_CHECK(hipMemsetAsync(ts_args.n_left_waves, 0, 4, ctx->stream));
+            {
+                LaunchTimer timer(ctx, "k_grid_timestamps_sparse");
+                hipLaunchKernelGGL(k_grid_timestamps_sparse, dim3(ts_blocks), dim3(TS_THREADS), 0, ctx->stream, ts_args);
+            }
+            LaunchTimer timer(ctx, "k_grid_timestamps");
+            hipLaunchKernelGGL(k_grid_timestamps_left, dim3(std::min<uint32_t>(ts_blocks, 2048u)), dim3(TS_THREADS), 0,
+                               ctx->stream, ts_args);
+        } else {
+            LaunchTimer timer(ctx, "k_grid_timestamps");
+            hipLaunchKernelGGL(k_grid_timestamps, dim3(ts_blocks), dim3(TS_THREADS), 0, ctx->stream, ts_args);
+        }
     }
     const uint64_t n_serial = plan.host_header.n_serial;
     const MvSeg *mv_segs = nullptr;

@@ -13,19 +13,25 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane"],
-                ids=["mv-default", "mv-from-1024-values", "mv-from-8-values", "timestamps-one-lane-per-segment"])
+@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane", "ts-general"],
+                ids=["mv-default", "mv-from-1024-values", "mv-from-8-values", "timestamps-one-lane-per-segment",
+                     "timestamps-general-kernel-only"])
 def macaque_decoder(request, monkeypatch):
     """Every grid test runs with the parallel MacaqueV decoder (mdb_macaque_parallel.hpp) at its
     default threshold, switched off (one lane per stream only) and forced onto every stream of at
     least 8 values; and with irregular timestamps decoded one lane per 256-bit piece of a stream
-    (k_grid_timestamps, the default) and one lane per segment (k_grid_serial)."""
+    (k_grid_timestamps, the default: its sparse flavour first where the batch has few points per piece, or
+    the general one alone) and one lane per segment (k_grid_serial)."""
     monkeypatch.delenv("MDB_GRID_TS_PIECES", raising=False)
+    monkeypatch.delenv("MDB_GRID_TS_SPARSE", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
     elif request.param == "ts-one-lane":
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
         monkeypatch.setenv("MDB_GRID_TS_PIECES", "off")
+    elif request.param == "ts-general":
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+        monkeypatch.setenv("MDB_GRID_TS_SPARSE", "0")
     else:
         monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
     return request.param
