@@ -496,6 +496,21 @@ def main():
         if not args.no_host_path:
             with phase("host_path"):
                 host_path_result = host_path(context, mdb, np, downloaded, args)
+            with phase("host_path_fit"):
+                # The fit through host pointers (what an ingest thread calls): timestamps and values in host
+                # memory, segments back in host memory, PCIe included. Same bytes as the device-resident fit.
+                context.compress_chunks(host_ts, fit_sample_values, offsets, eb)
+                started = time.perf_counter()
+                from_host = context.compress_chunks(host_ts, fit_sample_values, offsets, eb)
+                seconds = time.perf_counter() - started
+                if from_host.rows() != gpu_fitted.rows():
+                    raise SystemExit("VERIFICATION FAILED: the fit through host pointers differs from the device-resident one")
+                host_path_result["fit"] = {
+                    "points_per_s": n_fit * args.points / seconds, "segments_per_s": len(from_host) / seconds,
+                    "seconds": seconds, "points": n_fit * args.points,
+                    "note": "mdb_compress_chunks over host arrays of the first series (12 B per point handed over; "
+                            "host threads find every chunk's timestamps equally spaced while the values cross "
+                            "PCIe, so the timestamps never do), segments downloaded; second of two calls"}
         del downloaded
 
     if rank == 0:

@@ -77,6 +77,9 @@ enum ScratchSlot {
     SCRATCH_UPLOAD,
     SCRATCH_PENDING,
     SCRATCH_TS_LEFT,
+    SCRATCH_FIT_IN_TS,
+    SCRATCH_FIT_IN_VALUES,
+    SCRATCH_FIT_IN_OFFSETS,
     SCRATCH_SLOT_COUNT
 };
 

@@ -28,6 +28,11 @@
 #include "mdb_scan.hpp"
 #include "mdb_segment_dev.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
 namespace mdb {
 
 __global__ __launch_bounds__(1024) void k_scan_block_sums(unsigned long long *__restrict__ block_sums,
@@ -2267,18 +2272,21 @@ static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64
     return (uint32_t)piece;
 }
 
+// chunk_first / chunk_interval (device arrays, may be nullptr): the caller has looked at the timestamps of every
+// chunk itself, found them equally spaced and passes what k_fit_regular would have found (ts is nullptr then).
 int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *values,
                                const uint64_t *chunk_offsets, uint64_t n_chunks, mdb_error_bound eb,
                                int64_t regular_start, int64_t regular_interval,
-                               const uint64_t *series_first_index, mdb_segments_owned **out) {
+                               const uint64_t *series_first_index, mdb_segments_owned **out,
+                               const long long *chunk_first = nullptr, const long long *chunk_interval = nullptr) {
     if (!valid_error_bound(eb)) return fail("Invalid error bound.");
     if (n_chunks > 0xfffffff0ull) return fail("Too many chunks in one call.");
-    if (!ts && regular_interval <= 0 )
+    if (!ts && !chunk_first && regular_interval <= 0)
         return fail("Either timestamps or a positive regular_interval must be given.");
     FitArgs args;
     args.values = values;
     args.timestamps = {ts, regular_start, regular_interval,
-                       reinterpret_cast<const unsigned long long *>(series_first_index), nullptr, nullptr,
+                       reinterpret_cast<const unsigned long long *>(series_first_index), chunk_first, chunk_interval,
                        nullptr};
     args.chunk_offsets = reinterpret_cast<const unsigned long long *>(chunk_offsets);
     args.n_chunks = n_chunks;
@@ -2708,32 +2716,82 @@ int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
         if (chunk_offsets[c] > chunk_offsets[c + 1]) return fail("chunk_offsets must be non-decreasing.");
     mdb_segments_owned *dev = nullptr;
     int rc = 0;
-    void *dev_ts = nullptr, *dev_values = nullptr, *dev_offsets = nullptr;
     {
         mdb::CallGuard lock(ctx);
         MDB_HIP_CHECK(hipSetDevice(ctx->device));
-        auto upload = [&](void **dst, const void *src, uint64_t bytes) {
+        // Two thirds of what a caller hands over are timestamps, and nearly always they are equally spaced
+        // within every chunk: then nothing downstream loads one (k_fit_regular finds that out on the device,
+        // for timestamps that are there already). Here they are in host memory and PCIe is what the call
+        // waits for, so host threads look while the values cross: per chunk the first timestamp and the
+        // interval, or the news that some chunk is not regular - only then do the timestamps cross too.
+        std::vector<long long> first(n_chunks), interval(n_chunks);
+        std::atomic<bool> irregular{false};
+        const unsigned n_workers = (unsigned)std::min<uint64_t>(
+            std::max(1u, std::min(16u, std::thread::hardware_concurrency())), std::max<uint64_t>(1, total >> 20));
+        std::vector<std::thread> workers;
+        if (total > 0) {
+            // (contiguous ranges of chunks with about the same number of points)
+            uint64_t next_chunk = 0;
+            for (unsigned w = 0; w < n_workers; w++) {
+                const uint64_t target = chunk_offsets[0] + (total * (w + 1)) / n_workers;
+                uint64_t end_chunk = next_chunk;
+                while (end_chunk < n_chunks && (chunk_offsets[end_chunk + 1] <= target || w + 1 == n_workers)) end_chunk++;
+                const uint64_t begin = next_chunk;
+                next_chunk = end_chunk;
+                workers.emplace_back([&, begin, end_chunk] {
+                    for (uint64_t c = begin; c < end_chunk && !irregular.load(std::memory_order_relaxed); c++) {
+                        const int64_t *t = ts + chunk_offsets[c];
+                        const uint64_t n = chunk_offsets[c + 1] - chunk_offsets[c];
+                        first[c] = n > 0 ? t[0] : 0;
+                        const int64_t step = n > 1 ? (int64_t)((uint64_t)t[1] - (uint64_t)t[0]) : 0;
+                        interval[c] = step;
+                        bool differs = false;
+                        for (uint64_t j = 2; j < n; j++) differs |= (int64_t)((uint64_t)t[j] - (uint64_t)t[j - 1]) != step;
+                        if (differs) irregular.store(true, std::memory_order_relaxed);
+                    }
+                });
+            }
+        }
+        auto join = [&] {
+            for (auto &worker : workers)
+                if (worker.joinable()) worker.join();
+        };
+        void *dev_values = nullptr, *dev_offsets = nullptr, *dev_ts = nullptr;
+        auto upload = [&](ScratchSlot slot, void **dst, const void *src, uint64_t bytes) {
             if (rc) return;
-            if (hipMalloc(dst, bytes ? bytes : 256) != hipSuccess) {
-                rc = fail("hipMalloc failed.");
+            if (scratch_reserve(ctx, slot, bytes ? bytes : 256, dst)) {
+                rc = 1;
                 return;
             }
             if (bytes && hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                 rc = fail("hipMemcpy host to device failed.");
         };
-        upload(&dev_ts, ts, total * 8);
-        upload(&dev_values, values, total * 4);
-        upload(&dev_offsets, chunk_offsets, (n_chunks + 1) * 8);
-        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
-        if (!rc)
-            rc = compress_chunks_dev_locked(ctx, static_cast<const int64_t *>(dev_ts),
-                                            static_cast<const float *>(dev_values),
-                                            static_cast<const uint64_t *>(dev_offsets), n_chunks,
-                                            error_bound, 0, 0, nullptr, &dev);
+        upload(SCRATCH_FIT_IN_VALUES, &dev_values, values, total * 4);
+        upload(SCRATCH_FIT_IN_OFFSETS, &dev_offsets, chunk_offsets, (n_chunks + 1) * 8);
+        join();
+        const bool regular = total > 0 && !irregular.load();
+        if (regular) {
+            void *dev_first = nullptr;
+            std::vector<long long> both(2 * n_chunks);
+            std::copy(first.begin(), first.end(), both.begin());
+            std::copy(interval.begin(), interval.end(), both.begin() + n_chunks);
+            upload(SCRATCH_FIT_IN_TS, &dev_first, both.data(), 16 * n_chunks);
+            if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+            if (!rc)
+                rc = compress_chunks_dev_locked(ctx, nullptr, static_cast<const float *>(dev_values),
+                                                static_cast<const uint64_t *>(dev_offsets), n_chunks, error_bound, 0, 0,
+                                                nullptr, &dev, static_cast<const long long *>(dev_first),
+                                                static_cast<const long long *>(dev_first) + n_chunks);
+        } else {
+            upload(SCRATCH_FIT_IN_TS, &dev_ts, ts, total * 8);
+            if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+            if (!rc)
+                rc = compress_chunks_dev_locked(ctx, static_cast<const int64_t *>(dev_ts),
+                                                static_cast<const float *>(dev_values),
+                                                static_cast<const uint64_t *>(dev_offsets), n_chunks,
+                                                error_bound, 0, 0, nullptr, &dev);
+        }
         (void)hipStreamSynchronize(ctx->stream);
-        if (dev_ts) (void)hipFree(dev_ts);
-        if (dev_values) (void)hipFree(dev_values);
-        if (dev_offsets) (void)hipFree(dev_offsets);
     }
     if (rc) return 1;
     rc = mdb_segments_download(ctx, dev, out);
