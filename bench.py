@@ -221,6 +221,11 @@ def host_path(context, mdb, np, sample, args):
         points, seconds, bytes_down = host.measure_grid_stream(context, sample, batch_size)
         out[f"batch_{batch_size}"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
                                       "points": points, "segments": len(sample), "seconds": seconds}
+    # With a tag column (grid_exec.rs:341-346): a 16-byte view per data point, written by host threads.
+    host.measure_grid_stream(context, sample, 8192, tags={"tag": "wind-turbine-0042"})
+    points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192, tags={"tag": "wind-turbine-0042"})
+    out["batch_8192_one_tag_column"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
+                                        "seconds": seconds}
     return out
 
 

@@ -12,6 +12,8 @@
 #include <numeric>
 #include <thread>
 
+#include <emmintrin.h>
+
 namespace mdbhost {
 
 namespace {
@@ -493,6 +495,23 @@ GridStream::~GridStream() {
     if (second_ctx_) mdb_close(second_ctx_);
 }
 
+std::shared_ptr<GridStream::TagBlock> GridStream::take_tag_block(size_t rows) {
+    // A block nobody but the pool refers to any more (the batches sliced from it have been dropped) and that
+    // is large enough; otherwise a new one, in place of the smallest idle one if the pool is full.
+    std::shared_ptr<TagBlock> *smallest_idle = nullptr;
+    for (auto &block : tag_blocks_) {
+        if (block.use_count() != 1) continue;
+        if (block->capacity >= rows) return block;
+        if (!smallest_idle || block->capacity < (*smallest_idle)->capacity) smallest_idle = &block;
+    }
+    auto fresh = std::make_shared<TagBlock>();
+    fresh->capacity = rows + rows / 4 + 4096;
+    fresh->views.reset(new mdb_view16[fresh->capacity]);
+    if (smallest_idle) *smallest_idle = fresh;
+    else if (tag_blocks_.size() < 16) tag_blocks_.push_back(fresh);
+    return fresh;
+}
+
 GridStream::InFlight GridStream::start_grid(RecordBatch batch) {
     InFlight flight;
     flight.batch = std::make_shared<RecordBatch>(std::move(batch));
@@ -547,6 +566,11 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
     // Tag columns: the segment's tag value once per created row (grid_exec.rs:341-346). Views are
     // replicated; long strings stay in the input's data buffers (shared, not copied).
     std::vector<ColumnPtr> tag_columns;
+    struct Replication { // the views of one tag column: one per segment in, one per created row out
+        const mdb_view16 *input;
+        mdb_view16 *output;
+    };
+    std::vector<Replication> replications;
     for (size_t t = 0; t < n_tags; t++) {
         const Column &input_tags = *batch.columns[query_compressed_schema().size() + t];
         auto column = std::make_shared<Column>();
@@ -555,14 +579,14 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
         // 16 bytes per created row: not zero-filled first, and written by several threads when large
         // (this is the StringView append per row of grid_exec.rs:341-346, the host-side cost of a tag).
         struct TagStorage {
-            std::unique_ptr<mdb_view16[]> views;
+            std::shared_ptr<TagBlock> block;
             ColumnPtr input;
         };
         auto storage = std::make_shared<TagStorage>();
-        storage->views.reset(new mdb_view16[std::max<size_t>(static_cast<size_t>(total), 1)]);
+        storage->block = take_tag_block(std::max<size_t>(static_cast<size_t>(total), 1));
         storage->input = batch.columns[query_compressed_schema().size() + t];
         (void)flight.batch; // (the tag columns keep the input's buffers alive themselves)
-        mdb_view16 *views = storage->views.get();
+        mdb_view16 *views = storage->block->views.get();
         // buffer 0: long leftover strings, copied so old inputs can be dropped.
         column->owned_buffers.emplace_back();
         std::vector<uint8_t> &leftover_payload = column->owned_buffers[0];
@@ -581,29 +605,7 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
                 }
             }
         }
-        const mdb_view16 *input_views = input_tags.as<mdb_view16>();
-        auto replicate = [&](int64_t first_row, int64_t last_row, int64_t at) {
-            for (int64_t row = first_row; row < last_row; row++) {
-                mdb_view16 tag = input_views[row];
-                if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
-                for (uint32_t k = 0; k < rows_per_segment[row]; k++) views[at++] = tag;
-            }
-        };
-        const int64_t new_rows = total - leftovers;
-        const unsigned n_threads = new_rows >= (1 << 18) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        if (n_threads == 1) {
-            replicate(0, batch.num_rows, leftovers);
-        } else {
-            // Equal shares of the segment rows; every thread starts where the rows before it end.
-            std::vector<std::thread> workers;
-            int64_t at = leftovers, row = 0;
-            for (unsigned w = 0; w < n_threads; w++) {
-                const int64_t last_row = batch.num_rows * static_cast<int64_t>(w + 1) / n_threads;
-                workers.emplace_back(replicate, row, last_row, at);
-                for (; row < last_row; row++) at += rows_per_segment[row];
-            }
-            for (std::thread &worker : workers) worker.join();
-        }
+        replications.push_back({input_tags.as<mdb_view16>(), views});
         column->values = views;
         column->buffer_ptrs.push_back(leftover_payload.empty() ? reinterpret_cast<const uint8_t *>(views)
                                                                : leftover_payload.data());
@@ -614,6 +616,48 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
         }
         column->keep_alive = storage;
         tag_columns.push_back(column);
+    }
+    if (!replications.empty()) {
+        // All tag columns in one go, by several threads when there is much to write: equal shares of the
+        // segment rows, every thread starting where the rows before it end. The views are written past the
+        // cache (nobody reads them before the consumer does, and reading the lines first to own them would
+        // double the memory traffic of what is a plain fill).
+        auto replicate = [&](int64_t first_row, int64_t last_row, int64_t first_at) {
+            for (const Replication &r : replications) {
+                int64_t at = first_at;
+                for (int64_t row = first_row; row < last_row; row++) {
+                    mdb_view16 tag = r.input[row];
+                    if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
+                    __m128i bits;
+                    std::memcpy(&bits, &tag, 16);
+                    mdb_view16 *to = r.output + at;
+                    const uint32_t n = rows_per_segment[row];
+                    if ((reinterpret_cast<uintptr_t>(to) & 15u) == 0) {
+                        for (uint32_t k = 0; k < n; k++) _mm_stream_si128(reinterpret_cast<__m128i *>(to + k), bits);
+                    } else {
+                        for (uint32_t k = 0; k < n; k++) to[k] = tag;
+                    }
+                    at += n;
+                }
+            }
+            _mm_sfence();
+        };
+        const int64_t new_rows = total - leftovers;
+        const unsigned n_threads = new_rows * static_cast<int64_t>(replications.size()) >= (1 << 18)
+                                       ? std::min(16u, std::max(1u, std::thread::hardware_concurrency()))
+                                       : 1u;
+        if (n_threads == 1) {
+            replicate(0, batch.num_rows, leftovers);
+        } else {
+            std::vector<std::thread> workers;
+            int64_t at = leftovers, row = 0;
+            for (unsigned w = 0; w < n_threads; w++) {
+                const int64_t last_row = batch.num_rows * static_cast<int64_t>(w + 1) / n_threads;
+                workers.emplace_back(replicate, row, last_row, at);
+                for (; row < last_row; row++) at += rows_per_segment[row];
+            }
+            for (std::thread &worker : workers) worker.join();
+        }
     }
 
     auto aliased = [&](Type type, const void *data) {

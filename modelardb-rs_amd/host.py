@@ -161,7 +161,7 @@ class GridStream:
             pass
 
 
-def measure_grid_stream(context, segments, batch_size, segments_per_batch=8192):
+def measure_grid_stream(context, segments, batch_size, segments_per_batch=8192, tags=None):
     """The host operator end to end, for bench.py's host_path: `segments` (a SegmentBatch in host
     memory) handed to a GridStream `segments_per_batch` rows at a time - what the Parquet scan below a
     GridExec delivers - and the stream polled to its end in slices of `batch_size` data points. Every
@@ -169,7 +169,9 @@ def measure_grid_stream(context, segments, batch_size, segments_per_batch=8192):
     Returns (data points, seconds, bytes copied down)."""
     import time
     arrow = segments.to_arrow()
-    stream = GridStream(context, batch_size=batch_size)
+    if tags:  # (tag columns: their value is repeated for every data point of a segment, grid_exec.rs:341-346)
+        arrow = segments_with_tags(arrow, tags)
+    stream = GridStream(context, tag_names=tuple(tags or ()), batch_size=batch_size)
     for first in range(0, arrow.num_rows, segments_per_batch):
         stream.push(arrow.slice(first, min(segments_per_batch, arrow.num_rows - first)))
     stream.finish_input()

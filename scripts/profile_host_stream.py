@@ -28,9 +28,11 @@ def main():
     sample = dev.download()
     dev.free()
     host.measure_grid_stream(ctx, sample.slice(0, 65536), 8192)
-    for batch_size in sizes:
+    for tags in (None, {"tag": "wind-turbine-0042"}, {"tag": "wind-turbine-0042", "park": "north-sea-7", "country": "dk"}):
+      for batch_size in sizes:
         for _ in range(2):
-            n, seconds, down = host.measure_grid_stream(ctx, sample, batch_size)
+            n, seconds, down = host.measure_grid_stream(ctx, sample, batch_size, tags=tags)
+            print(f"{len(tags or ())} tag columns,", end=" ")
             print(f"batch_size {batch_size}: {n} points, {len(sample)} segments in {seconds * 1e3:.1f} ms: "
                   f"{n / seconds / 1e9:.2f} Gvalues/s, {down / seconds / 1e9:.1f} GB/s into page-locked memory", flush=True)
 
