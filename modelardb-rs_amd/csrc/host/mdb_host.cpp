@@ -1086,21 +1086,37 @@ void UncompressedDataManager::insert_data_points(const RecordBatch &data_points)
     for (size_t index : metadata_.tag_column_indices) tags.push_back(data_points.columns[index].get());
     for (size_t index : metadata_.field_column_indices) fields.push_back(data_points.columns[index].get());
     const uint64_t batch_index = current_batch_index_;
+    // calculate_tag_hash stands in: the tag values identify the series. Rows of several series usually arrive
+    // interleaved in a fixed order, so the buffer behind the one the previous row went to is tried first.
+    auto is_series_of = [&](const Buffer &buffer, int64_t row) {
+        for (size_t t = 0; t < tags.size(); t++)
+            if (tags[t]->view_value(row) != buffer.tag_values[t]) return false;
+        return true;
+    };
+    size_t previous = 0;
     for (int64_t row = 0; row < data_points.num_rows; row++) {
-        // calculate_tag_hash stands in: the joined tag values identify the series.
-        std::string key;
-        for (const Column *tag : tags) {
-            key.append(tag->view_value(row));
-            key.push_back('\x1f');
+        auto it = active_.end();
+        if (!active_.empty()) {
+            const size_t guess = (previous + 1) % active_.size();
+            if (is_series_of(active_[guess].second, row)) it = active_.begin() + static_cast<std::ptrdiff_t>(guess);
+            else if (is_series_of(active_[previous % active_.size()].second, row))
+                it = active_.begin() + static_cast<std::ptrdiff_t>(previous % active_.size());
+            else
+                it = std::find_if(active_.begin(), active_.end(), [&](const auto &kv) { return is_series_of(kv.second, row); });
         }
-        auto it = std::find_if(active_.begin(), active_.end(), [&](const auto &kv) { return kv.first == key; });
         if (it == active_.end()) {
+            std::string key;
             Buffer buffer;
-            for (const Column *tag : tags) buffer.tag_values.emplace_back(tag->view_value(row));
+            for (const Column *tag : tags) {
+                buffer.tag_values.emplace_back(tag->view_value(row));
+                key.append(tag->view_value(row));
+                key.push_back('\x1f');
+            }
             buffer.values.resize(fields.size());
             active_.emplace_back(key, std::move(buffer));
             it = active_.end() - 1;
         }
+        previous = static_cast<size_t>(it - active_.begin());
         Buffer &buffer = it->second;
         buffer.updated_by_batch_index = batch_index; // uncompressed_data_buffer.rs:141-158
         buffer.timestamps.push_back(ts_column.as<int64_t>()[row]);
@@ -1108,6 +1124,7 @@ void UncompressedDataManager::insert_data_points(const RecordBatch &data_points)
         if (buffer.timestamps.size() == capacity_) { // is_full(): transfer to the compressor (:301-318)
             finished_.push_back(std::move(buffer));
             active_.erase(it);
+            previous = previous > 0 ? previous - 1 : (active_.empty() ? 0 : active_.size() - 1); // (the next series has moved into its place)
         }
     }
     // Unused buffers are only finished at the end so buffers needed by this batch survive (:170-174).
@@ -1137,11 +1154,13 @@ std::vector<RecordBatch> UncompressedDataManager::compress_finished_buffers() {
     const size_t n_fields = metadata_.field_column_indices.size();
     std::vector<RecordBatch> result(finished_.size() * n_fields);
     // record_batch(): sort each buffer by time (sort_to_indices + take).
+    // (a buffer that is in time order already - a sensor sends its points that way - keeps an empty order)
     std::vector<std::vector<int64_t>> order(finished_.size());
     for (size_t b = 0; b < finished_.size(); b++) {
-        order[b].resize(finished_[b].timestamps.size());
-        std::iota(order[b].begin(), order[b].end(), 0);
         const std::vector<int64_t> &ts = finished_[b].timestamps;
+        if (std::is_sorted(ts.begin(), ts.end())) continue;
+        order[b].resize(ts.size());
+        std::iota(order[b].begin(), order[b].end(), 0);
         std::stable_sort(order[b].begin(), order[b].end(), [&](int64_t x, int64_t y) { return ts[x] < ts[y]; });
     }
     // Fields that share an error bound share a launch: chunk = (finished buffer, field).
@@ -1157,20 +1176,47 @@ std::vector<RecordBatch> UncompressedDataManager::compress_finished_buffers() {
                 done[f] = true;
             }
         }
-        std::vector<int64_t> chunk_ts;
-        std::vector<float> chunk_values;
         std::vector<uint64_t> offsets = {0};
-        for (size_t b = 0; b < finished_.size(); b++) {
-            for (size_t f : group) {
-                for (int64_t i : order[b]) {
-                    chunk_ts.push_back(finished_[b].timestamps[static_cast<size_t>(i)]);
-                    chunk_values.push_back(finished_[b].values[f][static_cast<size_t>(i)]);
+        uint64_t group_points = 0;
+        for (const Buffer &buffer : finished_) group_points += buffer.timestamps.size() * group.size();
+        // Where every (buffer, field) chunk goes is known up front, so the gather is shared by several threads
+        // when there is much to move (it is a copy of everything ingested: memory bandwidth, not one core's).
+        std::unique_ptr<int64_t[]> ts_storage(new int64_t[std::max<uint64_t>(group_points, 1)]);
+        std::unique_ptr<float[]> value_storage(new float[std::max<uint64_t>(group_points, 1)]);
+        int64_t *const chunk_ts_data = ts_storage.get();
+        float *const chunk_values_data = value_storage.get();
+        for (size_t b = 0; b < finished_.size(); b++)
+            for (size_t k = 0; k < group.size(); k++) offsets.push_back(offsets.back() + finished_[b].timestamps.size());
+        auto gather = [&](size_t first_buffer, size_t last_buffer) {
+            for (size_t b = first_buffer; b < last_buffer; b++) {
+                for (size_t k = 0; k < group.size(); k++) {
+                    const size_t f = group[k];
+                    const uint64_t at = offsets[b * group.size() + k];
+                    const size_t n = finished_[b].timestamps.size();
+                    if (order[b].empty()) {
+                        std::memcpy(chunk_ts_data + at, finished_[b].timestamps.data(), 8 * n);
+                        std::memcpy(chunk_values_data + at, finished_[b].values[f].data(), 4 * n);
+                    } else {
+                        for (size_t j = 0; j < n; j++) {
+                            const size_t i = static_cast<size_t>(order[b][j]);
+                            chunk_ts_data[at + j] = finished_[b].timestamps[i];
+                            chunk_values_data[at + j] = finished_[b].values[f][i];
+                        }
+                    }
                 }
-                offsets.push_back(chunk_ts.size());
             }
+        };
+        const unsigned n_gatherers = group_points >= (1u << 22) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (n_gatherers == 1) {
+            gather(0, finished_.size());
+        } else {
+            std::vector<std::thread> gatherers;
+            for (unsigned w = 0; w < n_gatherers; w++)
+                gatherers.emplace_back(gather, finished_.size() * w / n_gatherers, finished_.size() * (w + 1) / n_gatherers);
+            for (std::thread &gatherer : gatherers) gatherer.join();
         }
         OwnedGuard guard;
-        check(mdb_compress_chunks(ctx_, chunk_ts.data(), chunk_values.data(), offsets.data(), offsets.size() - 1,
+        check(mdb_compress_chunks(ctx_, chunk_ts_data, chunk_values_data, offsets.data(), offsets.size() - 1,
                                   bound, &guard.owned));
         uint64_t row = 0;
         const uint64_t total = guard.owned->seg.n;
