@@ -12,9 +12,106 @@
 #include <numeric>
 #include <thread>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+
 #include <emmintrin.h>
 
 namespace mdbhost {
+
+namespace {
+
+// A few threads that stay around for the fills that are memory bandwidth rather than one core's work (tag views,
+// the gather of ingested buffers): starting sixteen threads per batch costs as much as a small batch's fill.
+// One parallel region at a time; the caller takes a share itself.
+class WorkerPool {
+  public:
+    static WorkerPool &instance() {
+        static WorkerPool pool;
+        return pool;
+    }
+    unsigned width() const { return static_cast<unsigned>(threads_.size()) + 1; }
+    // Runs share(k) for k in [0, n_shares), spread over the pool's threads and the caller; returns when all are done.
+    void run(unsigned n_shares, const std::function<void(unsigned)> &share) {
+        if (n_shares == 0) return;
+        std::lock_guard<std::mutex> region(region_mutex_);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            share_ = &share;
+            n_shares_ = n_shares;
+            next_share_ = 0;
+            unfinished_ = n_shares;
+            generation_ += 1;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(mutex_);
+        done_.wait(lock, [&] { return unfinished_ == 0; });
+        share_ = nullptr;
+    }
+
+  private:
+    WorkerPool() {
+        const unsigned n = std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+        for (unsigned k = 0; k < n; k++) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stopping_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread &thread : threads_) thread.join();
+    }
+    void work() { // takes shares until none is left
+        for (;;) {
+            unsigned mine;
+            const std::function<void(unsigned)> *share;
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                if (!share_ || next_share_ >= n_shares_) return;
+                mine = next_share_++;
+                share = share_;
+            }
+            (*share)(mine);
+            std::lock_guard<std::mutex> lock(mutex_);
+            if (--unfinished_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                wake_.wait(lock, [&] { return stopping_ || generation_ != seen; });
+                if (stopping_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex region_mutex_, mutex_;
+    std::condition_variable wake_, done_;
+    const std::function<void(unsigned)> *share_ = nullptr;
+    unsigned n_shares_ = 0, next_share_ = 0, unfinished_ = 0;
+    unsigned long long generation_ = 0;
+    bool stopping_ = false;
+};
+
+// Rows (or values) from which such a fill is shared out (MDB_HOST_PARALLEL_MIN_ROWS: the sanitizer runs set it
+// low so that their small batches go through the pool too).
+size_t parallel_min_rows() {
+    static const size_t setting = [] {
+        const char *text = std::getenv("MDB_HOST_PARALLEL_MIN_ROWS");
+        const long long value = text ? std::atoll(text) : 0;
+        return value > 0 ? static_cast<size_t>(value) : static_cast<size_t>(1) << 18;
+    }();
+    return setting;
+}
+
+} // namespace
 
 namespace {
 
@@ -643,20 +740,23 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
             _mm_sfence();
         };
         const int64_t new_rows = total - leftovers;
-        const unsigned n_threads = new_rows * static_cast<int64_t>(replications.size()) >= (1 << 18)
-                                       ? std::min(16u, std::max(1u, std::thread::hardware_concurrency()))
+        const unsigned n_threads = static_cast<size_t>(new_rows) * replications.size() >= parallel_min_rows()
+                                       ? WorkerPool::instance().width()
                                        : 1u;
         if (n_threads == 1) {
             replicate(0, batch.num_rows, leftovers);
         } else {
-            std::vector<std::thread> workers;
+            struct Share {
+                int64_t first_row, last_row, at;
+            };
+            std::vector<Share> shares;
             int64_t at = leftovers, row = 0;
             for (unsigned w = 0; w < n_threads; w++) {
                 const int64_t last_row = batch.num_rows * static_cast<int64_t>(w + 1) / n_threads;
-                workers.emplace_back(replicate, row, last_row, at);
+                shares.push_back({row, last_row, at});
                 for (; row < last_row; row++) at += rows_per_segment[row];
             }
-            for (std::thread &worker : workers) worker.join();
+            WorkerPool::instance().run(n_threads, [&](unsigned k) { replicate(shares[k].first_row, shares[k].last_row, shares[k].at); });
         }
     }
 
@@ -1206,14 +1306,13 @@ std::vector<RecordBatch> UncompressedDataManager::compress_finished_buffers() {
                 }
             }
         };
-        const unsigned n_gatherers = group_points >= (1u << 22) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        const unsigned n_gatherers = group_points >= 16 * parallel_min_rows() ? WorkerPool::instance().width() : 1u;
         if (n_gatherers == 1) {
             gather(0, finished_.size());
         } else {
-            std::vector<std::thread> gatherers;
-            for (unsigned w = 0; w < n_gatherers; w++)
-                gatherers.emplace_back(gather, finished_.size() * w / n_gatherers, finished_.size() * (w + 1) / n_gatherers);
-            for (std::thread &gatherer : gatherers) gatherer.join();
+            WorkerPool::instance().run(n_gatherers, [&](unsigned w) {
+                gather(finished_.size() * w / n_gatherers, finished_.size() * (w + 1) / n_gatherers);
+            });
         }
         OwnedGuard guard;
         check(mdb_compress_chunks(ctx_, chunk_ts_data, chunk_values_data, offsets.data(), offsets.size() - 1,

@@ -38,6 +38,7 @@ def test_host_operators_over_canned_answers(built, flavour):
     env = dict(os.environ, **options)
     env["MDB_HOST_LIBRARY_UNDER_TEST"] = os.path.join(STUB, "_build", f"libmdb_host_{flavour}.so")
     env["MDB_STUB_FIXTURES"] = os.path.join(REPO_ROOT, "tests", "golden", "host_stub_fixtures.bin")
+    env["MDB_HOST_PARALLEL_MIN_ROWS"] = "64"  # the library's worker pool also for these small batches
     if runtime:
         path = subprocess.run(["gcc", f"-print-file-name={runtime}"], capture_output=True, text=True).stdout.strip()
         if not os.path.isabs(path):
