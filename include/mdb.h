@@ -42,7 +42,9 @@ typedef struct mdb_ctx mdb_ctx;
 int mdb_init(int device, mdb_ctx **ctx);
 int mdb_close(mdb_ctx *ctx);
 /* Another context on the device of `ctx` (its own stream and scratch memory): what an operator that
- * wants two batches in flight - the copy of one overlapping the kernels of the next - asks for. */
+ * wants two batches in flight - the copy of one overlapping the kernels of the next - asks for.
+ * (All contexts of a device share one pool of page-locked result blocks, so a context made per query does
+ * not pay for pinning memory again.) */
 int mdb_clone(mdb_ctx *ctx, mdb_ctx **out);
 const char *mdb_last_error(void);
 /* "libmdb_hip <version> gfx950"; never fails. */

@@ -109,8 +109,8 @@ struct mdb_ctx {
     void *pinned = nullptr; // pinned host staging
     uint64_t pinned_bytes = 0;
 
-    std::shared_ptr<mdb::PinnedPool> pinned_pool = std::make_shared<mdb::PinnedPool>();
-    bool owns_pinned_pool = true; // false for a clone: it shares the pool of the context it was made from
+    std::shared_ptr<mdb::PinnedPool> pinned_pool; // the device's pool of page-locked result blocks (mdb_init)
+    bool owns_pinned_pool = false;
     uint64_t scratch_limit = 0;   // mdb_set_scratch_limit: device scratch kept between calls (0: all of it)
 
     // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).

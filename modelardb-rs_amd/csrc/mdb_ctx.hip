@@ -231,6 +231,19 @@ int mdb_init(int device, mdb_ctx **out) {
         return fail("hipStreamCreate failed.");
     }
     ctx->own_stream = true;
+    // One pool of page-locked result blocks per device for the whole process: an operator makes its contexts per
+    // query, and a pool that died with them would pay hipHostMalloc (13 ms for 70 MB) for every block of every
+    // query again. At most eight blocks are kept (mdb_trim gives them back); never freed at process exit,
+    // when the HIP runtime may be gone already.
+    {
+        static std::mutex pools_mutex;
+        static std::map<int, std::shared_ptr<PinnedPool>> *pools = new std::map<int, std::shared_ptr<PinnedPool>>();
+        std::lock_guard<std::mutex> lock(pools_mutex);
+        std::shared_ptr<PinnedPool> &pool = (*pools)[device];
+        if (!pool) pool = std::make_shared<PinnedPool>();
+        ctx->pinned_pool = pool;
+        ctx->owns_pinned_pool = false;
+    }
     *out = ctx;
     return 0;
 }
@@ -238,10 +251,6 @@ int mdb_init(int device, mdb_ctx **out) {
 int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
     if (!ctx || !out) return fail("ctx and out must not be NULL.");
     if (mdb_init(ctx->device, out)) return 1;
-    // One pool of page-locked blocks for the context and its clones: an operator makes its second context
-    // per query, and a pool that died with it would pay hipHostMalloc for every block again.
-    (*out)->pinned_pool = ctx->pinned_pool;
-    (*out)->owns_pinned_pool = false;
     (*out)->scratch_limit = ctx->scratch_limit;
     return 0;
 }
