@@ -44,7 +44,8 @@ int mdb_close(mdb_ctx *ctx);
 /* Another context on the device of `ctx` (its own stream and scratch memory): what an operator that
  * wants two batches in flight - the copy of one overlapping the kernels of the next - asks for.
  * (All contexts of a device share one pool of page-locked result blocks, so a context made per query does
- * not pay for pinning memory again.) */
+ * not pay for pinning memory again; and a clone that is closed is kept - up to four of them - for the next
+ * mdb_clone of the same context, stream and scratch included, until that context is closed itself.) */
 int mdb_clone(mdb_ctx *ctx, mdb_ctx **out);
 const char *mdb_last_error(void);
 /* "libmdb_hip <version> gfx950"; never fails. */

@@ -95,6 +95,12 @@ struct PinnedPool {
     void close();
 };
 
+struct CloneCache {
+    std::mutex mutex;
+    std::vector<mdb_ctx *> idle;
+    bool origin_closed = false;
+};
+
 } // namespace mdb
 
 struct mdb_ctx {
@@ -112,6 +118,10 @@ struct mdb_ctx {
     std::shared_ptr<mdb::PinnedPool> pinned_pool; // the device's pool of page-locked result blocks (mdb_init)
     bool owns_pinned_pool = false;
     uint64_t scratch_limit = 0;   // mdb_set_scratch_limit: device scratch kept between calls (0: all of it)
+    // mdb_clone / mdb_close of a clone: closed clones wait here for the next mdb_clone of the same context (a
+    // stream costs 2-6 ms to make and as much to destroy, an operator asks for its second context per query).
+    std::shared_ptr<mdb::CloneCache> clones; // shared by a context and its clones
+    bool is_clone = false;
 
     // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).
     void *comm = nullptr;

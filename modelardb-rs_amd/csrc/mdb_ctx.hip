@@ -250,13 +250,49 @@ int mdb_init(int device, mdb_ctx **out) {
 
 int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
     if (!ctx || !out) return fail("ctx and out must not be NULL.");
+    {
+        mdb::CallGuard lock(ctx);
+        if (!ctx->clones) ctx->clones = std::make_shared<CloneCache>();
+    }
+    {
+        std::lock_guard<std::mutex> lock(ctx->clones->mutex);
+        if (!ctx->clones->idle.empty()) { // a clone closed earlier: its stream and scratch are still there
+            *out = ctx->clones->idle.back();
+            ctx->clones->idle.pop_back();
+            (*out)->scratch_limit = ctx->scratch_limit;
+            return 0;
+        }
+    }
     if (mdb_init(ctx->device, out)) return 1;
+    (*out)->clones = ctx->clones;
+    (*out)->is_clone = true;
     (*out)->scratch_limit = ctx->scratch_limit;
     return 0;
 }
 
 int mdb_close(mdb_ctx *ctx) {
     if (!ctx) return 0;
+    if (ctx->clones) {
+        std::vector<mdb_ctx *> orphans;
+        {
+            std::lock_guard<std::mutex> lock(ctx->clones->mutex);
+            if (ctx->is_clone && !ctx->clones->origin_closed && ctx->clones->idle.size() < 4) {
+                // kept for the next mdb_clone of the context it was made from (idle: nothing of it is in use)
+                (void)hipSetDevice(ctx->device);
+                (void)hipStreamSynchronize(ctx->stream);
+                ctx->clones->idle.push_back(ctx);
+                return 0;
+            }
+            if (!ctx->is_clone) {
+                ctx->clones->origin_closed = true;
+                orphans.swap(ctx->clones->idle);
+            }
+        }
+        for (mdb_ctx *orphan : orphans) {
+            orphan->clones.reset();
+            (void)mdb_close(orphan);
+        }
+    }
     (void)mdb_comm_close(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
