@@ -1546,6 +1546,23 @@ int mdbh_sorted_join_poll_next(void *handle, ArrowArray *out_array, ArrowSchema 
     });
 }
 
+/* Polls the join to its end inside the library (what a consumer written in a compiled language costs):
+ * rows and batches returned, for measurements. */
+int mdbh_sorted_join_drain(void *handle, uint64_t *rows, uint64_t *batches) {
+    return guarded([&] {
+        mdbhost::SortedJoinStream &stream = *static_cast<JoinHandle *>(handle)->stream;
+        uint64_t n_rows = 0, n_batches = 0;
+        while (true) {
+            mdbhost::RecordBatch batch;
+            if (stream.poll_next(&batch) != mdbhost::PollState::ReadySome) break;
+            n_rows += static_cast<uint64_t>(batch.num_rows);
+            n_batches += 1;
+        }
+        *rows = n_rows;
+        *batches = n_batches;
+    });
+}
+
 int mdbh_sorted_join_describe(void *handle, char *out, uint64_t cap) {
     return guarded([&] {
         JoinHandle *h = static_cast<JoinHandle *>(handle);

@@ -244,6 +244,12 @@ class SortedJoinStream:
                 return batches, state
             batches.append(batch)
 
+    def drain(self):
+        """Poll the join to its end inside the library; returns (rows, batches)."""
+        rows, batches = C.c_uint64(), C.c_uint64()
+        _check(lib().mdbh_sorted_join_drain(self.handle, C.byref(rows), C.byref(batches)))
+        return rows.value, batches.value
+
     def describe(self):
         out = C.create_string_buffer(1024)
         _check(lib().mdbh_sorted_join_describe(self.handle, out, C.c_uint64(1024)))

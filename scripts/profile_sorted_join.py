@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SortedJoinExec over one GridExec per field column (three fields sharing timestamps and a tag), host batches
-in, joined batches out, polled from Python in large slices. Development tool."""
+in, joined batches of 8 192 rows out, polled to the end inside the library. Development tool."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,19 +28,14 @@ def main():
     for tags in ((), ("tag",)):
         for rep in range(2):
             order = ["timestamp", "field", "field", "field"] + ([("tag", "tag")] if tags else [])
-            join = host.SortedJoinStream(ctx, 3, order, tag_names=tags, batch_size=1 << 20)
+            join = host.SortedJoinStream(ctx, 3, order, tag_names=tags, batch_size=8192)
             for index, arrow in enumerate(fields):
                 source = arrow if tags else arrow.drop_columns(["tag"])
                 for first in range(0, source.num_rows, 8192):
                     join.push(index, source.slice(first, 8192))
             join.finish_input()
             started = time.perf_counter()
-            rows = 0
-            while True:
-                state, batch = join.poll_next()
-                if state != host.SortedJoinStream.READY_SOME:
-                    break
-                rows += batch.num_rows
+            rows, _ = join.drain()
             seconds = time.perf_counter() - started
             print(f"{len(tags)} tag columns: {rows} joined rows of 3 fields in {seconds * 1e3:.1f} ms: "
                   f"{rows / seconds / 1e9:.2f} G rows/s, {3 * rows / seconds / 1e9:.2f} G values/s", flush=True)
