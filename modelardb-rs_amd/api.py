@@ -99,6 +99,13 @@ class Context:
             self.lib.mdb_close(self.handle)
             self.handle = C.c_void_p()
 
+    def clone(self):
+        """Another context on the same device (mdb_clone): its own stream and scratch."""
+        other = Context.__new__(Context)
+        other.lib, other.device, other.handle = self.lib, self.device, C.c_void_p()
+        self._check(self.lib.mdb_clone(self.handle, C.byref(other.handle)))
+        return other
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, hbm = C.c_int32(), C.c_uint64()

@@ -567,3 +567,25 @@ def test_scratch_limit_gives_memory_back_after_every_call():
     assert limited.trim() > 4 * len(timestamps)
     unlimited.close()
     limited.close()
+
+
+def test_clones_are_kept_for_the_next_clone_and_survive_their_origin():
+    # mdb_clone / mdb_close: a closed clone (stream, scratch) waits for the next mdb_clone of the same context;
+    # the origin's close destroys the waiting ones; a clone still in use then is simply closed when its time comes.
+    from modelardb_rs_amd import api
+    timestamps, values = cases.synthetic_series(50_000, True, (1.0, 1.05), seed=8)
+    batch = ora.try_compress_univariate_time_series(timestamps, values, cases.error_bounds()["rel1"])
+    expected = ora.grid_batch(batch)
+    origin = api.Context(0)
+    first = origin.clone()
+    cases.assert_grid_equal(first.grid_batch(batch), expected)
+    kept_handle = first.handle.value
+    first.close()
+    second, third = origin.clone(), origin.clone()
+    assert second.handle.value == kept_handle and third.handle.value != kept_handle   # recycled, then a new one
+    for context in (second, third, origin):
+        cases.assert_grid_equal(context.grid_batch(batch), expected)
+    second.close()
+    origin.close()                                   # destroys the idle clone; `third` is still in use
+    cases.assert_grid_equal(third.grid_batch(batch), expected)
+    third.close()
