@@ -47,6 +47,9 @@ struct GridHeader {
     unsigned long long metrics[10]; // [0..8] mdb_grid_metrics minus rows_created (= total_points);
                                     // [9] bytes of the MacaqueV streams the parallel decoder takes
     unsigned long long checkpointed_points; // visible points of the segments k_grid_timestamps decodes
+    unsigned long long checkpointed_pieces; // pieces of their streams
+    unsigned long long jump_segments;       // segments whose timestamps k_grid_tiles takes from a jump list
+    unsigned long long live_pieces;         // pieces listed in TsCheckpoints::live (k_grid_ts_count)
 };
 
 // MODE 0: every segment through the generic analysis (a time range is given).
@@ -61,16 +64,16 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     unsigned long long *__restrict__ block_serial, GridHeader *__restrict__ header, TsCheckpoints checkpoints,
     const uint32_t *__restrict__ known_totals, unsigned long long *__restrict__ pending,
     uint32_t *__restrict__ block_pending, uint32_t n_blocks) {
-    __shared__ unsigned long long lds_metrics[14];
+    __shared__ unsigned long long lds_metrics[16];
     // MODE 2 is launched with few workgroups that walk the blocks of the MODE 1 launch: a batch of simple
     // segments only costs a look at its block flags (32 k workgroups that return at once cost 0.16 ms).
     for (uint32_t block = blockIdx.x; block < n_blocks; block += gridDim.x) {
     if (MODE == 2 && block_pending[block] == 0) continue;
     if (MODE == 2) __syncthreads();
-    if (threadIdx.x < 14) lds_metrics[threadIdx.x] = 0;
+    if (threadIdx.x < 16) lds_metrics[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)block * SEGS_PER_BLOCK;
-    unsigned long long points = 0, serial = 0, checkpointed = 0;
+    unsigned long long points = 0, serial = 0, checkpointed = 0, checkpointed_pieces = 0, with_jumps = 0;
     unsigned long long m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t error = 0;
     bool left_any = false;
@@ -92,9 +95,23 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         }
         SegInfo info = MODE == 1 ? analyse_segment<true>(s, i) : analyse_segment<false>(s, i, known_totals, &checkpoints);
         if (MODE != 1 && range.enabled) apply_time_range(s, i, info, range, nullptr, nullptr, &checkpoints);
+        uint32_t jump_base = 0;
+        if (MODE != 1 && !range.enabled && (info.desc.flags & FLAG_CHECKPOINTS) && checkpoints.jumps) {
+            // A fixed rate with a few jumps (k_grid_ts_count has listed them): k_grid_tiles' work.
+            const unsigned long long first_piece = checkpoints.piece_base[i];
+            const TsJump list = checkpoints.jumps[first_piece * TS_JUMPS_PER_PIECE];
+            if (list.count != TS_NO_JUMPS) {
+                info.desc.flags = (info.desc.flags & ~FLAG_CHECKPOINTS) | FLAG_JUMPS | (list.count << FLAG_JUMP_COUNT_SHIFT);
+                info.desc.delta = list.value;
+                jump_base = (uint32_t)first_piece;
+                with_jumps += 1;
+            }
+        }
         error |= info.error;
         const SegDesc &d = info.desc;
-        desc[i] = make_tile_desc(d);
+        TileDesc tile_desc = make_tile_desc(d);
+        if (d.flags & FLAG_JUMPS) set_jump_list(tile_desc, jump_base);
+        desc[i] = tile_desc;
         bool is_serial = (d.flags & FLAG_SERIAL) != 0;
         counts[i] = d.n_visible | (is_serial ? SERIAL_BIT : 0u);
         if (MODE != 1 && !(d.flags & FLAG_REGULAR)) { // k_grid_serial need not parse the timestamps to count again
@@ -111,7 +128,10 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
         m[3] += (d.flags & FLAG_HAS_RESIDUALS) ? 1 : 0;
         m[7] += (d.flags & FLAG_REGULAR) ? 1 : 0;
         m[8] += (d.flags & FLAG_REGULAR) ? 0 : 1;
-        if (MODE != 1 && (d.flags & FLAG_CHECKPOINTS)) checkpointed += d.n_visible;
+        if (MODE != 1 && (d.flags & FLAG_CHECKPOINTS)) {
+            checkpointed += d.n_visible;
+            if (checkpoints.piece_base) checkpointed_pieces += checkpoints.piece_base[i + 1] - checkpoints.piece_base[i];
+        }
         // Bytes of the MacaqueV streams long enough for the parallel decoder (bounds its scratch).
         if (MODE != 1 && type == MDB_MACAQUE_V_ID && mv_min_values != 0xffffffffu) {
             const uint32_t bytes = s.values.views[i].x;
@@ -122,6 +142,8 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     atomicAdd(&lds_metrics[10], points);
     atomicAdd(&lds_metrics[11], serial);
     if (checkpointed) atomicAdd(&lds_metrics[13], checkpointed);
+    if (checkpointed_pieces) atomicAdd(&lds_metrics[15], checkpointed_pieces);
+    if (with_jumps) atomicAdd(&lds_metrics[14], with_jumps);
     if (MODE == 1 && left_any && (threadIdx.x & (MDB_WAVE - 1)) == 0) atomicAdd(&lds_metrics[12], 1ull);
 #pragma unroll
     for (int k = 0; k < 10; k++)
@@ -141,6 +163,8 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
     if (threadIdx.x < 10 && lds_metrics[threadIdx.x])
         atomicAdd(&header->metrics[threadIdx.x], lds_metrics[threadIdx.x]);
     if (threadIdx.x == 13 && lds_metrics[13]) atomicAdd(&header->checkpointed_points, lds_metrics[13]);
+    if (threadIdx.x == 14 && lds_metrics[14]) atomicAdd(&header->jump_segments, lds_metrics[14]);
+    if (threadIdx.x == 15 && lds_metrics[15]) atomicAdd(&header->checkpointed_pieces, lds_metrics[15]);
     }
 }
 
@@ -239,11 +263,16 @@ __device__ __forceinline__ PointValue reconstruct_point(const TileDesc &d, uint3
 }
 
 constexpr int TILE_LDS_DESCS = 128; // descriptors of the first segments of a tile staged in LDS
+constexpr uint32_t NO_JUMP_LIST = 0xffffffffu;
+constexpr uint32_t TILE_ROWS = 256; // (k_grid_tiles_jumps) segments plus jumps of a tile that is done by its table of rows
 
-__global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
+// JUMPS: some segment of the batch has a jump list (GridHeader::jump_segments; TsJump says what that is); the
+// flavour without is what a batch of regular timestamps runs.
+template <bool JUMPS>
+__device__ __forceinline__ void grid_tile(
     const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
-    uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val, const TsJump *__restrict__ jumps) {
     __shared__ uint32_t rel[TILE_LDS_SEGMENTS + 1]; // rel[k] = offsets[s0 + k] - tile_start, k >= 1
     __shared__ __attribute__((aligned(16))) TileDesc lds_desc[TILE_LDS_DESCS];
     __shared__ __attribute__((aligned(16))) longlong2 ts_slab[TILE_THREADS / MDB_WAVE][2 * MDB_WAVE];
@@ -273,18 +302,166 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     const int lane = threadIdx.x & (MDB_WAVE - 1);
     const int wave = threadIdx.x / MDB_WAVE;
 
+    // (JUMPS) The rows of the tile: a segment with a jump list is, between two jumps, a segment with regular
+    // timestamps that are all late by what the jumps so far add up to. So the table the points are looked up in
+    // gets a row per segment AND per jump - where it begins in the tile, which segment it belongs to, how late
+    // it is - built once per tile, the jumps read from memory by all threads at once, and a point costs what
+    // it costs in a batch of regular timestamps plus a few steps of the search. (Looking the jumps up where the
+    // points are computed, even by the whole wave together as below, doubles the instructions per point: 3.5
+    // instead of 2.0 ms per 10^9 points.) A tile with more rows than the table holds (a list of hundreds of
+    // jumps: the whole list is taken, not only the jumps inside the tile), or with more segments than have their
+    // descriptors in LDS, is done the other way.
+    __shared__ uint32_t row_rel[JUMPS ? TILE_ROWS : 1];
+    __shared__ uint8_t row_seg[JUMPS ? TILE_ROWS : 1];
+    __shared__ long long row_late[JUMPS ? TILE_ROWS : 1];
+    __shared__ uint32_t row_start[JUMPS ? TILE_LDS_DESCS + 1 : 1]; // the first row of segment k
+    __shared__ uint32_t row_totals[TILE_THREADS / MDB_WAVE];
+    uint32_t n_rows = 0; // (0: no table)
+    if (JUMPS && n_in_tile <= (uint32_t)TILE_LDS_DESCS) {
+        uint32_t mine = 0; // rows of segment threadIdx.x
+        if (threadIdx.x < n_in_tile) {
+            const uint32_t flags = lds_desc[threadIdx.x].flags;
+            mine = 1u + ((flags & FLAG_JUMPS) ? flags >> FLAG_JUMP_COUNT_SHIFT : 0u);
+        }
+        uint32_t inclusive = mine;
+#pragma unroll
+        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+            const uint32_t up = __shfl_up(inclusive, delta, MDB_WAVE);
+            if (lane >= delta) inclusive += up;
+        }
+        if (lane == MDB_WAVE - 1) row_totals[wave] = inclusive;
+        __syncthreads();
+        uint32_t in_front = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < TILE_THREADS / MDB_WAVE; w++) {
+            in_front += w < wave ? row_totals[w] : 0u;
+            total += row_totals[w];
+        }
+        if (threadIdx.x < n_in_tile) row_start[threadIdx.x] = in_front + inclusive - mine;
+        __syncthreads();
+        if (total <= TILE_ROWS) {
+            n_rows = total;
+            const uint32_t first_index = (uint32_t)(tile_start - s0_offset); // of segment 0's points, the first in the tile
+            for (uint32_t row = threadIdx.x; row < total; row += TILE_THREADS) {
+                uint32_t k = 0, hi = n_in_tile; // the last segment whose first row is at or before `row`
+                while (hi - k > 1) {
+                    const uint32_t mid = (k + hi) >> 1;
+                    if (row_start[mid] <= row) k = mid; else hi = mid;
+                }
+                const uint32_t e = row - row_start[k];
+                uint32_t begins = k == 0 ? 0u : rel[k];
+                long long late = 0;
+                if (e > 0) {
+                    const TsJump jump = jumps[(uint64_t)jump_list_of(lds_desc[k]) * TS_JUMPS_PER_PIECE + e];
+                    // (a jump of segment 0 in front of the tile: at the tile's first point, where the search
+                    // takes the last of the rows that begin at the same point)
+                    const uint32_t from = k == 0 ? first_index : 0u;
+                    begins += jump.position > from ? jump.position - from : 0u;
+                    late = jump.value;
+                }
+                row_rel[row] = begins;
+                row_seg[row] = (uint8_t)k;
+                row_late[row] = late;
+            }
+        }
+        __syncthreads();
+    }
+
+    // (JUMPS) the entries of a jump list this lane has read last: entry kept_first + lane of segment kept_segment
+    TsJump kept = TsJump{0xffffffffu, 0u, 0};
+    uint32_t kept_segment = NO_JUMP_LIST, kept_first = 0;
 #pragma unroll 1
     for (uint32_t j = 0; j < TILE_POINTS / (TILE_THREADS * 4); j++) {
         // The wave's 256 points of this iteration start at wave_base (wave-uniform).
-        const uint64_t wave_base = tile_start + (uint64_t)j * (TILE_THREADS * 4) + (uint64_t)wave * (MDB_WAVE * 4);
-        if (wave_base >= tile_end) break;
+        // (JUMPS, a tile without the table of rows: the four rounds of a wave follow each other in the output, so
+        // that they mostly stay inside one segment and the part of its jump list the wave has read serves the
+        // next round too)
+        const uint64_t wave_base = JUMPS && n_rows == 0 ? tile_start + (uint64_t)wave * (TILE_POINTS / (TILE_THREADS / MDB_WAVE)) + (uint64_t)j * (MDB_WAVE * 4)
+                                         : tile_start + (uint64_t)j * (TILE_THREADS * 4) + (uint64_t)wave * (MDB_WAVE * 4);
+        if (wave_base >= tile_end) {
+            if (JUMPS) continue;
+            break;
+        }
         const uint64_t p = wave_base + (uint64_t)lane * 4;
         int64_t t[4] = {0, 0, 0, 0};
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         // Points of a segment whose timestamps k_grid_timestamps decodes are written by it, values included:
         // where all 256 points of the wave's iteration are such points nothing is stored here.
         bool left_to_timestamps = p >= tile_end;
-        if (p < tile_end) {
+        // (JUMPS) for each of the lane's points: its segment (relative to s0) if that has a jump list, and its
+        // index in the segment.
+        uint32_t list_of[4] = {NO_JUMP_LIST, NO_JUMP_LIST, NO_JUMP_LIST, NO_JUMP_LIST};
+        uint32_t index_of[4] = {0, 0, 0, 0};
+        if (JUMPS && n_rows > 0) {
+            if (p < tile_end) {
+                const uint32_t local = (uint32_t)(p - tile_start);
+                uint32_t r = 0, hi = n_rows; // the last row that begins at or before the point
+                while (hi - r > 1) {
+                    const uint32_t mid = (r + hi) >> 1;
+                    if (row_rel[mid] <= local) r = mid; else hi = mid;
+                }
+                uint32_t segment = row_seg[r];
+                int64_t late = row_late[r];
+                uint64_t segment_offset = segment == 0 ? s0_offset : tile_start + rel[segment];
+                TileDesc d = lds_desc[segment];
+                const uint32_t index = (uint32_t)(p - segment_offset);
+                const uint32_t next_begins = r + 1 < n_rows ? row_rel[r + 1] : 0xffffffffu;
+                // All four points in one row, the common case - or in two rows of one segment, which is what a
+                // jump looks like to the lane it falls into (with a jump per hundred points every other round of
+                // a wave has such a lane, and the way out below costs the whole wave more than the round).
+                bool together = index + 4 <= d.n_points;
+                uint32_t split = 4; // the first of the four points that lies in the second row
+                int64_t late_then = late;
+                if (together && local + 4 > next_begins) {
+                    const uint32_t after_begins = r + 2 < n_rows ? row_rel[r + 2] : 0xffffffffu;
+                    together = row_seg[r + 1] == segment && local + 4 <= after_begins;
+                    split = next_begins - local;
+                    late_then = row_late[r + 1];
+                }
+                if (together) {
+                    left_to_timestamps = (d.flags & FLAG_CHECKPOINTS) != 0;
+                    const int64_t regular = reconstruct_point(d, index).t;
+                    t[0] = regular + late;
+                    t[1] = regular + d.delta + (split <= 1 ? late_then : late);
+                    t[2] = regular + 2 * d.delta + (split <= 2 ? late_then : late);
+                    t[3] = regular + 3 * d.delta + (split <= 3 ? late_then : late);
+                    if ((d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) {
+                        v.x = (float)(d.slope * (double)t[0] + d.intercept);
+                        v.y = (float)(d.slope * (double)t[1] + d.intercept);
+                        v.z = (float)(d.slope * (double)t[2] + d.intercept);
+                        v.w = (float)(d.slope * (double)t[3] + d.intercept);
+                    } else {
+                        v = make_float4(d.value, d.value, d.value, d.value);
+                    }
+                } else {
+                    // The group straddles a segment boundary (or two jumps): row by row.
+                    float values[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint64_t q = p + k;
+                        if (q >= tile_end) break;
+                        bool moved = false;
+                        while (r + 1 < n_rows && row_rel[r + 1] <= local + k) {
+                            r += 1;
+                            moved = true;
+                        }
+                        if (moved) {
+                            late = row_late[r];
+                            if (row_seg[r] != segment) {
+                                segment = row_seg[r];
+                                segment_offset = tile_start + rel[segment]; // (not segment 0: that one comes first)
+                                d = lds_desc[segment];
+                            }
+                        }
+                        const int64_t timestamp = reconstruct_point(d, (uint32_t)(q - segment_offset)).t + late;
+                        t[k] = timestamp;
+                        values[k] = (d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID ? (float)(d.slope * (double)timestamp + d.intercept)
+                                                                               : d.value;
+                    }
+                    v = make_float4(values[0], values[1], values[2], values[3]);
+                }
+            }
+        } else if (p < tile_end) {
             const uint32_t local = (uint32_t)(p - tile_start);
             // Largest k in [0, n_in_tile) with offsets[s0 + k] <= p.
             uint32_t lo = 0, hi = n_in_tile;
@@ -308,7 +485,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
                 left_to_timestamps = (d.flags & FLAG_CHECKPOINTS) != 0;
                 PointValue q0 = reconstruct_point(d, index);
                 t[0] = q0.t; t[1] = q0.t + d.delta; t[2] = t[1] + d.delta; t[3] = t[2] + d.delta;
-                if ((d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) {
+                if (JUMPS && (d.flags & FLAG_JUMPS)) {
+                    // (the timestamps are finished, and the values computed from them, below)
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        list_of[k] = lo;
+                        index_of[k] = index + k;
+                    }
+                } else if ((d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) {
                     v.x = q0.v;
                     v.y = (float)(d.slope * (double)t[1] + d.intercept);
                     v.z = (float)(d.slope * (double)t[2] + d.intercept);
@@ -333,6 +517,122 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
                     PointValue point = reconstruct_point(d, (uint32_t)(q - segment_offset));
                     t[k] = point.t;
                     values[k] = point.v;
+                    if (JUMPS && (d.flags & FLAG_JUMPS)) {
+                        // (k is not a compile-time index here: the arrays stay in registers this way)
+                        const uint32_t index = (uint32_t)(q - segment_offset);
+                        if (k == 0) { list_of[0] = lo; index_of[0] = index; }
+                        if (k == 1) { list_of[1] = lo; index_of[1] = index; }
+                        if (k == 2) { list_of[2] = lo; index_of[2] = index; }
+                        if (k == 3) { list_of[3] = lo; index_of[3] = index; }
+                    }
+                }
+                v = make_float4(values[0], values[1], values[2], values[3]);
+            }
+        }
+        if (JUMPS && n_rows == 0) {
+            // (A tile without the table of rows.)
+            // The points of the wave that lie in segments with a jump list, segment by segment (one or two per
+            // wave, unless the segments are short): they follow each other in the segment as they do in the
+            // wave, so the wave reads the part of the list it needs together, 64 entries per load, and every
+            // jump that lies among its points is applied by all lanes at once. (Every lane searching the list
+            // of its segment by itself is seven dependent loads per lane and four times that for a lane whose
+            // points lie in two segments: 4.8 ms per 10^9 points against 2.0 for regular timestamps.)
+            uint32_t next_segment = 0; // lists of segments below this one have been applied
+            for (;;) {
+                uint32_t lowest = NO_JUMP_LIST; // the lane's first segment with a list that is still to do
+#pragma unroll
+                for (int k = 3; k >= 0; k--)
+                    if (list_of[k] != NO_JUMP_LIST && list_of[k] >= next_segment) lowest = list_of[k];
+                const unsigned long long waiting = __ballot(lowest != NO_JUMP_LIST);
+                if (!waiting) break;
+                // (segments ascend with the points: the first waiting lane has the lowest one)
+                const uint32_t segment = (uint32_t)__builtin_amdgcn_readlane((int)lowest, __ffsll((long long)waiting) - 1);
+                next_segment = segment + 1;
+                bool in_it[4];
+                uint32_t my_first = 0xffffffffu, my_last = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    in_it[k] = list_of[k] == segment;
+                    if (in_it[k]) {
+                        my_first = min(my_first, index_of[k]);
+                        my_last = max(my_last, index_of[k]);
+                    }
+                }
+                const unsigned long long group = __ballot(my_first != 0xffffffffu);
+                const uint32_t index_first = (uint32_t)__builtin_amdgcn_readlane((int)my_first, __ffsll((long long)group) - 1);
+                const uint32_t index_end = (uint32_t)__builtin_amdgcn_readlane((int)my_last, 63 - __clzll((long long)group)) + 1u;
+                const TileDesc listed = descriptor(segment); // (the same for every lane)
+                const uint32_t count = listed.flags >> FLAG_JUMP_COUNT_SHIFT;
+                const TsJump *list = jumps + (uint64_t)jump_list_of(listed) * TS_JUMPS_PER_PIECE + 1;
+                // How many jumps lie before index_first: narrowed down to a range of at most 64 entries by
+                // probes of the whole wave (none for a list of up to 64 entries).
+                uint32_t e_lo = 0, e_hi = count;
+                while (e_hi - e_lo > (uint32_t)MDB_WAVE) {
+                    const uint32_t stride = (e_hi - e_lo + MDB_WAVE - 1) / MDB_WAVE;
+                    const uint32_t e = e_lo + (uint32_t)lane * stride;
+                    const bool before = e < e_hi && list[e].position < index_first;
+                    const uint32_t c = (uint32_t)__popcll(__ballot(before)); // (the probes ascend: a prefix of the lanes)
+                    const uint32_t probe_end = e_lo + c * stride;
+                    e_lo = c ? probe_end - stride + 1u : e_lo;
+                    e_hi = min(e_hi, probe_end);
+                }
+                e_lo -= e_lo ? 1u : 0u; // (the last jump before index_first may be the entry in front of that range)
+                int64_t applied = 0;    // what the jumps applied so far add up to (the last one's value)
+                for (;;) {
+                    const uint32_t e = e_lo + (uint32_t)lane;
+                    TsJump entry = kept;
+                    if (kept_segment != segment || kept_first != e_lo) {
+                        entry = TsJump{0xffffffffu, 0u, 0};
+                        if (e < count) entry = list[e];
+                        kept = entry;
+                        kept_segment = segment;
+                        kept_first = e_lo;
+                    }
+                    const unsigned long long before = __ballot(entry.position < index_first);
+                    unsigned long long inside = __ballot(entry.position >= index_first && entry.position < index_end);
+                    auto value_of = [&](int from) {
+                        const uint32_t high = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)entry.value >> 32), from);
+                        const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)entry.value, from);
+                        return (int64_t)(((uint64_t)high << 32) | low);
+                    };
+                    if (before) {
+                        const int64_t value = value_of(63 - __clzll((long long)before));
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (in_it[k]) t[k] += value - applied;
+                        applied = value;
+                    }
+                    while (inside) {
+                        const int from = __ffsll((long long)inside) - 1;
+                        inside &= inside - 1;
+                        const uint32_t position = (uint32_t)__builtin_amdgcn_readlane((int)entry.position, from);
+                        const int64_t value = value_of(from);
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (in_it[k] && index_of[k] >= position) t[k] += value - applied;
+                        applied = value;
+                    }
+                    // (more of the list may lie among the wave's points: the entries behind this load's last one)
+                    const uint32_t last_position = (uint32_t)__builtin_amdgcn_readlane((int)entry.position, MDB_WAVE - 1);
+                    if (e_lo + MDB_WAVE >= count || last_position >= index_end) break;
+                    e_lo += MDB_WAVE;
+                }
+            }
+            // Swing values of these points are values of their timestamps (swing.rs:304-319).
+            if (list_of[0] != NO_JUMP_LIST || list_of[1] != NO_JUMP_LIST || list_of[2] != NO_JUMP_LIST || list_of[3] != NO_JUMP_LIST) {
+                uint32_t have = NO_JUMP_LIST;
+                TileDesc listed = TileDesc{};
+                float values[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (list_of[k] == NO_JUMP_LIST) continue;
+                    if (list_of[k] != have) {
+                        have = list_of[k];
+                        listed = descriptor(have);
+                    }
+                    values[k] = (listed.flags & FLAG_TYPE_MASK) == MDB_SWING_ID
+                                    ? (float)(listed.slope * (double)t[k] + listed.intercept)
+                                    : ((listed.flags & FLAG_TYPE_MASK) == MDB_PMC_MEAN_ID ? listed.value : 0.0f);
                 }
                 v = make_float4(values[0], values[1], values[2], values[3]);
             }
@@ -368,6 +668,20 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
         if (point_b + 2 <= tile_end) ts_out[MDB_WAVE + lane] = chunk_b;
         else if (point_b < tile_end) out_ts[point_b] = chunk_b.x;
     }
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
+    const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
+    uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    grid_tile<false>(desc, offsets, tile_first, n_segments, total_points, n_tiles, out_ts, out_val, nullptr);
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles_jumps(
+    const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
+    const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
+    uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val, const TsJump *__restrict__ jumps) {
+    grid_tile<true>(desc, offsets, tile_first, n_segments, total_points, n_tiles, out_ts, out_val, jumps);
 }
 
 // ---- irregular timestamps, one lane per piece of a stream ---------------------------------------------------
@@ -581,13 +895,24 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     TsCursor *slots = keeps ? checkpoints.slots + checkpoints.piece_base[i] : nullptr;
     const uint32_t n_slots = keeps ? ts_pieces(nbytes) : 0u;
     TsCursor at = ts_stream_start(irregular ? s.start_time[i] : 0, bytes);
-    if (keeps) {
-        uint2 *owner = checkpoints.piece_segment + checkpoints.piece_base[i];
-        for (uint32_t k = 0; k < n_slots; k++) owner[k] = make_uint2((uint32_t)i, nbytes);
-        slots[0] = at;
-    }
+    if (keeps) slots[0] = at;
     uint32_t piece = 0;
     uint32_t error = 0;
+    // The stream's jumps (TsJump), as long as they are few: every point whose delta is not `base`.
+    TsJump *jumps = keeps && checkpoints.jumps ? checkpoints.jumps + checkpoints.piece_base[i] * TS_JUMPS_PER_PIECE : nullptr;
+    bool tracking = jumps != nullptr && checkpoints.piece_base[i] <= 0xffffffffull; // (TileDesc carries 32 bits of it)
+    const uint32_t jump_room = min(n_slots * TS_JUMPS_PER_PIECE - 1u, TS_MAX_JUMPS);
+    uint32_t n_jumps = 0;
+    uint64_t base = 0, jumped = 0; // the delta nearly every point has; what the jumps so far add up to
+    auto jump = [&](uint32_t position) { // (`jumped` has just changed, at this point)
+        // More than the list holds, or than one point in sixteen: not a fixed rate with the odd gap.
+        if (n_jumps >= jump_room || n_jumps * 16u > position + 64u) {
+            tracking = false;
+            return;
+        }
+        n_jumps += 1;
+        jumps[n_jumps] = TsJump{position, 0u, (int64_t)jumped};
+    };
     // (streams of 2^28 bytes and more have no checkpoints and go through the careful decoder whole)
     const uint32_t fast_end = nbytes < (1u << 28) && nbytes * 8u >= 80u ? nbytes * 8u - 80u : 0u;
     RingBitReader reader;
@@ -619,6 +944,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
             if (top < 0x08000000u) { // five `0` codes or more
                 uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
                 run = min(run, ((piece + 1u) << 8) - at.bit); // (the next piece's cursor is met)
+                tracking = tracking && at.last_delta == base;  // (five jumps in a row are not the odd gap)
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + (uint64_t)run * at.last_delta);
                 at.count += run;
                 length_of_code = run;
@@ -646,6 +972,14 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                     at.last_delta += (uint64_t)(int64_t)delta_of_delta;
                 }
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + at.last_delta);
+                if (tracking) {
+                    if (at.count == 1u) {
+                        base = at.last_delta; // the delta of the first code
+                    } else if (at.last_delta != base) {
+                        jumped += at.last_delta - base;
+                        jump(at.count);
+                    }
+                }
                 at.count += 1;
             }
             reader.consume(length_of_code);
@@ -653,6 +987,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
             active = at.bit <= fast_end;
         }
     }
+    bool listed = false; // the segment has a jump list
     if (irregular) {
         if (keeps && (at.bit >> 8) != piece && at.bit < nbytes * 8u) {
             piece = at.bit >> 8;
@@ -661,8 +996,16 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
         // The last codes with the careful decoder (it meets the cursors of the pieces it enters itself).
         uint32_t last_piece = piece;
         bool finished = false;
+        const int64_t start_time = s.start_time[i];
         at = decode_irregular_span(bytes, nbytes, s.end_time[i], 0xffffffffu, &error, at, 0xffffffffu, &finished,
-                                   [](uint32_t, int64_t) {},
+                                   [&](uint32_t k, int64_t t) {
+                                       // (the last point, which is end_time whatever the deltas say, included)
+                                       if (!tracking) return;
+                                       const uint64_t now = (uint64_t)t - (uint64_t)start_time - (uint64_t)k * base;
+                                       if (now == jumped) return;
+                                       jumped = now;
+                                       jump(k);
+                                   },
                                    [&](const TsCursor &c) {
                                        if (!keeps) return;
                                        last_piece = c.bit / TS_PIECE_BITS;
@@ -671,6 +1014,23 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
         for (uint32_t k = last_piece + 1; k < n_slots; k++)
             slots[k] = TsCursor{nbytes * 8u, TS_NO_CODE, s.end_time[i], 0ull, bytes};
         totals[i] = at.count;
+        // With a list the segment is k_grid_tiles' work: its pieces are marked as not to be decoded.
+        listed = tracking && finished && !error;
+        if (jumps) jumps[0] = TsJump{0u, listed ? n_jumps : TS_NO_JUMPS, (int64_t)base};
+        if (keeps) {
+            uint2 *owner = checkpoints.piece_segment + checkpoints.piece_base[i];
+            for (uint32_t k = 0; k < n_slots; k++) owner[k] = make_uint2((uint32_t)i, nbytes | (listed ? TS_PIECE_LISTED : 0u));
+        }
+    }
+    // Where most segments have jump lists, the pieces that are still to be decoded are few and far between:
+    // k_grid_timestamps, one lane per piece, would find a lane or two of every wave with work. They are written
+    // down, so that it can take 64 of them per wave. (Only by waves that have listed a segment: a batch of
+    // randomly spaced timestamps does not pay for a list it has no use for. Whether the list is complete the
+    // host sees by comparing GridHeader::live_pieces with the number of pieces the prepass counts.)
+    if (checkpoints.live && __any(listed) && keeps && !listed) {
+        const unsigned long long first_piece = checkpoints.piece_base[i];
+        const unsigned long long at_list = atomicAdd(&header->live_pieces, (unsigned long long)n_slots);
+        for (uint32_t k = 0; k < n_slots; k++) checkpoints.live[at_list + k] = (uint32_t)(first_piece + k);
     }
     if (error) atomicOr(&header->error, error);
 }
@@ -711,6 +1071,9 @@ struct TsWaveArgs {
     // (sparse flavour) waves it leaves to the general one: their numbers, and how many there are
     uint32_t *left_waves;
     unsigned int *n_left_waves;
+    // the pieces to decode, if they are few (TsCheckpoints::live), or nullptr: all n_pieces
+    const uint32_t *live;
+    uint64_t n_live;
 };
 
 // The 64 pieces `wave_index * 64 ...` of the batch, by one wave. SPARSE: only the first of the three ways
@@ -730,17 +1093,22 @@ __device__ __forceinline__ void ts_wave(const TsWaveArgs &args, uint64_t wave_in
     int64_t *__restrict__ out_ts = args.out_ts;
     float *__restrict__ out_val = args.out_val;
     const int lane = threadIdx.x % MDB_WAVE;
-    const uint64_t slot = wave_index * MDB_WAVE + (uint64_t)lane;
-    const bool present = slot < n_pieces;
+    // (with a list of the pieces that are to be decoded: the wave's 64 of those)
+    uint64_t slot = wave_index * MDB_WAVE + (uint64_t)lane;
+    if (args.live) slot = slot < args.n_live ? (uint64_t)args.live[slot] : n_pieces;
     // What the lane needs to know arrives in two rounds of loads: the piece's cursor (with the address
     // of the stream), its segment and the next piece's; then everything about the segment, together
     // with the bytes of the piece.
     TsCursor from = TsCursor{0u, TS_NO_CODE, 0, 0ull, nullptr};
     uint32_t i = 0, stream_bytes = 0, next_count = TS_NO_CODE;
     bool next_is_mine = false; // the next piece belongs to the same stream
+    // (the pieces of a segment with a jump list are not decoded: k_grid_tiles writes its points)
+    uint2 owner = make_uint2(0u, TS_PIECE_LISTED);
+    if (slot < n_pieces) owner = checkpoints.piece_segment[slot];
+    const bool present = !(owner.y & TS_PIECE_LISTED);
+    if (!__any(present)) return;
     if (present) {
         from = checkpoints.slots[slot];
-        const uint2 owner = checkpoints.piece_segment[slot];
         i = owner.x;
         stream_bytes = owner.y;
         if (slot + 1 < n_pieces) {
@@ -1347,7 +1715,7 @@ __global__ __launch_bounds__(256) void k_grid_swing_irregular(
     // The prepass has left what is needed in the segment's descriptor: the line, and how many of the
     // visible points the model stands for.
     const TileDesc t = desc[i];
-    if ((t.flags & (FLAG_REGULAR | FLAG_CHECKPOINTS)) || (t.flags & FLAG_TYPE_MASK) != MDB_SWING_ID) return;
+    if ((t.flags & (FLAG_REGULAR | FLAG_CHECKPOINTS | FLAG_JUMPS)) || (t.flags & FLAG_TYPE_MASK) != MDB_SWING_ID) return;
     const uint64_t o = offsets[i];
     for (uint32_t k = lane; k < t.n_model; k += MDB_WAVE)
         out_val[o + k] = (float)(t.slope * (double)out_ts[o + k] + t.intercept);
@@ -1418,7 +1786,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     std::memset(&plan->host_header, 0, sizeof(GridHeader));
     plan->mv_min_values = mv_min_values_setting();
     plan->mv_forced = std::getenv("MDB_GRID_MV_MIN_VALUES") != nullptr;
-    plan->checkpoints = TsCheckpoints{nullptr, nullptr, nullptr};
+    plan->checkpoints = TsCheckpoints{nullptr, nullptr, nullptr, nullptr, nullptr};
     plan->n_ts_pieces = 0;
     if (n == 0) return 0;
     DevSegments s = to_dev(in);
@@ -1438,10 +1806,18 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         MDB_HIP_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n, 8, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (n_pieces > 0) {
-            if (scratch_reserve(ctx, SCRATCH_TS_SLOTS, n_pieces * (sizeof(TsCursor) + sizeof(uint2)) + 64, &p)) return 1;
+            // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
+            const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
+            const bool jumps = !range.enabled && !(jumps_setting && std::strcmp(jumps_setting, "0") == 0);
+            const uint64_t per_piece = sizeof(TsCursor) + sizeof(uint2) + (jumps ? TS_JUMPS_PER_PIECE * sizeof(TsJump) + 4 : 0);
+            if (scratch_reserve(ctx, SCRATCH_TS_SLOTS, n_pieces * per_piece + 64, &p)) return 1;
             plan->checkpoints.piece_base = piece_base;
             plan->checkpoints.slots = static_cast<TsCursor *>(p);
             plan->checkpoints.piece_segment = reinterpret_cast<uint2 *>(plan->checkpoints.slots + n_pieces);
+            if (jumps) // (n_pieces * 40 bytes in front: 8-byte aligned, which is all a TsJump's members need)
+                plan->checkpoints.jumps = reinterpret_cast<TsJump *>(plan->checkpoints.piece_segment + n_pieces);
+            if (jumps && n_pieces < 0xffffffffull)
+                plan->checkpoints.live = reinterpret_cast<uint32_t *>(plan->checkpoints.jumps + n_pieces * TS_JUMPS_PER_PIECE);
             plan->n_ts_pieces = n_pieces;
         }
     }
@@ -1488,6 +1864,10 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
                                  hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (plan->host_header.error) return fail(describe_error(plan->host_header.error));
+    if (std::getenv("MDB_GRID_DEBUG"))
+        std::fprintf(stderr, "grid: %llu points, %llu segments with jump lists, %llu points in %llu of %llu pieces left to checkpoints (%llu listed)\n",
+                     plan->host_header.total_points, plan->host_header.jump_segments, plan->host_header.checkpointed_points,
+                     plan->host_header.checkpointed_pieces, (unsigned long long)plan->n_ts_pieces, plan->host_header.live_pieces);
     return 0;
 }
 
@@ -2045,22 +2425,36 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
     {
         // When no segment of the batch has regular timestamps, every timestamp comes from
         // k_grid_serial and the tiles need not store 8 placeholder bytes per point.
-        int64_t *tile_ts = plan.host_header.metrics[7] == 0 ? nullptr : out_ts;
-        LaunchTimer timer(ctx, "k_grid_tiles");
-        hipLaunchKernelGGL(k_grid_tiles, dim3((uint32_t)n_tiles), dim3(TILE_THREADS), 0, ctx->stream,
-                           plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, tile_ts,
-                           out_val);
+        const bool jumps = plan.host_header.jump_segments > 0;
+        int64_t *tile_ts = plan.host_header.metrics[7] == 0 && !jumps ? nullptr : out_ts;
+        LaunchTimer timer(ctx, jumps ? "k_grid_tiles_jumps" : "k_grid_tiles");
+        if (jumps)
+            hipLaunchKernelGGL(k_grid_tiles_jumps, dim3((uint32_t)n_tiles), dim3(TILE_THREADS), 0, ctx->stream,
+                               plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, tile_ts, out_val,
+                               plan.checkpoints.jumps);
+        else
+            hipLaunchKernelGGL(k_grid_tiles, dim3((uint32_t)n_tiles), dim3(TILE_THREADS), 0, ctx->stream,
+                               plan.desc, plan.offsets, plan.tile_first, s.n, total, n_tiles, tile_ts, out_val);
     }
-    if (plan.n_ts_pieces > 0) {
+    // (no checkpointed point: every stream with checkpoints has a jump list, or lies outside the time range)
+    if (plan.n_ts_pieces > 0 && plan.host_header.checkpointed_points > 0) {
         TsWaveArgs ts_args{s, plan.desc, plan.offsets, plan.irregular_totals, plan.irregular_first, plan.counts,
-                           plan.checkpoints, plan.n_ts_pieces, out_ts, out_val, nullptr, nullptr};
-        const uint64_t n_waves = (plan.n_ts_pieces + MDB_WAVE - 1) / MDB_WAVE;
-        const uint32_t ts_blocks = (uint32_t)((plan.n_ts_pieces + TS_THREADS - 1) / TS_THREADS);
+                           plan.checkpoints, plan.n_ts_pieces, out_ts, out_val, nullptr, nullptr, nullptr, 0};
+        // Few of the pieces are to be decoded (the others' segments have jump lists) and the list of those few
+        // is complete: one lane per entry of the list instead of one per piece.
+        uint64_t n_lanes = plan.n_ts_pieces;
+        if (plan.checkpoints.live && plan.host_header.live_pieces == plan.host_header.checkpointed_pieces &&
+            plan.host_header.live_pieces * 4 <= plan.n_ts_pieces) {
+            ts_args.live = plan.checkpoints.live;
+            ts_args.n_live = n_lanes = plan.host_header.live_pieces;
+        }
+        const uint64_t n_waves = (n_lanes + MDB_WAVE - 1) / MDB_WAVE;
+        const uint32_t ts_blocks = (uint32_t)((n_lanes + TS_THREADS - 1) / TS_THREADS);
         // Few points per piece (randomly sampled series): the sparse flavour, then the general one for the
         // waves it has listed. Many (a fixed rate with gaps), or MDB_GRID_TS_SPARSE=0: the general one.
         const char *sparse_setting = std::getenv("MDB_GRID_TS_SPARSE");
         const bool sparse = !(sparse_setting && std::strcmp(sparse_setting, "0") == 0) &&
-                            plan.host_header.checkpointed_points <= (uint64_t)(TS_STAGE_POINTS / MDB_WAVE) * plan.n_ts_pieces &&
+                            plan.host_header.checkpointed_points <= (uint64_t)(TS_STAGE_POINTS / MDB_WAVE) * plan.host_header.checkpointed_pieces &&
                             n_waves < 0xffffffffull;
         if (sparse) {
             void *p;

@@ -16,7 +16,10 @@ enum : uint32_t {
     FLAG_HAS_RESIDUALS = 1u << 3,
     FLAG_SERIAL = 1u << 4,
     FLAG_CHECKPOINTS = 1u << 5, // irregular timestamps with checkpoints: k_grid_timestamps writes them
+    FLAG_JUMPS = 1u << 6,       // (TileDesc only) irregular timestamps that are a fixed rate with a few jumps:
+                                // k_grid_tiles writes them from the segment's jump list (TsJump)
 };
+constexpr uint32_t FLAG_JUMP_COUNT_SHIFT = 8; // (TileDesc only) how many jumps: the bits above
 
 enum : uint32_t {
     ERR_TIMESTAMPS = 1u << 0,
@@ -277,6 +280,41 @@ __device__ __forceinline__ uint32_t decode_irregular_timestamps(const uint8_t *b
         .count;
 }
 
+// A series sampled at a fixed rate with the odd sample missing (or late) has "irregular" timestamps
+// (timestamps.rs:77-96), but nearly all of its deltas are one and the same: point k lies at
+//   start_time + k * base + (sum of (delta_j - base) over the points j <= k whose delta is not base),
+// and the few places where that sum changes - the jumps - are all there is to know about the stream. The walk
+// that counts the stream's codes (k_grid_ts_count) writes them down: the list of segment i is the
+// TS_JUMPS_PER_PIECE entries per piece of its stream from jumps[piece_base[i] * TS_JUMPS_PER_PIECE] on, entry 0 the
+// header, the jumps behind it in the order of their points. Such a segment is reconstructed by k_grid_tiles like
+// one with regular timestamps, plus a search in its list. A stream with more jumps than its list has room
+// for (one per 64 bits of the stream), or more than one per sixteen points, has none (TS_NO_JUMPS) and is
+// decoded piece by piece (k_grid_timestamps).
+struct TsJump {
+    uint32_t position; // index of the point (header: unused)
+    uint32_t count;    // header: how many jumps follow, or TS_NO_JUMPS
+    int64_t value;     // what the jumps up to and including this one add up to (header: the base delta)
+};
+static_assert(sizeof(TsJump) == 16, "16 bytes per jump");
+constexpr uint32_t TS_JUMPS_PER_PIECE = 4;
+constexpr uint32_t TS_NO_JUMPS = 0xffffffffu;
+constexpr uint32_t TS_MAX_JUMPS = (1u << (32 - FLAG_JUMP_COUNT_SHIFT)) - 1u; // (the count travels in TileDesc::flags)
+constexpr uint32_t TS_PIECE_LISTED = 0x80000000u; // TsCheckpoints::piece_segment[].y: the piece's segment has a jump list
+
+// Where the list of a segment with FLAG_JUMPS begins (its first piece, i.e. entry * TS_JUMPS_PER_PIECE of
+// TsCheckpoints::jumps), in the one member of its descriptor k_grid_tiles does not read for its model type:
+// a Swing segment's `value` (the seed of its residuals, which k_grid_serial works out again), the low half of
+// the `intercept` of any other. Knowing it from the descriptor saves the tile kernel a trip to memory per
+// segment and wave.
+__device__ __forceinline__ void set_jump_list(TileDesc &t, uint32_t first_piece) {
+    if ((t.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) t.value = __uint_as_float(first_piece);
+    else t.intercept = __longlong_as_double((long long)first_piece);
+}
+__device__ __forceinline__ uint32_t jump_list_of(const TileDesc &t) {
+    return (t.flags & FLAG_TYPE_MASK) == MDB_SWING_ID ? __float_as_uint(t.value)
+                                                       : (uint32_t)__double_as_longlong(t.intercept);
+}
+
 // The checkpoints of a batch (or none: piece_base == nullptr). Segment i owns the slots
 // [piece_base[i], piece_base[i + 1]): ts_pieces(length of its stream) of them if the stream has
 // checkpoints (irregular, out of line), none otherwise.
@@ -284,6 +322,8 @@ struct TsCheckpoints {
     const unsigned long long *piece_base;
     TsCursor *slots;
     uint2 *piece_segment; // slot -> {segment, bytes of its stream}
+    TsJump *jumps;        // TS_JUMPS_PER_PIECE entries per slot, or nullptr: no jump lists are kept
+    uint32_t *live;       // (with jump lists) the slots of segments that have none, where those are few; or nullptr
 };
 
 // How many of a stream's pieces have a code starting in them: all, or all but the last.

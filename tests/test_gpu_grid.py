@@ -13,17 +13,19 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane", "ts-general"],
+@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane", "ts-general", "ts-no-jumps"],
                 ids=["mv-default", "mv-from-1024-values", "mv-from-8-values", "timestamps-one-lane-per-segment",
-                     "timestamps-general-kernel-only"])
+                     "timestamps-general-kernel-only", "timestamps-no-jump-lists"])
 def macaque_decoder(request, monkeypatch):
     """Every grid test runs with the parallel MacaqueV decoder (mdb_macaque_parallel.hpp) at its
     default threshold, switched off (one lane per stream only) and forced onto every stream of at
     least 8 values; and with irregular timestamps decoded one lane per 256-bit piece of a stream
     (k_grid_timestamps, the default: its sparse flavour first where the batch has few points per piece, or
-    the general one alone) and one lane per segment (k_grid_serial)."""
+    the general one alone) and one lane per segment (k_grid_serial); and without the jump lists that let
+    k_grid_tiles write the timestamps of a fixed rate with the odd gap."""
     monkeypatch.delenv("MDB_GRID_TS_PIECES", raising=False)
     monkeypatch.delenv("MDB_GRID_TS_SPARSE", raising=False)
+    monkeypatch.delenv("MDB_GRID_TS_JUMPS", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
     elif request.param == "ts-one-lane":
@@ -32,6 +34,9 @@ def macaque_decoder(request, monkeypatch):
     elif request.param == "ts-general":
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
         monkeypatch.setenv("MDB_GRID_TS_SPARSE", "0")
+    elif request.param == "ts-no-jumps":
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+        monkeypatch.setenv("MDB_GRID_TS_JUMPS", "0")
     else:
         monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
     return request.param
@@ -365,6 +370,80 @@ def test_fixed_rate_series_with_a_few_very_long_gaps(hip):
         ts, reconstructed, rows, _ = hip.grid_batch_range(segments, t_lo, t_hi)
         assert np.array_equal(ts, exp_ts) and np.array_equal(rows, exp_rows)
         assert np.array_equal(reconstructed.view(np.uint32), exp_values.view(np.uint32))
+
+
+def test_jump_lists_at_their_edges(hip):
+    # A fixed rate with the odd gap is written by k_grid_tiles from the segment's jump list (TsJump): the first
+    # delta is what every other one is measured against; a list holds one jump per 64 bits of the stream and
+    # at most one per sixteen points; the last deltas of a stream are found by the careful decoder and the
+    # very last point is end_time, not a code. Every shape here sits on one of those edges, and segments of
+    # both kinds (with a list, decoded piece by piece) lie next to each other in one batch.
+    rng = np.random.default_rng(173)
+
+    def series(n, gaps_at, gap=3000, interval=1000):
+        deltas = np.full(n, interval, dtype=np.int64)
+        deltas[np.asarray(gaps_at, dtype=np.int64)] = gap
+        return 1_650_000_000_000_000 + np.cumsum(deltas)
+
+    n = 4000
+    shapes = {
+        "no-gap-but-one": series(n, [n // 2]),
+        "first-delta-is-the-gap": series(n, [1]),
+        "second-delta-is-the-gap": series(n, [2]),
+        "gap-before-the-last-point": series(n, [n - 1]),
+        "gaps-in-the-last-points": series(n, [n - 6, n - 4, n - 3, n - 2, n - 1]),
+        "a-sample-early-and-one-late": series(n, [100, 101, 2000], gap=1001) - np.where(np.arange(n) >= 3000, 1, 0),
+        "sixteen-gaps-in-a-row": series(n, list(range(500, 516))),
+        "a-gap-every-15": series(n, list(range(20, n, 15))),
+        "a-gap-every-17": series(n, list(range(20, n, 17))),
+        "a-gap-every-40": series(n, list(range(20, n, 40))),
+        "hours": series(n, [700, 701, 3000], gap=7_200_000_000),
+        "beyond-32-bits": series(n, [9, 1999, n - 2], gap=4_294_967_296 + 7),
+        "one-in-a-hundred": 1_650_000_000_000_000 + np.cumsum(np.where(rng.random(n) < 0.01, 2000, 1000).astype(np.int64)),
+    }
+    for name, timestamps in shapes.items():
+        assert np.all(np.diff(timestamps) > 0), name
+    timestamps = np.concatenate(list(shapes.values()))
+    offsets = np.arange(0, len(timestamps) + 1, n, dtype=np.uint64)
+    smooth = (30 + 4 * np.sin(np.arange(len(timestamps)) / 300.0)).astype(np.float32)
+    noisy = (smooth + rng.uniform(-2, 2, len(timestamps)).astype(np.float32)).astype(np.float32)
+    for values, eb_name in ((smooth, "rel1"), (smooth, "lossless"), (noisy, "rel1"), (noisy, "abs5")):
+        segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()[eb_name])
+        expected = ora.grid_batch(segments)
+        got = hip.grid_batch(segments)
+        cases.assert_grid_equal(got, expected)
+        assert np.array_equal(got[0], timestamps)
+        # a joined field column: values only, the Swing ones computed from timestamps that are not stored
+        _, only_values, _, _ = hip.grid_batch_owned(segments, values_only=True)
+        assert np.array_equal(only_values.view(np.uint32), expected[1].view(np.uint32))
+        # segment by segment, and the segments in another order (a list belongs to its segment, not its place)
+        order = rng.permutation(len(segments))
+        shuffled = segments.take(order)
+        cases.assert_grid_equal(hip.grid_batch(shuffled), ora.grid_batch(shuffled))
+        t_lo, t_hi = int(timestamps[n + 1990]), int(timestamps[9 * n + 30])
+        exp_ts, exp_values, exp_rows = _expected_range(segments, t_lo, t_hi)
+        ts, reconstructed, rows, _ = hip.grid_batch_range(segments, t_lo, t_hi)
+        assert np.array_equal(ts, exp_ts) and np.array_equal(rows, exp_rows)
+        assert np.array_equal(reconstructed.view(np.uint32), exp_values.view(np.uint32))
+
+
+def test_jump_lists_longer_than_a_wave(hip):
+    # k_grid_tiles reads a segment's jump list 64 entries at a time, the lanes of the wave that lie in the
+    # segment together; a list of more than 64 entries is first narrowed down by probes of the whole wave (of
+    # more than 4 096: twice). Constant values make segments as long as their chunks.
+    for n, every in ((20_000, 40), (60_000, 100), (300_000, 50), (300_000, 17)):
+        deltas = np.full(n, 1000, dtype=np.int64)
+        deltas[np.arange(30, n, every)] = 2000
+        deltas[n // 3] = 3_000_000_000_000
+        timestamps = 1_650_000_000_000_000 + np.cumsum(deltas)
+        values = np.full(n, 7.25, dtype=np.float32)
+        values[n // 2:] = np.linspace(1.0, 2.0, n - n // 2, dtype=np.float32)   # (a line: Swing, if it holds)
+        offsets = np.array([0, n], dtype=np.uint64)
+        for eb_name in ("rel1", "lossless"):
+            segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()[eb_name])
+            got = hip.grid_batch(segments)
+            cases.assert_grid_equal(got, ora.grid_batch(segments))
+            assert np.array_equal(got[0], timestamps)
 
 
 def test_grid_time_range_edge_cases(hip):
