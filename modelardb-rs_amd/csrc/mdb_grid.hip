@@ -273,7 +273,7 @@ __device__ __forceinline__ void grid_tile(
     const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
     uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val, const TsJump *__restrict__ jumps) {
-    __shared__ uint32_t rel[TILE_LDS_SEGMENTS + 1]; // rel[k] = offsets[s0 + k] - tile_start, k >= 1
+    __shared__ __attribute__((aligned(16))) uint32_t rel[TILE_LDS_SEGMENTS + 1]; // rel[k] = offsets[s0 + k] - tile_start, k >= 1
     __shared__ __attribute__((aligned(16))) TileDesc lds_desc[TILE_LDS_DESCS];
     __shared__ __attribute__((aligned(16))) longlong2 ts_slab[TILE_THREADS / MDB_WAVE][2 * MDB_WAVE];
     const uint64_t tile = blockIdx.x;
@@ -311,11 +311,16 @@ __device__ __forceinline__ void grid_tile(
     // instead of 2.0 ms per 10^9 points.) A tile with more rows than the table holds (a list of hundreds of
     // jumps: the whole list is taken, not only the jumps inside the tile), or with more segments than have their
     // descriptors in LDS, is done the other way.
-    __shared__ uint32_t row_rel[JUMPS ? TILE_ROWS : 1];
-    __shared__ uint8_t row_seg[JUMPS ? TILE_ROWS : 1];
-    __shared__ long long row_late[JUMPS ? TILE_ROWS : 1];
-    __shared__ uint32_t row_start[JUMPS ? TILE_LDS_DESCS + 1 : 1]; // the first row of segment k
-    __shared__ uint32_t row_totals[TILE_THREADS / MDB_WAVE];
+    // (The table takes no LDS of its own, which would cost the kernel an eighth of its waves: a tile done this
+    // way has at most TILE_LDS_DESCS segments, and the rest of `rel` is room enough; what is only needed while
+    // the table is built lies where the timestamps are transposed later.)
+    constexpr uint32_t ROWS_AT = (TILE_LDS_DESCS + 4) & ~3u;
+    static_assert(ROWS_AT + TILE_ROWS + 2 * TILE_ROWS + TILE_ROWS / 4 <= TILE_LDS_SEGMENTS + 1, "the rows fit behind rel[TILE_LDS_DESCS]");
+    uint32_t *row_rel = rel + ROWS_AT;
+    long long *row_late = reinterpret_cast<long long *>(rel + ROWS_AT + TILE_ROWS);
+    uint8_t *row_seg = reinterpret_cast<uint8_t *>(rel + ROWS_AT + 3 * TILE_ROWS);
+    uint32_t *row_start = reinterpret_cast<uint32_t *>(&ts_slab[0][0]); // the first row of segment k
+    uint32_t *row_totals = row_start + TILE_LDS_DESCS + 1;
     uint32_t n_rows = 0; // (0: no table)
     if (JUMPS && n_in_tile <= (uint32_t)TILE_LDS_DESCS) {
         uint32_t mine = 0; // rows of segment threadIdx.x
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles(
     grid_tile<false>(desc, offsets, tile_first, n_segments, total_points, n_tiles, out_ts, out_val, nullptr);
 }
 
-__global__ __launch_bounds__(TILE_THREADS) void k_grid_tiles_jumps(
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_grid_tiles_jumps(
     const TileDesc *__restrict__ desc, const unsigned long long *__restrict__ offsets,
     const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
     uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val, const TsJump *__restrict__ jumps) {
@@ -1103,18 +1108,26 @@ __device__ __forceinline__ void ts_wave(const TsWaveArgs &args, uint64_t wave_in
     uint32_t i = 0, stream_bytes = 0, next_count = TS_NO_CODE;
     bool next_is_mine = false; // the next piece belongs to the same stream
     // (the pieces of a segment with a jump list are not decoded: k_grid_tiles writes its points)
+    // (all four loads at once, whether the piece is to be decoded or not: one trip to memory, not two)
     uint2 owner = make_uint2(0u, TS_PIECE_LISTED);
-    if (slot < n_pieces) owner = checkpoints.piece_segment[slot];
+    uint32_t next_owner = 0xffffffffu;
+    if (slot < n_pieces) {
+        owner = checkpoints.piece_segment[slot];
+        from = checkpoints.slots[slot];
+        if (slot + 1 < n_pieces) {
+            next_owner = checkpoints.piece_segment[slot + 1].x;
+            next_count = checkpoints.slots[slot + 1].count;
+        }
+    }
     const bool present = !(owner.y & TS_PIECE_LISTED);
     if (!__any(present)) return;
     if (present) {
-        from = checkpoints.slots[slot];
         i = owner.x;
         stream_bytes = owner.y;
-        if (slot + 1 < n_pieces) {
-            next_is_mine = checkpoints.piece_segment[slot + 1].x == i;
-            next_count = checkpoints.slots[slot + 1].count;
-        }
+        next_is_mine = next_owner == i;
+    } else {
+        from = TsCursor{0u, TS_NO_CODE, 0, 0ull, nullptr};
+        next_count = TS_NO_CODE;
     }
     const bool has_code = from.count != TS_NO_CODE;
     const uint32_t piece = from.bit >> 8; // (a piece without a code is never the first of its stream)
