@@ -870,6 +870,64 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
     return bits;
 }
 
+// ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
+//
+// A wave of k_grid_ts_count walks 64 streams in lockstep and is done when the longest of them is. The
+// segments of a batch are not equally long - a model lasts as long as the signal lets it - and with 64
+// neighbours per wave the longest stream of a wave was three times the average one (counters: 2 000 to 2 500
+// steps per wave where the streams average 700 codes). So the streams are dealt to the waves by length, the
+// longest first: a counting sort of the segments with irregular timestamps by the bytes of their streams, in
+// 16-byte classes.
+
+constexpr int TS_SORT_CLASSES = 1024;
+constexpr int TS_SORT_ITEMS = 4;
+
+__device__ __forceinline__ bool ts_sort_class(const DevSegments &s, uint64_t i, uint32_t *sort_class) {
+    const uint4 view = s.timestamps.views[i];
+    const int32_t length = (int32_t)view.x;
+    if (!(length > 0 && (view_inline_byte(view, 0) & 0x80u) != 0)) return false;
+    *sort_class = (uint32_t)(TS_SORT_CLASSES - 1) - min((uint32_t)length >> 4, (uint32_t)(TS_SORT_CLASSES - 1));
+    return true;
+}
+
+// SCATTER = false: how many streams there are of every class (counts += ...). SCATTER = true: `counts` holds
+// where each class begins in `order` (k_ts_sort_scan) and is advanced by what the block places.
+template <bool SCATTER>
+__global__ __launch_bounds__(PREPASS_THREADS) void k_ts_sort(DevSegments s, uint32_t *__restrict__ counts,
+                                                             uint32_t *__restrict__ order) {
+    __shared__ uint32_t local[TS_SORT_CLASSES]; // of this block's streams; then where they begin in `order`
+    for (int c = threadIdx.x; c < TS_SORT_CLASSES; c += PREPASS_THREADS) local[c] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * (PREPASS_THREADS * TS_SORT_ITEMS);
+    uint32_t sort_class[TS_SORT_ITEMS], rank[TS_SORT_ITEMS];
+    bool irregular[TS_SORT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < TS_SORT_ITEMS; k++) {
+        const uint64_t i = base + (uint64_t)k * PREPASS_THREADS + threadIdx.x;
+        irregular[k] = i < s.n && ts_sort_class(s, i, &sort_class[k]);
+        if (irregular[k]) rank[k] = atomicAdd(&local[sort_class[k]], 1u);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < TS_SORT_CLASSES; c += PREPASS_THREADS) {
+        const uint32_t mine = local[c];
+        if (mine) local[c] = atomicAdd(&counts[c], mine);
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TS_SORT_ITEMS; k++)
+        if (irregular[k]) order[local[sort_class[k]] + rank[k]] = (uint32_t)(base + (uint64_t)k * PREPASS_THREADS + threadIdx.x);
+}
+
+// counts -> where each class begins; counts[TS_SORT_CLASSES] = how many streams there are.
+__global__ __launch_bounds__(TS_SORT_CLASSES) void k_ts_sort_scan(uint32_t *__restrict__ counts) {
+    __shared__ uint64_t lds[17];
+    uint64_t total;
+    const uint64_t begins = block_exclusive_scan_u64(counts[threadIdx.x], lds, &total);
+    counts[threadIdx.x] = (uint32_t)begins;
+    if (threadIdx.x == 0) counts[TS_SORT_CLASSES] = (uint32_t)total;
+}
+
 // ---- k_grid_ts_count: the one sequential walk over every delta-of-delta stream ---------------------------
 //
 // len() of a segment with irregular timestamps is the number of codes of its stream (models/mod.rs:
@@ -883,12 +941,15 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
 // one branch for the rare 32- and 64-bit codes, one for a run of `0` codes (counted and skipped at
 // once: a series sampled at a fixed rate with the odd gap is such runs almost entirely), one for the
 // checkpoint.
+// `order` (or nullptr: the segments as they come): the segments with irregular timestamps, n_order of them.
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s, TsCheckpoints checkpoints,
                                                                  uint32_t *__restrict__ totals,
-                                                                 GridHeader *__restrict__ header) {
+                                                                 GridHeader *__restrict__ header,
+                                                                 const uint32_t *__restrict__ order, uint64_t n_order) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
-    const uint64_t i = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    const uint64_t at_order = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    const uint64_t i = order ? (at_order < n_order ? (uint64_t)order[at_order] : s.n) : at_order;
     uint4 view = make_uint4(0u, 0u, 0u, 0u);
     if (i < s.n) view = s.timestamps.views[i];
     const int32_t length = (int32_t)view.x;
@@ -986,6 +1047,23 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                     }
                 }
                 at.count += 1;
+                // A second short code out of the same 32 bits, if it begins in the same piece (no cursor is due
+                // in front of it) and nobody is noting jumps: what a step costs around the code itself - the
+                // look at the ring, the refill, the checks - is then paid once for two codes. (Without a branch:
+                // the lanes of a wave do not agree on it.)
+                {
+                    const uint32_t rest = top << (length_of_code & 31u);
+                    const uint32_t ones_then = (uint32_t)__clz((int)~rest);
+                    int32_t delta_of_delta_then;
+                    const uint32_t both = length_of_code + ts_short_code(rest, min(ones_then, 3u), &delta_of_delta_then);
+                    const uint32_t bit_then = at.bit + length_of_code;
+                    const bool second = !tracking && length_of_code != 0u && ones_then < 4u && both <= 32u &&
+                                        (bit_then >> 8) == (at.bit >> 8) && bit_then <= fast_end;
+                    at.last_delta += second ? (uint64_t)(int64_t)delta_of_delta_then : 0ull;
+                    at.timestamp = (int64_t)((uint64_t)at.timestamp + (second ? at.last_delta : 0ull));
+                    at.count += second ? 1u : 0u;
+                    length_of_code = second ? both : length_of_code;
+                }
             }
             reader.consume(length_of_code);
             at.bit += length_of_code;
@@ -1807,17 +1885,39 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     // of points): a slot per 256-bit piece for the cursors the prepass leaves behind. The column's data
     // buffers say whether there are any (MDB_GRID_TS_PIECES=off: decode them one lane per segment).
     uint64_t ts_payload = 0;
+    uint32_t n_ts_streams = 0;          // segments with irregular timestamps, if they have been sorted
+    uint32_t *ts_order = nullptr;       // by the length of their streams
     for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
         ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
     const char *pieces_setting = std::getenv("MDB_GRID_TS_PIECES");
     if (pieces_setting && std::strcmp(pieces_setting, "off") == 0) ts_payload = 0;
     if (ts_payload > 0) {
-        if (scratch_reserve(ctx, SCRATCH_TS_BASE, (n + 1) * 8 + scan_block_sums_bytes(n) + 64, &p)) return 1;
+        // (behind the pieces' scan: the classes of the sort, then the order it puts the streams in)
+        const uint64_t scan_bytes = ((n + 1) * 8 + scan_block_sums_bytes(n) + 63) & ~63ull;
+        if (scratch_reserve(ctx, SCRATCH_TS_BASE, scan_bytes + (TS_SORT_CLASSES + 16) * 4 + n * 4 + 64, &p)) return 1;
         unsigned long long *piece_base = static_cast<unsigned long long *>(p);
         if (device_exclusive_scan(ctx, TsPieceCount{s}, n, piece_base, piece_base + n + 1, "k_grid_ts_scan")) return 1;
+        // The streams by length (MDB_GRID_TS_SORT=0: as they come).
+        const char *sort_setting = std::getenv("MDB_GRID_TS_SORT");
+        const bool sorted = !(sort_setting && std::strcmp(sort_setting, "0") == 0);
+        uint32_t *sort_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(p) + scan_bytes);
+        const uint32_t sort_blocks = (uint32_t)((n + PREPASS_THREADS * TS_SORT_ITEMS - 1) / (PREPASS_THREADS * TS_SORT_ITEMS));
+        if (sorted) {
+            MDB_HIP_CHECK(hipMemsetAsync(sort_counts, 0, (TS_SORT_CLASSES + 1) * 4, ctx->stream));
+            LaunchTimer timer(ctx, "k_ts_sort");
+            hipLaunchKernelGGL(k_ts_sort<false>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts,
+                               static_cast<uint32_t *>(nullptr));
+            hipLaunchKernelGGL(k_ts_sort_scan, dim3(1), dim3(TS_SORT_CLASSES), 0, ctx->stream, sort_counts);
+            MDB_HIP_CHECK(hipMemcpyAsync(&n_ts_streams, sort_counts + TS_SORT_CLASSES, 4, hipMemcpyDeviceToHost, ctx->stream));
+            ts_order = sort_counts + TS_SORT_CLASSES + 16;
+        }
         unsigned long long n_pieces = 0;
         MDB_HIP_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n, 8, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (sorted && n_ts_streams > 0) {
+            LaunchTimer timer(ctx, "k_ts_sort");
+            hipLaunchKernelGGL(k_ts_sort<true>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts, ts_order);
+        }
         if (n_pieces > 0) {
             // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
             const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
@@ -1838,10 +1938,13 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     // its own, so that it can be a wave-synchronous one.
     const uint32_t *known_totals = nullptr;
     if (ts_payload > 0) {
-        LaunchTimer timer(ctx, "k_grid_ts_count");
-        hipLaunchKernelGGL(k_grid_ts_count, dim3((uint32_t)((n + SERIAL_THREADS - 1) / SERIAL_THREADS)),
-                           dim3(SERIAL_THREADS), 0, ctx->stream, s, plan->checkpoints, plan->irregular_totals,
-                           plan->header);
+        const uint64_t lanes = ts_order ? n_ts_streams : n;
+        if (lanes > 0) {
+            LaunchTimer timer(ctx, "k_grid_ts_count");
+            hipLaunchKernelGGL(k_grid_ts_count, dim3((uint32_t)((lanes + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+                               dim3(SERIAL_THREADS), 0, ctx->stream, s, plan->checkpoints, plan->irregular_totals,
+                               plan->header, ts_order, (uint64_t)n_ts_streams);
+        }
         known_totals = plan->irregular_totals;
     }
     // Simple segments (PMC-Mean / Swing, regular timestamps, no residuals) first, through the trimmed

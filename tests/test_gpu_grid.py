@@ -22,10 +22,12 @@ def macaque_decoder(request, monkeypatch):
     least 8 values; and with irregular timestamps decoded one lane per 256-bit piece of a stream
     (k_grid_timestamps, the default: its sparse flavour first where the batch has few points per piece, or
     the general one alone) and one lane per segment (k_grid_serial); and without the jump lists that let
-    k_grid_tiles write the timestamps of a fixed rate with the odd gap."""
+    k_grid_tiles write the timestamps of a fixed rate with the odd gap (and with the streams counted in the
+    order of their segments instead of by length)."""
     monkeypatch.delenv("MDB_GRID_TS_PIECES", raising=False)
     monkeypatch.delenv("MDB_GRID_TS_SPARSE", raising=False)
     monkeypatch.delenv("MDB_GRID_TS_JUMPS", raising=False)
+    monkeypatch.delenv("MDB_GRID_TS_SORT", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
     elif request.param == "ts-one-lane":
@@ -37,6 +39,7 @@ def macaque_decoder(request, monkeypatch):
     elif request.param == "ts-no-jumps":
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
         monkeypatch.setenv("MDB_GRID_TS_JUMPS", "0")
+        monkeypatch.setenv("MDB_GRID_TS_SORT", "0")
     else:
         monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
     return request.param
