@@ -430,6 +430,27 @@ def test_jump_lists_at_their_edges(hip):
         assert np.array_equal(reconstructed.view(np.uint32), exp_values.view(np.uint32))
 
 
+def test_randomly_spaced_and_gapped_series_in_one_batch(hip):
+    # The pieces that are left to k_grid_timestamps are listed only by waves of the counting walk that have met a
+    # segment with a jump list; the list is used if it turns out complete. Here it does not (the walk takes the
+    # streams longest first: its first waves see randomly spaced timestamps only), in a second batch it does, and
+    # in a third nothing is left to list.
+    rng = np.random.default_rng(174)
+    n_random, n_gapped, chunk = 80_000, 40_000, 500
+    random_ts = np.cumsum(rng.integers(900, 1100, n_random).astype(np.int64))
+    gapped_ts = np.cumsum(np.where(rng.random(n_gapped) < 0.01, 2000, 1000).astype(np.int64))
+    for n_a, n_b in ((n_random, n_gapped), (3 * chunk, n_gapped), (0, n_gapped)):
+        timestamps = np.concatenate([1_640_000_000_000_000 + random_ts[:n_a],
+                                     1_640_000_000_000_000 + (int(random_ts[n_a - 1]) if n_a else 0) + gapped_ts[:n_b]])
+        values = (10 + np.sin(np.arange(len(timestamps)) / 200.0)).astype(np.float32)
+        offsets = np.arange(0, len(timestamps) + 1, chunk, dtype=np.uint64)
+        for eb_name in ("rel1", "lossless"):
+            segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()[eb_name])
+            got = hip.grid_batch(segments)
+            cases.assert_grid_equal(got, ora.grid_batch(segments))
+            assert np.array_equal(got[0], timestamps)
+
+
 def test_jump_lists_longer_than_a_wave(hip):
     # k_grid_tiles reads a segment's jump list 64 entries at a time, the lanes of the wave that lie in the
     # segment together; a list of more than 64 entries is first narrowed down by probes of the whole wave (of
