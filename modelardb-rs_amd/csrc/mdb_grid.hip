@@ -980,7 +980,14 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
         jumps[n_jumps] = TsJump{position, 0u, (int64_t)jumped};
     };
     // (streams of 2^28 bytes and more have no checkpoints and go through the careful decoder whole)
-    const uint32_t fast_end = nbytes < (1u << 28) && nbytes * 8u >= 80u ? nbytes * 8u - 80u : 0u;
+    // The walk goes on as long as a short code (16 bits at most) lies inside the stream wherever it begins: a
+    // code that lies inside the stream means what it means anywhere else (timestamps.rs:228-292: only a code the
+    // stream ends in the middle of, or the ones that pad its last byte, are something else), a `0` inside it
+    // is a point. A 37- or 69-bit code that does not fit any more is left to the careful decoder, with whatever
+    // follows. (Stopping 80 bits in front of the end, the longest code and some, left some sixty codes of a
+    // stream of `0` runs to the careful decoder: a third of what a wave executed.)
+    const uint32_t total_bits = nbytes * 8u;
+    const uint32_t fast_end = nbytes < (1u << 28) && total_bits >= 16u ? total_bits - 16u : 0u;
     RingBitReader reader;
     reader.begin(bytes, nbytes);
     bool active = irregular && at.bit <= fast_end;
@@ -1007,15 +1014,20 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
             reader.refill(ring, lane);
             const uint32_t top = (uint32_t)(reader.buffer >> 32);
             uint32_t length_of_code;
+            bool beyond = false; // a long code that does not lie inside the stream
             if (top < 0x08000000u) { // five `0` codes or more
                 uint32_t run = top == 0u ? 32u : (uint32_t)__clz((int)top);
                 run = min(run, ((piece + 1u) << 8) - at.bit); // (the next piece's cursor is met)
+                run = min(run, total_bits - at.bit);          // (behind the stream's last bit the buffer is zeros)
                 tracking = tracking && at.last_delta == base;  // (five jumps in a row are not the odd gap)
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + (uint64_t)run * at.last_delta);
                 at.count += run;
                 length_of_code = run;
+            } else if (const uint32_t ones = (uint32_t)__clz((int)~top);
+                       ones >= 4 && at.bit + (ones >= 5 ? 69u : 37u) > total_bits) {
+                beyond = true;
+                length_of_code = 0;
             } else {
-                const uint32_t ones = (uint32_t)__clz((int)~top);
                 if (ones >= 4) {
                     reader.consume(5); // `11110` + 32 bits or `11111` + 64 bits
                     reader.refill(ring, lane);
@@ -1067,7 +1079,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
             }
             reader.consume(length_of_code);
             at.bit += length_of_code;
-            active = at.bit <= fast_end;
+            active = !beyond && at.bit <= fast_end;
         }
     }
     bool listed = false; // the segment has a jump list
