@@ -872,12 +872,11 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
 
 // ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
 //
-// A wave of k_grid_ts_count walks 64 streams in lockstep and is done when the longest of them is. The
-// segments of a batch are not equally long - a model lasts as long as the signal lets it - and with 64
-// neighbours per wave the longest stream of a wave was three times the average one (counters: 2 000 to 2 500
-// steps per wave where the streams average 700 codes). So the streams are dealt to the waves by length, the
-// longest first: a counting sort of the segments with irregular timestamps by the bytes of their streams, in
-// 16-byte classes.
+// A wave of k_grid_ts_count walks 64 streams in lockstep and is done when the longest of them is, and the
+// segments of a batch are not equally long - a model lasts as long as the signal lets it. So the streams are
+// dealt to the waves by length, the longest first: a counting sort of the segments with irregular timestamps
+// by the bytes of their streams, in 16-byte classes (10^9 randomly spaced points in 1.4 M streams: the walk
+// 3.9 -> 3.4 ms, the sort 0.05 ms; segments with regular timestamps take no lane at all).
 
 constexpr int TS_SORT_CLASSES = 1024;
 constexpr int TS_SORT_ITEMS = 4;
