@@ -1350,9 +1350,20 @@ __device__ __forceinline__ void ts_wave(const TsWaveArgs &args, uint64_t wave_in
                             length = ts_short_code(top, ones, &delta_of_delta);
                             last_delta += (uint64_t)(int64_t)delta_of_delta;
                         }
-                        consume(length);
                         timestamp = (int64_t)((uint64_t)timestamp + last_delta);
                         emit(k++, timestamp);
+                        // A second short code out of the same 32 bits: the refill and the loop are paid once for two.
+                        const uint32_t rest = top << (length & 31u);
+                        const uint32_t ones_then = (uint32_t)__clz((int)~rest);
+                        int32_t delta_of_delta_then;
+                        const uint32_t both = length + ts_short_code(rest, min(ones_then, 3u), &delta_of_delta_then);
+                        if (length != 0u && ones_then < 4u && both <= 32u && k < codes_end) {
+                            last_delta += (uint64_t)(int64_t)delta_of_delta_then;
+                            timestamp = (int64_t)((uint64_t)timestamp + last_delta);
+                            emit(k++, timestamp);
+                            length = both;
+                        }
+                        consume(length);
                     }
                     if (last_of_stream && run_end == n_total) emit(n_total - 1u, end_time);
                 }
