@@ -991,6 +991,12 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     reader.begin(bytes, nbytes);
     bool active = irregular && at.bit <= fast_end;
     bool fresh = true;
+    // Everything loaded so far has to have arrived before the loop, not in it: a value whose load is still on
+    // its way when the loop is entered gets its wait (s_waitcnt vmcnt(0)) at the top of the loop, where it is met
+    // again in every round - and there it also waits for the round before's stores of cursors to be acknowledged
+    // by memory. (No measurable difference here - the walk is bound by the issue of vector instructions, 81 000
+    // per wave at five waves per SIMD - but a wait on stores in every round is nothing to leave lying around.)
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
     while (__any(active)) {
         if (__any(active && reader.hungry())) {
             ring_top_up(reader, ring, lane, active);
