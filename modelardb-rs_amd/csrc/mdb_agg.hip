@@ -90,8 +90,10 @@ __device__ __forceinline__ AggPartial empty_partial() {
 }
 
 // models/mod.rs:129-184: the f32 sum of one segment.
+// `walked_sums` (may be nullptr): what the walk of the irregular timestamp streams has added up for the Swing
+// segments it adds up (ts_walk_adds): the same terms in the same order as below.
 __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, const SegInfo &info,
-                                             uint32_t length, uint32_t *error) {
+                                             uint32_t length, uint32_t *error, const double *walked_sums = nullptr) {
     const SegDesc &d = info.desc;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     const uint32_t n_res = d.n_total - d.n_model;
@@ -115,6 +117,8 @@ __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, c
             double last = line.slope * (double)end + line.intercept;
             double average = (first + last) / 2.0;
             model_sum = (float)(average * (double)model_length);
+        } else if (walked_sums && ts_walk_adds(s, i)) {
+            model_sum = (float)walked_sums[i];
         } else {
             const uint4 vt = s.timestamps.views[i];
             double sum = 0.0;
@@ -152,17 +156,25 @@ __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, c
 // which it only does beyond 2^40 values).
 enum : uint32_t { AGG_SUM_ALL = 0, AGG_SUM_DEFER = 1, AGG_SUM_ONLY_DEFERRED = 2 };
 
+// `walked_totals`, `walked_sums`, `walked_error` (all may be nullptr): len() of the segments with irregular
+// timestamps, the sums of the Swing segments among them, and the error word of the walk that found them
+// (ts_walk_for_aggregates) - without them every such segment's stream is decoded here, by one lane, once to be
+// counted and once more to be summed.
 __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uint32_t which_mask, uint32_t mode,
                                                               uint32_t mv_min_values,
-                                                              AggPartial *__restrict__ partials) {
+                                                              AggPartial *__restrict__ partials,
+                                                              const uint32_t *__restrict__ walked_totals,
+                                                              const double *__restrict__ walked_sums,
+                                                              const unsigned int *__restrict__ walked_error) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
+    if (walked_error && blockIdx.x == 0 && threadIdx.x == 0) p.error |= *walked_error;
     const bool need_len = which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM);
     for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
          i += (uint64_t)gridDim.x * AGG_THREADS) {
         if (mode == AGG_SUM_ONLY_DEFERRED) {
             if (s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
-            SegInfo info = analyse_segment(s, i);
+            SegInfo info = analyse_segment(s, i, walked_totals);
             if (mv_deferred_values(s, i, info, mv_min_values, TimeRange{0, 0, 0}) == 0) continue;
             uint32_t error = 0;
             p.sum += (double)segment_sum(s, i, info, info.desc.n_model, &error);
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
         if (which_mask & MDB_AGG_MIN) p.min = min_num(p.min, s.min_value[i]);
         if (which_mask & MDB_AGG_MAX) p.max = max_num(p.max, s.max_value[i]);
         if (!need_len) continue;
-        SegInfo info = analyse_segment(s, i);
+        SegInfo info = analyse_segment(s, i, walked_totals);
         // Only what len()/sum() themselves would trip over is an error here.
         uint32_t error = info.error & (ERR_TIMESTAMPS | ERR_TOO_LONG);
         // len() (models/mod.rs:98-124): a regular stream reports its stored length.
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
                 p.deferred_values += length;
                 p.deferred_bytes += s.values.views[i].x;
             } else if (!error) {
-                p.sum += (double)segment_sum(s, i, info, length, &error);
+                p.sum += (double)segment_sum(s, i, info, length, &error, walked_sums);
             }
         }
         p.error |= error;
@@ -449,6 +461,14 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     const bool sums_wanted = !range && (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG));
     bool mv_forced = false;
     const uint32_t mv_min_values = macaque_parallel_min_values(&mv_forced);
+    // Irregular timestamps: len() is the number of codes of the stream and swing::sum a sum over its timestamps;
+    // the wave-synchronous walk of the grid path finds both (MDB_AGG_TS_WALK=0: every lane for itself).
+    const uint32_t *walked_totals = nullptr;
+    const double *walked_sums = nullptr;
+    const unsigned int *walked_error = nullptr; // (what the walk found wrong with a stream)
+    if (!range && (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM)) &&
+        ts_walk_for_aggregates(ctx, in, s, sums_wanted, &walked_totals, &walked_sums, &walked_error))
+        return 1;
     if (range) {
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
@@ -456,7 +476,8 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     } else {
         LaunchTimer timer(ctx, "k_agg_segments");
         hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
-                           which_mask, sums_wanted ? AGG_SUM_DEFER : AGG_SUM_ALL, mv_min_values, partials);
+                           which_mask, sums_wanted ? AGG_SUM_DEFER : AGG_SUM_ALL, mv_min_values, partials,
+                           walked_totals, walked_sums, walked_error);
     }
     {
         LaunchTimer timer(ctx, "k_agg_finish");
@@ -485,7 +506,9 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             } else {
                 LaunchTimer timer(ctx, "k_agg_segments");
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
-                                   which_mask, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials);
+                                   which_mask, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials,
+                                   static_cast<const uint32_t *>(nullptr), static_cast<const double *>(nullptr),
+                                   static_cast<const unsigned int *>(nullptr));
             }
             {
                 LaunchTimer timer(ctx, "k_agg_finish");

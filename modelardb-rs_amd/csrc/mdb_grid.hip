@@ -941,10 +941,16 @@ __global__ __launch_bounds__(TS_SORT_CLASSES) void k_ts_sort_scan(uint32_t *__re
 // once: a series sampled at a fixed rate with the odd gap is such runs almost entirely), one for the
 // checkpoint.
 // `order` (or nullptr: the segments as they come): the segments with irregular timestamps, n_order of them.
+// SUMS (for the aggregates, mdb_agg.hip): the walk also adds up what swing::sum adds up for a Swing segment
+// without residuals - (slope * t + intercept) of every timestamp, in f64, in the order of the points
+// (swing.rs:283-299; the line through the SEGMENT's end points) - and leaves it in sums[i]; `header`
+// is then a plain error word.
+template <bool SUMS>
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s, TsCheckpoints checkpoints,
                                                                  uint32_t *__restrict__ totals,
                                                                  GridHeader *__restrict__ header,
-                                                                 const uint32_t *__restrict__ order, uint64_t n_order) {
+                                                                 const uint32_t *__restrict__ order, uint64_t n_order,
+                                                                 double *__restrict__ sums) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t at_order = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -963,6 +969,16 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     if (keeps) slots[0] = at;
     uint32_t piece = 0;
     uint32_t error = 0;
+    // (SUMS) the line of a Swing segment without residuals, and the sum of its values so far
+    bool adds = false;
+    LineDev line = LineDev{0.0, 0.0};
+    double added = 0.0;
+    if (SUMS && irregular && ts_walk_adds(s, i)) {
+        float first = 0.0f, last = 0.0f;
+        adds = decode_swing_values(s.values.views[i], s.min_value[i], s.max_value[i], &first, &last);
+        line = line_through(at.timestamp, (double)first, s.end_time[i], (double)last);
+        added = line.slope * (double)at.timestamp + line.intercept; // point 0 is the start time
+    }
     // The stream's jumps (TsJump), as long as they are few: every point whose delta is not `base`.
     TsJump *jumps = keeps && checkpoints.jumps ? checkpoints.jumps + checkpoints.piece_base[i] * TS_JUMPS_PER_PIECE : nullptr;
     bool tracking = jumps != nullptr && checkpoints.piece_base[i] <= 0xffffffffull; // (TileDesc carries 32 bits of it)
@@ -1012,9 +1028,9 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                 reader.consume(1);
                 fresh = false;
             }
-            if (keeps && (at.bit >> 8) != piece) {
+            if ((at.bit >> 8) != piece) { // (every lane keeps count of its pieces: a run of `0` codes ends with one)
                 piece = at.bit >> 8;
-                slots[piece] = at;
+                if (keeps) slots[piece] = at;
             }
             reader.refill(ring, lane);
             const uint32_t top = (uint32_t)(reader.buffer >> 32);
@@ -1025,6 +1041,13 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                 run = min(run, ((piece + 1u) << 8) - at.bit); // (the next piece's cursor is met)
                 run = min(run, total_bits - at.bit);          // (behind the stream's last bit the buffer is zeros)
                 tracking = tracking && at.last_delta == base;  // (five jumps in a row are not the odd gap)
+                if (SUMS && adds) {
+                    int64_t t = at.timestamp;
+                    for (uint32_t k = 0; k < run; k++) {
+                        t = (int64_t)((uint64_t)t + at.last_delta);
+                        added += line.slope * (double)t + line.intercept;
+                    }
+                }
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + (uint64_t)run * at.last_delta);
                 at.count += run;
                 length_of_code = run;
@@ -1055,6 +1078,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                     at.last_delta += (uint64_t)(int64_t)delta_of_delta;
                 }
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + at.last_delta);
+                if (SUMS && adds) added += line.slope * (double)at.timestamp + line.intercept;
                 if (tracking) {
                     if (at.count == 1u) {
                         base = at.last_delta; // the delta of the first code
@@ -1078,6 +1102,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                                         (bit_then >> 8) == (at.bit >> 8) && bit_then <= fast_end;
                     at.last_delta += second ? (uint64_t)(int64_t)delta_of_delta_then : 0ull;
                     at.timestamp = (int64_t)((uint64_t)at.timestamp + (second ? at.last_delta : 0ull));
+                    if (SUMS && adds && second) added += line.slope * (double)at.timestamp + line.intercept;
                     at.count += second ? 1u : 0u;
                     length_of_code = second ? both : length_of_code;
                 }
@@ -1100,6 +1125,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
         at = decode_irregular_span(bytes, nbytes, s.end_time[i], 0xffffffffu, &error, at, 0xffffffffu, &finished,
                                    [&](uint32_t k, int64_t t) {
                                        // (the last point, which is end_time whatever the deltas say, included)
+                                       if (SUMS && adds) added += line.slope * (double)t + line.intercept;
                                        if (!tracking) return;
                                        const uint64_t now = (uint64_t)t - (uint64_t)start_time - (uint64_t)k * base;
                                        if (now == jumped) return;
@@ -1114,6 +1140,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
         for (uint32_t k = last_piece + 1; k < n_slots; k++)
             slots[k] = TsCursor{nbytes * 8u, TS_NO_CODE, s.end_time[i], 0ull, bytes};
         totals[i] = at.count;
+        if (SUMS && adds) sums[i] = added;
         // With a list the segment is k_grid_tiles' work: its pieces are marked as not to be decoded.
         listed = tracking && finished && !error;
         if (jumps) jumps[0] = TsJump{0u, listed ? n_jumps : TS_NO_JUMPS, (int64_t)base};
@@ -1127,12 +1154,12 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     // down, so that it can take 64 of them per wave. (Only by waves that have listed a segment: a batch of
     // randomly spaced timestamps does not pay for a list it has no use for. Whether the list is complete the
     // host sees by comparing GridHeader::live_pieces with the number of pieces the prepass counts.)
-    if (checkpoints.live && __any(listed) && keeps && !listed) {
+    if (!SUMS && checkpoints.live && __any(listed) && keeps && !listed) {
         const unsigned long long first_piece = checkpoints.piece_base[i];
         const unsigned long long at_list = atomicAdd(&header->live_pieces, (unsigned long long)n_slots);
         for (uint32_t k = 0; k < n_slots; k++) checkpoints.live[at_list + k] = (uint32_t)(first_piece + k);
     }
-    if (error) atomicOr(&header->error, error);
+    if (error) atomicOr(SUMS ? reinterpret_cast<unsigned int *>(header) : &header->error, error);
 }
 
 // ---- k_grid_timestamps: the second walk is not one -----------------------------------------------------------
@@ -1872,6 +1899,76 @@ static uint32_t mv_min_values_setting() {
     return MV_DEFAULT_MIN_VALUES;
 }
 
+// The segments with irregular timestamps in the order k_grid_ts_count takes them (by the length of their
+// streams, the longest first): counts them (k_ts_sort<false>, k_ts_sort_scan; *n_streams arrives with the
+// caller's next synchronisation of the stream) ...
+static int ts_sort_count(mdb_ctx *ctx, const DevSegments &s, uint64_t n, uint32_t *sort_counts, uint32_t *n_streams) {
+    const uint32_t sort_blocks = (uint32_t)((n + PREPASS_THREADS * TS_SORT_ITEMS - 1) / (PREPASS_THREADS * TS_SORT_ITEMS));
+    MDB_HIP_CHECK(hipMemsetAsync(sort_counts, 0, (TS_SORT_CLASSES + 1) * 4, ctx->stream));
+    LaunchTimer timer(ctx, "k_ts_sort");
+    hipLaunchKernelGGL(k_ts_sort<false>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts,
+                       static_cast<uint32_t *>(nullptr));
+    hipLaunchKernelGGL(k_ts_sort_scan, dim3(1), dim3(TS_SORT_CLASSES), 0, ctx->stream, sort_counts);
+    MDB_HIP_CHECK(hipMemcpyAsync(n_streams, sort_counts + TS_SORT_CLASSES, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+// ... and places them.
+static void ts_sort_place(mdb_ctx *ctx, const DevSegments &s, uint64_t n, uint32_t *sort_counts, uint32_t *order) {
+    const uint32_t sort_blocks = (uint32_t)((n + PREPASS_THREADS * TS_SORT_ITEMS - 1) / (PREPASS_THREADS * TS_SORT_ITEMS));
+    LaunchTimer timer(ctx, "k_ts_sort");
+    hipLaunchKernelGGL(k_ts_sort<true>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts, order);
+}
+
+// For the aggregates (mdb_agg.hip): len() of every segment with irregular timestamps (models/mod.rs:98-124: the
+// number of codes of its stream) and the sum of every Swing segment among them that has no residuals
+// (ts_walk_adds), by the wave-synchronous walk of the grid path instead of one lane per segment decoding its
+// stream by itself, twice for a Swing segment. *totals stays nullptr if the batch has no out-of-line timestamps
+// (streams inside their views are a handful of points; k_agg_segments counts those itself).
+int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums,
+                           const uint32_t **totals, const double **sums, const unsigned int **error_word_out) {
+    *totals = nullptr;
+    *sums = nullptr;
+    *error_word_out = nullptr;
+    const uint64_t n = in->n;
+    uint64_t ts_payload = 0;
+    for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
+        ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
+    const char *setting = std::getenv("MDB_AGG_TS_WALK");
+    if (ts_payload == 0 || n == 0 || n > 0xfffffff0ull || (setting && std::strcmp(setting, "0") == 0)) return 0;
+    void *p;
+    // totals, sums, the classes of the sort, the order, an error word
+    const uint64_t n_padded = (n + 15) & ~15ull;
+    if (scratch_reserve(ctx, SCRATCH_COUNTS, n_padded * (4 + 8 + 4) + (TS_SORT_CLASSES + 32) * 4, &p)) return 1;
+    double *walk_sums = static_cast<double *>(p);
+    uint32_t *walk_totals = reinterpret_cast<uint32_t *>(walk_sums + n_padded);
+    uint32_t *order = walk_totals + n_padded;
+    uint32_t *sort_counts = order + n_padded;
+    unsigned int *error_word = sort_counts + TS_SORT_CLASSES + 16;
+    uint32_t n_streams = 0;
+    MDB_HIP_CHECK(hipMemsetAsync(error_word, 0, 4, ctx->stream));
+    if (ts_sort_count(ctx, s, n, sort_counts, &n_streams)) return 1;
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n_streams == 0) return 0;
+    ts_sort_place(ctx, s, n, sort_counts, order);
+    {
+        LaunchTimer timer(ctx, "k_grid_ts_count");
+        const dim3 blocks((uint32_t)(((uint64_t)n_streams + SERIAL_THREADS - 1) / SERIAL_THREADS));
+        const TsCheckpoints none{nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (with_sums)
+            hipLaunchKernelGGL(k_grid_ts_count<true>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
+                               reinterpret_cast<GridHeader *>(error_word), order, (uint64_t)n_streams, walk_sums);
+        else
+            hipLaunchKernelGGL(k_grid_ts_count<false>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
+                               reinterpret_cast<GridHeader *>(error_word), order, (uint64_t)n_streams,
+                               static_cast<double *>(nullptr));
+    }
+    // (what the walk finds wrong with a stream k_agg_segments reports with its own findings)
+    *error_word_out = error_word;
+    *totals = walk_totals;
+    *sums = with_sums ? walk_sums : nullptr;
+    return 0;
+}
+
 // Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
 // capacity_tiles bounds the tile map: if the batch needs more the caller gets an error before any
 // out-of-bounds write can happen (tile map writes are guarded by the allocation made here).
@@ -1929,23 +2026,14 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         const char *sort_setting = std::getenv("MDB_GRID_TS_SORT");
         const bool sorted = !(sort_setting && std::strcmp(sort_setting, "0") == 0);
         uint32_t *sort_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(p) + scan_bytes);
-        const uint32_t sort_blocks = (uint32_t)((n + PREPASS_THREADS * TS_SORT_ITEMS - 1) / (PREPASS_THREADS * TS_SORT_ITEMS));
         if (sorted) {
-            MDB_HIP_CHECK(hipMemsetAsync(sort_counts, 0, (TS_SORT_CLASSES + 1) * 4, ctx->stream));
-            LaunchTimer timer(ctx, "k_ts_sort");
-            hipLaunchKernelGGL(k_ts_sort<false>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts,
-                               static_cast<uint32_t *>(nullptr));
-            hipLaunchKernelGGL(k_ts_sort_scan, dim3(1), dim3(TS_SORT_CLASSES), 0, ctx->stream, sort_counts);
-            MDB_HIP_CHECK(hipMemcpyAsync(&n_ts_streams, sort_counts + TS_SORT_CLASSES, 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (ts_sort_count(ctx, s, n, sort_counts, &n_ts_streams)) return 1;
             ts_order = sort_counts + TS_SORT_CLASSES + 16;
         }
         unsigned long long n_pieces = 0;
         MDB_HIP_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n, 8, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (sorted && n_ts_streams > 0) {
-            LaunchTimer timer(ctx, "k_ts_sort");
-            hipLaunchKernelGGL(k_ts_sort<true>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts, ts_order);
-        }
+        if (sorted && n_ts_streams > 0) ts_sort_place(ctx, s, n, sort_counts, ts_order);
         if (n_pieces > 0) {
             // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
             const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
@@ -1969,9 +2057,9 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         const uint64_t lanes = ts_order ? n_ts_streams : n;
         if (lanes > 0) {
             LaunchTimer timer(ctx, "k_grid_ts_count");
-            hipLaunchKernelGGL(k_grid_ts_count, dim3((uint32_t)((lanes + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+            hipLaunchKernelGGL(k_grid_ts_count<false>, dim3((uint32_t)((lanes + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                                dim3(SERIAL_THREADS), 0, ctx->stream, s, plan->checkpoints, plan->irregular_totals,
-                               plan->header, ts_order, (uint64_t)n_ts_streams);
+                               plan->header, ts_order, (uint64_t)n_ts_streams, static_cast<double *>(nullptr));
         }
         known_totals = plan->irregular_totals;
     }

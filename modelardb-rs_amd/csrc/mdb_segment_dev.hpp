@@ -797,6 +797,16 @@ __device__ __forceinline__ uint32_t mv_deferred_values(const DevSegments &s, uin
     return mv_qualifies(info, bytes, min_values) ? info.desc.n_visible : 0u;
 }
 
+// Does the walk of the irregular timestamp streams (k_grid_ts_count<SUMS>, mdb_grid.hip) add up segment i's
+// values for the aggregates? A Swing segment without residuals: swing::sum needs every timestamp of such a
+// segment (swing.rs:283-299) and nothing else. Evaluated identically by the walk and by k_agg_segments.
+__device__ __forceinline__ bool ts_walk_adds(const DevSegments &s, uint64_t i) {
+    return s.model_type_id[i] == MDB_SWING_ID && (int32_t)s.residuals.views[i].x == 0;
+}
+
+int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums,
+                           const uint32_t **totals, const double **sums, const unsigned int **error_word);
+
 int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,
                      uint64_t n_streams, uint64_t n_values, uint64_t n_bytes, bool *handled,
                      DeferredTotals *totals);

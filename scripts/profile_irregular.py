@@ -40,6 +40,15 @@ def main():
         ctx.sync(); grid = (time.perf_counter() - t0) / 3
         kernels = {k: round(v[1] / v[0], 3) for k, v in ctx.profile().items() if v[1] / v[0] > 0.05}
         ctx.profile_enable(False)
+        mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+        ctx.agg_batch_dev(dev, mask)
+        ctx.profile_enable(True); ctx.profile_reset(); ctx.sync(); t0 = time.perf_counter()
+        for _ in range(3):
+            state = ctx.agg_batch_dev(dev, mask)
+        ctx.sync(); agg = (time.perf_counter() - t0) / 3
+        agg_kernels = {k: round(v[1] / v[0], 3) for k, v in ctx.profile().items() if v[1] / v[0] > 0.05}
+        ctx.profile_enable(False)
+        print(f"{label}: COUNT/MIN/MAX/SUM of the segments {agg*1e3:.2f} ms (count {state.count}) {agg_kernels}", flush=True)
         got = ctx.download_array(out_ts, 1_000_000, np.int64)
         assert os.environ.get("MDB_HIP_LIBRARY") or np.array_equal(got, ts[:1_000_000])
         print(f"{label}: fit {fit*1e3:.1f} ms ({total/fit/1e9:.1f} Gpts/s), {len(dev)} segments; grid {grid*1e3:.2f} ms "

@@ -18,13 +18,20 @@ ALL = MDB_AGG_COUNT | MDB_AGG_MIN | MDB_AGG_MAX | MDB_AGG_SUM
 SUM_TOLERANCE = 1e-5  # 0.001 %
 
 
-@pytest.fixture(autouse=True, params=[None, "off", "8"], ids=["mv-default", "mv-off", "mv-from-8-values"])
+@pytest.fixture(autouse=True, params=[None, "off", "8", "no-walk"],
+                ids=["mv-default", "mv-off", "mv-from-8-values", "timestamps-every-lane-for-itself"])
 def macaque_decoder(request, monkeypatch):
     """SUM leaves long MacaqueV streams to the parallel decoder (macaque_deferred_sum in mdb_grid.hip):
     every test runs with its default threshold, with it switched off and with every stream of at
-    least 8 values going that way."""
+    least 8 values going that way. len() and swing::sum of segments with irregular timestamps come from the
+    wave-synchronous walk of their streams (k_grid_ts_count<SUMS>), or - the last mode - from every lane
+    decoding its own stream."""
+    monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+    elif request.param == "no-walk":
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+        monkeypatch.setenv("MDB_AGG_TS_WALK", "0")
     else:
         monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", request.param)
     return request.param
@@ -269,3 +276,26 @@ def test_range_aggregates_edge_cases(hip):
                            (int(ts[0]) - 5, int(ts[len(ts) // 2]))):
             _assert_state(hip.agg_batch_range(batch, t_lo, t_hi, ALL),
                           ora.agg_batch_range(batch, t_lo, t_hi, ALL))
+
+
+def test_sums_of_irregular_swing_segments_are_the_same_either_way(hip, monkeypatch):
+    # The walk adds up (slope * t + intercept) over a Swing segment's timestamps in the order of the points, as
+    # the lane that decodes the stream by itself does: the two ways agree to the last bit, per segment.
+    rng = np.random.default_rng(181)
+    n = 120_000
+    for timestamps in (1_600_000_000_000_000 + np.cumsum(rng.integers(900, 1100, n).astype(np.int64)),
+                       1_600_000_000_000_000 + np.cumsum(np.where(rng.random(n) < 0.01, 2000, 1000).astype(np.int64))):
+        values = (np.linspace(-5.0, 9.0, n) + 2 * np.sin(np.arange(n) / 900.0)).astype(np.float32)
+        offsets = np.arange(0, n + 1, 4000, dtype=np.uint64)
+        segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()["rel5"])
+        assert (segments.model_type_id == mdb.MDB_SWING_ID).sum() > 10
+        for row in range(0, len(segments), 7):
+            one = segments.take(np.array([row]))
+            monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
+            walked = hip.agg_batch(one, ALL)
+            monkeypatch.setenv("MDB_AGG_TS_WALK", "0")
+            alone = hip.agg_batch(one, ALL)
+            assert (walked.count, walked.min, walked.max) == (alone.count, alone.min, alone.max)
+            assert np.float64(walked.sum).tobytes() == np.float64(alone.sum).tobytes()
+        monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
+        _assert_state(hip.agg_batch(segments, ALL), ora.agg_batch(segments, ALL))
