@@ -184,7 +184,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
         if (which_mask & MDB_AGG_MIN) p.min = min_num(p.min, s.min_value[i]);
         if (which_mask & MDB_AGG_MAX) p.max = max_num(p.max, s.max_value[i]);
         if (!need_len) continue;
-        SegInfo info = analyse_segment(s, i, walked_totals);
+        SegInfo info = analyse_segment(s, i, walked_totals, nullptr, false);
         // Only what len()/sum() themselves would trip over is an error here.
         uint32_t error = info.error & (ERR_TIMESTAMPS | ERR_TOO_LONG);
         // len() (models/mod.rs:98-124): a regular stream reports its stored length.

@@ -443,10 +443,14 @@ __device__ __forceinline__ bool segment_is_simple(const DevSegments &s, uint64_t
 // (segment_is_simple(): PMC-Mean or Swing, regular timestamps, no residuals): the branches such a
 // segment cannot take are not compiled, which is what lets the prepass run them at three times the
 // occupancy (the delta-of-delta decoders are most of the generic version's 132 registers).
+// `line_wanted` = false: the caller has no use for the Swing line through the MODEL's end (grid()'s line; the
+// aggregates' goes through the segment's end, swing.rs:273-274) - which, for a segment with irregular timestamps
+// and residuals, costs a decode of its stream up to that point.
 template <bool SIMPLE = false>
 __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i,
                                                    const uint32_t *known_totals = nullptr,
-                                                   const TsCheckpoints *checkpoints = nullptr) {
+                                                   const TsCheckpoints *checkpoints = nullptr,
+                                                   bool line_wanted = true) {
     SegInfo info;
     info.error = 0;
     info.swing_first = 0.0f;
@@ -564,7 +568,7 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
             int64_t model_end = start;
             if (regular || SIMPLE) {
                 model_end = start + (int64_t)((uint64_t)(n_model - 1) * (uint64_t)d.delta);
-            } else if (n_res == 0) {
+            } else if (n_res == 0 || !line_wanted) {
                 model_end = end; // the last timestamp is not stored in the stream: it is end_time
             } else if (slots) {
                 model_end = n_model == 1 ? start
