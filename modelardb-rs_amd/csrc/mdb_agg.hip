@@ -408,18 +408,26 @@ __device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, 
     }
 }
 
+// `walked_totals`, `walked_ranges`, `walked_error` (all may be nullptr): of the segments with irregular timestamps
+// that reach into the range, len() and - PMC-Mean / Swing without residuals - the aggregates of their points inside
+// it, as the walk of their streams has found them (ts_walk_for_aggregates; the same values in the same order as
+// segment_range's own pass over such a segment).
 __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_t t_lo, int64_t t_hi, uint32_t mode,
                                                            uint32_t mv_min_values,
-                                                           AggPartial *__restrict__ partials) {
+                                                           AggPartial *__restrict__ partials,
+                                                           const uint32_t *__restrict__ walked_totals,
+                                                           const TsWalkRange *__restrict__ walked_ranges,
+                                                           const unsigned int *__restrict__ walked_error) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
+    if (walked_error && blockIdx.x == 0 && threadIdx.x == 0) p.error |= *walked_error;
     const TimeRange range = {t_lo, t_hi, 1};
     for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
          i += (uint64_t)gridDim.x * AGG_THREADS) {
         // Cheap rejection on the two columns the reference prunes on (start_time / end_time).
         if (s.end_time[i] < t_lo || s.start_time[i] > t_hi) continue;
         if (mode == AGG_SUM_ONLY_DEFERRED && s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
-        SegInfo info = analyse_segment(s, i);
+        SegInfo info = analyse_segment(s, i, walked_totals);
         uint32_t error = info.error;
         // Long MacaqueV streams are left to the decoders of mdb_grid.hip (see AGG_SUM_DEFER).
         const uint32_t deferred_values =
@@ -434,7 +442,15 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
         }
         if (!error) {
             RangeAcc acc;
-            segment_range(s, i, info, t_lo, t_hi, acc, &error);
+            if (walked_ranges && !(info.desc.flags & FLAG_REGULAR) && ts_walk_aggregates_range(s, i)) {
+                const TsWalkRange walked = walked_ranges[i];
+                acc.sum = walked.sum;
+                acc.count = walked.count;
+                acc.min = walked.min;
+                acc.max = walked.max;
+            } else {
+                segment_range(s, i, info, t_lo, t_hi, acc, &error);
+            }
             p.sum += acc.sum;
             p.count += acc.count;
             p.min = min_num(p.min, acc.min);
@@ -465,14 +481,16 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     // the wave-synchronous walk of the grid path finds both (MDB_AGG_TS_WALK=0: every lane for itself).
     const uint32_t *walked_totals = nullptr;
     const double *walked_sums = nullptr;
+    const TsWalkRange *walked_ranges = nullptr;
     const unsigned int *walked_error = nullptr; // (what the walk found wrong with a stream)
-    if (!range && (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM)) &&
-        ts_walk_for_aggregates(ctx, in, s, sums_wanted, &walked_totals, &walked_sums, &walked_error))
+    if ((range || (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM))) &&
+        ts_walk_for_aggregates(ctx, in, s, sums_wanted, TimeRange{t_lo, t_hi, range ? 1 : 0}, &walked_totals, &walked_sums,
+                               &walked_ranges, &walked_error))
         return 1;
     if (range) {
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
-                           t_hi, AGG_SUM_DEFER, mv_min_values, partials);
+                           t_hi, AGG_SUM_DEFER, mv_min_values, partials, walked_totals, walked_ranges, walked_error);
     } else {
         LaunchTimer timer(ctx, "k_agg_segments");
         hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
@@ -502,7 +520,9 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             if (range) {
                 LaunchTimer timer(ctx, "k_agg_range");
                 hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
-                                   t_hi, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials);
+                                   t_hi, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials,
+                                   static_cast<const uint32_t *>(nullptr), static_cast<const TsWalkRange *>(nullptr),
+                                   static_cast<const unsigned int *>(nullptr));
             } else {
                 LaunchTimer timer(ctx, "k_agg_segments");
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,

@@ -881,10 +881,12 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
 constexpr int TS_SORT_CLASSES = 1024;
 constexpr int TS_SORT_ITEMS = 4;
 
-__device__ __forceinline__ bool ts_sort_class(const DevSegments &s, uint64_t i, uint32_t *sort_class) {
+__device__ __forceinline__ bool ts_sort_class(const DevSegments &s, uint64_t i, const TimeRange &range, uint32_t *sort_class) {
     const uint4 view = s.timestamps.views[i];
     const int32_t length = (int32_t)view.x;
     if (!(length > 0 && (view_inline_byte(view, 0) & 0x80u) != 0)) return false;
+    // (with a time range: only the segments that reach into it - start_time / end_time say which)
+    if (range.enabled && (s.end_time[i] < range.lo || s.start_time[i] > range.hi)) return false;
     *sort_class = (uint32_t)(TS_SORT_CLASSES - 1) - min((uint32_t)length >> 4, (uint32_t)(TS_SORT_CLASSES - 1));
     return true;
 }
@@ -892,7 +894,7 @@ __device__ __forceinline__ bool ts_sort_class(const DevSegments &s, uint64_t i, 
 // SCATTER = false: how many streams there are of every class (counts += ...). SCATTER = true: `counts` holds
 // where each class begins in `order` (k_ts_sort_scan) and is advanced by what the block places.
 template <bool SCATTER>
-__global__ __launch_bounds__(PREPASS_THREADS) void k_ts_sort(DevSegments s, uint32_t *__restrict__ counts,
+__global__ __launch_bounds__(PREPASS_THREADS) void k_ts_sort(DevSegments s, TimeRange range, uint32_t *__restrict__ counts,
                                                              uint32_t *__restrict__ order) {
     __shared__ uint32_t local[TS_SORT_CLASSES]; // of this block's streams; then where they begin in `order`
     for (int c = threadIdx.x; c < TS_SORT_CLASSES; c += PREPASS_THREADS) local[c] = 0;
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_ts_sort(DevSegments s, uint
 #pragma unroll
     for (int k = 0; k < TS_SORT_ITEMS; k++) {
         const uint64_t i = base + (uint64_t)k * PREPASS_THREADS + threadIdx.x;
-        irregular[k] = i < s.n && ts_sort_class(s, i, &sort_class[k]);
+        irregular[k] = i < s.n && ts_sort_class(s, i, range, &sort_class[k]);
         if (irregular[k]) rank[k] = atomicAdd(&local[sort_class[k]], 1u);
     }
     __syncthreads();
@@ -941,16 +943,24 @@ __global__ __launch_bounds__(TS_SORT_CLASSES) void k_ts_sort_scan(uint32_t *__re
 // once: a series sampled at a fixed rate with the odd gap is such runs almost entirely), one for the
 // checkpoint.
 // `order` (or nullptr: the segments as they come): the segments with irregular timestamps, n_order of them.
-// SUMS (for the aggregates, mdb_agg.hip): the walk also adds up what swing::sum adds up for a Swing segment
-// without residuals - (slope * t + intercept) of every timestamp, in f64, in the order of the points
-// (swing.rs:283-299; the line through the SEGMENT's end points) - and leaves it in sums[i]; `header`
-// is then a plain error word.
-template <bool SUMS>
+// WALK (for the aggregates, mdb_agg.hip) - WALK_SUMS: the walk also adds up what swing::sum adds up for a Swing
+// segment without residuals - (slope * t + intercept) of every timestamp, in f64, in the order of the points
+// (swing.rs:283-299; the line through the SEGMENT's end points) - and leaves it in sums[i].
+// WALK_RANGE: it aggregates, for a PMC-Mean or Swing segment without residuals, the values grid() would produce
+// for the points with range.lo <= timestamp <= range.hi, the way GridExec + filter + aggregate would (f32 values
+// added up in f64 in the order of the points, their count, minimum and maximum) into ranges[i]. In both, `header`
+// is a plain error word.
+enum : int { WALK_GRID = 0, WALK_SUMS = 1, WALK_RANGE = 2 };
+
+template <int WALK>
 __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s, TsCheckpoints checkpoints,
                                                                  uint32_t *__restrict__ totals,
                                                                  GridHeader *__restrict__ header,
                                                                  const uint32_t *__restrict__ order, uint64_t n_order,
-                                                                 double *__restrict__ sums) {
+                                                                 double *__restrict__ sums, TimeRange range,
+                                                                 TsWalkRange *__restrict__ ranges) {
+    constexpr bool SUMS = WALK == WALK_SUMS;
+    constexpr bool RANGE = WALK == WALK_RANGE;
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t at_order = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -978,6 +988,29 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
         adds = decode_swing_values(s.values.views[i], s.min_value[i], s.max_value[i], &first, &last);
         line = line_through(at.timestamp, (double)first, s.end_time[i], (double)last);
         added = line.slope * (double)at.timestamp + line.intercept; // point 0 is the start time
+    }
+    // (RANGE) what the points inside the range add up to, and the value of a PMC-Mean segment
+    TsWalkRange inside = TsWalkRange{0.0, 0ll, FLT_MAX, -FLT_MAX};
+    bool is_swing = false;
+    float pmc_value = 0.0f;
+    auto visit = [&](int64_t t) { // (RANGE) one point of a segment the walk aggregates
+        if (t < range.lo || t > range.hi) return;
+        const float v = is_swing ? (float)(line.slope * (double)t + line.intercept) : pmc_value;
+        inside.sum += (double)v;
+        inside.count += 1;
+        inside.min = min_num(inside.min, v);
+        inside.max = max_num(inside.max, v);
+    };
+    if (RANGE && irregular && ts_walk_aggregates_range(s, i)) {
+        is_swing = s.model_type_id[i] == MDB_SWING_ID;
+        if (is_swing) {
+            float first = 0.0f, last = 0.0f;
+            adds = decode_swing_values(s.values.views[i], s.min_value[i], s.max_value[i], &first, &last);
+            line = line_through(at.timestamp, (double)first, s.end_time[i], (double)last);
+        } else {
+            adds = decode_pmc_value(s.values.views[i], s.min_value[i], s.max_value[i], &pmc_value);
+        }
+        if (adds) visit(at.timestamp); // point 0 is the start time
     }
     // The stream's jumps (TsJump), as long as they are few: every point whose delta is not `base`.
     TsJump *jumps = keeps && checkpoints.jumps ? checkpoints.jumps + checkpoints.piece_base[i] * TS_JUMPS_PER_PIECE : nullptr;
@@ -1041,11 +1074,12 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                 run = min(run, ((piece + 1u) << 8) - at.bit); // (the next piece's cursor is met)
                 run = min(run, total_bits - at.bit);          // (behind the stream's last bit the buffer is zeros)
                 tracking = tracking && at.last_delta == base;  // (five jumps in a row are not the odd gap)
-                if (SUMS && adds) {
+                if ((SUMS || RANGE) && adds) {
                     int64_t t = at.timestamp;
                     for (uint32_t k = 0; k < run; k++) {
                         t = (int64_t)((uint64_t)t + at.last_delta);
-                        added += line.slope * (double)t + line.intercept;
+                        if (SUMS) added += line.slope * (double)t + line.intercept;
+                        else visit(t);
                     }
                 }
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + (uint64_t)run * at.last_delta);
@@ -1079,6 +1113,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                 }
                 at.timestamp = (int64_t)((uint64_t)at.timestamp + at.last_delta);
                 if (SUMS && adds) added += line.slope * (double)at.timestamp + line.intercept;
+                if (RANGE && adds) visit(at.timestamp);
                 if (tracking) {
                     if (at.count == 1u) {
                         base = at.last_delta; // the delta of the first code
@@ -1103,6 +1138,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                     at.last_delta += second ? (uint64_t)(int64_t)delta_of_delta_then : 0ull;
                     at.timestamp = (int64_t)((uint64_t)at.timestamp + (second ? at.last_delta : 0ull));
                     if (SUMS && adds && second) added += line.slope * (double)at.timestamp + line.intercept;
+                    if (RANGE && adds && second) visit(at.timestamp);
                     at.count += second ? 1u : 0u;
                     length_of_code = second ? both : length_of_code;
                 }
@@ -1126,6 +1162,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
                                    [&](uint32_t k, int64_t t) {
                                        // (the last point, which is end_time whatever the deltas say, included)
                                        if (SUMS && adds) added += line.slope * (double)t + line.intercept;
+                                       if (RANGE && adds) visit(t);
                                        if (!tracking) return;
                                        const uint64_t now = (uint64_t)t - (uint64_t)start_time - (uint64_t)k * base;
                                        if (now == jumped) return;
@@ -1141,6 +1178,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
             slots[k] = TsCursor{nbytes * 8u, TS_NO_CODE, s.end_time[i], 0ull, bytes};
         totals[i] = at.count;
         if (SUMS && adds) sums[i] = added;
+        if (RANGE && adds) ranges[i] = inside;
         // With a list the segment is k_grid_tiles' work: its pieces are marked as not to be decoded.
         listed = tracking && finished && !error;
         if (jumps) jumps[0] = TsJump{0u, listed ? n_jumps : TS_NO_JUMPS, (int64_t)base};
@@ -1154,12 +1192,12 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     // down, so that it can take 64 of them per wave. (Only by waves that have listed a segment: a batch of
     // randomly spaced timestamps does not pay for a list it has no use for. Whether the list is complete the
     // host sees by comparing GridHeader::live_pieces with the number of pieces the prepass counts.)
-    if (!SUMS && checkpoints.live && __any(listed) && keeps && !listed) {
+    if (WALK == WALK_GRID && checkpoints.live && __any(listed) && keeps && !listed) {
         const unsigned long long first_piece = checkpoints.piece_base[i];
         const unsigned long long at_list = atomicAdd(&header->live_pieces, (unsigned long long)n_slots);
         for (uint32_t k = 0; k < n_slots; k++) checkpoints.live[at_list + k] = (uint32_t)(first_piece + k);
     }
-    if (error) atomicOr(SUMS ? reinterpret_cast<unsigned int *>(header) : &header->error, error);
+    if (error) atomicOr(WALK != WALK_GRID ? reinterpret_cast<unsigned int *>(header) : &header->error, error);
 }
 
 // ---- k_grid_timestamps: the second walk is not one -----------------------------------------------------------
@@ -1902,21 +1940,23 @@ static uint32_t mv_min_values_setting() {
 // The segments with irregular timestamps in the order k_grid_ts_count takes them (by the length of their
 // streams, the longest first): counts them (k_ts_sort<false>, k_ts_sort_scan; *n_streams arrives with the
 // caller's next synchronisation of the stream) ...
-static int ts_sort_count(mdb_ctx *ctx, const DevSegments &s, uint64_t n, uint32_t *sort_counts, uint32_t *n_streams) {
+static int ts_sort_count(mdb_ctx *ctx, const DevSegments &s, uint64_t n, const TimeRange &range, uint32_t *sort_counts,
+                         uint32_t *n_streams) {
     const uint32_t sort_blocks = (uint32_t)((n + PREPASS_THREADS * TS_SORT_ITEMS - 1) / (PREPASS_THREADS * TS_SORT_ITEMS));
     MDB_HIP_CHECK(hipMemsetAsync(sort_counts, 0, (TS_SORT_CLASSES + 1) * 4, ctx->stream));
     LaunchTimer timer(ctx, "k_ts_sort");
-    hipLaunchKernelGGL(k_ts_sort<false>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts,
+    hipLaunchKernelGGL(k_ts_sort<false>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, range, sort_counts,
                        static_cast<uint32_t *>(nullptr));
     hipLaunchKernelGGL(k_ts_sort_scan, dim3(1), dim3(TS_SORT_CLASSES), 0, ctx->stream, sort_counts);
     MDB_HIP_CHECK(hipMemcpyAsync(n_streams, sort_counts + TS_SORT_CLASSES, 4, hipMemcpyDeviceToHost, ctx->stream));
     return 0;
 }
 // ... and places them.
-static void ts_sort_place(mdb_ctx *ctx, const DevSegments &s, uint64_t n, uint32_t *sort_counts, uint32_t *order) {
+static void ts_sort_place(mdb_ctx *ctx, const DevSegments &s, uint64_t n, const TimeRange &range, uint32_t *sort_counts,
+                          uint32_t *order) {
     const uint32_t sort_blocks = (uint32_t)((n + PREPASS_THREADS * TS_SORT_ITEMS - 1) / (PREPASS_THREADS * TS_SORT_ITEMS));
     LaunchTimer timer(ctx, "k_ts_sort");
-    hipLaunchKernelGGL(k_ts_sort<true>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, sort_counts, order);
+    hipLaunchKernelGGL(k_ts_sort<true>, dim3(sort_blocks), dim3(PREPASS_THREADS), 0, ctx->stream, s, range, sort_counts, order);
 }
 
 // For the aggregates (mdb_agg.hip): len() of every segment with irregular timestamps (models/mod.rs:98-124: the
@@ -1924,10 +1964,12 @@ static void ts_sort_place(mdb_ctx *ctx, const DevSegments &s, uint64_t n, uint32
 // (ts_walk_adds), by the wave-synchronous walk of the grid path instead of one lane per segment decoding its
 // stream by itself, twice for a Swing segment. *totals stays nullptr if the batch has no out-of-line timestamps
 // (streams inside their views are a handful of points; k_agg_segments counts those itself).
-int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums,
-                           const uint32_t **totals, const double **sums, const unsigned int **error_word_out) {
+int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums, TimeRange range,
+                           const uint32_t **totals, const double **sums, const TsWalkRange **ranges,
+                           const unsigned int **error_word_out) {
     *totals = nullptr;
     *sums = nullptr;
+    *ranges = nullptr;
     *error_word_out = nullptr;
     const uint64_t n = in->n;
     uint64_t ts_payload = 0;
@@ -1936,36 +1978,42 @@ int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegmen
     const char *setting = std::getenv("MDB_AGG_TS_WALK");
     if (ts_payload == 0 || n == 0 || n > 0xfffffff0ull || (setting && std::strcmp(setting, "0") == 0)) return 0;
     void *p;
-    // totals, sums, the classes of the sort, the order, an error word
+    // sums or range aggregates, totals, the order, the classes of the sort, an error word
     const uint64_t n_padded = (n + 15) & ~15ull;
-    if (scratch_reserve(ctx, SCRATCH_COUNTS, n_padded * (4 + 8 + 4) + (TS_SORT_CLASSES + 32) * 4, &p)) return 1;
-    double *walk_sums = static_cast<double *>(p);
-    uint32_t *walk_totals = reinterpret_cast<uint32_t *>(walk_sums + n_padded);
+    if (scratch_reserve(ctx, SCRATCH_COUNTS, n_padded * (sizeof(TsWalkRange) + 4 + 4) + (TS_SORT_CLASSES + 32) * 4, &p)) return 1;
+    TsWalkRange *walk_ranges = static_cast<TsWalkRange *>(p);
+    double *walk_sums = static_cast<double *>(p); // (one or the other)
+    uint32_t *walk_totals = reinterpret_cast<uint32_t *>(walk_ranges + n_padded);
     uint32_t *order = walk_totals + n_padded;
     uint32_t *sort_counts = order + n_padded;
     unsigned int *error_word = sort_counts + TS_SORT_CLASSES + 16;
     uint32_t n_streams = 0;
     MDB_HIP_CHECK(hipMemsetAsync(error_word, 0, 4, ctx->stream));
-    if (ts_sort_count(ctx, s, n, sort_counts, &n_streams)) return 1;
+    if (ts_sort_count(ctx, s, n, range, sort_counts, &n_streams)) return 1;
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (n_streams == 0) return 0;
-    ts_sort_place(ctx, s, n, sort_counts, order);
+    ts_sort_place(ctx, s, n, range, sort_counts, order);
     {
         LaunchTimer timer(ctx, "k_grid_ts_count");
         const dim3 blocks((uint32_t)(((uint64_t)n_streams + SERIAL_THREADS - 1) / SERIAL_THREADS));
         const TsCheckpoints none{nullptr, nullptr, nullptr, nullptr, nullptr};
-        if (with_sums)
-            hipLaunchKernelGGL(k_grid_ts_count<true>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
-                               reinterpret_cast<GridHeader *>(error_word), order, (uint64_t)n_streams, walk_sums);
+        GridHeader *errors = reinterpret_cast<GridHeader *>(error_word);
+        if (range.enabled)
+            hipLaunchKernelGGL(k_grid_ts_count<WALK_RANGE>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
+                               errors, order, (uint64_t)n_streams, static_cast<double *>(nullptr), range, walk_ranges);
+        else if (with_sums)
+            hipLaunchKernelGGL(k_grid_ts_count<WALK_SUMS>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
+                               errors, order, (uint64_t)n_streams, walk_sums, range, static_cast<TsWalkRange *>(nullptr));
         else
-            hipLaunchKernelGGL(k_grid_ts_count<false>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
-                               reinterpret_cast<GridHeader *>(error_word), order, (uint64_t)n_streams,
-                               static_cast<double *>(nullptr));
+            hipLaunchKernelGGL(k_grid_ts_count<WALK_GRID>, blocks, dim3(SERIAL_THREADS), 0, ctx->stream, s, none, walk_totals,
+                               errors, order, (uint64_t)n_streams, static_cast<double *>(nullptr), range,
+                               static_cast<TsWalkRange *>(nullptr));
     }
-    // (what the walk finds wrong with a stream k_agg_segments reports with its own findings)
+    // (what the walk finds wrong with a stream the aggregate kernels report with their own findings)
     *error_word_out = error_word;
     *totals = walk_totals;
-    *sums = with_sums ? walk_sums : nullptr;
+    *sums = !range.enabled && with_sums ? walk_sums : nullptr;
+    *ranges = range.enabled ? walk_ranges : nullptr;
     return 0;
 }
 
@@ -2027,13 +2075,13 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         const bool sorted = !(sort_setting && std::strcmp(sort_setting, "0") == 0);
         uint32_t *sort_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(p) + scan_bytes);
         if (sorted) {
-            if (ts_sort_count(ctx, s, n, sort_counts, &n_ts_streams)) return 1;
+            if (ts_sort_count(ctx, s, n, TimeRange{0, 0, 0}, sort_counts, &n_ts_streams)) return 1;
             ts_order = sort_counts + TS_SORT_CLASSES + 16;
         }
         unsigned long long n_pieces = 0;
         MDB_HIP_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n, 8, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (sorted && n_ts_streams > 0) ts_sort_place(ctx, s, n, sort_counts, ts_order);
+        if (sorted && n_ts_streams > 0) ts_sort_place(ctx, s, n, TimeRange{0, 0, 0}, sort_counts, ts_order);
         if (n_pieces > 0) {
             // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
             const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
@@ -2057,9 +2105,10 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         const uint64_t lanes = ts_order ? n_ts_streams : n;
         if (lanes > 0) {
             LaunchTimer timer(ctx, "k_grid_ts_count");
-            hipLaunchKernelGGL(k_grid_ts_count<false>, dim3((uint32_t)((lanes + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+            hipLaunchKernelGGL(k_grid_ts_count<WALK_GRID>, dim3((uint32_t)((lanes + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                                dim3(SERIAL_THREADS), 0, ctx->stream, s, plan->checkpoints, plan->irregular_totals,
-                               plan->header, ts_order, (uint64_t)n_ts_streams, static_cast<double *>(nullptr));
+                               plan->header, ts_order, (uint64_t)n_ts_streams, static_cast<double *>(nullptr),
+                               TimeRange{0, 0, 0}, static_cast<TsWalkRange *>(nullptr));
         }
         known_totals = plan->irregular_totals;
     }

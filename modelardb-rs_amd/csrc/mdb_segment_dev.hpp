@@ -808,8 +808,23 @@ __device__ __forceinline__ bool ts_walk_adds(const DevSegments &s, uint64_t i) {
     return s.model_type_id[i] == MDB_SWING_ID && (int32_t)s.residuals.views[i].x == 0;
 }
 
-int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums,
-                           const uint32_t **totals, const double **sums, const unsigned int **error_word);
+// ... and, under a time range, aggregate its points inside the range (k_grid_ts_count<WALK_RANGE>)? PMC-Mean and
+// Swing segments without residuals: their values follow from the timestamps alone.
+__device__ __forceinline__ bool ts_walk_aggregates_range(const DevSegments &s, uint64_t i) {
+    const int32_t type = s.model_type_id[i];
+    return (type == MDB_PMC_MEAN_ID || type == MDB_SWING_ID) && (int32_t)s.residuals.views[i].x == 0;
+}
+struct TsWalkRange { // the points of a segment inside a time range, as GridExec + filter + aggregate see them
+    double sum;      // of the f32 values, added up in f64 in the order of the points
+    long long count;
+    float min, max;
+};
+
+// (with_sums, !range.enabled): *sums; (range.enabled): *ranges, and only the segments that reach into the range
+// are walked; *totals in every case, for the segments that were walked.
+int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums, TimeRange range,
+                           const uint32_t **totals, const double **sums, const TsWalkRange **ranges,
+                           const unsigned int **error_word);
 
 int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,
                      uint64_t n_streams, uint64_t n_values, uint64_t n_bytes, bool *handled,

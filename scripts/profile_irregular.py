@@ -49,6 +49,16 @@ def main():
         agg_kernels = {k: round(v[1] / v[0], 3) for k, v in ctx.profile().items() if v[1] / v[0] > 0.05}
         ctx.profile_enable(False)
         print(f"{label}: COUNT/MIN/MAX/SUM of the segments {agg*1e3:.2f} ms (count {state.count}) {agg_kernels}", flush=True)
+        # ... and of the points in the middle half of the time axis (WHERE timestamp BETWEEN)
+        t_lo, t_hi = int(ts[points // 4]), int(ts[3 * points // 4])
+        ctx.agg_batch_range_dev(dev, t_lo, t_hi, mask)
+        ctx.profile_enable(True); ctx.profile_reset(); ctx.sync(); t0 = time.perf_counter()
+        for _ in range(3):
+            state = ctx.agg_batch_range_dev(dev, t_lo, t_hi, mask)
+        ctx.sync(); agg = (time.perf_counter() - t0) / 3
+        agg_kernels = {k: round(v[1] / v[0], 3) for k, v in ctx.profile().items() if v[1] / v[0] > 0.05}
+        ctx.profile_enable(False)
+        print(f"{label}: the same BETWEEN the quartiles of the time axis {agg*1e3:.2f} ms (count {state.count}) {agg_kernels}", flush=True)
         got = ctx.download_array(out_ts, 1_000_000, np.int64)
         assert os.environ.get("MDB_HIP_LIBRARY") or np.array_equal(got, ts[:1_000_000])
         print(f"{label}: fit {fit*1e3:.1f} ms ({total/fit/1e9:.1f} Gpts/s), {len(dev)} segments; grid {grid*1e3:.2f} ms "

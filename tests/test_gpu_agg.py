@@ -297,5 +297,16 @@ def test_sums_of_irregular_swing_segments_are_the_same_either_way(hip, monkeypat
             alone = hip.agg_batch(one, ALL)
             assert (walked.count, walked.min, walked.max) == (alone.count, alone.min, alone.max)
             assert np.float64(walked.sum).tobytes() == np.float64(alone.sum).tobytes()
+        # ... and under a time range: the points inside it, as GridExec + filter + aggregate see them
+        for t_lo, t_hi in ((int(timestamps[n // 4]), int(timestamps[3 * n // 4])), (int(timestamps[5]) + 1, int(timestamps[4100])),
+                           (int(timestamps[-3]), int(timestamps[-1]) + 10), (int(timestamps[0]) - 5, int(timestamps[0]))):
+            monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
+            walked = hip.agg_batch_range(segments, t_lo, t_hi, ALL)
+            monkeypatch.setenv("MDB_AGG_TS_WALK", "0")
+            alone = hip.agg_batch_range(segments, t_lo, t_hi, ALL)
+            assert (walked.count, walked.min, walked.max) == (alone.count, alone.min, alone.max), (t_lo, t_hi)
+            assert np.float64(walked.sum).tobytes() == np.float64(alone.sum).tobytes(), (t_lo, t_hi)
+            expected = ora.agg_batch_range(segments, t_lo, t_hi, ALL)
+            assert (walked.count, walked.min, walked.max) == (expected.count, expected.min, expected.max)
         monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
         _assert_state(hip.agg_batch(segments, ALL), ora.agg_batch(segments, ALL))
