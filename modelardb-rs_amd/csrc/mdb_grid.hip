@@ -976,7 +976,43 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     TsCursor *slots = keeps ? checkpoints.slots + checkpoints.piece_base[i] : nullptr;
     const uint32_t n_slots = keeps ? ts_pieces(nbytes) : 0u;
     TsCursor at = ts_stream_start(irregular ? s.start_time[i] : 0, bytes);
-    if (keeps) slots[0] = at;
+    // Cursors leave in pairs, 64 bytes that lie in one 64-byte block of memory: the first of a pair waits in
+    // LDS for the second. (One by one they are 32-byte writes scattered over the 5 000 waves' 64 streams each -
+    // more lines under way than the caches hold until their other halves arrive: the walk executed fewer
+    // instructions than the one without cursors and took twice as long, 296 000 of a wave's 430 000 cycles
+    // waiting to issue.)
+    __shared__ __attribute__((aligned(16))) uint4 waiting[WALK == WALK_GRID ? 2 : 1][WALK == WALK_GRID ? MDB_WAVE : 1];
+    bool one_waits = false;
+    uint32_t waiting_piece = 0;
+    const bool slots_begin_odd = keeps && (checkpoints.piece_base[i] & 1ull) != 0; // (in units of cursors)
+    auto leave = [&](uint32_t at_piece, const TsCursor &cursor) {
+        if (WALK != WALK_GRID) return;
+        const bool second_of_pair = ((at_piece & 1u) != 0) != slots_begin_odd;
+        const uint4 *halves = reinterpret_cast<const uint4 *>(&cursor);
+        if (!second_of_pair) { // waits for its neighbour (or for the end of the walk)
+            waiting[0][lane] = halves[0];
+            waiting[1][lane] = halves[1];
+            one_waits = true;
+            waiting_piece = at_piece;
+            return;
+        }
+        uint4 *out = reinterpret_cast<uint4 *>(slots + at_piece);
+        if (one_waits) {
+            out[-2] = waiting[0][lane];
+            out[-1] = waiting[1][lane];
+            one_waits = false;
+        }
+        out[0] = halves[0];
+        out[1] = halves[1];
+    };
+    auto leave_the_waiting_one = [&]() {
+        if (WALK != WALK_GRID || !one_waits) return;
+        uint4 *out = reinterpret_cast<uint4 *>(slots + waiting_piece);
+        out[0] = waiting[0][lane];
+        out[1] = waiting[1][lane];
+        one_waits = false;
+    };
+    if (keeps) leave(0u, at);
     uint32_t piece = 0;
     uint32_t error = 0;
     // (SUMS) the line of a Swing segment without residuals, and the sum of its values so far
@@ -1063,7 +1099,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
             }
             if ((at.bit >> 8) != piece) { // (every lane keeps count of its pieces: a run of `0` codes ends with one)
                 piece = at.bit >> 8;
-                if (keeps) slots[piece] = at;
+                if (keeps) leave(piece, at);
             }
             reader.refill(ring, lane);
             const uint32_t top = (uint32_t)(reader.buffer >> 32);
@@ -1150,6 +1186,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     }
     bool listed = false; // the segment has a jump list
     if (irregular) {
+        leave_the_waiting_one();
         if (keeps && (at.bit >> 8) != piece && at.bit < nbytes * 8u) {
             piece = at.bit >> 8;
             slots[piece] = at;
