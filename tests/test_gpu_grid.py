@@ -451,6 +451,27 @@ def test_randomly_spaced_and_gapped_series_in_one_batch(hip):
             assert np.array_equal(got[0], timestamps)
 
 
+def test_hundreds_of_listed_segments_in_one_tile(hip):
+    # A tile of k_grid_tiles_jumps with more than 128 segments (their descriptors are not all in LDS) or more rows
+    # than its table holds is done without the table: the waves read the lists of their points' segments
+    # together. Tiny chunks whose one gap is hours long have streams long enough (a 69-bit code each way) to get
+    # checkpoints and a list: four to sixteen points per segment, up to a thousand listed segments per tile.
+    rng = np.random.default_rng(175)
+    for chunk in (4, 5, 8, 16):
+        n = chunk * 3000
+        deltas = np.full(n, 1000, dtype=np.int64)
+        deltas[np.arange(2, n, chunk)] = 8_000_000_000_000 + rng.integers(0, 1000, len(np.arange(2, n, chunk)))
+        timestamps = 1_500_000_000_000_000 + np.cumsum(deltas)
+        values = np.repeat(rng.normal(5, 1, n // chunk).astype(np.float32), chunk)   # PMC-Mean
+        values[n // 2:] += (np.arange(n - n // 2) % chunk).astype(np.float32) * 0.5     # Swing
+        offsets = np.arange(0, n + 1, chunk, dtype=np.uint64)
+        for eb_name in ("rel1", "lossless"):
+            segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()[eb_name])
+            got = hip.grid_batch(segments)
+            cases.assert_grid_equal(got, ora.grid_batch(segments))
+            assert np.array_equal(got[0], timestamps)
+
+
 def test_jump_lists_longer_than_a_wave(hip):
     # k_grid_tiles reads a segment's jump list 64 entries at a time, the lanes of the wave that lie in the
     # segment together; a list of more than 64 entries is first narrowed down by probes of the whole wave (of
