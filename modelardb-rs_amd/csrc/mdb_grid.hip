@@ -4,6 +4,9 @@
 // and modelardb_compression::grid (crates/modelardb_compression/src/models/mod.rs:190-251).
 //
 // Pipeline (all on the context's stream):
+//   k_ts_sort, k_grid_ts_count  (batches with delta-of-delta timestamps) one lane per stream, longest streams
+//                    first: counts the codes (len()), leaves a cursor in front of every 256-bit piece, and
+//                    lists the jumps of a stream that is a fixed rate with the odd gap.
 //   k_grid_prepass   1 thread / segment: len(), residual count, values-column decode, Swing
 //                    slope/intercept (f64 divide once per segment, not per point) -> 48 B descriptor
 //                    + per-segment point count; per-block totals.
@@ -14,7 +17,8 @@
 //                    offsets and descriptors staged in LDS, each lane reconstructs 4 consecutive
 //                    points; every wave-level store instruction writes 1 KiB contiguous (timestamps
 //                    are transposed through LDS for that). Writes placeholders for points it cannot
-//                    reconstruct.
+//                    reconstruct. k_grid_tiles_jumps is the same for a batch with listed segments: a table
+//                    of rows per tile, one per segment and per jump.
 //   k_grid_timestamps 1 lane / 256-bit piece of a delta-of-delta timestamp stream, from the cursor the
 //                    prepass left in front of the piece's first code: timestamps and the Swing values
 //                    that follow from them overwrite the placeholders, each lane a contiguous run.
@@ -1079,8 +1083,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_ts_count(DevSegments s,
     // Everything loaded so far has to have arrived before the loop, not in it: a value whose load is still on
     // its way when the loop is entered gets its wait (s_waitcnt vmcnt(0)) at the top of the loop, where it is met
     // again in every round - and there it also waits for the round before's stores of cursors to be acknowledged
-    // by memory. (No measurable difference here - the walk is bound by the issue of vector instructions, 81 000
-    // per wave at five waves per SIMD - but a wait on stores in every round is nothing to leave lying around.)
+    // by memory. (No measurable difference by itself - what the cursor stores cost is their scatter, see `waiting`
+    // above - but a wait on stores in every round is nothing to leave lying around.)
     __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
     while (__any(active)) {
         if (__any(active && reader.hungry())) {
