@@ -1282,6 +1282,35 @@ struct TsWaveArgs {
     uint64_t n_live;
 };
 
+// The points a wave has staged in LDS (timestamps as 32-bit distances from base_time, and values) to their place in
+// the output, wave_first onwards. Every store instruction of the wave a kilobyte in one piece, as in k_grid_tiles:
+// two timestamps per lane, four values per lane; in front of and behind the aligned middle, one point per lane
+// (one point per lane and instruction throughout: 4.1 instead of 3.9 ms per 10^9 randomly spaced points).
+__device__ __forceinline__ void write_staged_points(int lane, uint64_t wave_first, uint32_t wave_total, int64_t base_time,
+                                                    const uint32_t *my_ts, const float *my_val,
+                                                    int64_t *__restrict__ out_ts, float *__restrict__ out_val) {
+    auto timestamp_of = [&](uint32_t k) { return base_time + (int64_t)(uint64_t)my_ts[k]; };
+    if (out_ts) {
+        const uint32_t head = (uint32_t)(wave_first & 1ull) & (wave_total > 0 ? 1u : 0u); // points in front of the 16-byte boundary
+        const uint32_t pairs = (wave_total - head) / 2u;
+        if (lane == 0 && head) out_ts[wave_first] = timestamp_of(0u);
+        longlong2 *out_pairs = reinterpret_cast<longlong2 *>(out_ts + wave_first + head);
+        for (uint32_t pair = lane; pair < pairs; pair += MDB_WAVE)
+            out_pairs[pair] = make_longlong2(timestamp_of(head + 2u * pair), timestamp_of(head + 2u * pair + 1u));
+        if (lane == 0 && head + 2u * pairs < wave_total) out_ts[wave_first + wave_total - 1u] = timestamp_of(wave_total - 1u);
+    }
+    const uint32_t head = min((uint32_t)((0ull - wave_first) & 3ull), wave_total);
+    const uint32_t quads = (wave_total - head) / 4u;
+    if ((uint32_t)lane < head) out_val[wave_first + lane] = my_val[lane];
+    float4 *out_quads = reinterpret_cast<float4 *>(out_val + wave_first + head);
+    for (uint32_t quad = lane; quad < quads; quad += MDB_WAVE) {
+        const uint32_t k = head + 4u * quad;
+        out_quads[quad] = make_float4(my_val[k], my_val[k + 1u], my_val[k + 2u], my_val[k + 3u]);
+    }
+    const uint32_t done = head + 4u * quads;
+    if (done + (uint32_t)lane < wave_total) out_val[wave_first + done + lane] = my_val[done + lane];
+}
+
 // The 64 pieces `wave_index * 64 ...` of the batch, by one wave. SPARSE: only the first of the three ways
 // out below, as a loop without the other two's branches and stores (they are most of what a wave executes
 // per code otherwise); a wave that needs another way is noted in args.left_waves for the general flavour.
@@ -1489,10 +1518,7 @@ __device__ __forceinline__ void ts_wave(const TsWaveArgs &args, uint64_t wave_in
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t k = lane; k < wave_total; k += MDB_WAVE) {
-            if (out_ts) out_ts[wave_first + k] = base_time + (int64_t)(uint64_t)my_ts[k];
-            out_val[wave_first + k] = my_val[k];
-        }
+        write_staged_points(lane, wave_first, wave_total, base_time, my_ts, my_val, out_ts, out_val);
         return;
     }
     // A wave with more points than its buffer holds has long runs of `0` codes in its pieces (hundreds of
@@ -1751,10 +1777,7 @@ __device__ __forceinline__ void ts_wave(const TsWaveArgs &args, uint64_t wave_in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t k = lane; k < wave_total; k += MDB_WAVE) {
-        if (out_ts) out_ts[wave_first + k] = base_time + (int64_t)(uint64_t)my_ts[k];
-        out_val[wave_first + k] = my_val[k];
-    }
+    write_staged_points(lane, wave_first, wave_total, base_time, my_ts, my_val, out_ts, out_val);
 }
 
 // Every wave of the batch, each in whichever way it needs.
