@@ -57,6 +57,8 @@ def parse_args():
     parser.add_argument("--fit-sample-series", type=int, default=16)
     parser.add_argument("--no-cpu-baseline", action="store_true",
                         help="skip the CPU legs AND the in-run verification against the oracle")
+    parser.add_argument("--no-irregular", action="store_true",
+                        help="skip the block of series with irregular timestamps")
     parser.add_argument("--no-host-path", action="store_true",
                         help="skip the end-to-end GridStream (PCIe-inclusive) measurement")
     parser.add_argument("--range-middle", type=float, default=0.0,
@@ -226,6 +228,73 @@ def host_path(context, mdb, np, sample, args):
     points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192, tags={"tag": "wind-turbine-0042"})
     out["batch_8192_one_tag_column"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
                                         "seconds": seconds}
+    return out
+
+
+def irregular_timestamps(context, mdb, np, args):
+    """Series whose timestamps are materialised and NOT equally spaced - the delta-of-delta streams of
+    timestamps.rs:228-292: fit, grid(), COUNT/MIN/MAX/SUM on the segments and the same under WHERE timestamp
+    BETWEEN, of 100 of the benchmark's series (10^9 points at the default size), for timestamps spaced at random and
+    for a fixed rate with one sample in a hundred missing, next to the same series with regular timestamps. Not
+    the headline; reported so that the cost of irregular timestamps is on the record of every run."""
+    series = max(1, min(args.series, 100, 1_000_000_000 // max(args.points, 1)))
+    points, total = args.points, series * args.points
+    eb = mdb.error_bound("relative", args.error_bound)
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    values = context.dev_alloc(4 * total)
+    context.synth_values_dev(values, 0, series, points)
+    starts = np.arange(0, points, CHUNK_POINTS, dtype=np.uint64)
+    offsets = np.concatenate([(s * points + starts) for s in range(series)] + [np.array([total], dtype=np.uint64)]).astype(np.uint64)
+    offsets_dev = context.upload_array(offsets)
+    rng = np.random.default_rng(5)
+    shapes = (("regular", np.arange(points, dtype=np.int64) * 1000),
+              ("random_intervals", np.cumsum(rng.integers(900, 1100, points).astype(np.int64))),
+              ("one_percent_gaps", np.cumsum(np.where(rng.random(points) < 0.01, 2000, 1000).astype(np.int64))))
+    out = {"points": total, "series": series,
+           "note": "timestamps materialised on the device; randomly spaced (every delta different) and a fixed "
+                   "rate with 1 % of the samples missing, next to the same series equally spaced; grid and "
+                   "aggregates: mean of 3 calls on resident segments; the first million reconstructed timestamps "
+                   "and the counts are checked"}
+    for label, one in shapes:
+        timestamps = np.tile(one, series)
+        ts_dev = context.upload_array(timestamps)
+        context.compress_chunks_dev(ts_dev, values, offsets_dev, len(offsets) - 1, eb, 0, 0, 0).free()
+        context.sync(); started = time.perf_counter()
+        segments = context.compress_chunks_dev(ts_dev, values, offsets_dev, len(offsets) - 1, eb, 0, 0, 0)
+        context.sync(); fit_seconds = time.perf_counter() - started
+        n = context.grid_count_dev(segments)
+        if n != total:
+            raise SystemExit(f"VERIFICATION FAILED: {label}: {n} points in the segments, {total} fitted")
+        out_ts, out_val = context.dev_alloc(8 * n), context.dev_alloc(4 * n)
+        t_lo, t_hi = int(one[points // 4]), int(one[3 * points // 4])
+        calls = (("grid", lambda: context.grid_batch_dev(segments, out_ts, out_val, n)),
+                 ("aggregates", lambda: context.agg_batch_dev(segments, mask)),
+                 ("aggregates_between_quartiles", lambda: context.agg_batch_range_dev(segments, t_lo, t_hi, mask)))
+        shape = {"fit_ms": 1e3 * fit_seconds, "segments": len(segments)}
+        for name, call in calls:
+            call()
+            context.profile_enable(True); context.profile_reset(); context.sync(); started = time.perf_counter()
+            for _ in range(3):
+                result = call()
+            context.sync(); seconds = (time.perf_counter() - started) / 3
+            shape[name + "_ms"] = 1e3 * seconds
+            shape[name + "_kernels_ms"] = {k: round(v[1] / v[0], 3) for k, v in context.profile().items() if v[1] / v[0] > 0.05}
+            context.profile_enable(False)
+            if name == "aggregates" and result.count != total:
+                raise SystemExit(f"VERIFICATION FAILED: {label}: COUNT {result.count} of {total} points")
+            if name == "aggregates_between_quartiles":
+                expected = series * int(np.count_nonzero((one >= t_lo) & (one <= t_hi)))
+                if result.count != expected:
+                    raise SystemExit(f"VERIFICATION FAILED: {label}: COUNT {result.count} BETWEEN, expected {expected}")
+        if not np.array_equal(context.download_array(out_ts, min(n, 1_000_000), np.int64), timestamps[:min(n, 1_000_000)]):
+            raise SystemExit(f"VERIFICATION FAILED: {label}: reconstructed timestamps differ from the ones fitted")
+        out[label] = shape
+        for pointer in (ts_dev, out_ts, out_val):
+            context.dev_free(pointer)
+        segments.free()
+        del timestamps
+    context.dev_free(values)
+    context.dev_free(offsets_dev)
     return out
 
 
@@ -404,6 +473,7 @@ def main():
     fit_cpu = None
     verified = None
     host_path_result = None
+    irregular_result = None
     if verify:
         import oracle_lib as ora
         cores = os.cpu_count() or 1
@@ -517,6 +587,9 @@ def main():
                             "host threads find every chunk's timestamps equally spaced while the values cross "
                             "PCIe, so the timestamps never do), segments downloaded; second of two calls"}
         del downloaded
+        if not args.no_irregular:
+            with phase("irregular_timestamps"):
+                irregular_result = irregular_timestamps(context, mdb, np, args)
 
     if rank == 0:
         value = world * points_per_step * args.steps / elapsed
@@ -572,6 +645,7 @@ def main():
             "phases_s": {name: round(seconds, 2) for name, seconds in PHASES.items()},
             "aggregates": aggregates,
             "host_path": host_path_result,
+            "irregular_timestamps": irregular_result,
             "fit": {
                 "cpu_baseline": fit_cpu,
                 "points_per_s": fit_points / fit_seconds if fit_seconds > 0 else None,
