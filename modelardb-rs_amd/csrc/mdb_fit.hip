@@ -163,10 +163,32 @@ __global__ __launch_bounds__(256) void k_fit_regular(const int64_t *__restrict__
     const int64_t interval = n > 1 ? t[1] - t[0] : 0;
     const int64_t exact_limit = 1ll << 52;
     bool mine = false, far = false;
-    for (uint64_t j = threadIdx.x; j < n; j += blockDim.x) {
-        const int64_t here = t[j];
-        far = far || here > exact_limit || here < -exact_limit;
-        if (j >= 2) mine = mine || (here - t[j - 1] != interval);
+    // Two timestamps per lane and load (16 bytes, a kilobyte per wave instruction) from the first 16-byte boundary
+    // on; the one in front of a pair comes from the lane below (from memory for a wave's first lane).
+    const uint64_t head = n > 0 ? min((uint64_t)((reinterpret_cast<uintptr_t>(t) >> 3) & 1u), n) : 0; // timestamps in front of the boundary
+    const uint64_t pairs = (n - head) / 2;
+    const longlong2 *__restrict__ t2 = reinterpret_cast<const longlong2 *>(t + head);
+    const int lane = threadIdx.x & (MDB_WAVE - 1);
+    for (uint64_t first_pair = 0; first_pair < pairs; first_pair += blockDim.x) { // (every lane takes every round)
+        const uint64_t pair = first_pair + threadIdx.x;
+        const bool have = pair < pairs;
+        const longlong2 here = have ? t2[pair] : make_longlong2(0, 0);
+        const uint64_t j = head + 2 * pair; // index of here.x
+        int64_t before = (int64_t)(((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)((uint64_t)here.y >> 32), 1, MDB_WAVE) << 32) |
+                                   (uint32_t)__shfl_up((int)(uint32_t)(uint64_t)here.y, 1, MDB_WAVE));
+        if (lane == 0 && have && j >= 1) before = t[j - 1];
+        if (have) {
+            far = far || here.x > exact_limit || here.x < -exact_limit || here.y > exact_limit || here.y < -exact_limit;
+            if (j >= 2) mine = mine || (here.x - before != interval);
+            if (j + 1 >= 2) mine = mine || (here.y - here.x != interval);
+        }
+    }
+    // (the timestamp in front of the boundary, and an odd one at the end)
+    if (threadIdx.x == 0 && head == 1) far = far || t[0] > exact_limit || t[0] < -exact_limit;
+    if (threadIdx.x == 0 && head + 2 * pairs < n) {
+        const uint64_t j = n - 1;
+        far = far || t[j] > exact_limit || t[j] < -exact_limit;
+        if (j >= 2) mine = mine || (t[j] - t[j - 1] != interval);
     }
     if (mine) irregular = 1;
     if (far) beyond = 1;
