@@ -145,6 +145,42 @@ int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, i
                          int64_t t_hi, uint64_t reserve_front, mdb_grid_result **out);
 void mdb_grid_result_free(mdb_grid_result *result);
 
+/* Pipelined form, for an operator that is polled (GridStream::poll_next, grid_exec.rs:402-429): submit
+ * returns at once with a ticket, a worker thread of the library reconstructs the batch on the context or
+ * on a clone of it that the library keeps (submits alternate between the two), so the kernels of one
+ * batch run while the previous batch's points still cross PCIe; mdb_grid_wait blocks until the result
+ * is in host memory. Two submits may be outstanding per context before the third one queues behind them.
+ *   - inputs: one OR SEVERAL RecordBatches of segments, reconstructed by one launch as if they were one
+ *     batch (rows in the order of the list): the batches DataSourceExec hands a GridStream hold 8 192
+ *     segments, and a launch pays off from 10^5 (SURVEY 8(f) N2 - the caller keeps polling its input and
+ *     submits what it has got, no concat_batches on the host). rows_per_segment and n_segments of the
+ *     result run over all inputs.
+ *   - tags (grid_exec.rs:339-346): with request->n_tag_columns > 0 every input carries the views of its
+ *     tag arrays; the result then also holds, per tag column, the views repeated once per reconstructed
+ *     row (mdb_grid_result_tag_views), written by the library's host threads past the cache while the
+ *     next batch is on the GPU. The strings themselves are not copied: an output view points into the
+ *     input's data buffers, which the caller lists behind its own (tag_buffer_shift).
+ *   - the mdb_grid_input / mdb_grid_request structs and the small tables they point at are copied by
+ *     submit; the Arrow buffers behind them must stay alive until mdb_grid_wait / mdb_grid_cancel returns.
+ *   - mdb_grid_wait consumes the ticket whether it succeeds or not; a stream that is dropped with a ticket
+ *     outstanding calls mdb_grid_cancel (waits for the job and frees its result).
+ * Replaces, together with mdb_grid_result_*: grid_exec.rs:261-391 for several input batches at once. */
+typedef struct mdb_grid_ticket mdb_grid_ticket;
+int mdb_grid_submit(mdb_ctx *ctx, const mdb_grid_input *inputs, uint32_t n_inputs,
+                    const mdb_grid_request *request, mdb_grid_ticket **ticket);
+int mdb_grid_wait(mdb_grid_ticket *ticket, mdb_grid_result **out);
+void mdb_grid_cancel(mdb_grid_ticket *ticket);
+/* The replicated views of tag column `column` of a result of mdb_grid_submit: result->n views, the view of
+ * the first reconstructed row first, with result->reserved_front writable views in front of it (the
+ * leftovers' tags). NULL if the request had fewer tag columns. Freed with the result. */
+mdb_view16 *mdb_grid_result_tag_views(const mdb_grid_result *result, uint32_t column);
+/* The replication by itself, for callers that keep their own output buffers (host arithmetic, no
+ * context): out[k] = views[i] for the rows_per_segment[i] rows of segment i, buffer_index of views longer
+ * than 12 bytes moved by buffer_shift. out needs sum(rows_per_segment) views (checked against out_cap).
+ * Large fills are split over the library's host threads and written with streaming stores. */
+int mdb_replicate_views(const mdb_view16 *views, const uint32_t *rows_per_segment, uint64_t n_segments,
+                        int32_t buffer_shift, mdb_view16 *out, uint64_t out_cap);
+
 /* ---- aggregates: replaces Model{Count,Min,Max,Sum,Avg}Accumulator::update_batch
  *      (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:345-358, 395-401,
  *      438-444, 481-513, 553-587) which call modelardb_compression::{len,sum}
@@ -188,6 +224,14 @@ int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, ui
 int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
                         const uint64_t *chunk_offsets, uint64_t n_chunks,
                         mdb_error_bound error_bound, mdb_segments_owned **out);
+
+/* The same for chunks that lie wherever the caller has them (one slice of a sorted RecordBatch per series
+ * and field, compression.rs:42-107; one finished ingest buffer per series and field,
+ * uncompressed_data_manager.rs:530-596): the library gathers them into its page-locked staging block with
+ * several threads while earlier parts cross PCIe, so the caller concatenates nothing. Chunks that share a
+ * timestamp array (the fields of one series) are checked for regular spacing once. Output as above. */
+int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks,
+                            mdb_error_bound error_bound, mdb_segments_owned **out);
 
 /* Device resident variant. ts may be NULL: then chunk c has the regular timestamps
  * regular_start + i * regular_interval (i counted from the start of the chunk's series, given by

@@ -139,6 +139,33 @@ typedef struct mdb_grid_result {
     void *priv_;
 } mdb_grid_result;
 
+/* One input RecordBatch of a pipelined grid call (mdb_grid_submit): its segment columns and, when the
+ * stream's table has tag columns, the views of the batch's tag arrays (Utf8View: the same 16-byte
+ * views, one per segment row), which the library repeats once per reconstructed data point. */
+typedef struct mdb_grid_input {
+    mdb_segments segments;
+    const mdb_view16 *const *tag_views; /* n_tag_columns arrays of segments.n views; NULL without tags */
+    /* n_tag_columns numbers added to buffer_index of every view longer than 12 bytes: the output tag
+     * column's data buffers are [the caller's own buffers..., this batch's buffers...], and this is
+     * where this batch's buffers start in that list. NULL: 0. */
+    const int32_t *tag_buffer_shift;
+} mdb_grid_input;
+
+/* What to do with the inputs of one mdb_grid_submit. */
+typedef struct mdb_grid_request {
+    uint32_t flags;          /* MDB_GRID_HAS_RANGE | MDB_GRID_VALUES_ONLY */
+    uint32_t n_tag_columns;  /* tag arrays per input */
+    int64_t t_lo, t_hi;      /* with MDB_GRID_HAS_RANGE */
+    uint64_t reserve_front;  /* writable rows in front of every output column (the leftovers) */
+} mdb_grid_request;
+
+/* One series chunk of mdb_compress_chunk_list: n sorted data points in two arrays of the caller. */
+typedef struct mdb_chunk {
+    const int64_t *ts;
+    const float *values;
+    uint64_t n;
+} mdb_chunk;
+
 #ifdef __cplusplus
 }
 #endif
@@ -191,5 +218,16 @@ MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, n_segments) == 32);
 MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, reserved_front) == 40);
 MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, metrics) == 48);
 MDB_LAYOUT_ASSERT(offsetof(mdb_grid_result, priv_) == 128);
+MDB_LAYOUT_ASSERT(sizeof(mdb_grid_input) == 160);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_input, tag_views) == 144);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_input, tag_buffer_shift) == 152);
+MDB_LAYOUT_ASSERT(sizeof(mdb_grid_request) == 32);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_request, n_tag_columns) == 4);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_request, t_lo) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_request, t_hi) == 16);
+MDB_LAYOUT_ASSERT(offsetof(mdb_grid_request, reserve_front) == 24);
+MDB_LAYOUT_ASSERT(sizeof(mdb_chunk) == 24);
+MDB_LAYOUT_ASSERT(offsetof(mdb_chunk, values) == 8);
+MDB_LAYOUT_ASSERT(offsetof(mdb_chunk, n) == 16);
 
 #endif /* MDB_FORMAT_H */

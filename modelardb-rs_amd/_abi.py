@@ -119,6 +119,28 @@ class GridResultC(C.Structure):
     ]
 
 
+class GridInputC(C.Structure):
+    _fields_ = [
+        ("segments", SegmentsC),
+        ("tag_views", C.POINTER(C.c_void_p)),
+        ("tag_buffer_shift", C.POINTER(C.c_int32)),
+    ]
+
+
+class GridRequestC(C.Structure):
+    _fields_ = [
+        ("flags", C.c_uint32),
+        ("n_tag_columns", C.c_uint32),
+        ("t_lo", C.c_int64),
+        ("t_hi", C.c_int64),
+        ("reserve_front", C.c_uint64),
+    ]
+
+
+class ChunkC(C.Structure):
+    _fields_ = [("ts", C.c_void_p), ("values", C.c_void_p), ("n", C.c_uint64)]
+
+
 _HIP_SYMBOLS = {
     # name: (restype, argtypes)
     "mdb_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -162,6 +184,12 @@ _HIP_SYMBOLS = {
     "mdb_grid_batch_owned": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32, C.c_int64,
                                        C.c_int64, C.c_uint64, C.POINTER(C.POINTER(GridResultC))]),
     "mdb_grid_result_free": (None, [C.POINTER(GridResultC)]),
+    "mdb_grid_submit": (C.c_int, [C.c_void_p, C.POINTER(GridInputC), C.c_uint32, C.POINTER(GridRequestC),
+                                  C.POINTER(C.c_void_p)]),
+    "mdb_grid_wait": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(GridResultC))]),
+    "mdb_grid_cancel": (None, [C.c_void_p]),
+    "mdb_grid_result_tag_views": (C.c_void_p, [C.POINTER(GridResultC), C.c_uint32]),
+    "mdb_replicate_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_uint64]),
     "mdb_agg_batch": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,
                                 C.POINTER(AggStateC)]),
     "mdb_agg_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,
@@ -174,6 +202,8 @@ _HIP_SYMBOLS = {
                                       C.POINTER(C.POINTER(SegmentsOwnedC))]),
     "mdb_compress_chunks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                       ErrorBoundC, C.POINTER(C.POINTER(SegmentsOwnedC))]),
+    "mdb_compress_chunk_list": (C.c_int, [C.c_void_p, C.POINTER(ChunkC), C.c_uint64, ErrorBoundC,
+                                          C.POINTER(C.POINTER(SegmentsOwnedC))]),
     "mdb_compress_chunks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_uint64, ErrorBoundC, C.c_int64, C.c_int64,
                                           C.c_void_p, C.POINTER(C.POINTER(SegmentsOwnedC))]),

@@ -54,6 +54,52 @@ class DeviceSegments:
             pass
 
 
+class GridTicket:
+    """An outstanding mdb_grid_submit. wait() returns (timestamps, values, rows_per_segment, metrics,
+    tag_views) as copies ((n, 16) uint8 arrays for the tag views) and consumes the ticket."""
+
+    def __init__(self, context, pointer, keep, n_tags, values_only):
+        self._context, self._pointer, self._keep = context, pointer, keep
+        self._n_tags, self._values_only = n_tags, values_only
+
+    def wait(self):
+        context, pointer = self._context, self._pointer
+        self._pointer = None
+        out = C.POINTER(_abi.GridResultC)()
+        context._check(context.lib.mdb_grid_wait(pointer, C.byref(out)))
+        self._keep = None
+        result = out.contents
+        n, n_segments = int(result.n), int(result.n_segments)
+
+        def copy_of(pointer, count, dtype, width=1):
+            if count == 0:
+                return np.zeros((0, width) if width > 1 else 0, dtype=dtype)
+            nbytes = count * width * np.dtype(dtype).itemsize
+            array = np.frombuffer((C.c_char * nbytes).from_address(pointer), dtype=dtype).copy()
+            return array.reshape(count, width) if width > 1 else array
+
+        try:
+            ts = None if self._values_only else copy_of(result.timestamps, n, np.int64)
+            values = copy_of(result.values, n, np.float32)
+            rows = copy_of(result.rows_per_segment, n_segments, np.uint32)
+            tags = [copy_of(context.lib.mdb_grid_result_tag_views(out, t), n, np.uint8, 16)
+                    for t in range(self._n_tags)]
+            return ts, values, rows, result.metrics.as_dict(), tags
+        finally:
+            context.lib.mdb_grid_result_free(out)
+
+    def cancel(self):
+        if self._pointer is not None:
+            self._context.lib.mdb_grid_cancel(self._pointer)
+            self._pointer = None
+
+    def __del__(self):
+        try:
+            self.cancel()
+        except Exception:
+            pass
+
+
 def comm_unique_id():
     """ncclGetUniqueId through the C ABI: 128 bytes, made by one rank."""
     lib = _abi.load_hip_library()
@@ -215,6 +261,42 @@ class Context:
             return ts, values, rows, metrics
         return ts, values, rows, metrics, release
 
+    def grid_submit(self, batches, tag_views=None, tag_buffer_shifts=None, time_range=None,
+                    values_only=False, reserve_front=0):
+        """mdb_grid_submit: one or several SegmentBatches through one launch, on a worker thread of the
+        library. tag_views: per batch, a list of (n, 16)-byte uint8 arrays (one per tag column) with one
+        view per segment; tag_buffer_shifts: per batch, one int per tag column. Returns a GridTicket."""
+        batches = list(batches)
+        n_tags = len(tag_views[0]) if tag_views else 0
+        inputs = (_abi.GridInputC * len(batches))()
+        keep = [batches]
+        for b, batch in enumerate(batches):
+            inputs[b].segments = batch.as_c()
+            if n_tags:
+                views = [np.ascontiguousarray(v, dtype=np.uint8) for v in tag_views[b]]
+                pointers = (C.c_void_p * n_tags)(*[v.ctypes.data for v in views])
+                shifts = (C.c_int32 * n_tags)(*(tag_buffer_shifts[b] if tag_buffer_shifts else [0] * n_tags))
+                inputs[b].tag_views = pointers
+                inputs[b].tag_buffer_shift = shifts
+                keep += [views, pointers, shifts]
+        has_range = time_range is not None
+        t_lo, t_hi = time_range if has_range else (0, 0)
+        request = _abi.GridRequestC((1 if has_range else 0) | (2 if values_only else 0), n_tags, t_lo, t_hi,
+                                    reserve_front)
+        ticket = C.c_void_p()
+        self._check(self.lib.mdb_grid_submit(self.handle, inputs, len(batches), C.byref(request),
+                                             C.byref(ticket)))
+        return GridTicket(self, ticket, keep, n_tags, values_only)
+
+    def replicate_views(self, views, rows_per_segment, buffer_shift=0):
+        """mdb_replicate_views: views (n, 16) uint8 -> (sum(rows), 16) uint8."""
+        views = np.ascontiguousarray(views, dtype=np.uint8).reshape(-1, 16)
+        rows = np.ascontiguousarray(rows_per_segment, dtype=np.uint32)
+        out = np.empty((int(rows.sum()), 16), dtype=np.uint8)
+        self._check(self.lib.mdb_replicate_views(views.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p),
+                                                 len(rows), buffer_shift, out.ctypes.data_as(C.c_void_p), len(out)))
+        return out
+
     def grid_batch_range(self, batch, t_lo, t_hi):
         """grid() with the predicate t_lo <= timestamp <= t_hi pushed down."""
         seg = batch.as_c()
@@ -302,6 +384,24 @@ class Context:
         self._check(self.lib.mdb_compress_chunks(
             self.handle, ts.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
             offsets.ctypes.data_as(C.c_void_p), len(offsets) - 1, eb, C.byref(out)))
+        try:
+            return SegmentBatch.from_owned(out)
+        finally:
+            self.lib.mdb_segments_free(out)
+
+    def compress_chunk_list(self, chunks, eb):
+        """mdb_compress_chunk_list: chunks = [(timestamps, values), ...] lying wherever they lie."""
+        arrays = [(np.ascontiguousarray(ts, dtype=np.int64), np.ascontiguousarray(v, dtype=np.float32))
+                  for ts, v in chunks]
+        for ts, v in arrays:
+            if len(ts) != len(v):
+                raise HipError("Uncompressed timestamps and uncompressed values have different lengths.")
+        # (an array that was contiguous already is passed as it is: chunks that share a timestamp array
+        # keep sharing it)
+        table = (_abi.ChunkC * max(len(arrays), 1))(*[_abi.ChunkC(ts.ctypes.data, v.ctypes.data, len(v))
+                                                      for ts, v in arrays])
+        out = C.POINTER(_abi.SegmentsOwnedC)()
+        self._check(self.lib.mdb_compress_chunk_list(self.handle, table, len(arrays), eb, C.byref(out)))
         try:
             return SegmentBatch.from_owned(out)
         finally:

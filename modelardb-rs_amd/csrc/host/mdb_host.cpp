@@ -16,102 +16,8 @@
 #include <functional>
 #include <mutex>
 
-#include <emmintrin.h>
 
 namespace mdbhost {
-
-namespace {
-
-// A few threads that stay around for the fills that are memory bandwidth rather than one core's work (tag views,
-// the gather of ingested buffers): starting sixteen threads per batch costs as much as a small batch's fill.
-// One parallel region at a time; the caller takes a share itself.
-class WorkerPool {
-  public:
-    static WorkerPool &instance() {
-        static WorkerPool pool;
-        return pool;
-    }
-    unsigned width() const { return static_cast<unsigned>(threads_.size()) + 1; }
-    // Runs share(k) for k in [0, n_shares), spread over the pool's threads and the caller; returns when all are done.
-    void run(unsigned n_shares, const std::function<void(unsigned)> &share) {
-        if (n_shares == 0) return;
-        std::lock_guard<std::mutex> region(region_mutex_);
-        {
-            std::lock_guard<std::mutex> lock(mutex_);
-            share_ = &share;
-            n_shares_ = n_shares;
-            next_share_ = 0;
-            unfinished_ = n_shares;
-            generation_ += 1;
-        }
-        wake_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lock(mutex_);
-        done_.wait(lock, [&] { return unfinished_ == 0; });
-        share_ = nullptr;
-    }
-
-  private:
-    WorkerPool() {
-        const unsigned n = std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
-        for (unsigned k = 0; k < n; k++) threads_.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lock(mutex_);
-            stopping_ = true;
-        }
-        wake_.notify_all();
-        for (std::thread &thread : threads_) thread.join();
-    }
-    void work() { // takes shares until none is left
-        for (;;) {
-            unsigned mine;
-            const std::function<void(unsigned)> *share;
-            {
-                std::lock_guard<std::mutex> lock(mutex_);
-                if (!share_ || next_share_ >= n_shares_) return;
-                mine = next_share_++;
-                share = share_;
-            }
-            (*share)(mine);
-            std::lock_guard<std::mutex> lock(mutex_);
-            if (--unfinished_ == 0) done_.notify_all();
-        }
-    }
-    void loop() {
-        unsigned long long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lock(mutex_);
-                wake_.wait(lock, [&] { return stopping_ || generation_ != seen; });
-                if (stopping_) return;
-                seen = generation_;
-            }
-            work();
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex region_mutex_, mutex_;
-    std::condition_variable wake_, done_;
-    const std::function<void(unsigned)> *share_ = nullptr;
-    unsigned n_shares_ = 0, next_share_ = 0, unfinished_ = 0;
-    unsigned long long generation_ = 0;
-    bool stopping_ = false;
-};
-
-// Rows (or values) from which such a fill is shared out (MDB_HOST_PARALLEL_MIN_ROWS: the sanitizer runs set it
-// low so that their small batches go through the pool too).
-size_t parallel_min_rows() {
-    static const size_t setting = [] {
-        const char *text = std::getenv("MDB_HOST_PARALLEL_MIN_ROWS");
-        const long long value = text ? std::atoll(text) : 0;
-        return value > 0 ? static_cast<size_t>(value) : static_cast<size_t>(1) << 18;
-    }();
-    return setting;
-}
-
-} // namespace
 
 namespace {
 
@@ -580,73 +486,94 @@ GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<Ti
     // MDB_HOST_GRID_PREFETCH=0: grid a batch when it is polled for and not before (A/B, tests).
     const char *setting = std::getenv("MDB_HOST_GRID_PREFETCH");
     prefetch_ = !(setting && std::string(setting) == "0");
+    if (const char *text = std::getenv("MDB_HOST_GRID_COALESCE_SEGMENTS"))
+        coalesce_segments_ = static_cast<size_t>(std::max(0ll, std::atoll(text)));
 }
 
 GridStream::~GridStream() {
-    if (ahead_ && ahead_->result.valid()) {
-        try {
-            mdb_grid_result_free(ahead_->result.get());
-        } catch (...) {
+    if (ahead_) mdb_grid_cancel(ahead_->raw); // (waits for the job and frees what it made)
+}
+
+// Data points a submit should decompress to, and the segments it may hold at most.
+constexpr uint64_t GRID_SUBMIT_TARGET_POINTS = 16u << 20;
+constexpr uint64_t GRID_SUBMIT_MAX_SEGMENTS = 1u << 20;
+
+PollState GridStream::poll_input_and_submit(std::optional<Ticket> *out) {
+    out->reset();
+    if (input_finished_) return PollState::ReadyNone;
+    // How many segments to gather: the batches of the input hold batch_size segments (8 192) whether they
+    // decompress to 65 536 points or to 500 M; the first submit takes one batch, later ones what the results so
+    // far say about 16 M points are.
+    uint64_t wanted = 1;
+    if (coalesce_segments_ > 0) {
+        wanted = coalesce_segments_;
+    } else if (seen_segments_ > 0) {
+        const uint64_t points_per_segment = std::max<uint64_t>(1, seen_points_ / seen_segments_);
+        wanted = std::min<uint64_t>(GRID_SUBMIT_TARGET_POINTS / points_per_segment, GRID_SUBMIT_MAX_SEGMENTS);
+    }
+    Ticket ticket;
+    uint64_t gathered = 0;
+    PollState state = PollState::ReadySome;
+    while (gathered < std::max<uint64_t>(wanted, 1)) {
+        RecordBatch batch;
+        state = input_->poll_next(&batch);
+        if (state != PollState::ReadySome) break;
+        gathered += static_cast<uint64_t>(batch.num_rows);
+        ticket.batches.push_back(std::make_shared<RecordBatch>(std::move(batch)));
+    }
+    if (state == PollState::ReadyNone) input_finished_ = true;
+    if (ticket.batches.empty()) return state; // ReadyNone or Pending
+    // One library call replaces the per-row loop of grid_exec.rs:323-356 for all gathered batches. A timestamp
+    // predicate is pushed down so out-of-range points are neither reconstructed nor copied over PCIe (the
+    // leftovers were filtered when they were created), which makes the filter step of grid_exec.rs:366-387 a
+    // no-op here. The points arrive in page-locked memory owned by the library with room in front for the
+    // leftovers (fewer than batch_size of them); the columns alias it. Tag views are repeated per created row
+    // by the library (grid_exec.rs:339-346); the strings stay where they are: an output tag column lists one
+    // buffer of its own (long leftover strings) and then the data buffers of every gathered batch.
+    const size_t n_fixed = query_compressed_schema().size();
+    const size_t n_tags = values_only_ ? 0 : ticket.batches[0]->columns.size() - n_fixed;
+    std::vector<SegmentsView> views(ticket.batches.size());
+    std::vector<mdb_grid_input> inputs(ticket.batches.size());
+    std::vector<const mdb_view16 *> tag_views(ticket.batches.size() * n_tags);
+    std::vector<int32_t> tag_shifts(ticket.batches.size() * n_tags);
+    std::vector<int32_t> next_buffer(n_tags, 1);
+    for (size_t b = 0; b < ticket.batches.size(); b++) {
+        const RecordBatch &batch = *ticket.batches[b];
+        if (!values_only_ && batch.columns.size() != n_fixed + n_tags) throw Error("GridStream should use a static schema.");
+        fill_segments_view(batch.columns, &views[b]);
+        inputs[b].segments = views[b].seg;
+        for (size_t t = 0; t < n_tags; t++) {
+            const Column &tags = *batch.columns[n_fixed + t];
+            tag_views[b * n_tags + t] = tags.as<mdb_view16>();
+            tag_shifts[b * n_tags + t] = next_buffer[t];
+            next_buffer[t] += static_cast<int32_t>(tags.buffer_ptrs.size());
         }
+        inputs[b].tag_views = n_tags ? tag_views.data() + b * n_tags : nullptr;
+        inputs[b].tag_buffer_shift = n_tags ? tag_shifts.data() + b * n_tags : nullptr;
     }
-    if (second_ctx_) mdb_close(second_ctx_);
-}
-
-std::shared_ptr<GridStream::TagBlock> GridStream::take_tag_block(size_t rows) {
-    // A block nobody but the pool refers to any more (the batches sliced from it have been dropped) and that
-    // is large enough; otherwise a new one, in place of the smallest idle one if the pool is full.
-    std::shared_ptr<TagBlock> *smallest_idle = nullptr;
-    for (auto &block : tag_blocks_) {
-        if (block.use_count() != 1) continue;
-        if (block->capacity >= rows) return block;
-        if (!smallest_idle || block->capacity < (*smallest_idle)->capacity) smallest_idle = &block;
-    }
-    auto fresh = std::make_shared<TagBlock>();
-    fresh->capacity = rows + rows / 4 + 4096;
-    fresh->views.reset(new mdb_view16[fresh->capacity]);
-    if (smallest_idle) *smallest_idle = fresh;
-    else if (tag_blocks_.size() < 16) tag_blocks_.push_back(fresh);
-    return fresh;
-}
-
-GridStream::InFlight GridStream::start_grid(RecordBatch batch) {
-    InFlight flight;
-    flight.batch = std::make_shared<RecordBatch>(std::move(batch));
-    mdb_ctx *ctx = ctx_;
-    if (prefetch_ && (started_ & 1u)) {
-        if (!second_ctx_) check(mdb_clone(ctx_, &second_ctx_));
-        ctx = second_ctx_;
-    }
-    started_ += 1;
-    // One library call replaces the per-row loop of grid_exec.rs:323-356. A timestamp predicate is
-    // pushed down so out-of-range points are neither reconstructed nor copied over PCIe (the
-    // leftovers were filtered when they were created), which makes the filter step of
-    // grid_exec.rs:366-387 a no-op here. The points arrive in page-locked memory owned by the
-    // library with room in front for the leftovers (fewer than batch_size of them); the columns alias it.
     const bool pushdown = maybe_predicate_.has_value();
-    const int64_t t_lo = pushdown && maybe_predicate_->lower ? *maybe_predicate_->lower : INT64_MIN;
-    const int64_t t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
-    const uint32_t flags = (pushdown ? MDB_GRID_HAS_RANGE : 0u) | (values_only_ ? MDB_GRID_VALUES_ONLY : 0u);
-    const uint64_t reserve_front = batch_size_;
-    std::shared_ptr<RecordBatch> held = flight.batch;
-    auto call = [held, ctx, flags, t_lo, t_hi, reserve_front]() {
-        SegmentsView view;
-        fill_segments_view(held->columns, &view);
-        mdb_grid_result *raw = nullptr;
-        check(mdb_grid_batch_owned(ctx, &view.seg, flags, t_lo, t_hi, reserve_front, &raw));
-        return raw;
-    };
-    flight.result = std::async(prefetch_ ? std::launch::async : std::launch::deferred, call);
-    return flight;
+    mdb_grid_request request{};
+    request.flags = (pushdown ? MDB_GRID_HAS_RANGE : 0u) | (values_only_ ? MDB_GRID_VALUES_ONLY : 0u);
+    request.n_tag_columns = static_cast<uint32_t>(n_tags);
+    request.t_lo = pushdown && maybe_predicate_->lower ? *maybe_predicate_->lower : INT64_MIN;
+    request.t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
+    request.reserve_front = batch_size_;
+    check(mdb_grid_submit(ctx_, inputs.data(), static_cast<uint32_t>(inputs.size()), &request, &ticket.raw));
+    *out = std::move(ticket);
+    return PollState::ReadySome;
 }
 
-void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) {
+void GridStream::wait_and_append_to_leftovers_in_current_batch(Ticket ticket) {
     const auto started = std::chrono::steady_clock::now();
-    const RecordBatch &batch = *flight.batch;
-    const size_t n_tags = values_only_ ? 0 : batch.columns.size() - query_compressed_schema().size();
-    if (!values_only_ && schema_.size() != 2 + n_tags) throw Error("GridStream should use a static schema.");
+    const size_t n_fixed = query_compressed_schema().size();
+    const size_t n_tags = values_only_ ? 0 : ticket.batches[0]->columns.size() - n_fixed;
+    if (!values_only_ && schema_.size() != 2 + n_tags) {
+        mdb_grid_cancel(ticket.raw);
+        throw Error("GridStream should use a static schema.");
+    }
     const int64_t leftovers = current_batch_.num_rows - current_batch_offset_;
-    mdb_grid_result *raw = flight.result.get(); // (rethrows what the call threw)
+    mdb_grid_result *raw = nullptr;
+    check(mdb_grid_wait(ticket.raw, &raw)); // (the ticket is gone either way)
     std::shared_ptr<mdb_grid_result> result(raw, [](mdb_grid_result *r) { mdb_grid_result_free(r); });
     const int64_t total = leftovers + static_cast<int64_t>(result->n);
     int64_t *timestamps = values_only_ ? nullptr : result->timestamps - leftovers;
@@ -657,107 +584,59 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
             std::memcpy(timestamps, current_batch_.columns[0]->as<int64_t>() + current_batch_offset_, 8 * leftovers);
         std::memcpy(values, current_batch_.columns[value_column]->as<float>() + current_batch_offset_, 4 * leftovers);
     }
-    const uint32_t *rows_per_segment = result->rows_per_segment;
     metrics_->add(result->metrics);
+    seen_segments_ += result->n_segments;
+    seen_points_ += result->n;
 
-    // Tag columns: the segment's tag value once per created row (grid_exec.rs:341-346). Views are
-    // replicated; long strings stay in the input's data buffers (shared, not copied).
+    // Tag columns: the library has written every segment's view once per created row behind the room for the
+    // leftovers (mdb_grid_result_tag_views); the leftovers' own views go in front. Long strings stay in the
+    // input's data buffers (shared, not copied); those of the leftovers are copied so old inputs can be dropped.
     std::vector<ColumnPtr> tag_columns;
-    struct Replication { // the views of one tag column: one per segment in, one per created row out
-        const mdb_view16 *input;
-        mdb_view16 *output;
-    };
-    std::vector<Replication> replications;
     for (size_t t = 0; t < n_tags; t++) {
-        const Column &input_tags = *batch.columns[query_compressed_schema().size() + t];
         auto column = std::make_shared<Column>();
         column->type = Type::Utf8View;
         column->length = total;
-        // 16 bytes per created row: not zero-filled first, and written by several threads when large
-        // (this is the StringView append per row of grid_exec.rs:341-346, the host-side cost of a tag).
-        struct TagStorage {
-            std::shared_ptr<TagBlock> block;
-            ColumnPtr input;
-        };
-        auto storage = std::make_shared<TagStorage>();
-        storage->block = take_tag_block(std::max<size_t>(static_cast<size_t>(total), 1));
-        storage->input = batch.columns[query_compressed_schema().size() + t];
-        (void)flight.batch; // (the tag columns keep the input's buffers alive themselves)
-        mdb_view16 *views = storage->block->views.get();
-        // buffer 0: long leftover strings, copied so old inputs can be dropped.
+        mdb_view16 *views = mdb_grid_result_tag_views(result.get(), static_cast<uint32_t>(t)) - leftovers;
         column->owned_buffers.emplace_back();
         std::vector<uint8_t> &leftover_payload = column->owned_buffers[0];
         if (leftovers > 0) {
             const Column &previous = *current_batch_.columns[2 + t];
             for (int64_t i = 0; i < leftovers; i++) {
                 std::string_view value = previous.view_value(current_batch_offset_ + i);
-                views[i].length = static_cast<int32_t>(value.size());
+                mdb_view16 view{};
+                view.length = static_cast<int32_t>(value.size());
                 if (value.size() <= 12) {
-                    std::memcpy(views[i].u.inlined, value.data(), value.size());
+                    std::memcpy(view.u.inlined, value.data(), value.size());
                 } else {
-                    std::memcpy(views[i].u.ref.prefix, value.data(), 4);
-                    views[i].u.ref.buffer_index = 0;
-                    views[i].u.ref.offset = static_cast<int32_t>(leftover_payload.size());
+                    std::memcpy(view.u.ref.prefix, value.data(), 4);
+                    view.u.ref.buffer_index = 0;
+                    view.u.ref.offset = static_cast<int32_t>(leftover_payload.size());
                     leftover_payload.insert(leftover_payload.end(), value.begin(), value.end());
                 }
+                views[i] = view;
             }
         }
-        replications.push_back({input_tags.as<mdb_view16>(), views});
         column->values = views;
         column->buffer_ptrs.push_back(leftover_payload.empty() ? reinterpret_cast<const uint8_t *>(views)
                                                                : leftover_payload.data());
         column->buffer_sizes.push_back(static_cast<int64_t>(leftover_payload.size()));
-        for (size_t b = 0; b < input_tags.buffer_ptrs.size(); b++) {
-            column->buffer_ptrs.push_back(input_tags.buffer_ptrs[b]);
-            column->buffer_sizes.push_back(input_tags.buffer_sizes[b]);
+        // (the same order poll_input_and_submit numbered them in: tag_buffer_shift)
+        struct TagStorage {
+            std::shared_ptr<mdb_grid_result> result;
+            std::vector<ColumnPtr> inputs;
+        };
+        auto storage = std::make_shared<TagStorage>();
+        storage->result = result;
+        for (const auto &batch : ticket.batches) {
+            const ColumnPtr &input_tags = batch->columns[n_fixed + t];
+            for (size_t b = 0; b < input_tags->buffer_ptrs.size(); b++) {
+                column->buffer_ptrs.push_back(input_tags->buffer_ptrs[b]);
+                column->buffer_sizes.push_back(input_tags->buffer_sizes[b]);
+            }
+            storage->inputs.push_back(input_tags);
         }
         column->keep_alive = storage;
         tag_columns.push_back(column);
-    }
-    if (!replications.empty()) {
-        // All tag columns in one go, by several threads when there is much to write: equal shares of the
-        // segment rows, every thread starting where the rows before it end. The views are written past the
-        // cache (nobody reads them before the consumer does, and reading the lines first to own them would
-        // double the memory traffic of what is a plain fill).
-        auto replicate = [&](int64_t first_row, int64_t last_row, int64_t first_at) {
-            for (const Replication &r : replications) {
-                int64_t at = first_at;
-                for (int64_t row = first_row; row < last_row; row++) {
-                    mdb_view16 tag = r.input[row];
-                    if (tag.length > 12) tag.u.ref.buffer_index += 1; // shifted behind the leftovers buffer
-                    __m128i bits;
-                    std::memcpy(&bits, &tag, 16);
-                    mdb_view16 *to = r.output + at;
-                    const uint32_t n = rows_per_segment[row];
-                    if ((reinterpret_cast<uintptr_t>(to) & 15u) == 0) {
-                        for (uint32_t k = 0; k < n; k++) _mm_stream_si128(reinterpret_cast<__m128i *>(to + k), bits);
-                    } else {
-                        for (uint32_t k = 0; k < n; k++) to[k] = tag;
-                    }
-                    at += n;
-                }
-            }
-            _mm_sfence();
-        };
-        const int64_t new_rows = total - leftovers;
-        const unsigned n_threads = static_cast<size_t>(new_rows) * replications.size() >= parallel_min_rows()
-                                       ? WorkerPool::instance().width()
-                                       : 1u;
-        if (n_threads == 1) {
-            replicate(0, batch.num_rows, leftovers);
-        } else {
-            struct Share {
-                int64_t first_row, last_row, at;
-            };
-            std::vector<Share> shares;
-            int64_t at = leftovers, row = 0;
-            for (unsigned w = 0; w < n_threads; w++) {
-                const int64_t last_row = batch.num_rows * static_cast<int64_t>(w + 1) / n_threads;
-                shares.push_back({row, last_row, at});
-                for (; row < last_row; row++) at += rows_per_segment[row];
-            }
-            WorkerPool::instance().run(n_threads, [&](unsigned k) { replicate(shares[k].first_row, shares[k].last_row, shares[k].at); });
-        }
     }
 
     auto aliased = [&](Type type, const void *data) {
@@ -783,24 +662,21 @@ void GridStream::grid_and_append_to_leftovers_in_current_batch(InFlight flight) 
 PollState GridStream::poll_next(RecordBatch *out) {
     // grid_exec.rs:402-429
     if (static_cast<size_t>(current_batch_.num_rows - current_batch_offset_) < batch_size_) {
-        std::optional<InFlight> flight = std::move(ahead_);
+        std::optional<Ticket> ticket = std::move(ahead_);
         ahead_.reset();
         PollState state = PollState::ReadySome;
-        if (!flight) {
-            RecordBatch batch;
-            state = input_finished_ ? PollState::ReadyNone : input_->poll_next(&batch);
-            if (state == PollState::ReadySome) flight = start_grid(std::move(batch));
-            if (state == PollState::ReadyNone) input_finished_ = true;
-        }
-        if (flight) {
-            // The batch after this one starts now, so that it is on the GPU while this one comes down.
-            if (prefetch_ && !input_finished_) {
-                RecordBatch next;
-                const PollState next_state = input_->poll_next(&next);
-                if (next_state == PollState::ReadySome) ahead_ = start_grid(std::move(next));
-                if (next_state == PollState::ReadyNone) input_finished_ = true;
+        if (!ticket) state = poll_input_and_submit(&ticket);
+        if (ticket) {
+            // The submit after this one starts now, so that it is on the GPU while this one comes down.
+            if (prefetch_) {
+                try {
+                    (void)poll_input_and_submit(&ahead_);
+                } catch (...) {
+                    mdb_grid_cancel(ticket->raw);
+                    throw;
+                }
             }
-            grid_and_append_to_leftovers_in_current_batch(std::move(*flight));
+            wait_and_append_to_leftovers_in_current_batch(std::move(*ticket));
         } else if (state == PollState::ReadyNone && current_batch_offset_ < current_batch_.num_rows) {
             // Ignore Ready(None): there are data points left in the current batch.
         } else {
@@ -1067,6 +943,54 @@ struct OwnedGuard {
     ~OwnedGuard() { mdb_segments_free(owned); }
 };
 
+// One series x field to compress: where its sorted data points lie, and what the resulting batch is labelled with.
+// (rust/modelardb_hip: SeriesChunk.)
+struct SeriesChunk {
+    const int64_t *timestamps;
+    const float *values;
+    uint64_t n;
+    mdb_error_bound error_bound;
+    const std::vector<std::string> *tag_values;
+    int16_t field_column_index;
+};
+
+bool same_bound(const mdb_error_bound &a, const mdb_error_bound &b) {
+    return a.kind == b.kind && (a.kind == MDB_EB_LOSSLESS || a.value == b.value);
+}
+
+// All chunks through ONE mdb_compress_chunk_list per distinct error bound (an error bound is an argument of the
+// launch), the resulting batches in the order of the chunks. rust/modelardb_hip: Context::compress_chunks - the
+// call the patched try_compress_multivariate_time_series and process_compressor_messages make.
+std::vector<RecordBatch> compress_chunks(mdb_ctx *ctx, const std::vector<SeriesChunk> &chunks,
+                                         const std::vector<Field> &compressed_schema) {
+    std::vector<RecordBatch> result(chunks.size());
+    std::vector<bool> done(chunks.size(), false);
+    for (size_t first = 0; first < chunks.size(); first++) {
+        if (done[first]) continue;
+        std::vector<size_t> group;
+        std::vector<mdb_chunk> list;
+        for (size_t c = first; c < chunks.size(); c++) {
+            if (done[c] || !same_bound(chunks[c].error_bound, chunks[first].error_bound)) continue;
+            done[c] = true;
+            group.push_back(c);
+            list.push_back({chunks[c].timestamps, chunks[c].values, chunks[c].n});
+        }
+        OwnedGuard guard;
+        check(mdb_compress_chunk_list(ctx, list.data(), list.size(), chunks[first].error_bound, &guard.owned));
+        // Segments come back grouped by chunk, in chunk order.
+        uint64_t row = 0;
+        const uint64_t total = guard.owned->seg.n;
+        for (size_t k = 0; k < group.size(); k++) {
+            const uint64_t begin = row;
+            while (row < total && guard.owned->chunk_index[row] == k) row++;
+            const SeriesChunk &chunk = chunks[group[k]];
+            result[group[k]] = record_batch_from_owned(guard.owned, begin, row, compressed_schema, *chunk.tag_values,
+                                                       chunk.field_column_index);
+        }
+    }
+    return result;
+}
+
 } // namespace
 
 RecordBatch try_compress_univariate_time_series(mdb_ctx *ctx, const Column &uncompressed_timestamps,
@@ -1133,43 +1057,27 @@ std::vector<RecordBatch> try_compress_multivariate_time_series(mdb_ctx *ctx,
         }
     }
 
-    // Every series x field is one chunk of a single launch.
+    // The sorted columns (take_arrays, compression.rs:138), then every series x field as one chunk of ONE launch
+    // per error bound (the reference: one try_compress_univariate_time_series per series and field, :159-176).
     const size_t n_fields = metadata.field_column_indices.size();
-    std::vector<int64_t> chunk_ts;
-    std::vector<float> chunk_values;
-    std::vector<uint64_t> offsets = {0};
-    chunk_ts.reserve(static_cast<size_t>(n) * n_fields);
-    chunk_values.reserve(static_cast<size_t>(n) * n_fields);
-    // Chunks with different error bounds need separate calls; group fields by bound.
-    std::vector<RecordBatch> result(series.size() * n_fields);
+    std::vector<int64_t> sorted_ts(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; i++) sorted_ts[static_cast<size_t>(i)] = ts[order[static_cast<size_t>(i)]];
+    std::vector<std::vector<float>> sorted_values(n_fields, std::vector<float>(static_cast<size_t>(n)));
     for (size_t f = 0; f < n_fields; f++) {
-        const size_t field_index = metadata.field_column_indices[f];
-        const float *values = batch.columns[field_index]->as<float>();
-        chunk_ts.clear();
-        chunk_values.clear();
-        offsets.assign(1, 0);
-        for (const Series &s : series) {
-            for (int64_t i = s.first; i < s.last; i++) {
-                chunk_ts.push_back(ts[order[static_cast<size_t>(i)]]);
-                chunk_values.push_back(values[order[static_cast<size_t>(i)]]);
-            }
-            offsets.push_back(chunk_ts.size());
-        }
-        OwnedGuard guard;
-        check(mdb_compress_chunks(ctx, chunk_ts.data(), chunk_values.data(), offsets.data(), series.size(),
-                                  metadata.error_bounds[field_index].c, &guard.owned));
-        // Segments come back grouped by chunk, in chunk order.
-        uint64_t row = 0;
-        const uint64_t total = guard.owned->seg.n;
-        for (size_t s = 0; s < series.size(); s++) {
-            uint64_t first = row;
-            while (row < total && guard.owned->chunk_index[row] == s) row++;
-            result[s * n_fields + f] = record_batch_from_owned(guard.owned, first, row, metadata.compressed_schema,
-                                                               series[s].tag_values,
-                                                               static_cast<int16_t>(field_index));
+        const float *values = batch.columns[metadata.field_column_indices[f]]->as<float>();
+        for (int64_t i = 0; i < n; i++) sorted_values[f][static_cast<size_t>(i)] = values[order[static_cast<size_t>(i)]];
+    }
+    std::vector<SeriesChunk> chunks;
+    chunks.reserve(series.size() * n_fields);
+    for (const Series &s : series) {
+        for (size_t f = 0; f < n_fields; f++) {
+            const size_t field_index = metadata.field_column_indices[f];
+            chunks.push_back({sorted_ts.data() + s.first, sorted_values[f].data() + s.first,
+                              static_cast<uint64_t>(s.last - s.first), metadata.error_bounds[field_index].c,
+                              &s.tag_values, static_cast<int16_t>(field_index)});
         }
     }
-    return result;
+    return compress_chunks(ctx, chunks, metadata.compressed_schema);
 }
 
 // ---- UncompressedDataManager --------------------------------------------------------------------------------
@@ -1251,86 +1159,46 @@ void UncompressedDataManager::flush() {
 }
 
 std::vector<RecordBatch> UncompressedDataManager::compress_finished_buffers() {
+    // What the patched process_compressor_messages does with the buffers it drained from its channel
+    // (rust/patches/0004-uncompressed_data_manager.patch): every finished buffer x field column is one chunk, all of
+    // them go through ONE launch per error bound, and the batches come back in the order buffer by buffer, field
+    // by field - where the reference compresses one buffer at a time on its single compression thread
+    // (uncompressed_data_manager.rs:505-596).
     const size_t n_fields = metadata_.field_column_indices.size();
-    std::vector<RecordBatch> result(finished_.size() * n_fields);
-    // record_batch(): sort each buffer by time (sort_to_indices + take).
-    // (a buffer that is in time order already - a sensor sends its points that way - keeps an empty order)
-    std::vector<std::vector<int64_t>> order(finished_.size());
+    // record_batch(): sort each buffer by time (sort_to_indices + take, uncompressed_data_buffer.rs:181-201).
+    // A buffer that is in time order already - a sensor sends its points that way - is used where it lies.
+    struct Sorted {
+        std::vector<int64_t> timestamps;
+        std::vector<std::vector<float>> values;
+    };
+    std::vector<std::unique_ptr<Sorted>> sorted(finished_.size());
     for (size_t b = 0; b < finished_.size(); b++) {
         const std::vector<int64_t> &ts = finished_[b].timestamps;
         if (std::is_sorted(ts.begin(), ts.end())) continue;
-        order[b].resize(ts.size());
-        std::iota(order[b].begin(), order[b].end(), 0);
-        std::stable_sort(order[b].begin(), order[b].end(), [&](int64_t x, int64_t y) { return ts[x] < ts[y]; });
-    }
-    // Fields that share an error bound share a launch: chunk = (finished buffer, field).
-    std::vector<bool> done(n_fields, false);
-    for (size_t f0 = 0; f0 < n_fields; f0++) {
-        if (done[f0]) continue;
-        const mdb_error_bound bound = metadata_.error_bounds[metadata_.field_column_indices[f0]].c;
-        std::vector<size_t> group;
-        for (size_t f = f0; f < n_fields; f++) {
-            const mdb_error_bound other = metadata_.error_bounds[metadata_.field_column_indices[f]].c;
-            if (!done[f] && other.kind == bound.kind && (bound.kind == MDB_EB_LOSSLESS || other.value == bound.value)) {
-                group.push_back(f);
-                done[f] = true;
-            }
-        }
-        std::vector<uint64_t> offsets = {0};
-        uint64_t group_points = 0;
-        for (const Buffer &buffer : finished_) group_points += buffer.timestamps.size() * group.size();
-        // Where every (buffer, field) chunk goes is known up front, so the gather is shared by several threads
-        // when there is much to move (it is a copy of everything ingested: memory bandwidth, not one core's).
-        std::unique_ptr<int64_t[]> ts_storage(new int64_t[std::max<uint64_t>(group_points, 1)]);
-        std::unique_ptr<float[]> value_storage(new float[std::max<uint64_t>(group_points, 1)]);
-        int64_t *const chunk_ts_data = ts_storage.get();
-        float *const chunk_values_data = value_storage.get();
-        for (size_t b = 0; b < finished_.size(); b++)
-            for (size_t k = 0; k < group.size(); k++) offsets.push_back(offsets.back() + finished_[b].timestamps.size());
-        auto gather = [&](size_t first_buffer, size_t last_buffer) {
-            for (size_t b = first_buffer; b < last_buffer; b++) {
-                for (size_t k = 0; k < group.size(); k++) {
-                    const size_t f = group[k];
-                    const uint64_t at = offsets[b * group.size() + k];
-                    const size_t n = finished_[b].timestamps.size();
-                    if (order[b].empty()) {
-                        std::memcpy(chunk_ts_data + at, finished_[b].timestamps.data(), 8 * n);
-                        std::memcpy(chunk_values_data + at, finished_[b].values[f].data(), 4 * n);
-                    } else {
-                        for (size_t j = 0; j < n; j++) {
-                            const size_t i = static_cast<size_t>(order[b][j]);
-                            chunk_ts_data[at + j] = finished_[b].timestamps[i];
-                            chunk_values_data[at + j] = finished_[b].values[f][i];
-                        }
-                    }
-                }
-            }
-        };
-        const unsigned n_gatherers = group_points >= 16 * parallel_min_rows() ? WorkerPool::instance().width() : 1u;
-        if (n_gatherers == 1) {
-            gather(0, finished_.size());
-        } else {
-            WorkerPool::instance().run(n_gatherers, [&](unsigned w) {
-                gather(finished_.size() * w / n_gatherers, finished_.size() * (w + 1) / n_gatherers);
-            });
-        }
-        OwnedGuard guard;
-        check(mdb_compress_chunks(ctx_, chunk_ts_data, chunk_values_data, offsets.data(), offsets.size() - 1,
-                                  bound, &guard.owned));
-        uint64_t row = 0;
-        const uint64_t total = guard.owned->seg.n;
-        uint32_t chunk = 0;
-        for (size_t b = 0; b < finished_.size(); b++) {
-            for (size_t f : group) {
-                uint64_t first = row;
-                while (row < total && guard.owned->chunk_index[row] == chunk) row++;
-                result[b * n_fields + f] = record_batch_from_owned(
-                    guard.owned, first, row, metadata_.compressed_schema, finished_[b].tag_values,
-                    static_cast<int16_t>(metadata_.field_column_indices[f]));
-                chunk++;
-            }
+        std::vector<int64_t> order(ts.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return ts[x] < ts[y]; });
+        sorted[b] = std::make_unique<Sorted>();
+        sorted[b]->timestamps.resize(ts.size());
+        sorted[b]->values.assign(n_fields, std::vector<float>(ts.size()));
+        for (size_t j = 0; j < ts.size(); j++) {
+            const size_t i = static_cast<size_t>(order[j]);
+            sorted[b]->timestamps[j] = ts[i];
+            for (size_t f = 0; f < n_fields; f++) sorted[b]->values[f][j] = finished_[b].values[f][i];
         }
     }
+    std::vector<SeriesChunk> chunks;
+    chunks.reserve(finished_.size() * n_fields);
+    for (size_t b = 0; b < finished_.size(); b++) {
+        for (size_t f = 0; f < n_fields; f++) {
+            const size_t field_index = metadata_.field_column_indices[f];
+            const std::vector<int64_t> &ts = sorted[b] ? sorted[b]->timestamps : finished_[b].timestamps;
+            const std::vector<float> &values = sorted[b] ? sorted[b]->values[f] : finished_[b].values[f];
+            chunks.push_back({ts.data(), values.data(), ts.size(), metadata_.error_bounds[field_index].c,
+                              &finished_[b].tag_values, static_cast<int16_t>(field_index)});
+        }
+    }
+    std::vector<RecordBatch> result = compress_chunks(ctx_, chunks, metadata_.compressed_schema);
     finished_.clear();
     return result;
 }

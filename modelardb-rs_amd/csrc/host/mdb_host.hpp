@@ -212,30 +212,28 @@ class GridStream : public SegmentStream { // grid_exec.rs:213-437
     ~GridStream();
 
   private:
-    // One batch of segments on its way through the GPU: mdb_grid_batch_owned runs on a thread of its
-    // own and on one of two contexts, so that the copy of one batch's data points to the host overlaps
-    // the upload and the kernels of the next (the reference grids a batch when it is polled for,
-    // grid_exec.rs:402-412; the stream returns the same rows in the same order).
-    struct InFlight {
-        std::shared_ptr<RecordBatch> batch;
-        std::future<mdb_grid_result *> result;
+    // One submit to the library on its way through the GPU (mdb_grid_submit): the input batches it was made from
+    // (one, or several that the input had ready - they become one launch) and the ticket to wait on. The library
+    // reconstructs it on a worker thread and on one of two contexts, so that the copy of one submit's data points
+    // to the host overlaps the upload and the kernels of the next (the reference grids a batch when it is polled
+    // for, grid_exec.rs:402-412; the stream returns the same rows in the same order). This is, call for call,
+    // what rust/patches/0001-grid_exec.patch does with rust/modelardb_hip's GridTicket.
+    struct Ticket {
+        std::vector<std::shared_ptr<RecordBatch>> batches;
+        mdb_grid_ticket *raw = nullptr;
     };
-    InFlight start_grid(RecordBatch batch);
-    void grid_and_append_to_leftovers_in_current_batch(InFlight flight); // :261-391
+    // Polls the input while it has batches ready and the submit is below the stream's target size, and submits
+    // what it got: ReadySome with a ticket, ReadyNone when the input has ended, Pending when it has nothing yet.
+    PollState poll_input_and_submit(std::optional<Ticket> *out);
+    void wait_and_append_to_leftovers_in_current_batch(Ticket ticket); // :261-391
     mdb_ctx *ctx_;
-    // Blocks of tag views (16 bytes per created row and tag column), recycled: a fresh 90 MB allocation per
-    // batch is 22 000 page faults, ten times what filling it costs.
-    struct TagBlock {
-        std::unique_ptr<mdb_view16[]> views;
-        size_t capacity = 0;
-    };
-    std::vector<std::shared_ptr<TagBlock>> tag_blocks_;
-    std::shared_ptr<TagBlock> take_tag_block(size_t rows);
-    mdb_ctx *second_ctx_ = nullptr; // created with the first batch that is started ahead
-    unsigned started_ = 0;
-    std::optional<InFlight> ahead_;
+    std::optional<Ticket> ahead_;
     bool input_finished_ = false;
     bool prefetch_ = true;
+    // Segments per submit: the input hands over 8 192-row batches whatever they decompress to; the stream asks
+    // for about 16 M data points per launch and learns the points per segment from the results it has seen.
+    uint64_t seen_segments_ = 0, seen_points_ = 0;
+    size_t coalesce_segments_ = 0; // (MDB_HOST_GRID_COALESCE_SEGMENTS: a fixed number, 0: learned)
     std::vector<Field> schema_;
     std::optional<TimestampPredicate> maybe_predicate_;
     std::unique_ptr<SegmentStream> input_;

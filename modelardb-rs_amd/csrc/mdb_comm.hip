@@ -54,7 +54,8 @@ static const Rccl *rccl() {
             if (handle) break;
         }
         if (!handle) {
-            r->error = std::string("librccl.so.1 cannot be loaded: ") + dlerror();
+            const char *why = dlerror(); // (may be NULL)
+            r->error = std::string("librccl.so.1 cannot be loaded: ") + (why ? why : "unknown reason");
             return r;
         }
         auto bind = [&](auto &slot, const char *symbol) {

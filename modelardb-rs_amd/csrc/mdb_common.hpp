@@ -16,17 +16,9 @@
 #include <vector>
 
 #include "../../include/mdb.h"
+#include "mdb_host_side.hpp"
 
 namespace mdb {
-
-// ---- errors (capi.rs:58-80 convention: 0 ok, 1 failure + thread-local message) -----------------
-
-extern thread_local std::string g_last_error;
-
-inline int fail(const std::string &message) {
-    g_last_error = message;
-    return 1;
-}
 
 #define MDB_HIP_CHECK(expr)                                                                        \
     do {                                                                                           \
@@ -83,23 +75,12 @@ enum ScratchSlot {
     SCRATCH_SLOT_COUNT
 };
 
-// Recycled page-locked blocks behind mdb_grid_result (hipHostMalloc is slow). Shared between the
-// context and the results it handed out, so a result may be freed after mdb_close().
-struct PinnedPool {
-    std::mutex mutex;
-    bool closed = false;
-    std::vector<std::pair<void *, uint64_t>> blocks;
-    int take(uint64_t bytes, void **out, uint64_t *capacity);
-    void give(void *block, uint64_t capacity);
-    void trim();  // frees the recycled blocks
-    void close();
-};
-
 struct CloneCache {
     std::mutex mutex;
     std::vector<mdb_ctx *> idle;
     bool origin_closed = false;
 };
+
 
 } // namespace mdb
 
@@ -122,6 +103,7 @@ struct mdb_ctx {
     // stream costs 2-6 ms to make and as much to destroy, an operator asks for its second context per query).
     std::shared_ptr<mdb::CloneCache> clones; // shared by a context and its clones
     bool is_clone = false;
+    mdb::GridPipeline *pipeline = nullptr; // made by the first mdb_grid_submit, ended by mdb_close
 
     // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).
     void *comm = nullptr;
@@ -157,7 +139,9 @@ struct CallGuard {
 };
 // mdb_segments_upload with ctx->mutex held; transient = into the context's upload scratch (mdb_ctx.hip).
 int upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool transient, mdb_segments_owned **out);
-int profile_collect(mdb_ctx *ctx);
+// The same for several host batches that become one device batch, rows in the order of the list.
+int upload_segment_list_locked(mdb_ctx *ctx, const mdb_segments *const *hosts, uint32_t n_hosts, bool transient,
+                               mdb_segments_owned **out);
 
 // Brackets a launch with events when profiling is on.
 struct LaunchTimer {

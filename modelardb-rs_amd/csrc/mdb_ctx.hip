@@ -125,6 +125,24 @@ void PinnedPool::close() {
     blocks.clear();
 }
 
+GridPipeline *ctx_pipeline(mdb_ctx *ctx) {
+    CallGuard lock(ctx);
+    return ctx->pipeline;
+}
+
+GridPipeline *ctx_pipeline_install(mdb_ctx *ctx, GridPipeline *fresh) {
+    CallGuard lock(ctx);
+    if (!ctx->pipeline) ctx->pipeline = fresh;
+    return ctx->pipeline;
+}
+
+GridPipeline *ctx_pipeline_detach(mdb_ctx *ctx) {
+    CallGuard lock(ctx);
+    GridPipeline *pipeline = ctx->pipeline;
+    ctx->pipeline = nullptr;
+    return pipeline;
+}
+
 LaunchTimer::LaunchTimer(mdb_ctx *c, const char *n) : ctx(c), name(n) {
     if (!ctx->profiling) return;
     auto take = [&]() {
@@ -272,16 +290,31 @@ int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
 
 int mdb_close(mdb_ctx *ctx) {
     if (!ctx) return 0;
+    pipeline_close(ctx); // the workers of mdb_grid_submit finish what is queued; their second context is closed
     if (ctx->clones) {
         std::vector<mdb_ctx *> orphans;
         {
-            std::lock_guard<std::mutex> lock(ctx->clones->mutex);
-            if (ctx->is_clone && !ctx->clones->origin_closed && ctx->clones->idle.size() < 4) {
-                // kept for the next mdb_clone of the context it was made from (idle: nothing of it is in use)
+            std::unique_lock<std::mutex> lock(ctx->clones->mutex);
+            // Kept for the next mdb_clone of the context it was made from - but only as what a fresh clone is:
+            // its own stream (a caller's stream set with mdb_set_stream may be destroyed behind our back), no
+            // communicator (the next owner's mdb_comm_init would find one), no timings of the previous owner.
+            if (ctx->is_clone && !ctx->clones->origin_closed && ctx->clones->idle.size() < 4 && ctx->own_stream) {
+                lock.unlock();
+                (void)mdb_comm_close(ctx);
                 (void)hipSetDevice(ctx->device);
                 (void)hipStreamSynchronize(ctx->stream);
-                ctx->clones->idle.push_back(ctx);
-                return 0;
+                for (auto &p : ctx->pending_events) {
+                    ctx->event_pool.push_back(p.start);
+                    ctx->event_pool.push_back(p.stop);
+                }
+                ctx->pending_events.clear();
+                ctx->kernel_times.clear();
+                ctx->profiling = false;
+                lock.lock();
+                if (!ctx->clones->origin_closed && ctx->clones->idle.size() < 4) {
+                    ctx->clones->idle.push_back(ctx);
+                    return 0;
+                }
             }
             if (!ctx->is_clone) {
                 ctx->clones->origin_closed = true;
@@ -427,18 +460,37 @@ int mdb_segments_upload(mdb_ctx *ctx, const mdb_segments *host, mdb_segments_own
 // small batch, and hipFree waits for the WHOLE device: with it, two contexts could never overlap the copy
 // of one batch with the kernels of the next (36 GB/s instead of the 56 GB/s the link gives).
 int mdb::upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool transient, mdb_segments_owned **out) {
-    const uint64_t n = host->n;
-    const mdb_binview_col *cols[3] = {&host->timestamps, &host->values, &host->residuals};
-    for (int c = 0; c < 3; c++) {
-        if (cols[c]->n_buffers < 0) return fail("n_buffers must not be negative.");
-        if (cols[c]->n_buffers > 0 && (!cols[c]->buffers || !cols[c]->buffer_sizes))
-            return fail("buffers and buffer_sizes must be given when n_buffers > 0.");
-        if (n > 0 && !cols[c]->views) return fail("views must not be NULL.");
-        if (validate_views_host(*cols[c], n)) return 1;
+    return upload_segment_list_locked(ctx, &host, 1, transient, out);
+}
+
+// Several host batches as ONE device batch, rows in the order of the list (what a GridStream that has been
+// handed several 8 192-row RecordBatches by its input gives to one launch): the primitive
+// columns and the views are laid end to end, every batch's data buffers follow those of the batches before it,
+// and the out-of-line views of the later batches are moved onto their buffers' new indices while they sit in
+// the staging block.
+int mdb::upload_segment_list_locked(mdb_ctx *ctx, const mdb_segments *const *hosts, uint32_t n_hosts, bool transient,
+                                    mdb_segments_owned **out) {
+    uint64_t n = 0;
+    int64_t n_buffers_total[3] = {0, 0, 0};
+    for (uint32_t h = 0; h < n_hosts; h++) {
+        const mdb_segments *host = hosts[h];
+        if (!host) return fail("A batch of the list is NULL.");
+        const mdb_binview_col *cols[3] = {&host->timestamps, &host->values, &host->residuals};
+        for (int c = 0; c < 3; c++) {
+            if (cols[c]->n_buffers < 0) return fail("n_buffers must not be negative.");
+            if (cols[c]->n_buffers > 0 && (!cols[c]->buffers || !cols[c]->buffer_sizes))
+                return fail("buffers and buffer_sizes must be given when n_buffers > 0.");
+            if (host->n > 0 && !cols[c]->views) return fail("views must not be NULL.");
+            if (validate_views_host(*cols[c], host->n)) return 1;
+            n_buffers_total[c] += cols[c]->n_buffers;
+        }
+        if (host->n > 0 && (!host->model_type_id || !host->start_time || !host->end_time || !host->min_value ||
+                            !host->max_value))
+            return fail("The primitive columns must not be NULL.");
+        n += host->n;
     }
-    if (n > 0 && (!host->model_type_id || !host->start_time || !host->end_time || !host->min_value ||
-                  !host->max_value))
-        return fail("The primitive columns must not be NULL.");
+    for (int c = 0; c < 3; c++)
+        if (n_buffers_total[c] > 0x7fffffff) return fail("Too many data buffers in one column.");
 
     struct Piece {
         const void *src;
@@ -447,26 +499,46 @@ int mdb::upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool tra
     };
     std::vector<Piece> pieces;
     uint64_t cursor = 0;
+    // One column of all batches end to end: `width` bytes per row.
+    auto add_column = [&](auto member, uint64_t width) {
+        const uint64_t offset = cursor;
+        uint64_t at = cursor;
+        for (uint32_t h = 0; h < n_hosts; h++) {
+            pieces.push_back({member(hosts[h]), width * hosts[h]->n, at});
+            at += width * hosts[h]->n;
+        }
+        cursor = align_up(at, 256);
+        return offset;
+    };
     auto add = [&](const void *src, uint64_t bytes) {
         uint64_t offset = cursor;
         pieces.push_back({src, bytes, offset});
         cursor = align_up(cursor + bytes, 256);
         return offset;
     };
-    uint64_t off_type = add(host->model_type_id, n);
-    uint64_t off_start = add(host->start_time, 8 * n);
-    uint64_t off_end = add(host->end_time, 8 * n);
-    uint64_t off_min = add(host->min_value, 4 * n);
-    uint64_t off_max = add(host->max_value, 4 * n);
+    auto column_of = [](const mdb_segments *host, int c) {
+        return c == 0 ? &host->timestamps : (c == 1 ? &host->values : &host->residuals);
+    };
+    uint64_t off_type = add_column([](const mdb_segments *s) { return (const void *)s->model_type_id; }, 1);
+    uint64_t off_start = add_column([](const mdb_segments *s) { return (const void *)s->start_time; }, 8);
+    uint64_t off_end = add_column([](const mdb_segments *s) { return (const void *)s->end_time; }, 8);
+    uint64_t off_min = add_column([](const mdb_segments *s) { return (const void *)s->min_value; }, 4);
+    uint64_t off_max = add_column([](const mdb_segments *s) { return (const void *)s->max_value; }, 4);
     uint64_t off_views[3];
     std::vector<uint64_t> off_buffers[3];
+    std::vector<int64_t> all_sizes[3];
     uint64_t off_tables[3];
     for (int c = 0; c < 3; c++) {
-        off_views[c] = add(cols[c]->views, 16 * n);
-        for (int b = 0; b < cols[c]->n_buffers; b++)
-            off_buffers[c].push_back(add(cols[c]->buffers[b], (uint64_t)cols[c]->buffer_sizes[b]));
+        off_views[c] = add_column([&](const mdb_segments *s) { return (const void *)column_of(s, c)->views; }, 16);
+        for (uint32_t h = 0; h < n_hosts; h++) {
+            const mdb_binview_col *col = column_of(hosts[h], c);
+            for (int b = 0; b < col->n_buffers; b++) {
+                off_buffers[c].push_back(add(col->buffers[b], (uint64_t)col->buffer_sizes[b]));
+                all_sizes[c].push_back(col->buffer_sizes[b]);
+            }
+        }
     }
-    for (int c = 0; c < 3; c++) off_tables[c] = add(nullptr, 8 * (uint64_t)(cols[c]->n_buffers + 1));
+    for (int c = 0; c < 3; c++) off_tables[c] = add(nullptr, 8 * (uint64_t)(n_buffers_total[c] + 1));
     uint64_t total = cursor ? cursor : 256;
 
     OwnedSegments *owned = new OwnedSegments();
@@ -497,9 +569,21 @@ int mdb::upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool tra
         if (p.src && p.bytes) std::memcpy(stage + p.offset, p.src, p.bytes);
     for (int c = 0; c < 3; c++) {
         uint64_t *table = reinterpret_cast<uint64_t *>(stage + off_tables[c]);
-        for (int b = 0; b < cols[c]->n_buffers; b++)
-            table[b] = reinterpret_cast<uint64_t>(dev + off_buffers[c][b]);
-        table[cols[c]->n_buffers] = 0;
+        for (int64_t b = 0; b < n_buffers_total[c]; b++)
+            table[b] = reinterpret_cast<uint64_t>(dev + off_buffers[c][(size_t)b]);
+        table[n_buffers_total[c]] = 0;
+        // the later batches' views onto their buffers' places in the joint table
+        int32_t first_buffer = 0;
+        uint64_t first_row = 0;
+        for (uint32_t h = 0; h < n_hosts; h++) {
+            if (first_buffer > 0) {
+                mdb_view16 *views = reinterpret_cast<mdb_view16 *>(stage + off_views[c]) + first_row;
+                for (uint64_t i = 0; i < hosts[h]->n; i++)
+                    if (views[i].length > 12) views[i].u.ref.buffer_index += first_buffer;
+            }
+            first_buffer += column_of(hosts[h], c)->n_buffers;
+            first_row += hosts[h]->n;
+        }
     }
     if (hipMemcpyAsync(dev, stage, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -519,13 +603,13 @@ int mdb::upload_segments_locked(mdb_ctx *ctx, const mdb_segments *host, bool tra
     s.max_value = reinterpret_cast<const float *>(dev + off_max);
     mdb_binview_col *out_cols[3] = {&s.timestamps, &s.values, &s.residuals};
     for (int c = 0; c < 3; c++) {
-        owned->host_allocs[c].resize(8 * (size_t)(cols[c]->n_buffers + 1));
+        owned->host_allocs[c].resize(8 * (size_t)(n_buffers_total[c] + 1));
         int64_t *sizes = reinterpret_cast<int64_t *>(owned->host_allocs[c].data());
-        for (int b = 0; b < cols[c]->n_buffers; b++) sizes[b] = cols[c]->buffer_sizes[b];
+        for (int64_t b = 0; b < n_buffers_total[c]; b++) sizes[b] = all_sizes[c][(size_t)b];
         out_cols[c]->views = reinterpret_cast<const mdb_view16 *>(dev + off_views[c]);
         out_cols[c]->buffers = reinterpret_cast<const uint8_t *const *>(dev + off_tables[c]);
         out_cols[c]->buffer_sizes = sizes;
-        out_cols[c]->n_buffers = cols[c]->n_buffers;
+        out_cols[c]->n_buffers = (int32_t)n_buffers_total[c];
     }
     owned->c.error = nullptr;
     owned->c.chunk_index = nullptr;
@@ -576,6 +660,10 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
     // fits below 2 GiB (what most consumers prefer), else buffer by buffer as they are on the device.
     // host_allocs[8 + c] is the single buffer, or the first of several; further ones go to the end.
     std::vector<size_t> buffer_slots[3];
+    // (MDB_SEGMENTS_MERGE_LIMIT, read once per download: tests of the several-buffers path without 2 GiB of payloads)
+    uint64_t merge_limit = 0x7fffffffull;
+    if (const char *text = std::getenv("MDB_SEGMENTS_MERGE_LIMIT"))
+        merge_limit = std::min<uint64_t>(merge_limit, (uint64_t)std::max(0ll, std::atoll(text)));
     for (int c = 0; c < 3 && !rc; c++) {
         uint64_t total = 0;
         std::vector<uint64_t> base((size_t)cols[c]->n_buffers);
@@ -584,9 +672,6 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
             total += (uint64_t)cols[c]->buffer_sizes[b];
         }
         // (MDB_SEGMENTS_MERGE_LIMIT: tests of the several-buffers path without 2 GiB of payloads)
-        uint64_t merge_limit = 0x7fffffffull;
-        if (const char *text = std::getenv("MDB_SEGMENTS_MERGE_LIMIT"))
-            merge_limit = std::min<uint64_t>(merge_limit, (uint64_t)std::max(0ll, std::atoll(text)));
         const bool merged = total <= merge_limit;
         if (merged) {
             owned->host_allocs[8 + c].resize(total);
@@ -677,6 +762,9 @@ int mdb_segments_validate_dev(mdb_ctx *ctx, const mdb_segments *dev) {
         const int32_t n_buffers = cols[c]->n_buffers;
         if (n_buffers < 0) return fail("n_buffers must not be negative.");
         if (n_buffers > 0 && !cols[c]->buffer_sizes) return fail("buffer_sizes must be given when n_buffers > 0.");
+        if (!cols[c]->views) return fail("views must not be NULL.");
+        for (int32_t b = 0; b < n_buffers; b++)
+            if (cols[c]->buffer_sizes[b] < 0) return fail("Malformed BinaryView: negative buffer size.");
         if (scratch_reserve(ctx, SCRATCH_STAGE_DEV, 8 * (uint64_t)(n_buffers + 1), &p)) return 1;
         long long *sizes = static_cast<long long *>(p);
         if (n_buffers > 0)

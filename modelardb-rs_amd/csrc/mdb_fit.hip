@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace mdb {
@@ -2812,6 +2813,151 @@ int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
                                                 static_cast<const float *>(dev_values),
                                                 static_cast<const uint64_t *>(dev_offsets), n_chunks,
                                                 error_bound, 0, 0, nullptr, &dev);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (rc) return 1;
+    rc = mdb_segments_download(ctx, dev, out);
+    mdb_segments_free(dev);
+    return rc;
+}
+
+namespace {
+
+// One share of the gather of mdb_compress_chunk_list: a run of chunks whose values are copied into the staging
+// block and whose timestamp arrays (those seen for the first time) are looked at.
+struct GatherJob {
+    const mdb_chunk *chunks;
+    const uint64_t *offsets;       // n_chunks + 1
+    const uint64_t *same_ts_as;    // per chunk: the earlier chunk with the same timestamp array, or itself
+    float *stage_values;           // total points
+    int64_t *stage_ts;             // total points, or nullptr while only the values are gathered
+    long long *first, *interval;   // per chunk
+    unsigned char *irregular;      // per chunk
+    std::vector<std::pair<uint64_t, uint64_t>> shares; // [first chunk, last chunk)
+};
+
+void gather_share(unsigned index, void *arg) {
+    GatherJob &job = *static_cast<GatherJob *>(arg);
+    for (uint64_t c = job.shares[index].first; c < job.shares[index].second; c++) {
+        const mdb_chunk &chunk = job.chunks[c];
+        if (chunk.n == 0) continue;
+        if (job.stage_ts) {
+            std::memcpy(job.stage_ts + job.offsets[c], chunk.ts, 8 * chunk.n);
+            continue;
+        }
+        std::memcpy(job.stage_values + job.offsets[c], chunk.values, 4 * chunk.n);
+        if (job.same_ts_as[c] != c) continue; // (checked with the chunk that had this array first)
+        const int64_t *t = chunk.ts;
+        job.first[c] = t[0];
+        const int64_t step = chunk.n > 1 ? (int64_t)((uint64_t)t[1] - (uint64_t)t[0]) : 0;
+        job.interval[c] = step;
+        bool differs = false;
+        for (uint64_t j = 2; j < chunk.n; j++) differs |= (int64_t)((uint64_t)t[j] - (uint64_t)t[j - 1]) != step;
+        job.irregular[c] = differs ? 1 : 0;
+    }
+}
+
+} // namespace
+
+int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb_error_bound error_bound,
+                            mdb_segments_owned **out) {
+    if (!ctx || !out) return fail("ctx and out must not be NULL.");
+    if (n_chunks > 0 && !chunks) return fail("chunks must not be NULL.");
+    std::vector<uint64_t> offsets(n_chunks + 1, 0), same_ts_as(n_chunks);
+    {
+        std::unordered_map<const int64_t *, uint64_t> seen;
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            if (chunks[c].n > 0 && (!chunks[c].ts || !chunks[c].values)) return fail("ts and values of a chunk must not be NULL.");
+            offsets[c + 1] = offsets[c] + chunks[c].n;
+            same_ts_as[c] = c;
+            if (chunks[c].n == 0) continue;
+            auto found = seen.emplace(chunks[c].ts, c);
+            if (!found.second && chunks[found.first->second].n == chunks[c].n) same_ts_as[c] = found.first->second;
+        }
+    }
+    const uint64_t total = offsets[n_chunks];
+    mdb_segments_owned *dev = nullptr;
+    int rc = 0;
+    {
+        mdb::CallGuard lock(ctx);
+        MDB_HIP_CHECK(hipSetDevice(ctx->device));
+        void *stage = nullptr, *dev_values = nullptr, *dev_offsets = nullptr, *dev_ts = nullptr;
+        if (pinned_reserve(ctx, total * 4, &stage)) return 1;
+        if (scratch_reserve(ctx, SCRATCH_FIT_IN_VALUES, total * 4, &dev_values)) return 1;
+        if (scratch_reserve(ctx, SCRATCH_FIT_IN_OFFSETS, (n_chunks + 1) * 8, &dev_offsets)) return 1;
+        std::vector<long long> both(2 * n_chunks, 0);
+        std::vector<unsigned char> irregular(n_chunks, 0);
+        GatherJob job{chunks, offsets.data(), same_ts_as.data(), static_cast<float *>(stage), nullptr,
+                      both.data(), both.data() + n_chunks, irregular.data(), {}};
+        MDB_HIP_CHECK(hipMemcpyAsync(dev_offsets, offsets.data(), (n_chunks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        // The gather in slices of about 64 MB of values, each slice by all host threads, and behind every slice its
+        // copy to the device: the copy of one slice runs while the threads gather the next.
+        const uint64_t slice_points = 16u << 20;
+        const unsigned width = host_parallel_width();
+        auto gather = [&](auto copy_slice) {
+            uint64_t c = 0;
+            while (c < n_chunks && !rc) {
+                const uint64_t slice_first = c, slice_begin = offsets[c];
+                while (c < n_chunks && offsets[c + 1] - slice_begin <= slice_points) c++;
+                if (c == slice_first) c++; // (one chunk longer than a slice)
+                const uint64_t slice_end = offsets[c], slice_chunks = c - slice_first;
+                job.shares.clear();
+                const unsigned n_shares = (unsigned)std::min<uint64_t>(
+                    std::min<uint64_t>(width, slice_chunks), std::max<uint64_t>(1, (slice_end - slice_begin) >> 16));
+                uint64_t next = slice_first;
+                for (unsigned w = 0; w < n_shares; w++) {
+                    const uint64_t target = slice_begin + (slice_end - slice_begin) * (w + 1) / n_shares;
+                    uint64_t last = next;
+                    while (last < c && (offsets[last + 1] <= target || w + 1 == n_shares)) last++;
+                    job.shares.push_back({next, last});
+                    next = last;
+                }
+                host_parallel((unsigned)job.shares.size(), gather_share, &job);
+                copy_slice(slice_begin, slice_end);
+            }
+        };
+        gather([&](uint64_t begin, uint64_t end) {
+            if (end > begin && hipMemcpyAsync(static_cast<float *>(dev_values) + begin, job.stage_values + begin, 4 * (end - begin),
+                                              hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy host to device failed.");
+        });
+        bool regular = total > 0;
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            const uint64_t source = same_ts_as[c];
+            if (source != c) {
+                both[c] = both[source];
+                both[n_chunks + c] = both[n_chunks + source];
+            }
+            regular = regular && !irregular[source];
+        }
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+        if (!rc && regular) {
+            void *dev_first = nullptr;
+            if (scratch_reserve(ctx, SCRATCH_FIT_IN_TS, 16 * n_chunks, &dev_first)) return 1;
+            if (hipMemcpyAsync(dev_first, both.data(), 16 * n_chunks, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = fail("hipMemcpy host to device failed.");
+            if (!rc)
+                rc = compress_chunks_dev_locked(ctx, nullptr, static_cast<const float *>(dev_values),
+                                                static_cast<const uint64_t *>(dev_offsets), n_chunks, error_bound, 0, 0,
+                                                nullptr, &dev, static_cast<const long long *>(dev_first),
+                                                static_cast<const long long *>(dev_first) + n_chunks);
+        } else if (!rc) {
+            // Some chunk is not equally spaced: the timestamps cross too (the staging block is free again).
+            if (pinned_reserve(ctx, total * 8, &stage)) return 1;
+            if (scratch_reserve(ctx, SCRATCH_FIT_IN_TS, total * 8, &dev_ts)) return 1;
+            job.stage_ts = static_cast<int64_t *>(stage);
+            gather([&](uint64_t begin, uint64_t end) {
+                if (end > begin && hipMemcpyAsync(static_cast<int64_t *>(dev_ts) + begin, job.stage_ts + begin, 8 * (end - begin),
+                                                  hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    rc = fail("hipMemcpy host to device failed.");
+            });
+            if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+            if (!rc)
+                rc = compress_chunks_dev_locked(ctx, static_cast<const int64_t *>(dev_ts), static_cast<const float *>(dev_values),
+                                                static_cast<const uint64_t *>(dev_offsets), n_chunks, error_bound, 0, 0,
+                                                nullptr, &dev);
         }
         (void)hipStreamSynchronize(ctx->stream);
     }

@@ -2951,20 +2951,21 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
     return rc;
 }
 
-struct OwnedGridResult {
-    mdb_grid_result c;
-    std::shared_ptr<PinnedPool> pool;
-    void *block;
-    uint64_t capacity;
-};
+} // namespace
 
-int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, bool values_only,
-                          uint64_t reserve_front, mdb_grid_result **out) {
-    if (!ctx || !in || !out) return fail("ctx, in and out must not be NULL.");
+// One or several host batches (rows in the order of the list) reconstructed by one launch into a page-locked
+// block of the device's pool: the body of mdb_grid_batch_owned and of the jobs behind mdb_grid_submit.
+int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uint32_t n_ins, TimeRangeArg range_arg,
+                               bool values_only, uint64_t reserve_front, mdb_grid_result **out) {
+    if (!ctx || !ins || !out || n_ins == 0) return fail("ctx, in and out must not be NULL.");
+    for (uint32_t k = 0; k < n_ins; k++)
+        if (!ins[k]) return fail("ctx, in and out must not be NULL.");
+    const TimeRange range{range_arg.lo, range_arg.hi, range_arg.enabled};
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
-    if (upload_segments_locked(ctx, in, true, &dev)) return 1;
+    if (upload_segment_list_locked(ctx, ins, n_ins, true, &dev)) return 1;
+    const uint64_t n_segments = dev->seg.n;
     int rc = 0;
     OwnedGridResult *result = nullptr;
     {
@@ -2975,7 +2976,7 @@ int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
         const uint64_t front = align_up(reserve_front, 4); // keeps the 16-byte store alignment
         const uint64_t ts_bytes = values_only ? 0 : align_up((front + total) * 8, 256);
         const uint64_t val_bytes = align_up((front + total) * 4, 256);
-        const uint64_t rows_bytes = align_up(in->n * 4, 256);
+        const uint64_t rows_bytes = align_up(n_segments * 4, 256);
         void *stage = nullptr;
         if (!rc) rc = scratch_reserve(ctx, SCRATCH_STAGE_DEV, ts_bytes + val_bytes + rows_bytes, &stage);
         uint8_t *base = static_cast<uint8_t *>(stage);
@@ -3003,7 +3004,7 @@ int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
                 result->c.values = reinterpret_cast<float *>(host + ts_bytes) + front;
                 result->c.rows_per_segment = reinterpret_cast<uint32_t *>(host + ts_bytes + val_bytes);
                 result->c.n = total;
-                result->c.n_segments = in->n;
+                result->c.n_segments = n_segments;
                 result->c.reserved_front = front;
                 std::memset(&result->c.metrics, 0, sizeof(result->c.metrics));
                 fill_metrics(plan.host_header, &result->c.metrics);
@@ -3018,6 +3019,14 @@ int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
     if (rc) return 1;
     *out = &result->c;
     return 0;
+}
+
+namespace {
+
+int grid_batch_owned_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, bool values_only,
+                          uint64_t reserve_front, mdb_grid_result **out) {
+    return mdb::grid_batch_owned_list(ctx, &in, 1, TimeRangeArg{range.lo, range.hi, range.enabled}, values_only,
+                                      reserve_front, out);
 }
 
 } // namespace
@@ -3035,6 +3044,7 @@ void mdb_grid_result_free(mdb_grid_result *result) {
     OwnedGridResult *owned = static_cast<OwnedGridResult *>(result->priv_);
     if (!owned) return;
     owned->pool->give(owned->block, owned->capacity);
+    for (auto &tags : owned->tag_blocks) host_block_give(tags.first, tags.second);
     delete owned;
 }
 

@@ -1,0 +1,73 @@
+// mdb_host_side.hpp - the part of libmdb_hip.so's internals that has no device code and no HIP type in it:
+// errors, the pools of host blocks, the bookkeeping behind mdb_grid_result, and what mdb_pipeline.cpp (the
+// threads behind mdb_grid_submit) needs from the rest of the library. mdb_pipeline.cpp includes only this, so
+// it also builds with g++ under the CPU sanitizers against a stand-in for the kernels (tests/stub).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mdb.h"
+
+namespace mdb {
+
+// ---- errors (capi.rs:58-80 convention: 0 ok, 1 failure + thread-local message) -----------------
+
+extern thread_local std::string g_last_error;
+
+inline int fail(const std::string &message) {
+    g_last_error = message;
+    return 1;
+}
+
+// Recycled page-locked blocks behind mdb_grid_result (hipHostMalloc is slow). Shared between the
+// context and the results it handed out, so a result may be freed after mdb_close().
+struct PinnedPool {
+    std::mutex mutex;
+    bool closed = false;
+    std::vector<std::pair<void *, uint64_t>> blocks;
+    int take(uint64_t bytes, void **out, uint64_t *capacity);
+    void give(void *block, uint64_t capacity);
+    void trim();  // frees the recycled blocks
+    void close();
+};
+
+struct GridPipeline; // the workers behind mdb_grid_submit (mdb_pipeline.cpp)
+// The pipeline of a context, read and installed under the context's lock (mdb_ctx.hip; tests/stub).
+// install: makes `fresh` the context's pipeline unless it has one already; returns the one it has afterwards.
+GridPipeline *ctx_pipeline(mdb_ctx *ctx);
+GridPipeline *ctx_pipeline_install(mdb_ctx *ctx, GridPipeline *fresh);
+GridPipeline *ctx_pipeline_detach(mdb_ctx *ctx);
+
+// Owner bookkeeping behind mdb_grid_result::priv_.
+struct OwnedGridResult {
+    mdb_grid_result c;
+    std::shared_ptr<PinnedPool> pool;
+    void *block = nullptr;
+    uint64_t capacity = 0;
+    // replicated tag views of mdb_grid_submit, one block per tag column: (block, capacity in bytes)
+    std::vector<std::pair<void *, uint64_t>> tag_blocks;
+    std::vector<mdb_view16 *> tag_views; // per column: the view of the first reconstructed row
+};
+struct TimeRangeArg { // (TimeRange of mdb_segment_dev.hpp, for translation units that have no device code)
+    int64_t lo;
+    int64_t hi;
+    int32_t enabled;
+};
+// mdb_grid.hip: one or several host batches through one launch into a page-locked block.
+int grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uint32_t n_ins, TimeRangeArg range,
+                          bool values_only, uint64_t reserve_front, mdb_grid_result **out);
+// mdb_pipeline.hip: recycled ordinary host blocks (64-byte aligned) for the replicated tag views - a fresh 90 MB
+// allocation per batch and tag column is 22 000 page faults - and the pool of host threads that fills them.
+int host_block_take(uint64_t bytes, void **out, uint64_t *capacity);
+void host_block_give(void *block, uint64_t capacity);
+void host_parallel(unsigned n_shares, void (*share)(unsigned index, void *arg), void *arg);
+unsigned host_parallel_width();
+void pipeline_close(mdb_ctx *ctx);
+int profile_collect(mdb_ctx *ctx);
+
+} // namespace mdb

@@ -1,8 +1,15 @@
-//! Safe wrappers over `libmdb_hip.so` for the three call sites of ModelarDB-RS that this library
-//! replaces (see `rust/patches/`): `GridStream::grid_and_append_to_leftovers_in_current_batch`
-//! (crates/modelardb_storage/src/query/grid_exec.rs:261-391), the `Model*Accumulator::update_batch`
-//! methods (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:345-587) and
-//! `try_compress_univariate_time_series` (crates/modelardb_compression/src/compression.rs:191-275).
+//! Safe wrappers over `libmdb_hip.so` for the call sites of ModelarDB-RS that this library replaces
+//! (see `rust/patches/`): `GridStream::poll_next` / `grid_and_append_to_leftovers_in_current_batch`
+//! (crates/modelardb_storage/src/query/grid_exec.rs:261-429) through [`Context::grid_submit`] and
+//! [`GridTicket::wait`]; the `Model*Accumulator::update_batch` methods
+//! (crates/modelardb_storage/src/optimizer/model_simple_aggregates.rs:345-587) through
+//! [`Context::aggregate`]; `try_compress_multivariate_time_series` and
+//! `try_split_and_compress_univariate_time_series` (crates/modelardb_compression/src/compression.rs:42-179)
+//! and `UncompressedDataManager::process_compressor_messages`
+//! (crates/modelardb_server/src/storage/uncompressed_data_manager.rs:505-596) through
+//! [`Context::compress_chunks`]: every series and field of a batch, or every finished ingest buffer of a
+//! drained channel, in ONE launch per error bound (the fitter needs more than 10^4 chunks per launch to
+//! beat one CPU thread; one launch per series does not).
 //!
 //! Every decision lives behind the C ABI; this crate only converts between Arrow arrays and the
 //! pointer structs of `include/mdb_format.h`, owns the handles, and turns the `0 / 1 + last error`
@@ -17,8 +24,7 @@ use std::ptr::{self, NonNull};
 use std::sync::Arc;
 
 use arrow::array::{
-    Array, ArrayRef, BinaryViewArray, BinaryViewBuilder, Float32Array, Int8Array, Int16Array,
-    StringViewArray,
+    Array, ArrayRef, BinaryViewArray, Float32Array, Int8Array, Int16Array, StringViewArray,
 };
 use arrow::buffer::{Buffer, ScalarBuffer};
 use arrow::datatypes::Schema;
@@ -194,6 +200,28 @@ impl<'a> SegmentsView<'a> {
         };
         Self { raw, _tables: tables, _arrays: std::marker::PhantomData }
     }
+
+    /// From a batch whose first eight columns follow `QUERY_COMPRESSED_SCHEMA` (what `GridStream` and
+    /// the accumulators are handed; tag columns may follow).
+    pub fn from_record_batch(batch: &'a RecordBatch) -> Self {
+        fn column<'b, T: 'static>(batch: &'b RecordBatch, index: usize) -> &'b T {
+            batch
+                .column(index)
+                .as_any()
+                .downcast_ref::<T>()
+                .expect("The batch should follow QUERY_COMPRESSED_SCHEMA.")
+        }
+        Self::new(
+            column::<Int8Array>(batch, 0),
+            column::<TimestampArray>(batch, 1),
+            column::<TimestampArray>(batch, 2),
+            column::<BinaryViewArray>(batch, 3),
+            column::<ValueArray>(batch, 4),
+            column::<ValueArray>(batch, 5),
+            column::<BinaryViewArray>(batch, 6),
+            column::<BinaryViewArray>(batch, 7),
+        )
+    }
 }
 
 /// The block of page-locked memory `mdb_grid_batch_owned` reconstructed a batch into. Arrow buffers
@@ -301,6 +329,12 @@ impl Context {
         tag_values: &[String],
         field_column_index: i16,
     ) -> Result<RecordBatch> {
+        // compression.rs:202-206: the library reads `len` timestamps and `len` values.
+        if uncompressed_timestamps.len() != uncompressed_values.len() {
+            return Err(HipError(
+                "Uncompressed timestamps and uncompressed values have different lengths.".to_owned(),
+            ));
+        }
         let mut raw = ptr::null_mut();
         check(unsafe {
             sys::mdb_compress_series(
@@ -312,13 +346,321 @@ impl Context {
                 &mut raw,
             )
         })?;
-        let owned = OwnedSegments(NonNull::new(raw).expect("success with a null result"));
-        Ok(owned.to_record_batch(compressed_schema, tag_values, field_column_index))
+        let owned = Arc::new(OwnedSegments(NonNull::new(raw).expect("success with a null result")));
+        let rows = unsafe { owned.0.as_ref() }.seg.n as usize;
+        owned.to_record_batch(0, rows, compressed_schema, tag_values, field_column_index)
+    }
+
+    /// Compresses MANY univariate time series with one launch per distinct error bound and returns one
+    /// batch of segments per chunk, in the order of `chunks`. This is the form the fitter is fast in: a
+    /// launch fits one chunk per lane, so 10^4 chunks take about as long as one. The chunks are read where
+    /// they lie (slices of the caller's arrays); chunks that share a timestamp array - the fields of one
+    /// series - have it looked at once.
+    pub fn compress_chunks(&self, chunks: &[SeriesChunk]) -> Result<Vec<RecordBatch>> {
+        let mut compressed: Vec<Option<RecordBatch>> = vec![None; chunks.len()];
+        let mut done = vec![false; chunks.len()];
+        for first in 0..chunks.len() {
+            if done[first] {
+                continue;
+            }
+            // Every chunk with this error bound (an error bound is an argument of the launch).
+            let bound: sys::mdb_error_bound = chunks[first].error_bound.into();
+            let mut group = Vec::new();
+            let mut list = Vec::new();
+            for index in first..chunks.len() {
+                let chunk = &chunks[index];
+                let chunk_bound: sys::mdb_error_bound = chunk.error_bound.into();
+                if done[index] || chunk_bound != bound {
+                    continue;
+                }
+                if chunk.timestamps.len() != chunk.values.len() {
+                    return Err(HipError(
+                        "Uncompressed timestamps and uncompressed values have different lengths.".to_owned(),
+                    ));
+                }
+                done[index] = true;
+                group.push(index);
+                list.push(sys::mdb_chunk {
+                    ts: chunk.timestamps.as_ptr(),
+                    values: chunk.values.as_ptr(),
+                    n: chunk.values.len() as u64,
+                });
+            }
+            let mut raw = ptr::null_mut();
+            check(unsafe { sys::mdb_compress_chunk_list(self.raw(), list.as_ptr(), list.len() as u64, bound, &mut raw) })?;
+            let owned = Arc::new(OwnedSegments(NonNull::new(raw).expect("success with a null result")));
+            // Segments come back grouped by chunk, in chunk order.
+            let (rows, chunk_index) = unsafe {
+                let c = owned.0.as_ref();
+                if c.seg.n > 0 && c.chunk_index.is_null() {
+                    return Err(HipError("The library returned segments without their chunk index.".to_owned()));
+                }
+                (c.seg.n as usize, std::slice::from_raw_parts(c.chunk_index, c.seg.n as usize))
+            };
+            let mut row = 0;
+            for (position, &index) in group.iter().enumerate() {
+                let begin = row;
+                while row < rows && chunk_index[row] as usize == position {
+                    row += 1;
+                }
+                let chunk = &chunks[index];
+                compressed[index] = Some(owned.to_record_batch(
+                    begin,
+                    row - begin,
+                    chunk.compressed_schema.clone(),
+                    chunk.tag_values,
+                    chunk.field_column_index,
+                )?);
+            }
+        }
+        Ok(compressed.into_iter().map(|batch| batch.expect("every chunk is in one group")).collect())
+    }
+
+    /// `try_split_and_compress_univariate_time_series` (compression.rs:147-179): the field columns of ONE
+    /// time series, which share its timestamps; `fields` = (values, error bound, field column index).
+    pub fn split_and_compress(
+        &self,
+        uncompressed_timestamps: &TimestampArray,
+        fields: &[(&ValueArray, ErrorBound, i16)],
+        compressed_schema: Arc<Schema>,
+        tag_values: &[String],
+    ) -> Result<Vec<RecordBatch>> {
+        let chunks: Vec<SeriesChunk> = fields
+            .iter()
+            .map(|(values, error_bound, field_column_index)| SeriesChunk {
+                timestamps: uncompressed_timestamps.values(),
+                values: values.values(),
+                error_bound: *error_bound,
+                compressed_schema: compressed_schema.clone(),
+                tag_values,
+                field_column_index: *field_column_index,
+            })
+            .collect();
+        self.compress_chunks(&chunks)
     }
 }
 
-/// Segments returned by the compressor (host memory), freed on drop.
+/// One univariate time series to compress: its sorted data points where they lie, and what the resulting
+/// batch of segments is labelled with (`CompressedSegmentBatchBuilder::new`, types.rs:444-470).
+pub struct SeriesChunk<'a> {
+    pub timestamps: &'a [i64],
+    pub values: &'a [f32],
+    pub error_bound: ErrorBound,
+    pub compressed_schema: Arc<Schema>,
+    pub tag_values: &'a [String],
+    pub field_column_index: i16,
+}
+
+/// Number of columns of `QUERY_COMPRESSED_SCHEMA` (crates/modelardb_types/src/schemas.rs:40-52); the tag
+/// columns of a batch of segments follow them.
+const QUERY_COMPRESSED_COLUMNS: usize = 9;
+
+/// An outstanding [`Context::grid_submit`]: the library reconstructs the batches on one of its worker
+/// threads while the caller goes on (polls its input for the next batches, hands out slices of the
+/// previous result). Keeps the input batches alive, since the library reads their Arrow buffers until
+/// [`GridTicket::wait`] returns. Dropping a ticket waits for the job and frees what it made.
+pub struct GridTicket {
+    raw: Option<NonNull<sys::mdb_grid_ticket>>,
+    batches: Vec<RecordBatch>,
+    n_tag_columns: usize,
+}
+
+// The ticket is only a handle; the library synchronises the job behind it.
+unsafe impl Send for GridTicket {}
+
+impl Drop for GridTicket {
+    fn drop(&mut self) {
+        if let Some(raw) = self.raw.take() {
+            unsafe { sys::mdb_grid_cancel(raw.as_ptr()) };
+        }
+    }
+}
+
+/// What [`GridTicket::wait`] returns: the columns of the new current batch of a `GridStream`.
+pub struct PipelinedGridOutput {
+    /// Leftovers first, then the reconstructed data points (grid_exec.rs:302-320).
+    pub timestamps: TimestampArray,
+    pub values: ValueArray,
+    /// One array per tag column: every segment's tag once per data point reconstructed from it
+    /// (grid_exec.rs:339-346), the leftovers' tags in front. The strings are not copied: long ones stay in
+    /// the data buffers of the input batches, which the arrays share.
+    pub tags: Vec<StringViewArray>,
+    pub metrics: GridMetrics,
+    /// Segments and data points of this submit (a stream sizes its next submit by them).
+    pub segments: u64,
+    pub rows_created: u64,
+}
+
+impl Context {
+    /// Starts the reconstruction of ALL segments of `batches` (each with the columns of
+    /// `QUERY_COMPRESSED_SCHEMA` followed by the table's tag columns) as one launch and returns at once.
+    /// `reserve_front`: room in front of the result for the rows the stream has left (`batch_size` is
+    /// enough: a stream only asks for more when it has fewer than that). Replaces, together with
+    /// [`GridTicket::wait`], grid_exec.rs:261-364 for several input batches at once.
+    pub fn grid_submit(
+        &self,
+        batches: Vec<RecordBatch>,
+        reserve_front: usize,
+        time_range: Option<(i64, i64)>,
+    ) -> Result<GridTicket> {
+        assert!(!batches.is_empty(), "grid_submit needs at least one batch.");
+        let n_tag_columns = batches[0].num_columns() - QUERY_COMPRESSED_COLUMNS;
+        let views: Vec<SegmentsView> = batches.iter().map(SegmentsView::from_record_batch).collect();
+        // Per batch: the views of its tag arrays, and where its data buffers start in the output tag
+        // column's list of buffers (buffer 0 is the ticket's own, for long leftover strings).
+        let mut tag_views: Vec<Vec<*const sys::mdb_view16>> = Vec::with_capacity(batches.len());
+        let mut tag_shifts: Vec<Vec<i32>> = Vec::with_capacity(batches.len());
+        let mut next_buffer = vec![1i32; n_tag_columns];
+        for batch in &batches {
+            assert_eq!(batch.num_columns(), QUERY_COMPRESSED_COLUMNS + n_tag_columns);
+            let mut views_of_batch = Vec::with_capacity(n_tag_columns);
+            let mut shifts_of_batch = Vec::with_capacity(n_tag_columns);
+            for tag_column in 0..n_tag_columns {
+                let tags = tag_array(batch, tag_column);
+                views_of_batch.push(tags.views().as_ptr().cast::<sys::mdb_view16>());
+                shifts_of_batch.push(next_buffer[tag_column]);
+                next_buffer[tag_column] += tags.data_buffers().len() as i32;
+            }
+            tag_views.push(views_of_batch);
+            tag_shifts.push(shifts_of_batch);
+        }
+        let inputs: Vec<sys::mdb_grid_input> = (0..batches.len())
+            .map(|index| sys::mdb_grid_input {
+                segments: views[index].raw,
+                tag_views: if n_tag_columns > 0 { tag_views[index].as_ptr() } else { ptr::null() },
+                tag_buffer_shift: if n_tag_columns > 0 { tag_shifts[index].as_ptr() } else { ptr::null() },
+            })
+            .collect();
+        let (flags, t_lo, t_hi) = match time_range {
+            Some((lo, hi)) => (sys::MDB_GRID_HAS_RANGE, lo, hi),
+            None => (0, 0, 0),
+        };
+        let request = sys::mdb_grid_request {
+            flags,
+            n_tag_columns: n_tag_columns as u32,
+            t_lo,
+            t_hi,
+            reserve_front: reserve_front as u64,
+        };
+        let mut raw = ptr::null_mut();
+        // The structs and the small tables above are copied by the library before this returns; the
+        // Arrow buffers behind them are kept alive by `batches` in the ticket.
+        check(unsafe {
+            sys::mdb_grid_submit(self.raw(), inputs.as_ptr(), inputs.len() as u32, &request, &mut raw)
+        })?;
+        drop(views);
+        Ok(GridTicket {
+            raw: Some(NonNull::new(raw).expect("success with a null ticket")),
+            batches,
+            n_tag_columns,
+        })
+    }
+}
+
+fn tag_array(batch: &RecordBatch, tag_column: usize) -> &StringViewArray {
+    batch
+        .column(QUERY_COMPRESSED_COLUMNS + tag_column)
+        .as_any()
+        .downcast_ref::<StringViewArray>()
+        .expect("The tag columns of a batch of segments should be StringViewArrays.")
+}
+
+impl GridTicket {
+    /// Segment rows this ticket was made from.
+    pub fn segments(&self) -> usize {
+        self.batches.iter().map(RecordBatch::num_rows).sum()
+    }
+
+    /// Blocks until the batches are reconstructed and returns the columns of the stream's new current
+    /// batch: `leftover_*` (the rows of the current batch that have not been handed out, fewer than the
+    /// `reserve_front` of the submit) in front, the new data points behind them. The arrays wrap memory of
+    /// the library (page-locked for the data points) without copying; the last of them to be dropped
+    /// returns it to the library's pools.
+    pub fn wait(
+        mut self,
+        leftover_timestamps: &[i64],
+        leftover_values: &[f32],
+        leftover_tags: &[StringViewArray],
+    ) -> Result<PipelinedGridOutput> {
+        assert_eq!(leftover_timestamps.len(), leftover_values.len());
+        assert_eq!(leftover_tags.len(), self.n_tag_columns);
+        let leftovers = leftover_timestamps.len();
+        let ticket = self.raw.take().expect("a ticket is waited for once");
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::mdb_grid_wait(ticket.as_ptr(), &mut raw) })?;
+        let block = Arc::new(GridBlock(NonNull::new(raw).expect("success with a null result")));
+        let result = unsafe { block.0.as_ref() };
+        assert!(leftovers as u64 <= result.reserved_front, "more leftovers than room was reserved for");
+        let total = leftovers + result.n as usize;
+        let (timestamps, values) = unsafe {
+            let first_timestamp = result.timestamps.sub(leftovers);
+            let first_value = result.values.sub(leftovers);
+            ptr::copy_nonoverlapping(leftover_timestamps.as_ptr(), first_timestamp, leftovers);
+            ptr::copy_nonoverlapping(leftover_values.as_ptr(), first_value, leftovers);
+            (
+                Buffer::from_custom_allocation(
+                    NonNull::new_unchecked(first_timestamp.cast::<u8>()),
+                    8 * total,
+                    block.clone(),
+                ),
+                Buffer::from_custom_allocation(NonNull::new_unchecked(first_value.cast::<u8>()), 4 * total, block.clone()),
+            )
+        };
+        let mut tags = Vec::with_capacity(self.n_tag_columns);
+        for (tag_column, leftover) in leftover_tags.iter().enumerate() {
+            assert_eq!(leftover.len(), leftovers);
+            // The leftovers' views in front of the replicated ones. Their long strings are copied into a
+            // buffer of the new array (buffer 0), so that old inputs can be dropped.
+            let mut leftover_payload: Vec<u8> = Vec::new();
+            let first_view = unsafe {
+                let replicated = sys::mdb_grid_result_tag_views(result, tag_column as u32);
+                assert!(!replicated.is_null(), "the result has fewer tag columns than the submit asked for");
+                let first_view = replicated.sub(leftovers);
+                for row in 0..leftovers {
+                    let value = leftover.value(row).as_bytes();
+                    let mut view = sys::mdb_view16 { length: value.len() as i32, u: [0; 12] };
+                    if value.len() <= 12 {
+                        view.u[..value.len()].copy_from_slice(value);
+                    } else {
+                        view.u[..4].copy_from_slice(&value[..4]);
+                        view.u[4..8].copy_from_slice(&0i32.to_le_bytes());
+                        view.u[8..12].copy_from_slice(&(leftover_payload.len() as i32).to_le_bytes());
+                        leftover_payload.extend_from_slice(value);
+                    }
+                    first_view.add(row).write(view);
+                }
+                first_view
+            };
+            let views = unsafe {
+                Buffer::from_custom_allocation(NonNull::new_unchecked(first_view.cast::<u8>()), 16 * total, block.clone())
+            };
+            // The same order `grid_submit` numbered them in (`tag_buffer_shift`).
+            let mut buffers = vec![Buffer::from_vec(leftover_payload)];
+            for batch in &self.batches {
+                buffers.extend(tag_array(batch, tag_column).data_buffers().iter().cloned());
+            }
+            // Every view is a copy of a view of a valid StringViewArray with its buffer index moved to where
+            // that buffer is in `buffers`, or was written above from a &str: valid by construction, and
+            // validating 16 bytes per data point again would cost more than reconstructing the point.
+            tags.push(unsafe { StringViewArray::new_unchecked(ScalarBuffer::new(views, 0, total), buffers, None) });
+        }
+        Ok(PipelinedGridOutput {
+            timestamps: TimestampArray::new(ScalarBuffer::new(timestamps, 0, total), None),
+            values: ValueArray::new(ScalarBuffer::new(values, 0, total), None),
+            tags,
+            metrics: result.metrics,
+            segments: result.n_segments,
+            rows_created: result.n,
+        })
+    }
+}
+
+/// Segments returned by the compressor (host memory), freed when the last array made from them is dropped.
 struct OwnedSegments(NonNull<sys::mdb_segments_owned>);
+
+unsafe impl Send for OwnedSegments {}
+unsafe impl Sync for OwnedSegments {}
+impl std::panic::RefUnwindSafe for OwnedSegments {}
 
 impl Drop for OwnedSegments {
     fn drop(&mut self) {
@@ -327,45 +669,59 @@ impl Drop for OwnedSegments {
 }
 
 impl OwnedSegments {
-    fn to_record_batch(&self, compressed_schema: Arc<Schema>, tag_values: &[String], field_column_index: i16) -> RecordBatch {
+    /// Rows `[first, first + length)` as a batch with `compressed_schema`
+    /// (`CompressedSegmentBatchBuilder::finish`, types.rs:492-516). The columns wrap the library's memory
+    /// (kept alive by `self`), so cutting one result into a batch per chunk copies nothing.
+    fn to_record_batch(
+        self: &Arc<Self>,
+        first: usize,
+        length: usize,
+        compressed_schema: Arc<Schema>,
+        tag_values: &[String],
+        field_column_index: i16,
+    ) -> Result<RecordBatch> {
         let owned = unsafe { self.0.as_ref() };
         let segments = &owned.seg;
         let n = segments.n as usize;
-        let primitive = |pointer: *const u8, bytes: usize| -> Buffer {
-            // Copied: the batch outlives the library's block (9 small columns per call).
-            Buffer::from(unsafe { std::slice::from_raw_parts(pointer, bytes) })
-        };
-        let binary_view = |column: &sys::mdb_binview_col| -> BinaryViewArray {
-            let mut builder = BinaryViewBuilder::with_capacity(n);
-            for row in 0..n {
-                let view = unsafe { &*column.views.add(row) };
-                let length = view.length as usize;
-                let bytes = if length <= 12 {
-                    &view.u[..length]
-                } else {
-                    let buffer_index = i32::from_le_bytes(view.u[4..8].try_into().unwrap()) as usize;
-                    let offset = i32::from_le_bytes(view.u[8..12].try_into().unwrap()) as usize;
-                    unsafe { std::slice::from_raw_parts((*column.buffers.add(buffer_index)).add(offset), length) }
-                };
-                builder.append_value(bytes);
+        assert!(first + length <= n);
+        if n > 0 && owned.error.is_null() {
+            return Err(HipError("The library returned segments without their error column.".to_owned()));
+        }
+        let wrap = |pointer: *const u8, bytes: usize| -> Buffer {
+            match NonNull::new(pointer.cast_mut()) {
+                Some(pointer) if bytes > 0 => unsafe { Buffer::from_custom_allocation(pointer, bytes, self.clone()) },
+                _ => Buffer::from(Vec::<u8>::new()),
             }
-            builder.finish()
+        };
+        let binary_view = |column: &sys::mdb_binview_col| -> Result<ArrayRef> {
+            if column.n_buffers < 0 || (column.n_buffers > 0 && (column.buffers.is_null() || column.buffer_sizes.is_null())) {
+                return Err(HipError("The library returned a malformed BinaryView column.".to_owned()));
+            }
+            let mut buffers = Vec::with_capacity(column.n_buffers as usize);
+            for index in 0..column.n_buffers as usize {
+                let (pointer, size) = unsafe { (*column.buffers.add(index), *column.buffer_sizes.add(index)) };
+                buffers.push(wrap(pointer, size as usize));
+            }
+            let views = ScalarBuffer::<u128>::new(wrap(column.views.cast(), 16 * n), 0, n);
+            // try_new checks every view against `buffers` (length, buffer index, offset, prefix).
+            let array = BinaryViewArray::try_new(views, buffers, None).map_err(|error| HipError(error.to_string()))?;
+            Ok(Arc::new(array.slice(first, length)))
         };
         let mut columns: Vec<ArrayRef> = Vec::with_capacity(compressed_schema.fields().len());
-        columns.push(Arc::new(Int8Array::new(ScalarBuffer::new(primitive(segments.model_type_id.cast(), n), 0, n), None)));
-        columns.push(Arc::new(TimestampArray::new(ScalarBuffer::new(primitive(segments.start_time.cast(), 8 * n), 0, n), None)));
-        columns.push(Arc::new(TimestampArray::new(ScalarBuffer::new(primitive(segments.end_time.cast(), 8 * n), 0, n), None)));
-        columns.push(Arc::new(binary_view(&segments.timestamps)));
-        columns.push(Arc::new(ValueArray::new(ScalarBuffer::new(primitive(segments.min_value.cast(), 4 * n), 0, n), None)));
-        columns.push(Arc::new(ValueArray::new(ScalarBuffer::new(primitive(segments.max_value.cast(), 4 * n), 0, n), None)));
-        columns.push(Arc::new(binary_view(&segments.values)));
-        columns.push(Arc::new(binary_view(&segments.residuals)));
-        columns.push(Arc::new(Float32Array::new(ScalarBuffer::new(primitive(owned.error.cast(), 4 * n), 0, n), None)));
-        columns.push(Arc::new(iter::repeat_n(field_column_index, n).collect::<Int16Array>()));
+        columns.push(Arc::new(Int8Array::new(ScalarBuffer::new(wrap(segments.model_type_id.cast(), n), first, length), None)));
+        columns.push(Arc::new(TimestampArray::new(ScalarBuffer::new(wrap(segments.start_time.cast(), 8 * n), first, length), None)));
+        columns.push(Arc::new(TimestampArray::new(ScalarBuffer::new(wrap(segments.end_time.cast(), 8 * n), first, length), None)));
+        columns.push(binary_view(&segments.timestamps)?);
+        columns.push(Arc::new(ValueArray::new(ScalarBuffer::new(wrap(segments.min_value.cast(), 4 * n), first, length), None)));
+        columns.push(Arc::new(ValueArray::new(ScalarBuffer::new(wrap(segments.max_value.cast(), 4 * n), first, length), None)));
+        columns.push(binary_view(&segments.values)?);
+        columns.push(binary_view(&segments.residuals)?);
+        columns.push(Arc::new(Float32Array::new(ScalarBuffer::new(wrap(owned.error.cast(), 4 * n), first, length), None)));
+        columns.push(Arc::new(iter::repeat_n(field_column_index, length).collect::<Int16Array>()));
         for tag_value in tag_values {
-            columns.push(Arc::new(iter::repeat_n(Some(tag_value), n).collect::<StringViewArray>()));
+            columns.push(Arc::new(iter::repeat_n(Some(tag_value), length).collect::<StringViewArray>()));
         }
-        RecordBatch::try_new(compressed_schema, columns).expect("the columns follow COMPRESSED_SCHEMA")
+        RecordBatch::try_new(compressed_schema, columns).map_err(|error| HipError(error.to_string()))
     }
 }
 

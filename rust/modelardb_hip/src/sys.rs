@@ -126,6 +126,42 @@ pub struct mdb_grid_result {
     pub priv_: *mut c_void,
 }
 
+/// One input `RecordBatch` of a pipelined grid call: its segment columns and the views of its tag arrays.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mdb_grid_input {
+    pub segments: mdb_segments,
+    /// `n_tag_columns` arrays of `segments.n` views (`StringViewArray::views()`), or null without tags.
+    pub tag_views: *const *const mdb_view16,
+    /// Per tag column: added to `buffer_index` of every view longer than 12 bytes; null means 0.
+    pub tag_buffer_shift: *const i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mdb_grid_request {
+    pub flags: u32,
+    pub n_tag_columns: u32,
+    pub t_lo: i64,
+    pub t_hi: i64,
+    pub reserve_front: u64,
+}
+
+/// An outstanding `mdb_grid_submit`.
+#[repr(C)]
+pub struct mdb_grid_ticket {
+    _private: [u8; 0],
+}
+
+/// One series chunk of `mdb_compress_chunk_list`: `n` sorted data points in two arrays of the caller.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mdb_chunk {
+    pub ts: *const i64,
+    pub values: *const f32,
+    pub n: u64,
+}
+
 #[link(name = "mdb_hip")]
 unsafe extern "C" {
     // ---- lifetime ----------------------------------------------------------------------------
@@ -174,6 +210,14 @@ unsafe extern "C" {
     pub fn mdb_grid_batch_owned(ctx: *mut mdb_ctx, input: *const mdb_segments, flags: u32, t_lo: i64, t_hi: i64,
                                 reserve_front: u64, out: *mut *mut mdb_grid_result) -> c_int;
     pub fn mdb_grid_result_free(result: *mut mdb_grid_result);
+    // (pipelined: several input batches per launch, two launches in flight, tag views replicated by the library)
+    pub fn mdb_grid_submit(ctx: *mut mdb_ctx, inputs: *const mdb_grid_input, n_inputs: u32,
+                           request: *const mdb_grid_request, ticket: *mut *mut mdb_grid_ticket) -> c_int;
+    pub fn mdb_grid_wait(ticket: *mut mdb_grid_ticket, out: *mut *mut mdb_grid_result) -> c_int;
+    pub fn mdb_grid_cancel(ticket: *mut mdb_grid_ticket);
+    pub fn mdb_grid_result_tag_views(result: *const mdb_grid_result, column: u32) -> *mut mdb_view16;
+    pub fn mdb_replicate_views(views: *const mdb_view16, rows_per_segment: *const u32, n_segments: u64,
+                               buffer_shift: i32, out: *mut mdb_view16, out_cap: u64) -> c_int;
 
     // ---- aggregates (replace Model*Accumulator::update_batch, model_simple_aggregates.rs:345-587) ----
     pub fn mdb_agg_batch(ctx: *mut mdb_ctx, input: *const mdb_segments, which_mask: u32,
@@ -191,6 +235,8 @@ unsafe extern "C" {
     pub fn mdb_compress_chunks(ctx: *mut mdb_ctx, ts: *const i64, values: *const f32, chunk_offsets: *const u64,
                                n_chunks: u64, error_bound: mdb_error_bound,
                                out: *mut *mut mdb_segments_owned) -> c_int;
+    pub fn mdb_compress_chunk_list(ctx: *mut mdb_ctx, chunks: *const mdb_chunk, n_chunks: u64,
+                                   error_bound: mdb_error_bound, out: *mut *mut mdb_segments_owned) -> c_int;
     pub fn mdb_compress_chunks_dev(ctx: *mut mdb_ctx, ts: *const i64, values: *const f32,
                                    chunk_offsets: *const u64, n_chunks: u64, error_bound: mdb_error_bound,
                                    regular_start: i64, regular_interval: i64, series_first_index: *const u64,
@@ -262,3 +308,14 @@ const _: () = assert!(offset_of!(mdb_grid_result, n_segments) == 32);
 const _: () = assert!(offset_of!(mdb_grid_result, reserved_front) == 40);
 const _: () = assert!(offset_of!(mdb_grid_result, metrics) == 48);
 const _: () = assert!(offset_of!(mdb_grid_result, priv_) == 128);
+const _: () = assert!(size_of::<mdb_grid_input>() == 160);
+const _: () = assert!(offset_of!(mdb_grid_input, tag_views) == 144);
+const _: () = assert!(offset_of!(mdb_grid_input, tag_buffer_shift) == 152);
+const _: () = assert!(size_of::<mdb_grid_request>() == 32);
+const _: () = assert!(offset_of!(mdb_grid_request, n_tag_columns) == 4);
+const _: () = assert!(offset_of!(mdb_grid_request, t_lo) == 8);
+const _: () = assert!(offset_of!(mdb_grid_request, t_hi) == 16);
+const _: () = assert!(offset_of!(mdb_grid_request, reserve_front) == 24);
+const _: () = assert!(size_of::<mdb_chunk>() == 24);
+const _: () = assert!(offset_of!(mdb_chunk, values) == 8);
+const _: () = assert!(offset_of!(mdb_chunk, n) == 16);

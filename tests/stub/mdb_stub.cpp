@@ -1,5 +1,6 @@
-// mdb_stub.cpp - TEST INFRASTRUCTURE, never part of the product: a stand-in for the nine entry points
-// of include/mdb.h that libmdb_host calls, so the host operators (mdb_host.cpp: GridStream with its
+// mdb_stub.cpp - TEST INFRASTRUCTURE, never part of the product: a stand-in for the KERNELS behind the entry
+// points of include/mdb.h that libmdb_host calls (the threads of mdb_grid_submit / mdb_grid_wait and the tag
+// replication are the product's own mdb_pipeline.cpp, built into the same object), so the host operators (mdb_host.cpp: GridStream with its
 // worker threads and aliasing of library-owned blocks, SortedJoinStream, the accumulators, the
 // uncompressed data manager) can be built with -fsanitize=address,undefined and -fsanitize=thread and
 // driven on a machine without a GPU (GPU AddressSanitizer is not available on the MI355X pool).
@@ -14,6 +15,7 @@
 // against this file compiled with -DMDB_STUB_RECORD: only then it links the CPU oracle
 // (oracle/libmdb_oracle.so), asks it for the answer of every call and appends (key, answer).
 #include "../../include/mdb.h"
+#include "../../modelardb-rs_amd/csrc/mdb_host_side.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -32,7 +34,11 @@
 
 struct mdb_ctx {
     uint32_t magic;
+    std::mutex mutex;
+    mdb::GridPipeline *pipeline = nullptr;
 };
+
+thread_local std::string mdb::g_last_error;
 
 namespace {
 
@@ -40,12 +46,7 @@ constexpr uint32_t CTX_MAGIC = 0x6d646273; // "mdbs"
 constexpr uint32_t RECORD_MAGIC = 0x5342444d;
 enum Kind : uint32_t { KIND_GRID = 1, KIND_AGG = 2, KIND_FIT = 3 };
 
-thread_local std::string last_error;
-
-int fail(const std::string &message) {
-    last_error = message;
-    return 1;
-}
+using mdb::fail;
 
 struct Hasher {
     uint64_t state = 1469598103934665603ull;
@@ -293,8 +294,7 @@ std::vector<uint8_t> payload_from_segments(const mdb_segments_owned &made) {
 }
 #endif
 
-struct OwnedGrid {
-    mdb_grid_result result{};
+struct OwnedGrid : mdb::OwnedGridResult { // (the pipeline attaches the replicated tag views to the base)
     void *ts_block = nullptr, *value_block = nullptr, *rows_block = nullptr;
 };
 
@@ -313,31 +313,113 @@ uint64_t fit_key(const int64_t *ts, const float *values, const uint64_t *offsets
 
 bool valid(const mdb_ctx *ctx) { return ctx && ctx->magic == CTX_MAGIC; }
 
+// MDB_STUB_CALL_LOG=<file>: one line per data call, in the order the kernels' side sees them (the tests of the
+// call sequence: a GridStream keeps one submit ahead and gathers small input batches into one launch).
+void log_call(const char *what, uint64_t a = 0, uint64_t b = 0, uint64_t c = 0) {
+    static const char *path = std::getenv("MDB_STUB_CALL_LOG");
+    if (!path) return;
+    static std::mutex mutex;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (FILE *f = std::fopen(path, "a")) {
+        std::fprintf(f, "%s %llu %llu %llu\n", what, (unsigned long long)a, (unsigned long long)b, (unsigned long long)c);
+        std::fclose(f);
+    }
+}
+
+// Several batches as one: primitive columns copied end to end, views copied with buffer_index moved onto a joint
+// buffer table (what upload_segment_list_locked does on its way to the device in the product).
+struct JoinedSegments {
+    mdb_segments seg{};
+    bool ok = true;
+    std::vector<int8_t> type;
+    std::vector<int64_t> start, end;
+    std::vector<float> mn, mx;
+    std::vector<mdb_view16> views[3];
+    std::vector<const uint8_t *> pointers[3];
+    std::vector<int64_t> sizes[3];
+    JoinedSegments(const mdb_segments *const *ins, uint32_t n_ins) {
+        for (uint32_t k = 0; k < n_ins; k++) {
+            const mdb_segments &s = *ins[k];
+            type.insert(type.end(), s.model_type_id, s.model_type_id + s.n);
+            start.insert(start.end(), s.start_time, s.start_time + s.n);
+            end.insert(end.end(), s.end_time, s.end_time + s.n);
+            mn.insert(mn.end(), s.min_value, s.min_value + s.n);
+            mx.insert(mx.end(), s.max_value, s.max_value + s.n);
+            const mdb_binview_col *cols[3] = {&s.timestamps, &s.values, &s.residuals};
+            for (int c = 0; c < 3; c++) {
+                const int32_t first_buffer = static_cast<int32_t>(pointers[c].size());
+                for (uint64_t i = 0; i < s.n; i++) {
+                    mdb_view16 view = cols[c]->views[i];
+                    if (view.length > 12) {
+                        if (view.u.ref.buffer_index < 0 || view.u.ref.buffer_index >= cols[c]->n_buffers) ok = false;
+                        view.u.ref.buffer_index += first_buffer;
+                    }
+                    views[c].push_back(view);
+                }
+                for (int32_t b = 0; b < cols[c]->n_buffers; b++) {
+                    pointers[c].push_back(cols[c]->buffers[b]);
+                    sizes[c].push_back(cols[c]->buffer_sizes[b]);
+                }
+            }
+        }
+        seg.n = type.size();
+        seg.model_type_id = type.data();
+        seg.start_time = start.data();
+        seg.end_time = end.data();
+        seg.min_value = mn.data();
+        seg.max_value = mx.data();
+        mdb_binview_col *out[3] = {&seg.timestamps, &seg.values, &seg.residuals};
+        for (int c = 0; c < 3; c++) {
+            out[c]->views = views[c].data();
+            out[c]->buffers = pointers[c].data();
+            out[c]->buffer_sizes = sizes[c].data();
+            out[c]->n_buffers = static_cast<int32_t>(pointers[c].size());
+        }
+    }
+};
+
 } // namespace
+
+mdb::GridPipeline *mdb::ctx_pipeline(mdb_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    return ctx->pipeline;
+}
+mdb::GridPipeline *mdb::ctx_pipeline_install(mdb_ctx *ctx, GridPipeline *fresh) {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (!ctx->pipeline) ctx->pipeline = fresh;
+    return ctx->pipeline;
+}
+mdb::GridPipeline *mdb::ctx_pipeline_detach(mdb_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    GridPipeline *pipeline = ctx->pipeline;
+    ctx->pipeline = nullptr;
+    return pipeline;
+}
 
 extern "C" {
 
 int mdb_init(int device, mdb_ctx **ctx) {
     if (!ctx || device < 0) return fail("mdb_init: NULL out pointer or negative device");
-    *ctx = new mdb_ctx{CTX_MAGIC};
+    *ctx = new mdb_ctx();
+    (*ctx)->magic = CTX_MAGIC;
     return 0;
 }
 
 int mdb_clone(mdb_ctx *ctx, mdb_ctx **out) {
     if (!valid(ctx) || !out) return fail("mdb_clone: NULL or closed context");
-    *out = new mdb_ctx{CTX_MAGIC};
-    return 0;
+    return mdb_init(0, out);
 }
 
 int mdb_close(mdb_ctx *ctx) {
     if (!ctx) return 0;
     if (!valid(ctx)) return fail("mdb_close: not a context (closed twice?)");
+    mdb::pipeline_close(ctx);
     ctx->magic = 0;
     delete ctx;
     return 0;
 }
 
-const char *mdb_last_error(void) { return last_error.c_str(); }
+const char *mdb_last_error(void) { return mdb::g_last_error.c_str(); }
 
 void mdb_segments_free(mdb_segments_owned *segments) {
     if (segments) delete static_cast<OwnedSegments *>(segments->priv_);
@@ -345,19 +427,33 @@ void mdb_segments_free(mdb_segments_owned *segments) {
 
 void mdb_grid_result_free(mdb_grid_result *result) {
     if (!result) return;
-    auto *owned = static_cast<OwnedGrid *>(result->priv_);
+    auto *owned = static_cast<OwnedGrid *>(static_cast<mdb::OwnedGridResult *>(result->priv_));
+    for (auto &tags : owned->tag_blocks) mdb::host_block_give(tags.first, tags.second);
     std::free(owned->ts_block);
     std::free(owned->value_block);
     std::free(owned->rows_block);
     delete owned;
 }
 
-int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, int64_t t_lo, int64_t t_hi,
-                         uint64_t reserve_front, mdb_grid_result **out) {
-    if (!valid(ctx) || !in || !out) return fail("mdb_grid_batch_owned: NULL argument or closed context");
-    const bool ranged = flags & MDB_GRID_HAS_RANGE, values_only = flags & MDB_GRID_VALUES_ONLY;
+} // extern "C"
+
+// The kernels' side of mdb_grid_batch_owned and of the jobs of mdb_grid_submit (mdb_grid.hip in the product):
+// several input batches are answered as the one batch they make up.
+int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uint32_t n_ins, TimeRangeArg range,
+                               bool values_only, uint64_t reserve_front, mdb_grid_result **out) {
+    if (!valid(ctx) || !ins || !out || n_ins == 0) return fail("mdb_grid_batch_owned: NULL argument or closed context");
+    const bool ranged = range.enabled != 0;
+    const int64_t t_lo = range.lo, t_hi = range.hi;
+    {
+        uint64_t segments = 0;
+        for (uint32_t k = 0; k < n_ins; k++) segments += ins[k]->n;
+        log_call("grid", n_ins, segments, reserve_front);
+    }
+    // (one batch holding the rows of all inputs: the views keep pointing into their own batch's buffers)
+    JoinedSegments joined(ins, n_ins);
+    const mdb_segments *in = &joined.seg;
     Hasher h;
-    if (!hash_segments(*in, h)) return fail("mdb_grid_batch_owned: a view points outside its data buffers");
+    if (!joined.ok || !hash_segments(*in, h)) return fail("mdb_grid_batch_owned: a view points outside its data buffers");
     h.value<uint32_t>(ranged ? 1 : 0);
     if (ranged) {
         h.value(t_lo);
@@ -403,7 +499,8 @@ int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, i
     if (!payload) return no_record("mdb_grid_batch_owned", h.state);
     Reader reader(*payload);
     auto *owned = new OwnedGrid();
-    mdb_grid_result &r = owned->result;
+    mdb_grid_result &r = owned->c;
+    std::memset(&r, 0, sizeof r);
     r.n = reader.value<uint64_t>();
     r.n_segments = reader.value<uint64_t>();
     r.metrics = reader.value<mdb_grid_metrics>();
@@ -422,13 +519,22 @@ int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, i
     }
     reader.bytes(r.values, 4 * r.n);
     reader.bytes(r.rows_per_segment, 4 * r.n_segments);
-    r.priv_ = owned;
+    r.priv_ = static_cast<mdb::OwnedGridResult *>(owned);
     if (!reader.ok || r.n_segments != in->n) {
         mdb_grid_result_free(&r);
         return fail("mdb_stub: damaged grid record");
     }
     *out = &r;
     return 0;
+}
+
+extern "C" {
+
+int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, int64_t t_lo, int64_t t_hi,
+                         uint64_t reserve_front, mdb_grid_result **out) {
+    if (!in) return fail("mdb_grid_batch_owned: NULL argument or closed context");
+    return mdb::grid_batch_owned_list(ctx, &in, 1, mdb::TimeRangeArg{t_lo, t_hi, (flags & MDB_GRID_HAS_RANGE) ? 1 : 0},
+                                      (flags & MDB_GRID_VALUES_ONLY) != 0, reserve_front, out);
 }
 
 int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout) {
@@ -474,6 +580,24 @@ int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values, co
     if (!payload) return no_record("mdb_compress_chunks", key);
     *out = segments_from_payload(*payload);
     return *out ? 0 : fail("mdb_stub: damaged fit record");
+}
+
+int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb_error_bound error_bound,
+                            mdb_segments_owned **out) {
+    if (!valid(ctx) || !out || (n_chunks > 0 && !chunks)) return fail("mdb_compress_chunk_list: NULL argument or closed context");
+    log_call("compress_chunk_list", n_chunks, static_cast<uint64_t>(error_bound.kind));
+    std::vector<int64_t> ts;
+    std::vector<float> values;
+    std::vector<uint64_t> offsets = {0};
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        if (chunks[c].n > 0 && (!chunks[c].ts || !chunks[c].values)) return fail("mdb_compress_chunk_list: NULL chunk");
+        ts.insert(ts.end(), chunks[c].ts, chunks[c].ts + chunks[c].n);
+        values.insert(values.end(), chunks[c].values, chunks[c].values + chunks[c].n);
+        offsets.push_back(ts.size());
+    }
+    ts.push_back(0); // (data() of an empty vector may be NULL)
+    values.push_back(0.0f);
+    return mdb_compress_chunks(ctx, ts.data(), values.data(), offsets.data(), n_chunks, error_bound, out);
 }
 
 int mdb_compress_series(mdb_ctx *ctx, const int64_t *ts, const float *values, uint64_t n,

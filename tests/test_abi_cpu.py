@@ -50,7 +50,8 @@ def test_struct_layouts_match_the_pinned_numbers_of_the_header():
     mirror = {"mdb_error_bound": _abi.ErrorBoundC, "mdb_binview_col": _abi.BinViewColC,
               "mdb_segments": _abi.SegmentsC, "mdb_grid_metrics": _abi.GridMetricsC,
               "mdb_agg_state": _abi.AggStateC, "mdb_segments_owned": _abi.SegmentsOwnedC,
-              "mdb_grid_result": _abi.GridResultC}
+              "mdb_grid_result": _abi.GridResultC, "mdb_grid_input": _abi.GridInputC,
+              "mdb_grid_request": _abi.GridRequestC, "mdb_chunk": _abi.ChunkC}
     sizes = dict(re.findall(r"MDB_LAYOUT_ASSERT\(sizeof\((\w+)\) == (\d+)\)", text))
     offsets = re.findall(r"MDB_LAYOUT_ASSERT\(offsetof\((\w+), (\w+)\) == (\d+)\)", text)
     assert set(mirror) <= set(sizes) and len(offsets) >= 30
@@ -114,7 +115,7 @@ def test_rust_patches_apply_to_the_reference():
     if not os.path.isdir(os.path.join(reference, "crates")):
         pytest.skip("the reference tree is not present")
     patches = sorted(glob.glob(os.path.join(REPO_ROOT, "rust", "patches", "*.patch")))
-    assert len(patches) == 3
+    assert len(patches) == 4
     for patch in patches:
         with open(patch) as f:
             done = subprocess.run(["patch", "-p1", "--dry-run", "--force", "-d", reference], stdin=f,
@@ -150,6 +151,39 @@ def test_null_arguments_are_errors_not_crashes():
     assert library.mdb_are_compressed_timestamps_regular(None, 4, None) == 1
     assert library.mdb_split_and_compress_univariate(None, None, None, None, 0, 0, None) == 1
     assert library.mdb_segments_validate_dev(None, None) == 1
+    assert library.mdb_grid_submit(None, None, 0, None, None) == 1
+    assert library.mdb_grid_wait(None, None) == 1
+    library.mdb_grid_cancel(None)
+    assert library.mdb_grid_result_tag_views(None, 0) is None
+    assert library.mdb_compress_chunk_list(None, None, 0, mdb.error_bound("lossless"), None) == 1
+    assert library.mdb_replicate_views(None, None, 3, 0, None, 0) == 1
+
+
+def test_replicate_views_is_host_arithmetic():
+    """mdb_replicate_views needs no context and no GPU: every segment's 16-byte view once per reconstructed row,
+    buffer_index of the long ones moved (grid_exec.rs:339-346), also when the fill is split over threads."""
+    library = mdb.load_hip_library()
+    rng = np.random.default_rng(11)
+    for n_segments, most in ((0, 1), (5, 4), (3000, 90), (70_000, 4)):
+        views = rng.integers(0, 256, (n_segments, 16), dtype=np.uint8)
+        lengths = rng.integers(0, 40, n_segments).astype("<i4")
+        views[:, 0:4] = lengths.view(np.uint8).reshape(-1, 4)
+        views[:, 8:12] = rng.integers(0, 5, n_segments).astype("<i4").view(np.uint8).reshape(-1, 4)
+        rows = rng.integers(0, most, n_segments).astype(np.uint32)
+        expected = np.repeat(views, rows, axis=0)
+        long_rows = np.repeat(lengths > 12, rows)
+        index = expected[:, 8:12].copy().view("<i4").reshape(-1)
+        index[long_rows] += 3
+        expected[:, 8:12] = index.view(np.uint8).reshape(-1, 4)
+        for misalign in (0, 8):  # (an output that is not 16-byte aligned takes the plain stores)
+            backing = np.zeros(16 * len(expected) + 64, dtype=np.uint8)
+            start = (-backing.ctypes.data) % 16 + misalign
+            out = backing[start:start + 16 * len(expected)]
+            assert library.mdb_replicate_views(views.ctypes.data, rows.ctypes.data, n_segments, 3, out.ctypes.data,
+                                               len(expected)) == 0, library.mdb_last_error()
+            assert np.array_equal(out.reshape(-1, 16), expected)
+    assert library.mdb_replicate_views(views.ctypes.data, rows.ctypes.data, n_segments, 0, out.ctypes.data, 1) == 1
+    assert b"capacity" in library.mdb_last_error()
 
 
 def test_segment_batch_arrow_round_trip():

@@ -401,3 +401,33 @@ def test_fit_irregular_timestamps_around_and_beyond_the_exact_f64_range(hip, ori
         eb = cases.error_bounds()[eb_name]
         assert_same_segments(hip.compress_chunks(timestamps, values, offsets, eb),
                              ora.compress_chunks(timestamps, values, offsets, eb))
+
+
+def test_fit_chunk_list_gathers_chunks_where_they_lie(hip):
+    # mdb_compress_chunk_list (what the patched try_compress_multivariate_time_series and
+    # process_compressor_messages call): every chunk its own pair of arrays, fields of one series sharing their
+    # timestamp array, regular and irregular, empty ones, more than one gather slice.
+    eb = cases.error_bounds()["rel1"]
+    rng = np.random.default_rng(59)
+    chunks = []
+    for s, n in enumerate([5000, 0, 1, 2, 70_000, 2500, 300_000, 9, 65_536]):
+        ts = 1_000_000 * s + np.arange(n, dtype=np.int64) * (1000 + s)
+        for field in range(3):                       # three fields share ts
+            values = datagen.sine_series(7 * s + field, n)[1] if n else np.zeros(0, np.float32)
+            chunks.append((ts, values))
+    flat_ts = np.concatenate([ts for ts, _ in chunks])
+    flat_values = np.concatenate([v for _, v in chunks])
+    offsets = np.concatenate([[0], np.cumsum([len(v) for _, v in chunks])]).astype(np.uint64)
+    assert_same_segments(hip.compress_chunk_list(chunks, eb), ora.compress_chunks(flat_ts, flat_values, offsets, eb))
+    # one chunk with irregular timestamps among them: the timestamps cross as well
+    irregular = 5_000_000 + np.cumsum(rng.integers(1, 2000, 40_000)).astype(np.int64)
+    chunks.insert(4, (irregular, datagen.sine_series(99, len(irregular))[1]))
+    flat_ts = np.concatenate([ts for ts, _ in chunks])
+    flat_values = np.concatenate([v for _, v in chunks])
+    offsets = np.concatenate([[0], np.cumsum([len(v) for _, v in chunks])]).astype(np.uint64)
+    for bound in (eb, cases.LOSSLESS):
+        assert_same_segments(hip.compress_chunk_list(chunks, bound),
+                             ora.compress_chunks(flat_ts, flat_values, offsets, bound))
+    assert len(hip.compress_chunk_list([], eb)) == 0
+    with pytest.raises(mdb.HipError):
+        hip.compress_chunk_list([(np.arange(3), np.zeros(2, np.float32))], eb)

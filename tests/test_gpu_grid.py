@@ -713,3 +713,126 @@ def test_clones_are_kept_for_the_next_clone_and_survive_their_origin():
     origin.close()                                   # destroys the idle clone; `third` is still in use
     cases.assert_grid_equal(third.grid_batch(batch), expected)
     third.close()
+
+
+def _tag_views(rng, n, long_share=0.3, buffers=2):
+    """n random Utf8View views the way arrow lays them out (length, then the bytes or prefix / buffer / offset)."""
+    views = np.zeros((n, 16), dtype=np.uint8)
+    lengths = np.where(rng.random(n) < long_share, rng.integers(13, 40, n), rng.integers(0, 13, n)).astype("<i4")
+    views[:, 0:4] = lengths.view(np.uint8).reshape(-1, 4)
+    views[:, 4:16] = rng.integers(0, 256, (n, 12), dtype=np.uint8)
+    long_rows = lengths > 12
+    views[long_rows, 8:12] = rng.integers(0, buffers, int(long_rows.sum())).astype("<i4").view(np.uint8).reshape(-1, 4)
+    short = ~long_rows
+    for k in range(12):  # inline bytes beyond the length are zero
+        views[short & (lengths <= k), 4 + k] = 0
+    return views, long_rows
+
+
+def _expected_tags(views, long_rows, rows, shift):
+    expected = np.repeat(views, rows, axis=0)
+    index = expected[:, 8:12].copy().view("<i4").reshape(-1)
+    index[np.repeat(long_rows, rows)] += shift
+    expected[:, 8:12] = index.view(np.uint8).reshape(-1, 4)
+    return expected
+
+
+def test_submitted_batches_come_back_as_one_with_their_tags_repeated(hip):
+    # mdb_grid_submit / mdb_grid_wait (what the patched GridStream::poll_next calls, grid_exec.rs:261-429): several
+    # input batches through one launch, rows in the order of the list; tag views repeated per created row
+    # (grid_exec.rs:339-346), long ones moved onto the output column's buffer list.
+    rng = np.random.default_rng(17)
+    eb = cases.error_bounds()["rel1"]
+    batches = [cases.mixed_batch(eb, irregular, seed=300 + k, length=length)[2]
+               for k, (irregular, length) in enumerate(((False, 9000), (True, 7000), (False, 0), (False, 12_000)))]
+    batches[2] = mdb.SegmentBatch.from_rows([])                       # an empty input in the middle
+    batches.append(cases.edge_case_batch())                           # MacaqueV streams, residual tails, data buffers
+    joined = mdb.SegmentBatch.concat(batches)
+    expected = ora.grid_batch(joined)
+    tags = [[_tag_views(rng, len(batch)) for _ in range(2)] for batch in batches]
+    shifts = [[1 + 2 * b, 5 + 3 * b] for b in range(len(batches))]
+    for reserve_front in (0, 37, 8192):
+        ticket = hip.grid_submit(batches, [[views for views, _ in columns] for columns in tags], shifts,
+                                 reserve_front=reserve_front)
+        ts, values, rows, metrics, tag_columns = ticket.wait()
+        cases.assert_grid_equal((ts, values), expected)
+        assert np.array_equal(rows, expected[2]) and metrics == expected[3]
+        at_segment, at_row = 0, 0
+        for b, batch in enumerate(batches):
+            batch_rows = rows[at_segment:at_segment + len(batch)]
+            created = int(batch_rows.sum())
+            for column in range(2):
+                views, long_rows = tags[b][column]
+                assert np.array_equal(tag_columns[column][at_row:at_row + created],
+                                      _expected_tags(views, long_rows, batch_rows, shifts[b][column]))
+            at_segment, at_row = at_segment + len(batch), at_row + created
+        assert at_row == len(ts)
+    # one input: the same as mdb_grid_batch_owned, with and without a time range, values only
+    lo, hi = int(expected[0][len(expected[0]) // 5]), int(expected[0][len(expected[0]) // 2])
+    for batch in batches:
+        plain = hip.grid_submit([batch]).wait()
+        cases.assert_grid_equal(plain, ora.grid_batch(batch))
+        ranged = hip.grid_submit([batch], time_range=(lo, hi)).wait()
+        cases.assert_grid_equal(ranged, hip.grid_batch_range(batch, lo, hi))
+        only_values = hip.grid_submit([batch], values_only=True).wait()
+        assert only_values[0] is None
+        assert np.array_equal(only_values[1].view(np.uint32), plain[1].view(np.uint32))
+    ranged = hip.grid_submit(batches, time_range=(lo, hi)).wait()
+    cases.assert_grid_equal(ranged, hip.grid_batch_range(joined, lo, hi))
+
+
+def test_many_tickets_in_flight_waited_in_any_order_and_cancelled(hip):
+    # Two submits run at once (the context and the clone the library keeps), further ones queue; results may be
+    # waited for in any order; a ticket nobody waits for is cancelled (a GridStream dropped mid-query); a failing
+    # batch fails its own wait only, with its own message on the waiting thread.
+    eb = cases.error_bounds()["rel5"]
+    batches = [cases.mixed_batch(eb, k % 2 == 1, seed=400 + k, length=3000 + 500 * k)[2] for k in range(7)]
+    expected = [ora.grid_batch(batch) for batch in batches]
+    bad = mdb.SegmentBatch.from_rows([(7, 100, 500, bytes([5]), 1.0, 1.0, b"", b"")])  # unknown model type
+    from modelardb_rs_amd import api
+    for context in (hip, api.Context(0)):
+        for round_ in range(3):
+            tickets = [context.grid_submit([batch]) for batch in batches]
+            failing = context.grid_submit([bad])
+            order = np.random.default_rng(round_).permutation(len(tickets))
+            for k in order[:5]:
+                cases.assert_grid_equal(tickets[k].wait(), expected[k])
+            with pytest.raises(mdb.HipError, match="model type"):
+                failing.wait()
+            for k in order[5:]:
+                tickets[k].cancel()
+            cases.assert_grid_equal(context.grid_batch(batches[0]), expected[0])   # the context still works
+    context.grid_submit([batches[1]])   # (an outstanding ticket when the context is closed: finished, then freed)
+    context.close()
+
+
+def test_a_reused_clone_is_a_fresh_one(hip):
+    # mdb_close of a clone keeps it for the next mdb_clone - but not what its owner did to it: a stream set with
+    # mdb_set_stream may be destroyed behind it (such a clone is closed for real), a communicator is closed,
+    # timings are forgotten.
+    from modelardb_rs_amd import api
+    import torch
+    eb = cases.error_bounds()["rel5"]
+    _, _, batch = cases.mixed_batch(eb, False, seed=77, length=5000)
+    expected = ora.grid_batch(batch)
+    origin = api.Context(0)
+    first = origin.clone()
+    first.profile_enable(True)
+    first.comm_init(0, 1, mdb.comm_unique_id())
+    cases.assert_grid_equal(first.grid_batch(batch), expected)
+    kept = first.handle.value
+    first.close()
+    second = origin.clone()
+    assert second.handle.value == kept
+    assert second.profile() == {}                      # nothing of the previous owner's launches
+    second.comm_init(0, 1, mdb.comm_unique_id())       # ("already has a communicator" before)
+    cases.assert_grid_equal(second.grid_batch(batch), expected)
+    stream = torch.cuda.Stream()
+    second.set_stream(stream.cuda_stream)
+    cases.assert_grid_equal(second.grid_batch(batch), expected)
+    second.close()                                     # not kept: its stream is the caller's
+    del stream
+    third = origin.clone()
+    cases.assert_grid_equal(third.grid_batch(batch), expected)
+    third.close()
+    origin.close()
