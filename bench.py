@@ -211,10 +211,12 @@ def host_path(context, mdb, np, sample, args):
     chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
     sample_series = max(1, min(args.series, 1_000_000_000 // max(args.points, 1)))
     sample = sample.take(np.nonzero(sample.chunk_index < sample_series * chunks_per_series)[0])
-    out = {"note": "C++ GridExec/GridStream of libmdb_host over host segment batches (8 192 segment rows per "
-                   "input batch), polled to the end in slices of batch_size data points; upload of the segments, "
-                   "kernels and the copy of 12 B per data point into page-locked host memory included; two "
-                   "batches in flight (copy of one overlapping the kernels of the next)"}
+    out = {"note": "the call sequence of the patched GridStream (rust/patches/0001-grid_exec.patch through "
+                   "rust/modelardb_hip), issued by its C++ twin in libmdb_host: host segment batches of 8 192 rows "
+                   "are gathered into mdb_grid_submit calls of about 16 M data points, one submit is kept ahead "
+                   "(mdb_grid_wait of one while the next is on the GPU), tag views are repeated per row by the "
+                   "library; polled to the end in slices of batch_size data points. Upload of the segments, kernels "
+                   "and the copy of 12 B per data point into page-locked host memory included"}
     # The first pass over the sample is the cold one: the context's pool of page-locked blocks grows to the sizes
     # the batches need (a hipHostMalloc of 70 MB takes 13 ms). A server's pool is warm; both are reported.
     points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192)
@@ -228,6 +230,67 @@ def host_path(context, mdb, np, sample, args):
     points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192, tags={"tag": "wind-turbine-0042"})
     out["batch_8192_one_tag_column"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
                                         "seconds": seconds}
+    # What gathering buys: one input batch per submit (round 2's call shape) against the learned size.
+    os.environ["MDB_HOST_GRID_COALESCE_SEGMENTS"] = "1"
+    try:
+        points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192)
+    finally:
+        del os.environ["MDB_HOST_GRID_COALESCE_SEGMENTS"]
+    out["batch_8192_one_input_batch_per_submit"] = {"values_per_s": points / seconds,
+                                                    "GB_per_s_pcie": bytes_down / seconds / 1e9}
+    return out
+
+
+def host_fit(context, mdb, np, ora, host_ts, values, offsets, eb, gpu_fitted):
+    """The fit from host memory the way the patched call sites make it (rust/patches/0003, 0004): every series x
+    field or finished buffer is one chunk where it lies, all of them in ONE mdb_compress_chunk_list - against the
+    reference's call shape (one call per buffer) and, per launch size, against one CPU thread of the port."""
+    n_chunks = len(offsets) - 1
+    chunks = [(host_ts[int(a):int(b)], values[int(a):int(b)]) for a, b in zip(offsets[:-1], offsets[1:])]
+    points = int(offsets[-1])
+    context.compress_chunk_list(chunks, eb)
+    from_host = context.compress_chunk_list(chunks, eb)
+    seconds = context.last_call_seconds
+    if from_host.rows() != gpu_fitted.rows():
+        raise SystemExit("VERIFICATION FAILED: the fit through host pointers differs from the device-resident one")
+    out = {"points_per_s": points / seconds, "segments_per_s": len(from_host) / seconds, "seconds": seconds,
+           "points": points, "chunks": n_chunks,
+           "note": "mdb_compress_chunk_list over the chunks where they lie in host memory (12 B per point handed "
+                   "over; host threads gather the values into page-locked memory slice by slice while the previous "
+                   "slice crosses PCIe and find every chunk's timestamps equally spaced, so the timestamps never "
+                   "cross), segments downloaded; second of two calls; segments == the device-resident fit's"}
+    # The reference's call shape: one call per finished buffer (uncompressed_data_manager.rs:505-596).
+    per_buffer = chunks[:64]
+    context.compress_chunk_list(per_buffer[:1], eb)
+    started = time.perf_counter()
+    for chunk in per_buffer:
+        context.compress_chunk_list([chunk], eb)
+    seconds = time.perf_counter() - started
+    out["one_call_per_buffer"] = {"points_per_s": sum(len(v) for _, v in per_buffer) / seconds,
+                                  "ms_per_buffer": 1e3 * seconds / len(per_buffer), "buffers": len(per_buffer)}
+    # Latency by launch size against ONE CPU thread (the reference's single compression thread).
+    cpu_chunks = min(n_chunks, 32)
+    cpu_offsets = (offsets[:cpu_chunks + 1] - offsets[0]).astype(np.uint64)
+    cpu_points = int(cpu_offsets[-1])
+    _, cpu_seconds = ora.compress_chunks_timed(host_ts[:cpu_points], values[:cpu_points], cpu_offsets, eb, 1,
+                                               repetitions=3)
+    cpu_ms_per_chunk = 1e3 * statistics.median(cpu_seconds) / cpu_chunks
+    table = []
+    for n in (1, 4, 16, 64, 256, 1024, 4096):
+        launch = [chunks[k % n_chunks] for k in range(n)]
+        context.compress_chunk_list(launch, eb)
+        timings = []
+        for _ in range(3):
+            context.compress_chunk_list(launch, eb)
+            timings.append(context.last_call_seconds)
+        gpu_ms = 1e3 * min(timings)
+        table.append({"chunks": n, "points": sum(len(v) for _, v in launch), "gpu_ms": round(gpu_ms, 3),
+                      "cpu_1_thread_ms": round(cpu_ms_per_chunk * n, 3),
+                      "gpu_points_per_s": sum(len(v) for _, v in launch) / (gpu_ms * 1e-3)})
+    out["fit_latency"] = {"rows": table, "cpu_ms_per_chunk": cpu_ms_per_chunk,
+                          "note": "chunks of 65 536 points (the server's ingest buffer) from host memory through "
+                                  "mdb_compress_chunk_list to segments in host memory, best of 3; the CPU column is "
+                                  "the port on one thread (measured on 32 chunks, scaled)"}
     return out
 
 
@@ -572,20 +635,8 @@ def main():
             with phase("host_path"):
                 host_path_result = host_path(context, mdb, np, downloaded, args)
             with phase("host_path_fit"):
-                # The fit through host pointers (what an ingest thread calls): timestamps and values in host
-                # memory, segments back in host memory, PCIe included. Same bytes as the device-resident fit.
-                context.compress_chunks(host_ts, fit_sample_values, offsets, eb)
-                started = time.perf_counter()
-                from_host = context.compress_chunks(host_ts, fit_sample_values, offsets, eb)
-                seconds = time.perf_counter() - started
-                if from_host.rows() != gpu_fitted.rows():
-                    raise SystemExit("VERIFICATION FAILED: the fit through host pointers differs from the device-resident one")
-                host_path_result["fit"] = {
-                    "points_per_s": n_fit * args.points / seconds, "segments_per_s": len(from_host) / seconds,
-                    "seconds": seconds, "points": n_fit * args.points,
-                    "note": "mdb_compress_chunks over host arrays of the first series (12 B per point handed over; "
-                            "host threads find every chunk's timestamps equally spaced while the values cross "
-                            "PCIe, so the timestamps never do), segments downloaded; second of two calls"}
+                host_path_result["fit"] = host_fit(context, mdb, np, ora, host_ts, fit_sample_values, offsets, eb,
+                                                   gpu_fitted)
         del downloaded
         if not args.no_irregular:
             with phase("irregular_timestamps"):

@@ -7,6 +7,7 @@ library cannot be loaded or a call fails, ``HipError`` is raised.
 """
 
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -135,6 +136,7 @@ class Context:
         if self.lib.mdb_init(int(device), C.byref(self.handle)) != 0:
             raise HipError(self.lib.mdb_last_error().decode())
         self.device = device
+        self.last_call_seconds = 0.0
 
     def _check(self, code):
         if code != 0:
@@ -381,9 +383,12 @@ class Context:
                 "Uncompressed timestamps and uncompressed values have different lengths.")
         offsets = np.ascontiguousarray(chunk_offsets, dtype=np.uint64)
         out = C.POINTER(_abi.SegmentsOwnedC)()
-        self._check(self.lib.mdb_compress_chunks(
+        started = time.perf_counter()
+        code = self.lib.mdb_compress_chunks(
             self.handle, ts.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
-            offsets.ctypes.data_as(C.c_void_p), len(offsets) - 1, eb, C.byref(out)))
+            offsets.ctypes.data_as(C.c_void_p), len(offsets) - 1, eb, C.byref(out))
+        self.last_call_seconds = time.perf_counter() - started
+        self._check(code)
         try:
             return SegmentBatch.from_owned(out)
         finally:
@@ -401,7 +406,10 @@ class Context:
         table = (_abi.ChunkC * max(len(arrays), 1))(*[_abi.ChunkC(ts.ctypes.data, v.ctypes.data, len(v))
                                                       for ts, v in arrays])
         out = C.POINTER(_abi.SegmentsOwnedC)()
-        self._check(self.lib.mdb_compress_chunk_list(self.handle, table, len(arrays), eb, C.byref(out)))
+        started = time.perf_counter()
+        code = self.lib.mdb_compress_chunk_list(self.handle, table, len(arrays), eb, C.byref(out))
+        self.last_call_seconds = time.perf_counter() - started  # (the library call alone, for bench.py)
+        self._check(code)
         try:
             return SegmentBatch.from_owned(out)
         finally:

@@ -104,6 +104,7 @@ struct mdb_ctx {
     std::shared_ptr<mdb::CloneCache> clones; // shared by a context and its clones
     bool is_clone = false;
     mdb::GridPipeline *pipeline = nullptr; // made by the first mdb_grid_submit, ended by mdb_close
+    std::mutex pipeline_mutex;             // guards `pipeline` (not `mutex`: a running job holds that one)
 
     // RCCL communicator of mdb_comm_init (an ncclComm_t; rccl.h stays out of this header).
     void *comm = nullptr;

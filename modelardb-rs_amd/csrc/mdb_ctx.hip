@@ -125,19 +125,21 @@ void PinnedPool::close() {
     blocks.clear();
 }
 
+// (under a lock of their own: the context's call lock is held by a running job from its upload to its last copy,
+// and a submit that waited for it could never put a second job next to the first)
 GridPipeline *ctx_pipeline(mdb_ctx *ctx) {
-    CallGuard lock(ctx);
+    std::lock_guard<std::mutex> lock(ctx->pipeline_mutex);
     return ctx->pipeline;
 }
 
 GridPipeline *ctx_pipeline_install(mdb_ctx *ctx, GridPipeline *fresh) {
-    CallGuard lock(ctx);
+    std::lock_guard<std::mutex> lock(ctx->pipeline_mutex);
     if (!ctx->pipeline) ctx->pipeline = fresh;
     return ctx->pipeline;
 }
 
 GridPipeline *ctx_pipeline_detach(mdb_ctx *ctx) {
-    CallGuard lock(ctx);
+    std::lock_guard<std::mutex> lock(ctx->pipeline_mutex);
     GridPipeline *pipeline = ctx->pipeline;
     ctx->pipeline = nullptr;
     return pipeline;

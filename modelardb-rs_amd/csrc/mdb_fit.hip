@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -2879,6 +2880,11 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
     const uint64_t total = offsets[n_chunks];
     mdb_segments_owned *dev = nullptr;
     int rc = 0;
+    // MDB_FIT_DEBUG: where the call's time goes, on stderr
+    static const bool debug = std::getenv("MDB_FIT_DEBUG") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_gathered = 0.0, t_uploaded = 0.0, t_fitted = 0.0;
     {
         mdb::CallGuard lock(ctx);
         MDB_HIP_CHECK(hipSetDevice(ctx->device));
@@ -2922,6 +2928,7 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
                                               hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                 rc = fail("hipMemcpy host to device failed.");
         });
+        t_gathered = since_start();
         bool regular = total > 0;
         for (uint64_t c = 0; c < n_chunks; c++) {
             const uint64_t source = same_ts_as[c];
@@ -2932,6 +2939,7 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
             regular = regular && !irregular[source];
         }
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+        t_uploaded = since_start();
         if (!rc && regular) {
             void *dev_first = nullptr;
             if (scratch_reserve(ctx, SCRATCH_FIT_IN_TS, 16 * n_chunks, &dev_first)) return 1;
@@ -2960,10 +2968,15 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
                                                 nullptr, &dev);
         }
         (void)hipStreamSynchronize(ctx->stream);
+        t_fitted = since_start();
     }
     if (rc) return 1;
     rc = mdb_segments_download(ctx, dev, out);
     mdb_segments_free(dev);
+    if (debug)
+        std::fprintf(stderr, "mdb_compress_chunk_list: %llu chunks, %llu points: gathered %.2f ms, on the device %.2f, fitted %.2f, "
+                             "downloaded %.2f\n", (unsigned long long)n_chunks, (unsigned long long)total, t_gathered, t_uploaded,
+                     t_fitted, since_start());
     return rc;
 }
 

@@ -88,6 +88,57 @@ def test_grid_stream_reconstructs_two_series_with_tags(hip, batch_size):
     assert metrics["elapsed_compute_ns"] > 0
 
 
+@pytest.mark.parametrize("coalesce", ["learned", "3", "1000000"])
+def test_grid_stream_gathers_input_batches_and_keeps_one_submit_ahead(hip, coalesce, monkeypatch, grid_prefetch):
+    """What the patched GridStream::poll_next (rust/patches/0001-grid_exec.patch) does, call for call: input
+    batches that are ready are gathered into ONE mdb_grid_submit (several RecordBatches per launch, SURVEY 8(f)
+    N2), the next submit is made before the current one is waited for, and the tag views of every gathered batch
+    are repeated per row with their strings left in that batch's own data buffers. The rows are the same in the
+    same order however the batches are gathered."""
+    if coalesce != "learned":
+        monkeypatch.setenv("MDB_HOST_GRID_COALESCE_SEGMENTS", coalesce)
+    log = os.environ.get("MDB_STUB_CALL_LOG")
+    if log and os.path.exists(log):
+        os.remove(log)
+    stream = host.GridStream(hip, tag_names=("site", "sensor"), batch_size=1000)
+    expected_ts, expected_values, expected_tags = [], [], []
+    pushed = []
+    for seed in range(4):
+        _, _, batch = _series(200 + seed, length=_n(12_000), irregular=seed % 2 == 1)
+        tags = {"site": f"a-site-name-that-is-not-inlined-{seed}", "sensor": f"s{seed}"}
+        for part in _segment_batches(batch, tags, 2):
+            stream.push(part)
+            pushed.append(part.num_rows)
+        ts, values, _, _ = ora.grid_batch(batch)
+        expected_ts.append(ts)
+        expected_values.append(values)
+        expected_tags += [(tags["site"], tags["sensor"])] * len(ts)
+    stream.finish_input()
+    batches, state = stream.collect()
+    assert state == host.GridStream.READY_NONE
+    ts, values, table = _concat(batches)
+    assert np.array_equal(ts, np.concatenate(expected_ts))
+    assert np.array_equal(values.view(np.uint32), np.concatenate(expected_values).view(np.uint32))
+    assert list(zip(table.column("site").to_pylist(), table.column("sensor").to_pylist())) == expected_tags
+    assert stream.metrics()["rows_created"] == len(ts)
+    if log:  # (tests/test_shim_call_sequence_cpu.py: the launches the kernels' side saw, in order)
+        calls = [line.split() for line in open(log).read().splitlines()]
+        launches = [(int(n_inputs), int(segments)) for what, n_inputs, segments, _ in calls if what == "grid"]
+        assert sum(segments for _, segments in launches) == sum(pushed)
+        assert all(int(reserve_front) >= 1000 for what, _, _, reserve_front in calls if what == "grid")
+        if coalesce == "3":
+            assert all(n_inputs <= 2 for n_inputs, _ in launches)           # batches of 1-2 segments until 3 are there
+            assert len(launches) >= len(pushed) / 2
+        elif coalesce == "1000000":
+            assert launches == [(len(pushed), sum(pushed))]                  # everything that was ready: one launch
+        else:
+            # the first submit is one batch (nothing is known about the data yet), with one submit kept ahead so
+            # is the second; then the stream has seen what a segment decompresses to and takes all that is ready
+            alone = 2 if grid_prefetch is None else 1
+            assert launches[:alone] == [(1, rows) for rows in pushed[:alone]]
+            assert launches[alone:] == [(len(pushed) - alone, sum(pushed[alone:]))]
+
+
 def test_grid_stream_drained_inside_the_library_returns_every_row(hip):
     """bench.py's host_path polls the stream to its end in C++ (mdbh_grid_stream_drain): the rows and
     the first timestamp of every batch must be those the same stream yields batch by batch."""
