@@ -61,6 +61,14 @@ def parse_args():
                         help="skip the block of series with irregular timestamps")
     parser.add_argument("--no-host-path", action="store_true",
                         help="skip the end-to-end GridStream (PCIe-inclusive) measurement")
+    parser.add_argument("--no-mixed-models", action="store_true",
+                        help="skip the block of Constant / Linear / Random data (all three model types)")
+    parser.add_argument("--mixed-points", type=int, default=1_000_000_000)
+    parser.add_argument("--full-tail", action="store_true",
+                        help="with --gpus > 1: rank 0 also runs the host path, irregular and mixed-model blocks "
+                             "(by default a multi-GPU run is short: the other ranks wait for rank 0's tail)")
+    parser.add_argument("--collective-timeout", type=float, default=900.0,
+                        help="seconds a rank waits in a collective before the job is torn down")
     parser.add_argument("--range-middle", type=float, default=0.0,
                         help="BASELINE config 5: the timed step is a point-range GridExec query over this "
                              "fraction of the time axis (centred), e.g. 0.5; 0 = the whole series (config 2)")
@@ -87,15 +95,17 @@ def launch_ranks_if_needed(args):
                "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
     environment = dict(os.environ)
     environment.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (a retry is a fresh child: a process that has touched the GPU is never re-executed)
     child = subprocess.run(command, env=environment, stdout=subprocess.PIPE, text=True)
     sys.stdout.write(child.stdout)
     sys.stdout.flush()
     sys.exit(child.returncode)
 
 
-def init_distributed(args):
+def init_distributed(args, backend="nccl", timeout=None):
     """Every run is a torch.distributed job over RCCL, the single-GPU one included (a process group
-    of one rank), so the collective path is exercised wherever the bench runs."""
+    of one rank), so the collective path is exercised wherever the bench runs. (backend "gloo": the
+    orchestration test of tests/test_bench_cpu.py, two ranks on CPU over a canned workload.)"""
     launched = "WORLD_SIZE" in os.environ
     if not launched:
         os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
@@ -107,8 +117,12 @@ def init_distributed(args):
         raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}")
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    options = {"timeout": timeout} if timeout is not None else {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), **options)
+    else:
+        dist.init_process_group(backend=backend, **options)
     return rank, local_rank, world, dist
 
 
@@ -141,14 +155,28 @@ def pmc_traffic(args, points_per_launch, segments_per_launch):
             + pmc["fetch_bytes_per_segment_corrected"] * segments_per_launch), None
 
 
-def barrier_and_sync(context, dist):
-    """Both sides of the timed region: this rank's launch stream drained, every rank arrived, and
-    (the barrier is a collective on torch's stream) torch's streams drained too."""
-    import torch
-    context.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
-    context.sync()
+def usable_cores():
+    """The CPU baseline's thread count: the CPUs this process may run on - the affinity mask, capped by the
+    cgroup's CPU quota when there is one (the GPU boxes of this pool show 256 CPUs and allow 16 CPUs' worth of
+    time per period: 256 threads then run in bursts between throttles, 0.3 % parallel efficiency, while 16 pinned
+    threads keep 0.6-0.9). Returns (threads, how it was decided)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = f"{cores} CPUs in the affinity mask"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            allowed = max(1, int(quota) // int(period))
+            if allowed < cores:
+                cores, how = allowed, f"cgroup cpu.max {quota} {period} = {allowed} CPUs of the {cores} visible"
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and quota // period < cores:
+                cores, how = max(1, quota // period), f"cgroup cfs quota {quota}/{period} of the {cores} visible"
+        except (OSError, ValueError):
+            pass
+    return cores, how
 
 
 def summary(seconds, units):
@@ -361,6 +389,123 @@ def irregular_timestamps(context, mdb, np, args):
     return out
 
 
+def verified_aggregates(context, mdb, np, ora, sample, t_lo, t_hi):
+    """COUNT / MIN / MAX / SUM of the sample segments, plain and under WHERE timestamp BETWEEN, from the HIP library
+    against the oracle: COUNT, MIN and MAX exact (bit patterns), SUM within the reference's own 0.001 %
+    (crates/modelardb_server/tests/integration_test.rs:1128-1171)."""
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    bits = lambda x: int(np.float32(x).view(np.uint32))
+    checked = {}
+    for label, got, expected in (
+            ("plain", context.agg_batch(sample, mask), ora.agg_batch(sample, mask)),
+            ("range", context.agg_batch_range(sample, t_lo, t_hi, mask), ora.agg_batch_range(sample, t_lo, t_hi, mask))):
+        if (got.count, bits(got.min), bits(got.max)) != (expected.count, bits(expected.min), bits(expected.max)):
+            raise SystemExit(f"VERIFICATION FAILED: {label} aggregates: COUNT/MIN/MAX {got.count, got.min, got.max} "
+                             f"but the oracle has {expected.count, expected.min, expected.max}")
+        if abs(got.sum - expected.sum) > 1e-5 * abs(expected.sum):
+            raise SystemExit(f"VERIFICATION FAILED: {label} aggregates: SUM {got.sum} but the oracle has {expected.sum}")
+        checked[label] = {"count": got.count, "sum_relative_difference": abs(got.sum - expected.sum) / max(abs(expected.sum), 1e-300)}
+    return checked
+
+
+def mixed_models(context, mdb, np, ora, args):
+    """The other model types on the record of every run: the reference's own acceptance recipe
+    (crates/modelardb_compression/src/compression.rs:733-863 over crates/modelardb_test/src/data_generation.rs:
+    108-284: runs of 50..500 points that are Constant, Linear or Random in 100..200, half of the series with noise
+    from 1.0..1.05 added, regular timestamps 100 us apart) at 10^9 points, under a lossless and a relative 1 % bound:
+    fit, grid and segment aggregates with their rates against the HBM peak, the segment mix, and the first series
+    fitted and reconstructed by the oracle."""
+    import datagen
+    points = 1_000_000
+    distinct = max(2, min(64, args.mixed_points // points // 2 * 2))
+    copies = max(1, args.mixed_points // (distinct * points))
+    series, total = distinct * copies, distinct * copies * points
+    host_values = np.concatenate([datagen.mixed_series(points, 1000 + s, (1.0, 1.05) if s % 2 else None)[1]
+                                  for s in range(distinct)])
+    values = context.dev_alloc(4 * total)
+    for copy in range(copies):
+        context.lib.mdb_dev_upload(context.handle, values + 4 * copy * distinct * points,
+                                   host_values.ctypes.data, host_values.nbytes)
+    starts = np.arange(0, points, CHUNK_POINTS, dtype=np.uint64)
+    offsets = np.concatenate([(s * points + starts) for s in range(series)] + [np.array([total], dtype=np.uint64)]).astype(np.uint64)
+    first_index = np.tile(starts, series)
+    offsets_dev, first_index_dev = context.upload_array(offsets), context.upload_array(first_index)
+    n_chunks = len(offsets) - 1
+    chunks_per_series = len(starts)
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    sample_ts = np.arange(points, dtype=np.int64) * 100
+    out = {"points": total, "series": series, "distinct_series": distinct,
+           "note": "the reference's acceptance recipe (compression.rs:733-863): runs of 50..500 points, Constant / Linear "
+                   "/ Random(100..200), every second series with noise 1.0..1.05 added, regular timestamps; chunks of "
+                   "65 536 points; fit: second of two calls; grid and aggregates: median of 5 calls on the resident "
+                   "segments; bytes: 4 B/point read by the fit, 73 B/segment + out-of-line payloads + 12 B/point for "
+                   "grid, 73 B/segment + out-of-line payloads for the aggregates; checked: the first two series "
+                   "(one without, one with noise) fitted by the oracle == the GPU's segments, their grid == the "
+                   "oracle's, COUNT == points"}
+    for label, eb in (("lossless", mdb.error_bound("lossless")), ("relative_1_percent", mdb.error_bound("relative", 1.0))):
+        context.compress_chunks_dev(0, values, offsets_dev, n_chunks, eb, 0, 100, first_index_dev).free()
+        context.sync()
+        context.profile_enable(True); context.profile_reset()
+        started = time.perf_counter()
+        segments = context.compress_chunks_dev(0, values, offsets_dev, n_chunks, eb, 0, 100, first_index_dev)
+        context.sync()
+        fit_seconds = time.perf_counter() - started
+        fit_kernels = {k: round(v[1], 3) for k, v in context.profile().items() if v[1] > 0.05}
+        context.profile_enable(False)
+        n = context.grid_count_dev(segments)
+        if n != total:
+            raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: {n} points in the segments, {total} fitted")
+        seg = segments.seg
+        payload_bytes = sum(int(col.buffer_sizes[b]) for col in (seg.timestamps, seg.values, seg.residuals)
+                            for b in range(col.n_buffers))
+        out_ts, out_val = context.dev_alloc(8 * n), context.dev_alloc(4 * n)
+        shape = {"segments": len(segments), "out_of_line_payload_bytes": payload_bytes,
+                 "fit": {"ms": 1e3 * fit_seconds, "points_per_s": total / fit_seconds, "kernels_ms": fit_kernels,
+                         "GB_per_s": 4.0 * total / fit_seconds / 1e9, "frac_of_hbm_peak": 4.0 * total / fit_seconds / 1e9 / HBM_PEAK_GBPS}}
+        for name, call, algorithmic in (
+                ("grid", lambda: context.grid_batch_dev(segments, out_ts, out_val, n), 73.0 * len(segments) + payload_bytes + 12.0 * n),
+                ("aggregates", lambda: context.agg_batch_dev(segments, mask), 73.0 * len(segments) + payload_bytes)):
+            result = call()
+            context.profile_enable(True); context.profile_reset()
+            timings = []
+            for _ in range(5):
+                context.sync(); started = time.perf_counter()
+                result = call()
+                context.sync(); timings.append(time.perf_counter() - started)
+            seconds = statistics.median(timings)
+            shape[name] = {"ms": 1e3 * seconds, "values_per_s": n / seconds, "GB_per_s": algorithmic / seconds / 1e9,
+                           "frac_of_hbm_peak": algorithmic / seconds / 1e9 / HBM_PEAK_GBPS,
+                           "kernels_ms": {k: round(v[1] / v[0], 3) for k, v in context.profile().items() if v[1] / v[0] > 0.05}}
+            context.profile_enable(False)
+            if name == "grid":
+                shape["segment_mix"] = result[1]
+            elif result.count != total:
+                raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: COUNT {result.count} of {total} points")
+        # the first two series (without and with noise) against the oracle: segments byte for byte, points bit for bit
+        downloaded = segments.download()
+        for s in range(2):
+            gpu_segments = downloaded.take(np.nonzero((downloaded.chunk_index >= s * chunks_per_series) &
+                                                      (downloaded.chunk_index < (s + 1) * chunks_per_series))[0])
+            series_values = host_values[s * points:(s + 1) * points]
+            series_offsets = np.concatenate([starts, [points]]).astype(np.uint64)
+            expected = ora.compress_chunks(sample_ts, series_values, series_offsets, eb)
+            if not gpu_segments.identical(expected):
+                raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: the segments of series {s} differ from the oracle's")
+            expected_ts, expected_values = ora.grid_batch(expected)[:2]
+            got_ts = context.download_array(out_ts, points, np.int64, offset_elements=s * points)
+            got_values = context.download_array(out_val, points, np.float32, offset_elements=s * points)
+            if not (np.array_equal(got_ts, expected_ts) and np.array_equal(got_values.view(np.uint32), expected_values.view(np.uint32))):
+                raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: the grid of series {s} differs from the oracle's")
+        del downloaded
+        out[label] = shape
+        for pointer in (out_ts, out_val):
+            context.dev_free(pointer)
+        segments.free()
+    for pointer in (values, offsets_dev, first_index_dev):
+        context.dev_free(pointer)
+    return out
+
+
 PHASES = {}
 
 
@@ -388,265 +533,302 @@ def claim_stdout():
     return original
 
 
-def main():
-    args = parse_args()
-    launch_ranks_if_needed(args)
-    result_fd = claim_stdout()
-    with phase("init_distributed"):
-        rank, local_rank, world, dist = init_distributed(args)
-    import numpy as np
-    import torch
+class GpuWorkload:
+    """BASELINE configs[1] on one rank's GPU: build = fit on the GPU (setup), step = grid() of all resident
+    segments into resident columns, report = roofline of the dominant kernel from HIP events, the segment
+    aggregates merged over RCCL (a collective: every rank), and - on rank 0 only - the CPU legs, the
+    verification against the oracle and the secondary blocks."""
 
-    import modelardb_rs_amd as mdb
-    from modelardb_rs_amd import sharding
+    def __init__(self, args, rank, local_rank, world, dist):
+        import numpy as np
+        import modelardb_rs_amd as mdb
+        from modelardb_rs_amd import sharding
+        self.args, self.rank, self.local_rank, self.world, self.dist = args, rank, local_rank, world, dist
+        self.np, self.mdb = np, mdb
+        self.context = mdb.Context(local_rank)
+        self.info = self.context.device_info()
+        with phase("comm_init"):
+            sharding.init_comm(self.context, dist)  # the C ABI's own RCCL communicator (mdb_comm_init)
+        self.verify = rank == 0 and not args.no_cpu_baseline
+        self.parts, self.out_ts, self.out_val = [], None, None
 
-    context = mdb.Context(local_rank)
-    info = context.device_info()
-    with phase("comm_init"):
-        sharding.init_comm(context, dist)  # the C ABI's own RCCL communicator (mdb_comm_init)
-    verify = rank == 0 and not args.no_cpu_baseline
+    def sync(self):
+        import torch
+        self.context.sync()
+        torch.cuda.synchronize()
 
-    # ---- build the workload: fit on the GPU, keep the segments in HBM ---------------------------
-    n_fit_sample = min(args.fit_sample_series, args.series) if verify else 0
-    with phase("generate_and_fit"):
-        parts, fit_seconds, fit_points, fit_kernel_ms, fit_sample_values = fit_on_gpu(
-            context, mdb, np, args, rank, n_fit_sample)
-    n_segments = sum(len(p) for p in parts)
+    def build(self):
+        args, context, np = self.args, self.context, self.np
+        self.n_fit_sample = min(args.fit_sample_series, args.series) if self.verify else 0
+        with phase("generate_and_fit"):
+            (self.parts, self.fit_seconds, self.fit_points, self.fit_kernel_ms,
+             self.fit_sample_values) = fit_on_gpu(context, self.mdb, np, args, self.rank, self.n_fit_sample)
+        self.n_segments = sum(len(p) for p in self.parts)
+        self.total_points = sum(context.grid_count_dev(part) for part in self.parts)
+        assert self.total_points == args.series * args.points, (self.total_points, args.series * args.points)
+        self.out_ts = context.dev_alloc(8 * self.total_points)
+        self.out_val = context.dev_alloc(4 * self.total_points)
+        self.ranged = 0.0 < args.range_middle < 1.0
+        self.step_lo = int(args.points * (0.5 - args.range_middle / 2)) * INTERVAL_US
+        self.step_hi = int(args.points * (0.5 + args.range_middle / 2)) * INTERVAL_US
+        settle_until = time.perf_counter() + args.settle_seconds
+        while time.perf_counter() < settle_until:
+            self.step()
+            context.sync()
 
-    total_points = 0
-    for part in parts:
-        total_points += context.grid_count_dev(part)
-    assert total_points == args.series * args.points, (total_points, args.series * args.points)
-    out_ts = context.dev_alloc(8 * total_points)
-    out_val = context.dev_alloc(4 * total_points)
-
-    ranged = 0.0 < args.range_middle < 1.0
-    step_lo = int(args.points * (0.5 - args.range_middle / 2)) * INTERVAL_US
-    step_hi = int(args.points * (0.5 + args.range_middle / 2)) * INTERVAL_US
-
-    def step():
-        at = 0
-        metrics_total = None
-        for part in parts:
-            if ranged:
-                n, metrics = context.grid_batch_range_dev(part, step_lo, step_hi, out_ts + 8 * at,
-                                                          out_val + 4 * at, total_points - at)
+    def step(self):
+        context, at, metrics_total = self.context, 0, None
+        for part in self.parts:
+            if self.ranged:
+                n, metrics = context.grid_batch_range_dev(part, self.step_lo, self.step_hi, self.out_ts + 8 * at,
+                                                          self.out_val + 4 * at, self.total_points - at)
             else:
-                n, metrics = context.grid_batch_dev(part, out_ts + 8 * at, out_val + 4 * at,
-                                                    total_points - at)
+                n, metrics = context.grid_batch_dev(part, self.out_ts + 8 * at, self.out_val + 4 * at,
+                                                    self.total_points - at)
             at += n
             if metrics_total is None:
                 metrics_total = dict(metrics)
             else:
                 for key, value in metrics.items():
                     metrics_total[key] += value
-        return at, metrics_total
+        self.produced, self.metrics = at, metrics_total
+        return at
 
-    settle_until = time.perf_counter() + args.settle_seconds
-    while time.perf_counter() < settle_until:
-        step()
-        context.sync()
-    for _ in range(args.warmup):
-        step()
-    barrier_and_sync(context, dist)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        produced, metrics = step()
-    barrier_and_sync(context, dist)
-    own_elapsed = time.perf_counter() - t0
-    assert ranged or produced == total_points
-    points_per_step = produced
+    def report(self, elapsed, per_rank_seconds):
+        args, context, np, mdb, dist = self.args, self.context, self.np, self.mdb, self.dist
+        rank, world, parts = self.rank, self.world, self.parts
+        ranged, step_lo, step_hi = self.ranged, self.step_lo, self.step_hi
+        total_points, n_segments, out_ts, out_val = self.total_points, self.n_segments, self.out_ts, self.out_val
+        assert ranged or self.produced == total_points
+        points_per_step = self.produced
+        metrics = self.metrics
 
-    # MAX over ranks (and every rank's own time, for the min/max on the line).
-    t = torch.tensor([own_elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    gathered = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(gathered, t)
-    per_rank_seconds = [float(x.item()) for x in gathered]
-    elapsed = max(per_rank_seconds)
+        # ---- roofline of the dominant kernel: HIP events on the launch stream ------------------------
+        context.profile_enable(True)
+        context.profile_reset()
+        for _ in range(args.steps):
+            self.step()
+        profile = context.profile()
+        context.profile_enable(False)
+        launches, total_ms = profile.get("k_grid_tiles", (0, 0.0))
+        kernel_ms = total_ms / max(launches, 1)
+        # Algorithmic bytes of one launch (SURVEY 8(d) / BASELINE.md 3): 73 B per segment read + payloads
+        # larger than 12 B (out of line) + 12 B per reconstructed point written. The tile kernel itself
+        # reads a 48 B descriptor + 8 B offset per segment instead of the raw 73 B (the prepass did that),
+        # so pricing it at 73 B/segment + 12 B/point is the figure the contract names.
+        points_per_launch = points_per_step / len(parts)
+        segments_per_launch = n_segments / len(parts)
+        algorithmic_bytes = 73.0 * segments_per_launch + 12.0 * points_per_launch
+        achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(args, points_per_launch, segments_per_launch)
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream ------------------------
-    context.profile_enable(True)
-    context.profile_reset()
-    for _ in range(args.steps):
-        step()
-    profile = context.profile()
-    context.profile_enable(False)
-    launches, total_ms = profile.get("k_grid_tiles", (0, 0.0))
-    kernel_ms = total_ms / max(launches, 1)
-    # Algorithmic bytes of one launch (SURVEY 8(d) / BASELINE.md 3): 73 B per segment read + payloads
-    # larger than 12 B (out of line) + 12 B per reconstructed point written. The tile kernel itself
-    # reads a 48 B descriptor + 8 B offset per segment instead of the raw 73 B (the prepass did that),
-    # so pricing it at 73 B/segment + 12 B/point is the figure the contract names.
-    points_per_launch = points_per_step / len(parts)
-    segments_per_launch = n_segments / len(parts)
-    algorithmic_bytes = 73.0 * segments_per_launch + 12.0 * points_per_launch
-    achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic, traffic_note = pmc_traffic(args, points_per_launch, segments_per_launch)
+        # ---- the segment aggregates (BASELINE config 3) on the same resident segments: median of 5 -----
+        mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+        t_lo, t_hi = (args.points // 4) * INTERVAL_US, (3 * args.points // 4) * INTERVAL_US
+        payload_bytes = sum(int(col.buffer_sizes[b]) for part in parts
+                            for col in (part.seg.timestamps, part.seg.values, part.seg.residuals)
+                            for b in range(col.n_buffers))
+        agg_bytes = 73.0 * n_segments + payload_bytes
 
-    # ---- secondary measurements on the same resident segments (not the headline) ----------------
-    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
-    t_lo, t_hi = (args.points // 4) * INTERVAL_US, (3 * args.points // 4) * INTERVAL_US
-    for part in parts:  # warm
-        context.agg_batch_dev(part, mask)
-    context.profile_enable(True)
-    context.profile_reset()
-    barrier_and_sync(context, dist)
-    t0 = time.perf_counter()
-    state = None
-    for part in parts:
-        state = context.agg_batch_dev(part, mask, state)
-    context.sync()
-    agg_seconds = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    range_state = None
-    for part in parts:
-        range_state = context.agg_batch_range_dev(part, t_lo, t_hi, mask, range_state)
-    context.sync()
-    range_seconds = time.perf_counter() - t0
-    agg_profile = context.profile()
-    context.profile_enable(False)
-    # The one exchange step of the path: merge the per-GPU aggregate partials with the C ABI's
-    # mdb_agg_all_reduce (one 32-byte ncclAllGather over RCCL / xGMI + a rank-ordered fold).
-    local_state = mdb._abi.AggStateC(state.sum, state.count, state.min, state.max)
-    context.agg_all_reduce(state)  # first collective on the communicator: connection set-up
-    t0 = time.perf_counter()
-    state, ranks_seen = context.agg_all_reduce(local_state)
-    range_state, _ = context.agg_all_reduce(range_state)
-    reduce_seconds = (time.perf_counter() - t0) / 2
-    assert ranks_seen == world, (ranks_seen, world)
-    assert state.count == world * total_points, (state.count, world * total_points)
-    aggregates = {
-        "segments_per_s": n_segments / agg_seconds,
-        "seconds": agg_seconds,
-        "kernel_ms": agg_profile.get("k_agg_segments", (1, 0.0))[1] / max(agg_profile.get("k_agg_segments", (1, 0.0))[0], 1),
-        "result": {"count": state.count, "min": state.min, "max": state.max, "sum": state.sum,
-                   "avg": state.sum / max(state.count, 1)},
-        "range": {"t_lo": t_lo, "t_hi": t_hi, "seconds": range_seconds,
-                  "segments_per_s": n_segments / range_seconds,
-                  "kernel_ms": agg_profile.get("k_agg_range", (1, 0.0))[1] / max(agg_profile.get("k_agg_range", (1, 0.0))[0], 1),
-                  "count": range_state.count, "min": range_state.min, "max": range_state.max, "sum": range_state.sum},
-        "final_reduce_seconds": reduce_seconds,
-        "note": "COUNT/MIN/MAX/SUM on the resident segments (BASELINE config 3: no grid); the range "
-                "variant clips to the middle half of the time axis; the partials of all ranks are merged "
-                "by mdb_agg_all_reduce (C ABI): one 32-byte all-gather over RCCL per merge",
-    }
+        def timed_aggregates(call):
+            for part in parts:  # warm
+                call(part, None)
+            context.profile_enable(True)
+            context.profile_reset()
+            seconds, state = [], None
+            for _ in range(5):
+                context.sync()
+                started = time.perf_counter()
+                state = None
+                for part in parts:
+                    state = call(part, state)
+                context.sync()
+                seconds.append(time.perf_counter() - started)
+            kernels = {name: ms / max(n, 1) for name, (n, ms) in context.profile().items()}
+            context.profile_enable(False)
+            return state, seconds, kernels
 
-    # ---- in-run verification + CPU baseline: the oracle on a bounded sample -----------------------
-    cpu_baseline = None
-    fit_cpu = None
-    verified = None
-    host_path_result = None
-    irregular_result = None
-    if verify:
-        import oracle_lib as ora
-        cores = os.cpu_count() or 1
-        eb = mdb.error_bound("relative", args.error_bound)
-        chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
-        with phase("download_segments"):
-            downloaded = parts[0].download()
-        n_sample = min(args.cpu_sample_series, args.series)
-        # Whole leading series: segments are ordered by chunk, chunks by series.
-        sample = downloaded.take(np.nonzero(downloaded.chunk_index < n_sample * chunks_per_series)[0])
-        with phase("cpu_baseline_grid"):
-            ts_cpu, val_cpu, cpu_seconds = ora.grid_batch_timed(sample, cores, repetitions=3)
-            single = downloaded.take(np.nonzero(downloaded.chunk_index < chunks_per_series)[0])
-            ts_single, _, single_seconds = ora.grid_batch_timed(single, 1, repetitions=3)
-        rates = summary(cpu_seconds, len(ts_cpu))
-        cpu_baseline = {
-            "value": rates["median"], "min": rates["min"], "max": rates["max"],
-            "repetitions": rates["repetitions"],
-            "unit": "values/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": f"grid() of the first {n_sample} series ({len(ts_cpu)} points, {len(sample)} "
-                      f"segments) of the same workload, segment ranges sharded over {cores} host "
-                      f"threads; median of 3 timed passes after one untimed pass",
-            "threads": f"{cores} worker threads, worker w pinned to the w-th allowed CPU; NUMA: Linux "
-                       "first-touch, every worker first-touches (untimed pass) the output pages it writes",
-            "single_thread_value": summary(single_seconds, len(ts_single))["median"],
+        state, agg_seconds, agg_kernels = timed_aggregates(lambda part, st: context.agg_batch_dev(part, mask, st))
+        range_state, range_seconds, range_kernels = timed_aggregates(
+            lambda part, st: context.agg_batch_range_dev(part, t_lo, t_hi, mask, st))
+        # The one exchange step of the path: merge the per-GPU aggregate partials with the C ABI's
+        # mdb_agg_all_reduce (one 32-byte ncclAllGather over RCCL / xGMI + a rank-ordered fold).
+        local_state = mdb._abi.AggStateC(state.sum, state.count, state.min, state.max)
+        context.agg_all_reduce(state)  # first collective on the communicator: connection set-up
+        t0 = time.perf_counter()
+        state, ranks_seen = context.agg_all_reduce(local_state)
+        range_state, _ = context.agg_all_reduce(range_state)
+        reduce_seconds = (time.perf_counter() - t0) / 2
+        assert ranks_seen == world, (ranks_seen, world)
+        assert state.count == world * total_points, (state.count, world * total_points)
+        self.ranks_seen = ranks_seen
+
+        def aggregate_roofline(seconds, kernels, name):
+            median = statistics.median(seconds)
+            kernel = kernels.get(name, 0.0)
+            return {"bound": "hbm", "kernel": name, "achieved": agg_bytes / (kernel * 1e-3) / 1e9 if kernel > 0 else 0.0,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": agg_bytes / (kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel > 0 else 0.0,
+                    "kernel_ms": kernel, "call_ms": {"median": 1e3 * median, "min": 1e3 * min(seconds), "max": 1e3 * max(seconds)},
+                    "algorithmic_bytes_per_launch": agg_bytes,
+                    "note": "73 B per segment (the columns a SUM reads) + out-of-line payloads, output O(1); "
+                            "kernel time from HIP events over 5 calls, call time = wall clock of the calls"}
+
+        aggregates = {
+            "segments_per_s": n_segments / statistics.median(agg_seconds),
+            "seconds": statistics.median(agg_seconds),
+            "kernel_ms": agg_kernels.get("k_agg_segments", 0.0),
+            "roofline": aggregate_roofline(agg_seconds, agg_kernels, "k_agg_segments"),
+            "result": {"count": state.count, "min": state.min, "max": state.max, "sum": state.sum,
+                       "avg": state.sum / max(state.count, 1)},
+            "range": {"t_lo": t_lo, "t_hi": t_hi, "seconds": statistics.median(range_seconds),
+                      "segments_per_s": n_segments / statistics.median(range_seconds),
+                      "kernel_ms": range_kernels.get("k_agg_range", 0.0),
+                      "roofline": aggregate_roofline(range_seconds, range_kernels, "k_agg_range"),
+                      "count": range_state.count, "min": range_state.min, "max": range_state.max, "sum": range_state.sum},
+            "final_reduce_seconds": reduce_seconds,
+            "note": "COUNT/MIN/MAX/SUM on the resident segments (BASELINE config 3: no grid); the range "
+                    "variant clips to the middle half of the time axis; the partials of all ranks are merged "
+                    "by mdb_agg_all_reduce (C ABI): one 32-byte all-gather over RCCL per merge",
         }
-        # grid verification: the device columns of the timed step against the oracle's, bit for bit.
-        if ranged:
-            keep = (ts_cpu >= step_lo) & (ts_cpu <= step_hi)
-            ts_cpu, val_cpu = ts_cpu[keep], val_cpu[keep]
-        grid_points_verified = 0
-        piece = 1 << 26
-        verify_started = time.perf_counter()
-        for at in range(0, len(ts_cpu), piece):
-            n_piece = min(piece, len(ts_cpu) - at)
-            got_ts = context.download_array(out_ts, n_piece, np.int64, offset_elements=at)
-            got_val = context.download_array(out_val, n_piece, np.float32, offset_elements=at)
-            if not np.array_equal(got_ts, ts_cpu[at:at + n_piece]):
-                raise SystemExit("VERIFICATION FAILED: grid timestamps differ from the oracle")
-            if not np.array_equal(got_val.view(np.uint32), val_cpu[at:at + n_piece].view(np.uint32)):
-                raise SystemExit("VERIFICATION FAILED: grid values differ from the oracle")
-            grid_points_verified += n_piece
-        del ts_cpu, val_cpu
-        # ... and at full size, a property that does not need the oracle: every one of the rank's series occupies
-        # exactly its block of the output, from its first to its last (visible) timestamp.
-        first_us = -(-step_lo // INTERVAL_US) * INTERVAL_US if ranged else 0
-        last_us = min(step_hi // INTERVAL_US, args.points - 1) * INTERVAL_US if ranged else (args.points - 1) * INTERVAL_US
-        per_series = (last_us - first_us) // INTERVAL_US + 1
-        if points_per_step != args.series * per_series:
-            raise SystemExit(f"VERIFICATION FAILED: {points_per_step} points per step, expected {args.series * per_series}")
-        for series_index in range(args.series):
-            block = series_index * per_series
-            edge = (int(context.download_array(out_ts, 1, np.int64, offset_elements=block)[0]),
-                    int(context.download_array(out_ts, 1, np.int64, offset_elements=block + per_series - 1)[0]))
-            if edge != (first_us, last_us):
-                raise SystemExit(f"VERIFICATION FAILED: series {series_index} starts / ends at {edge}")
-        PHASES["verify_grid"] = time.perf_counter() - verify_started
-        print(f"[bench] verify_grid: {PHASES['verify_grid']:.2f} s", file=sys.stderr, flush=True)
-        verify_started = time.perf_counter()
-        # fit verification: the oracle's greedy compression of the very bytes the GPU fitted.
-        n_fit = n_fit_sample
-        host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
-        offsets = np.array([s * args.points + c for s in range(n_fit)
-                            for c in range(0, args.points, CHUNK_POINTS)] + [n_fit * args.points],
-                           dtype=np.uint64)
-        import datagen
-        host_defined = np.concatenate([datagen.bench_series(rank * args.series + s, min(args.points, 1 << 20), SEED)
-                                       for s in range(n_fit)])
-        device_made = np.concatenate([fit_sample_values[s * args.points: s * args.points + min(args.points, 1 << 20)]
-                                      for s in range(n_fit)])
-        if not np.array_equal(host_defined.view(np.uint32), device_made.view(np.uint32)):
-            raise SystemExit("VERIFICATION FAILED: the device generator differs from tests/datagen.bench_series")
-        fitted, fit_cpu_seconds = ora.compress_chunks_timed(host_ts, fit_sample_values, offsets, eb, cores,
-                                                            repetitions=3)
-        gpu_fitted = downloaded.take(np.nonzero(downloaded.chunk_index < n_fit * chunks_per_series)[0])
-        if fitted.rows() != gpu_fitted.rows():
-            raise SystemExit("VERIFICATION FAILED: GPU segments differ from the oracle's")
-        fit_rates = summary(fit_cpu_seconds, n_fit * args.points)
-        fit_cpu = {"points_per_s": fit_rates["median"], "min": fit_rates["min"], "max": fit_rates["max"],
-                   "repetitions": fit_rates["repetitions"],
-                   "segments_per_s": len(fitted) / statistics.median(fit_cpu_seconds), "cores": cores,
-                   "kind": "port",
-                   "sample": f"{n_fit} series x {args.points} points, chunks sharded over {cores} pinned threads"}
-        verified = {"fit_segments": len(fitted), "fit_points": n_fit * args.points,
-                    "grid_points": grid_points_verified, "generator_points": len(host_defined),
-                    "series_blocks": args.series,
-                    "how": "after the timed region: oracle fit of the sample series' exact bytes == GPU "
-                           "segments (all columns, byte for byte); oracle grid of the sample == the device "
-                           "columns the timed step wrote (bit for bit); device generator == host definition; "
-                           "every series of the rank starts and ends its block of the output columns where it must"}
-        PHASES["verify_fit_and_cpu_baseline_fit"] = time.perf_counter() - verify_started
-        print(f"[bench] verify_fit_and_cpu_baseline_fit: {PHASES['verify_fit_and_cpu_baseline_fit']:.2f} s", file=sys.stderr, flush=True)
-        if not args.no_host_path:
-            with phase("host_path"):
-                host_path_result = host_path(context, mdb, np, downloaded, args)
-            with phase("host_path_fit"):
-                host_path_result["fit"] = host_fit(context, mdb, np, ora, host_ts, fit_sample_values, offsets, eb,
-                                                   gpu_fitted)
-        del downloaded
-        if not args.no_irregular:
-            with phase("irregular_timestamps"):
-                irregular_result = irregular_timestamps(context, mdb, np, args)
+        if rank != 0:
+            return None
 
-    if rank == 0:
+        # ---- rank 0's tail: in-run verification + CPU baseline (the oracle on a bounded sample) ---------
+        cpu_baseline = fit_cpu = verified = host_path_result = irregular_result = mixed_result = None
+        secondary = world == 1 or args.full_tail
+        if self.verify:
+            import oracle_lib as ora
+            cores, cores_how = usable_cores()
+            eb = mdb.error_bound("relative", args.error_bound)
+            chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
+            with phase("download_segments"):
+                downloaded = parts[0].download()
+            n_sample = min(args.cpu_sample_series, args.series)
+            # Whole leading series: segments are ordered by chunk, chunks by series.
+            sample = downloaded.take(np.nonzero(downloaded.chunk_index < n_sample * chunks_per_series)[0])
+            with phase("cpu_baseline_grid"):
+                ts_cpu, val_cpu, cpu_seconds = ora.grid_batch_timed(sample, cores, repetitions=3)
+                single = downloaded.take(np.nonzero(downloaded.chunk_index < chunks_per_series)[0])
+                ts_single, _, single_seconds = ora.grid_batch_timed(single, 1, repetitions=3)
+            rates = summary(cpu_seconds, len(ts_cpu))
+            single_rate = summary(single_seconds, len(ts_single))["median"]
+            cpu_baseline = {
+                "value": rates["median"], "min": rates["min"], "max": rates["max"],
+                "repetitions": rates["repetitions"],
+                "unit": "values/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"grid() of the first {n_sample} series ({len(ts_cpu)} points, {len(sample)} "
+                          f"segments) of the same workload, segment ranges sharded over {cores} host "
+                          f"threads; median of 3 timed passes after one untimed pass",
+                "threads": f"a standing pool of {cores} worker threads ({cores_how}) made by the untimed pass, worker w "
+                           "pinned to the w-th allowed CPU; NUMA: Linux first-touch, every worker first-touches "
+                           "(untimed pass) the output pages it writes",
+                "single_thread_value": single_rate,
+                "parallel_efficiency": rates["median"] / cores / single_rate if single_rate > 0 else None,
+            }
+            # grid verification: the device columns of the timed step against the oracle's, bit for bit.
+            if ranged:
+                keep = (ts_cpu >= step_lo) & (ts_cpu <= step_hi)
+                ts_cpu, val_cpu = ts_cpu[keep], val_cpu[keep]
+            grid_points_verified = 0
+            piece = 1 << 26
+            verify_started = time.perf_counter()
+            for at in range(0, len(ts_cpu), piece):
+                n_piece = min(piece, len(ts_cpu) - at)
+                got_ts = context.download_array(out_ts, n_piece, np.int64, offset_elements=at)
+                got_val = context.download_array(out_val, n_piece, np.float32, offset_elements=at)
+                if not np.array_equal(got_ts, ts_cpu[at:at + n_piece]):
+                    raise SystemExit("VERIFICATION FAILED: grid timestamps differ from the oracle")
+                if not np.array_equal(got_val.view(np.uint32), val_cpu[at:at + n_piece].view(np.uint32)):
+                    raise SystemExit("VERIFICATION FAILED: grid values differ from the oracle")
+                grid_points_verified += n_piece
+            del ts_cpu, val_cpu
+            # ... and at full size, a property that does not need the oracle: every one of the rank's series occupies
+            # exactly its block of the output, from its first to its last (visible) timestamp.
+            first_us = -(-step_lo // INTERVAL_US) * INTERVAL_US if ranged else 0
+            last_us = min(step_hi // INTERVAL_US, args.points - 1) * INTERVAL_US if ranged else (args.points - 1) * INTERVAL_US
+            per_series = (last_us - first_us) // INTERVAL_US + 1
+            if points_per_step != args.series * per_series:
+                raise SystemExit(f"VERIFICATION FAILED: {points_per_step} points per step, expected {args.series * per_series}")
+            for series_index in range(args.series):
+                block = series_index * per_series
+                edge = (int(context.download_array(out_ts, 1, np.int64, offset_elements=block)[0]),
+                        int(context.download_array(out_ts, 1, np.int64, offset_elements=block + per_series - 1)[0]))
+                if edge != (first_us, last_us):
+                    raise SystemExit(f"VERIFICATION FAILED: series {series_index} starts / ends at {edge}")
+            PHASES["verify_grid"] = time.perf_counter() - verify_started
+            print(f"[bench] verify_grid: {PHASES['verify_grid']:.2f} s", file=sys.stderr, flush=True)
+            with phase("verify_aggregates"):
+                # (a sample of the segments through the same kernels, against the oracle's per-row loops)
+                n_agg = min(8, n_sample)
+                agg_sample = downloaded.take(np.nonzero(downloaded.chunk_index < n_agg * chunks_per_series)[0])
+                aggregates["verified"] = verified_aggregates(context, mdb, np, ora, agg_sample, t_lo, t_hi)
+                aggregates["verified"]["sample"] = f"the first {n_agg} series ({len(agg_sample)} segments)"
+            verify_started = time.perf_counter()
+            # fit verification: the oracle's greedy compression of the very bytes the GPU fitted.
+            n_fit = self.n_fit_sample
+            fit_sample_values = self.fit_sample_values
+            host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
+            offsets = np.array([s * args.points + c for s in range(n_fit)
+                                for c in range(0, args.points, CHUNK_POINTS)] + [n_fit * args.points],
+                               dtype=np.uint64)
+            import datagen
+            host_defined = np.concatenate([datagen.bench_series(rank * args.series + s, min(args.points, 1 << 20), SEED)
+                                           for s in range(n_fit)])
+            device_made = np.concatenate([fit_sample_values[s * args.points: s * args.points + min(args.points, 1 << 20)]
+                                          for s in range(n_fit)])
+            if not np.array_equal(host_defined.view(np.uint32), device_made.view(np.uint32)):
+                raise SystemExit("VERIFICATION FAILED: the device generator differs from tests/datagen.bench_series")
+            fitted, fit_cpu_seconds = ora.compress_chunks_timed(host_ts, fit_sample_values, offsets, eb, cores,
+                                                                repetitions=3)
+            single_chunks = min(len(offsets) - 1, 64)
+            single_offsets = offsets[:single_chunks + 1]
+            _, fit_single_seconds = ora.compress_chunks_timed(host_ts[:int(single_offsets[-1])], fit_sample_values[:int(single_offsets[-1])],
+                                                              single_offsets, eb, 1, repetitions=3)
+            gpu_fitted = downloaded.take(np.nonzero(downloaded.chunk_index < n_fit * chunks_per_series)[0])
+            if not fitted.identical(gpu_fitted):
+                raise SystemExit("VERIFICATION FAILED: GPU segments differ from the oracle's")
+            fit_rates = summary(fit_cpu_seconds, n_fit * args.points)
+            fit_single_rate = summary(fit_single_seconds, int(single_offsets[-1]))["median"]
+            fit_cpu = {"points_per_s": fit_rates["median"], "min": fit_rates["min"], "max": fit_rates["max"],
+                       "repetitions": fit_rates["repetitions"],
+                       "segments_per_s": len(fitted) / statistics.median(fit_cpu_seconds), "cores": cores,
+                       "kind": "port", "single_thread_points_per_s": fit_single_rate,
+                       "parallel_efficiency": fit_rates["median"] / cores / fit_single_rate if fit_single_rate > 0 else None,
+                       "sample": f"{n_fit} series x {args.points} points, chunks sharded over a standing pool of {cores} pinned threads"}
+            verified = {"fit_segments": len(fitted), "fit_points": n_fit * args.points,
+                        "grid_points": grid_points_verified, "generator_points": len(host_defined),
+                        "series_blocks": args.series, "aggregates": aggregates["verified"],
+                        "how": "after the timed region: oracle fit of the sample series' exact bytes == GPU "
+                               "segments (all columns, bit patterns); oracle grid of the sample == the device "
+                               "columns the timed step wrote (bit for bit); COUNT/MIN/MAX of a sample of the segments, "
+                               "plain and over the time range, == the oracle's, SUM within 0.001 %; device generator == "
+                               "host definition; every series of the rank starts and ends its block of the output "
+                               "columns where it must"}
+            PHASES["verify_fit_and_cpu_baseline_fit"] = time.perf_counter() - verify_started
+            print(f"[bench] verify_fit_and_cpu_baseline_fit: {PHASES['verify_fit_and_cpu_baseline_fit']:.2f} s", file=sys.stderr, flush=True)
+            if secondary and not args.no_host_path:
+                with phase("host_path"):
+                    host_path_result = host_path(context, mdb, np, downloaded, args)
+                with phase("host_path_fit"):
+                    host_path_result["fit"] = host_fit(context, mdb, np, ora, host_ts, fit_sample_values, offsets, eb,
+                                                       gpu_fitted)
+            del downloaded
+            if secondary and not args.no_irregular:
+                with phase("irregular_timestamps"):
+                    irregular_result = irregular_timestamps(context, mdb, np, args)
+            if secondary and not args.no_mixed_models:
+                # (the headline's columns and segments are no longer needed: room for 10^9 points of other data)
+                with phase("mixed_models"):
+                    mixed_result = mixed_models(context, mdb, np, ora, args)
+
         value = world * points_per_step * args.steps / elapsed
+        fit_kernel_ms, fit_points, fit_seconds = self.fit_kernel_ms, self.fit_points, self.fit_seconds
         fit_models_ms = fit_kernel_ms.get("k_fit_models", 0.0) + fit_kernel_ms.get("k_fit_models_split", 0.0)
         fit_gbps = 4.0 * fit_points / (fit_models_ms * 1e-3) / 1e9 if fit_models_ms > 0 else 0.0
-        result = {
+        return {
             "metric": "gridded values/sec",
             "value": value,
             "unit": "values/s",
@@ -675,7 +857,7 @@ def main():
                 "parallelism": f"series-sharded x{world}, no data-path collective",
                 "arithmetic": "Swing values as (f64 slope * f64 t + f64 intercept) -> f32, timestamps i64; "
                               "output columns i64 + f32 (12 B/point)",
-                "device": info["name"],
+                "device": self.info["name"],
             },
             "roofline": {
                 "bound": "hbm",
@@ -697,6 +879,7 @@ def main():
             "aggregates": aggregates,
             "host_path": host_path_result,
             "irregular_timestamps": irregular_result,
+            "mixed_models": mixed_result,
             "fit": {
                 "cpu_baseline": fit_cpu,
                 "points_per_s": fit_points / fit_seconds if fit_seconds > 0 else None,
@@ -714,14 +897,81 @@ def main():
                         "in the timed region), regular timestamps synthesised on the fly",
             },
         }
-        os.write(result_fd, (json.dumps(result) + "\n").encode())
 
-    for part in parts:
-        part.free()
-    context.dev_free(out_ts)
-    context.dev_free(out_val)
-    context.close()
-    dist.destroy_process_group()
+    def free_headline_buffers(self):
+        for part in self.parts:
+            part.free()
+        self.parts = []
+        for pointer in (self.out_ts, self.out_val):
+            if pointer:
+                self.context.dev_free(pointer)
+        self.out_ts = self.out_val = None
+
+    def close(self):
+        self.free_headline_buffers()
+        self.context.close()  # (mdb_comm_close first, then the stream and the scratch)
+
+
+def orchestrate(args, make_workload, backend="nccl", result_fd=1):
+    """The rank protocol of the contract, for any workload object with build / step / sync / report / close:
+    W untimed steps, a barrier + device sync, K timed steps, a barrier + device sync, the MAX over ranks; then the
+    report (its collectives on every rank, rank 0's tail alone) and - whatever happened in the tail of whichever
+    rank - ONE meeting point: every rank says whether it is fine, all of them close their communicators and the
+    process group in the same order, rank 0 prints the line only if every rank was fine, and every rank exits
+    non-zero otherwise. A rank that dies is noticed by the others through the process group's timeout."""
+    import datetime
+    with phase("init_distributed"):
+        rank, local_rank, world, dist = init_distributed(args, backend, datetime.timedelta(seconds=args.collective_timeout))
+    import torch
+    device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+    workload, line, failure = None, None, None
+    try:
+        workload = make_workload(args, rank, local_rank, world, dist)
+        workload.build()
+        for _ in range(args.warmup):
+            workload.step()
+        workload.sync(); dist.barrier(); workload.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            workload.step()
+        workload.sync(); dist.barrier(); workload.sync()
+        own_elapsed = time.perf_counter() - t0
+        # MAX over ranks (and every rank's own time, for the min/max on the line).
+        t = torch.tensor([own_elapsed], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_seconds = [float(x.item()) for x in gathered]
+        line = workload.report(max(per_rank_seconds), per_rank_seconds)
+    except BaseException as error:  # noqa: BLE001 - reported, then the job ends non-zero on every rank
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        failure = error
+    # The meeting point (the ranks other than 0 have been here since their report() returned).
+    fine = torch.tensor([0 if failure else 1], dtype=torch.int32, device=device)
+    everyone_fine = False
+    try:
+        dist.all_reduce(fine, op=dist.ReduceOp.MIN)
+        everyone_fine = bool(fine.item())
+        dist.barrier()
+    except BaseException:  # noqa: BLE001 - a rank is gone: leave with an error, do not hang
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+    try:
+        if workload is not None:
+            workload.close()
+        dist.destroy_process_group()
+    except BaseException:  # noqa: BLE001
+        everyone_fine = False
+    if rank == 0 and everyone_fine and line is not None:
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    return 0 if everyone_fine else 1
+
+
+def main():
+    args = parse_args()
+    launch_ranks_if_needed(args)
+    result_fd = claim_stdout()
+    sys.exit(orchestrate(args, GpuWorkload, "nccl", result_fd))
 
 
 if __name__ == "__main__":

@@ -727,7 +727,10 @@ SortedJoinStream::SortedJoinStream(std::vector<Field> schema, std::vector<Sorted
                                    std::vector<std::unique_ptr<SegmentStream>> inputs,
                                    std::shared_ptr<uint64_t> output_rows)
     : schema_(std::move(schema)), return_order_(std::move(return_order)), inputs_(std::move(inputs)),
-      batches_(inputs_.size()), output_rows_(std::move(output_rows)) {}
+      batches_(inputs_.size()), output_rows_(std::move(output_rows)) {
+    const char *setting = std::getenv("MDB_HOST_SORTED_JOIN_CARRY_OVER");
+    carry_over_ = setting && std::string(setting) == "1";
+}
 
 std::optional<PollState> SortedJoinStream::poll_all_pending_inputs() {
     // Every input without a batch is polled; the last poll that was not Ready(Some) is the reason
@@ -746,18 +749,18 @@ std::optional<PollState> SortedJoinStream::poll_all_pending_inputs() {
 }
 
 void SortedJoinStream::set_batch_num_rows_to_smallest() {
-    // Inputs can differ in length (sorted_join_exec.rs:248-272): a GridStream emits a short batch
-    // whenever a predicate leaves it with fewer than batch_size points (grid_exec.rs:419-423). The
-    // reference cuts every batch to the smallest and DROPS the surplus, which also shifts every later
-    // row of that input against the others. Here the surplus is kept for the next poll instead: the
-    // output is identical whenever the inputs are aligned and when one input simply ends early
-    // (the join then ends, surplus unread), and stays row-aligned where the reference would not.
+    // Inputs can differ in length (sorted_join_exec.rs:248-272): compressed segments are not transferred
+    // atomically, and a GridStream emits a short batch whenever a predicate leaves it with fewer than batch_size
+    // points (grid_exec.rs:419-423). The reference cuts every batch to the smallest and DROPS the surplus - and
+    // so does this stream by default: results identical to the reference's. (Dropping also shifts every later row
+    // of that input against the others; MDB_HOST_SORTED_JOIN_CARRY_OVER=1 keeps the surplus for the next poll
+    // instead, which leaves the rows aligned. tests/test_host_ops_cpu.py shows both on the same inputs.)
     int64_t smallest = INT64_MAX;
     for (const auto &batch : batches_) smallest = std::min(smallest, batch->num_rows);
     surplus_.assign(batches_.size(), std::nullopt);
     for (size_t index = 0; index < batches_.size(); index++) {
         if (batches_[index]->num_rows == smallest) continue;
-        surplus_[index] = batches_[index]->slice(smallest, batches_[index]->num_rows - smallest);
+        if (carry_over_) surplus_[index] = batches_[index]->slice(smallest, batches_[index]->num_rows - smallest);
         batches_[index] = batches_[index]->slice(0, smallest);
     }
 }

@@ -303,7 +303,8 @@ class SortedJoinStream : public SegmentStream { // sorted_join_exec.rs:200-336
     std::vector<SortedJoinColumnType> return_order_;
     std::vector<std::unique_ptr<SegmentStream>> inputs_;
     std::vector<std::optional<RecordBatch>> batches_;
-    std::vector<std::optional<RecordBatch>> surplus_; // rows beyond the smallest batch, kept for the next poll
+    std::vector<std::optional<RecordBatch>> surplus_; // rows beyond the smallest batch, if they are carried over
+    bool carry_over_ = false; // MDB_HOST_SORTED_JOIN_CARRY_OVER=1 (default: dropped, as sorted_join_exec.rs:248-272 does)
     std::shared_ptr<uint64_t> output_rows_;
 };
 

@@ -131,6 +131,19 @@ class SegmentBatch:
                  float(self.min_value[i]), float(self.max_value[i]), vals[i], res[i])
                 for i in range(len(self))]
 
+    def identical(self, other):
+        """Every column of the two batches bit for bit: ids, times, payload bytes, and min / max as BIT PATTERNS
+        (as Python floats -0.0 equals 0.0 and a NaN never equals itself)."""
+        return (len(self) == len(other)
+                and np.array_equal(self.model_type_id, other.model_type_id)
+                and np.array_equal(self.start_time, other.start_time)
+                and np.array_equal(self.end_time, other.end_time)
+                and np.array_equal(self.min_value.view(np.uint32), other.min_value.view(np.uint32))
+                and np.array_equal(self.max_value.view(np.uint32), other.max_value.view(np.uint32))
+                and self.timestamps.to_bytes_list() == other.timestamps.to_bytes_list()
+                and self.values.to_bytes_list() == other.values.to_bytes_list()
+                and self.residuals.to_bytes_list() == other.residuals.to_bytes_list())
+
     def take(self, indices):
         indices = np.asarray(indices)
         return SegmentBatch(self.model_type_id[indices], self.start_time[indices],

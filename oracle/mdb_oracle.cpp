@@ -20,8 +20,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <pthread.h>
@@ -1323,30 +1326,91 @@ int ora_model_finish(const ora_model *model, mdb_error_bound eb, uint64_t residu
     return 0;
 }
 
-/* Baseline hygiene for the timed legs (bench.py's cpu_baseline): with pinning on, worker w of the
- * threaded entry points runs on the w-th CPU the process is allowed on and stays there, so a page a
- * worker touches first is and remains local to it (Linux first-touch NUMA policy). */
+/* Baseline hygiene for the timed legs (bench.py's cpu_baseline): the threaded entry points run on a STANDING
+ * pool of workers - made (and, with pinning on, pinned: worker w to the w-th CPU the process is allowed on, so
+ * that a page a worker touches first is and stays local to it under Linux's first-touch policy) by the first
+ * call that needs them, i.e. by the untimed warm-up pass, and kept for the later ones. Starting and joining 256
+ * threads twice per call cost ten times what the workers then computed. */
 static int g_pin_threads = 0;
-static void pin_worker(uint64_t w) {
-    if (!g_pin_threads) return;
-    cpu_set_t allowed;
-    CPU_ZERO(&allowed);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
-    const int count = CPU_COUNT(&allowed);
-    if (count <= 0) return;
-    int want = (int)(w % (uint64_t)count), seen = 0;
-    for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
-        if (!CPU_ISSET(cpu, &allowed)) continue;
-        if (seen++ == want) {
-            cpu_set_t one;
-            CPU_ZERO(&one);
-            CPU_SET(cpu, &one);
-            (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
-            return;
+void ora_set_thread_pinning(int enabled) { g_pin_threads = enabled != 0; }
+
+extern "C++" {
+namespace {
+class StandingPool {
+  public:
+    static StandingPool &instance() {
+        static StandingPool *pool = new StandingPool(); /* never destroyed: the workers outlive main() */
+        return *pool;
+    }
+    /* job(w) for w in [0, workers) on workers of the pool, the caller waits. One run at a time. */
+    void run(uint64_t workers, const std::function<void(uint64_t)> &call) {
+        if (workers == 0) return;
+        std::lock_guard<std::mutex> one_run(run_mutex_);
+        grow(workers);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            job_ = &call;
+            active_ = workers;
+            unfinished_ = workers;
+            generation_ += 1;
+        }
+        wake_.notify_all();
+        std::unique_lock<std::mutex> lock(mutex_);
+        done_.wait(lock, [&] { return unfinished_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void grow(uint64_t workers) {
+        if (threads_.empty()) { /* the CPUs of the process, read before any worker narrows its own mask */
+            cpu_set_t allowed;
+            CPU_ZERO(&allowed);
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+                for (int cpu = 0; cpu < CPU_SETSIZE; cpu++)
+                    if (CPU_ISSET(cpu, &allowed)) cpus_.push_back(cpu);
+        }
+        while (threads_.size() < workers) {
+            const uint64_t w = threads_.size();
+            const bool pin = g_pin_threads && !cpus_.empty();
+            const int cpu = pin ? cpus_[w % cpus_.size()] : -1;
+            uint64_t seen;
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                seen = generation_;
+            }
+            threads_.emplace_back([this, w, cpu, seen]() mutable {
+                if (cpu >= 0) {
+                    cpu_set_t one;
+                    CPU_ZERO(&one);
+                    CPU_SET(cpu, &one);
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+                }
+                for (;;) {
+                    const std::function<void(uint64_t)> *job = nullptr;
+                    {
+                        std::unique_lock<std::mutex> lock(mutex_);
+                        wake_.wait(lock, [&] { return generation_ != seen; });
+                        seen = generation_;
+                        if (w < active_) job = job_;
+                    }
+                    if (!job) continue;
+                    (*job)(w);
+                    std::lock_guard<std::mutex> lock(mutex_);
+                    if (--unfinished_ == 0) done_.notify_all();
+                }
+            });
+            threads_.back().detach();
         }
     }
-}
-void ora_set_thread_pinning(int enabled) { g_pin_threads = enabled != 0; }
+    std::mutex run_mutex_, mutex_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> threads_;
+    std::vector<int> cpus_;
+    const std::function<void(uint64_t)> *job_ = nullptr;
+    uint64_t active_ = 0, unfinished_ = 0, generation_ = 0;
+};
+} /* namespace */
+} /* extern "C++" */
 
 int ora_compress_chunks(const int64_t *ts, const float *v, const uint64_t *chunk_offsets,
                         uint64_t n_chunks, mdb_error_bound eb, int n_threads,
@@ -1360,19 +1424,13 @@ int ora_compress_chunks(const int64_t *ts, const float *v, const uint64_t *chunk
     } else {
         uint64_t workers = std::min<uint64_t>((uint64_t)n_threads, n_chunks);
         std::vector<OwnedBatch> parts(workers);
-        std::vector<std::thread> threads;
-        for (uint64_t w = 0; w < workers; w++) {
-            threads.emplace_back([&, w]() {
-                pin_worker(w);
-                uint64_t begin = n_chunks * w / workers;
-                uint64_t end = n_chunks * (w + 1) / workers;
-                for (uint64_t c = begin; c < end; c++)
-                    compress_univariate(ts + chunk_offsets[c], v + chunk_offsets[c],
-                                        chunk_offsets[c + 1] - chunk_offsets[c], eb, parts[w],
-                                        (uint32_t)c);
-            });
-        }
-        for (auto &t : threads) t.join();
+        StandingPool::instance().run(workers, [&](uint64_t w) {
+            uint64_t begin = n_chunks * w / workers;
+            uint64_t end = n_chunks * (w + 1) / workers;
+            for (uint64_t c = begin; c < end; c++)
+                compress_univariate(ts + chunk_offsets[c], v + chunk_offsets[c],
+                                    chunk_offsets[c + 1] - chunk_offsets[c], eb, parts[w], (uint32_t)c);
+        });
         for (auto &p : parts) batch->append_all(p);
     }
     *out = batch->seal();
@@ -1437,69 +1495,59 @@ int ora_grid_batch_mt(const mdb_segments *in, int64_t *out_ts, float *out_val, u
      * write straight into the output at the right offset. Pass 2 is GridStream's per-row loop
      * (grid_exec.rs:323-356): grid one row into a builder, append it to the output. */
     const uint64_t workers = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_threads, in->n));
-    std::vector<uint64_t> counts(workers, 0);
-    std::vector<int> failed(workers, 0);
+    struct alignas(128) PerWorker { /* (a cache line of its own: 256 workers' counters side by side would share 32) */
+        uint64_t count = 0;
+        uint64_t offset = 0;
+        int failed = 0;
+    };
+    std::vector<PerWorker> per_worker(workers);
     auto range = [&](uint64_t w, uint64_t *begin, uint64_t *end) {
         *begin = in->n * w / workers;
         *end = in->n * (w + 1) / workers;
     };
-    {
-        std::vector<std::thread> threads;
-        for (uint64_t w = 0; w < workers; w++) {
-            threads.emplace_back([&, w]() {
-                pin_worker(w);
-                uint64_t begin, end;
-                range(w, &begin, &end);
-                for (uint64_t row = begin; row < end; row++) {
-                    const uint8_t *ts;
-                    uint64_t ts_len, count;
-                    if (!view_bytes(in->timestamps, row, &ts, &ts_len) ||
-                        !decompressed_timestamp_count(in->start_time[row], in->end_time[row], ts, ts_len, &count)) {
-                        failed[w] = 1;
-                        return;
-                    }
-                    counts[w] += count;
-                }
-            });
+    StandingPool::instance().run(workers, [&](uint64_t w) {
+        uint64_t begin, end, sum = 0;
+        range(w, &begin, &end);
+        for (uint64_t row = begin; row < end; row++) {
+            const uint8_t *ts;
+            uint64_t ts_len, count;
+            if (!view_bytes(in->timestamps, row, &ts, &ts_len) ||
+                !decompressed_timestamp_count(in->start_time[row], in->end_time[row], ts, ts_len, &count)) {
+                per_worker[w].failed = 1;
+                return;
+            }
+            sum += count;
         }
-        for (auto &t : threads) t.join();
-    }
+        per_worker[w].count = sum;
+    });
     uint64_t total = 0;
-    std::vector<uint64_t> offsets(workers, 0);
     for (uint64_t w = 0; w < workers; w++) {
-        if (failed[w]) return fail("Malformed compressed timestamps.");
-        offsets[w] = total;
-        total += counts[w];
+        if (per_worker[w].failed) return fail("Malformed compressed timestamps.");
+        per_worker[w].offset = total;
+        total += per_worker[w].count;
     }
     *n_out = total;
     if (total > cap) return fail("Output buffer too small.");
-    {
-        std::vector<std::thread> threads;
-        for (uint64_t w = 0; w < workers; w++) {
-            threads.emplace_back([&, w]() {
-                pin_worker(w);
-                uint64_t begin, end;
-                range(w, &begin, &end);
-                std::vector<int64_t> ts_builder;
-                std::vector<float> value_builder;
-                uint64_t at = offsets[w];
-                for (uint64_t row = begin; row < end; row++) {
-                    ts_builder.clear();
-                    value_builder.clear();
-                    if (!grid_row(in, row, ts_builder, value_builder)) {
-                        failed[w] = 1;
-                        return;
-                    }
-                    std::memcpy(out_ts + at, ts_builder.data(), ts_builder.size() * sizeof(int64_t));
-                    std::memcpy(out_val + at, value_builder.data(), value_builder.size() * sizeof(float));
-                    at += ts_builder.size();
-                }
-            });
+    StandingPool::instance().run(workers, [&](uint64_t w) {
+        uint64_t begin, end;
+        range(w, &begin, &end);
+        std::vector<int64_t> ts_builder;
+        std::vector<float> value_builder;
+        uint64_t at = per_worker[w].offset;
+        for (uint64_t row = begin; row < end; row++) {
+            ts_builder.clear();
+            value_builder.clear();
+            if (!grid_row(in, row, ts_builder, value_builder)) {
+                per_worker[w].failed = 1;
+                return;
+            }
+            std::memcpy(out_ts + at, ts_builder.data(), ts_builder.size() * sizeof(int64_t));
+            std::memcpy(out_val + at, value_builder.data(), value_builder.size() * sizeof(float));
+            at += ts_builder.size();
         }
-        for (auto &t : threads) t.join();
-    }
+    });
     for (uint64_t w = 0; w < workers; w++)
-        if (failed[w]) return fail("Malformed segment or unknown model type.");
+        if (per_worker[w].failed) return fail("Malformed segment or unknown model type.");
     return 0;
 }
 

@@ -70,6 +70,34 @@ def generate_univariate_time_series(length, segment_length_range, irregular, noi
     return timestamps, values[:length]
 
 
+def mixed_series(length, seed, noise_range=None, segment_length_range=(50, 501), random_value_range=(100.0, 200.0),
+                 interval=100):
+    """The same recipe as generate_univariate_time_series with regular timestamps (runs of 50..500 points that
+    are Constant, Linear or Random, data_generation.rs:108-284; compression.rs:733-863 uses exactly these
+    ranges), vectorised so that bench.py can make 10^8 points of it. Returns (timestamps, values)."""
+    rng = np.random.default_rng(seed)
+    n_runs = length // segment_length_range[0] + 1
+    run_lengths = rng.integers(segment_length_range[0], segment_length_range[1], n_runs)
+    run_ends = np.cumsum(run_lengths)
+    n_runs = int(np.searchsorted(run_ends, length)) + 1
+    run_lengths = run_lengths[:n_runs]
+    structure = rng.integers(0, 3, n_runs)
+    constant = rng.random(n_runs, dtype=np.float32)
+    slope = rng.integers(-10, 9, n_runs)
+    slope = np.where(slope >= 0, slope + 1, slope)            # -10..10 without 0
+    intercept = rng.integers(1, 50, n_runs)
+    run_of_point = np.repeat(np.arange(n_runs), run_lengths)[:length]
+    timestamps = np.arange(length, dtype=np.int64) * interval
+    values = np.where(structure[run_of_point] == 0, constant[run_of_point],
+                      (slope[run_of_point] * timestamps + intercept[run_of_point]).astype(np.float32))
+    if noise_range is not None:
+        noise = rng.uniform(noise_range[0], noise_range[1], length).astype(np.float32)
+        values = (values.astype(np.float32) + noise).astype(np.float32)
+    random = rng.uniform(random_value_range[0], random_value_range[1], length).astype(np.float32)
+    values = np.where(structure[run_of_point] == 2, random, values).astype(np.float32)
+    return timestamps, values
+
+
 def sine_series(series_index, n_points, seed=0x4D44425F52454631, t0=0, delta=1000):
     """SURVEY 8(d) benchmark recipe evaluated on the host in f64 then rounded to f32:
     v = 100 + 10 sin(2 pi i / P_s + phi_s) + u, P_s = 2000 + 37 (s mod 64),

@@ -63,3 +63,44 @@ def test_world_size_must_match_gpus(monkeypatch):
     monkeypatch.setenv("RANK", "0")
     with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
         bench.init_distributed(_args(8))
+
+
+def _run_two_ranks(fail_on=None):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    environment = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if fail_on:
+        environment["FAIL_ON"] = fail_on
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           os.path.join(root, "tests", "stub", "run_bench_orchestration.py")],
+                          env=environment, capture_output=True, text=True, timeout=300)
+
+
+def test_two_ranks_over_gloo_meet_close_in_order_and_print_one_line():
+    """bench.orchestrate() at WORLD_SIZE = 2 (gloo, a canned workload): warm-up, barrier, K timed steps, barrier,
+    MAX over ranks; the report's collective on every rank, rank 0's tail alone while rank 1 waits at the meeting
+    point; every rank closes its workload; ONE line, n_gpus 2, both states seen, exit code 0."""
+    import json
+    done = _run_two_ranks()
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["steps"] == 3
+    assert line["aggregates"]["result"]["count"] == 2_000_000
+    assert line["value"] > 0 and line["ms_per_step_per_rank"]["max"] >= line["ms_per_step_per_rank"]["min"]
+    assert "rank 0 closed" in done.stderr and "rank 1 closed" in done.stderr
+
+
+@pytest.mark.parametrize("fail_on", ["1:step", "0:tail"])
+def test_a_failing_rank_ends_the_job_non_zero_without_a_line(fail_on):
+    """Whichever rank fails, wherever: no JSON line, a non-zero exit, nobody hangs (the survivors leave through
+    the meeting point, or through the process group's timeout when the failing rank never gets there)."""
+    done = _run_two_ranks(fail_on)
+    assert done.returncode != 0
+    assert not [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert "asked to" in done.stderr

@@ -97,25 +97,41 @@ def test_sorted_join_stream_zips_fields_in_return_order():
     assert "output_rows=3" in join.describe()
 
 
-def test_sorted_join_stream_poll_protocol_and_smallest_batch():
-    join = host.SortedJoinStream(None, 2, ["timestamp", "field", "field"], tag_names=("tag",), use_grid=False)
-    assert join.poll_next() == (host.SortedJoinStream.PENDING, None)
-    join.push(0, _points([1, 2, 3, 4], [1.0, 2.0, 3.0, 4.0], "A"))
-    assert join.poll_next() == (host.SortedJoinStream.PENDING, None)   # input 1 has nothing yet; batch 0 kept
-    join.push(1, _points([1, 2], [5.0, 6.0], "A"))
-    state, batch = join.poll_next()
-    # Inputs of different length are cut to the smallest (sorted_join_exec.rs:248-272) ...
-    assert state == host.SortedJoinStream.READY_SOME and batch.num_rows == 2
-    assert batch.column(0).cast("int64").to_pylist() == [1, 2]
-    assert batch.column(2).to_pylist() == [5.0, 6.0]
-    # ... and the surplus of the longer one waits for the next poll, so the rows stay aligned.
-    join.push(1, _points([3], [7.0], "A"))
-    state, batch = join.poll_next()
-    assert state == host.SortedJoinStream.READY_SOME
-    assert batch.column(0).cast("int64").to_pylist() == [3] and batch.column(2).to_pylist() == [7.0]
-    join.finish_input(1)
-    assert join.poll_next() == (host.SortedJoinStream.READY_NONE, None)  # a finished input ends the join
-    join.close()
+def test_sorted_join_stream_poll_protocol_and_smallest_batch(monkeypatch):
+    import pytest
+    for carry_over in (False, True):
+        if carry_over:
+            monkeypatch.setenv("MDB_HOST_SORTED_JOIN_CARRY_OVER", "1")
+        else:
+            monkeypatch.delenv("MDB_HOST_SORTED_JOIN_CARRY_OVER", raising=False)
+        join = host.SortedJoinStream(None, 2, ["timestamp", "field", "field"], tag_names=("tag",), use_grid=False)
+        assert join.poll_next() == (host.SortedJoinStream.PENDING, None)
+        join.push(0, _points([1, 2, 3, 4], [1.0, 2.0, 3.0, 4.0], "A"))
+        assert join.poll_next() == (host.SortedJoinStream.PENDING, None)   # input 1 has nothing yet; batch 0 kept
+        join.push(1, _points([1, 2], [5.0, 6.0], "A"))
+        state, batch = join.poll_next()
+        # Inputs of different length are cut to the smallest (sorted_join_exec.rs:248-272) ...
+        assert state == host.SortedJoinStream.READY_SOME and batch.num_rows == 2
+        assert batch.column(0).cast("int64").to_pylist() == [1, 2]
+        assert batch.column(2).to_pylist() == [5.0, 6.0]
+        join.push(1, _points([3], [7.0], "A"))
+        if carry_over:
+            # ... and with the switch the surplus of the longer one waits for the next poll: the rows stay aligned.
+            state, batch = join.poll_next()
+            assert state == host.SortedJoinStream.READY_SOME
+            assert batch.column(0).cast("int64").to_pylist() == [3] and batch.column(2).to_pylist() == [7.0]
+        else:
+            # ... and by default the surplus is DROPPED, as the reference drops it (rows 3 and 4 of input 0 are
+            # gone): the join waits for a new batch of input 0, and pairs whatever comes with input 1's next rows.
+            assert join.poll_next() == (host.SortedJoinStream.PENDING, None)
+            join.push(0, _points([5, 6], [5.5, 6.5], "A"))
+            state, batch = join.poll_next()
+            assert state == host.SortedJoinStream.READY_SOME
+            assert batch.column(0).cast("int64").to_pylist() == [5] and batch.column(2).to_pylist() == [7.0]
+        join.finish_input(1)
+        if carry_over:
+            assert join.poll_next() == (host.SortedJoinStream.READY_NONE, None)  # a finished input ends the join
+        join.close()
 
 
 def test_sorted_join_exec_plan_surface():
