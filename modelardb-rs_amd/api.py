@@ -345,6 +345,25 @@ class Context:
             C.c_void_p(rows_ptr), cap, C.byref(n_out), C.byref(metrics)))
         return n_out.value, metrics.as_dict()
 
+    def grid_resident(self, dev_segments, time_range=None):
+        """grid() of a batch that is resident on the device into device columns, downloaded for the tests:
+        (timestamps, values). The path a server with its segments in HBM takes (mdb_grid_batch[_range]_dev)."""
+        if time_range is None:
+            n = self.grid_count_dev(dev_segments)
+        else:
+            n = self.grid_count_range_dev(dev_segments, *time_range)
+        out_ts, out_val = self.dev_alloc(8 * max(n, 1)), self.dev_alloc(4 * max(n, 1))
+        try:
+            if time_range is None:
+                produced, _ = self.grid_batch_dev(dev_segments, out_ts, out_val, n)
+            else:
+                produced, _ = self.grid_batch_range_dev(dev_segments, time_range[0], time_range[1], out_ts, out_val, n)
+            assert produced == n
+            return self.download_array(out_ts, n, np.int64), self.download_array(out_val, n, np.float32)
+        finally:
+            self.dev_free(out_ts)
+            self.dev_free(out_val)
+
     # ---- aggregates ------------------------------------------------------------------------------
 
     def agg_batch(self, batch, which_mask, state=None):

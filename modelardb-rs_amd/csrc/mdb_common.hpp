@@ -154,6 +154,29 @@ struct LaunchTimer {
     ~LaunchTimer();
 };
 
+// Random access into the MacaqueV streams of a batch that stays on the device (mdb_grid.hip: mv_index_*): one
+// 32-byte cursor in front of every 64th value of every stream - where the code begins, the window, the XOR of all
+// deltas so far - so that every piece is decoded by a lane of its own. Not an Arrow column: it belongs to the
+// mdb_segments_owned the library made (mdb_segments_upload, mdb_compress_chunks_dev), is built by the first
+// grid / aggregate call that could use it and dies with the batch.
+struct MvIndex {
+    std::mutex mutex;      // building
+    bool built = false;
+    bool usable = false;   // false: a stream of the batch is malformed, or there is nothing to index
+    int device = 0;
+    unsigned long long n_pieces = 0;
+    void *cursors = nullptr;    // MvCursor[n_pieces]
+    void *piece_base = nullptr; // unsigned long long[n + 1]: first piece of every segment
+    unsigned long long stream_values = 0; // values behind the cursors
+    ~MvIndex() {
+        if (cursors || piece_base) {
+            (void)hipSetDevice(device);
+            if (cursors) (void)hipFree(cursors);
+            if (piece_base) (void)hipFree(piece_base);
+        }
+    }
+};
+
 // Owner bookkeeping behind mdb_segments_owned::priv_.
 struct OwnedSegments {
     mdb_segments_owned c;
@@ -163,7 +186,15 @@ struct OwnedSegments {
     // host batches: per column, the data buffers (pointers into host_allocs) and their sizes
     std::vector<const uint8_t *> buffer_ptrs[3];
     std::vector<int64_t> buffer_sizes[3];
+    std::shared_ptr<MvIndex> mv_index; // device batches that stay (not the transient uploads of one call)
 };
+
+// The device batches this library made and still owns, by the address of their `values` views: a "_dev" entry
+// point is handed a plain mdb_segments (possibly a copy of the owned struct's member) and finds the batch's
+// index through this. (mdb_ctx.hip)
+void owned_segments_register(OwnedSegments *owned);
+void owned_segments_forget(OwnedSegments *owned);
+std::shared_ptr<MvIndex> owned_segments_index(const mdb_segments *in);
 
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 

@@ -127,6 +127,48 @@ void PinnedPool::close() {
 
 // (under a lock of their own: the context's call lock is held by a running job from its upload to its last copy,
 // and a submit that waited for it could never put a second job next to the first)
+namespace {
+struct OwnedRegistry {
+    std::mutex mutex;
+    std::map<const void *, OwnedSegments *> by_values_views;
+    static OwnedRegistry &instance() {
+        static OwnedRegistry *registry = new OwnedRegistry();
+        return *registry;
+    }
+};
+} // namespace
+
+void owned_segments_register(OwnedSegments *owned) {
+    if (!owned->c.on_device || owned->c.seg.n == 0 || !owned->c.seg.values.views) return;
+    owned->mv_index = std::make_shared<MvIndex>();
+    owned->mv_index->device = owned->device;
+    OwnedRegistry &registry = OwnedRegistry::instance();
+    std::lock_guard<std::mutex> lock(registry.mutex);
+    registry.by_values_views[owned->c.seg.values.views] = owned;
+}
+
+void owned_segments_forget(OwnedSegments *owned) {
+    if (!owned->mv_index) return;
+    OwnedRegistry &registry = OwnedRegistry::instance();
+    std::lock_guard<std::mutex> lock(registry.mutex);
+    auto found = registry.by_values_views.find(owned->c.seg.values.views);
+    if (found != registry.by_values_views.end() && found->second == owned) registry.by_values_views.erase(found);
+}
+
+std::shared_ptr<MvIndex> owned_segments_index(const mdb_segments *in) {
+    if (!in || in->n == 0) return nullptr;
+    OwnedRegistry &registry = OwnedRegistry::instance();
+    std::lock_guard<std::mutex> lock(registry.mutex);
+    auto found = registry.by_values_views.find(in->values.views);
+    if (found == registry.by_values_views.end()) return nullptr;
+    const mdb_segments &own = found->second->c.seg;
+    // (the same batch, not a slice or a foreign struct that happens to share a column)
+    if (own.n != in->n || own.model_type_id != in->model_type_id || own.residuals.views != in->residuals.views ||
+        own.timestamps.views != in->timestamps.views)
+        return nullptr;
+    return found->second->mv_index;
+}
+
 GridPipeline *ctx_pipeline(mdb_ctx *ctx) {
     std::lock_guard<std::mutex> lock(ctx->pipeline_mutex);
     return ctx->pipeline;
@@ -617,6 +659,7 @@ int mdb::upload_segment_list_locked(mdb_ctx *ctx, const mdb_segments *const *hos
     owned->c.chunk_index = nullptr;
     owned->c.on_device = 1;
     owned->c.priv_ = owned;
+    if (!transient) owned_segments_register(owned);
     *out = &owned->c;
     return 0;
 }
@@ -789,6 +832,7 @@ void mdb_segments_free(mdb_segments_owned *segments) {
     if (!segments) return;
     OwnedSegments *owned = static_cast<OwnedSegments *>(segments->priv_);
     if (!owned) return;
+    owned_segments_forget(owned);
     if (owned->device >= 0 && !owned->device_allocs.empty()) {
         (void)hipSetDevice(owned->device);
         (void)hipDeviceSynchronize();

@@ -2704,6 +2704,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     }
     owned->c.on_device = 1;
     owned->c.priv_ = owned;
+    owned_segments_register(owned);
     *out = &owned->c;
     return 0;
 #undef FIT_CHECK

@@ -874,6 +874,248 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
     return bits;
 }
 
+// ---- random access into MacaqueV streams: the cursor index of a resident batch -----------------------------
+//
+// macaque_v.rs:272-323 decodes a stream from its first bit: where code i begins depends on every code before it,
+// and its value on the XOR of all of them. One lane per stream therefore needs 20 ms for 50 000 values however idle
+// the GPU is (MacaqueV streams). But a batch that STAYS on the device (mdb_segments_upload,
+// mdb_compress_chunks_dev) is decoded again and again, and what a lane needs to start in the middle of a stream is
+// little: the bit position of the code, the window (leading / trailing zeros of the last `11` code) and the XOR of
+// all deltas so far. k_mv_index_walk leaves such a cursor in front of every 64th value of every stream - the
+// model's values of a MacaqueV segment, and the residual tail of any segment - once per batch; from then on
+// k_grid_mv_pieces decodes every piece with a lane of its own, 64 pieces per wave, the wave's 4 096 values staged
+// in LDS and written in rows of 64 consecutive values.
+//
+// The XOR is kept relative to the stream's seed (a residual tail is XOR-seeded with the last RECONSTRUCTED value
+// of its model, models/mod.rs:241-249, which for a Swing model with irregular timestamps only the grid call's own
+// analysis knows): value = seed ^ cursor.xor_bits ^ (deltas of the piece so far). A MacaqueV segment's values
+// start from 0 with the raw first value as their first delta, and its residual tail (the reference's compressor
+// never makes one, a foreign batch may) continues that chain, seed 0.
+
+constexpr uint32_t MV_PIECE_VALUES = 64;
+constexpr uint32_t MV_WINDOW_RESIDUAL = 1u << 16; // the piece belongs to the residual tail
+constexpr uint32_t MV_WINDOW_RAW = 1u << 17;      // its first value is the stream's raw first value
+
+struct MvCursor { // 32 bytes
+    uint32_t bit_position; // of the piece's first code in its stream
+    uint32_t xor_bits;     // XOR of all deltas of the chain before it
+    uint32_t segment;
+    uint32_t point_index;  // of the piece's first value among the segment's data points
+    uint32_t n_values;     // 1..64
+    uint32_t window;       // leading | trailing << 8 | MV_WINDOW_*
+    uint32_t pad[2];
+};
+static_assert(sizeof(MvCursor) == 32, "cursors are loaded as two uint4");
+
+// Values of the two streams of segment i: the model's (MacaqueV segments only) and the residual tail's.
+__device__ __forceinline__ void mv_stream_lengths(const DevSegments &s, uint64_t i, const uint32_t *known_totals,
+                                                  uint32_t *n_model_values, uint32_t *n_residuals, uint32_t *n_model_points,
+                                                  uint32_t *error) {
+    const SegInfo info = analyse_segment(s, i, known_totals, nullptr, false);
+    *error = info.error;
+    const uint32_t n_res = info.desc.n_total - info.desc.n_model;
+    *n_model_points = info.desc.n_model;
+    *n_model_values = (info.desc.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID ? info.desc.n_model : 0u;
+    *n_residuals = n_res;
+}
+
+struct MvIndexPieces { // pieces of segment i (0 for a malformed one: the batch is then not indexed at all)
+    DevSegments s;
+    const uint32_t *known_totals;
+    __device__ uint64_t operator()(uint64_t i) const {
+        uint32_t n_values, n_res, n_model, error;
+        mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
+        if (error) return 0;
+        return (uint64_t)((n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES) + (n_res + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES;
+    }
+};
+
+// One lane per segment, one wave per workgroup, the streams read through the LDS ring of k_grid_serial: the walk
+// that k_grid_serial makes on every call, made once, leaving cursors instead of values. verdict[0] |= what is
+// wrong with a stream (the batch is then left to the kernels that report it), verdict[1] += values walked.
+__global__ __launch_bounds__(SERIAL_THREADS) void k_mv_index_walk(DevSegments s, const uint32_t *__restrict__ known_totals,
+                                                                  const unsigned long long *__restrict__ piece_base,
+                                                                  MvCursor *__restrict__ cursors,
+                                                                  unsigned long long *__restrict__ verdict) {
+    __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
+    const bool present = i < s.n;
+    uint32_t n_values = 0, n_res = 0, n_model = 0, error = 0;
+    if (present) mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
+    if (error) n_values = n_res = 0;
+    unsigned long long piece = present ? piece_base[i] : 0;
+    bool values_pending = n_values > 0, residuals_pending = n_res > 0;
+    RingBitReader reader;
+    reader.begin(nullptr, 0);
+    MacaqueStream stream;
+    stream.remaining = 0; stream.position = 0; stream.last = 0;
+    stream.leading = 255; stream.trailing = 0; stream.first_is_raw = false; stream.fresh = false;
+    bool active = false, residual = false;
+    uint32_t in_stream = 0; // values of the open stream walked so far
+    unsigned long long walked = 0;
+    auto open_next_stream = [&]() {
+        in_stream = 0;
+        if (values_pending) {
+            const uint4 vv = s.values.views[i];
+            reader.begin(view_data(s.values, i, vv), vv.x);
+            if (vv.x == 0) error |= ERR_BITSTREAM;
+            stream.remaining = n_values; stream.position = 0; stream.leading = 255; stream.trailing = 0;
+            stream.first_is_raw = true; stream.fresh = true;
+            values_pending = false; residual = false;
+            active = vv.x != 0;
+        } else if (residuals_pending) {
+            const uint4 vr = s.residuals.views[i];
+            reader.begin(view_data(s.residuals, i, vr), vr.x - 1);
+            if (vr.x < 2) error |= ERR_BITSTREAM;
+            stream.remaining = n_res; stream.position = n_model; stream.leading = 255; stream.trailing = 0;
+            stream.first_is_raw = false; stream.fresh = true;
+            residuals_pending = false; residual = true;
+            active = vr.x >= 2;
+        } else {
+            active = false;
+        }
+    };
+    open_next_stream();
+    while (__any(active)) {
+        if (__any(active && reader.hungry())) ring_top_up(reader, ring, lane, active);
+        if (active) {
+            if (in_stream % MV_PIECE_VALUES == 0) {
+                MvCursor cursor;
+                cursor.bit_position = (uint32_t)reader.used_bits;
+                cursor.xor_bits = stream.last;
+                cursor.segment = (uint32_t)i;
+                cursor.point_index = stream.position;
+                cursor.n_values = min(stream.remaining, MV_PIECE_VALUES);
+                cursor.window = (stream.leading & 255u) | ((stream.trailing & 255u) << 8) | (residual ? MV_WINDOW_RESIDUAL : 0u) |
+                                (stream.first_is_raw ? MV_WINDOW_RAW : 0u);
+                cursor.pad[0] = cursor.pad[1] = 0;
+                uint4 *to = reinterpret_cast<uint4 *>(cursors + piece);
+                const uint4 *from = reinterpret_cast<const uint4 *>(&cursor);
+                to[0] = from[0];
+                to[1] = from[1];
+                piece += 1;
+            }
+            bool malformed;
+            (void)ring_decode_value(reader, stream, ring, lane, &malformed);
+            if (malformed) {
+                error |= ERR_BITSTREAM;
+                stream.remaining = 1;
+                values_pending = residuals_pending = false;
+            }
+            stream.position += 1;
+            stream.remaining -= 1;
+            in_stream += 1;
+            walked += 1;
+            if (stream.remaining == 0) {
+                if (reader.overrun() || reader.used_bits > 0xffffffffull) error |= ERR_BITSTREAM;
+                open_next_stream();
+            }
+        }
+    }
+    if (error) atomicOr(verdict, (unsigned long long)error);
+    if (walked) atomicAdd(verdict + 1, walked);
+}
+
+// The decode step of ring_decode_value over a lane's own reader (LeanReaderDev: 16-byte chunks, one ahead).
+struct MvPieceState {
+    uint32_t last, leading, trailing;
+    bool raw;
+};
+__device__ __forceinline__ uint32_t lean_decode_value(LeanReaderDev &reader, MvPieceState &state) {
+    reader.refill();
+    const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
+    const bool raw = state.raw;
+    const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
+    const bool opens = !raw && c0 && c1;
+    const bool repeats = !raw && c0 && !c1;
+    const uint32_t header_bits = raw ? 0u : (c0 ? (c1 ? 13u : 2u) : 1u);
+    const uint32_t leading = opens ? ((top >> 6) & 31u) : state.leading;
+    const uint32_t trailing = opens ? 32u - (top & 63u) - leading : state.trailing;
+    uint32_t meaningful = (32u - leading - trailing) & 63u; // (the index has seen every window: it is a possible one)
+    state.leading = leading;
+    state.trailing = trailing;
+    state.raw = false;
+    meaningful = raw ? 32u : (repeats ? 0u : min(meaningful, 32u));
+    reader.consume(header_bits);
+    reader.refill();
+    const uint32_t payload = (uint32_t)((reader.buffer >> 1) >> (63u - meaningful)); // 0 bits: 0
+    reader.consume(meaningful);
+    const uint32_t bits = raw ? payload : (state.last ^ (payload << (trailing & 31u)));
+    state.last = bits;
+    return bits;
+}
+
+constexpr int MV_STAGE_STRIDE = MV_PIECE_VALUES + 1; // (a row per lane: stride 65 words keeps the banks apart)
+
+// One lane per piece, one wave per workgroup. first_of: where the visible part of segment i begins among its
+// points (0 without a time range).
+__global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, TimeRange range, const TileDesc *__restrict__ desc,
+                                                             const unsigned long long *__restrict__ offsets,
+                                                             const uint32_t *__restrict__ irregular_first,
+                                                             const uint32_t *__restrict__ irregular_totals, TsCheckpoints checkpoints,
+                                                             const MvCursor *__restrict__ cursors, unsigned long long n_pieces,
+                                                             float *__restrict__ out_val) {
+    __shared__ uint32_t stage[MDB_WAVE * MV_STAGE_STRIDE];
+    const int lane = threadIdx.x;
+    const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
+    uint32_t count = 0, skip = 0; // values of this lane's piece to write, and how many in front of them are not wanted
+    unsigned long long out_at = 0;
+    LeanReaderDev reader;
+    MvPieceState state;
+    state.last = 0; state.leading = 255; state.trailing = 0; state.raw = false;
+    if (piece < n_pieces) {
+        const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
+        const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
+        const uint32_t i = c0.z, point_index = c0.w, n_values = c1.x, window = c1.y;
+        const TileDesc t = desc[i];
+        uint32_t first = 0;
+        if (range.enabled) {
+            if (t.flags & FLAG_REGULAR) first = t.delta > 0 ? (uint32_t)((uint64_t)(t.start - s.start_time[i]) / (uint64_t)t.delta) : 0u;
+            else first = irregular_first[i];
+        }
+        const uint32_t lo = max(point_index, first), hi = min(point_index + n_values, first + t.n_points);
+        if (lo < hi) {
+            skip = lo - point_index;
+            count = hi - lo;
+            out_at = offsets[i] + (lo - first);
+            const bool residual = (window & MV_WINDOW_RESIDUAL) != 0;
+            const DevCol &column = residual ? s.residuals : s.values;
+            const uint4 view = column.views[i];
+            const uint64_t nbytes = residual ? (uint64_t)view.x - 1u : (uint64_t)view.x;
+            reader.open(view_data(column, i, view), nbytes, c0.x);
+            const bool macaque = (t.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID;
+            float seed = t.value;
+            // (a Swing segment whose timestamps the tile kernel writes from a jump list keeps the list's place where
+            // its seed would be, set_jump_list(): the seed is worked out again, as k_grid_serial does)
+            if ((t.flags & FLAG_JUMPS) && (t.flags & FLAG_TYPE_MASK) == MDB_SWING_ID)
+                seed = analyse_segment(s, i, irregular_totals, &checkpoints).desc.value;
+            state.last = (macaque ? 0u : __float_as_uint(seed)) ^ c0.y;
+            state.leading = window & 255u;
+            state.trailing = (window >> 8) & 255u;
+            state.raw = (window & MV_WINDOW_RAW) != 0;
+        }
+    }
+    const uint32_t to_decode = skip + count;
+    for (uint32_t k = 0; __any(k < to_decode); k++) {
+        if (k < to_decode) {
+            const uint32_t bits = lean_decode_value(reader, state);
+            stage[lane * MV_STAGE_STRIDE + k] = bits;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // Row r = the wanted values of lane r's piece: 64 consecutive floats per store instruction.
+    for (int r = 0; r < MDB_WAVE; r++) {
+        const uint32_t row_count = __builtin_amdgcn_readlane(count, r);
+        if (row_count == 0) continue;
+        const uint32_t row_skip = __builtin_amdgcn_readlane(skip, r);
+        const unsigned long long row_at = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(out_at >> 32), r) << 32) |
+                                          __builtin_amdgcn_readlane((uint32_t)out_at, r);
+        if ((uint32_t)lane < row_count)
+            out_val[row_at + lane] = __uint_as_float(stage[r * MV_STAGE_STRIDE + row_skip + lane]);
+    }
+}
+
 // ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
 //
 // A wave of k_grid_ts_count walks 64 streams in lockstep and is done when the longest of them is, and the
@@ -1815,7 +2057,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ irregular_totals,
     const uint32_t *__restrict__ irregular_first, int64_t *__restrict__ out_ts, float *__restrict__ out_val,
-    GridHeader *__restrict__ header, TsCheckpoints checkpoints) {
+    GridHeader *__restrict__ header, TsCheckpoints checkpoints, bool skip_macaque) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -1883,10 +2125,11 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     // A stream is decoded from its beginning (the format has no random access) but only as far as
     // the last wanted value; the model's values are also needed in full when residuals are wanted,
     // because the residual stream is seeded with the model's last value.
+    // (skip_macaque: the batch has a cursor index and k_grid_mv_pieces decodes every stream piece by piece)
     const uint32_t n_res = d.n_total - d.n_model;
-    const bool residuals_wanted = present && n_res > 0 && visible_end > d.n_model;
+    const bool residuals_wanted = present && !skip_macaque && n_res > 0 && visible_end > d.n_model;
     const uint32_t values_to_decode = residuals_wanted ? d.n_model : min(d.n_model, visible_end);
-    bool values_pending = present && type == MDB_MACAQUE_V_ID && d.n_model > 0 && d.n_visible > 0 &&
+    bool values_pending = present && !skip_macaque && type == MDB_MACAQUE_V_ID && d.n_model > 0 && d.n_visible > 0 &&
                           (residuals_wanted || d.first < d.n_model);
     // Long streams may already have been decoded by the parallel decoder (mdb_macaque_parallel.hpp).
     if (values_pending && mv_segs != nullptr && mv_segs[slot].done) values_pending = false;
@@ -1988,6 +2231,7 @@ struct GridPlan {
     bool mv_forced;         // MDB_GRID_MV_MIN_VALUES is set: no upper limit on the number of pieces
     TsCheckpoints checkpoints; // of the batch's irregular timestamp streams (piece_base == nullptr: none)
     uint64_t n_ts_pieces;
+    std::shared_ptr<MvIndex> mv_index; // cursors into the batch's MacaqueV streams, if it is a resident batch
 };
 
 // MDB_GRID_MV_MIN_VALUES: "off" disables the parallel MacaqueV decoder, a number sets the stream
@@ -2078,6 +2322,59 @@ int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegmen
     *totals = walk_totals;
     *sums = !range.enabled && with_sums ? walk_sums : nullptr;
     *ranges = range.enabled ? walk_ranges : nullptr;
+    return 0;
+}
+
+// The cursor index of a batch the library owns on the device (see k_mv_index_walk), built by the first call that
+// asks for it. *out stays empty for a foreign or transient batch, for one without MacaqueV streams, for one with a
+// malformed stream (the serial kernel reports it) and with MDB_GRID_MV_INDEX=0 (A/B, tests). Uses the counting
+// walk's scratch: call it BEFORE grid_plan / the aggregate kernels lay theirs out.
+int mv_index_prepare(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvIndex> *out) {
+    out->reset();
+    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    if (setting && std::strcmp(setting, "0") == 0) return 0;
+    std::shared_ptr<MvIndex> index = owned_segments_index(in);
+    if (!index) return 0;
+    std::lock_guard<std::mutex> lock(index->mutex);
+    if (!index->built) {
+        const uint64_t n = in->n;
+        if (n > 0xfffffff0ull) return 0;
+        const DevSegments s = to_dev(in);
+        const uint32_t *totals = nullptr;
+        const double *sums = nullptr;
+        const TsWalkRange *ranges = nullptr;
+        const unsigned int *walk_error = nullptr;
+        if (ts_walk_for_aggregates(ctx, in, s, false, TimeRange{0, 0, 0}, &totals, &sums, &ranges, &walk_error)) return 1;
+        void *p = nullptr;
+        if (scratch_reserve(ctx, SCRATCH_MV, scan_block_sums_bytes(n) + 64, &p)) return 1;
+        unsigned long long *block_sums = static_cast<unsigned long long *>(p);
+        unsigned long long *verdict = block_sums + scan_block_sums_bytes(n) / 8; // [0] errors, [1] values walked
+        MDB_HIP_CHECK(hipMalloc(&index->piece_base, (n + 1) * 8));
+        unsigned long long *piece_base = static_cast<unsigned long long *>(index->piece_base);
+        if (device_exclusive_scan(ctx, MvIndexPieces{s, totals}, n, piece_base, block_sums, "k_mv_index_scan")) return 1;
+        unsigned long long n_pieces = 0;
+        MDB_HIP_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP_CHECK(hipMemsetAsync(verdict, 0, 16, ctx->stream));
+        MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        unsigned long long host_verdict[2] = {0, 0};
+        if (n_pieces > 0) {
+            MDB_HIP_CHECK(hipMalloc(&index->cursors, n_pieces * sizeof(MvCursor)));
+            {
+                LaunchTimer timer(ctx, "k_mv_index_walk");
+                hipLaunchKernelGGL(k_mv_index_walk, dim3((uint32_t)((n + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+                                   dim3(SERIAL_THREADS), 0, ctx->stream, s, totals, piece_base,
+                                   static_cast<MvCursor *>(index->cursors), verdict);
+            }
+            MDB_HIP_CHECK(hipMemcpyAsync(host_verdict, verdict, 16, hipMemcpyDeviceToHost, ctx->stream));
+            MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            MDB_HIP_CHECK(hipGetLastError());
+        }
+        index->n_pieces = n_pieces;
+        index->stream_values = host_verdict[1];
+        index->usable = n_pieces > 0 && host_verdict[0] == 0;
+        index->built = true;
+    }
+    if (index->usable) *out = index;
     return 0;
 }
 
@@ -2821,18 +3118,26 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
     }
     const uint64_t n_serial = plan.host_header.n_serial;
     const MvSeg *mv_segs = nullptr;
-    if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
+    const MvIndex *index = plan.mv_index.get();
+    if (index) {
+        // A resident batch with cursors into its MacaqueV streams: every piece of 64 values by a lane of its own.
+        LaunchTimer timer(ctx, "k_grid_mv_pieces");
+        hipLaunchKernelGGL(k_grid_mv_pieces, dim3((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE)), dim3(MDB_WAVE), 0,
+                           ctx->stream, s, range, plan.desc, plan.offsets, plan.irregular_first, plan.irregular_totals,
+                           plan.checkpoints, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val);
+    } else if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
         MvSeg *segs = nullptr;
         if (grid_parallel_macaque(ctx, s, range, plan, out_val, &segs)) return 1;
         mv_segs = segs;
     }
-    if (n_serial > 0) {
+    // (with the index the serial kernel is left with the irregular timestamps that live inside their views)
+    if (n_serial > 0 && (!index || plan.host_header.metrics[8] > 0)) {
         LaunchTimer timer(ctx, "k_grid_serial");
         hipLaunchKernelGGL(k_grid_serial,
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
-                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints);
+                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints, index != nullptr);
     }
     if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
         LaunchTimer timer(ctx, "k_grid_swing_irregular");
@@ -2857,7 +3162,10 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
                           float *out_val, uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
                           mdb_grid_metrics *metrics) {
     GridPlan plan;
+    std::shared_ptr<MvIndex> index;
+    if (mv_index_prepare(ctx, in, &index)) return 1;
     if (grid_plan(ctx, in, range, &plan)) return 1;
+    plan.mv_index = index;
     const uint64_t total = plan.host_header.total_points;
     if (n_out) *n_out = total;
     fill_metrics(plan.host_header, metrics);

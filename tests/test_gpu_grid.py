@@ -836,3 +836,51 @@ def test_a_reused_clone_is_a_fresh_one(hip):
     cases.assert_grid_equal(third.grid_batch(batch), expected)
     third.close()
     origin.close()
+
+
+@pytest.mark.parametrize("index", ["cursors", "off"])
+def test_resident_batches_are_decoded_piece_by_piece(hip, index, monkeypatch):
+    # A batch that stays on the device gets, with its first grid call, a cursor in front of every 64th value of
+    # every MacaqueV stream (k_mv_index_walk); from then on one lane decodes one piece (k_grid_mv_pieces) instead
+    # of one lane one stream (macaque_v.rs:272-323 is sequential). Long lossless streams, residual tails of every
+    # length up to 255 and beyond (a separate MacaqueV segment), streams inside their views, irregular timestamps,
+    # specials; whole and under time ranges that begin and end inside pieces. MDB_GRID_MV_INDEX=0: the same
+    # through the serial kernel.
+    if index == "off":
+        monkeypatch.setenv("MDB_GRID_MV_INDEX", "0")
+    rng = np.random.default_rng(29)
+    batches = [cases.edge_case_batch(), cases.edge_case_batch(cases.error_bounds()["rel5"])]
+    for eb_name in ("lossless", "abs0.01", "rel1"):
+        for irregular in (False, True):
+            batches.append(cases.mixed_batch(cases.error_bounds()[eb_name], irregular, seed=61, length=30_000)[2])
+    noise = rng.uniform(-1e3, 1e3, 200_000).astype(np.float32)         # long streams: every value a new window
+    offsets = np.arange(0, len(noise) + 1, 50_000, dtype=np.uint64)
+    batches.append(ora.compress_chunks(np.arange(len(noise), dtype=np.int64) * 10, noise, offsets, cases.LOSSLESS))
+    tails = []                                                          # residual tails of 1..300 values
+    for n_res in (1, 2, 63, 64, 65, 127, 128, 129, 200, 255, 256, 300):
+        values = np.concatenate([np.full(20, 5.0, dtype=np.float32), rng.uniform(-1e30, 1e30, n_res).astype(np.float32),
+                                 np.arange(20, dtype=np.float32) * 3 + 1])
+        tails.append(ora.try_compress_univariate_time_series(np.arange(len(values), dtype=np.int64) * 100, values, cases.LOSSLESS))
+    batches.append(mdb.SegmentBatch.concat(tails))
+    for batch in batches:
+        expected = ora.grid_batch(batch)
+        resident = hip.upload_segments(batch)
+        for _ in range(2):   # (the first call builds the index)
+            cases.assert_grid_equal(hip.grid_resident(resident), expected)
+        all_ts = expected[0]
+        for a, b in ((len(all_ts) // 7, len(all_ts) // 3), (0, 70), (len(all_ts) - 100, len(all_ts) - 1), (5, 5)):
+            lo, hi = int(np.sort(all_ts)[a]), int(np.sort(all_ts)[min(b, len(all_ts) - 1)])
+            keep = (all_ts >= lo) & (all_ts <= hi)
+            got_ts, got_values = hip.grid_resident(resident, (lo, hi))
+            assert np.array_equal(got_ts, all_ts[keep])
+            assert np.array_equal(got_values.view(np.uint32), expected[1][keep].view(np.uint32))
+        resident.free()
+    # a batch the fitter leaves on the device is resident too
+    values_dev = hip.upload_array(noise)
+    offsets_dev = hip.upload_array(offsets)
+    fitted = hip.compress_chunks_dev(0, values_dev, offsets_dev, len(offsets) - 1, cases.LOSSLESS, 0, 10,
+                                     hip.upload_array(offsets[:-1] * 0))
+    for _ in range(2):
+        ts, values = hip.grid_resident(fitted)
+        assert np.array_equal(values.view(np.uint32), noise.view(np.uint32))
+    fitted.free()
