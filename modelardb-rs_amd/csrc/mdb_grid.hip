@@ -1109,8 +1109,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
         const uint32_t row_count = __builtin_amdgcn_readlane(count, r);
         if (row_count == 0) continue;
         const uint32_t row_skip = __builtin_amdgcn_readlane(skip, r);
-        const unsigned long long row_at = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(out_at >> 32), r) << 32) |
-                                          __builtin_amdgcn_readlane((uint32_t)out_at, r);
+        // (readlane returns an int: without the casts a low word from 2^31 on would sign-extend into the high one)
+        const unsigned long long row_at = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(out_at >> 32), r) << 32) |
+                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)out_at, r);
         if ((uint32_t)lane < row_count)
             out_val[row_at + lane] = __uint_as_float(stage[r * MV_STAGE_STRIDE + row_skip + lane]);
     }

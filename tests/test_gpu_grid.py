@@ -884,3 +884,29 @@ def test_resident_batches_are_decoded_piece_by_piece(hip, index, monkeypatch):
         ts, values = hip.grid_resident(fitted)
         assert np.array_equal(values.view(np.uint32), noise.view(np.uint32))
     fitted.free()
+
+
+def test_piece_decoder_beyond_two_to_the_31_values(hip):
+    # Output positions are 64-bit everywhere: 45 000 lossless streams of 50 000 values are 2.25 x 10^9 values, past
+    # 2^31 (the wave hands a row's output position from lane to lane in two 32-bit halves; a sign-extended low half
+    # once wrote below the column). Sampled streams against the generator they were fitted from.
+    import datagen
+    streams, per = 45_000, 50_000
+    n = streams * per
+    values = hip.dev_alloc(4 * n)
+    hip.synth_values_dev(values, 0, streams, per)
+    offsets_dev = hip.upload_array(np.arange(0, n + per, per, dtype=np.uint64))
+    fitted = hip.compress_chunks_dev(0, values, offsets_dev, streams, cases.LOSSLESS, 0, 1000, 0)
+    hip.dev_free(values)
+    assert hip.grid_count_dev(fitted) == n
+    out_ts, out_val = hip.dev_alloc(8 * n), hip.dev_alloc(4 * n)
+    for _ in range(2):
+        produced, metrics = hip.grid_batch_dev(fitted, out_ts, out_val, n)
+        assert produced == n and metrics["rows_created_by_macaque_v"] == n
+    for series in (0, 1, streams // 2, 42_949, 42_950, streams - 1):   # (42 949.67 streams are 2^31 values)
+        got = hip.download_array(out_val, per, np.float32, offset_elements=series * per)
+        assert np.array_equal(got.view(np.uint32), datagen.bench_series(series, per).view(np.uint32)), series
+        assert np.array_equal(hip.download_array(out_ts, 3, np.int64, offset_elements=series * per), [0, 1000, 2000])
+    for pointer in (out_ts, out_val, offsets_dev):
+        hip.dev_free(pointer)
+    fitted.free()
