@@ -92,8 +92,11 @@ __device__ __forceinline__ AggPartial empty_partial() {
 // models/mod.rs:129-184: the f32 sum of one segment.
 // `walked_sums` (may be nullptr): what the walk of the irregular timestamp streams has added up for the Swing
 // segments it adds up (ts_walk_adds): the same terms in the same order as below.
+// `stream_sums` (may be nullptr): the sums of the batch's MacaqueV streams, added up by k_agg_mv_chains from the
+// values the batch's cursor index let k_agg_mv_pieces decode piece by piece: 2 i the model's, 2 i + 1 the tail's.
 __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, const SegInfo &info,
-                                             uint32_t length, uint32_t *error, const double *walked_sums = nullptr) {
+                                             uint32_t length, uint32_t *error, const double *walked_sums = nullptr,
+                                             const float *stream_sums = nullptr) {
     const SegDesc &d = info.desc;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     const uint32_t n_res = d.n_total - d.n_model;
@@ -129,6 +132,8 @@ __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, c
                                         });
             model_sum = (float)sum;
         }
+    } else if (stream_sums && model_length == d.n_model) {
+        model_sum = stream_sums[2 * i];
     } else {
         model_last_value = __uint_as_float(0x7fc00000u); // f32::NAN (models/mod.rs:167)
         const uint4 vv = s.values.views[i];
@@ -142,6 +147,7 @@ __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, c
         model_sum = sum;
     }
     if (!(d.flags & FLAG_HAS_RESIDUALS)) return model_sum;
+    if (stream_sums) return model_sum + stream_sums[2 * i + 1];
     const uint4 vr = s.residuals.views[i];
     float residuals_sum = 0.0f;
     decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, n_res, true,
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
                                                               AggPartial *__restrict__ partials,
                                                               const uint32_t *__restrict__ walked_totals,
                                                               const double *__restrict__ walked_sums,
-                                                              const unsigned int *__restrict__ walked_error) {
+                                                              const unsigned int *__restrict__ walked_error,
+                                                              const float *__restrict__ stream_sums) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
     if (walked_error && blockIdx.x == 0 && threadIdx.x == 0) p.error |= *walked_error;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
                 p.deferred_values += length;
                 p.deferred_bytes += s.values.views[i].x;
             } else if (!error) {
-                p.sum += (double)segment_sum(s, i, info, length, &error, walked_sums);
+                p.sum += (double)segment_sum(s, i, info, length, &error, walked_sums, stream_sums);
             }
         }
         p.error |= error;
@@ -483,6 +490,9 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     const double *walked_sums = nullptr;
     const TsWalkRange *walked_ranges = nullptr;
     const unsigned int *walked_error = nullptr; // (what the walk found wrong with a stream)
+    // A batch that stays on the device has (from its first grid or aggregate call on) cursors into its MacaqueV
+    // streams: SUM then decodes them piece by piece (mdb_grid.hip, k_agg_mv_pieces) instead of one lane per stream.
+    if (sums_wanted && mv_index_ensure(ctx, in)) return 1;
     if ((range || (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM))) &&
         ts_walk_for_aggregates(ctx, in, s, sums_wanted, TimeRange{t_lo, t_hi, range ? 1 : 0}, &walked_totals, &walked_sums,
                                &walked_ranges, &walked_error))
@@ -492,10 +502,12 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
                            t_hi, AGG_SUM_DEFER, mv_min_values, partials, walked_totals, walked_ranges, walked_error);
     } else {
+        const float *stream_sums = nullptr;
+        if (sums_wanted && mv_index_stream_sums(ctx, in, s, walked_totals, &stream_sums)) return 1;
         LaunchTimer timer(ctx, "k_agg_segments");
         hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
-                           which_mask, sums_wanted ? AGG_SUM_DEFER : AGG_SUM_ALL, mv_min_values, partials,
-                           walked_totals, walked_sums, walked_error);
+                           which_mask, sums_wanted && !stream_sums ? AGG_SUM_DEFER : AGG_SUM_ALL, mv_min_values, partials,
+                           walked_totals, walked_sums, walked_error, stream_sums);
     }
     {
         LaunchTimer timer(ctx, "k_agg_finish");
@@ -528,7 +540,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
                                    which_mask, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials,
                                    static_cast<const uint32_t *>(nullptr), static_cast<const double *>(nullptr),
-                                   static_cast<const unsigned int *>(nullptr));
+                                   static_cast<const unsigned int *>(nullptr), static_cast<const float *>(nullptr));
             }
             {
                 LaunchTimer timer(ctx, "k_agg_finish");

@@ -256,6 +256,11 @@ struct DeferredTotals {
     float max = 0.0f;
 };
 uint32_t macaque_parallel_min_values(bool *forced);
+struct DevSegments;
+// (with a cursor index into the batch's MacaqueV streams, MvIndex: their f32 sums, 2 per segment)
+int mv_index_ensure(mdb_ctx *ctx, const mdb_segments *in);
+int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, const uint32_t *known_totals,
+                         const float **stream_sums);
 
 inline DevSegments to_dev(const mdb_segments *s) {
     DevSegments d;

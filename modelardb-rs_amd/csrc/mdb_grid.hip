@@ -886,11 +886,13 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
 // k_grid_mv_pieces decodes every piece with a lane of its own, 64 pieces per wave, the wave's 4 096 values staged
 // in LDS and written in rows of 64 consecutive values.
 //
-// The XOR is kept relative to the stream's seed (a residual tail is XOR-seeded with the last RECONSTRUCTED value
-// of its model, models/mod.rs:241-249, which for a Swing model with irregular timestamps only the grid call's own
-// analysis knows): value = seed ^ cursor.xor_bits ^ (deltas of the piece so far). A MacaqueV segment's values
-// start from 0 with the raw first value as their first delta, and its residual tail (the reference's compressor
-// never makes one, a foreign batch may) continues that chain, seed 0.
+// The XOR is kept relative to the stream's seed: value = seed ^ cursor.xor_bits ^ (deltas of the piece so far). A
+// residual tail is XOR-seeded with the last RECONSTRUCTED value of its model by grid() (models/mod.rs:241-249:
+// for a Swing model with irregular timestamps only the grid call's own analysis knows it) and with the last
+// DECODED value, or NaN for a MacaqueV model, by sum() (models/mod.rs:145-181) - the caller brings the seed. A
+// MacaqueV segment's values start from 0 with the raw first value as their first delta; the last of them is what
+// grid() seeds such a segment's residual tail with (the reference's compressor never makes one, a foreign batch
+// may), and the walk leaves it in the tail's cursors (chain_seed).
 
 constexpr uint32_t MV_PIECE_VALUES = 64;
 constexpr uint32_t MV_WINDOW_RESIDUAL = 1u << 16; // the piece belongs to the residual tail
@@ -903,7 +905,8 @@ struct MvCursor { // 32 bytes
     uint32_t point_index;  // of the piece's first value among the segment's data points
     uint32_t n_values;     // 1..64
     uint32_t window;       // leading | trailing << 8 | MV_WINDOW_*
-    uint32_t pad[2];
+    uint32_t chain_seed;   // residual tail of a MacaqueV segment: the bits of its last model value (else 0)
+    uint32_t pad;
 };
 static_assert(sizeof(MvCursor) == 32, "cursors are loaded as two uint4");
 
@@ -952,7 +955,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_mv_index_walk(DevSegments s,
     stream.remaining = 0; stream.position = 0; stream.last = 0;
     stream.leading = 255; stream.trailing = 0; stream.first_is_raw = false; stream.fresh = false;
     bool active = false, residual = false;
-    uint32_t in_stream = 0; // values of the open stream walked so far
+    uint32_t in_stream = 0;  // values of the open stream walked so far
+    uint32_t chain_seed = 0; // (residual tail: the last value of the MacaqueV model in front of it)
     unsigned long long walked = 0;
     auto open_next_stream = [&]() {
         in_stream = 0;
@@ -970,6 +974,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_mv_index_walk(DevSegments s,
             if (vr.x < 2) error |= ERR_BITSTREAM;
             stream.remaining = n_res; stream.position = n_model; stream.leading = 255; stream.trailing = 0;
             stream.first_is_raw = false; stream.fresh = true;
+            chain_seed = stream.last; // (0 unless a MacaqueV model's values have just been walked)
+            stream.last = 0;
             residuals_pending = false; residual = true;
             active = vr.x >= 2;
         } else {
@@ -989,7 +995,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_mv_index_walk(DevSegments s,
                 cursor.n_values = min(stream.remaining, MV_PIECE_VALUES);
                 cursor.window = (stream.leading & 255u) | ((stream.trailing & 255u) << 8) | (residual ? MV_WINDOW_RESIDUAL : 0u) |
                                 (stream.first_is_raw ? MV_WINDOW_RAW : 0u);
-                cursor.pad[0] = cursor.pad[1] = 0;
+                cursor.chain_seed = residual ? chain_seed : 0u;
+                cursor.pad = 0;
                 uint4 *to = reinterpret_cast<uint4 *>(cursors + piece);
                 const uint4 *from = reinterpret_cast<const uint4 *>(&cursor);
                 to[0] = from[0];
@@ -1046,17 +1053,25 @@ __device__ __forceinline__ uint32_t lean_decode_value(LeanReaderDev &reader, MvP
     return bits;
 }
 
-constexpr int MV_STAGE_STRIDE = MV_PIECE_VALUES + 1; // (a row per lane: stride 65 words keeps the banks apart)
+// The one kind of stream of an indexed batch that k_grid_serial keeps (see k_grid_mv_pieces).
+__device__ __forceinline__ bool mv_left_to_serial(uint32_t tile_flags) {
+    return (tile_flags & FLAG_JUMPS) && (tile_flags & FLAG_TYPE_MASK) == MDB_SWING_ID;
+}
 
-// One lane per piece, one wave per workgroup. first_of: where the visible part of segment i begins among its
-// points (0 without a time range).
+// One lane per piece, one wave per workgroup. The piece is decoded ROUND values at a time into the wave's LDS
+// (a row per lane) and written out between the rounds, ROUND consecutive values per lane-row. (Measured: the
+// kernel is bound by vector instructions - 104 per value step of the wave at four cycles each, rocprofv3
+// SQ_INSTS_VALU x 4 = SQ_WAVE_CYCLES - so neither more waves per SIMD (16 / 32 / 64 values per round: 15.3 / 13.8
+// / 16.3 ms for 5 x 10^9 values) nor staging the streams in LDS (25.7 ms: more instructions, and pieces 48 words
+// apart meet in two banks) changes it; 32 values per round are whole 128-byte lines per row.)
+template <int ROUND>
 __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, TimeRange range, const TileDesc *__restrict__ desc,
                                                              const unsigned long long *__restrict__ offsets,
                                                              const uint32_t *__restrict__ irregular_first,
-                                                             const uint32_t *__restrict__ irregular_totals, TsCheckpoints checkpoints,
                                                              const MvCursor *__restrict__ cursors, unsigned long long n_pieces,
                                                              float *__restrict__ out_val) {
-    __shared__ uint32_t stage[MDB_WAVE * MV_STAGE_STRIDE];
+    constexpr int STRIDE = ROUND + 1; // (a row per lane: an odd stride keeps the banks apart)
+    __shared__ uint32_t stage[MDB_WAVE * STRIDE];
     const int lane = threadIdx.x;
     const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
     uint32_t count = 0, skip = 0; // values of this lane's piece to write, and how many in front of them are not wanted
@@ -1075,7 +1090,10 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
             else first = irregular_first[i];
         }
         const uint32_t lo = max(point_index, first), hi = min(point_index + n_values, first + t.n_points);
-        if (lo < hi) {
+        // (a Swing segment whose timestamps the tile kernel writes from a jump list keeps the list's place where the
+        // seed of its residual tail would be, set_jump_list(): such a tail is left to k_grid_serial, which works the
+        // seed out again - the analysis that takes would cost this kernel 40 registers)
+        if (lo < hi && !mv_left_to_serial(t.flags)) {
             skip = lo - point_index;
             count = hi - lo;
             out_at = offsets[i] + (lo - first);
@@ -1085,36 +1103,134 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
             const uint64_t nbytes = residual ? (uint64_t)view.x - 1u : (uint64_t)view.x;
             reader.open(view_data(column, i, view), nbytes, c0.x);
             const bool macaque = (t.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID;
-            float seed = t.value;
-            // (a Swing segment whose timestamps the tile kernel writes from a jump list keeps the list's place where
-            // its seed would be, set_jump_list(): the seed is worked out again, as k_grid_serial does)
-            if ((t.flags & FLAG_JUMPS) && (t.flags & FLAG_TYPE_MASK) == MDB_SWING_ID)
-                seed = analyse_segment(s, i, irregular_totals, &checkpoints).desc.value;
-            state.last = (macaque ? 0u : __float_as_uint(seed)) ^ c0.y;
+            state.last = (macaque ? c1.z : __float_as_uint(t.value)) ^ c0.y;
             state.leading = window & 255u;
             state.trailing = (window >> 8) & 255u;
             state.raw = (window & MV_WINDOW_RAW) != 0;
         }
     }
-    const uint32_t to_decode = skip + count;
-    for (uint32_t k = 0; __any(k < to_decode); k++) {
-        if (k < to_decode) {
-            const uint32_t bits = lean_decode_value(reader, state);
-            stage[lane * MV_STAGE_STRIDE + k] = bits;
+    // The values in front of the wanted ones are decoded (the chain runs through them) and dropped.
+    for (uint32_t k = 0; __any(k < skip); k++)
+        if (k < skip) (void)lean_decode_value(reader, state);
+    for (uint32_t done = 0; __any(done < count); done += ROUND) {
+        const uint32_t mine = done < count ? min(count - done, (uint32_t)ROUND) : 0u;
+        for (uint32_t k = 0; __any(k < mine); k++)
+            if (k < mine) stage[lane * STRIDE + k] = lean_decode_value(reader, state);
+        __builtin_amdgcn_wave_barrier();
+        // Row r = this round's values of lane r's piece: consecutive floats, (64 / ROUND) rows per store instruction.
+        constexpr int ROWS_PER_STORE = MDB_WAVE / ROUND;
+        const int sub_row = lane / ROUND, column_of_lane = lane % ROUND;
+        for (int r0 = 0; r0 < MDB_WAVE; r0 += ROWS_PER_STORE) {
+            const int r = r0 + sub_row;
+            // (every lane needs its own row's numbers: a permute, not a broadcast, when a store covers several rows)
+            const uint32_t row_mine = __shfl(mine, r, MDB_WAVE);
+            const uint32_t row_lo = __shfl((uint32_t)(out_at + done), r, MDB_WAVE);
+            const uint32_t row_hi = __shfl((uint32_t)((out_at + done) >> 32), r, MDB_WAVE);
+            if ((uint32_t)column_of_lane < row_mine) {
+                const unsigned long long row_at = ((unsigned long long)row_hi << 32) | row_lo;
+                out_val[row_at + column_of_lane] = __uint_as_float(stage[r * STRIDE + column_of_lane]);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
+}
+
+// ---- the same cursors for SUM: macaque_v::sum adds a stream's values one after the other in f32 --------------
+//
+// f32 addition does not associate, so the additions of one stream stay a chain - but 64 chains fit into a wave, and
+// the decoding, a hundred times the work, is again one lane per piece: k_agg_mv_pieces decodes every piece of the
+// batch into scratch (piece p at values[64 p ..]: a stream's values follow each other), with the seeds sum() uses
+// (models/mod.rs:145-181: the model's last DECODED value, NaN behind a MacaqueV model), and k_agg_mv_chains adds
+// every stream up with one lane. stream_sums[2 i] = the sum of MacaqueV segment i's values (macaque_v.rs:228-235:
+// it starts AS the first value), [2 i + 1] = the sum of segment i's residual tail.
+__global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const MvCursor *__restrict__ cursors,
+                                                            unsigned long long n_pieces, uint32_t *__restrict__ values) {
+    constexpr int STRIDE = MV_PIECE_VALUES + 1; // (a row per lane: stride 65 words keeps the banks apart)
+    __shared__ uint32_t stage[MDB_WAVE * STRIDE];
+    const int lane = threadIdx.x;
+    const unsigned long long first_piece = (unsigned long long)blockIdx.x * MDB_WAVE;
+    const unsigned long long piece = first_piece + lane;
+    uint32_t to_decode = 0;
+    LeanReaderDev reader;
+    MvPieceState state;
+    state.last = 0; state.leading = 255; state.trailing = 0; state.raw = false;
+    if (piece < n_pieces) {
+        const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
+        const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
+        const uint32_t i = c0.z, window = c1.y;
+        to_decode = c1.x;
+        const bool residual = (window & MV_WINDOW_RESIDUAL) != 0;
+        const DevCol &column = residual ? s.residuals : s.values;
+        const uint4 view = column.views[i];
+        reader.open(view_data(column, i, view), residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
+        uint32_t seed = 0;
+        if (residual) {
+            const int32_t type = s.model_type_id[i];
+            if (type == MDB_PMC_MEAN_ID) {
+                float value = 0.0f;
+                (void)decode_pmc_value(s.values.views[i], s.min_value[i], s.max_value[i], &value);
+                seed = __float_as_uint(value);
+            } else if (type == MDB_SWING_ID) {
+                float first = 0.0f, last = 0.0f;
+                (void)decode_swing_values(s.values.views[i], s.min_value[i], s.max_value[i], &first, &last);
+                seed = __float_as_uint(last);
+            } else {
+                seed = 0x7fc00000u; // f32::NAN (models/mod.rs:167)
+            }
+        }
+        state.last = seed ^ c0.y;
+        state.leading = window & 255u;
+        state.trailing = (window >> 8) & 255u;
+        state.raw = (window & MV_WINDOW_RAW) != 0;
+    }
+    for (uint32_t k = 0; __any(k < to_decode); k++)
+        if (k < to_decode) stage[lane * STRIDE + k] = lean_decode_value(reader, state);
     __builtin_amdgcn_wave_barrier();
-    // Row r = the wanted values of lane r's piece: 64 consecutive floats per store instruction.
-    for (int r = 0; r < MDB_WAVE; r++) {
-        const uint32_t row_count = __builtin_amdgcn_readlane(count, r);
-        if (row_count == 0) continue;
-        const uint32_t row_skip = __builtin_amdgcn_readlane(skip, r);
-        // (readlane returns an int: without the casts a low word from 2^31 on would sign-extend into the high one)
-        const unsigned long long row_at = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(out_at >> 32), r) << 32) |
-                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)out_at, r);
-        if ((uint32_t)lane < row_count)
-            out_val[row_at + lane] = __uint_as_float(stage[r * MV_STAGE_STRIDE + row_skip + lane]);
-    }
+    // The wave's 64 pieces are 16 KB in a row in `values` (what lies behind a stream's last value is not read).
+    const unsigned long long rows = min((unsigned long long)MDB_WAVE, n_pieces > first_piece ? n_pieces - first_piece : 0ull);
+    for (unsigned long long r = 0; r < rows; r++)
+        values[(first_piece + r) * MV_PIECE_VALUES + lane] = stage[r * STRIDE + lane];
+}
+
+__global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint32_t *__restrict__ known_totals,
+                                                       const unsigned long long *__restrict__ piece_base,
+                                                       const uint32_t *__restrict__ values, float *__restrict__ stream_sums) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    const unsigned long long first_piece = piece_base[i];
+    if (piece_base[i + 1] == first_piece) return; // (no stream: nobody reads this segment's sums)
+    uint32_t n_values, n_res, n_model, error;
+    mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
+    // 32 values per round: eight independent 16-byte loads (a lane that waited for one load per four additions
+    // spent its time waiting - 3.4 ms for a 50 000-value chain), then the additions, in stream order.
+    auto chain = [&](unsigned long long at_piece, uint32_t n, bool starts_as_first) {
+        const uint4 *from = reinterpret_cast<const uint4 *>(values + at_piece * MV_PIECE_VALUES);
+        float sum = 0.0f;
+        uint32_t k = 0;
+        if (starts_as_first && n > 0) { // macaque_v.rs:228-235: the sum starts AS the first value
+            sum = __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES));
+            k = 1;
+        }
+        // (up to the next multiple of 32, one value at a time)
+        for (; k < n && (k & 31u) != 0; k++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + k));
+        for (; k + 32 <= n; k += 32) {
+            uint4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = load_global(from + (k >> 2) + q);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                sum += __uint_as_float(v[q].x);
+                sum += __uint_as_float(v[q].y);
+                sum += __uint_as_float(v[q].z);
+                sum += __uint_as_float(v[q].w);
+            }
+        }
+        for (; k < n; k++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + k));
+        return sum;
+    };
+    const unsigned long long value_pieces = (n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES;
+    stream_sums[2 * i] = n_values ? chain(first_piece, n_values, true) : 0.0f;
+    stream_sums[2 * i + 1] = n_res ? chain(first_piece + value_pieces, n_res, false) : 0.0f;
 }
 
 // ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
@@ -2058,7 +2174,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ irregular_totals,
     const uint32_t *__restrict__ irregular_first, int64_t *__restrict__ out_ts, float *__restrict__ out_val,
-    GridHeader *__restrict__ header, TsCheckpoints checkpoints, bool skip_macaque) {
+    GridHeader *__restrict__ header, TsCheckpoints checkpoints, const TileDesc *__restrict__ indexed_desc) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -2126,7 +2242,9 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     // A stream is decoded from its beginning (the format has no random access) but only as far as
     // the last wanted value; the model's values are also needed in full when residuals are wanted,
     // because the residual stream is seeded with the model's last value.
-    // (skip_macaque: the batch has a cursor index and k_grid_mv_pieces decodes every stream piece by piece)
+    // (indexed_desc: the batch has a cursor index and k_grid_mv_pieces decodes every stream piece by piece, but for
+    // the residual tails it leaves here, mv_left_to_serial)
+    const bool skip_macaque = present && indexed_desc != nullptr && !mv_left_to_serial(indexed_desc[i].flags);
     const uint32_t n_res = d.n_total - d.n_model;
     const bool residuals_wanted = present && !skip_macaque && n_res > 0 && visible_end > d.n_model;
     const uint32_t values_to_decode = residuals_wanted ? d.n_model : min(d.n_model, visible_end);
@@ -2377,6 +2495,43 @@ int mv_index_prepare(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvInd
     }
     if (index->usable) *out = index;
     return 0;
+}
+
+// For mdb_agg.hip: the f32 sums of all MacaqueV streams of a batch that has a cursor index (see k_agg_mv_pieces);
+// *stream_sums stays nullptr when it has none. known_totals: of the caller's own counting walk (may be nullptr).
+int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, const uint32_t *known_totals,
+                         const float **stream_sums) {
+    *stream_sums = nullptr;
+    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    if (setting && std::strcmp(setting, "0") == 0) return 0;
+    std::shared_ptr<MvIndex> index = owned_segments_index(in);
+    if (!index) return 0;
+    {
+        std::lock_guard<std::mutex> lock(index->mutex);
+        if (!index->built || !index->usable) return 0; // (built by the first grid call, or by agg_run before its own walk)
+    }
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 8 + 256, &p)) return 1;
+    uint32_t *values = static_cast<uint32_t *>(p);
+    float *sums = reinterpret_cast<float *>(values + index->n_pieces * MV_PIECE_VALUES);
+    {
+        LaunchTimer timer(ctx, "k_agg_mv_pieces");
+        hipLaunchKernelGGL(k_agg_mv_pieces, dim3((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE)), dim3(MDB_WAVE), 0,
+                           ctx->stream, s, static_cast<const MvCursor *>(index->cursors), index->n_pieces, values);
+    }
+    {
+        LaunchTimer timer(ctx, "k_agg_mv_chains");
+        hipLaunchKernelGGL(k_agg_mv_chains, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
+                           static_cast<const unsigned long long *>(index->piece_base), values, sums);
+    }
+    *stream_sums = sums;
+    return 0;
+}
+
+// For mdb_agg.hip: make sure the batch's index exists before the aggregates lay out their scratch.
+int mv_index_ensure(mdb_ctx *ctx, const mdb_segments *in) {
+    std::shared_ptr<MvIndex> index;
+    return mv_index_prepare(ctx, in, &index);
 }
 
 // Runs prepass + scans; leaves descriptors/offsets in scratch and the header on the host.
@@ -3123,9 +3278,20 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
     if (index) {
         // A resident batch with cursors into its MacaqueV streams: every piece of 64 values by a lane of its own.
         LaunchTimer timer(ctx, "k_grid_mv_pieces");
-        hipLaunchKernelGGL(k_grid_mv_pieces, dim3((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE)), dim3(MDB_WAVE), 0,
-                           ctx->stream, s, range, plan.desc, plan.offsets, plan.irregular_first, plan.irregular_totals,
-                           plan.checkpoints, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val);
+        // (MDB_GRID_MV_ROUND: values a lane stages per round, 16 / 32 / 64: A/B)
+        static const int round = [] {
+            const char *text = std::getenv("MDB_GRID_MV_ROUND");
+            const int value = text ? std::atoi(text) : 0;
+            return value == 64 || value == 16 ? value : 32;
+        }();
+        const dim3 blocks((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE));
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, blocks, dim3(MDB_WAVE), 0, ctx->stream, s, range, plan.desc, plan.offsets,
+                               plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val);
+        };
+        if (round == 64) launch(k_grid_mv_pieces<64>);
+        else if (round == 16) launch(k_grid_mv_pieces<16>);
+        else launch(k_grid_mv_pieces<32>);
     } else if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
         MvSeg *segs = nullptr;
         if (grid_parallel_macaque(ctx, s, range, plan, out_val, &segs)) return 1;
@@ -3138,7 +3304,8 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
-                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints, index != nullptr);
+                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints,
+                           index ? plan.desc : static_cast<const TileDesc *>(nullptr));
     }
     if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
         LaunchTimer timer(ctx, "k_grid_swing_irregular");

@@ -310,3 +310,43 @@ def test_sums_of_irregular_swing_segments_are_the_same_either_way(hip, monkeypat
             assert (walked.count, walked.min, walked.max) == (expected.count, expected.min, expected.max)
         monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
         _assert_state(hip.agg_batch(segments, ALL), ora.agg_batch(segments, ALL))
+
+
+def test_sum_over_resident_batches_comes_from_the_cursor_index(hip):
+    # A batch that stays on the device: SUM builds (or finds) the cursors into its MacaqueV streams, decodes every
+    # piece of 64 values with a lane of its own and adds every stream up in stream order with one lane
+    # (k_agg_mv_pieces, k_agg_mv_chains) - the f32 sums macaque_v.rs:220-265 produces, whoever decodes.
+    import datagen
+    n = 1_000_000
+    timestamps, values = datagen.sine_series(3, n)
+    offsets = np.arange(0, n + 65536, 65536, dtype=np.uint64)
+    offsets[-1] = n
+    segments = ora.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
+    resident = hip.upload_segments(segments)
+    hip.profile_enable(True)
+    hip.profile_reset()
+    state = hip.agg_batch_dev(resident, ALL)          # (no grid call before it: the aggregate call builds the index)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert "k_agg_mv_chains" in kernels and "k_mv_index_walk" in kernels and "k_mv_serial_sums" not in kernels
+    _assert_state(state, ora.agg_batch(segments, ALL))
+    per_stream = 0.0
+    for k in range(len(offsets) - 1):
+        per_stream += float(np.add.accumulate(values[int(offsets[k]):int(offsets[k + 1])], dtype=np.float32)[-1])
+    assert abs(state.sum - per_stream) <= 1e-12 * abs(per_stream)
+    resident.free()
+    # residual tails with the seeds sum() uses (the model's last DECODED value), streams of every length, specials
+    rng = np.random.default_rng(83)
+    batches = [cases.edge_case_batch(), cases.edge_case_batch(cases.error_bounds()["rel5"])]
+    for eb_name in ("lossless", "abs0.01", "rel1", "rel5"):
+        for irregular in (False, True):
+            batches.append(cases.mixed_batch(cases.error_bounds()[eb_name], irregular, seed=int(rng.integers(1, 1000)),
+                                             length=25_000)[2])
+    for batch in batches:
+        resident = hip.upload_segments(batch)
+        expected = ora.agg_batch(batch, ALL)
+        for _ in range(2):
+            _assert_state(hip.agg_batch_dev(resident, ALL), expected)
+        lo, hi = int(batch.start_time[len(batch) // 3]), int(batch.end_time[2 * len(batch) // 3])
+        _assert_state(hip.agg_batch_range_dev(resident, lo, hi, ALL), ora.agg_batch_range(batch, lo, hi, ALL))
+        resident.free()
