@@ -97,7 +97,7 @@ __global__ __launch_bounds__(PREPASS_THREADS) void k_grid_prepass(
             if (i >= s.n) break;
             if (MODE == 2 && !((pending[i >> 6] >> (i & 63)) & 1ull)) continue;
         }
-        SegInfo info = MODE == 1 ? analyse_segment<true>(s, i) : analyse_segment<false>(s, i, known_totals, &checkpoints);
+        SegInfo info = MODE == 1 ? analyse_segment<ANALYSE_SIMPLE>(s, i) : analyse_segment<ANALYSE_GENERIC>(s, i, known_totals, &checkpoints);
         if (MODE != 1 && range.enabled) apply_time_range(s, i, info, range, nullptr, nullptr, &checkpoints);
         uint32_t jump_base = 0;
         if (MODE != 1 && !range.enabled && (info.desc.flags & FLAG_CHECKPOINTS) && checkpoints.jumps) {
@@ -691,6 +691,279 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_grid_tiles_jumps(
     const uint32_t *__restrict__ tile_first, uint64_t n_segments, uint64_t total_points,
     uint64_t n_tiles, int64_t *__restrict__ out_ts, float *__restrict__ out_val, const TsJump *__restrict__ jumps) {
     grid_tile<true>(desc, offsets, tile_first, n_segments, total_points, n_tiles, out_ts, out_val, jumps);
+}
+
+// ---- short segments: one pass over the raw rows ------------------------------------------------------------
+//
+// With 8 points per segment the pipeline above moves 193 bytes per segment around its 96 bytes of output - the
+// prepass reads the 73-byte row and writes a 48-byte descriptor and a count, the offsets pass turns the count into
+// an offset, the tile kernel reads descriptor and offset - and runs at a third of the HBM peak against the
+// algorithmic bytes. A batch of SIMPLE segments (PMC-Mean / Swing, regular timestamps, no residuals: nothing any
+// other kernel needs a descriptor for) can do without all of that: a workgroup takes 256 consecutive segments,
+// analyses them from the raw rows into LDS, learns where its points begin from the workgroups before it
+// (a decoupled look-back over one 64-bit word per workgroup: 2 flag bits and a running total) and writes them,
+// 73 + 12 L bytes per segment in all. The first segment that is not simple raises a flag and the call falls back
+// to the general pipeline, which overwrites whatever this pass wrote.
+
+constexpr int FUSED_THREADS = 256;
+// (a workgroup takes FUSED_ROUNDS x 256 segments: fewer, larger links in the look-back)
+constexpr unsigned long long FUSED_FLAG_AGGREGATE = 1ull << 62, FUSED_FLAG_PREFIX = 2ull << 62, FUSED_VALUE_MASK = (1ull << 62) - 1;
+
+// The points of a segment with regular timestamps (decompress_all_timestamps' count, timestamps.rs:163-223), from
+// its timestamps view, start and end time alone; 0 where analyse_segment finds an error.
+__device__ __forceinline__ uint32_t regular_segment_points(const DevSegments &s, uint64_t i) {
+    const uint4 vt = s.timestamps.views[i];
+    const int32_t ts_len = (int32_t)vt.x;
+    const int64_t start = s.start_time[i], end = s.end_time[i];
+    if (ts_len == 0) return start == end ? 1u : 2u;
+    if (ts_len < 0 || ts_len > 8) return 0;
+    uint64_t length = 0;
+    for (int32_t k = 0; k < ts_len; k++) length = (length << 8) | view_inline_byte(vt, k);
+    if (length < 2 || end < start) return 0;
+    const uint64_t span = (uint64_t)(end - start), interval = span / (length - 1);
+    if (interval == 0) return 0;
+    const uint64_t produced = span / interval + 1;
+    return produced > COUNT_MASK ? 0u : (uint32_t)produced;
+}
+
+// desc / offsets / serial_ids: written for the segments with serial work only (MacaqueV values, residual tails),
+// which the kernels behind this one decode (k_grid_mv_pieces or k_grid_serial); header->n_serial counts them.
+template <int FUSED_ROUNDS>
+__global__ __launch_bounds__(FUSED_THREADS) void k_grid_fused(DevSegments s, unsigned long long *__restrict__ lookback,
+                                                              GridHeader *__restrict__ header, int64_t *__restrict__ out_ts,
+                                                              float *__restrict__ out_val, uint32_t *__restrict__ rows_per_segment,
+                                                              uint64_t cap, TileDesc *__restrict__ desc,
+                                                              unsigned long long *__restrict__ offsets,
+                                                              uint32_t *__restrict__ serial_ids) {
+    __shared__ __attribute__((aligned(16))) TileDesc lds_desc[FUSED_THREADS];
+    __shared__ uint32_t rel[FUSED_THREADS + 1]; // rel[k]: where segment k's points begin among the round's
+    __shared__ uint64_t scan_lds[17];
+    __shared__ unsigned long long lds_metrics[12];
+    __shared__ unsigned long long block_base;
+    __shared__ __attribute__((aligned(16))) longlong2 ts_slab[FUSED_THREADS / MDB_WAVE][2 * MDB_WAVE];
+    const int lane = threadIdx.x & (MDB_WAVE - 1);
+    const int wave = threadIdx.x / MDB_WAVE;
+    constexpr int FUSED_SEGMENTS = FUSED_THREADS * FUSED_ROUNDS;
+    if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
+    const uint64_t block_first = (uint64_t)blockIdx.x * FUSED_SEGMENTS;
+
+    // ---- how many points the workgroup's segments have, and where they begin in the output ---------------------
+    uint32_t counts[FUSED_ROUNDS];
+    uint64_t mine_total = 0;
+    bool irregular = false;
+#pragma unroll
+    for (int k = 0; k < FUSED_ROUNDS; k++) {
+        const uint64_t i = block_first + (uint64_t)k * FUSED_THREADS + threadIdx.x;
+        counts[k] = 0;
+        if (i < s.n) {
+            if (segment_has_regular_timestamps(s, i)) counts[k] = regular_segment_points(s, i);
+            else irregular = true;
+        }
+        mine_total += counts[k];
+    }
+    if (irregular) header->pad = 1u; // (a delta-of-delta stream: the general pipeline takes the batch)
+    uint64_t total;
+    (void)block_exclusive_scan_u64(mine_total, scan_lds, &total);
+    if (wave == 0) {
+        // The look-back, by the whole wave: publish this workgroup's total, read the states of the 64 workgroups in
+        // front at once, add up their totals down to the nearest one that has its running total already, publish
+        // ours. (Workgroups start in the order of their indices, so the ones looked back at are running or done.)
+        unsigned long long in_front = 0;
+        if (blockIdx.x > 0) {
+            if (lane == 0)
+                __hip_atomic_store(lookback + blockIdx.x, FUSED_FLAG_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long top = (long long)blockIdx.x - 1;
+            for (;;) {
+                const long long b = top - lane;
+                const unsigned long long state = b >= 0 ? __hip_atomic_load(lookback + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                        : FUSED_FLAG_PREFIX; // (in front of the first workgroup: nothing)
+                const unsigned long long has_prefix = __ballot((state & FUSED_FLAG_PREFIX) != 0);
+                const unsigned long long missing = __ballot((state >> 62) == 0);
+                const int nearest_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : MDB_WAVE - 1;
+                const unsigned long long needed = nearest_prefix >= MDB_WAVE - 1 ? ~0ull : ((1ull << (nearest_prefix + 1)) - 1ull);
+                if (missing & needed) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                unsigned long long value = lane <= nearest_prefix ? (state & FUSED_VALUE_MASK) : 0ull;
+#pragma unroll
+                for (int delta = 1; delta < MDB_WAVE; delta <<= 1)
+                    value += ((unsigned long long)__shfl_xor((uint32_t)(value >> 32), delta, MDB_WAVE) << 32) |
+                             __shfl_xor((uint32_t)value, delta, MDB_WAVE);
+                in_front += value;
+                if (has_prefix) break;
+                top -= MDB_WAVE;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(lookback + blockIdx.x, FUSED_FLAG_PREFIX | (in_front + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            block_base = in_front;
+            if ((uint64_t)blockIdx.x == (s.n - 1) / FUSED_SEGMENTS) header->total_points = in_front + total;
+        }
+    }
+    __syncthreads();
+    unsigned long long running = block_base;
+
+    // ---- 256 segments at a time: analysed from their rows into LDS, their points written -----------------------
+#pragma unroll 1
+    for (int k = 0; k < FUSED_ROUNDS; k++) {
+        const uint64_t round_first = block_first + (uint64_t)k * FUSED_THREADS;
+        if (round_first >= s.n) break;
+        const uint64_t i = round_first + threadIdx.x;
+        const uint32_t n_in_round = (uint32_t)min((uint64_t)FUSED_THREADS, s.n - round_first);
+        const uint32_t count = counts[k];
+        TileDesc mine = TileDesc{};
+        uint32_t error = 0;
+        bool serial = false;
+        if (i < s.n && segment_has_regular_timestamps(s, i)) {
+            const SegInfo info = analyse_segment<ANALYSE_REGULAR>(s, i);
+            error = info.error;
+            mine = make_tile_desc(info.desc);
+            mine.n_points = count; // (what the layout was made with; differs from the analysis only where that fails)
+            mine.n_model = min(mine.n_model, count);
+            serial = !error && (info.desc.flags & FLAG_SERIAL) != 0;
+            const uint32_t type = mine.flags & FLAG_TYPE_MASK;
+            if (type < 3) {
+                atomicAdd(&lds_metrics[type], (unsigned long long)count);
+                atomicAdd(&lds_metrics[4 + type], 1ull);
+            }
+            if (info.desc.flags & FLAG_HAS_RESIDUALS) atomicAdd(&lds_metrics[3], 1ull);
+            atomicAdd(&lds_metrics[7], 1ull);
+        }
+        lds_desc[threadIdx.x] = mine;
+        uint64_t round_total;
+        const uint64_t exclusive = block_exclusive_scan_u64(count, scan_lds, &round_total);
+        rel[threadIdx.x] = (uint32_t)exclusive;
+        if (error) atomicOr(&header->error, error);
+        if (rows_per_segment && i < s.n) rows_per_segment[i] = count;
+        // (the kernels behind this one look the segments with serial work up; a place in their list for each of the
+        // wave's with ONE atomic - one per segment on the one counter took 2 ms for a million of them)
+        const unsigned long long serial_lanes = __ballot(serial);
+        if (serial_lanes) {
+            unsigned long long first_place = 0;
+            if (lane == __ffsll((long long)serial_lanes) - 1)
+                first_place = atomicAdd(&header->n_serial, (unsigned long long)__popcll(serial_lanes));
+            first_place = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(first_place >> 32), __ffsll((long long)serial_lanes) - 1) << 32) |
+                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)first_place, __ffsll((long long)serial_lanes) - 1);
+            if (serial) {
+                desc[i] = mine;
+                offsets[i] = running + exclusive;
+                serial_ids[first_place + __popcll(serial_lanes & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            }
+        }
+        __syncthreads();
+
+        // The round's points [base, end) of the output, four consecutive ones per lane and step; the groups of four
+        // are aligned in the OUTPUT (16-byte stores), so the first and the last group may be shared with the
+        // neighbouring round or workgroup: each stores its own points of them one by one.
+        const unsigned long long base = min(running, (unsigned long long)cap), end = min(running + round_total, (unsigned long long)cap);
+        running += round_total;
+        if (base < end) {
+            const unsigned long long first_group = base >> 2, groups = ((end + 3) >> 2) - first_group;
+            for (unsigned long long g0 = 0; g0 < groups; g0 += FUSED_THREADS) {
+                const unsigned long long wave_base = ((first_group + g0) << 2) + (unsigned long long)wave * (MDB_WAVE * 4);
+                if (wave_base >= end) break; // (wave-uniform: the wave's points lie behind the round's)
+                const unsigned long long p = wave_base + (unsigned long long)lane * 4;
+                int64_t t[4] = {0, 0, 0, 0};
+                float values[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (p + 4 > base && p < end) {
+                    // The segment of the group's first point that belongs to this round.
+                    const unsigned long long q0 = max(p, base);
+                    const uint32_t local = (uint32_t)(q0 - base);
+                    // Largest k with rel[k] <= local: segments of a round are about equally long more often than not, so
+                    // the search starts where equally long ones would put the point and looks at most four segments
+                    // to either side before it halves what is left (eight dependent LDS reads per group otherwise).
+                    uint32_t lo = 0, hi = n_in_round;
+                    {
+                        uint32_t guess = min(n_in_round - 1, (uint32_t)(((unsigned long long)local * n_in_round) / round_total));
+#pragma unroll 1
+                        for (int step = 0; step < 4 && rel[guess] > local; step++) guess -= 1; // (rel[0] = 0 <= local)
+                        if (rel[guess] <= local) {
+                            lo = guess;
+#pragma unroll 1
+                            for (int step = 0; step < 4 && lo + 1 < n_in_round && rel[lo + 1] <= local; step++) lo += 1;
+                            hi = (lo + 1 < n_in_round && rel[lo + 1] <= local) ? n_in_round : lo + 1;
+                        } else {
+                            hi = guess;
+                        }
+                    }
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (rel[mid] <= local) lo = mid; else hi = mid;
+                    }
+                    TileDesc d = lds_desc[lo];
+                    unsigned long long segment_offset = base + rel[lo];
+                    const uint32_t index = (uint32_t)(q0 - segment_offset);
+                    if (p >= base && index + 4 <= d.n_model) { // all four points of one segment's model
+                        const PointValue first_point = reconstruct_point(d, index);
+                        t[0] = first_point.t; t[1] = t[0] + d.delta; t[2] = t[1] + d.delta; t[3] = t[2] + d.delta;
+                        if ((d.flags & FLAG_TYPE_MASK) == MDB_SWING_ID) {
+                            values[0] = first_point.v;
+                            values[1] = (float)(d.slope * (double)t[1] + d.intercept);
+                            values[2] = (float)(d.slope * (double)t[2] + d.intercept);
+                            values[3] = (float)(d.slope * (double)t[3] + d.intercept);
+                        } else {
+                            values[0] = values[1] = values[2] = values[3] = d.value;
+                        }
+                    } else {
+                        unsigned long long next_offset = segment_offset + d.n_points;
+#pragma unroll 1
+                        for (uint32_t m = 0; m < 4; m++) {
+                            const unsigned long long q = p + m;
+                            if (q < base) continue;
+                            if (q >= end) break;
+                            while (q >= next_offset) {
+                                lo += 1;
+                                segment_offset = next_offset;
+                                d = lds_desc[lo];
+                                next_offset = segment_offset + d.n_points;
+                            }
+                            const uint32_t at = (uint32_t)(q - segment_offset);
+                            PointValue point = reconstruct_point(d, at);
+                            // (a residual or MacaqueV value: a placeholder, the kernels behind this one write it)
+                            if (at >= d.n_model || (d.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID) point.v = 0.0f;
+                            if (m == 0) { t[0] = point.t; values[0] = point.v; }
+                            if (m == 1) { t[1] = point.t; values[1] = point.v; }
+                            if (m == 2) { t[2] = point.t; values[2] = point.v; }
+                            if (m == 3) { t[3] = point.t; values[3] = point.v; }
+                        }
+                    }
+                    if (p >= base && p + 4 <= end) {
+                        *reinterpret_cast<float4 *>(out_val + p) = make_float4(values[0], values[1], values[2], values[3]);
+                    } else {
+#pragma unroll
+                        for (uint32_t m = 0; m < 4; m++)
+                            if (p + m >= base && p + m < end) out_val[p + m] = values[m];
+                    }
+                }
+                // Timestamps through the wave's LDS slab, as k_grid_tiles does: 1 KiB per store instruction.
+                longlong2 *slab = ts_slab[wave];
+                slab[2 * lane] = make_longlong2(t[0], t[1]);
+                slab[2 * lane + 1] = make_longlong2(t[2], t[3]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const longlong2 chunk_a = slab[lane];
+                const longlong2 chunk_b = slab[MDB_WAVE + lane];
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long point_a = wave_base + 2 * (unsigned long long)lane;
+                const unsigned long long point_b = point_a + 2 * MDB_WAVE;
+                longlong2 *ts_out = reinterpret_cast<longlong2 *>(out_ts + wave_base);
+                if (point_a >= base && point_a + 2 <= end) ts_out[lane] = chunk_a;
+                else {
+                    if (point_a >= base && point_a < end) out_ts[point_a] = chunk_a.x;
+                    if (point_a + 1 >= base && point_a + 1 < end) out_ts[point_a + 1] = chunk_a.y;
+                }
+                if (point_b >= base && point_b + 2 <= end) ts_out[MDB_WAVE + lane] = chunk_b;
+                else {
+                    if (point_b >= base && point_b < end) out_ts[point_b] = chunk_b.x;
+                    if (point_b + 1 >= base && point_b + 1 < end) out_ts[point_b + 1] = chunk_b.y;
+                }
+            }
+        }
+        __syncthreads(); // (the next round reuses lds_desc and rel)
+    }
+    if (threadIdx.x < 10 && lds_metrics[threadIdx.x]) atomicAdd(&header->metrics[threadIdx.x], lds_metrics[threadIdx.x]);
 }
 
 // ---- irregular timestamps, one lane per piece of a stream ---------------------------------------------------
@@ -3208,6 +3481,53 @@ int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32
     return 0;
 }
 
+// What k_grid_tiles (or k_grid_fused) leaves: MacaqueV values and residual tails - piece by piece when the batch has
+// a cursor index, else by the speculative decoder and one lane per stream - and the irregular timestamps that live
+// inside their views.
+int grid_launch_streams(mdb_ctx *ctx, const DevSegments &s, TimeRange range, GridPlan &plan, int64_t *out_ts, float *out_val) {
+    const uint64_t n_serial = plan.host_header.n_serial;
+    const MvSeg *mv_segs = nullptr;
+    const MvIndex *index = plan.mv_index.get();
+    if (index) {
+        // A resident batch with cursors into its MacaqueV streams: every piece of 64 values by a lane of its own.
+        LaunchTimer timer(ctx, "k_grid_mv_pieces");
+        // (MDB_GRID_MV_ROUND: values a lane stages per round, 16 / 32 / 64: A/B)
+        static const int round = [] {
+            const char *text = std::getenv("MDB_GRID_MV_ROUND");
+            const int value = text ? std::atoi(text) : 0;
+            return value == 64 || value == 16 ? value : 32;
+        }();
+        const dim3 blocks((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE));
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, blocks, dim3(MDB_WAVE), 0, ctx->stream, s, range, plan.desc, plan.offsets,
+                               plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val);
+        };
+        if (round == 64) launch(k_grid_mv_pieces<64>);
+        else if (round == 16) launch(k_grid_mv_pieces<16>);
+        else launch(k_grid_mv_pieces<32>);
+    } else if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
+        MvSeg *segs = nullptr;
+        if (grid_parallel_macaque(ctx, s, range, plan, out_val, &segs)) return 1;
+        mv_segs = segs;
+    }
+    // (with the index the serial kernel is left with the irregular timestamps that live inside their views)
+    if (n_serial > 0 && (!index || plan.host_header.metrics[8] > 0)) {
+        LaunchTimer timer(ctx, "k_grid_serial");
+        hipLaunchKernelGGL(k_grid_serial,
+                           dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
+                           dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
+                           plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
+                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints,
+                           index ? plan.desc : static_cast<const TileDesc *>(nullptr));
+    }
+    if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
+        LaunchTimer timer(ctx, "k_grid_swing_irregular");
+        hipLaunchKernelGGL(k_grid_swing_irregular, dim3((uint32_t)((n_serial + 3) / 4)), dim3(256), 0, ctx->stream,
+                           plan.desc, plan.offsets, plan.serial_ids, n_serial, out_ts, out_val);
+    }
+    return 0;
+}
+
 // Launch the reconstruction of a planned batch into device buffers (enqueue + final error check).
 int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan &plan, int64_t *out_ts,
                 float *out_val, uint32_t *out_rows) {
@@ -3272,47 +3592,7 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
             hipLaunchKernelGGL(k_grid_timestamps, dim3(ts_blocks), dim3(TS_THREADS), 0, ctx->stream, ts_args);
         }
     }
-    const uint64_t n_serial = plan.host_header.n_serial;
-    const MvSeg *mv_segs = nullptr;
-    const MvIndex *index = plan.mv_index.get();
-    if (index) {
-        // A resident batch with cursors into its MacaqueV streams: every piece of 64 values by a lane of its own.
-        LaunchTimer timer(ctx, "k_grid_mv_pieces");
-        // (MDB_GRID_MV_ROUND: values a lane stages per round, 16 / 32 / 64: A/B)
-        static const int round = [] {
-            const char *text = std::getenv("MDB_GRID_MV_ROUND");
-            const int value = text ? std::atoi(text) : 0;
-            return value == 64 || value == 16 ? value : 32;
-        }();
-        const dim3 blocks((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE));
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, blocks, dim3(MDB_WAVE), 0, ctx->stream, s, range, plan.desc, plan.offsets,
-                               plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val);
-        };
-        if (round == 64) launch(k_grid_mv_pieces<64>);
-        else if (round == 16) launch(k_grid_mv_pieces<16>);
-        else launch(k_grid_mv_pieces<32>);
-    } else if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
-        MvSeg *segs = nullptr;
-        if (grid_parallel_macaque(ctx, s, range, plan, out_val, &segs)) return 1;
-        mv_segs = segs;
-    }
-    // (with the index the serial kernel is left with the irregular timestamps that live inside their views)
-    if (n_serial > 0 && (!index || plan.host_header.metrics[8] > 0)) {
-        LaunchTimer timer(ctx, "k_grid_serial");
-        hipLaunchKernelGGL(k_grid_serial,
-                           dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
-                           dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
-                           plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
-                           plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints,
-                           index ? plan.desc : static_cast<const TileDesc *>(nullptr));
-    }
-    if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
-        LaunchTimer timer(ctx, "k_grid_swing_irregular");
-        hipLaunchKernelGGL(k_grid_swing_irregular, dim3((uint32_t)((n_serial + 3) / 4)), dim3(256), 0, ctx->stream,
-                           plan.desc, plan.offsets, plan.serial_ids, n_serial, out_ts, out_val);
-    }
-    return 0;
+    return grid_launch_streams(ctx, s, range, plan, out_ts, out_val);
 }
 
 // The serial kernel can still find a malformed bitstream; read its verdict (syncs the stream).
@@ -3326,9 +3606,87 @@ int grid_late_error(mdb_ctx *ctx, GridPlan &plan) {
     return 0;
 }
 
+// The one-pass path for a batch of short segments with regular timestamps (k_grid_fused). *done = false: the batch
+// does not qualify (or turned out to hold a delta-of-delta timestamp stream) and the general pipeline has to run.
+int grid_fused(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out_val, uint32_t *out_rows, uint64_t cap,
+               uint64_t *n_out, mdb_grid_metrics *metrics, bool *done) {
+    *done = false;
+    const uint64_t n = in->n;
+    // (MDB_GRID_FUSED=0: never; =1: whenever the batch has no out-of-line timestamps, whatever its segments' lengths)
+    const char *setting = std::getenv("MDB_GRID_FUSED");
+    const bool forced = setting && std::strcmp(setting, "1") == 0;
+    if (setting && std::strcmp(setting, "0") == 0) return 0;
+    if (!out_ts || !out_val || n == 0 || n > 0xfffffff0ull) return 0;
+    if (!forced && (n < 65536 || cap / n > 96)) return 0; // (long segments: the tile kernel's ground)
+    for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
+        if (in->timestamps.buffer_sizes[b] > 0) return 0; // (out-of-line timestamps: delta-of-delta streams)
+    if ((reinterpret_cast<uintptr_t>(out_ts) & 15u) || (reinterpret_cast<uintptr_t>(out_val) & 15u)) return 0;
+    GridPlan plan;
+    if (mv_index_prepare(ctx, in, &plan.mv_index)) return 1; // (before the scratch below is laid out)
+    static const int rounds = [] { // (MDB_GRID_FUSED_ROUNDS: 256-segment rounds per workgroup, 2 / 4 / 8 / 16: A/B; 2.0 / 1.8 / 1.6 / 2.4 ms at 8 points per segment)
+        const char *text = std::getenv("MDB_GRID_FUSED_ROUNDS");
+        const int value = text ? std::atoi(text) : 0;
+        return value == 2 || value == 4 || value == 16 ? value : 8;
+    }();
+    const uint64_t n_blocks = (n + (uint64_t)FUSED_THREADS * rounds - 1) / ((uint64_t)FUSED_THREADS * rounds);
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_BLOCK_SUMS, n_blocks * 8 + 64, &p)) return 1;
+    unsigned long long *lookback = static_cast<unsigned long long *>(p);
+    if (scratch_reserve(ctx, SCRATCH_HEADER, sizeof(GridHeader), &p)) return 1;
+    plan.header = static_cast<GridHeader *>(p);
+    // (for the segments with serial work only: the three arrays are sparse)
+    if (scratch_reserve(ctx, SCRATCH_DESC, n * sizeof(TileDesc), &p)) return 1;
+    plan.desc = static_cast<TileDesc *>(p);
+    if (scratch_reserve(ctx, SCRATCH_OFFSETS, (n + 1) * 8, &p)) return 1;
+    plan.offsets = static_cast<unsigned long long *>(p);
+    if (scratch_reserve(ctx, SCRATCH_SERIAL_IDS, (n + 1) * 4, &p)) return 1;
+    plan.serial_ids = static_cast<uint32_t *>(p);
+    plan.counts = plan.irregular_totals = plan.irregular_first = nullptr;
+    plan.checkpoints = TsCheckpoints{nullptr, nullptr, nullptr, nullptr, nullptr};
+    plan.n_ts_pieces = 0;
+    MDB_HIP_CHECK(hipMemsetAsync(lookback, 0, n_blocks * 8, ctx->stream));
+    MDB_HIP_CHECK(hipMemsetAsync(plan.header, 0, sizeof(GridHeader), ctx->stream));
+    const DevSegments s = to_dev(in);
+    {
+        LaunchTimer timer(ctx, "k_grid_fused");
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)n_blocks), dim3(FUSED_THREADS), 0, ctx->stream, s, lookback, plan.header,
+                               out_ts, out_val, out_rows, cap, plan.desc, plan.offsets, plan.serial_ids);
+        };
+        if (rounds == 2) launch(k_grid_fused<2>);
+        else if (rounds == 4) launch(k_grid_fused<4>);
+        else if (rounds == 16) launch(k_grid_fused<16>);
+        else launch(k_grid_fused<8>);
+    }
+    MDB_HIP_CHECK(hipMemcpyAsync(&plan.host_header, plan.header, sizeof(GridHeader), hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipGetLastError());
+    const GridHeader &host = plan.host_header;
+    if (host.pad) return 0; // a delta-of-delta timestamp stream: the general pipeline
+    if (host.error) return fail(describe_error(host.error));
+    if (n_out) *n_out = host.total_points;
+    fill_metrics(host, metrics);
+    if (host.total_points > cap)
+        return fail("Output buffers too small: " + std::to_string(host.total_points) + " data points but capacity " +
+                    std::to_string(cap) + ".");
+    if (host.n_serial > 0) {
+        plan.mv_min_values = 0xffffffffu; // (the speculative decoder is for a few long streams: not this path's batches)
+        plan.mv_forced = false;
+        if (grid_launch_streams(ctx, s, TimeRange{0, 0, 0}, plan, out_ts, out_val)) return 1;
+        if (grid_late_error(ctx, plan)) return 1;
+    }
+    *done = true;
+    return 0;
+}
+
 int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, int64_t *out_ts,
                           float *out_val, uint32_t *out_rows, uint64_t cap, uint64_t *n_out,
                           mdb_grid_metrics *metrics) {
+    if (!range.enabled) {
+        bool done = false;
+        if (grid_fused(ctx, in, out_ts, out_val, out_rows, cap, n_out, metrics, &done)) return 1;
+        if (done) return 0;
+    }
     GridPlan plan;
     std::shared_ptr<MvIndex> index;
     if (mv_index_prepare(ctx, in, &index)) return 1;

@@ -422,6 +422,13 @@ struct SegInfo {
     uint32_t regular_length; // len() of a regular stream = the stored big-endian integer
 };
 
+// The timestamps of segment i are regular (timestamps.rs:199-202), or the empty stream of one or two points.
+__device__ __forceinline__ bool segment_has_regular_timestamps(const DevSegments &s, uint64_t i) {
+    const uint4 vt = s.timestamps.views[i];
+    const int32_t ts_len = (int32_t)vt.x;
+    return ts_len == 0 || (ts_len > 0 && (view_inline_byte(vt, 0) & 0x80u) == 0);
+}
+
 // PMC-Mean or Swing, timestamps regular (or the empty stream of one or two points), no residuals: nothing
 // about such a segment needs a bit stream walked.
 __device__ __forceinline__ bool segment_is_simple(const DevSegments &s, uint64_t i) {
@@ -439,18 +446,23 @@ __device__ __forceinline__ bool segment_is_simple(const DevSegments &s, uint64_t
 // `checkpoints` (may be nullptr): the batch's timestamp checkpoints, made by k_grid_ts_count (which has
 // also left the streams' lengths in known_totals).
 //
-// SIMPLE = true is the same analysis for a segment the caller has found to be "simple"
+// KIND = 1 (ANALYSE_SIMPLE) is the same analysis for a segment the caller has found to be "simple"
 // (segment_is_simple(): PMC-Mean or Swing, regular timestamps, no residuals): the branches such a
 // segment cannot take are not compiled, which is what lets the prepass run them at three times the
 // occupancy (the delta-of-delta decoders are most of the generic version's 132 registers).
 // `line_wanted` = false: the caller has no use for the Swing line through the MODEL's end (grid()'s line; the
 // aggregates' goes through the segment's end, swing.rs:273-274) - which, for a segment with irregular timestamps
 // and residuals, costs a decode of its stream up to that point.
-template <bool SIMPLE = false>
+// KIND = 2 (ANALYSE_REGULAR): any model type, residuals allowed, but timestamps the caller has found to be regular
+// (segment_has_regular_timestamps): the delta-of-delta decoders are not compiled, the rest is the generic analysis.
+constexpr int ANALYSE_GENERIC = 0, ANALYSE_SIMPLE = 1, ANALYSE_REGULAR = 2;
+template <int KIND = ANALYSE_GENERIC>
 __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_t i,
                                                    const uint32_t *known_totals = nullptr,
                                                    const TsCheckpoints *checkpoints = nullptr,
                                                    bool line_wanted = true) {
+    constexpr bool SIMPLE = KIND == ANALYSE_SIMPLE;         // no residuals, not a MacaqueV model
+    constexpr bool NO_STREAMS = KIND != ANALYSE_GENERIC;    // no delta-of-delta timestamps
     SegInfo info;
     info.error = 0;
     info.swing_first = 0.0f;
@@ -517,8 +529,8 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
                 }
             }
         }
-    } else if (SIMPLE) {
-        if (ts_len > 0) info.error |= ERR_TIMESTAMPS; // (not a simple segment: the caller's mistake)
+    } else if (NO_STREAMS) {
+        if (ts_len > 0) info.error |= ERR_TIMESTAMPS; // (not a segment with regular timestamps: the caller's mistake)
     } else if (ts_len > 0) {
         regular = false;
         ts_bytes = view_data(s.timestamps, i, vt);
@@ -566,7 +578,7 @@ __device__ __forceinline__ SegInfo analyse_segment(const DevSegments &s, uint64_
             info.error |= ERR_VALUES; // expect("Model should represent at least one value.")
         } else if (!info.error) {
             int64_t model_end = start;
-            if (regular || SIMPLE) {
+            if (regular || NO_STREAMS) {
                 model_end = start + (int64_t)((uint64_t)(n_model - 1) * (uint64_t)d.delta);
             } else if (n_res == 0 || !line_wanted) {
                 model_end = end; // the last timestamp is not stored in the stream: it is end_time

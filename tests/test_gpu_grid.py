@@ -910,3 +910,94 @@ def test_piece_decoder_beyond_two_to_the_31_values(hip):
     for pointer in (out_ts, out_val, offsets_dev):
         hip.dev_free(pointer)
     fitted.free()
+
+
+def _short_simple_segments(rng, n, longest=20):
+    """n PMC-Mean / Swing segments of 1..longest points with regular timestamps and no residuals, as rows."""
+    lengths = rng.integers(1, longest + 1, n)
+    types = rng.integers(0, 2, n)
+    deltas = rng.integers(1, 2000, n)
+    starts = np.cumsum(lengths * deltas + rng.integers(1, 50, n)) - lengths * deltas
+    first = rng.uniform(-100.0, 100.0, n).astype(np.float32)
+    last = (first + rng.uniform(0.5, 30.0, n).astype(np.float32)).astype(np.float32)
+    decreasing = rng.random(n) < 0.5
+    rows = []
+    for k in range(n):
+        length, start, delta = int(lengths[k]), int(starts[k]), int(deltas[k])
+        end = start + (length - 1) * delta
+        timestamps = b"" if length <= 2 else bytes([length])
+        if length == 2 and rng.random() < 0.5:
+            timestamps = bytes([2])   # (two points may also carry their length)
+        if types[k] == 0 or length == 1:
+            rows.append((0, start, end, timestamps, float(first[k]), float(first[k]), b"", b""))
+        else:   # Swing: (min, max) are (first, last) or, with the one-byte flag, (last, first)
+            rows.append((1, start, end, timestamps, float(first[k]), float(last[k]), bytes([0]) if decreasing[k] else b"", b""))
+    return rows
+
+
+@pytest.mark.parametrize("fused", ["auto", "forced", "off"])
+def test_short_simple_segments_in_one_pass(hip, fused, monkeypatch):
+    # k_grid_fused: a batch of short PMC-Mean / Swing segments with regular timestamps is reconstructed from the
+    # raw rows in one pass (workgroups of 256 segments, their place in the output from a look-back over the
+    # workgroups in front), the same points as the prepass / offsets / tiles pipeline writes.
+    if fused == "forced":
+        monkeypatch.setenv("MDB_GRID_FUSED", "1")
+    elif fused == "off":
+        monkeypatch.setenv("MDB_GRID_FUSED", "0")
+    rng = np.random.default_rng(71)
+    for n, longest in ((70_000, 20), (3, 5), (257, 3), (1000, 1), (5000, 64)):
+        if fused == "auto" and n < 65536:
+            continue
+        rows = _short_simple_segments(rng, n, longest)
+        batch = mdb.SegmentBatch.from_rows(rows)
+        expected = ora.grid_batch(batch)
+        hip.profile_enable(True)
+        hip.profile_reset()
+        got = hip.grid_batch(batch)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        assert ("k_grid_fused" in kernels) == (fused != "off") and ("k_grid_tiles" in kernels) == (fused == "off")
+        cases.assert_grid_equal(got, expected)
+        assert np.array_equal(got[2], expected[2]) and got[3] == expected[3]
+        resident = hip.upload_segments(batch)
+        cases.assert_grid_equal(hip.grid_resident(resident), expected)
+        resident.free()
+        with pytest.raises(mdb.HipError, match="too small"):
+            hip.grid_batch(batch, cap=len(expected[0]) - 1)
+    # segments with serial work among them (a residual tail, a MacaqueV model): their model parts and timestamps
+    # come from the same pass, their streams from the kernels behind it
+    rows = _short_simple_segments(rng, 70_000 if fused == "auto" else 600, 12)
+    at = rows[400][2] + 1
+    tail = ora.try_compress_univariate_time_series(
+        np.arange(30, dtype=np.int64) * 100 + at,
+        np.concatenate([np.arange(20) * 3.0 + 1.0, rng.uniform(-1e3, 1e3, 10)]).astype(np.float32), cases.LOSSLESS)
+    noise = ora.try_compress_univariate_time_series(np.arange(40, dtype=np.int64) * 100 + int(tail.end_time[-1]) + 1,
+                                                    rng.uniform(-1e3, 1e3, 40).astype(np.float32), cases.LOSSLESS)
+    assert set(noise.model_type_id.tolist()) == {2} and (tail.residuals.lengths() > 0).any()
+    shift = int(noise.end_time[-1]) + 1
+    with_streams = rows[:401] + tail.rows() + noise.rows() + [(r[0], r[1] + shift, r[2] + shift) + r[3:] for r in rows[401:]]
+    batch = mdb.SegmentBatch.from_rows(with_streams)
+    expected = ora.grid_batch(batch)
+    for resident in (None, hip.upload_segments(batch)):
+        hip.profile_enable(True)
+        hip.profile_reset()
+        got = hip.grid_batch(batch) if resident is None else hip.grid_resident(resident)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        assert ("k_grid_fused" in kernels) == (fused != "off") and ("k_grid_tiles" in kernels) == (fused == "off")
+        assert ("k_grid_mv_pieces" in kernels) == (resident is not None) and ("k_grid_serial" in kernels) == (resident is None)
+        cases.assert_grid_equal(got, expected)
+        if resident is not None:
+            resident.free()
+    # a delta-of-delta timestamp stream (three irregular points, inside its view): the general pipeline takes the batch
+    irregular = ora.try_compress_univariate_time_series(np.array([0, 130, 200], dtype=np.int64) + shift + rows[-1][2] + 1,
+                                                        np.array([1.0, 1.0, 1.0], dtype=np.float32), cases.LOSSLESS)
+    assert not mdb.are_compressed_timestamps_regular(irregular.timestamps.value(0))
+    batch = mdb.SegmentBatch.from_rows(with_streams + irregular.rows())
+    hip.profile_enable(True)
+    hip.profile_reset()
+    got = hip.grid_batch(batch)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert "k_grid_tiles" in kernels
+    cases.assert_grid_equal(got, ora.grid_batch(batch))
