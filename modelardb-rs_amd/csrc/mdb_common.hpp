@@ -168,11 +168,20 @@ struct MvIndex {
     void *cursors = nullptr;    // MvCursor[n_pieces]
     void *piece_base = nullptr; // unsigned long long[n + 1]: first piece of every segment
     unsigned long long stream_values = 0; // values behind the cursors
+    // The same for the batch's delta-of-delta TIMESTAMP streams: what the counting walk of a grid call without a
+    // time range leaves behind (k_grid_ts_count: a cursor per 256 bits of stream, the jump lists, the list of
+    // pieces still to decode, every stream's number of points), kept from the first such call for the later ones.
+    bool ts_built = false;
+    bool ts_jumps = false;          // (built with jump lists: MDB_GRID_TS_JUMPS)
+    unsigned long long ts_n_pieces = 0, ts_live_pieces = 0;
+    void *ts_piece_base = nullptr;  // unsigned long long[n + 1]
+    void *ts_slots = nullptr;       // the block TsCheckpoints points into
+    void *ts_totals = nullptr;      // uint32_t[n + 4]
     ~MvIndex() {
-        if (cursors || piece_base) {
+        if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals) {
             (void)hipSetDevice(device);
-            if (cursors) (void)hipFree(cursors);
-            if (piece_base) (void)hipFree(piece_base);
+            for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals})
+                if (allocation) (void)hipFree(allocation);
         }
     }
 };

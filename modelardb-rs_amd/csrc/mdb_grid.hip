@@ -2624,6 +2624,7 @@ struct GridPlan {
     TsCheckpoints checkpoints; // of the batch's irregular timestamp streams (piece_base == nullptr: none)
     uint64_t n_ts_pieces;
     std::shared_ptr<MvIndex> mv_index; // cursors into the batch's MacaqueV streams, if it is a resident batch
+    std::shared_ptr<MvIndex> ts_cache_pending; // (grid_plan: the batch's timestamp cursors were copied for later calls)
 };
 
 // MDB_GRID_MV_MIN_VALUES: "off" disables the parallel MacaqueV decoder, a number sets the stream
@@ -2854,7 +2855,38 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
     const char *pieces_setting = std::getenv("MDB_GRID_TS_PIECES");
     if (pieces_setting && std::strcmp(pieces_setting, "off") == 0) ts_payload = 0;
-    if (ts_payload > 0) {
+    // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
+    const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
+    const bool jumps = !range.enabled && !(jumps_setting && std::strcmp(jumps_setting, "0") == 0);
+    auto point_checkpoints_into = [&](void *block, unsigned long long *piece_base, unsigned long long n_pieces) {
+        plan->checkpoints.piece_base = piece_base;
+        plan->checkpoints.slots = static_cast<TsCursor *>(block);
+        plan->checkpoints.piece_segment = reinterpret_cast<uint2 *>(plan->checkpoints.slots + n_pieces);
+        if (jumps) // (n_pieces * 40 bytes in front: 8-byte aligned, which is all a TsJump's members need)
+            plan->checkpoints.jumps = reinterpret_cast<TsJump *>(plan->checkpoints.piece_segment + n_pieces);
+        if (jumps && n_pieces < 0xffffffffull)
+            plan->checkpoints.live = reinterpret_cast<uint32_t *>(plan->checkpoints.jumps + n_pieces * TS_JUMPS_PER_PIECE);
+        plan->n_ts_pieces = n_pieces;
+    };
+    const uint64_t per_piece = sizeof(TsCursor) + sizeof(uint2) + (jumps ? TS_JUMPS_PER_PIECE * sizeof(TsJump) + 4 : 0);
+    // A batch that stays on the device keeps what the walk below leaves (MvIndex::ts_*): the walk is the same
+    // every time, and for randomly spaced timestamps it is a third of the call (MDB_GRID_TS_CACHE=0: walk every time).
+    const char *cache_setting = std::getenv("MDB_GRID_TS_CACHE");
+    std::shared_ptr<MvIndex> resident;
+    if (ts_payload > 0 && !range.enabled && !(cache_setting && std::strcmp(cache_setting, "0") == 0)) resident = owned_segments_index(in);
+    bool from_cache = false;
+    if (resident) {
+        std::lock_guard<std::mutex> lock(resident->mutex);
+        from_cache = resident->ts_built && resident->ts_jumps == jumps;
+    }
+    const uint32_t *known_totals = nullptr;
+    if (from_cache) {
+        if (resident->ts_n_pieces > 0)
+            point_checkpoints_into(resident->ts_slots, static_cast<unsigned long long *>(resident->ts_piece_base), resident->ts_n_pieces);
+        MDB_HIP_CHECK(hipMemcpyAsync(plan->irregular_totals, resident->ts_totals, (n + 4) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        MDB_HIP_CHECK(hipMemcpyAsync(&plan->header->live_pieces, &resident->ts_live_pieces, 8, hipMemcpyHostToDevice, ctx->stream));
+        known_totals = plan->irregular_totals;
+    } else if (ts_payload > 0) {
         // (behind the pieces' scan: the classes of the sort, then the order it puts the streams in)
         const uint64_t scan_bytes = ((n + 1) * 8 + scan_block_sums_bytes(n) + 63) & ~63ull;
         if (scratch_reserve(ctx, SCRATCH_TS_BASE, scan_bytes + (TS_SORT_CLASSES + 16) * 4 + n * 4 + 64, &p)) return 1;
@@ -2873,25 +2905,11 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (sorted && n_ts_streams > 0) ts_sort_place(ctx, s, n, TimeRange{0, 0, 0}, sort_counts, ts_order);
         if (n_pieces > 0) {
-            // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
-            const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
-            const bool jumps = !range.enabled && !(jumps_setting && std::strcmp(jumps_setting, "0") == 0);
-            const uint64_t per_piece = sizeof(TsCursor) + sizeof(uint2) + (jumps ? TS_JUMPS_PER_PIECE * sizeof(TsJump) + 4 : 0);
             if (scratch_reserve(ctx, SCRATCH_TS_SLOTS, n_pieces * per_piece + 64, &p)) return 1;
-            plan->checkpoints.piece_base = piece_base;
-            plan->checkpoints.slots = static_cast<TsCursor *>(p);
-            plan->checkpoints.piece_segment = reinterpret_cast<uint2 *>(plan->checkpoints.slots + n_pieces);
-            if (jumps) // (n_pieces * 40 bytes in front: 8-byte aligned, which is all a TsJump's members need)
-                plan->checkpoints.jumps = reinterpret_cast<TsJump *>(plan->checkpoints.piece_segment + n_pieces);
-            if (jumps && n_pieces < 0xffffffffull)
-                plan->checkpoints.live = reinterpret_cast<uint32_t *>(plan->checkpoints.jumps + n_pieces * TS_JUMPS_PER_PIECE);
-            plan->n_ts_pieces = n_pieces;
+            point_checkpoints_into(p, piece_base, n_pieces);
         }
-    }
-    // The lengths of the irregular timestamp streams (and the cursors of their pieces) first: a walk of
-    // its own, so that it can be a wave-synchronous one.
-    const uint32_t *known_totals = nullptr;
-    if (ts_payload > 0) {
+        // The lengths of the irregular timestamp streams (and the cursors of their pieces) first: a walk of
+        // its own, so that it can be a wave-synchronous one.
         const uint64_t lanes = ts_order ? n_ts_streams : n;
         if (lanes > 0) {
             LaunchTimer timer(ctx, "k_grid_ts_count");
@@ -2901,6 +2919,24 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
                                TimeRange{0, 0, 0}, static_cast<TsWalkRange *>(nullptr));
         }
         known_totals = plan->irregular_totals;
+        if (resident) {
+            // Kept for the batch's later calls: copies of what lies in scratch now (enqueued behind the walk).
+            std::lock_guard<std::mutex> lock(resident->mutex);
+            if (!resident->ts_built && !resident->ts_totals) {
+                bool kept = hipMalloc(&resident->ts_totals, (n + 4) * 4) == hipSuccess &&
+                            hipMemcpyAsync(resident->ts_totals, plan->irregular_totals, (n + 4) * 4, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+                if (kept && n_pieces > 0)
+                    kept = hipMalloc(&resident->ts_piece_base, (n + 1) * 8) == hipSuccess &&
+                           hipMalloc(&resident->ts_slots, n_pieces * per_piece + 64) == hipSuccess &&
+                           hipMemcpyAsync(resident->ts_piece_base, piece_base, (n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                           hipMemcpyAsync(resident->ts_slots, plan->checkpoints.slots, n_pieces * per_piece + 64, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+                if (kept) {
+                    resident->ts_n_pieces = n_pieces;
+                    resident->ts_jumps = jumps;
+                    plan->ts_cache_pending = resident; // (usable once this plan's header says the walk found no fault)
+                }
+            }
+        }
     }
     // Simple segments (PMC-Mean / Swing, regular timestamps, no residuals) first, through the trimmed
     // analysis; what that leaves, through the generic one (MDB_GRID_PREPASS_SPLIT=0: everything generic).
@@ -2934,6 +2970,20 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     MDB_HIP_CHECK(hipMemcpyAsync(&plan->host_header, plan->header, sizeof(GridHeader),
                                  hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (plan->ts_cache_pending) {
+        std::lock_guard<std::mutex> lock(plan->ts_cache_pending->mutex);
+        MvIndex &kept = *plan->ts_cache_pending;
+        if (!plan->host_header.error) {
+            kept.ts_live_pieces = plan->host_header.live_pieces;
+            kept.ts_built = true;
+        } else { // (a malformed stream: nothing is kept)
+            for (void **allocation : {&kept.ts_totals, &kept.ts_piece_base, &kept.ts_slots}) {
+                if (*allocation) (void)hipFree(*allocation);
+                *allocation = nullptr;
+            }
+        }
+        plan->ts_cache_pending.reset();
+    }
     if (plan->host_header.error) return fail(describe_error(plan->host_header.error));
     if (std::getenv("MDB_GRID_DEBUG"))
         std::fprintf(stderr, "grid: %llu points, %llu segments with jump lists, %llu points in %llu of %llu pieces left to checkpoints (%llu listed)\n",
