@@ -261,6 +261,7 @@ def host_path(context, mdb, np, sample, args):
     # What gathering buys: one input batch per submit (round 2's call shape) against the learned size.
     os.environ["MDB_HOST_GRID_COALESCE_SEGMENTS"] = "1"
     try:
+        host.measure_grid_stream(context, sample, 8192)  # (the pool of page-locked blocks gets blocks of this size)
         points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192)
     finally:
         del os.environ["MDB_HOST_GRID_COALESCE_SEGMENTS"]
