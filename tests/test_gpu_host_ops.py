@@ -134,9 +134,10 @@ def test_grid_stream_gathers_input_batches_and_keeps_one_submit_ahead(hip, coale
         else:
             # the first submit is one batch (nothing is known about the data yet), with one submit kept ahead so
             # is the second; then the stream has seen what a segment decompresses to and takes all that is ready
+            # (two submits are outstanding at a time on two worker threads: the log's order is not the submits')
             alone = 2 if grid_prefetch is None else 1
-            assert launches[:alone] == [(1, rows) for rows in pushed[:alone]]
-            assert launches[alone:] == [(len(pushed) - alone, sum(pushed[alone:]))]
+            expected = [(1, rows) for rows in pushed[:alone]] + [(len(pushed) - alone, sum(pushed[alone:]))]
+            assert sorted(launches) == sorted(expected)
 
 
 def test_grid_stream_drained_inside_the_library_returns_every_row(hip):
