@@ -72,6 +72,7 @@ enum ScratchSlot {
     SCRATCH_FIT_IN_TS,
     SCRATCH_FIT_IN_VALUES,
     SCRATCH_FIT_IN_OFFSETS,
+    SCRATCH_FIT_WAVE,
     SCRATCH_SLOT_COUNT
 };
 

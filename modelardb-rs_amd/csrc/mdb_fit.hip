@@ -839,6 +839,9 @@ struct SplitArgs {
     unsigned int *entry; // indexed by chunk_offsets[chunk] + point
     float *p0;
     float *p1;
+    // Per chunk, or nullptr: 0 = this chunk has its models already (k_fit_models_wave), it gets no pieces and
+    // is not walked.
+    const unsigned int *chunk_left;
 };
 
 constexpr uint32_t ENTRY_REJECTED = 1u;
@@ -847,7 +850,9 @@ constexpr uint32_t ENTRY_END_BIAS = 2u;
 struct PieceCount {
     const unsigned long long *chunk_offsets;
     uint32_t piece_points;
+    const unsigned int *chunk_left;
     __device__ uint64_t operator()(uint64_t c) const {
+        if (chunk_left && chunk_left[c] == 0u) return 0;
         const uint64_t length = chunk_offsets[c + 1] - chunk_offsets[c];
         return length > COUNT_MASK - ENTRY_END_BIAS ? 0 : (length + piece_points - 1) / piece_points;
     }
@@ -1507,6 +1512,423 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     }
 }
 
+// ---- k_fit_models_wave: one WAVE per chunk ---------------------------------------------------------------------
+//
+// For calls with few chunks (an embedded-API series, some thousand ingest buffers) under an absolute or relative
+// bound with regular timestamps that are exact in f64 (the regime of k_fit_models_lean). One lane per chunk
+// leaves most of the GPU idle there, and speculative pieces (split mode) only help while models are shorter than
+// a piece: a model that spans its chunk (a generous bound: PMC-Mean over all 65 536 points) is walked by every
+// piece's lane to its end. Here the 64 lanes of a wave take 64 CONSECUTIVE points of ONE model per step:
+//
+// PMC-Mean (pmc_mean.rs:58-75)  The model accepts point i iff the minimum and maximum of points 0..i are within
+//     the bound of (f32)(sum(0..i) / (i + 1)): three prefix scans and one test per lane, the first lane that fails
+//     ends the model. min_num / max_num keep their first operand on ties, which is associative. The f64 sum is the
+//     one place where the order of the additions could show - it cannot where every partial sum is exact: the
+//     summands are f32 (24 bits) whose exponents span `spread` binades, so `length` of them add up below
+//     2^(24 + spread + bits(length)) quanta; while that stays within 53 bits no addition rounds in ANY order. The
+//     spread is tracked per model (a block that breaks the condition hands the model to one lane, below).
+// Swing (swing.rs:101-198)      Both bounds are lines through the model's first point; a step replaces the upper
+//     one by the line through (t, v + deviation) when that line is lower, the lower one likewise. Which line is
+//     current at point i is a sequential chain - but a predictable one: in exact arithmetic the upper bound after
+//     points 2..i-1 is the candidate with the smallest slope. So every lane computes its two candidate lines
+//     (functions of the first point and its own), a scan finds the running extremes, and every lane evaluates the
+//     reference's own three comparisons against the state the scan predicts for it. The prediction is only a
+//     guess; what is exact is the check: the first lane that fails, or whose comparisons do not come out as the
+//     scan assumed (a rounding-level disagreement), has - by induction over the lanes in front of it - seen the
+//     true state, so its own outcome is the reference's; the wave takes it and scans again behind that lane.
+//     The sums of model() (swing.rs:212-228, 246-259) are f64 sums of rounded products: sequential by nature, and
+//     only needed once a Swing model has been chosen. They are queued and computed by one lane per model, 64
+//     models at a time.
+// Rejected start points (neither model reaches the 8 points it needs, compression.rs:238, 258-262) would cost a
+// step each; after one, the next 64 start points are tried by one lane each (8 points suffice to know) and the
+// run of rejected ones is skipped at once.
+// A model that meets a non-finite value or an inexact sum is fitted by lane 0 with the plain fitters.
+// Same records as the other kernels: every fit test runs with MDB_FIT_WAVE=1 (always), 0 (never) and the default.
+struct PendingSwing {
+    uint32_t record;
+    uint32_t start;
+    uint32_t length;
+    double lower_slope, upper_slope;
+};
+
+// Data-parallel primitives: values move between the lanes of a wave inside the vector ALU (no trip through LDS).
+template <int CONTROL, typename T> __device__ __forceinline__ T dpp_move(T x) {
+    static_assert(sizeof(T) % 4 == 0, "made of 32-bit words");
+    int words[sizeof(T) / 4];
+    __builtin_memcpy(words, &x, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; k++)
+        words[k] = __builtin_amdgcn_update_dpp(words[k], words[k], CONTROL, 0xf, 0xf, false);
+    __builtin_memcpy(&x, words, sizeof(T));
+    return x;
+}
+
+// Inclusive scan over the 64 lanes; op(earlier, later) need not commute. Within rows of 16 lanes by shifts of
+// 1, 2, 4, 8, then the last lane of a row to the row above, then lane 31 to the upper half.
+template <typename T, typename Op> __device__ __forceinline__ T wave_inclusive_scan(T x, int lane, Op op) {
+    const int row_lane = lane & 15;
+    { const T t = dpp_move<0x111>(x); if (row_lane >= 1) x = op(t, x); }          // row_shr:1
+    { const T t = dpp_move<0x112>(x); if (row_lane >= 2) x = op(t, x); }          // row_shr:2
+    { const T t = dpp_move<0x114>(x); if (row_lane >= 4) x = op(t, x); }          // row_shr:4
+    { const T t = dpp_move<0x118>(x); if (row_lane >= 8) x = op(t, x); }          // row_shr:8
+    { const T t = dpp_move<0x142>(x); if ((lane & 31) >= 16) x = op(t, x); }      // row_bcast:15
+    { const T t = dpp_move<0x143>(x); if (lane >= 32) x = op(t, x); }             // row_bcast:31
+    return x;
+}
+
+// The value of one lane, the same lane for the whole wave, in every lane.
+template <typename T> __device__ __forceinline__ T read_lane(T x, int lane_of_all) {
+    static_assert(sizeof(T) % 4 == 0, "made of 32-bit words");
+    const int from = __builtin_amdgcn_readfirstlane(lane_of_all);
+    int words[sizeof(T) / 4];
+    __builtin_memcpy(words, &x, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; k++) words[k] = __builtin_amdgcn_readlane(words[k], from);
+    __builtin_memcpy(&x, words, sizeof(T));
+    return x;
+}
+
+struct PmcScan {
+    float min_value, max_value;
+    double sum;
+};
+
+struct ExponentRange {
+    int low, high;
+};
+
+// A chunk whose models turn out short is not this kernel's: a step per model (and per run of rejected start points)
+// costs what a whole block of a long model costs. Every `window_points` the wave looks at the steps it has taken
+// since the last look; more than one per `points_per_step` points and it leaves the chunk to split mode
+// (chunk_left[chunk] = 1, counted in *n_left; nothing the wave has written for the chunk is used then).
+struct WaveLeave {
+    unsigned int *chunk_left; // nullptr: never leave
+    unsigned int *n_left;
+    uint32_t window_points;
+    uint32_t points_per_step;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, WaveLeave leave,
+                                                             const unsigned long long *__restrict__ record_base,
+                                                             ModelRec *__restrict__ records,
+                                                             ChunkPlan *__restrict__ plans,
+                                                             unsigned int *__restrict__ error) {
+    __shared__ PendingSwing pending[MDB_WAVE];
+    const int lane = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const uint64_t base = args.chunk_offsets[chunk];
+    const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
+    if (length64 > COUNT_MASK - ENTRY_END_BIAS) {
+        if (lane == 0) {
+            atomicOr(error, ERR_TOO_LONG);
+            plans[chunk] = {0, 0};
+        }
+        return;
+    }
+    const uint32_t n = (uint32_t)length64;
+    if (n == 0) {
+        if (lane == 0) plans[chunk] = {0, 0};
+        return;
+    }
+    const float *__restrict__ values = args.values + base;
+    const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, chunk, base);
+    const double first_time = (double)regular_ts.first, interval = (double)regular_ts.interval; // exact
+    const mdb_error_bound eb = args.eb;
+    const DeviationFactor dev = deviation_factor(eb);
+    ModelRec *__restrict__ out = records + record_base[chunk];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+
+    uint32_t n_models = 0, n_pending = 0;
+    GapCounter gaps;
+    uint32_t current = 0;
+    bool after_rejection = false;
+    uint32_t steps = 0, next_look = leave.window_points, looked_at = 0; // (WaveLeave)
+    if (leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
+
+    // The sums of the queued Swing models, one lane per model, and with them the models' last values.
+    auto flush_pending = [&]() {
+        if (lane < (int)n_pending) {
+            const PendingSwing item = pending[lane];
+            const float *__restrict__ v = values + item.start;
+            const double first_value = (double)v[0];
+            double numerator = 0.0, denominator = 0.0;
+            auto add_point = [&](uint32_t r, float v32) {
+                const double value = (double)v32;
+                if (first_value != value) { // (adding 0.0 otherwise: swing.rs:222-227, no change)
+                    const double dt = (double)r * interval; // = (f64)(t - start_time), exact
+                    numerator += (value - first_value) * dt;
+                    denominator += dt * dt;
+                }
+            };
+            uint32_t r = 2;
+            for (; r + 8 <= item.length; r += 8) { // (eight loads in flight, then the two chains of additions)
+                float group[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) group[k] = v[r + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) add_point(r + k, group[k]);
+            }
+            for (; r < item.length; r++) add_point(r, v[r]);
+            const double projected = numerator / denominator; // swing.rs:246-259
+            const double slope = max_num(item.lower_slope, min_num(projected, item.upper_slope));
+            const double last_value = slope * ((double)(item.length - 1) * interval) + first_value;
+            out[item.record].p1 = (float)last_value;
+        }
+        n_pending = 0;
+    };
+
+    while (current < n) {
+        if (leave.chunk_left && current >= next_look) {
+            if ((uint64_t)steps * leave.points_per_step > (uint64_t)(current - looked_at)) {
+                if (lane == 0) {
+                    leave.chunk_left[chunk] = 1u;
+                    atomicAdd(leave.n_left, 1u);
+                }
+                return;
+            }
+            steps = 0;
+            looked_at = current;
+            next_look = current + leave.window_points;
+        }
+        steps += 1;
+        if (after_rejection) {
+            // The next 64 start points, one lane each: rejected iff neither fitter gets to 8 points.
+            const uint32_t start = current + lane;
+            bool rejected = false;
+            if (KIND == MDB_EB_LOSSLESS && start + 2 < n) {
+                // Under a lossless bound three points that are neither equal nor exactly collinear decide it
+                // (pmc_mean.rs:58-76 and swing.rs:101-198 with a zero deviation; k_fit_models does the same).
+                const float v0 = values[start], v1 = values[start + 1], v2 = values[start + 2];
+                if (isfinite(v0) && isfinite(v1) && isfinite(v2) && v0 != v1) {
+                    const double t0 = __builtin_fma((double)start, interval, first_time);
+                    const LineDev line = line_through_exact(t0, (double)v0, t0 + interval, (double)v1);
+                    const double approximation = line.slope * (t0 + interval + interval) + line.intercept;
+                    rejected = approximation < (double)v2 || approximation > (double)v2;
+                }
+            }
+            if (start < n && !rejected) {
+                PmcDev pmc;
+                SwingFast swing;
+                pmc.reset();
+                swing.reset();
+                bool pmc_fits = true, swing_fits = true;
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t j = start + k;
+                    if (j >= n || !(pmc_fits || swing_fits)) break;
+                    const float v = values[j];
+                    const double t = __builtin_fma((double)j, interval, first_time);
+                    if (pmc_fits) pmc_fits = pmc.fit(eb, v);
+                    if (swing_fits) swing_fits = swing.fit(dev, t, v);
+                }
+                rejected = pmc.length < 8 && swing.length < 8;
+            }
+            const unsigned long long mask = __ballot(rejected);
+            const uint32_t skipped = ~mask ? (uint32_t)__builtin_ctzll(~mask) : (uint32_t)MDB_WAVE;
+            current += skipped;
+            after_rejection = skipped == (uint32_t)MDB_WAVE;
+            continue;
+        }
+
+        // ---- one model from `current` ----
+        uint32_t pmc_length = 0, swing_length = 0;
+        double pmc_sum = 0.0;
+        float pmc_min = __uint_as_float(0x7fc00000u), pmc_max = __uint_as_float(0x7fc00000u);
+        int exponent_low = 255, exponent_high = 0; // of the non-zero values PMC-Mean has been offered
+        bool pmc_alive = true, swing_alive = true, by_one_lane = false;
+        double first_value = nan;
+        const double start_time = __builtin_fma((double)current, interval, first_time);
+        LineDev upper = {nan, nan}, lower = {nan, nan};
+        uint32_t position = current;
+        while ((pmc_alive || swing_alive) && position < n) {
+            const uint32_t index = position + lane;
+            const int n_valid = (int)min((uint32_t)MDB_WAVE, n - position);
+            const bool valid = lane < n_valid;
+            const float v = valid ? values[index] : 0.0f;
+            if (__ballot(valid && !isfinite(v))) {
+                by_one_lane = true;
+                break;
+            }
+            const double value = (double)v;
+            if (position == current) first_value = read_lane(value, 0);
+
+            if (pmc_alive) {
+                const uint32_t bits = __float_as_uint(v);
+                const bool non_zero = valid && (bits << 1) != 0u;
+                const int exponent = max((int)((bits >> 23) & 0xffu), 1);
+                ExponentRange range = {non_zero ? exponent : 255, non_zero ? exponent : 0};
+                range = wave_inclusive_scan(range, lane, [](ExponentRange a, ExponentRange b) {
+                    return ExponentRange{min(a.low, b.low), max(a.high, b.high)};
+                });
+                range = read_lane(range, MDB_WAVE - 1);
+                exponent_low = min(exponent_low, range.low);
+                exponent_high = max(exponent_high, range.high);
+                const uint32_t most = pmc_length + (uint32_t)n_valid;
+                const int length_bits = 32 - __clz((int)most);
+                if (exponent_high >= exponent_low && exponent_high - exponent_low + 24 + length_bits + 1 > 53) {
+                    by_one_lane = true;
+                    break;
+                }
+                const PmcScan scan = wave_inclusive_scan(PmcScan{v, v, value}, lane, [](PmcScan a, PmcScan b) {
+                    return PmcScan{min_num(a.min_value, b.min_value), max_num(a.max_value, b.max_value), a.sum + b.sum};
+                });
+                const float scan_min = scan.min_value, scan_max = scan.max_value;
+                const double scan_sum = scan.sum;
+                const float next_min = min_num(pmc_min, scan_min);
+                const float next_max = max_num(pmc_max, scan_max);
+                const double next_sum = pmc_sum + scan_sum;
+                const uint32_t next_length = pmc_length + (uint32_t)lane + 1u;
+                const float average = (float)(next_sum / (double)next_length);
+                const bool within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
+                const unsigned long long failing = __ballot(valid && !within);
+                const int accepted = failing ? __builtin_ctzll(failing) : n_valid;
+                if (accepted > 0) {
+                    pmc_min = read_lane(next_min, accepted - 1);
+                    pmc_max = read_lane(next_max, accepted - 1);
+                    pmc_sum = read_lane(next_sum, accepted - 1);
+                }
+                pmc_length += (uint32_t)accepted;
+                if (failing) pmc_alive = false;
+            }
+
+            if (swing_alive) {
+                const double t = __builtin_fma((double)index, interval, first_time);
+                const double deviation = lean_deviation<KIND>(dev.factor, value);
+                const LineDev upper_candidate = line_through_exact(start_time, first_value, t, value + deviation);
+                const LineDev lower_candidate = line_through_exact(start_time, first_value, t, value - deviation);
+                int first_lane = 0;
+                if (position == current) { // the model's first two points are accepted as they come (swing.rs:107-143)
+                    swing_length = (uint32_t)min(n_valid, 2);
+                    first_lane = 2;
+                    if (n_valid >= 2) {
+                        upper = read_lane(upper_candidate, 1);
+                        lower = read_lane(lower_candidate, 1);
+                    }
+                }
+                while (swing_alive && first_lane < n_valid) {
+                    // The bounds this lane would meet if every lane in front of it moved them as lines of smaller /
+                    // larger slope do: the extreme of the state's slope and the candidates of [first_lane, lane).
+                    LineDev above = dpp_move<0x138>(upper_candidate); // wave_shr:1
+                    LineDev below = dpp_move<0x138>(lower_candidate);
+                    if (lane <= first_lane) {
+                        above = upper;
+                        below = lower;
+                    }
+                    // (the earlier one stays on ties: a step only replaces a bound by a strictly lower / higher line)
+                    above = wave_inclusive_scan(above, lane, [](LineDev a, LineDev b) { return b.slope < a.slope ? b : a; });
+                    below = wave_inclusive_scan(below, lane, [](LineDev a, LineDev b) { return b.slope > a.slope ? b : a; });
+                    // The step itself (swing.rs:144-197) against that state.
+                    const double upper_approximation = above.slope * t + above.intercept;
+                    const double lower_approximation = below.slope * t + below.intercept;
+                    const bool fails = upper_approximation + deviation < value || lower_approximation - deviation > value;
+                    const bool lowers_upper = upper_approximation - deviation > value;
+                    const bool raises_lower = lower_approximation + deviation < value;
+                    const bool as_assumed = lowers_upper == (upper_candidate.slope < above.slope) &&
+                                            raises_lower == (lower_candidate.slope > below.slope);
+                    const bool mine = lane >= first_lane && lane < n_valid;
+                    const unsigned long long stops = __ballot(mine && (fails || !as_assumed));
+                    const int at = stops ? __builtin_ctzll(stops) : n_valid - 1; // its incoming state is the true one
+                    const bool ends = stops && ((__ballot(fails) >> at) & 1ull) != 0;
+                    // The state behind lane `at` (in front of it when the model ends there).
+                    upper = read_lane((lowers_upper && !ends) ? upper_candidate : above, at);
+                    lower = read_lane((raises_lower && !ends) ? lower_candidate : below, at);
+                    if (ends) {
+                        swing_length += (uint32_t)(at - first_lane);
+                        swing_alive = false;
+                    } else {
+                        swing_length += (uint32_t)(at + 1 - first_lane);
+                        first_lane = at + 1;
+                    }
+                }
+            }
+            position += MDB_WAVE;
+        }
+
+        bool accepted_model = false;
+        ModelRec rec{};
+        if (by_one_lane) {
+            // The plain fitters, lane 0 alone (non-finite values, sums that may round).
+            int accepted_flag = 0;
+            if (lane == 0) {
+                PmcDev pmc;
+                SwingFast swing;
+                pmc.reset();
+                swing.reset();
+                bool pmc_fits = true, swing_fits = true;
+                for (uint32_t j = current; j < n && (pmc_fits || swing_fits); j++) {
+                    const float v = values[j];
+                    const double t = __builtin_fma((double)j, interval, first_time);
+                    if (pmc_fits) pmc_fits = pmc.fit(eb, v);
+                    if (swing_fits) swing_fits = swing.fit(dev, t, v);
+                }
+                const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc.length;
+                const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing.length;
+                const bool choose_pmc = pmc_bpv <= swing_bpv;
+                if ((choose_pmc ? pmc_bpv : swing_bpv) <= (float)MDB_VALUE_SIZE_IN_BYTES) {
+                    accepted_flag = 1;
+                    if (choose_pmc) {
+                        rec.start_and_type = current;
+                        rec.end = current + pmc.length - 1;
+                        rec.p0 = (float)(pmc.sum / (double)pmc.length);
+                        rec.p1 = rec.p0;
+                    } else {
+                        rec.start_and_type = current | 0x80000000u;
+                        rec.end = current + swing.length - 1;
+                        swing.model(interval, &rec.p0, &rec.p1);
+                    }
+                }
+            }
+            accepted_model = __shfl(accepted_flag, 0) != 0;
+            rec.start_and_type = __shfl(rec.start_and_type, 0);
+            rec.end = __shfl(rec.end, 0);
+            if (accepted_model && lane == 0) out[n_models] = rec;
+        } else {
+            // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
+            const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc_length;
+            const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing_length;
+            const bool choose_pmc = pmc_bpv <= swing_bpv;
+            accepted_model = (choose_pmc ? pmc_bpv : swing_bpv) <= (float)MDB_VALUE_SIZE_IN_BYTES; // compression.rs:238
+            if (accepted_model) {
+                if (choose_pmc) {
+                    rec.start_and_type = current;
+                    rec.end = current + pmc_length - 1;
+                    rec.p0 = (float)(pmc_sum / (double)pmc_length); // pmc_mean.rs:91-93
+                    rec.p1 = rec.p0;
+                } else {
+                    rec.start_and_type = current | 0x80000000u;
+                    rec.end = current + swing_length - 1;
+                    rec.p0 = (float)first_value;
+                    if (lane == 0) pending[n_pending] = {n_models, current, swing_length, lower.slope, upper.slope};
+                    n_pending += 1;
+                }
+                if (lane == 0) {
+                    // (p1 of a queued Swing model is flush_pending's to write: some lane's, some time later)
+                    out[n_models].start_and_type = rec.start_and_type;
+                    out[n_models].end = rec.end;
+                    out[n_models].p0 = rec.p0;
+                    if (choose_pmc) out[n_models].p1 = rec.p1;
+                }
+            }
+        }
+        if (accepted_model) {
+            gaps.on_model(current, rec.end);
+            n_models += 1;
+            current = rec.end + 1;
+            if (n_pending == (uint32_t)MDB_WAVE) {
+                __syncthreads();
+                flush_pending();
+                __syncthreads();
+            }
+        } else {
+            current += 1; // the point becomes a residual (compression.rs:258-262)
+            after_rejection = true;
+        }
+    }
+    __syncthreads();
+    flush_pending();
+    if (lane == 0) plans[chunk] = {n_models, gaps.finish(n)};
+}
+
 // ---- k_fit_walk (split mode) ---------------------------------------------------------------------------------
 //
 // One wave per chunk follows the table from point 0. The wave keeps the entries of 64 consecutive
@@ -1520,6 +1942,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
                                                        unsigned int *__restrict__ error) {
     const uint64_t chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
+    if (split.chunk_left && split.chunk_left[chunk] == 0u) return;
     const int lane = threadIdx.x;
     const uint64_t base = chunk_offsets[chunk];
     const uint64_t length64 = chunk_offsets[chunk + 1] - base;
@@ -2282,6 +2705,22 @@ static bool fit_lean_setting() {
 // Points per piece for split mode, 0 = one lane per chunk. Split when the call has too few chunks
 // to give every SIMD a couple of waves and the chunks are long enough to be worth cutting.
 // MDB_FIT_PIECE_POINTS overrides: 1 = never split, N >= 64 = always split into pieces of N points.
+// MDB_FIT_WAVE: 0 = never k_fit_models_wave; 1 = wherever it applies, every chunk to its end; 2 = wherever split
+// mode is possible (also with a forced piece size), chunks with short models left to split mode; otherwise 2's
+// behaviour for the calls the library would have given to split mode by itself.
+static int fit_wave_setting() {
+    const char *setting = std::getenv("MDB_FIT_WAVE");
+    if (!setting || !*setting) return -1;
+    const int value = std::atoi(setting);
+    return value == 1 || value == 2 ? value : 0;
+}
+
+static uint32_t fit_wave_number(const char *name, uint32_t otherwise) {
+    const char *setting = std::getenv(name);
+    if (!setting || !*setting) return otherwise;
+    return (uint32_t)std::min<long long>(std::max<long long>(std::atoll(setting), 1), 1ll << 30);
+}
+
 static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64_t total_points) {
     if (const char *forced = std::getenv("MDB_FIT_PIECE_POINTS")) {
         const long long value = std::atoll(forced);
@@ -2418,7 +2857,47 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_D, (n_chunks + 1) * 8, &p));
         unsigned long long *segment_base = static_cast<unsigned long long *>(p);
         const uint32_t chunk_blocks = (uint32_t)((n_chunks + 255) / 256);
-        if (piece_points == 0) {
+        // Few chunks: one wave per chunk, which leaves the chunks whose models turn out short to split mode
+        // (forced piece sizes are the tests' way to ask for split mode alone; MDB_FIT_WAVE=1: every chunk, to the end).
+        const int wave_setting = fit_wave_setting();
+        const bool wave = fast && !ts && fit_lean_setting() && wave_setting != 0 &&
+                          (wave_setting == 1 ||
+                           (piece_points != 0 && (wave_setting == 2 || !std::getenv("MDB_FIT_PIECE_POINTS"))));
+        bool split_mode = !wave && piece_points != 0;
+        const unsigned int *split_only = nullptr; // (per chunk: 1 = left to split mode by k_fit_models_wave)
+        if (wave) {
+            WaveLeave leave{};
+            if (wave_setting != 1 && piece_points != 0) {
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_WAVE, (n_chunks + 1) * 4, &p));
+                leave.chunk_left = static_cast<unsigned int *>(p);
+                leave.n_left = leave.chunk_left + n_chunks;
+                leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 2048);
+                leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", 96);
+                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 4, ctx->stream));
+            }
+            {
+                LaunchTimer timer(ctx, "k_fit_models_wave");
+                if (eb.kind == MDB_EB_RELATIVE)
+                    hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_RELATIVE>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
+                                       ctx->stream, args, leave, record_base, records, plans, error_flag);
+                else if (eb.kind == MDB_EB_ABSOLUTE)
+                    hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_ABSOLUTE>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
+                                       ctx->stream, args, leave, record_base, records, plans, error_flag);
+                else
+                    hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_LOSSLESS>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
+                                       ctx->stream, args, leave, record_base, records, plans, error_flag);
+            }
+            if (leave.chunk_left) {
+                unsigned int n_left = 0;
+                FIT_CHECK(hipMemcpyAsync(&n_left, leave.n_left, 4, hipMemcpyDeviceToHost, ctx->stream));
+                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                if (n_left > 0) {
+                    split_mode = true;
+                    split_only = leave.chunk_left;
+                }
+            }
+        }
+        if (!wave && piece_points == 0) {
             LaunchTimer timer(ctx, "k_fit_models");
             const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
             if (lean_ts && eb.kind == MDB_EB_RELATIVE)
@@ -2442,10 +2921,12 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             else
                 hipLaunchKernelGGL((k_fit_models<false, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
-        } else {
+        }
+        if (split_mode) {
             // Split mode: pieces of every chunk fitted speculatively, then the real chain is walked.
             SplitArgs split{};
             split.piece_points = piece_points;
+            split.chunk_left = split_only;
             const uint64_t table_points = points_end;
             FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_SPLIT, (n_chunks + 1) * 8 + 64 + table_points * 12, &p));
             unsigned long long *piece_base = static_cast<unsigned long long *>(p);
@@ -2455,7 +2936,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             split.p0 = reinterpret_cast<float *>(split.entry + table_points);
             split.p1 = split.p0 + table_points;
             FIT_CHECK(hipMemsetAsync(split.entry, 0, table_points * 4, ctx->stream));
-            FIT_TRY(device_exclusive_scan(ctx, PieceCount{args.chunk_offsets, piece_points}, n_chunks, piece_base,
+            FIT_TRY(device_exclusive_scan(ctx, PieceCount{args.chunk_offsets, piece_points, split_only}, n_chunks, piece_base,
                                           block_sums, "k_fit_scan"));
             unsigned long long n_pieces = 0;
             FIT_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n_chunks, 8, hipMemcpyDeviceToHost, ctx->stream));

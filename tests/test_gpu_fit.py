@@ -17,18 +17,31 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=[("auto", None, None), ("1", "off", None), ("64", "8", None),
-                                      ("1000", None, "lean-off"), ("1", None, "plain")],
+                                      ("1000", None, "lean-off"), ("1", None, "plain"), ("auto", None, "wave"),
+                                      ("64", None, "wave-or-pieces")],
                 ids=["split-auto", "lane-per-chunk+lane-per-gap", "pieces-of-64+gaps-from-8",
-                     "pieces-of-1000+k_fit_models-fast", "lane-per-chunk+k_fit_models-plain"])
+                     "pieces-of-1000+k_fit_models-fast", "lane-per-chunk+k_fit_models-plain", "wave-per-chunk",
+                     "wave-leaving-short-models-to-pieces-of-64"])
 def fit_mode(request, monkeypatch):
     """Every fit test runs with the library choosing between one lane per chunk and split mode
     (speculative pieces + chain walk, mdb_fit.hip), with split mode off, and with it forced; with
     long lossless MacaqueV-only segments encoded by one wave each (k_fit_gap) from the default length,
-    never, and from 8 values; and with each of the three forms of the greedy loop (k_fit_models_lean
-    where it applies, k_fit_models with the fast forms of the fitters, k_fit_models plain)."""
+    never, and from 8 values; and with each of the forms of the greedy loop (k_fit_models_lean where it
+    applies, k_fit_models with the fast forms of the fitters, k_fit_models plain, and k_fit_models_wave:
+    one wave per chunk, 64 consecutive points per step - to the end of every chunk, and leaving chunks
+    with short models to split mode)."""
     pieces, gaps, loop = request.param
-    for name in ("MDB_FIT_LEAN", "MDB_FIT_FAST"):
+    for name in ("MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_WAVE", "MDB_FIT_WAVE_WINDOW_POINTS",
+                 "MDB_FIT_WAVE_POINTS_PER_STEP"):
         monkeypatch.delenv(name, raising=False)
+    if loop == "wave":
+        monkeypatch.setenv("MDB_FIT_WAVE", "1")  # one wave per chunk (k_fit_models_wave) wherever it applies
+    if loop == "wave-or-pieces":
+        # ... which looks at its progress every 64 points and leaves a chunk with fewer than 40 points per step
+        # to split mode: calls with several chunks end up with some chunks from either.
+        monkeypatch.setenv("MDB_FIT_WAVE", "2")
+        monkeypatch.setenv("MDB_FIT_WAVE_WINDOW_POINTS", "64")
+        monkeypatch.setenv("MDB_FIT_WAVE_POINTS_PER_STEP", "40")
     if loop in ("lean-off", "plain"):
         monkeypatch.setenv("MDB_FIT_LEAN", "0")
     if loop == "plain":
