@@ -1540,8 +1540,9 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
 //     only needed once a Swing model has been chosen. They are queued and computed by one lane per model, 64
 //     models at a time.
 // Rejected start points (neither model reaches the 8 points it needs, compression.rs:238, 258-262) would cost a
-// step each; after one, the next 64 start points are tried by one lane each (8 points suffice to know) and the
-// run of rejected ones is skipped at once.
+// step each; after two in a row the start points that follow are tried by one lane each - on three points first,
+// which is where noise is rejected, the survivors of up to 1 024 start points then on the eight that decide - and
+// the run of rejected ones is skipped at once.
 // A model that meets a non-finite value or an inexact sum is fitted by lane 0 with the plain fitters.
 // Same records as the other kernels: every fit test runs with MDB_FIT_WAVE=1 (always), 0 (never) and the default.
 struct PendingSwing {
@@ -1597,16 +1598,27 @@ struct ExponentRange {
     int low, high;
 };
 
-// A chunk whose models turn out short is not this kernel's: a step per model (and per run of rejected start points)
-// costs what a whole block of a long model costs. Every `window_points` the wave looks at the steps it has taken
-// since the last look; more than one per `points_per_step` points and it leaves the chunk to split mode
+// A chunk whose models turn out short is not this kernel's: a model costs at least one block of 64 points however
+// short it is, a pass over rejected start points half a block per 64 start points it looks at and four for its
+// second stage. Split mode takes about 100 cycles per point on such data, a block 2 300. Every `window_points` the
+// wave looks at the steps it has taken since the last look: if the rest of the chunk at more than one step per
+// `points_per_step` points would cost more than the whole chunk in split mode, it leaves the chunk to split mode
 // (chunk_left[chunk] = 1, counted in *n_left; nothing the wave has written for the chunk is used then).
 struct WaveLeave {
     unsigned int *chunk_left; // nullptr: never leave
     unsigned int *n_left;
     uint32_t window_points;
     uint32_t points_per_step;
+    // MDB_FIT_DEBUG: models, rejected start points, passes over 64 start points, blocks of 64 points, scans of a
+    // Swing block, models fitted by one lane, chunks left (nullptr: not counted).
+    unsigned long long *counts;
 };
+
+enum WaveCount { WAVE_MODELS, WAVE_REJECTED, WAVE_START_PASSES, WAVE_BLOCKS, WAVE_SWING_SCANS, WAVE_BY_ONE_LANE,
+                 WAVE_COUNTS };
+
+constexpr uint32_t WAVE_PASS_POINTS = 1024; // start points a pass over rejected start points looks at, at most
+constexpr uint32_t WAVE_PASS_STEPS = 4;     // what its second stage costs, in blocks of a model
 
 template <int KIND>
 __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, WaveLeave leave,
@@ -1615,6 +1627,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                                                              ChunkPlan *__restrict__ plans,
                                                              unsigned int *__restrict__ error) {
     __shared__ PendingSwing pending[MDB_WAVE];
+    __shared__ uint32_t survivors[2 * MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const uint64_t base = args.chunk_offsets[chunk];
@@ -1636,6 +1649,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     const double first_time = (double)regular_ts.first, interval = (double)regular_ts.interval; // exact
     const mdb_error_bound eb = args.eb;
     const DeviationFactor dev = deviation_factor(eb);
+    const PmcFast pmc_fast = pmc_fast_constants(eb);
     ModelRec *__restrict__ out = records + record_base[chunk];
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
 
@@ -1643,7 +1657,13 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     GapCounter gaps;
     uint32_t current = 0;
     bool after_rejection = false;
-    uint32_t steps = 0, next_look = leave.window_points, looked_at = 0; // (WaveLeave)
+    uint32_t half_steps = 0, next_look = leave.window_points, looked_at = 0; // (WaveLeave)
+    uint32_t counted[WAVE_COUNTS] = {};
+    uint32_t rejections_in_a_row = 0;
+    auto report_counts = [&]() {
+        if (leave.counts && lane == 0)
+            for (int k = 0; k < WAVE_COUNTS; k++) atomicAdd(leave.counts + k, (unsigned long long)counted[k]);
+    };
     if (leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
 
     // The sums of the queued Swing models, one lane per model, and with them the models' last values.
@@ -1680,34 +1700,68 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 
     while (current < n) {
         if (leave.chunk_left && current >= next_look) {
-            if ((uint64_t)steps * leave.points_per_step > (uint64_t)(current - looked_at)) {
+            // (what is left of the chunk at the pace of this window against the whole chunk in split mode)
+            if ((uint64_t)half_steps * leave.points_per_step * (n - current) > 2ull * (current - looked_at) * n) {
                 if (lane == 0) {
                     leave.chunk_left[chunk] = 1u;
                     atomicAdd(leave.n_left, 1u);
                 }
+                report_counts();
                 return;
             }
-            steps = 0;
+            half_steps = 0;
             looked_at = current;
             next_look = current + leave.window_points;
         }
-        steps += 1;
         if (after_rejection) {
-            // The next 64 start points, one lane each: rejected iff neither fitter gets to 8 points.
-            const uint32_t start = current + lane;
-            bool rejected = false;
-            if (KIND == MDB_EB_LOSSLESS && start + 2 < n) {
-                // Under a lossless bound three points that are neither equal nor exactly collinear decide it
-                // (pmc_mean.rs:58-76 and swing.rs:101-198 with a zero deviation; k_fit_models does the same).
-                const float v0 = values[start], v1 = values[start + 1], v2 = values[start + 2];
-                if (isfinite(v0) && isfinite(v1) && isfinite(v2) && v0 != v1) {
-                    const double t0 = __builtin_fma((double)start, interval, first_time);
-                    const LineDev line = line_through_exact(t0, (double)v0, t0 + interval, (double)v1);
-                    const double approximation = line.slope * (t0 + interval + interval) + line.intercept;
-                    rejected = approximation < (double)v2 || approximation > (double)v2;
+            counted[WAVE_START_PASSES] += 1;
+            // Start points after a rejected one, one lane each. Most rejected start points are rejected early:
+            // PMC-Mean by the second or third point, Swing by the third (the first two only draw its bounds). So
+            // the next start points are first tried on three points, 64 at a time, and those that survive - up to
+            // 64 of them, from up to 1 024 start points - are collected ...
+            uint32_t n_survivors = 0, scanned = 0;
+            while (n_survivors < (uint32_t)MDB_WAVE && scanned < WAVE_PASS_POINTS && current + scanned < n) {
+                const uint32_t start = current + scanned + lane;
+                bool early = false;
+                if (start + 2 < n) {
+                    const float v0 = values[start], v1 = values[start + 1], v2 = values[start + 2];
+                    if (isfinite(v0) && isfinite(v1) && isfinite(v2)) {
+                        PmcDev pmc;
+                        pmc.reset();
+                        const bool pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v0) && pmc_fit_fast(pmc, pmc_fast, eb, v1) &&
+                                              pmc_fit_fast(pmc, pmc_fast, eb, v2);
+                        // swing.rs:126-143 for the second point, :144-160 for the third
+                        const double t0 = __builtin_fma((double)start, interval, first_time);
+                        const double t1 = t0 + interval, t2 = t1 + interval; // (exact, as every timestamp here)
+                        const double deviation1 = dev.of((double)v1), deviation2 = dev.of((double)v2);
+                        const LineDev above = line_through_exact(t0, (double)v0, t1, (double)v1 + deviation1);
+                        const LineDev below = line_through_exact(t0, (double)v0, t1, (double)v1 - deviation1);
+                        const double upper_approximation = above.slope * t2 + above.intercept;
+                        const double lower_approximation = below.slope * t2 + below.intercept;
+                        const bool swing_fits = !(upper_approximation + deviation2 < (double)v2 ||
+                                                  lower_approximation - deviation2 > (double)v2);
+                        early = !pmc_fits && !swing_fits;
+                    }
                 }
+                const bool survives = start < n && !early;
+                const unsigned long long survivors_here = __ballot(survives);
+                if (survives)
+                    survivors[n_survivors + (uint32_t)__popcll(survivors_here & ((1ull << lane) - 1ull))] = scanned + lane;
+                n_survivors += (uint32_t)__popcll(survivors_here);
+                scanned += MDB_WAVE;
+                half_steps += 1; // (a look at 64 start points costs about half of what a block of a model costs)
             }
-            if (start < n && !rejected) {
+            if (n_survivors > 0) half_steps += 2 * WAVE_PASS_STEPS;
+            __syncthreads();
+            // ... and taken through the 8 points that decide it (neither fitter gets to 8: rejected), one lane each.
+            // What lies behind the 64th survivor is the next pass's.
+            uint32_t covered = min(scanned, n - current);
+            if (n_survivors > (uint32_t)MDB_WAVE) covered = survivors[MDB_WAVE];
+            bool stands = false;
+            uint32_t offset = 0;
+            if ((uint32_t)lane < n_survivors) { // (nobody: the branch is not taken)
+                offset = survivors[lane];
+                const uint32_t start = current + offset;
                 PmcDev pmc;
                 SwingFast swing;
                 pmc.reset();
@@ -1718,15 +1772,22 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     if (j >= n || !(pmc_fits || swing_fits)) break;
                     const float v = values[j];
                     const double t = __builtin_fma((double)j, interval, first_time);
-                    if (pmc_fits) pmc_fits = pmc.fit(eb, v);
+                    if (pmc_fits) pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v);
                     if (swing_fits) swing_fits = swing.fit(dev, t, v);
                 }
-                rejected = pmc.length < 8 && swing.length < 8;
+                stands = pmc.length >= 8 || swing.length >= 8;
             }
-            const unsigned long long mask = __ballot(rejected);
-            const uint32_t skipped = ~mask ? (uint32_t)__builtin_ctzll(~mask) : (uint32_t)MDB_WAVE;
-            current += skipped;
-            after_rejection = skipped == (uint32_t)MDB_WAVE;
+            const unsigned long long standing = __ballot(stands);
+            __syncthreads();
+            if (standing) { // the first start point a model stands on: everything in front of it is rejected
+                const uint32_t skipped = read_lane(offset, __builtin_ctzll(standing));
+                current += skipped;
+                counted[WAVE_REJECTED] += skipped;
+                after_rejection = false;
+            } else {
+                current += covered;
+                counted[WAVE_REJECTED] += covered;
+            }
             continue;
         }
 
@@ -1741,6 +1802,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         LineDev upper = {nan, nan}, lower = {nan, nan};
         uint32_t position = current;
         while ((pmc_alive || swing_alive) && position < n) {
+            counted[WAVE_BLOCKS] += 1;
+            half_steps += 2;
             const uint32_t index = position + lane;
             const int n_valid = (int)min((uint32_t)MDB_WAVE, n - position);
             const bool valid = lane < n_valid;
@@ -1753,6 +1816,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             if (position == current) first_value = read_lane(value, 0);
 
             if (pmc_alive) {
+                // Up to which lane is every partial sum exact (file comment)? The exponents met so far, per lane.
                 const uint32_t bits = __float_as_uint(v);
                 const bool non_zero = valid && (bits << 1) != 0u;
                 const int exponent = max((int)((bits >> 23) & 0xffu), 1);
@@ -1760,32 +1824,42 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                 range = wave_inclusive_scan(range, lane, [](ExponentRange a, ExponentRange b) {
                     return ExponentRange{min(a.low, b.low), max(a.high, b.high)};
                 });
-                range = read_lane(range, MDB_WAVE - 1);
-                exponent_low = min(exponent_low, range.low);
-                exponent_high = max(exponent_high, range.high);
-                const uint32_t most = pmc_length + (uint32_t)n_valid;
-                const int length_bits = 32 - __clz((int)most);
-                if (exponent_high >= exponent_low && exponent_high - exponent_low + 24 + length_bits + 1 > 53) {
-                    by_one_lane = true;
-                    break;
-                }
+                range.low = min(range.low, exponent_low);
+                range.high = max(range.high, exponent_high);
+                const uint32_t next_length = pmc_length + (uint32_t)lane + 1u;
+                const int length_bits = 32 - __clz((int)next_length);
+                const bool exact_to_here = range.high < range.low || range.high - range.low + 24 + length_bits + 1 <= 53;
                 const PmcScan scan = wave_inclusive_scan(PmcScan{v, v, value}, lane, [](PmcScan a, PmcScan b) {
                     return PmcScan{min_num(a.min_value, b.min_value), max_num(a.max_value, b.max_value), a.sum + b.sum};
                 });
-                const float scan_min = scan.min_value, scan_max = scan.max_value;
-                const double scan_sum = scan.sum;
-                const float next_min = min_num(pmc_min, scan_min);
-                const float next_max = max_num(pmc_max, scan_max);
-                const double next_sum = pmc_sum + scan_sum;
-                const uint32_t next_length = pmc_length + (uint32_t)lane + 1u;
+                const float next_min = min_num(pmc_min, scan.min_value);
+                const float next_max = max_num(pmc_max, scan.max_value);
+                // The reference's sum at this lane is (sum of everything in front) + value: the former in any order
+                // while it is exact, the latter one addition, rounded as the reference rounds it.
+                double in_front = dpp_move<0x138>(scan.sum); // wave_shr:1
+                bool exact_in_front = dpp_move<0x138>((int)exact_to_here) != 0;
+                if (lane == 0) {
+                    in_front = 0.0;
+                    exact_in_front = true; // (the model's state is, or the model would be lane 0's already)
+                }
+                const double next_sum = (pmc_sum + in_front) + value;
                 const float average = (float)(next_sum / (double)next_length);
                 const bool within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
-                const unsigned long long failing = __ballot(valid && !within);
-                const int accepted = failing ? __builtin_ctzll(failing) : n_valid;
+                const unsigned long long known = __ballot(valid && exact_in_front); // lanes 0..e, e the first inexact one
+                const unsigned long long failing = __ballot(valid && !within) & known;
+                const int reach = ~known ? __builtin_ctzll(~known) : MDB_WAVE;     // (lane 0 is always known)
+                const int accepted = failing ? __builtin_ctzll(failing) : reach;
+                if (!failing && reach < n_valid) { // a sum has rounded and the model goes on: one lane, in order
+                    by_one_lane = true;
+                    break;
+                }
                 if (accepted > 0) {
                     pmc_min = read_lane(next_min, accepted - 1);
                     pmc_max = read_lane(next_max, accepted - 1);
                     pmc_sum = read_lane(next_sum, accepted - 1);
+                    const ExponentRange met = read_lane(range, accepted - 1);
+                    exponent_low = met.low;
+                    exponent_high = met.high;
                 }
                 pmc_length += (uint32_t)accepted;
                 if (failing) pmc_alive = false;
@@ -1806,6 +1880,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     }
                 }
                 while (swing_alive && first_lane < n_valid) {
+                    counted[WAVE_SWING_SCANS] += 1;
                     // The bounds this lane would meet if every lane in front of it moved them as lines of smaller /
                     // larger slope do: the extreme of the state's slope and the candidates of [first_lane, lane).
                     LineDev above = dpp_move<0x138>(upper_candidate); // wave_shr:1
@@ -1847,6 +1922,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         bool accepted_model = false;
         ModelRec rec{};
         if (by_one_lane) {
+            counted[WAVE_BY_ONE_LANE] += 1;
             // The plain fitters, lane 0 alone (non-finite values, sums that may round).
             int accepted_flag = 0;
             if (lane == 0) {
@@ -1911,6 +1987,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             }
         }
         if (accepted_model) {
+            rejections_in_a_row = 0;
             gaps.on_model(current, rec.end);
             n_models += 1;
             current = rec.end + 1;
@@ -1921,12 +1998,18 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             }
         } else {
             current += 1; // the point becomes a residual (compression.rs:258-262)
-            after_rejection = true;
+            counted[WAVE_REJECTED] += 1;
+            // (a lone rejected point between two models is cheaper found by the next model's step than by a pass
+            // over 64 start points)
+            rejections_in_a_row += 1;
+            after_rejection = rejections_in_a_row >= 2;
         }
     }
     __syncthreads();
     flush_pending();
     if (lane == 0) plans[chunk] = {n_models, gaps.finish(n)};
+    counted[WAVE_MODELS] = n_models;
+    report_counts();
 }
 
 // ---- k_fit_walk (split mode) ---------------------------------------------------------------------------------
@@ -2715,6 +2798,10 @@ static int fit_wave_setting() {
     return value == 1 || value == 2 ? value : 0;
 }
 
+// One wave per chunk takes about 2 200 cycles per 64 points with every SIMD busy, one lane per chunk about 800 per
+// point with one wave per 64 chunks: beyond some 24 000 chunks the latter has enough waves to be the faster one.
+constexpr uint64_t FIT_WAVE_MAX_CHUNKS = 24576;
+
 static uint32_t fit_wave_number(const char *name, uint32_t otherwise) {
     const char *setting = std::getenv(name);
     if (!setting || !*setting) return otherwise;
@@ -2849,7 +2936,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         // straight-line fitter with a ring of timestamps.
         const bool lean_ts = ts && chunk_irregular && regular_verdict[1] == 0 && fit_fast_setting() &&
                              fit_lean_setting() && eb.kind != MDB_EB_LOSSLESS;
-        const uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
+        uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
         ModelRec *records = static_cast<ModelRec *>(p);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_C, n_chunks * sizeof(ChunkPlan), &p));
@@ -2862,7 +2949,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         const int wave_setting = fit_wave_setting();
         const bool wave = fast && !ts && fit_lean_setting() && wave_setting != 0 &&
                           (wave_setting == 1 ||
-                           (piece_points != 0 && (wave_setting == 2 || !std::getenv("MDB_FIT_PIECE_POINTS"))));
+                           (piece_points != 0 &&
+                            (wave_setting == 2 || (n_chunks <= FIT_WAVE_MAX_CHUNKS && !std::getenv("MDB_FIT_PIECE_POINTS")))));
         bool split_mode = !wave && piece_points != 0;
         const unsigned int *split_only = nullptr; // (per chunk: 1 = left to split mode by k_fit_models_wave)
         if (wave) {
@@ -2871,9 +2959,16 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_WAVE, (n_chunks + 1) * 4, &p));
                 leave.chunk_left = static_cast<unsigned int *>(p);
                 leave.n_left = leave.chunk_left + n_chunks;
-                leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 2048);
-                leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", 96);
+                leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 1024);
+                // (2 300 cycles per step against split mode's 107 per point under a relative or absolute bound -
+                // k_fit_models_lean - and 166 under a lossless one, measured on the bench's mixed series)
+                leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 12 : 20);
                 FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 4, ctx->stream));
+            }
+            static const bool count_steps = std::getenv("MDB_FIT_DEBUG") != nullptr;
+            if (count_steps) {
+                FIT_CHECK(hipMalloc(reinterpret_cast<void **>(&leave.counts), WAVE_COUNTS * 8));
+                FIT_CHECK(hipMemsetAsync(leave.counts, 0, WAVE_COUNTS * 8, ctx->stream));
             }
             {
                 LaunchTimer timer(ctx, "k_fit_models_wave");
@@ -2887,6 +2982,16 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                     hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_LOSSLESS>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
                                        ctx->stream, args, leave, record_base, records, plans, error_flag);
             }
+            if (leave.counts) {
+                unsigned long long counts[WAVE_COUNTS] = {};
+                FIT_CHECK(hipMemcpyAsync(counts, leave.counts, sizeof(counts), hipMemcpyDeviceToHost, ctx->stream));
+                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                FIT_CHECK(hipFree(leave.counts));
+                std::fprintf(stderr, "[fit] k_fit_models_wave: %llu chunks, %llu points: %llu models, %llu rejected start points, "
+                             "%llu passes over 64 start points, %llu blocks, %llu Swing scans, %llu models by one lane\n",
+                             (unsigned long long)n_chunks, (unsigned long long)points_end, counts[WAVE_MODELS], counts[WAVE_REJECTED],
+                             counts[WAVE_START_PASSES], counts[WAVE_BLOCKS], counts[WAVE_SWING_SCANS], counts[WAVE_BY_ONE_LANE]);
+            }
             if (leave.chunk_left) {
                 unsigned int n_left = 0;
                 FIT_CHECK(hipMemcpyAsync(&n_left, leave.n_left, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2894,6 +2999,11 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 if (n_left > 0) {
                     split_mode = true;
                     split_only = leave.chunk_left;
+                    // (pieces sized for the chunks that are left, taken to be as long as the others)
+                    if (!std::getenv("MDB_FIT_PIECE_POINTS")) {
+                        const uint32_t for_these = split_piece_points(ctx, n_left, points_end / n_chunks * n_left);
+                        if (for_these != 0) piece_points = for_these;
+                    }
                 }
             }
         }
