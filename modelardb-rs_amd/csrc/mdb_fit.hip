@@ -1620,7 +1620,8 @@ enum WaveCount { WAVE_MODELS, WAVE_REJECTED, WAVE_START_PASSES, WAVE_BLOCKS, WAV
 constexpr uint32_t WAVE_PASS_POINTS = 1024; // start points a pass over rejected start points looks at, at most
 constexpr uint32_t WAVE_PASS_STEPS = 4;     // what its second stage costs, in blocks of a model
 
-template <int KIND>
+// HAS_TS: the timestamps are loaded (some chunk is irregular; all of them within +-2^52, so exact as f64).
+template <int KIND, bool HAS_TS = false>
 __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, WaveLeave leave,
                                                              const unsigned long long *__restrict__ record_base,
                                                              ModelRec *__restrict__ records,
@@ -1647,6 +1648,11 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     const float *__restrict__ values = args.values + base;
     const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, chunk, base);
     const double first_time = (double)regular_ts.first, interval = (double)regular_ts.interval; // exact
+    const int64_t *__restrict__ chunk_ts = HAS_TS ? args.timestamps.ts + base : nullptr;
+    // (f64)timestamp of point j: computed (the product and the sum are integers below 2^53) or loaded, exact
+    auto time_at = [&](uint32_t j) -> double {
+        return HAS_TS ? (double)chunk_ts[j] : __builtin_fma((double)j, interval, first_time);
+    };
     const mdb_error_bound eb = args.eb;
     const DeviationFactor dev = deviation_factor(eb);
     const PmcFast pmc_fast = pmc_fast_constants(eb);
@@ -1672,11 +1678,13 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             const PendingSwing item = pending[lane];
             const float *__restrict__ v = values + item.start;
             const double first_value = (double)v[0];
+            const double start_time = time_at(item.start);
             double numerator = 0.0, denominator = 0.0;
             auto add_point = [&](uint32_t r, float v32) {
                 const double value = (double)v32;
                 if (first_value != value) { // (adding 0.0 otherwise: swing.rs:222-227, no change)
-                    const double dt = (double)r * interval; // = (f64)(t - start_time), exact
+                    // (f64)(t - start_time), exact
+                    const double dt = HAS_TS ? time_at(item.start + r) - start_time : (double)r * interval;
                     numerator += (value - first_value) * dt;
                     denominator += dt * dt;
                 }
@@ -1692,7 +1700,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             for (; r < item.length; r++) add_point(r, v[r]);
             const double projected = numerator / denominator; // swing.rs:246-259
             const double slope = max_num(item.lower_slope, min_num(projected, item.upper_slope));
-            const double last_value = slope * ((double)(item.length - 1) * interval) + first_value;
+            const double span = HAS_TS ? time_at(item.start + item.length - 1) - start_time
+                                       : (double)(item.length - 1) * interval;
+            const double last_value = slope * span + first_value;
             out[item.record].p1 = (float)last_value;
         }
         n_pending = 0;
@@ -1731,8 +1741,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                         const bool pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v0) && pmc_fit_fast(pmc, pmc_fast, eb, v1) &&
                                               pmc_fit_fast(pmc, pmc_fast, eb, v2);
                         // swing.rs:126-143 for the second point, :144-160 for the third
-                        const double t0 = __builtin_fma((double)start, interval, first_time);
-                        const double t1 = t0 + interval, t2 = t1 + interval; // (exact, as every timestamp here)
+                        const double t0 = time_at(start);
+                        const double t1 = HAS_TS ? time_at(start + 1) : t0 + interval; // (exact, as every timestamp here)
+                        const double t2 = HAS_TS ? time_at(start + 2) : t1 + interval;
                         const double deviation1 = dev.of((double)v1), deviation2 = dev.of((double)v2);
                         const LineDev above = line_through_exact(t0, (double)v0, t1, (double)v1 + deviation1);
                         const LineDev below = line_through_exact(t0, (double)v0, t1, (double)v1 - deviation1);
@@ -1771,7 +1782,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     const uint32_t j = start + k;
                     if (j >= n || !(pmc_fits || swing_fits)) break;
                     const float v = values[j];
-                    const double t = __builtin_fma((double)j, interval, first_time);
+                    const double t = time_at(j);
                     if (pmc_fits) pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v);
                     if (swing_fits) swing_fits = swing.fit(dev, t, v);
                 }
@@ -1798,7 +1809,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         int exponent_low = 255, exponent_high = 0; // of the non-zero values PMC-Mean has been offered
         bool pmc_alive = true, swing_alive = true, by_one_lane = false;
         double first_value = nan;
-        const double start_time = __builtin_fma((double)current, interval, first_time);
+        const double start_time = time_at(current);
         LineDev upper = {nan, nan}, lower = {nan, nan};
         uint32_t position = current;
         while ((pmc_alive || swing_alive) && position < n) {
@@ -1866,7 +1877,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             }
 
             if (swing_alive) {
-                const double t = __builtin_fma((double)index, interval, first_time);
+                const double t = valid ? time_at(index) : 0.0;
                 const double deviation = lean_deviation<KIND>(dev.factor, value);
                 const LineDev upper_candidate = line_through_exact(start_time, first_value, t, value + deviation);
                 const LineDev lower_candidate = line_through_exact(start_time, first_value, t, value - deviation);
@@ -1933,7 +1944,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                 bool pmc_fits = true, swing_fits = true;
                 for (uint32_t j = current; j < n && (pmc_fits || swing_fits); j++) {
                     const float v = values[j];
-                    const double t = __builtin_fma((double)j, interval, first_time);
+                    const double t = time_at(j);
                     if (pmc_fits) pmc_fits = pmc.fit(eb, v);
                     if (swing_fits) swing_fits = swing.fit(dev, t, v);
                 }
@@ -1950,7 +1961,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     } else {
                         rec.start_and_type = current | 0x80000000u;
                         rec.end = current + swing.length - 1;
-                        swing.model(interval, &rec.p0, &rec.p1);
+                        if (HAS_TS) { // SwingFast::model with the span from the timestamps (swing.rs:246-259)
+                            const double projected = swing.numerator / swing.denominator;
+                            const double slope = max_num(swing.lower.slope, min_num(projected, swing.upper.slope));
+                            const double span = time_at(rec.end) - swing.start_time;
+                            rec.p0 = (float)swing.first_value;
+                            rec.p1 = (float)(slope * span + swing.first_value);
+                        } else {
+                            swing.model(interval, &rec.p0, &rec.p1);
+                        }
                     }
                 }
             }
@@ -2947,7 +2966,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         // Few chunks: one wave per chunk, which leaves the chunks whose models turn out short to split mode
         // (forced piece sizes are the tests' way to ask for split mode alone; MDB_FIT_WAVE=1: every chunk, to the end).
         const int wave_setting = fit_wave_setting();
-        const bool wave = fast && !ts && fit_lean_setting() && wave_setting != 0 &&
+        const bool exact_loaded_timestamps = ts && chunk_irregular && regular_verdict[1] == 0 && fit_fast_setting();
+        const bool wave = ((fast && !ts) || exact_loaded_timestamps) && fit_lean_setting() && wave_setting != 0 &&
                           (wave_setting == 1 ||
                            (piece_points != 0 &&
                             (wave_setting == 2 || (n_chunks <= FIT_WAVE_MAX_CHUNKS && !std::getenv("MDB_FIT_PIECE_POINTS")))));
@@ -2972,15 +2992,20 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             }
             {
                 LaunchTimer timer(ctx, "k_fit_models_wave");
-                if (eb.kind == MDB_EB_RELATIVE)
-                    hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_RELATIVE>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
-                                       ctx->stream, args, leave, record_base, records, plans, error_flag);
-                else if (eb.kind == MDB_EB_ABSOLUTE)
-                    hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_ABSOLUTE>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
-                                       ctx->stream, args, leave, record_base, records, plans, error_flag);
-                else
-                    hipLaunchKernelGGL((k_fit_models_wave<MDB_EB_LOSSLESS>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0,
-                                       ctx->stream, args, leave, record_base, records, plans, error_flag);
+#define MDB_LAUNCH_WAVE(KIND, HAS_TS)                                                                                    \
+    hipLaunchKernelGGL((k_fit_models_wave<KIND, HAS_TS>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream, args, \
+                       leave, record_base, records, plans, error_flag)
+                if (eb.kind == MDB_EB_RELATIVE) {
+                    if (ts) MDB_LAUNCH_WAVE(MDB_EB_RELATIVE, true);
+                    else MDB_LAUNCH_WAVE(MDB_EB_RELATIVE, false);
+                } else if (eb.kind == MDB_EB_ABSOLUTE) {
+                    if (ts) MDB_LAUNCH_WAVE(MDB_EB_ABSOLUTE, true);
+                    else MDB_LAUNCH_WAVE(MDB_EB_ABSOLUTE, false);
+                } else {
+                    if (ts) MDB_LAUNCH_WAVE(MDB_EB_LOSSLESS, true);
+                    else MDB_LAUNCH_WAVE(MDB_EB_LOSSLESS, false);
+                }
+#undef MDB_LAUNCH_WAVE
             }
             if (leave.counts) {
                 unsigned long long counts[WAVE_COUNTS] = {};
