@@ -2980,9 +2980,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 leave.chunk_left = static_cast<unsigned int *>(p);
                 leave.n_left = leave.chunk_left + n_chunks;
                 leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 1024);
-                // (2 300 cycles per step against split mode's 107 per point under a relative or absolute bound -
-                // k_fit_models_lean - and 166 under a lossless one, measured on the bench's mixed series)
-                leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 12 : 20);
+                // (2 300 cycles per step against split mode's 107 per point under a relative or absolute bound:
+                // k_fit_models_lean. Under a lossless one split mode is k_fit_models, and on the bench's mixed series
+                // every threshold above 3 only moved chunks to the slower side: 41 ms at 3, 54 at 12, 81 at 45.)
+                leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 3 : 20);
                 FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 4, ctx->stream));
             }
             static const bool count_steps = std::getenv("MDB_FIT_DEBUG") != nullptr;
