@@ -1598,6 +1598,10 @@ struct ExponentRange {
     int low, high;
 };
 
+struct ValueRange {
+    float low, high;
+};
+
 // A chunk whose models turn out short is not this kernel's: a model costs at least one block of 64 points however
 // short it is, a pass over rejected start points half a block per 64 start points it looks at and four for its
 // second stage. Split mode takes about 100 cycles per point on such data, a block 2 300. Every `window_points` the
@@ -2069,7 +2073,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
             window = (position + lane < n) ? split.entry[base + position + lane] : 0u;
             window_valid = true;
         }
-        const uint32_t entry = __shfl(window, (int)(position - window_first), MDB_WAVE);
+        const uint32_t entry = read_lane(window, (int)(position - window_first));
         if (entry == ENTRY_REJECTED) {
             // A run of rejected points (noise under a lossless bound rejects every point) is skipped
             // in one step: to the first entry of the window that is something else.
@@ -2513,6 +2517,13 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         if (eb.kind != MDB_EB_LOSSLESS) {
             const float raw = stored;
             const float rewritten = active ? rewrite_least_mantissa_bits(eb, raw) : 0.0f;
+            // Where nearly every value breaks away from the one stored before it (noise under a tight bound), one
+            // trip per breaker is 64 trips per batch. If lane i - 1 stores its own value, lane i is compared with
+            // that: whether it then breaks too is known up front for all lanes at once, so a run of breakers
+            // behind a breaker is taken in one trip.
+            const float rewritten_before = dpp_move<0x138>(rewritten); // wave_shr:1
+            const unsigned long long breaks_behind_a_breaker =
+                __ballot(active && lane > 0 && !within_error_bound(eb, raw, rewritten_before));
             int cursor = 0;
             while (true) {
                 const bool breaks = active && lane >= cursor && !within_error_bound(eb, raw, last_stored);
@@ -2523,17 +2534,19 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
                 }
                 const int breaker = __ffsll((long long)mask) - 1;
                 if (lane >= cursor && lane < breaker) stored = last_stored;
-                last_stored = __shfl(rewritten, breaker, MDB_WAVE);
-                if (lane == breaker) stored = last_stored;
-                cursor = breaker + 1;
+                const unsigned long long behind = breaker + 1 < MDB_WAVE ? breaks_behind_a_breaker >> (breaker + 1) : 0ull;
+                const int last_breaker = breaker + (~behind ? __builtin_ctzll(~behind) : MDB_WAVE - 1 - breaker);
+                if (lane >= breaker && lane <= last_breaker) stored = rewritten;
+                last_stored = read_lane(rewritten, last_breaker);
+                cursor = last_breaker + 1;
             }
         }
-        const float before = __shfl_up(stored, 1, MDB_WAVE);
+        const float before = dpp_move<0x138>(stored); // wave_shr:1 (lane 0: not used)
         const uint32_t current = active ? __float_as_uint(stored) : 0u;
         const uint32_t previous = active ? __float_as_uint(lane == 0 ? carried_in : before) : 0u;
         // The value stored last in this batch is what the next batch starts from.
         const int last_lane = (int)min((uint32_t)MDB_WAVE, n - base) - 1;
-        carried_in = __shfl(stored, last_lane, MDB_WAVE);
+        carried_in = read_lane(stored, last_lane);
         last_stored = carried_in;
         const uint32_t x = current ^ previous;
         const bool repeat = x == 0;
@@ -2542,6 +2555,11 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         // The window each lane's code is written with; lanes that open one get their own.
         uint32_t my_leading = window_leading, my_trailing = window_trailing;
         bool opens = false;
+        // (runs of lanes that each open a window of their own in one trip, as with the stored values above: a lane
+        // behind an opener is written with that lane's window unless it does not fit it)
+        const uint32_t leading_before = dpp_move<0x138>(leading), trailing_before = dpp_move<0x138>(trailing);
+        const unsigned long long opens_behind_an_opener =
+            __ballot(active && lane > 0 && !repeat && !(leading >= leading_before && trailing >= trailing_before));
         int cursor = 0;
         while (true) {
             const bool misfit = active && lane >= cursor && !repeat &&
@@ -2559,42 +2577,32 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
                 my_leading = window_leading;
                 my_trailing = window_trailing;
             }
-            window_leading = __shfl(leading, opener, MDB_WAVE);
-            window_trailing = __shfl(trailing, opener, MDB_WAVE);
-            if (lane == opener) {
+            const unsigned long long behind = opener + 1 < MDB_WAVE ? opens_behind_an_opener >> (opener + 1) : 0ull;
+            const int last_opener = opener + (~behind ? __builtin_ctzll(~behind) : MDB_WAVE - 1 - opener);
+            if (lane >= opener && lane <= last_opener) {
                 opens = true;
-                my_leading = window_leading;
-                my_trailing = window_trailing;
+                my_leading = leading;
+                my_trailing = trailing;
             }
-            cursor = opener + 1;
+            window_leading = read_lane(leading, last_opener);
+            window_trailing = read_lane(trailing, last_opener);
+            cursor = last_opener + 1;
         }
         const uint32_t meaningful = 32u - my_leading - my_trailing;
         uint32_t code_bits = 0;
         if (active) code_bits = repeat ? 2u : (opens ? 13u + meaningful : 1u + meaningful);
         // Exclusive prefix sum of the code lengths: where each code goes.
-        uint32_t inclusive = code_bits;
-#pragma unroll
-        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
-            const uint32_t up = __shfl_up(inclusive, delta, MDB_WAVE);
-            if (lane >= delta) inclusive += up;
-        }
-        const uint32_t batch_bits = __shfl(inclusive, MDB_WAVE - 1, MDB_WAVE);
+        const uint32_t inclusive = wave_inclusive_scan(code_bits, lane, [](uint32_t a, uint32_t b) { return a + b; });
+        const uint32_t batch_bits = read_lane(inclusive, MDB_WAVE - 1);
         // min / max with the first operand kept on ties, NaN as the neutral element (macaque_v.rs:199-204).
         // The reduction keeps the order of the values (earlier blocks are the first operand), so that
         // e.g. the sign of a zero minimum is the one the sequential encoder would report.
-        float low = active ? stored : __uint_as_float(0x7fc00000u);
-        float high = low;
-#pragma unroll
-        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
-            const float low_before = __shfl_up(low, delta, MDB_WAVE);
-            const float high_before = __shfl_up(high, delta, MDB_WAVE);
-            if (lane >= delta) {
-                low = min_num(low_before, low);
-                high = max_num(high_before, high);
-            }
-        }
-        min_value = min_num(min_value, __shfl(low, MDB_WAVE - 1, MDB_WAVE));
-        max_value = max_num(max_value, __shfl(high, MDB_WAVE - 1, MDB_WAVE));
+        const float mine = active ? stored : __uint_as_float(0x7fc00000u);
+        const ValueRange range = read_lane(wave_inclusive_scan(ValueRange{mine, mine}, lane, [](ValueRange a, ValueRange b) {
+            return ValueRange{min_num(a.low, b.low), max_num(a.high, b.high)};
+        }), MDB_WAVE - 1);
+        min_value = min_num(min_value, range.low);
+        max_value = max_num(max_value, range.high);
         if (WRITE) {
             if (active) {
                 const uint32_t at = carry_bits + inclusive - code_bits;
@@ -2717,13 +2725,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_timestamps(FitArgs args, const
             payload_bits = delta_of_delta_code(dod, &prefix, &prefix_bits);
         }
         const uint32_t code_bits = prefix_bits + payload_bits;
-        uint32_t inclusive = code_bits;
-#pragma unroll
-        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
-            const uint32_t up = __shfl_up(inclusive, delta, MDB_WAVE);
-            if (lane >= delta) inclusive += up;
-        }
-        const uint32_t batch_bits = __shfl(inclusive, MDB_WAVE - 1, MDB_WAVE);
+        const uint32_t inclusive = wave_inclusive_scan(code_bits, lane, [](uint32_t x, uint32_t y) { return x + y; });
+        const uint32_t batch_bits = read_lane(inclusive, MDB_WAVE - 1);
         if (active) {
             uint32_t at = carry_bits + inclusive - code_bits;
             gap_put(buffer, at, prefix, prefix_bits);
