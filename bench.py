@@ -497,6 +497,15 @@ def mixed_models(context, mdb, np, ora, args):
             got_values = context.download_array(out_val, points, np.float32, offset_elements=s * points)
             if not (np.array_equal(got_ts, expected_ts) and np.array_equal(got_values.view(np.uint32), expected_values.view(np.uint32))):
                 raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: the grid of series {s} differs from the oracle's")
+        if not args.no_host_path:
+            # The same segments as host batches through the pipelined grid of the boundary (the patched GridStream's
+            # call sequence, PCIe included): all three model types, MacaqueV streams without the resident batch's
+            # cursors.
+            from modelardb_rs_amd import host
+            host.measure_grid_stream(context, downloaded, 8192)
+            host_points, host_seconds, host_bytes = host.measure_grid_stream(context, downloaded, 8192)
+            shape["host_path"] = {"values_per_s": host_points / host_seconds, "GB_per_s_pcie": host_bytes / host_seconds / 1e9,
+                                  "seconds": host_seconds, "segments": len(downloaded)}
         del downloaded
         out[label] = shape
         for pointer in (out_ts, out_val):

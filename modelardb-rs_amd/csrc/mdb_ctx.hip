@@ -571,14 +571,29 @@ int mdb::upload_segment_list_locked(mdb_ctx *ctx, const mdb_segments *const *hos
     uint64_t off_views[3];
     std::vector<uint64_t> off_buffers[3];
     std::vector<int64_t> all_sizes[3];
+    std::vector<int64_t> span_starts[3]; // what of every data buffer travels: [start, start + size) of the original
     uint64_t off_tables[3];
     for (int c = 0; c < 3; c++) {
         off_views[c] = add_column([&](const mdb_segments *s) { return (const void *)column_of(s, c)->views; }, 16);
         for (uint32_t h = 0; h < n_hosts; h++) {
+            // Only the bytes the batch's views point at: a batch that is a slice of a larger array (arrow's
+            // RecordBatch::slice, the batches a Parquet page is cut into) shares that array's data buffers,
+            // hundreds of megabytes of which belong to other rows.
             const mdb_binview_col *col = column_of(hosts[h], c);
+            std::vector<int64_t> low((size_t)col->n_buffers, INT64_MAX), high((size_t)col->n_buffers, 0);
+            for (uint64_t i = 0; i < hosts[h]->n; i++) {
+                const mdb_view16 &view = col->views[i];
+                if (view.length <= 12) continue;
+                const size_t b = (size_t)view.u.ref.buffer_index; // (validate_views_host has been through them)
+                low[b] = std::min<int64_t>(low[b], view.u.ref.offset);
+                high[b] = std::max<int64_t>(high[b], (int64_t)view.u.ref.offset + view.length);
+            }
             for (int b = 0; b < col->n_buffers; b++) {
-                off_buffers[c].push_back(add(col->buffers[b], (uint64_t)col->buffer_sizes[b]));
-                all_sizes[c].push_back(col->buffer_sizes[b]);
+                const int64_t start = high[(size_t)b] > 0 ? (low[(size_t)b] & ~int64_t(15)) : 0; // (alignment kept)
+                const int64_t size = high[(size_t)b] > 0 ? high[(size_t)b] - start : 0;
+                off_buffers[c].push_back(add(col->buffers[b] + start, (uint64_t)size));
+                all_sizes[c].push_back(size);
+                span_starts[c].push_back(start);
             }
         }
     }
@@ -616,16 +631,23 @@ int mdb::upload_segment_list_locked(mdb_ctx *ctx, const mdb_segments *const *hos
         for (int64_t b = 0; b < n_buffers_total[c]; b++)
             table[b] = reinterpret_cast<uint64_t>(dev + off_buffers[c][(size_t)b]);
         table[n_buffers_total[c]] = 0;
-        // the later batches' views onto their buffers' places in the joint table
+        // the views onto their buffers' places in the joint table and onto the part of each buffer that travels
         int32_t first_buffer = 0;
         uint64_t first_row = 0;
         for (uint32_t h = 0; h < n_hosts; h++) {
-            if (first_buffer > 0) {
+            const int32_t n_buffers_here = column_of(hosts[h], c)->n_buffers;
+            bool moved = first_buffer > 0;
+            for (int32_t b = 0; b < n_buffers_here; b++) moved = moved || span_starts[c][(size_t)(first_buffer + b)] != 0;
+            if (moved) {
                 mdb_view16 *views = reinterpret_cast<mdb_view16 *>(stage + off_views[c]) + first_row;
-                for (uint64_t i = 0; i < hosts[h]->n; i++)
-                    if (views[i].length > 12) views[i].u.ref.buffer_index += first_buffer;
+                for (uint64_t i = 0; i < hosts[h]->n; i++) {
+                    if (views[i].length <= 12) continue;
+                    const int32_t joint = views[i].u.ref.buffer_index + first_buffer;
+                    views[i].u.ref.offset -= (int32_t)span_starts[c][(size_t)joint];
+                    views[i].u.ref.buffer_index = joint;
+                }
             }
-            first_buffer += column_of(hosts[h], c)->n_buffers;
+            first_buffer += n_buffers_here;
             first_row += hosts[h]->n;
         }
     }

@@ -1814,7 +1814,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         bool pmc_alive = true, swing_alive = true, by_one_lane = false;
         double first_value = nan;
         const double start_time = time_at(current);
-        LineDev upper = {nan, nan}, lower = {nan, nan};
+        double upper_slope = nan, lower_slope = nan;
         uint32_t position = current;
         while ((pmc_alive || swing_alive) && position < n) {
             counted[WAVE_BLOCKS] += 1;
@@ -1883,45 +1883,46 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             if (swing_alive) {
                 const double t = valid ? time_at(index) : 0.0;
                 const double deviation = lean_deviation<KIND>(dev.factor, value);
-                const LineDev upper_candidate = line_through_exact(start_time, first_value, t, value + deviation);
-                const LineDev lower_candidate = line_through_exact(start_time, first_value, t, value - deviation);
+                // Every bound is a line through the model's first point, so its slope says it all: the intercept of
+                // line_through_exact is first_value - slope * start_time (its special case, slope 0 through equal
+                // values, gives the same up to the sign of a zero, which no comparison sees).
+                const double upper_candidate = line_through_exact(start_time, first_value, t, value + deviation).slope;
+                const double lower_candidate = line_through_exact(start_time, first_value, t, value - deviation).slope;
                 int first_lane = 0;
                 if (position == current) { // the model's first two points are accepted as they come (swing.rs:107-143)
                     swing_length = (uint32_t)min(n_valid, 2);
                     first_lane = 2;
                     if (n_valid >= 2) {
-                        upper = read_lane(upper_candidate, 1);
-                        lower = read_lane(lower_candidate, 1);
+                        upper_slope = read_lane(upper_candidate, 1);
+                        lower_slope = read_lane(lower_candidate, 1);
                     }
                 }
                 while (swing_alive && first_lane < n_valid) {
                     counted[WAVE_SWING_SCANS] += 1;
                     // The bounds this lane would meet if every lane in front of it moved them as lines of smaller /
                     // larger slope do: the extreme of the state's slope and the candidates of [first_lane, lane).
-                    LineDev above = dpp_move<0x138>(upper_candidate); // wave_shr:1
-                    LineDev below = dpp_move<0x138>(lower_candidate);
+                    double above = dpp_move<0x138>(upper_candidate); // wave_shr:1
+                    double below = dpp_move<0x138>(lower_candidate);
                     if (lane <= first_lane) {
-                        above = upper;
-                        below = lower;
+                        above = upper_slope;
+                        below = lower_slope;
                     }
-                    // (the earlier one stays on ties: a step only replaces a bound by a strictly lower / higher line)
-                    above = wave_inclusive_scan(above, lane, [](LineDev a, LineDev b) { return b.slope < a.slope ? b : a; });
-                    below = wave_inclusive_scan(below, lane, [](LineDev a, LineDev b) { return b.slope > a.slope ? b : a; });
+                    above = wave_inclusive_scan(above, lane, [](double a, double b) { return b < a ? b : a; });
+                    below = wave_inclusive_scan(below, lane, [](double a, double b) { return b > a ? b : a; });
                     // The step itself (swing.rs:144-197) against that state.
-                    const double upper_approximation = above.slope * t + above.intercept;
-                    const double lower_approximation = below.slope * t + below.intercept;
+                    const double upper_approximation = above * t + (first_value - above * start_time);
+                    const double lower_approximation = below * t + (first_value - below * start_time);
                     const bool fails = upper_approximation + deviation < value || lower_approximation - deviation > value;
                     const bool lowers_upper = upper_approximation - deviation > value;
                     const bool raises_lower = lower_approximation + deviation < value;
-                    const bool as_assumed = lowers_upper == (upper_candidate.slope < above.slope) &&
-                                            raises_lower == (lower_candidate.slope > below.slope);
+                    const bool as_assumed = lowers_upper == (upper_candidate < above) && raises_lower == (lower_candidate > below);
                     const bool mine = lane >= first_lane && lane < n_valid;
                     const unsigned long long stops = __ballot(mine && (fails || !as_assumed));
                     const int at = stops ? __builtin_ctzll(stops) : n_valid - 1; // its incoming state is the true one
                     const bool ends = stops && ((__ballot(fails) >> at) & 1ull) != 0;
                     // The state behind lane `at` (in front of it when the model ends there).
-                    upper = read_lane((lowers_upper && !ends) ? upper_candidate : above, at);
-                    lower = read_lane((raises_lower && !ends) ? lower_candidate : below, at);
+                    upper_slope = read_lane((lowers_upper && !ends) ? upper_candidate : above, at);
+                    lower_slope = read_lane((raises_lower && !ends) ? lower_candidate : below, at);
                     if (ends) {
                         swing_length += (uint32_t)(at - first_lane);
                         swing_alive = false;
@@ -1997,7 +1998,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     rec.start_and_type = current | 0x80000000u;
                     rec.end = current + swing_length - 1;
                     rec.p0 = (float)first_value;
-                    if (lane == 0) pending[n_pending] = {n_models, current, swing_length, lower.slope, upper.slope};
+                    if (lane == 0) pending[n_pending] = {n_models, current, swing_length, lower_slope, upper_slope};
                     n_pending += 1;
                 }
                 if (lane == 0) {
