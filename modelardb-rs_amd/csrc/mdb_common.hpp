@@ -73,6 +73,7 @@ enum ScratchSlot {
     SCRATCH_FIT_IN_VALUES,
     SCRATCH_FIT_IN_OFFSETS,
     SCRATCH_FIT_WAVE,
+    SCRATCH_MV_HOST_INDEX,
     SCRATCH_SLOT_COUNT
 };
 
@@ -178,7 +179,12 @@ struct MvIndex {
     void *ts_piece_base = nullptr;  // unsigned long long[n + 1]
     void *ts_slots = nullptr;       // the block TsCheckpoints points into
     void *ts_totals = nullptr;      // uint32_t[n + 4]
+    // The index of ONE call over host batches (mv_host_index, mdb_grid.hip): made by host threads while the batches
+    // are on their way, for the long streams only - a segment without pieces is the serial kernel's - and living in
+    // the context's scratch.
+    bool of_one_call = false;
     ~MvIndex() {
+        if (of_one_call) return;
         if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals) {
             (void)hipSetDevice(device);
             for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals})

@@ -30,6 +30,7 @@
 #include "mdb_scan.hpp"
 #include "mdb_macaque_parallel.hpp"
 
+#include <atomic>
 #include <cfloat>
 
 namespace mdb {
@@ -2447,7 +2448,8 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     const uint32_t *__restrict__ serial_ids, uint64_t n_serial, const MvSeg *__restrict__ mv_segs,
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ irregular_totals,
     const uint32_t *__restrict__ irregular_first, int64_t *__restrict__ out_ts, float *__restrict__ out_val,
-    GridHeader *__restrict__ header, TsCheckpoints checkpoints, const TileDesc *__restrict__ indexed_desc) {
+    GridHeader *__restrict__ header, TsCheckpoints checkpoints, const TileDesc *__restrict__ indexed_desc,
+    const unsigned long long *__restrict__ indexed_piece_base) {
     __shared__ uint32_t ring[SERIAL_RING_WORDS][MDB_WAVE];
     const int lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * SERIAL_THREADS + lane;
@@ -2517,7 +2519,9 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_grid_serial(
     // because the residual stream is seeded with the model's last value.
     // (indexed_desc: the batch has a cursor index and k_grid_mv_pieces decodes every stream piece by piece, but for
     // the residual tails it leaves here, mv_left_to_serial)
-    const bool skip_macaque = present && indexed_desc != nullptr && !mv_left_to_serial(indexed_desc[i].flags);
+    // (indexed_piece_base: the index covers the long streams only - a segment without pieces is decoded here)
+    const bool skip_macaque = present && indexed_desc != nullptr && !mv_left_to_serial(indexed_desc[i].flags) &&
+                              (indexed_piece_base == nullptr || indexed_piece_base[i + 1] > indexed_piece_base[i]);
     const uint32_t n_res = d.n_total - d.n_model;
     const bool residuals_wanted = present && !skip_macaque && n_res > 0 && visible_end > d.n_model;
     const uint32_t values_to_decode = residuals_wanted ? d.n_model : min(d.n_model, visible_end);
@@ -2722,10 +2726,19 @@ int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegmen
 // asks for it. *out stays empty for a foreign or transient batch, for one without MacaqueV streams, for one with a
 // malformed stream (the serial kernel reports it) and with MDB_GRID_MV_INDEX=0 (A/B, tests). Uses the counting
 // walk's scratch: call it BEFORE grid_plan / the aggregate kernels lay theirs out.
+// (the index of a call's own upload, mv_host_index, for the entry points that reach the kernels through
+// grid_batch_dev_locked: set around that call by the thread that makes it)
+thread_local std::shared_ptr<MvIndex> t_call_index;
+thread_local const void *t_call_index_views = nullptr;
+
 int mv_index_prepare(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvIndex> *out) {
     out->reset();
     const char *setting = std::getenv("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return 0;
+    if (t_call_index && t_call_index_views == in->values.views) {
+        *out = t_call_index;
+        return 0;
+    }
     std::shared_ptr<MvIndex> index = owned_segments_index(in);
     if (!index) return 0;
     std::lock_guard<std::mutex> lock(index->mutex);
@@ -3120,8 +3133,11 @@ int grid_parallel_macaque(mdb_ctx *ctx, const DevSegments &s, TimeRange range, G
     const uint64_t n_serial = plan.host_header.n_serial;
     auto select = [&](MvSeg *segs) {
         LaunchTimer timer(ctx, "k_mv_select");
+        const MvIndex *index = plan.mv_index.get();
         hipLaunchKernelGGL(k_mv_select, dim3((uint32_t)((n_serial + 255) / 256)), dim3(256), 0, ctx->stream, s,
-                           range, plan.offsets, plan.serial_ids, n_serial, plan.mv_min_values, segs);
+                           range, plan.offsets, plan.serial_ids, n_serial, plan.mv_min_values, segs,
+                           index && index->of_one_call ? static_cast<const unsigned long long *>(index->piece_base)
+                                                       : static_cast<const unsigned long long *>(nullptr));
     };
     return mv_pipeline(ctx, n_serial, plan.host_header.metrics[9], plan.mv_forced, select, out_val,
                        &plan.header->error, segs_out);
@@ -3555,20 +3571,24 @@ int grid_launch_streams(mdb_ctx *ctx, const DevSegments &s, TimeRange range, Gri
         if (round == 64) launch(k_grid_mv_pieces<64>);
         else if (round == 16) launch(k_grid_mv_pieces<16>);
         else launch(k_grid_mv_pieces<32>);
-    } else if (n_serial > 0 && plan.host_header.metrics[9] > 0) {
+    }
+    // (the index of one call covers its long streams with regular timestamps: the others are still this decoder's)
+    if ((!index || index->of_one_call) && n_serial > 0 && plan.host_header.metrics[9] > 0) {
         MvSeg *segs = nullptr;
         if (grid_parallel_macaque(ctx, s, range, plan, out_val, &segs)) return 1;
         mv_segs = segs;
     }
     // (with the index the serial kernel is left with the irregular timestamps that live inside their views)
-    if (n_serial > 0 && (!index || plan.host_header.metrics[8] > 0)) {
+    if (n_serial > 0 && (!index || index->of_one_call || plan.host_header.metrics[8] > 0)) {
         LaunchTimer timer(ctx, "k_grid_serial");
         hipLaunchKernelGGL(k_grid_serial,
                            dim3((uint32_t)((n_serial + SERIAL_THREADS - 1) / SERIAL_THREADS)),
                            dim3(SERIAL_THREADS), 0, ctx->stream, s, range, plan.offsets,
                            plan.serial_ids, n_serial, mv_segs, plan.counts, plan.irregular_totals,
                            plan.irregular_first, out_ts, out_val, plan.header, plan.checkpoints,
-                           index ? plan.desc : static_cast<const TileDesc *>(nullptr));
+                           index ? plan.desc : static_cast<const TileDesc *>(nullptr),
+                           index && index->of_one_call ? static_cast<const unsigned long long *>(index->piece_base)
+                                                       : static_cast<const unsigned long long *>(nullptr));
     }
     if (n_serial > 0 && out_ts != nullptr && plan.host_header.metrics[8] > 0) { // irregular segments exist
         LaunchTimer timer(ctx, "k_grid_swing_irregular");
@@ -3756,6 +3776,231 @@ int grid_batch_dev_locked(mdb_ctx *ctx, const mdb_segments *in, TimeRange range,
 
 using namespace mdb;
 
+// ---- the cursor index of ONE call over host batches, made by host threads -------------------------------------
+//
+// A batch that comes from the host is decoded once: an index walk on the GPU (one lane per stream, k_mv_index_walk)
+// would cost what the serial decode costs. But the long streams are what hurts - a 65 536-value MacaqueV segment
+// (a whole ingest buffer of noise under a lossless bound) keeps one lane busy for 10 ms however idle the GPU is - and
+// a CPU core walks such a stream in a third of a millisecond. So the call's host threads walk the long streams of the
+// batches (segments with regular timestamps whose model values number at least MV_HOST_MIN_VALUES; their residual
+// tails with them) while nothing else needs them, the cursors travel with the batch (0.5 bytes per value), and
+// k_grid_mv_pieces decodes those streams piece by piece; everything else is k_grid_serial's as before. Same cursors
+// as k_mv_index_walk leaves (macaque_v.rs:272-323 walked, not decoded to floats). A malformed stream or segment:
+// no index at all, the kernels that report it run as before.
+constexpr uint32_t MV_HOST_MIN_VALUES = 512;
+
+struct HostStreamBits { // MSB-first bits of a byte string; zeros behind its end
+    const uint8_t *bytes;
+    uint64_t n_bytes;
+    uint64_t used = 0;
+    uint64_t peek64() const {
+        const uint64_t byte = used >> 3, shift = used & 7u;
+        uint64_t window = 0;
+        uint8_t next = 0;
+        if (byte + 9 <= n_bytes) {
+            std::memcpy(&window, bytes + byte, 8);
+            window = __builtin_bswap64(window);
+            next = bytes[byte + 8];
+        } else {
+            for (uint64_t k = 0; k < 8; k++) window = (window << 8) | (byte + k < n_bytes ? bytes[byte + k] : 0u);
+        }
+        return shift ? (window << shift) | ((uint64_t)next >> (8u - shift)) : window;
+    }
+};
+
+struct HostViewBytes {
+    const uint8_t *data;
+    uint64_t length;
+};
+static HostViewBytes host_view_bytes(const mdb_binview_col &col, uint64_t i) {
+    const mdb_view16 &view = col.views[i];
+    if (view.length <= 12) return {view.u.inlined, (uint64_t)std::max(view.length, 0)};
+    return {col.buffers[view.u.ref.buffer_index] + view.u.ref.offset, (uint64_t)view.length};
+}
+
+// Points of a segment with regular timestamps (analyse_segment's rules); false: not regular, or malformed.
+static bool host_regular_points(const mdb_segments &seg, uint64_t i, uint32_t *n_total) {
+    const HostViewBytes ts = host_view_bytes(seg.timestamps, i);
+    const int64_t start = seg.start_time[i], end = seg.end_time[i];
+    if (ts.length == 0) {
+        *n_total = start == end ? 1u : 2u;
+        return true;
+    }
+    if ((ts.data[0] & 0x80u) != 0 || ts.length > 8) return false;
+    uint64_t length = 0;
+    for (uint64_t k = 0; k < ts.length; k++) length = (length << 8) | ts.data[k];
+    if (length < 2) return false;
+    if (end < start) {
+        *n_total = 0;
+        return true;
+    }
+    const uint64_t span = (uint64_t)(end - start), interval = span / (length - 1);
+    if (interval == 0) return false;
+    const uint64_t produced = span / interval + 1;
+    if (produced > COUNT_MASK) return false;
+    *n_total = (uint32_t)produced;
+    return true;
+}
+
+struct HostIndexJob {
+    const mdb_segments *const *ins;
+    std::vector<uint64_t> first_row;     // of every input batch in the joint batch
+    std::vector<uint64_t> chosen;        // joint row of every segment that gets cursors
+    std::vector<uint32_t> chosen_input;  // its input batch
+    std::vector<uint32_t> n_values, n_residuals, n_model;
+    std::vector<unsigned long long> *piece_base;
+    std::vector<MvCursor> *cursors;
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> malformed{0};
+};
+
+static void host_index_share(unsigned, void *arg) {
+    HostIndexJob &job = *static_cast<HostIndexJob *>(arg);
+    while (true) {
+        const uint64_t k = job.next.fetch_add(1);
+        if (k >= job.chosen.size() || job.malformed.load()) return;
+        const uint64_t joint = job.chosen[k];
+        const mdb_segments &seg = *job.ins[job.chosen_input[k]];
+        const uint64_t i = joint - job.first_row[job.chosen_input[k]];
+        MvCursor *out = job.cursors->data() + (*job.piece_base)[joint];
+        uint32_t last = 0, chain_seed = 0;
+        for (int which = 0; which < 2; which++) { // the model's values, then the residual tail
+            const bool residual = which == 1;
+            uint32_t remaining = residual ? job.n_residuals[k] : job.n_values[k];
+            if (remaining == 0) continue;
+            HostViewBytes bytes = host_view_bytes(residual ? seg.residuals : seg.values, i);
+            if (residual) {
+                if (bytes.length < 2) { job.malformed = 1; return; }
+                bytes.length -= 1; // (its last byte is the number of residuals)
+                chain_seed = last; // (0 unless a MacaqueV model's values have just been walked)
+                last = 0;
+            } else if (bytes.length == 0) {
+                job.malformed = 1;
+                return;
+            }
+            HostStreamBits bits{bytes.data, bytes.length};
+            uint32_t leading = 255, trailing = 0, position = residual ? job.n_model[k] : 0u, in_stream = 0;
+            bool raw = !residual;
+            while (remaining > 0) {
+                if (in_stream % MV_PIECE_VALUES == 0) {
+                    MvCursor cursor;
+                    cursor.bit_position = (uint32_t)bits.used;
+                    cursor.xor_bits = last;
+                    cursor.segment = (uint32_t)joint;
+                    cursor.point_index = position;
+                    cursor.n_values = std::min(remaining, MV_PIECE_VALUES);
+                    cursor.window = (leading & 255u) | ((trailing & 255u) << 8) | (residual ? MV_WINDOW_RESIDUAL : 0u) |
+                                    (raw ? MV_WINDOW_RAW : 0u);
+                    cursor.chain_seed = residual ? chain_seed : 0u;
+                    cursor.pad = 0;
+                    *out++ = cursor;
+                }
+                // one code (ring_decode_value)
+                const uint64_t window = bits.peek64();
+                const uint32_t top = (uint32_t)(window >> 51);
+                const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
+                const bool opens = !raw && c0 && c1, repeats = !raw && c0 && !c1;
+                const uint32_t header_bits = raw ? 0u : (c0 ? (c1 ? 13u : 2u) : 1u);
+                if (opens) {
+                    leading = (top >> 6) & 31u;
+                    trailing = 32u - (top & 63u) - leading;
+                }
+                uint32_t meaningful = 32u - leading - trailing;
+                if (!raw && !repeats && (meaningful > 32u || trailing > 31u)) { job.malformed = 1; return; }
+                meaningful = raw ? 32u : (repeats ? 0u : meaningful);
+                bits.used += header_bits;
+                const uint32_t payload = meaningful ? (uint32_t)(bits.peek64() >> (64u - meaningful)) : 0u;
+                bits.used += meaningful;
+                last = raw ? payload : (last ^ (payload << (trailing & 31u)));
+                raw = false;
+                position += 1;
+                remaining -= 1;
+                in_stream += 1;
+            }
+            if (bits.used > bytes.length * 8 || bits.used > 0xffffffffull) { job.malformed = 1; return; }
+        }
+    }
+}
+
+// piece_base (rows + 1) and cursors of the call's long streams; both stay empty when there is nothing to index
+// (MDB_GRID_MV_INDEX=0 included).
+static void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
+                          std::vector<MvCursor> *cursors) {
+    piece_base->clear();
+    cursors->clear();
+    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    if (setting && std::strcmp(setting, "0") == 0) return;
+    // (MDB_GRID_MV_HOST_MIN_VALUES: streams from that many values on: tests index short ones too)
+    const char *text = std::getenv("MDB_GRID_MV_HOST_MIN_VALUES");
+    const long long wanted = text ? std::atoll(text) : 0;
+    const uint32_t min_values = wanted > 0 ? (uint32_t)std::min<long long>(wanted, 1 << 30) : MV_HOST_MIN_VALUES;
+    HostIndexJob job;
+    job.ins = ins;
+    uint64_t rows = 0;
+    for (uint32_t h = 0; h < n_ins; h++) {
+        job.first_row.push_back(rows);
+        rows += ins[h]->n;
+    }
+    if (rows == 0 || rows > 0xfffffff0ull) return;
+    std::vector<unsigned long long> pieces(rows + 1, 0);
+    for (uint32_t h = 0; h < n_ins; h++) {
+        const mdb_segments &seg = *ins[h];
+        for (uint64_t i = 0; i < seg.n; i++) {
+            if (seg.model_type_id[i] != MDB_MACAQUE_V_ID) continue; // (residual tails alone are short: at most 255 values)
+            uint32_t n_total = 0;
+            if (!host_regular_points(seg, i, &n_total)) continue;
+            const HostViewBytes residuals = host_view_bytes(seg.residuals, i);
+            const uint32_t n_res = residuals.length > 0 ? residuals.data[residuals.length - 1] : 0u;
+            if (n_res > n_total || residuals.length == 1) continue;
+            const uint32_t n_model = n_total - n_res;
+            if (n_model < min_values) continue;
+            job.chosen.push_back(job.first_row[h] + i);
+            job.chosen_input.push_back(h);
+            job.n_values.push_back(n_model);
+            job.n_residuals.push_back(n_res);
+            job.n_model.push_back(n_model);
+            pieces[job.first_row[h] + i] = (n_model + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES + (n_res + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES;
+        }
+    }
+    if (job.chosen.empty()) return;
+    unsigned long long total = 0;
+    for (uint64_t r = 0; r < rows; r++) { // exclusive scan
+        const unsigned long long here = pieces[r];
+        pieces[r] = total;
+        total += here;
+    }
+    pieces[rows] = total;
+    std::vector<MvCursor> walked((size_t)total);
+    job.piece_base = &pieces;
+    job.cursors = &walked;
+    host_parallel((unsigned)std::min<uint64_t>(host_parallel_width(), job.chosen.size()), host_index_share, &job);
+    if (job.malformed.load()) return;
+    piece_base->swap(pieces);
+    cursors->swap(walked);
+}
+
+// The walked cursors onto the device (the context's scratch) as the index of the uploaded batch `seg`.
+static int mv_host_index_attach(mdb_ctx *ctx, const mdb_segments &seg, const std::vector<unsigned long long> &piece_base,
+                                const std::vector<MvCursor> &cursors, std::shared_ptr<MvIndex> *out) {
+    out->reset();
+    if (cursors.empty() || piece_base.size() != seg.n + 1) return 0;
+    const uint64_t base_bytes = align_up(piece_base.size() * 8, 256);
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_MV_HOST_INDEX, base_bytes + cursors.size() * sizeof(MvCursor), &p)) return 1;
+    MDB_HIP_CHECK(hipMemcpyAsync(p, piece_base.data(), piece_base.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(p) + base_bytes, cursors.data(), cursors.size() * sizeof(MvCursor),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    auto index = std::make_shared<MvIndex>();
+    index->of_one_call = true;
+    index->built = index->usable = true;
+    index->device = ctx->device;
+    index->n_pieces = cursors.size();
+    index->piece_base = p;
+    index->cursors = static_cast<uint8_t *>(p) + base_bytes;
+    *out = index;
+    return 0;
+}
+
 namespace {
 
 const TimeRange NO_RANGE = {0, 0, 0};
@@ -3801,17 +4046,27 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
                          mdb_grid_metrics *metrics) {
     if (!ctx || !in) return fail("ctx and in must not be NULL.");
     if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
+    std::vector<unsigned long long> index_piece_base;
+    std::vector<MvCursor> index_cursors;
+    mv_host_index(&in, 1, &index_piece_base, &index_cursors); // (cursors into the long MacaqueV streams, by host threads)
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
-    int rc = 0;
+    int rc = mv_host_index_attach(ctx, dev->seg, index_piece_base, index_cursors, &t_call_index);
+    t_call_index_views = dev->seg.values.views;
+    struct ForgetCallIndex {
+        ~ForgetCallIndex() {
+            t_call_index.reset();
+            t_call_index_views = nullptr;
+        }
+    } forget_call_index;
     {
         void *stage = nullptr;
         // Device staging for the outputs: timestamps, values, rows-per-segment (256 B aligned).
         const uint64_t ts_bytes = align_up(cap * 8, 256), val_bytes = align_up(cap * 4, 256);
         const uint64_t rows_bytes = align_up(in->n * 4, 256);
-        rc = scratch_reserve(ctx, SCRATCH_STAGE_DEV, ts_bytes + val_bytes + rows_bytes, &stage);
+        if (!rc) rc = scratch_reserve(ctx, SCRATCH_STAGE_DEV, ts_bytes + val_bytes + rows_bytes, &stage);
         uint8_t *base = static_cast<uint8_t *>(stage);
         int64_t *dev_ts = reinterpret_cast<int64_t *>(base);
         float *dev_val = reinterpret_cast<float *>(base + ts_bytes);
@@ -3845,6 +4100,11 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
     for (uint32_t k = 0; k < n_ins; k++)
         if (!ins[k]) return fail("ctx, in and out must not be NULL.");
     const TimeRange range{range_arg.lo, range_arg.hi, range_arg.enabled};
+    // Cursors into the call's long MacaqueV streams, by host threads (before the context is taken: the other worker
+    // of a pipelined stream has it while this one walks).
+    std::vector<unsigned long long> index_piece_base;
+    std::vector<MvCursor> index_cursors;
+    mv_host_index(ins, n_ins, &index_piece_base, &index_cursors);
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
@@ -3855,6 +4115,7 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
     {
         GridPlan plan;
         rc = grid_plan(ctx, &dev->seg, range, &plan);
+        if (!rc) rc = mv_host_index_attach(ctx, dev->seg, index_piece_base, index_cursors, &plan.mv_index);
         const uint64_t total = plan.host_header.total_points;
         // The device staging area mirrors the host block (same gaps), so one copy moves it all.
         const uint64_t front = align_up(reserve_front, 4); // keeps the 16-byte store alignment

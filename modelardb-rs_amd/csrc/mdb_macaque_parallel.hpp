@@ -342,13 +342,16 @@ __device__ __forceinline__ MvSeg mv_describe(const DevSegments &s, uint64_t i, c
 __global__ __launch_bounds__(256) void k_mv_select(DevSegments s, TimeRange range,
                                                    const unsigned long long *__restrict__ offsets,
                                                    const uint32_t *__restrict__ serial_ids, uint64_t n_serial,
-                                                   uint32_t min_values, MvSeg *__restrict__ segs) {
+                                                   uint32_t min_values, MvSeg *__restrict__ segs,
+                                                   const unsigned long long *__restrict__ indexed_piece_base) {
     const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_serial) return;
     const uint32_t i = serial_ids[slot];
     SegInfo info = analyse_segment(s, i);
     if (range.enabled) apply_time_range(s, i, info, range);
-    segs[slot] = mv_describe(s, i, info, min_values, offsets[i]);
+    // (a segment the call's cursor index has pieces for is k_grid_mv_pieces': never long enough for this decoder)
+    const bool indexed = indexed_piece_base != nullptr && indexed_piece_base[i + 1] > indexed_piece_base[i];
+    segs[slot] = mv_describe(s, i, info, indexed ? 0xffffffffu : min_values, offsets[i]);
 }
 
 #ifdef MDB_MV_DEBUG

@@ -13,9 +13,9 @@ import modelardb_rs_amd as mdb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane", "ts-general", "ts-no-jumps"],
+@pytest.fixture(autouse=True, params=[None, "1024", "8", "ts-one-lane", "ts-general", "ts-no-jumps", "host-cursors"],
                 ids=["mv-default", "mv-from-1024-values", "mv-from-8-values", "timestamps-one-lane-per-segment",
-                     "timestamps-general-kernel-only", "timestamps-no-jump-lists"])
+                     "timestamps-general-kernel-only", "timestamps-no-jump-lists", "mv-cursors-by-host-threads"])
 def macaque_decoder(request, monkeypatch):
     """Every grid test runs with the parallel MacaqueV decoder (mdb_macaque_parallel.hpp) at its
     default threshold, switched off (one lane per stream only) and forced onto every stream of at
@@ -23,13 +23,21 @@ def macaque_decoder(request, monkeypatch):
     (k_grid_timestamps, the default: its sparse flavour first where the batch has few points per piece, or
     the general one alone) and one lane per segment (k_grid_serial); and without the jump lists that let
     k_grid_tiles write the timestamps of a fixed rate with the odd gap (and with the streams counted in the
-    order of their segments instead of by length)."""
+    order of their segments instead of by length); and with cursors into the MacaqueV streams left by the
+    call's host threads (mv_host_index)."""
     monkeypatch.delenv("MDB_GRID_TS_PIECES", raising=False)
     monkeypatch.delenv("MDB_GRID_TS_SPARSE", raising=False)
     monkeypatch.delenv("MDB_GRID_TS_JUMPS", raising=False)
     monkeypatch.delenv("MDB_GRID_TS_SORT", raising=False)
+    monkeypatch.delenv("MDB_GRID_MV_HOST_MIN_VALUES", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+    elif request.param == "host-cursors":
+        # A call over host batches has its host threads walk the MacaqueV streams of segments with regular timestamps
+        # (by default the long ones, here all of them) and decodes those piece by piece from the cursors they leave;
+        # the parallel decoder from 8 values on for what is left.
+        monkeypatch.setenv("MDB_GRID_MV_HOST_MIN_VALUES", "1")
+        monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", "8")
     elif request.param == "ts-one-lane":
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
         monkeypatch.setenv("MDB_GRID_TS_PIECES", "off")
@@ -183,7 +191,7 @@ def test_grid_full_size_properties(hip):
     assert (relative <= np.float32(1.0)).all()
 
 
-def test_config1_one_series_one_million_points_lossless(hip):
+def test_config1_one_series_one_million_points_lossless(hip, monkeypatch):
     # BASELINE configs[0]: 1 univariate series, 1M regular-timestamp f32 points, lossless,
     # compress + grid. Chunked like the reference server (65 536 point buffers).
     import datagen
@@ -199,16 +207,22 @@ def test_config1_one_series_one_million_points_lossless(hip):
     assert np.array_equal(ts, timestamps)
     assert np.array_equal(reconstructed.view(np.uint32), values.view(np.uint32))  # lossless
     assert metrics["rows_created_by_macaque_v"] == n
-    # 16 streams of 65 536 values: the parallel MacaqueV decoder takes them unless it is switched off
-    # (k_mv_decode ran and decoded them: the one-lane decoder then has nothing left and the values
-    # above came from it).
-    hip.profile_enable(True)
-    hip.profile_reset()
-    again = hip.grid_batch(segments)
-    kernels = hip.profile()
-    hip.profile_enable(False)
-    assert np.array_equal(again[1].view(np.uint32), values.view(np.uint32))
-    assert "k_mv_decode" in kernels and "k_mv_walk" in kernels
+    # 16 streams of 65 536 values from the host: the call's host threads walk them and leave cursors, every piece
+    # of 64 values is then decoded by a lane of its own (k_grid_mv_pieces); without that index
+    # (MDB_GRID_MV_INDEX=0) the parallel MacaqueV decoder takes them unless it is switched off (k_mv_decode
+    # ran and decoded them: the one-lane decoder then has nothing left and the values came from it).
+    for index in ("on", "off"):
+        if index == "off":
+            monkeypatch.setenv("MDB_GRID_MV_INDEX", "0")
+        hip.profile_enable(True)
+        hip.profile_reset()
+        again = hip.grid_batch(segments)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        assert np.array_equal(again[1].view(np.uint32), values.view(np.uint32))
+        assert ("k_grid_mv_pieces" in kernels) == (index == "on")
+        assert "k_mv_decode" in kernels and "k_mv_walk" in kernels
+    monkeypatch.delenv("MDB_GRID_MV_INDEX")
     mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
     state, reference = hip.agg_batch(segments, mask), ora.agg_batch(segments, mask)
     assert (state.count, state.min, state.max) == (n, values.min(), values.max())
@@ -216,11 +230,13 @@ def test_config1_one_series_one_million_points_lossless(hip):
 
 
 @pytest.mark.parametrize("streams", [40, 130])
-def test_many_long_lossless_streams(hip, streams, macaque_decoder):
+def test_many_long_lossless_streams(hip, streams, macaque_decoder, monkeypatch):
     # The parallel MacaqueV decoder stages half (above 12 288 pieces of 4 096 bits) or a quarter (above
     # 49 152) of each piece in LDS instead of all of it; 40 and 130 streams of 65 536 values are 15 600
-    # and 50 700 pieces. Still bit for bit what one lane per stream produces.
+    # and 50 700 pieces. Still bit for bit what one lane per stream produces. (Without the cursors of the call's
+    # host threads, which would take such streams away from it.)
     import datagen
+    monkeypatch.setenv("MDB_GRID_MV_INDEX", "0")
     n = 65536
     distinct = [datagen.sine_series(100 + k, n)[1] for k in range(5)]
     values = np.concatenate([distinct[k % 5] for k in range(streams)])
@@ -936,7 +952,7 @@ def _short_simple_segments(rng, n, longest=20):
 
 
 @pytest.mark.parametrize("fused", ["auto", "forced", "off"])
-def test_short_simple_segments_in_one_pass(hip, fused, monkeypatch):
+def test_short_simple_segments_in_one_pass(hip, fused, monkeypatch, macaque_decoder):
     # k_grid_fused: a batch of short PMC-Mean / Swing segments with regular timestamps is reconstructed from the
     # raw rows in one pass (workgroups of 256 segments, their place in the output from a look-back over the
     # workgroups in front), the same points as the prepass / offsets / tiles pipeline writes.
@@ -985,7 +1001,10 @@ def test_short_simple_segments_in_one_pass(hip, fused, monkeypatch):
         kernels = hip.profile()
         hip.profile_enable(False)
         assert ("k_grid_fused" in kernels) == (fused != "off") and ("k_grid_tiles" in kernels) == (fused == "off")
-        assert ("k_grid_mv_pieces" in kernels) == (resident is not None) and ("k_grid_serial" in kernels) == (resident is None)
+        # (the MacaqueV model's 40 values: by pieces from a resident batch's cursors - or, in the one mode of this
+        # file that asks for them from a single value on, from the cursors the call's host threads leave)
+        by_pieces = resident is not None or macaque_decoder == "host-cursors"
+        assert ("k_grid_mv_pieces" in kernels) == by_pieces and ("k_grid_serial" in kernels) == (resident is None)
         cases.assert_grid_equal(got, expected)
         if resident is not None:
             resident.free()
