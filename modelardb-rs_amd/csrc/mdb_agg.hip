@@ -96,7 +96,10 @@ __device__ __forceinline__ AggPartial empty_partial() {
 // values the batch's cursor index let k_agg_mv_pieces decode piece by piece: 2 i the model's, 2 i + 1 the tail's.
 __device__ __forceinline__ float segment_sum(const DevSegments &s, uint64_t i, const SegInfo &info,
                                              uint32_t length, uint32_t *error, const double *walked_sums = nullptr,
-                                             const float *stream_sums = nullptr) {
+                                             const float *stream_sums = nullptr,
+                                             const unsigned long long *only_with_pieces = nullptr) {
+    // (only_with_pieces: the index behind stream_sums is one call's, of the long streams: piece_base of the segments)
+    if (stream_sums && only_with_pieces && only_with_pieces[i + 1] == only_with_pieces[i]) stream_sums = nullptr;
     const SegDesc &d = info.desc;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     const uint32_t n_res = d.n_total - d.n_model;
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
                                                               const uint32_t *__restrict__ walked_totals,
                                                               const double *__restrict__ walked_sums,
                                                               const unsigned int *__restrict__ walked_error,
-                                                              const float *__restrict__ stream_sums) {
+                                                              const float *__restrict__ stream_sums,
+                                                              const unsigned long long *__restrict__ only_with_pieces) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
     if (walked_error && blockIdx.x == 0 && threadIdx.x == 0) p.error |= *walked_error;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_segments(DevSegments s, uin
                 p.deferred_values += length;
                 p.deferred_bytes += s.values.views[i].x;
             } else if (!error) {
-                p.sum += (double)segment_sum(s, i, info, length, &error, walked_sums, stream_sums);
+                p.sum += (double)segment_sum(s, i, info, length, &error, walked_sums, stream_sums, only_with_pieces);
             }
         }
         p.error |= error;
@@ -503,11 +507,12 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                            t_hi, AGG_SUM_DEFER, mv_min_values, partials, walked_totals, walked_ranges, walked_error);
     } else {
         const float *stream_sums = nullptr;
-        if (sums_wanted && mv_index_stream_sums(ctx, in, s, walked_totals, &stream_sums)) return 1;
+        const unsigned long long *only_with_pieces = nullptr;
+        if (sums_wanted && mv_index_stream_sums(ctx, in, s, walked_totals, &stream_sums, &only_with_pieces)) return 1;
         LaunchTimer timer(ctx, "k_agg_segments");
         hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
                            which_mask, sums_wanted && !stream_sums ? AGG_SUM_DEFER : AGG_SUM_ALL, mv_min_values, partials,
-                           walked_totals, walked_sums, walked_error, stream_sums);
+                           walked_totals, walked_sums, walked_error, stream_sums, only_with_pieces);
     }
     {
         LaunchTimer timer(ctx, "k_agg_finish");
@@ -540,7 +545,8 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
                                    which_mask, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials,
                                    static_cast<const uint32_t *>(nullptr), static_cast<const double *>(nullptr),
-                                   static_cast<const unsigned int *>(nullptr), static_cast<const float *>(nullptr));
+                                   static_cast<const unsigned int *>(nullptr), static_cast<const float *>(nullptr),
+                                   static_cast<const unsigned long long *>(nullptr));
             }
             {
                 LaunchTimer timer(ctx, "k_agg_finish");
@@ -599,11 +605,17 @@ int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, 
 
 int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    // SUM decodes every value of a MacaqueV stream: the long ones piece by piece from cursors that host threads
+    // leave while the batch is on its way (mdb_grid.hip, mv_host_index).
+    MvCallIndex index;
+    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) mv_call_index_build(in, &index);
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
-    int rc = agg_run(ctx, &dev->seg, false, 0, 0, which_mask, inout);
+    int rc = mv_call_index_use(ctx, dev->seg, index);
+    if (!rc) rc = agg_run(ctx, &dev->seg, false, 0, 0, which_mask, inout);
+    mv_call_index_done();
     mdb_segments_free(dev);
     return rc;
 }

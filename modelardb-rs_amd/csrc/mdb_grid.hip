@@ -1168,21 +1168,7 @@ __device__ __forceinline__ uint32_t ring_decode_value(RingBitReader &reader, Mac
 // grid() seeds such a segment's residual tail with (the reference's compressor never makes one, a foreign batch
 // may), and the walk leaves it in the tail's cursors (chain_seed).
 
-constexpr uint32_t MV_PIECE_VALUES = 64;
-constexpr uint32_t MV_WINDOW_RESIDUAL = 1u << 16; // the piece belongs to the residual tail
-constexpr uint32_t MV_WINDOW_RAW = 1u << 17;      // its first value is the stream's raw first value
-
-struct MvCursor { // 32 bytes
-    uint32_t bit_position; // of the piece's first code in its stream
-    uint32_t xor_bits;     // XOR of all deltas of the chain before it
-    uint32_t segment;
-    uint32_t point_index;  // of the piece's first value among the segment's data points
-    uint32_t n_values;     // 1..64
-    uint32_t window;       // leading | trailing << 8 | MV_WINDOW_*
-    uint32_t chain_seed;   // residual tail of a MacaqueV segment: the bits of its last model value (else 0)
-    uint32_t pad;
-};
-static_assert(sizeof(MvCursor) == 32, "cursors are loaded as two uint4");
+// (MvCursor, MV_PIECE_VALUES, MV_WINDOW_*: mdb_common.hpp)
 
 // Values of the two streams of segment i: the model's (MacaqueV segments only) and the residual tail's.
 __device__ __forceinline__ void mv_stream_lengths(const DevSegments &s, uint64_t i, const uint32_t *known_totals,
@@ -2787,16 +2773,20 @@ int mv_index_prepare(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvInd
 // For mdb_agg.hip: the f32 sums of all MacaqueV streams of a batch that has a cursor index (see k_agg_mv_pieces);
 // *stream_sums stays nullptr when it has none. known_totals: of the caller's own counting walk (may be nullptr).
 int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, const uint32_t *known_totals,
-                         const float **stream_sums) {
+                         const float **stream_sums, const unsigned long long **only_with_pieces) {
     *stream_sums = nullptr;
+    *only_with_pieces = nullptr;
     const char *setting = std::getenv("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return 0;
-    std::shared_ptr<MvIndex> index = owned_segments_index(in);
+    const bool of_this_call = t_call_index && t_call_index_views == in->values.views;
+    std::shared_ptr<MvIndex> index = of_this_call ? t_call_index : owned_segments_index(in);
     if (!index) return 0;
     {
         std::lock_guard<std::mutex> lock(index->mutex);
         if (!index->built || !index->usable) return 0; // (built by the first grid call, or by agg_run before its own walk)
     }
+    // (the index of one call covers its long streams only: the sums of a segment without pieces are nobody's)
+    if (index->of_one_call) *only_with_pieces = static_cast<const unsigned long long *>(index->piece_base);
     void *p = nullptr;
     if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 8 + 256, &p)) return 1;
     uint32_t *values = static_cast<uint32_t *>(p);
@@ -4091,6 +4081,20 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
 }
 
 } // namespace
+
+// For mdb_agg.hip: the same around an aggregate call over one host batch.
+void mdb::mv_call_index_build(const mdb_segments *in, MvCallIndex *out) {
+    mv_host_index(&in, 1, &out->piece_base, &out->cursors);
+}
+int mdb::mv_call_index_use(mdb_ctx *ctx, const mdb_segments &uploaded, const MvCallIndex &index) {
+    if (mv_host_index_attach(ctx, uploaded, index.piece_base, index.cursors, &t_call_index)) return 1;
+    t_call_index_views = uploaded.values.views;
+    return 0;
+}
+void mdb::mv_call_index_done() {
+    t_call_index.reset();
+    t_call_index_views = nullptr;
+}
 
 // One or several host batches (rows in the order of the list) reconstructed by one launch into a page-locked
 // block of the device's pool: the body of mdb_grid_batch_owned and of the jobs behind mdb_grid_submit.

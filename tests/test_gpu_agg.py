@@ -18,8 +18,9 @@ ALL = MDB_AGG_COUNT | MDB_AGG_MIN | MDB_AGG_MAX | MDB_AGG_SUM
 SUM_TOLERANCE = 1e-5  # 0.001 %
 
 
-@pytest.fixture(autouse=True, params=[None, "off", "8", "no-walk"],
-                ids=["mv-default", "mv-off", "mv-from-8-values", "timestamps-every-lane-for-itself"])
+@pytest.fixture(autouse=True, params=[None, "off", "8", "no-walk", "host-cursors"],
+                ids=["mv-default", "mv-off", "mv-from-8-values", "timestamps-every-lane-for-itself",
+                     "mv-cursors-by-host-threads"])
 def macaque_decoder(request, monkeypatch):
     """SUM leaves long MacaqueV streams to the parallel decoder (macaque_deferred_sum in mdb_grid.hip):
     every test runs with its default threshold, with it switched off and with every stream of at
@@ -27,8 +28,14 @@ def macaque_decoder(request, monkeypatch):
     wave-synchronous walk of their streams (k_grid_ts_count<SUMS>), or - the last mode - from every lane
     decoding its own stream."""
     monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
+    monkeypatch.delenv("MDB_GRID_MV_HOST_MIN_VALUES", raising=False)
     if request.param is None:
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+    elif request.param == "host-cursors":
+        # SUM over a host batch: the call's host threads walk the MacaqueV streams of segments with regular timestamps
+        # (by default the long ones, here all) and the values are decoded piece by piece from their cursors.
+        monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
+        monkeypatch.setenv("MDB_GRID_MV_HOST_MIN_VALUES", "1")
     elif request.param == "no-walk":
         monkeypatch.delenv("MDB_GRID_MV_MIN_VALUES", raising=False)
         monkeypatch.setenv("MDB_AGG_TS_WALK", "0")
@@ -110,13 +117,22 @@ def test_sum_of_long_lossless_streams(hip, macaque_decoder, monkeypatch):
     offsets[-1] = n
     segments = hip.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
     assert set(segments.model_type_id.tolist()) == {2}
-    hip.profile_enable(True)
-    hip.profile_reset()
-    state = hip.agg_batch(segments, ALL)
-    kernels = hip.profile()
-    hip.profile_enable(False)
-    assert ("k_mv_sums" in kernels) == (macaque_decoder != "off")
-    _assert_state(state, ora.agg_batch(segments, ALL))
+    # (with the cursors of the call's host threads the values come from the piece decoder and one lane adds a stream
+    # up; without them - MDB_GRID_MV_INDEX=0 - from the parallel decoder unless that is switched off)
+    for index in ("on", "off"):
+        if index == "off":
+            monkeypatch.setenv("MDB_GRID_MV_INDEX", "0")
+        hip.profile_enable(True)
+        hip.profile_reset()
+        state = hip.agg_batch(segments, ALL)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        if index == "on":
+            assert "k_agg_mv_chains" in kernels and "k_mv_sums" not in kernels
+        else:
+            assert ("k_mv_sums" in kernels) == (macaque_decoder != "off")
+        _assert_state(state, ora.agg_batch(segments, ALL))
+    monkeypatch.delenv("MDB_GRID_MV_INDEX")
     per_stream = 0.0
     for k in range(len(offsets) - 1):
         per_stream += float(np.add.accumulate(values[int(offsets[k]):int(offsets[k + 1])], dtype=np.float32)[-1])
