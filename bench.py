@@ -267,6 +267,12 @@ def host_path(context, mdb, np, sample, args):
         del os.environ["MDB_HOST_GRID_COALESCE_SEGMENTS"]
     out["batch_8192_one_input_batch_per_submit"] = {"values_per_s": points / seconds,
                                                     "GB_per_s_pcie": bytes_down / seconds / 1e9}
+    # SUM through the patched accumulator (rust/patches/0002-model_simple_aggregates.patch): one mdb_agg_batch per
+    # 8 192-row batch, as DataFusion hands them to update_batch.
+    host.measure_accumulator(context, sample, host.ModelSumAccumulator)
+    state, seconds = host.measure_accumulator(context, sample, host.ModelSumAccumulator)
+    out["sum_accumulator_batch_8192"] = {"segments_per_s": len(sample) / seconds, "values_per_s": points / seconds,
+                                         "seconds": seconds, "calls": (len(sample) + 8191) // 8192, "sum": state[0]}
     return out
 
 
@@ -482,6 +488,8 @@ def mixed_models(context, mdb, np, ora, args):
                 shape["segment_mix"] = result[1]
             elif result.count != total:
                 raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: COUNT {result.count} of {total} points")
+            else:
+                resident_sum = result.sum
         # the first two series (without and with noise) against the oracle: segments byte for byte, points bit for bit
         downloaded = segments.download()
         for s in range(2):
@@ -506,6 +514,14 @@ def mixed_models(context, mdb, np, ora, args):
             host_points, host_seconds, host_bytes = host.measure_grid_stream(context, downloaded, 8192)
             shape["host_path"] = {"values_per_s": host_points / host_seconds, "GB_per_s_pcie": host_bytes / host_seconds / 1e9,
                                   "seconds": host_seconds, "segments": len(downloaded)}
+            # SUM through the patched accumulator (rust/patches/0002): one mdb_agg_batch per 8 192-row batch.
+            host.measure_accumulator(context, downloaded, host.ModelSumAccumulator)
+            state, sum_seconds = host.measure_accumulator(context, downloaded, host.ModelSumAccumulator)
+            if abs(state[0] - resident_sum) > 1e-9 * abs(resident_sum):
+                raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: SUM through the accumulator {state[0]!r}, "
+                                 f"of the resident segments {resident_sum!r}")
+            shape["host_path"]["sum_accumulator"] = {"values_per_s": total / sum_seconds, "segments_per_s": len(downloaded) / sum_seconds,
+                                                     "seconds": sum_seconds, "sum": state[0]}
         del downloaded
         out[label] = shape
         for pointer in (out_ts, out_val):

@@ -301,6 +301,22 @@ class _ModelAccumulator:
             pass
 
 
+def measure_accumulator(context, segments, accumulator_class, segments_per_batch=8192):
+    """One of the five accumulators fed `segments` (a SegmentBatch in host memory) `segments_per_batch` rows at a
+    time - the batches DataFusion hands update_batch, one mdb_agg_batch each as rust/patches/0002 makes it - for
+    bench.py. Returns (state, seconds)."""
+    import time
+    arrow = segments.to_arrow()
+    batches = [arrow.slice(first, min(segments_per_batch, arrow.num_rows - first))
+               for first in range(0, arrow.num_rows, segments_per_batch)]
+    accumulator = accumulator_class(context)
+    started = time.perf_counter()
+    for batch in batches:
+        accumulator.update_batch(batch)
+    seconds = time.perf_counter() - started
+    return accumulator.state(), seconds
+
+
 class ModelCountAccumulator(_ModelAccumulator):
     KIND = 0
 

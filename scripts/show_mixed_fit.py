@@ -7,3 +7,4 @@ for k in ("lossless","relative_1_percent"):
     h=d["mixed_models"][k].get("host_path")
     if h: print(k, "host path", h)
     g=d["mixed_models"][k]["grid"]; print(k, "grid ms", round(g["ms"],2), g["kernels_ms"])
+print("sum accumulator (swing sample)", d.get("host_path",{}).get("sum_accumulator_batch_8192"))
