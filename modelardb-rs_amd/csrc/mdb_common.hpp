@@ -161,33 +161,6 @@ struct LaunchTimer {
 // deltas so far - so that every piece is decoded by a lane of its own. Not an Arrow column: it belongs to the
 // mdb_segments_owned the library made (mdb_segments_upload, mdb_compress_chunks_dev), is built by the first
 // grid / aggregate call that could use it and dies with the batch.
-constexpr uint32_t MV_PIECE_VALUES = 64;
-constexpr uint32_t MV_WINDOW_RESIDUAL = 1u << 16; // the piece belongs to the residual tail
-constexpr uint32_t MV_WINDOW_RAW = 1u << 17;      // its first value is the stream's raw first value
-
-struct MvCursor { // 32 bytes
-    uint32_t bit_position; // of the piece's first code in its stream
-    uint32_t xor_bits;     // XOR of all deltas of the chain before it
-    uint32_t segment;
-    uint32_t point_index;  // of the piece's first value among the segment's data points
-    uint32_t n_values;     // 1..64
-    uint32_t window;       // leading | trailing << 8 | MV_WINDOW_*
-    uint32_t chain_seed;   // residual tail of a MacaqueV segment: the bits of its last model value (else 0)
-    uint32_t pad;
-};
-static_assert(sizeof(MvCursor) == 32, "cursors are loaded as two uint4");
-
-// The cursors the host threads of ONE call leave in the long MacaqueV streams of a host batch (mdb_grid.hip,
-// mv_host_index): built before the batch is uploaded, used (uploaded, found by the kernels' launchers through the
-// calling thread) around the call, done after it.
-struct MvCallIndex {
-    std::vector<unsigned long long> piece_base;
-    std::vector<MvCursor> cursors;
-};
-void mv_call_index_build(const mdb_segments *in, MvCallIndex *out);
-int mv_call_index_use(mdb_ctx *ctx, const mdb_segments &uploaded, const MvCallIndex &index);
-void mv_call_index_done();
-
 struct MvIndex {
     std::mutex mutex;      // building
     bool built = false;

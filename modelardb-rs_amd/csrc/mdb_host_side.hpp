@@ -67,6 +67,36 @@ int host_block_take(uint64_t bytes, void **out, uint64_t *capacity);
 void host_block_give(void *block, uint64_t capacity);
 void host_parallel(unsigned n_shares, void (*share)(unsigned index, void *arg), void *arg);
 unsigned host_parallel_width();
+constexpr uint32_t MV_PIECE_VALUES = 64;
+constexpr uint32_t MV_WINDOW_RESIDUAL = 1u << 16; // the piece belongs to the residual tail
+constexpr uint32_t MV_WINDOW_RAW = 1u << 17;      // its first value is the stream's raw first value
+
+struct MvCursor { // 32 bytes
+    uint32_t bit_position; // of the piece's first code in its stream
+    uint32_t xor_bits;     // XOR of all deltas of the chain before it
+    uint32_t segment;
+    uint32_t point_index;  // of the piece's first value among the segment's data points
+    uint32_t n_values;     // 1..64
+    uint32_t window;       // leading | trailing << 8 | MV_WINDOW_*
+    uint32_t chain_seed;   // residual tail of a MacaqueV segment: the bits of its last model value (else 0)
+    uint32_t pad;
+};
+static_assert(sizeof(MvCursor) == 32, "cursors are loaded as two uint4");
+
+// The cursors the host threads of ONE call leave in the long MacaqueV streams of a host batch (mdb_grid.hip,
+// mv_host_index): built before the batch is uploaded, used (uploaded, found by the kernels' launchers through the
+// calling thread) around the call, done after it.
+struct MvCallIndex {
+    std::vector<unsigned long long> piece_base;
+    std::vector<MvCursor> cursors;
+};
+// mdb_mv_host_index.cpp: piece_base (rows + 1) and cursors of the long MacaqueV streams of a list of host batches.
+void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
+                   std::vector<MvCursor> *cursors);
+void mv_call_index_build(const mdb_segments *in, MvCallIndex *out);
+int mv_call_index_use(mdb_ctx *ctx, const mdb_segments &uploaded, const MvCallIndex &index);
+void mv_call_index_done();
+
 void pipeline_close(mdb_ctx *ctx);
 int profile_collect(mdb_ctx *ctx);
 
