@@ -220,8 +220,12 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 // The three 32-bit payload words of a BinaryView are [1..3] of the 16-byte view loaded as uint4.
 __device__ __forceinline__ uint32_t view_inline_byte(const uint4 &view, uint32_t k) {
-    uint32_t word = (k < 4) ? view.y : ((k < 8) ? view.z : view.w);
-    return (word >> (8u * (k & 3u))) & 0xffu;
+    // (two shifts and a select: a chain of selects between the three words is turned into an array in scratch
+    // memory indexed by k / 4 - a store of the view and a dependent load per call, with a wait for EVERY load in flight)
+    const uint64_t low = ((uint64_t)view.z << 32) | (uint64_t)view.y; // bytes 0..7
+    const uint32_t from_low = (uint32_t)(low >> (8u * (k & 7u)));
+    const uint32_t from_high = view.w >> (8u * (k & 3u));             // bytes 8..11
+    return (k < 8 ? from_low : from_high) & 0xffu;
 }
 
 // A pointer the compiler has lost track of - read from the table of data buffers, or put together from

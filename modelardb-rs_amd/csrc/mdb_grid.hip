@@ -730,7 +730,7 @@ __device__ __forceinline__ uint32_t regular_segment_points(const DevSegments &s,
 // desc / offsets / serial_ids: written for the segments with serial work only (MacaqueV values, residual tails),
 // which the kernels behind this one decode (k_grid_mv_pieces or k_grid_serial); header->n_serial counts them.
 template <int FUSED_ROUNDS>
-__global__ __launch_bounds__(FUSED_THREADS) void k_grid_fused(DevSegments s, unsigned long long *__restrict__ lookback,
+__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(7))) void k_grid_fused(DevSegments s, unsigned long long *__restrict__ lookback,
                                                               GridHeader *__restrict__ header, int64_t *__restrict__ out_ts,
                                                               float *__restrict__ out_val, uint32_t *__restrict__ rows_per_segment,
                                                               uint64_t cap, TileDesc *__restrict__ desc,
@@ -749,18 +749,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_grid_fused(DevSegments s, uns
     const uint64_t block_first = (uint64_t)blockIdx.x * FUSED_SEGMENTS;
 
     // ---- how many points the workgroup's segments have, and where they begin in the output ---------------------
-    uint32_t counts[FUSED_ROUNDS];
+    // (the counts are worked out again in the rounds below: kept here they would be an array indexed by the round,
+    // which lives in scratch memory - a store and a load per segment)
     uint64_t mine_total = 0;
     bool irregular = false;
 #pragma unroll
     for (int k = 0; k < FUSED_ROUNDS; k++) {
         const uint64_t i = block_first + (uint64_t)k * FUSED_THREADS + threadIdx.x;
-        counts[k] = 0;
         if (i < s.n) {
-            if (segment_has_regular_timestamps(s, i)) counts[k] = regular_segment_points(s, i);
+            if (segment_has_regular_timestamps(s, i)) mine_total += regular_segment_points(s, i);
             else irregular = true;
         }
-        mine_total += counts[k];
     }
     if (irregular) header->pad = 1u; // (a delta-of-delta stream: the general pipeline takes the batch)
     uint64_t total;
@@ -812,11 +811,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_grid_fused(DevSegments s, uns
         if (round_first >= s.n) break;
         const uint64_t i = round_first + threadIdx.x;
         const uint32_t n_in_round = (uint32_t)min((uint64_t)FUSED_THREADS, s.n - round_first);
-        const uint32_t count = counts[k];
+        uint32_t count = 0;
         TileDesc mine = TileDesc{};
         uint32_t error = 0;
         bool serial = false;
         if (i < s.n && segment_has_regular_timestamps(s, i)) {
+            count = regular_segment_points(s, i);
             const SegInfo info = analyse_segment<ANALYSE_REGULAR>(s, i);
             error = info.error;
             mine = make_tile_desc(info.desc);
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_grid_fused(DevSegments s, uns
                         }
                     } else {
                         unsigned long long next_offset = segment_offset + d.n_points;
-#pragma unroll 1
+#pragma unroll
                         for (uint32_t m = 0; m < 4; m++) {
                             const unsigned long long q = p + m;
                             if (q < base) continue;
@@ -1405,7 +1405,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
 // it starts AS the first value), [2 i + 1] = the sum of segment i's residual tail.
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const MvCursor *__restrict__ cursors,
                                                             unsigned long long n_pieces, uint32_t *__restrict__ values) {
-    constexpr int STRIDE = MV_PIECE_VALUES + 1; // (a row per lane: stride 65 words keeps the banks apart)
+    // (32 values per lane and round, as k_grid_mv_pieces: a row of 64 values per lane is 16.6 KB of LDS per wave,
+    // which leaves room for 2.4 waves per SIMD where the decoding needs the vector ALU busy)
+    constexpr int ROUND = 32, STRIDE = ROUND + 1; // (an odd stride keeps the banks apart)
     __shared__ uint32_t stage[MDB_WAVE * STRIDE];
     const int lane = threadIdx.x;
     const unsigned long long first_piece = (unsigned long long)blockIdx.x * MDB_WAVE;
@@ -1443,13 +1445,22 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
         state.trailing = (window >> 8) & 255u;
         state.raw = (window & MV_WINDOW_RAW) != 0;
     }
-    for (uint32_t k = 0; __any(k < to_decode); k++)
-        if (k < to_decode) stage[lane * STRIDE + k] = lean_decode_value(reader, state);
-    __builtin_amdgcn_wave_barrier();
     // The wave's 64 pieces are 16 KB in a row in `values` (what lies behind a stream's last value is not read).
     const unsigned long long rows = min((unsigned long long)MDB_WAVE, n_pieces > first_piece ? n_pieces - first_piece : 0ull);
-    for (unsigned long long r = 0; r < rows; r++)
-        values[(first_piece + r) * MV_PIECE_VALUES + lane] = stage[r * STRIDE + lane];
+    for (uint32_t done = 0; __any(done < to_decode); done += ROUND) {
+        const uint32_t mine = done < to_decode ? min(to_decode - done, (uint32_t)ROUND) : 0u;
+        for (uint32_t k = 0; __any(k < mine); k++)
+            if (k < mine) stage[lane * STRIDE + k] = lean_decode_value(reader, state);
+        __builtin_amdgcn_wave_barrier();
+        // (two rows of 32 values - two 128-byte lines - per store instruction)
+        const unsigned long long sub_row = (unsigned long long)(lane / ROUND);
+        const int column = lane % ROUND;
+        for (unsigned long long r0 = 0; r0 < rows; r0 += MDB_WAVE / ROUND) {
+            const unsigned long long r = r0 + sub_row;
+            if (r < rows) values[(first_piece + r) * MV_PIECE_VALUES + done + column] = stage[r * STRIDE + column];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint32_t *__restrict__ known_totals,
