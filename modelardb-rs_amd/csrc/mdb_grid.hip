@@ -1463,6 +1463,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
     }
 }
 
+template <int LOADS> // 16-byte loads a lane has in flight per round of a long stream: 8, 16 or 32
 __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint32_t *__restrict__ known_totals,
                                                        const unsigned long long *__restrict__ piece_base,
                                                        const uint32_t *__restrict__ values, float *__restrict__ stream_sums) {
@@ -1484,19 +1485,21 @@ __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint
         }
         // (up to the next multiple of 32, one value at a time)
         for (; k < n && (k & 31u) != 0; k++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + k));
-        // (a lane's trip to memory is what a round costs, not its additions: 32 loads in flight while the stream is
+        // (a lane's trip to memory is what a round costs, not its additions: LOADS loads in flight while the stream is
         // long. Tried: the next round's loads under way during the additions, 2.6 -> 3.0 ms on the mixed series; the
         // wave fetching whole lines together through LDS, 2.6 -> 5.1 ms)
-        for (; k + 128 <= n; k += 128) {
-            uint4 v[32];
+        if (LOADS > 8) {
+            for (; k + 4 * LOADS <= n; k += 4 * LOADS) {
+                uint4 v[LOADS];
 #pragma unroll
-            for (int q = 0; q < 32; q++) v[q] = load_global(from + (k >> 2) + q);
+                for (int q = 0; q < LOADS; q++) v[q] = load_global(from + (k >> 2) + q);
 #pragma unroll
-            for (int q = 0; q < 32; q++) {
-                sum += __uint_as_float(v[q].x);
-                sum += __uint_as_float(v[q].y);
-                sum += __uint_as_float(v[q].z);
-                sum += __uint_as_float(v[q].w);
+                for (int q = 0; q < LOADS; q++) {
+                    sum += __uint_as_float(v[q].x);
+                    sum += __uint_as_float(v[q].y);
+                    sum += __uint_as_float(v[q].z);
+                    sum += __uint_as_float(v[q].w);
+                }
             }
         }
         for (; k + 32 <= n; k += 32) {
@@ -2824,8 +2827,18 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
     }
     {
         LaunchTimer timer(ctx, "k_agg_mv_chains");
-        hipLaunchKernelGGL(k_agg_mv_chains, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
-                           static_cast<const unsigned long long *>(index->piece_base), values, sums);
+        // 16-byte loads in flight per lane: many while the batch has few streams (16 streams of 65 536 values: 0.82 / 0.51 /
+        // 0.43 ms with 8 / 16 / 32), few when every lane of every wave has one (100 000 streams of 50 000 values: 4.2 / 4.7 /
+        // 5.7 ms). MDB_AGG_CHAIN_LOADS: A/B.
+        const char *text = std::getenv("MDB_AGG_CHAIN_LOADS");
+        const int loads = text ? std::atoi(text) : (in->n <= 512 ? 32 : 8);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums);
+        };
+        if (loads == 32) launch(k_agg_mv_chains<32>);
+        else if (loads == 16) launch(k_agg_mv_chains<16>);
+        else launch(k_agg_mv_chains<8>);
     }
     *stream_sums = sums;
     return 0;
