@@ -267,12 +267,14 @@ def host_path(context, mdb, np, sample, args):
         del os.environ["MDB_HOST_GRID_COALESCE_SEGMENTS"]
     out["batch_8192_one_input_batch_per_submit"] = {"values_per_s": points / seconds,
                                                     "GB_per_s_pcie": bytes_down / seconds / 1e9}
-    # SUM through the patched accumulator (rust/patches/0002-model_simple_aggregates.patch): one mdb_agg_batch per
-    # 8 192-row batch, as DataFusion hands them to update_batch.
+    # SUM through the patched accumulator (rust/patches/0002-model_simple_aggregates.patch): update_batch is handed
+    # 8 192-row batches as by DataFusion and keeps them until 262 144 segments are pending or the state is read, then
+    # ONE mdb_agg_batch_list.
     host.measure_accumulator(context, sample, host.ModelSumAccumulator)
     state, seconds = host.measure_accumulator(context, sample, host.ModelSumAccumulator)
     out["sum_accumulator_batch_8192"] = {"segments_per_s": len(sample) / seconds, "values_per_s": points / seconds,
-                                         "seconds": seconds, "calls": (len(sample) + 8191) // 8192, "sum": state[0]}
+                                         "seconds": seconds, "update_batch_calls": (len(sample) + 8191) // 8192,
+                                         "library_calls": (len(sample) + 262143) // 262144, "sum": state[0]}
     return out
 
 
@@ -514,7 +516,7 @@ def mixed_models(context, mdb, np, ora, args):
             host_points, host_seconds, host_bytes = host.measure_grid_stream(context, downloaded, 8192)
             shape["host_path"] = {"values_per_s": host_points / host_seconds, "GB_per_s_pcie": host_bytes / host_seconds / 1e9,
                                   "seconds": host_seconds, "segments": len(downloaded)}
-            # SUM through the patched accumulator (rust/patches/0002): one mdb_agg_batch per 8 192-row batch.
+            # SUM through the patched accumulator (rust/patches/0002): 8 192-row batches gathered into mdb_agg_batch_list.
             host.measure_accumulator(context, downloaded, host.ModelSumAccumulator)
             state, sum_seconds = host.measure_accumulator(context, downloaded, host.ModelSumAccumulator)
             if abs(state[0] - resident_sum) > 1e-9 * abs(resident_sum):

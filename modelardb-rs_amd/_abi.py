@@ -194,6 +194,8 @@ _HIP_SYMBOLS = {
                                 C.POINTER(AggStateC)]),
     "mdb_agg_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_uint32,
                                     C.POINTER(AggStateC)]),
+    "mdb_agg_batch_list": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(SegmentsC)), C.c_uint32, C.c_uint32,
+                                     C.POINTER(AggStateC)]),
     "mdb_agg_batch_range": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,
                                       C.c_uint32, C.POINTER(AggStateC)]),
     "mdb_agg_batch_range_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,

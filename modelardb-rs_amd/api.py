@@ -372,6 +372,15 @@ class Context:
         self._check(self.lib.mdb_agg_batch(self.handle, C.byref(seg), which_mask, C.byref(state)))
         return state
 
+    def agg_batch_list(self, batches, which_mask, state=None):
+        """Several host batches folded as one (mdb_agg_batch_list): what an accumulator that has gathered the batches
+        of a run of update_batch calls passes."""
+        views = [batch.as_c() for batch in batches]
+        pointers = (C.POINTER(_abi.SegmentsC) * len(views))(*[C.pointer(view) for view in views])
+        state = state or _abi.AggStateC.fresh()
+        self._check(self.lib.mdb_agg_batch_list(self.handle, pointers, len(views), which_mask, C.byref(state)))
+        return state
+
     def agg_batch_range(self, batch, t_lo, t_hi, which_mask, state=None):
         seg = batch.as_c()
         state = state or _abi.AggStateC.fresh()

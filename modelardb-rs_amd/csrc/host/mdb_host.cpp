@@ -811,17 +811,37 @@ PollState SortedJoinStream::poll_next(RecordBatch *out) {
 
 namespace {
 
+// Segments an accumulator collects before they are folded into its state with one call: DataFusion hands update_batch
+// 8 192 at a time, a call costs the same for 8 192 and for 262 144 (rust/patches/0002: PENDING_SEGMENTS_PER_CALL).
+constexpr size_t PENDING_SEGMENTS_PER_CALL = 262144;
+
 class ModelAccumulator : public Accumulator {
   public:
     ModelAccumulator(mdb_ctx *ctx, uint32_t mask) : ctx_(ctx), mask_(mask) { reset(); }
+    // (PendingSegments::push of the patched accumulators: the columns are kept, not copied, until enough segments are
+    // pending or the state is read - nobody can observe it in between)
     void update_batch(const std::vector<ColumnPtr> &arrays) override {
-        SegmentsView view;
-        fill_segments_view(arrays, &view);
-        check(mdb_agg_batch(ctx_, &view.seg, mask_, &state_));
+        pending_segments_ += arrays.empty() ? 0 : static_cast<size_t>(arrays[0]->length);
+        pending_.push_back(arrays);
+        if (pending_segments_ >= PENDING_SEGMENTS_PER_CALL) fold_pending();
     }
-    size_t size() const override { return sizeof(*this); }
+    size_t size() const override { return sizeof(*this) + pending_segments_ * 73; }
 
   protected:
+    // PendingSegments::fold_into: ALL pending batches through one mdb_agg_batch_list.
+    void fold_pending() {
+        if (pending_.empty()) return;
+        std::vector<SegmentsView> views(pending_.size());
+        std::vector<const mdb_segments *> inputs(pending_.size());
+        for (size_t k = 0; k < pending_.size(); k++) {
+            fill_segments_view(pending_[k], &views[k]);
+            inputs[k] = &views[k].seg;
+        }
+        const int code = mdb_agg_batch_list(ctx_, inputs.data(), static_cast<uint32_t>(inputs.size()), mask_, &state_);
+        pending_.clear();
+        pending_segments_ = 0;
+        check(code);
+    }
     void reset() {
         state_.sum = 0.0;
         state_.count = 0;
@@ -831,11 +851,14 @@ class ModelAccumulator : public Accumulator {
     mdb_ctx *ctx_;
     uint32_t mask_;
     mdb_agg_state state_;
+    std::vector<std::vector<ColumnPtr>> pending_;
+    size_t pending_segments_ = 0;
 };
 
 struct ModelCountAccumulator : ModelAccumulator {
     explicit ModelCountAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_COUNT) {}
     std::vector<ScalarValue> state() override { // :367-372
+        fold_pending();
         ScalarValue v{ScalarValue::Kind::Int64};
         v.i64 = state_.count;
         reset();
@@ -846,6 +869,7 @@ struct ModelCountAccumulator : ModelAccumulator {
 struct ModelMinAccumulator : ModelAccumulator {
     explicit ModelMinAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_MIN) {}
     std::vector<ScalarValue> state() override { // :410-415
+        fold_pending();
         ScalarValue v{ScalarValue::Kind::Float32};
         v.f32 = state_.min;
         reset();
@@ -856,6 +880,7 @@ struct ModelMinAccumulator : ModelAccumulator {
 struct ModelMaxAccumulator : ModelAccumulator {
     explicit ModelMaxAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_MAX) {}
     std::vector<ScalarValue> state() override { // :453-458
+        fold_pending();
         ScalarValue v{ScalarValue::Kind::Float32};
         v.f32 = state_.max;
         reset();
@@ -866,6 +891,7 @@ struct ModelMaxAccumulator : ModelAccumulator {
 struct ModelSumAccumulator : ModelAccumulator {
     explicit ModelSumAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_SUM) {}
     std::vector<ScalarValue> state() override { // :523-528
+        fold_pending();
         ScalarValue v{ScalarValue::Kind::Float64};
         v.f64 = state_.sum;
         reset();
@@ -876,6 +902,7 @@ struct ModelSumAccumulator : ModelAccumulator {
 struct ModelAvgAccumulator : ModelAccumulator {
     explicit ModelAvgAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_AVG) {}
     std::vector<ScalarValue> state() override { // :597-606: [UInt64 count, Float64 sum]
+        fold_pending();
         ScalarValue count{ScalarValue::Kind::UInt64};
         count.u64 = static_cast<uint64_t>(state_.count);
         ScalarValue sum{ScalarValue::Kind::Float64};

@@ -620,6 +620,25 @@ int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb
     return rc;
 }
 
+int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t n_inputs, uint32_t which_mask,
+                       mdb_agg_state *inout) {
+    if (!ctx || !inputs || !inout) return fail("ctx, inputs and inout must not be NULL.");
+    if (n_inputs == 0) return 0;
+    for (uint32_t k = 0; k < n_inputs; k++)
+        if (!inputs[k]) return fail("A batch of the list is NULL.");
+    MvCallIndex index;
+    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) mv_host_index(inputs, n_inputs, &index.piece_base, &index.cursors);
+    mdb::CallGuard lock(ctx);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    mdb_segments_owned *dev = nullptr;
+    if (upload_segment_list_locked(ctx, inputs, n_inputs, true, &dev)) return 1;
+    int rc = mv_call_index_use(ctx, dev->seg, index);
+    if (!rc) rc = agg_run(ctx, &dev->seg, false, 0, 0, which_mask, inout);
+    mv_call_index_done();
+    mdb_segments_free(dev);
+    return rc;
+}
+
 int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                         uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");

@@ -303,8 +303,9 @@ class _ModelAccumulator:
 
 def measure_accumulator(context, segments, accumulator_class, segments_per_batch=8192):
     """One of the five accumulators fed `segments` (a SegmentBatch in host memory) `segments_per_batch` rows at a
-    time - the batches DataFusion hands update_batch, one mdb_agg_batch each as rust/patches/0002 makes it - for
-    bench.py. Returns (state, seconds)."""
+    time - the batches DataFusion hands update_batch; the accumulator keeps them until 262 144 segments are pending or
+    its state is read and folds them with ONE mdb_agg_batch_list, as rust/patches/0002 makes it - for bench.py.
+    Returns (state, seconds)."""
     import time
     arrow = segments.to_arrow()
     batches = [arrow.slice(first, min(segments_per_batch, arrow.num_rows - first))

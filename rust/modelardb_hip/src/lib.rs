@@ -305,6 +305,14 @@ impl Context {
         check(unsafe { sys::mdb_agg_batch(self.raw(), &segments.raw, which_mask, state) })
     }
 
+    /// The same for several batches at once (rows in the order of the slice): uploaded and reduced as ONE
+    /// batch, so that accumulators which are handed 8192 segments at a time can fold hundreds of
+    /// thousands with one call (patches/0002-model_simple_aggregates.patch: `PendingSegments`).
+    pub fn aggregate_list(&self, segments: &[SegmentsView], which_mask: u32, state: &mut AggState) -> Result<()> {
+        let inputs: Vec<*const sys::mdb_segments> = segments.iter().map(|view| &view.raw as *const _).collect();
+        check(unsafe { sys::mdb_agg_batch_list(self.raw(), inputs.as_ptr(), inputs.len() as u32, which_mask, state) })
+    }
+
     /// The same restricted to `t_lo <= timestamp <= t_hi`, without materialising a data point.
     pub fn aggregate_range(
         &self,

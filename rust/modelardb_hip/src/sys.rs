@@ -224,6 +224,8 @@ unsafe extern "C" {
                          inout: *mut mdb_agg_state) -> c_int;
     pub fn mdb_agg_batch_dev(ctx: *mut mdb_ctx, input: *const mdb_segments, which_mask: u32,
                              inout: *mut mdb_agg_state) -> c_int;
+    pub fn mdb_agg_batch_list(ctx: *mut mdb_ctx, inputs: *const *const mdb_segments, n_inputs: u32,
+                              which_mask: u32, inout: *mut mdb_agg_state) -> c_int;
     pub fn mdb_agg_batch_range(ctx: *mut mdb_ctx, input: *const mdb_segments, t_lo: i64, t_hi: i64,
                                which_mask: u32, inout: *mut mdb_agg_state) -> c_int;
     pub fn mdb_agg_batch_range_dev(ctx: *mut mdb_ctx, input: *const mdb_segments, t_lo: i64, t_hi: i64,

@@ -563,6 +563,16 @@ int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb
     return 0;
 }
 
+// (the canned answers are per batch: the list is the sum of its batches' - what the library computes in one launch)
+int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t n_inputs, uint32_t which_mask,
+                       mdb_agg_state *inout) {
+    if (!valid(ctx) || !inputs || !inout) return fail("mdb_agg_batch_list: NULL argument or closed context");
+    log_call("agg_list", n_inputs, which_mask);
+    for (uint32_t k = 0; k < n_inputs; k++)
+        if (mdb_agg_batch(ctx, inputs[k], which_mask, inout)) return 1;
+    return 0;
+}
+
 int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values, const uint64_t *chunk_offsets,
                         uint64_t n_chunks, mdb_error_bound error_bound, mdb_segments_owned **out) {
     if (!valid(ctx) || !chunk_offsets || !out || ((!ts || !values) && chunk_offsets[n_chunks] > chunk_offsets[0]))

@@ -106,6 +106,27 @@ def test_aggregates_continue_a_running_state(hip):
     _assert_state(state, ora.agg_batch(batch, ALL))
 
 
+def test_a_list_of_batches_is_folded_as_one(hip):
+    # mdb_agg_batch_list: what an accumulator that has gathered the batches of a run of update_batch calls passes.
+    # COUNT / MIN / MAX as the batches one by one, SUM to the rounding of the f64 additions.
+    batches = []
+    for eb_name, irregular, seed in (("lossless", False, 3), ("rel1", True, 4), ("abs5", False, 5), ("rel5", True, 6)):
+        batches.append(cases.mixed_batch(cases.error_bounds()[eb_name], irregular, seed=seed)[2])
+    one_by_one = None
+    for batch in batches:
+        one_by_one = hip.agg_batch(batch, ALL, one_by_one)
+    together = hip.agg_batch_list(batches, ALL)
+    assert (together.count, together.min, together.max) == (one_by_one.count, one_by_one.min, one_by_one.max)
+    assert abs(together.sum - one_by_one.sum) <= 1e-12 * abs(one_by_one.sum)
+    expected = ora.agg_batch(batches[0], ALL)
+    for batch in batches[1:]:
+        expected = ora.agg_batch(batch, ALL, expected)
+    _assert_state(together, expected)
+    assert hip.agg_batch_list([], ALL).count == 0
+    seeded = hip.agg_batch_list(batches[:1], ALL, hip.agg_batch_list(batches[1:], ALL))
+    assert seeded.count == together.count and abs(seeded.sum - together.sum) <= 1e-12 * abs(together.sum)
+
+
 def test_sum_of_long_lossless_streams(hip, macaque_decoder, monkeypatch):
     # BASELINE configs[0] as an aggregate query: 16 MacaqueV streams of 65 536 values. Each stream is
     # added up in f32 in stream order whoever decodes it (macaque_v.rs:220-265), so the two ways must

@@ -37,8 +37,12 @@ def test_rust_patch_and_cpp_twin_name_the_same_steps():
         assert name in patch and name in twin
     for call in ("mdb_grid_submit", "mdb_grid_wait", "mdb_grid_cancel", "mdb_grid_result_tag_views"):
         assert f"sys::{call}(" in binding and f"{call}(" in twin
-    for call in ("mdb_compress_chunk_list",):
+    for call in ("mdb_compress_chunk_list", "mdb_agg_batch_list"):
         assert f"sys::{call}(" in binding and f"{call}(" in twin
+    # the accumulators: batches gathered until 262 144 segments are pending or the state is read, then ONE call
+    aggregates = open(os.path.join(REPO_ROOT, "rust", "patches", "0002-model_simple_aggregates.patch")).read()
+    assert "PENDING_SEGMENTS_PER_CALL: usize = 262_144" in aggregates and "aggregate_list(" in aggregates
+    assert "PENDING_SEGMENTS_PER_CALL = 262144" in twin and "fold_pending()" in twin and "fold_pending()" in aggregates
     for constant, value in (("SUBMIT_TARGET_ROWS", "16 * 1024 * 1024"), ("SUBMIT_MAX_SEGMENTS", "1024 * 1024")):
         assert f"{constant}: u64 = {value}" in patch
     assert "GRID_SUBMIT_TARGET_POINTS = 16u << 20" in twin and "GRID_SUBMIT_MAX_SEGMENTS = 1u << 20" in twin
