@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace mdb {
@@ -19,8 +20,9 @@ constexpr uint32_t COUNT_LIMIT = 0x7fffffffu; // COUNT_MASK of the device code: 
 // would cost what the serial decode costs. But the long streams are what hurts - a 65 536-value MacaqueV segment
 // (a whole ingest buffer of noise under a lossless bound) keeps one lane busy for 10 ms however idle the GPU is - and
 // a CPU core walks such a stream in a third of a millisecond. So the call's host threads walk the long streams of the
-// batches (segments with regular timestamps whose model values number at least MV_HOST_MIN_VALUES; their residual
-// tails with them) while nothing else needs them, the cursors travel with the batch (0.5 bytes per value), and
+// batches (MacaqueV segments whose model values number at least MV_HOST_MIN_VALUES; their residual tails with them;
+// where the timestamps are irregular the points are counted from the delta-of-delta stream first) while nothing else
+// needs them, the cursors travel with the batch (0.5 bytes per value), and
 // k_grid_mv_pieces decodes those streams piece by piece; everything else is k_grid_serial's as before. Same cursors
 // as k_mv_index_walk leaves (macaque_v.rs:272-323 walked, not decoded to floats). A malformed stream or segment:
 // no index at all, the kernels that report it run as before.
@@ -55,6 +57,24 @@ HostViewBytes host_view_bytes(const mdb_binview_col &col, uint64_t i) {
     return {col.buffers[view.u.ref.buffer_index] + view.u.ref.offset, (uint64_t)view.length};
 }
 
+// Every view inside its column's data buffers (validate_views_host's rules, without the error text: the upload
+// that follows makes that check again and reports what it finds).
+bool host_views_are_valid(const mdb_binview_col &col, uint64_t n) {
+    if (n > 0 && !col.views) return false;
+    if (col.n_buffers < 0 || (col.n_buffers > 0 && (!col.buffers || !col.buffer_sizes))) return false;
+    for (uint64_t i = 0; i < n; i++) {
+        const mdb_view16 &view = col.views[i];
+        if (view.length < 0) return false;
+        if (view.length <= 12) continue;
+        const int32_t buffer = view.u.ref.buffer_index;
+        const int64_t offset = view.u.ref.offset;
+        if (buffer < 0 || buffer >= col.n_buffers || offset < 0 || col.buffer_sizes[buffer] < 0 ||
+            offset + (int64_t)view.length > col.buffer_sizes[buffer] || !col.buffers[buffer])
+            return false;
+    }
+    return true;
+}
+
 // Points of a segment with regular timestamps (analyse_segment's rules); false: not regular, or malformed.
 bool host_regular_points(const mdb_segments &seg, uint64_t i, uint32_t *n_total) {
     const HostViewBytes ts = host_view_bytes(seg.timestamps, i);
@@ -76,6 +96,40 @@ bool host_regular_points(const mdb_segments &seg, uint64_t i, uint32_t *n_total)
     const uint64_t produced = span / interval + 1;
     if (produced > COUNT_LIMIT) return false;
     *n_total = (uint32_t)produced;
+    return true;
+}
+
+// Points of a segment with irregular timestamps: the codes of its delta-of-delta stream (timestamps.rs:228-292;
+// decode_irregular_timestamps of the device code) counted, plus its first and its last point. false: malformed.
+bool host_irregular_points(const HostViewBytes &ts, uint32_t *n_total) {
+    HostStreamBits bits{ts.data, ts.length};
+    const uint64_t total_bits = ts.length * 8;
+    bits.used = 1; // (bit 0: the flag "irregular")
+    uint64_t count = 1;
+    while (bits.used < total_bits) {
+        const uint64_t window = bits.peek64(), left = total_bits - bits.used;
+        if ((window >> 63) == 0) { // a run of `0` codes: the delta repeats
+            const uint64_t run = std::min<uint64_t>(window ? (uint64_t)__builtin_clzll(window) : 64u, left);
+            bits.used += run;
+            count += run;
+            if (count > COUNT_LIMIT) return false;
+            continue;
+        }
+        // `10`, `110`, `1110`, `11110` or `11111` in front of 7, 9, 12, 32 or 64 bits
+        const uint64_t leading_ones = ~window ? (uint64_t)__builtin_clzll(~window) : 64u;
+        const uint64_t ones = std::min<uint64_t>(std::min<uint64_t>(leading_ones, 5u), left);
+        bits.used += ones < 5 && ones < left ? ones + 1 : ones; // (the `0` behind fewer than five ones, if there is one)
+        const uint64_t remaining = total_bits - bits.used;
+        if (remaining < 7) break; // (the ones that pad the last byte)
+        static const uint32_t widths[6] = {0, 7, 9, 12, 32, 64};
+        if (remaining < widths[ones]) return false;
+        bits.used += widths[ones];
+        count += 1;
+        if (count > COUNT_LIMIT) return false;
+    }
+    count += 1; // (the last point is end_time, which is not stored)
+    if (count > COUNT_LIMIT) return false;
+    *n_total = (uint32_t)count;
     return true;
 }
 
@@ -181,13 +235,56 @@ void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<u
         rows += ins[h]->n;
     }
     if (rows == 0 || rows > 0xfffffff0ull) return;
+    for (uint32_t h = 0; h < n_ins; h++) { // (nothing below looks at a byte before the views are known to be sound)
+        const mdb_segments &seg = *ins[h];
+        if (seg.n > 0 && (!seg.model_type_id || !seg.start_time || !seg.end_time)) return;
+        if (!host_views_are_valid(seg.timestamps, seg.n) || !host_views_are_valid(seg.values, seg.n) ||
+            !host_views_are_valid(seg.residuals, seg.n))
+            return;
+    }
     std::vector<unsigned long long> pieces(rows + 1, 0);
+    // Segments with irregular timestamps: their number of points is the number of codes of a delta-of-delta
+    // stream. The streams that can be long enough (a code is at least a bit) are counted by the host threads first.
+    struct CountJob {
+        const mdb_segments *const *ins;
+        std::vector<std::pair<uint32_t, uint64_t>> segments; // (input, row)
+        std::vector<uint32_t> points;                         // 0: malformed
+        std::atomic<uint64_t> next{0};
+    } counting;
+    counting.ins = ins;
+    for (uint32_t h = 0; h < n_ins; h++) {
+        const mdb_segments &seg = *ins[h];
+        for (uint64_t i = 0; i < seg.n; i++) {
+            if (seg.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
+            const HostViewBytes ts = host_view_bytes(seg.timestamps, i);
+            if (ts.length > 0 && (ts.data[0] & 0x80u) != 0 && ts.length * 8 + 1 >= min_values) counting.segments.push_back({h, i});
+        }
+    }
+    counting.points.assign(counting.segments.size(), 0);
+    if (!counting.segments.empty())
+        host_parallel((unsigned)std::min<uint64_t>(host_parallel_width(), counting.segments.size()),
+                      [](unsigned, void *arg) {
+                          CountJob &job = *static_cast<CountJob *>(arg);
+                          for (uint64_t k = job.next.fetch_add(1); k < job.segments.size(); k = job.next.fetch_add(1)) {
+                              const mdb_segments &seg = *job.ins[job.segments[k].first];
+                              uint32_t n_total = 0;
+                              if (host_irregular_points(host_view_bytes(seg.timestamps, job.segments[k].second), &n_total))
+                                  job.points[k] = n_total;
+                          }
+                      },
+                      &counting);
+    size_t next_counted = 0;
     for (uint32_t h = 0; h < n_ins; h++) {
         const mdb_segments &seg = *ins[h];
         for (uint64_t i = 0; i < seg.n; i++) {
             if (seg.model_type_id[i] != MDB_MACAQUE_V_ID) continue; // (residual tails alone are short: at most 255 values)
             uint32_t n_total = 0;
-            if (!host_regular_points(seg, i, &n_total)) continue;
+            if (next_counted < counting.segments.size() && counting.segments[next_counted] == std::make_pair(h, i)) {
+                n_total = counting.points[next_counted++];
+                if (n_total == 0) continue; // (malformed: the kernels that report it take the segment)
+            } else if (!host_regular_points(seg, i, &n_total)) {
+                continue;
+            }
             const HostViewBytes residuals = host_view_bytes(seg.residuals, i);
             const uint32_t n_res = residuals.length > 0 ? residuals.data[residuals.length - 1] : 0u;
             if (n_res > n_total || residuals.length == 1) continue;

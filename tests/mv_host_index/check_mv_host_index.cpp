@@ -133,11 +133,34 @@ int main() {
         }
         return view;
     };
+    int irregular_segments = 0;
     for (size_t i = 0; i < n_segments; i++) {
         value_views[i] = make_view(value_buffer, models[i].bytes);
         residual_views[i] = make_view(residual_buffer, tails[i].bytes);
         const uint64_t total = models[i].n + tails[i].n;
         starts[i] = 1000 * (int64_t)i;
+        if (i % 2 == 1 && total >= 3) {
+            // irregular timestamps: the oracle's delta-of-delta stream (timestamps.rs:56-155), whose codes the host
+            // threads count to know how many points - and so how many model values - the segment has
+            std::vector<int64_t> timestamps(total);
+            int64_t t = starts[i];
+            for (uint64_t k = 0; k < total; k++) {
+                timestamps[k] = t;
+                const uint32_t kind = rng() % 100;
+                t += kind < 70 ? 10 : (kind < 90 ? 1 + (int64_t)(rng() % 300) : (kind < 99 ? 1 + (int64_t)(rng() % 100000) : 5000000000ll));
+            }
+            ends[i] = timestamps[total - 1];
+            std::vector<uint8_t> stream(16 + 10 * total);
+            uint64_t length = 0;
+            if (ora_compress_residual_timestamps(timestamps.data(), total, stream.data(), stream.size(), &length)) return 2;
+            stream.resize(length);
+            if (stream.empty() || (stream[0] & 0x80u) == 0) { // (came out regular after all)
+                irregular_segments -= 1;
+            }
+            irregular_segments += 1;
+            timestamp_views[i] = make_view(timestamp_buffer, stream);
+            continue;
+        }
         ends[i] = starts[i] + 10 * (int64_t)(total - 1);
         std::vector<uint8_t> length_bytes; // timestamps.rs:99-108: the length, big endian, as few bytes as it needs
         if (total > 2)
@@ -233,7 +256,19 @@ int main() {
     batches[1].values = {value_views.data() + split, grown_buffers, grown_sizes, 1};
     mdb::mv_host_index(list, 2, &piece_base, &cursors);
     expect(piece_base.empty() && cursors.empty(), "a malformed stream leaves no index", piece_base.size(), cursors.size());
-    std::printf("%s: %zu segments, %llu values decoded from %zu cursors\n", failures ? "FAILED" : "ok", n_segments,
-                (unsigned long long)checked_values, n_cursors);
+    // A view that points outside its data buffers: nothing is dereferenced, no index (the upload reports it).
+    value_views[victim] = value_views[victim + 1];
+    value_views[victim].length = 1 << 20;
+    value_views[victim].u.ref.offset = (int32_t)value_buffer.size() - 8;
+    mdb::mv_host_index(list, 2, &piece_base, &cursors);
+    expect(piece_base.empty() && cursors.empty(), "a view outside its buffers leaves no index", piece_base.size(), cursors.size());
+    timestamp_views[victim + 2].length = 4000;
+    timestamp_views[victim + 2].u.ref.buffer_index = 7;
+    value_views[victim] = value_views[victim + 1];
+    mdb::mv_host_index(list, 2, &piece_base, &cursors);
+    expect(piece_base.empty() && cursors.empty(), "a view into a buffer that does not exist leaves no index", piece_base.size(), cursors.size());
+    expect(irregular_segments >= 10, "segments with irregular timestamps among them", irregular_segments, 10);
+    std::printf("%s: %zu segments (%d with irregular timestamps), %llu values decoded from %zu cursors\n",
+                failures ? "FAILED" : "ok", n_segments, irregular_segments, (unsigned long long)checked_values, n_cursors);
     return failures ? 1 : 0;
 }
