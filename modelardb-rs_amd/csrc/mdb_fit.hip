@@ -1613,6 +1613,9 @@ struct WaveLeave {
     unsigned int *n_left;
     uint32_t window_points;
     uint32_t points_per_step;
+    // A chunk longer than this is left at once: one wave walks 65 536 points in a millisecond, a million (a whole
+    // series handed over by the embedded API) in 15 to 30 - speculative pieces take 10 for it.
+    uint32_t max_chunk_points;
     // MDB_FIT_DEBUG: models, rejected start points, passes over 64 start points, blocks of 64 points, scans of a
     // Swing block, models fitted by one lane, chunks left (nullptr: not counted).
     unsigned long long *counts;
@@ -1674,6 +1677,13 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         if (leave.counts && lane == 0)
             for (int k = 0; k < WAVE_COUNTS; k++) atomicAdd(leave.counts + k, (unsigned long long)counted[k]);
     };
+    if (leave.chunk_left && n > leave.max_chunk_points) {
+        if (lane == 0) {
+            leave.chunk_left[chunk] = 1u;
+            atomicAdd(leave.n_left, 1u);
+        }
+        return;
+    }
     if (leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
 
     // The sums of the queued Swing models, one lane per model, and with them the models' last values.
@@ -2984,6 +2994,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 leave.chunk_left = static_cast<unsigned int *>(p);
                 leave.n_left = leave.chunk_left + n_chunks;
                 leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 1024);
+                leave.max_chunk_points = fit_wave_number("MDB_FIT_WAVE_MAX_CHUNK_POINTS", 262144);
                 // (2 300 cycles per step against split mode's 107 per point under a relative or absolute bound:
                 // k_fit_models_lean. Under a lossless one split mode is k_fit_models, and on the bench's mixed series
                 // every threshold above 3 only moved chunks to the slower side: 41 ms at 3, 54 at 12, 81 at 45.)
