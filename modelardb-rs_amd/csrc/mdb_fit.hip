@@ -1577,6 +1577,31 @@ template <typename T, typename Op> __device__ __forceinline__ T wave_inclusive_s
     return x;
 }
 
+// The same scan without the lane tests: a lane that has no source lane for a step (the first k lanes of a row, the
+// rows a broadcast does not reach) receives `otherwise(x)` instead - its own value where op(x, x) = x (minimum,
+// maximum), the neutral element where there is one (0 for a sum) - so that op can be applied by every lane.
+template <int CONTROL, int ROW_MASK, typename T> __device__ __forceinline__ T dpp_move_or(T otherwise, T x) {
+    static_assert(sizeof(T) % 4 == 0, "made of 32-bit words");
+    int words[sizeof(T) / 4], kept[sizeof(T) / 4];
+    __builtin_memcpy(words, &x, sizeof(T));
+    __builtin_memcpy(kept, &otherwise, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; k++)
+        words[k] = __builtin_amdgcn_update_dpp(kept[k], words[k], CONTROL, ROW_MASK, 0xf, false);
+    __builtin_memcpy(&x, words, sizeof(T));
+    return x;
+}
+template <typename T, typename Op, typename Otherwise>
+__device__ __forceinline__ T wave_inclusive_scan_all_lanes(T x, Op op, Otherwise otherwise) {
+    x = op(dpp_move_or<0x111, 0xf>(otherwise(x), x), x); // row_shr:1
+    x = op(dpp_move_or<0x112, 0xf>(otherwise(x), x), x); // row_shr:2
+    x = op(dpp_move_or<0x114, 0xf>(otherwise(x), x), x); // row_shr:4
+    x = op(dpp_move_or<0x118, 0xf>(otherwise(x), x), x); // row_shr:8
+    x = op(dpp_move_or<0x142, 0xa>(otherwise(x), x), x); // row_bcast:15 into rows 1 and 3
+    x = op(dpp_move_or<0x143, 0xc>(otherwise(x), x), x); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // The value of one lane, the same lane for the whole wave, in every lane.
 template <typename T> __device__ __forceinline__ T read_lane(T x, int lane_of_all) {
     static_assert(sizeof(T) % 4 == 0, "made of 32-bit words");
@@ -1622,7 +1647,7 @@ struct WaveLeave {
 };
 
 enum WaveCount { WAVE_MODELS, WAVE_REJECTED, WAVE_START_PASSES, WAVE_BLOCKS, WAVE_SWING_SCANS, WAVE_BY_ONE_LANE,
-                 WAVE_COUNTS };
+                 WAVE_QUIET_BLOCKS, WAVE_PMC_BLOCKS, WAVE_COUNTS };
 
 constexpr uint32_t WAVE_PASS_POINTS = 1024; // start points a pass over rejected start points looks at, at most
 constexpr uint32_t WAVE_PASS_STEPS = 4;     // what its second stage costs, in blocks of a model
@@ -1841,22 +1866,26 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             if (position == current) first_value = read_lane(value, 0);
 
             if (pmc_alive) {
+                counted[WAVE_PMC_BLOCKS] += 1;
                 // Up to which lane is every partial sum exact (file comment)? The exponents met so far, per lane.
                 const uint32_t bits = __float_as_uint(v);
                 const bool non_zero = valid && (bits << 1) != 0u;
                 const int exponent = max((int)((bits >> 23) & 0xffu), 1);
                 ExponentRange range = {non_zero ? exponent : 255, non_zero ? exponent : 0};
-                range = wave_inclusive_scan(range, lane, [](ExponentRange a, ExponentRange b) {
-                    return ExponentRange{min(a.low, b.low), max(a.high, b.high)};
-                });
+                range = wave_inclusive_scan_all_lanes(
+                    range, [](ExponentRange a, ExponentRange b) { return ExponentRange{min(a.low, b.low), max(a.high, b.high)}; },
+                    [](ExponentRange x) { return x; });
                 range.low = min(range.low, exponent_low);
                 range.high = max(range.high, exponent_high);
                 const uint32_t next_length = pmc_length + (uint32_t)lane + 1u;
                 const int length_bits = 32 - __clz((int)next_length);
                 const bool exact_to_here = range.high < range.low || range.high - range.low + 24 + length_bits + 1 <= 53;
-                const PmcScan scan = wave_inclusive_scan(PmcScan{v, v, value}, lane, [](PmcScan a, PmcScan b) {
-                    return PmcScan{min_num(a.min_value, b.min_value), max_num(a.max_value, b.max_value), a.sum + b.sum};
-                });
+                // (the block's values are finite: minimum and maximum without min_num's care for NaN, and the sign of a
+                // zero among them is nothing within_error_bound can see)
+                const PmcScan scan = wave_inclusive_scan_all_lanes(
+                    PmcScan{v, v, value},
+                    [](PmcScan a, PmcScan b) { return PmcScan{fminf(a.min_value, b.min_value), fmaxf(a.max_value, b.max_value), a.sum + b.sum}; },
+                    [](PmcScan x) { return PmcScan{x.min_value, x.max_value, 0.0}; });
                 const float next_min = min_num(pmc_min, scan.min_value);
                 const float next_max = max_num(pmc_max, scan.max_value);
                 // The reference's sum at this lane is (sum of everything in front) + value: the former in any order
@@ -1917,8 +1946,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                         above = upper_slope;
                         below = lower_slope;
                     }
-                    above = wave_inclusive_scan(above, lane, [](double a, double b) { return b < a ? b : a; });
-                    below = wave_inclusive_scan(below, lane, [](double a, double b) { return b > a ? b : a; });
+                    // (slopes are finite here; which of two equal ones stays does not matter: they are the same line)
+                    above = wave_inclusive_scan_all_lanes(above, [](double a, double b) { return fmin(a, b); }, [](double x) { return x; });
+                    below = wave_inclusive_scan_all_lanes(below, [](double a, double b) { return fmax(a, b); }, [](double x) { return x; });
                     // The step itself (swing.rs:144-197) against that state.
                     const double upper_approximation = above * t + (first_value - above * start_time);
                     const double lower_approximation = below * t + (first_value - below * start_time);
@@ -1927,6 +1957,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     const bool raises_lower = lower_approximation + deviation < value;
                     const bool as_assumed = lowers_upper == (upper_candidate < above) && raises_lower == (lower_candidate > below);
                     const bool mine = lane >= first_lane && lane < n_valid;
+                    if (leave.counts && first_lane == 0 && !__ballot(mine && (lowers_upper || raises_lower || fails)))
+                        counted[WAVE_QUIET_BLOCKS] += 1; // (a whole block in which neither bound moves)
                     const unsigned long long stops = __ballot(mine && (fails || !as_assumed));
                     const int at = stops ? __builtin_ctzll(stops) : n_valid - 1; // its incoming state is the true one
                     const bool ends = stops && ((__ballot(fails) >> at) & 1ull) != 0;
@@ -3029,9 +3061,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 FIT_CHECK(hipStreamSynchronize(ctx->stream));
                 FIT_CHECK(hipFree(leave.counts));
                 std::fprintf(stderr, "[fit] k_fit_models_wave: %llu chunks, %llu points: %llu models, %llu rejected start points, "
-                             "%llu passes over 64 start points, %llu blocks, %llu Swing scans, %llu models by one lane\n",
+                             "%llu passes over 64 start points, %llu blocks (%llu with PMC-Mean alive, %llu in which no bound of Swing moves), %llu Swing scans, %llu models by one lane\n",
                              (unsigned long long)n_chunks, (unsigned long long)points_end, counts[WAVE_MODELS], counts[WAVE_REJECTED],
-                             counts[WAVE_START_PASSES], counts[WAVE_BLOCKS], counts[WAVE_SWING_SCANS], counts[WAVE_BY_ONE_LANE]);
+                             counts[WAVE_START_PASSES], counts[WAVE_BLOCKS], counts[WAVE_PMC_BLOCKS], counts[WAVE_QUIET_BLOCKS],
+                             counts[WAVE_SWING_SCANS], counts[WAVE_BY_ONE_LANE]);
             }
             if (leave.chunk_left) {
                 unsigned int n_left = 0;
