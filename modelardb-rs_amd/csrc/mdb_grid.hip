@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
                                                              const unsigned long long *__restrict__ offsets,
                                                              const uint32_t *__restrict__ irregular_first,
                                                              const MvCursor *__restrict__ cursors, unsigned long long n_pieces,
-                                                             float *__restrict__ out_val) {
+                                                             float *__restrict__ out_val, GridHeader *__restrict__ header) {
     constexpr int STRIDE = ROUND + 1; // (a row per lane: an odd stride keeps the banks apart)
     __shared__ uint32_t stage[MDB_WAVE * STRIDE];
     const int lane = threadIdx.x;
@@ -1344,6 +1344,11 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
         const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
         const uint32_t i = c0.z, point_index = c0.w, n_values = c1.x, window = c1.y;
         const TileDesc t = desc[i];
+        // Cursors that host threads have left (mv_host_index) mark the last piece of every stream: it has to end where
+        // this call's own analysis of the segment ends the stream, or the two disagree about the segment's length.
+        if ((c1.w & MV_CURSOR_LAST_OF_STREAM) && !range.enabled &&
+            point_index + n_values != ((window & MV_WINDOW_RESIDUAL) ? t.n_points : t.n_model))
+            atomicOr(&header->error, ERR_HOST_INDEX);
         uint32_t first = 0;
         if (range.enabled) {
             if (t.flags & FLAG_REGULAR) first = t.delta > 0 ? (uint32_t)((uint64_t)(t.start - s.start_time[i]) / (uint64_t)t.delta) : 0u;
@@ -1473,6 +1478,13 @@ __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint
     if (piece_base[i + 1] == first_piece) return; // (no stream: nobody reads this segment's sums)
     uint32_t n_values, n_res, n_model, error;
     mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
+    // (cursors left by host threads: should they ever disagree with this analysis about the segment's streams, the
+    // sum is made unusable rather than a little wrong)
+    if ((unsigned long long)((n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES + (n_res + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES) !=
+        piece_base[i + 1] - first_piece) {
+        stream_sums[2 * i] = stream_sums[2 * i + 1] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     // 32 values per round: eight independent 16-byte loads (a lane that waited for one load per four additions
     // spent its time waiting - 3.4 ms for a 50 000-value chain), then the additions, in stream order.
     auto chain = [&](unsigned long long at_piece, uint32_t n, bool starts_as_first) {
@@ -3595,7 +3607,8 @@ int grid_launch_streams(mdb_ctx *ctx, const DevSegments &s, TimeRange range, Gri
         const dim3 blocks((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE));
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, blocks, dim3(MDB_WAVE), 0, ctx->stream, s, range, plan.desc, plan.offsets,
-                               plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val);
+                               plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val,
+                               plan.header);
         };
         if (round == 64) launch(k_grid_mv_pieces<64>);
         else if (round == 16) launch(k_grid_mv_pieces<16>);

@@ -79,8 +79,9 @@ struct MvCursor { // 32 bytes
     uint32_t n_values;     // 1..64
     uint32_t window;       // leading | trailing << 8 | MV_WINDOW_*
     uint32_t chain_seed;   // residual tail of a MacaqueV segment: the bits of its last model value (else 0)
-    uint32_t pad;
+    uint32_t pad;          // MV_CURSOR_LAST_OF_STREAM (cursors left by host threads only)
 };
+constexpr uint32_t MV_CURSOR_LAST_OF_STREAM = 1u;
 static_assert(sizeof(MvCursor) == 32, "cursors are loaded as two uint4");
 
 // The cursors the host threads of ONE call leave in the long MacaqueV streams of a host batch (mdb_grid.hip,

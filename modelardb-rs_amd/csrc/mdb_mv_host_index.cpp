@@ -183,7 +183,7 @@ void host_index_share(unsigned, void *arg) {
                     cursor.window = (leading & 255u) | ((trailing & 255u) << 8) | (residual ? MV_WINDOW_RESIDUAL : 0u) |
                                     (raw ? MV_WINDOW_RAW : 0u);
                     cursor.chain_seed = residual ? chain_seed : 0u;
-                    cursor.pad = 0;
+                    cursor.pad = remaining <= MV_PIECE_VALUES ? MV_CURSOR_LAST_OF_STREAM : 0u; // (checked by k_grid_mv_pieces)
                     *out++ = cursor;
                 }
                 // one code (ring_decode_value)

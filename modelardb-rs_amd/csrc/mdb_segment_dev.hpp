@@ -29,6 +29,7 @@ enum : uint32_t {
     ERR_BITSTREAM = 1u << 4,
     ERR_TOO_LONG = 1u << 5,
     ERR_SPLIT_CHAIN = 1u << 6, // fit, split mode: the walk reached a point no lane visited (a bug)
+    ERR_HOST_INDEX = 1u << 7,  // grid: the cursors host threads left disagree with the kernels' analysis (a bug)
 };
 
 struct SegDesc { // what one lane knows about a segment (registers only)
@@ -768,6 +769,7 @@ inline std::string describe_error(uint32_t error) {
     if (error & ERR_RESIDUALS) message += " residuals;";
     if (error & ERR_BITSTREAM) message += " MacaqueV bitstream;";
     if (error & ERR_TOO_LONG) message += " more than 2^31-1 data points in one segment;";
+    if (error & ERR_HOST_INDEX) message += " (internal) the host threads' cursors and the kernels disagree about a segment's length;";
     return message;
 }
 

@@ -209,6 +209,8 @@ int main() {
             expect(c.point_index == (residual ? models[i].n : 0u) + first, "cursor.point_index", c.point_index, first);
             expect(c.n_values == std::min<uint32_t>(64, stream.n - first), "cursor.n_values", c.n_values, stream.n - first);
             expect(((c.window & mdb::MV_WINDOW_RESIDUAL) != 0) == residual, "cursor is of the tail", i, p);
+            expect(((c.pad & mdb::MV_CURSOR_LAST_OF_STREAM) != 0) == (first + 64 >= stream.n),
+                   "only the last piece of a stream says so", i, p);
             uint32_t seed_bits = 0; // (k_grid_mv_pieces: a MacaqueV model's tail starts from chain_seed, its values from 0)
             if (residual) seed_bits = c.chain_seed;
             if (residual) {
