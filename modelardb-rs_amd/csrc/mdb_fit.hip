@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models(FitArgs args, SplitA
 // ---- k_fit_models_lean --------------------------------------------------------------------------------------
 //
 // The same greedy loop for the case that matters most - regular timestamps that are exact in f64
-// (k_fit_exact_double_timestamps) under an absolute or relative bound - written for how a wave
+// (k_fit_exact_double_timestamps), any kind of error bound - written for how a wave
 // executes it. Counters of k_fit_models on the benchmark workload (scripts/pmc_fit_modes.sh): per
 // point 161 vector, 131 SCALAR and 28 branch instructions - every `if` on a per-lane condition costs
 // the wave a handful of scalar instructions to split and rejoin its lanes whether or not a lane
@@ -1143,6 +1143,7 @@ __device__ __forceinline__ bool in_lanes(LaneMask mask) { return __builtin_amdgc
 __device__ __forceinline__ void keep_under_mask() { asm volatile(""); }
 
 template <int KIND> __device__ __forceinline__ double lean_deviation(double factor, double value) {
+    if (KIND == MDB_EB_LOSSLESS) return 0.0;
     return KIND == MDB_EB_RELATIVE ? fabs(value * factor) : factor; // DeviationFactor::of
 }
 
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
                                                                 ModelRec *__restrict__ records,
                                                                 ChunkPlan *__restrict__ plans,
                                                                 unsigned int *__restrict__ error) {
-    static_assert(KIND == MDB_EB_RELATIVE || KIND == MDB_EB_ABSOLUTE, "lossless data has its own shortcuts");
+    static_assert(KIND == MDB_EB_RELATIVE || KIND == MDB_EB_ABSOLUTE || KIND == MDB_EB_LOSSLESS, "an error bound's kind");
     constexpr int LEAN_GROUPS = HAS_TS ? 4 : mdb::LEAN_GROUPS; // (shadow the constants of the values-only form)
     constexpr int LEAN_LOADS = HAS_TS ? 2 : mdb::LEAN_LOADS;
     constexpr int LEAN_TRASH = LEAN_GROUPS;
@@ -1257,6 +1258,56 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     const LaneMask pmc_fast_m = pmc_fast.enabled ? ~0ull : 0ull;
 
     while (active_m != 0) {
+        if (KIND == MDB_EB_LOSSLESS) {
+            // Noise under a lossless bound: a start point whose next value differs (PMC-Mean ends at one point) and
+            // whose third one is off the line through the first two (Swing ends at two) is rejected, which the three
+            // points say at once (k_fit_models has the same shortcut and the reasoning): runs of such start points
+            // are skipped here while their points are in the ring.
+            for (int skipped = 0; skipped < FIT_QUICK_REJECTS; skipped++) {
+                const uint32_t start = current + misalign;
+                const LaneMask candidate_m = active_m & lanes_where(j == current) & lanes_where(current + 2 < n) &
+                                             lanes_where((start >> 2) >= low_group) &
+                                             lanes_where(((start + 2) >> 2) < loaded_group);
+                if (candidate_m == 0) break;
+                const float v0 = ring_value<LEAN_GROUPS>(ring, lane, start);
+                const float v1 = ring_value<LEAN_GROUPS>(ring, lane, start + 1);
+                const float v2 = ring_value<LEAN_GROUPS>(ring, lane, start + 2);
+                double t0, t1, t2;
+                if (HAS_TS) {
+                    const longlong2 a = ring_ts[(start >> 1) % (2 * LEAN_GROUPS)][lane];
+                    const longlong2 b = ring_ts[((start + 1) >> 1) % (2 * LEAN_GROUPS)][lane];
+                    const longlong2 c = ring_ts[((start + 2) >> 1) % (2 * LEAN_GROUPS)][lane];
+                    t0 = (double)((start & 1u) ? a.y : a.x);
+                    t1 = (double)((start & 1u) ? b.x : b.y);
+                    t2 = (double)((start & 1u) ? c.y : c.x);
+                } else {
+                    t0 = __builtin_fma((double)current, interval_time, first_time);
+                    t1 = __builtin_fma((double)(current + 1), interval_time, first_time);
+                    t2 = __builtin_fma((double)(current + 2), interval_time, first_time);
+                }
+                const double slope = ((double)v1 - (double)v0) / (t1 - t0); // line_through_exact of two different values
+                const double approximation = slope * t2 + ((double)v0 - slope * t0);
+                const LaneMask rejected_m = candidate_m & lanes_where(__builtin_amdgcn_classf(v0, 0x1f8)) &
+                                            lanes_where(__builtin_amdgcn_classf(v1, 0x1f8)) &
+                                            lanes_where(__builtin_amdgcn_classf(v2, 0x1f8)) & lanes_where(v0 != v1) &
+                                            (lanes_where(approximation < (double)v2) | lanes_where(approximation > (double)v2));
+                if (rejected_m == 0) break;
+                bool met = false;
+                if (in_lanes(rejected_m)) {
+                    if (SPLIT)
+                        __hip_atomic_store(&split.entry[base + current], ENTRY_REJECTED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    current += 1;
+                    j = current;
+                    // (past the end of its piece a lane looks for another lane's tracks)
+                    if (SPLIT && current >= piece_end &&
+                        __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                        met = true;
+                }
+                if (SPLIT) active_m &= ~lanes_where(met);
+            }
+            if (active_m == 0) break;
+        }
         const LaneMask feeding_m = active_m & lanes_where(j < n) & (pmc_fits_m | swing_fits_m);
         const uint32_t position = j + misalign; // of point j, counted from the 16-byte boundary
         const uint32_t group = position >> 2;
@@ -1312,7 +1363,23 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         const double next_sum = pmc_sum + value;
         const uint32_t next_length = pmc_length + 1;
         LaneMask pmc_accepts_m;
-        {
+        if (KIND == MDB_EB_LOSSLESS) {
+            // Within a lossless bound of the average are a minimum and a maximum that both equal it. Certain: every
+            // value so far and this one are the same finite number and few enough for every partial sum to be
+            // exact (a 24-bit significand times a count below 2^24), so the average is that number. Certainly not:
+            // a minimum below the maximum. Anything else (NaNs, infinities, very long models): the exact test.
+            pmc_accepts_m = lanes_where(__builtin_amdgcn_classf(value32, 0x1f8)) & lanes_where(next_length < (1u << 24)) &
+                            (lanes_where(pmc_length == 0) | (lanes_where(pmc_min == value32) & lanes_where(pmc_max == value32)));
+            const LaneMask doubtful_m = pmc_steps_m & ~pmc_accepts_m & ~lanes_where(next_min < next_max);
+            if (doubtful_m) {
+                bool exactly_within = false;
+                if (in_lanes(doubtful_m)) {
+                    const float average = (float)(next_sum / (double)next_length);
+                    exactly_within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
+                }
+                pmc_accepts_m |= lanes_where(exactly_within);
+            }
+        } else {
             const float approximate = (float)next_sum * __builtin_amdgcn_rcpf((float)next_length);
             const float average_error = fmaxf(fabsf(approximate) * 0x1p-20f, 0x1p-120f);
             pmc_accepts_m = pmc_fast_m & lean_passes<KIND>(pmc_fast, next_min, approximate, average_error) &
@@ -2996,11 +3063,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             FIT_CHECK(hipStreamSynchronize(ctx->stream));
             fast = inexact == 0;
         }
-        const bool lean = fast && fit_lean_setting() && eb.kind != MDB_EB_LOSSLESS;
+        const bool lean = fast && fit_lean_setting();
         // Timestamps that have to be loaded (some chunk is irregular), all of them exact as f64: the
         // straight-line fitter with a ring of timestamps.
-        const bool lean_ts = ts && chunk_irregular && regular_verdict[1] == 0 && fit_fast_setting() &&
-                             fit_lean_setting() && eb.kind != MDB_EB_LOSSLESS;
+        const bool lean_ts = ts && chunk_irregular && regular_verdict[1] == 0 && fit_fast_setting() && fit_lean_setting();
         uint32_t piece_points = split_piece_points(ctx, n_chunks, points_end);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_B, total_records * sizeof(ModelRec), &p));
         ModelRec *records = static_cast<ModelRec *>(p);
@@ -3028,8 +3094,9 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 1024);
                 leave.max_chunk_points = fit_wave_number("MDB_FIT_WAVE_MAX_CHUNK_POINTS", 262144);
                 // (2 300 cycles per step against split mode's 107 per point under a relative or absolute bound:
-                // k_fit_models_lean. Under a lossless one split mode is k_fit_models, and on the bench's mixed series
-                // every threshold above 3 only moved chunks to the slower side: 41 ms at 3, 54 at 12, 81 at 45.)
+                // k_fit_models_lean. Under a lossless one, on the bench's mixed series, every threshold above 3 only
+                // moved chunks to the slower side: 41 ms at 3, 54 at 12, 81 at 45 - measured with k_fit_models as
+                // split mode's fitter; the lean one that has replaced it is a fifth faster, which does not turn that.)
                 leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 3 : 20);
                 FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 4, ctx->stream));
             }
@@ -3084,21 +3151,25 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         if (!wave && piece_points == 0) {
             LaunchTimer timer(ctx, "k_fit_models");
             const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
-            if (lean_ts && eb.kind == MDB_EB_RELATIVE)
-                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_RELATIVE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
-            else if (lean_ts)
-                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_ABSOLUTE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+#define MDB_LAUNCH_LEAN(SPLIT, SPLIT_ARGS, HAS_TS)                                                                          \
+    do {                                                                                                                   \
+        if (eb.kind == MDB_EB_RELATIVE)                                                                                    \
+            hipLaunchKernelGGL((k_fit_models_lean<SPLIT, MDB_EB_RELATIVE, HAS_TS>), dim3(fit_blocks), dim3(FIT_THREADS), 0, \
+                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag);                    \
+        else if (eb.kind == MDB_EB_ABSOLUTE)                                                                               \
+            hipLaunchKernelGGL((k_fit_models_lean<SPLIT, MDB_EB_ABSOLUTE, HAS_TS>), dim3(fit_blocks), dim3(FIT_THREADS), 0, \
+                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag);                    \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_fit_models_lean<SPLIT, MDB_EB_LOSSLESS, HAS_TS>), dim3(fit_blocks), dim3(FIT_THREADS), 0, \
+                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag);                    \
+    } while (0)
+            if (lean_ts)
+                MDB_LAUNCH_LEAN(false, SplitArgs{}, true);
             else if (ts)
                 hipLaunchKernelGGL((k_fit_models<true, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
-            else if (lean && eb.kind == MDB_EB_RELATIVE)
-                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_RELATIVE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
-            else if (lean && eb.kind == MDB_EB_ABSOLUTE)
-                hipLaunchKernelGGL((k_fit_models_lean<false, MDB_EB_ABSOLUTE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                   ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
+            else if (lean)
+                MDB_LAUNCH_LEAN(false, SplitArgs{}, false);
             else if (fast)
                 hipLaunchKernelGGL((k_fit_models<false, false, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
@@ -3129,21 +3200,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             if (n_pieces > 0) {
                 LaunchTimer timer(ctx, "k_fit_models_split");
                 const uint32_t fit_blocks = (uint32_t)((n_pieces + FIT_THREADS - 1) / FIT_THREADS);
-                if (lean_ts && eb.kind == MDB_EB_RELATIVE)
-                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_RELATIVE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                       ctx->stream, args, split, record_base, records, plans, error_flag);
-                else if (lean_ts)
-                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_ABSOLUTE, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                if (lean_ts)
+                    MDB_LAUNCH_LEAN(true, split, true);
                 else if (ts)
                     hipLaunchKernelGGL((k_fit_models<true, true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                        ctx->stream, args, split, record_base, records, plans, error_flag);
-                else if (lean && eb.kind == MDB_EB_RELATIVE)
-                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_RELATIVE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                       ctx->stream, args, split, record_base, records, plans, error_flag);
-                else if (lean && eb.kind == MDB_EB_ABSOLUTE)
-                    hipLaunchKernelGGL((k_fit_models_lean<true, MDB_EB_ABSOLUTE>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
-                                       ctx->stream, args, split, record_base, records, plans, error_flag);
+                else if (lean)
+                    MDB_LAUNCH_LEAN(true, split, false);
                 else if (fast)
                     hipLaunchKernelGGL((k_fit_models<false, true, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                        ctx->stream, args, split, record_base, records, plans, error_flag);
