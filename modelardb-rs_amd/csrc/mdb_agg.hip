@@ -497,10 +497,41 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     // A batch that stays on the device has (from its first grid or aggregate call on) cursors into its MacaqueV
     // streams: SUM then decodes them piece by piece (mdb_grid.hip, k_agg_mv_pieces) instead of one lane per stream.
     if (sums_wanted && mv_index_ensure(ctx, in)) return 1;
-    if ((range || (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM))) &&
-        ts_walk_for_aggregates(ctx, in, s, sums_wanted, TimeRange{t_lo, t_hi, range ? 1 : 0}, &walked_totals, &walked_sums,
-                               &walked_ranges, &walked_error))
-        return 1;
+    // What that walk finds is the same for every call without a time range: a batch that stays on the device keeps it
+    // (MvIndex::agg_walk_*, as the grid path keeps its cursors; MDB_GRID_TS_CACHE=0: walk every time).
+    const bool walk_wanted = range || (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM));
+    const char *cache_setting = std::getenv("MDB_GRID_TS_CACHE");
+    std::shared_ptr<MvIndex> resident;
+    const char *walk_setting = std::getenv("MDB_AGG_TS_WALK"); // (0: no walk, every lane for itself - nothing to keep)
+    if (walk_wanted && !range && !(cache_setting && std::strcmp(cache_setting, "0") == 0) &&
+        !(walk_setting && std::strcmp(walk_setting, "0") == 0))
+        resident = owned_segments_index(in);
+    bool walk_kept = false, keep_walk = false;
+    if (resident) {
+        std::lock_guard<std::mutex> lock(resident->mutex);
+        if (resident->agg_walk_built && (!sums_wanted || resident->agg_walk_with_sums)) {
+            walk_kept = true;
+            walked_totals = static_cast<const uint32_t *>(resident->agg_walk_totals); // (nullptr: no such streams)
+            walked_sums = sums_wanted ? static_cast<const double *>(resident->agg_walk_sums) : nullptr;
+        }
+    }
+    if (walk_wanted && !walk_kept) {
+        if (ts_walk_for_aggregates(ctx, in, s, sums_wanted, TimeRange{t_lo, t_hi, range ? 1 : 0}, &walked_totals, &walked_sums,
+                                   &walked_ranges, &walked_error))
+            return 1;
+        if (resident) { // copied now (the scratch is reused), valid once this call has found no fault in the streams
+            std::lock_guard<std::mutex> lock(resident->mutex);
+            keep_walk = true;
+            if (walked_totals) {
+                if (!resident->agg_walk_totals) MDB_HIP_CHECK(hipMalloc(&resident->agg_walk_totals, in->n * 4));
+                MDB_HIP_CHECK(hipMemcpyAsync(resident->agg_walk_totals, walked_totals, in->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                if (walked_sums) {
+                    if (!resident->agg_walk_sums) MDB_HIP_CHECK(hipMalloc(&resident->agg_walk_sums, in->n * 8));
+                    MDB_HIP_CHECK(hipMemcpyAsync(resident->agg_walk_sums, walked_sums, in->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+            }
+        }
+    }
     if (range) {
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
@@ -524,6 +555,11 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                                  ctx->stream));
     MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MDB_HIP_CHECK(hipGetLastError());
+    if (keep_walk && !host.error) {
+        std::lock_guard<std::mutex> lock(resident->mutex);
+        resident->agg_walk_built = true;
+        if (walked_sums || !walked_totals) resident->agg_walk_with_sums = true;
+    }
     if (host.error) return fail(describe_error(host.error));
     if (host.deferred > 0) {
         // Long MacaqueV streams were left aside for the decoders of mdb_grid.hip ...

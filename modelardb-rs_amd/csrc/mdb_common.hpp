@@ -179,15 +179,20 @@ struct MvIndex {
     void *ts_piece_base = nullptr;  // unsigned long long[n + 1]
     void *ts_slots = nullptr;       // the block TsCheckpoints points into
     void *ts_totals = nullptr;      // uint32_t[n + 4]
+    // And for the aggregates without a time range (agg_run): every irregular segment's number of points and, once a
+    // call has asked for sums, the sum of every Swing segment among them (ts_walk_for_aggregates), kept likewise.
+    bool agg_walk_built = false, agg_walk_with_sums = false;
+    void *agg_walk_totals = nullptr; // uint32_t[n]
+    void *agg_walk_sums = nullptr;   // double[n]
     // The index of ONE call over host batches (mv_host_index, mdb_grid.hip): made by host threads while the batches
     // are on their way, for the long streams only - a segment without pieces is the serial kernel's - and living in
     // the context's scratch.
     bool of_one_call = false;
     ~MvIndex() {
         if (of_one_call) return;
-        if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals) {
+        if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals || agg_walk_totals || agg_walk_sums) {
             (void)hipSetDevice(device);
-            for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals})
+            for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals, agg_walk_totals, agg_walk_sums})
                 if (allocation) (void)hipFree(allocation);
         }
     }

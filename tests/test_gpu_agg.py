@@ -387,3 +387,46 @@ def test_sum_over_resident_batches_comes_from_the_cursor_index(hip):
         lo, hi = int(batch.start_time[len(batch) // 3]), int(batch.end_time[2 * len(batch) // 3])
         _assert_state(hip.agg_batch_range_dev(resident, lo, hi, ALL), ora.agg_batch_range(batch, lo, hi, ALL))
         resident.free()
+
+
+def test_a_resident_batch_keeps_what_the_walk_of_its_timestamps_found(hip, monkeypatch):
+    # Aggregates without a time range over segments with irregular timestamps: len() and swing::sum come from a walk
+    # of the streams that is the same every time, so a batch that stays on the device keeps its result - the counts
+    # from the first call on, the sums from the first call that asks for them - and later calls do not walk.
+    monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)   # (the mode without the walk has nothing to keep)
+    rng = np.random.default_rng(29)
+    n = 200_000
+    timestamps = 1_600_000_000_000_000 + np.cumsum(rng.integers(900, 1100, n).astype(np.int64))
+    values = (np.linspace(-5.0, 9.0, n) + 2 * np.sin(np.arange(n) / 900.0)).astype(np.float32)
+    offsets = np.arange(0, n + 1, 4000, dtype=np.uint64)
+    segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()["rel5"])
+    expected = ora.agg_batch(segments, ALL)
+    transient = hip.agg_batch(segments, ALL)
+    resident = hip.upload_segments(segments)
+
+    def call(mask):
+        hip.profile_enable(True)
+        hip.profile_reset()
+        state = hip.agg_batch_dev(resident, mask)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        return state, kernels
+
+    counted, kernels = call(mdb.MDB_AGG_COUNT)
+    assert "k_grid_ts_count" in kernels and counted.count == n
+    counted, kernels = call(mdb.MDB_AGG_COUNT)
+    assert "k_grid_ts_count" not in kernels and counted.count == n
+    state, kernels = call(ALL)                      # the sums have not been asked for yet: one more walk
+    assert "k_grid_ts_count" in kernels
+    for _ in range(2):
+        again, kernels = call(ALL)
+        assert "k_grid_ts_count" not in kernels
+        for got in (state, again):
+            assert (got.count, got.min, got.max) == (transient.count, transient.min, transient.max)
+            assert np.float64(got.sum).tobytes() == np.float64(transient.sum).tobytes()
+    _assert_state(state, expected)
+    monkeypatch.setenv("MDB_GRID_TS_CACHE", "0")    # (the switch: walk every time)
+    again, kernels = call(ALL)
+    assert "k_grid_ts_count" in kernels
+    assert np.float64(again.sum).tobytes() == np.float64(transient.sum).tobytes()
+    resident.free()
