@@ -452,8 +452,8 @@ def mixed_models(context, mdb, np, ora, args):
     out = {"points": total, "series": series, "distinct_series": distinct,
            "note": "the reference's acceptance recipe (compression.rs:733-863): runs of 50..500 points, Constant / Linear "
                    "/ Random(100..200), every second series with noise 1.0..1.05 added, regular timestamps; chunks of "
-                   "65 536 points; fit: second of two calls; grid and aggregates: median of 5 calls on the resident "
-                   "segments; bytes: 4 B/point read by the fit, 73 B/segment + out-of-line payloads + 12 B/point for "
+                   "65 536 points; fit: second of two calls; grid and aggregates (all points; the middle half of the "
+                   "time axis): median of 5 calls on the resident segments; bytes: 4 B/point read by the fit, 73 B/segment + out-of-line payloads + 12 B/point for "
                    "grid, 73 B/segment + out-of-line payloads for the aggregates; checked: the first two series "
                    "(one without, one with noise) fitted by the oracle == the GPU's segments, their grid == the "
                    "oracle's, COUNT == points"}
@@ -477,9 +477,14 @@ def mixed_models(context, mdb, np, ora, args):
         shape = {"segments": len(segments), "out_of_line_payload_bytes": payload_bytes,
                  "fit": {"ms": 1e3 * fit_seconds, "points_per_s": total / fit_seconds, "kernels_ms": fit_kernels,
                          "GB_per_s": 4.0 * total / fit_seconds / 1e9, "frac_of_hbm_peak": 4.0 * total / fit_seconds / 1e9 / HBM_PEAK_GBPS}}
+        # (WHERE timestamp BETWEEN the quartiles of the series' common time axis, N1: half of every series' points)
+        t_lo, t_hi = int(sample_ts[points // 4]), int(sample_ts[3 * points // 4])
+        between = series * int(np.count_nonzero((sample_ts >= t_lo) & (sample_ts <= t_hi)))
         for name, call, algorithmic in (
                 ("grid", lambda: context.grid_batch_dev(segments, out_ts, out_val, n), 73.0 * len(segments) + payload_bytes + 12.0 * n),
-                ("aggregates", lambda: context.agg_batch_dev(segments, mask), 73.0 * len(segments) + payload_bytes)):
+                ("aggregates", lambda: context.agg_batch_dev(segments, mask), 73.0 * len(segments) + payload_bytes),
+                ("aggregates_between_quartiles", lambda: context.agg_batch_range_dev(segments, t_lo, t_hi, mask),
+                 73.0 * len(segments) + payload_bytes / 2.0)):
             result = call()
             context.profile_enable(True); context.profile_reset()
             timings = []
@@ -494,6 +499,9 @@ def mixed_models(context, mdb, np, ora, args):
             context.profile_enable(False)
             if name == "grid":
                 shape["segment_mix"] = result[1]
+            elif name == "aggregates_between_quartiles":
+                if result.count != between:
+                    raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: COUNT {result.count} BETWEEN, expected {between}")
             elif result.count != total:
                 raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: COUNT {result.count} of {total} points")
             else:

@@ -428,7 +428,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
                                                            AggPartial *__restrict__ partials,
                                                            const uint32_t *__restrict__ walked_totals,
                                                            const TsWalkRange *__restrict__ walked_ranges,
-                                                           const unsigned int *__restrict__ walked_error) {
+                                                           const unsigned int *__restrict__ walked_error,
+                                                           const unsigned long long *__restrict__ indexed_piece_base) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
     if (walked_error && blockIdx.x == 0 && threadIdx.x == 0) p.error |= *walked_error;
@@ -440,6 +441,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
         if (mode == AGG_SUM_ONLY_DEFERRED && s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
         SegInfo info = analyse_segment(s, i, walked_totals);
         uint32_t error = info.error;
+        // MacaqueV segments with cursors into their stream: piece by piece (k_agg_mv_range, mdb_grid.hip).
+        if (indexed_piece_base && indexed_piece_base[i + 1] > indexed_piece_base[i] && mv_range_by_pieces(s, i, info)) continue;
         // Long MacaqueV streams are left to the decoders of mdb_grid.hip (see AGG_SUM_DEFER).
         const uint32_t deferred_values =
             (mode != AGG_SUM_ALL && !error && s.model_type_id[i] == MDB_MACAQUE_V_ID)
@@ -497,6 +500,14 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     // A batch that stays on the device has (from its first grid or aggregate call on) cursors into its MacaqueV
     // streams: SUM then decodes them piece by piece (mdb_grid.hip, k_agg_mv_pieces) instead of one lane per stream.
     if (sums_wanted && mv_index_ensure(ctx, in)) return 1;
+    // Under a time range the same cursors let the points inside it be decoded piece by piece (MDB_AGG_RANGE_PIECES=0:
+    // one lane per stream, or the parallel decoder for the long ones).
+    std::shared_ptr<MvIndex> range_index;
+    const unsigned long long *indexed_piece_base = nullptr;
+    const char *range_pieces_setting = std::getenv("MDB_AGG_RANGE_PIECES");
+    if (range && !(range_pieces_setting && std::strcmp(range_pieces_setting, "0") == 0) &&
+        mv_index_for_range(ctx, in, &range_index, &indexed_piece_base))
+        return 1;
     // What that walk finds is the same for every call without a time range: a batch that stays on the device keeps it
     // (MvIndex::agg_walk_*, as the grid path keeps its cursors; MDB_GRID_TS_CACHE=0: walk every time).
     const bool walk_wanted = range || (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM));
@@ -535,7 +546,8 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     if (range) {
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
-                           t_hi, AGG_SUM_DEFER, mv_min_values, partials, walked_totals, walked_ranges, walked_error);
+                           t_hi, AGG_SUM_DEFER, mv_min_values, partials, walked_totals, walked_ranges, walked_error,
+                           indexed_piece_base);
     } else {
         const float *stream_sums = nullptr;
         const unsigned long long *only_with_pieces = nullptr;
@@ -567,7 +579,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
         DeferredTotals totals;
         const TimeRange time_range = {t_lo, t_hi, range ? 1 : 0};
         if (macaque_deferred(ctx, s, time_range, mv_min_values, mv_forced, host.deferred, host.deferred_values,
-                             host.deferred_bytes, &handled, &totals))
+                             host.deferred_bytes, &handled, &totals, indexed_piece_base))
             return 1;
         if (!handled) { // ... or, if those decline, one lane per stream here after all
             if (range) {
@@ -575,7 +587,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                 hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
                                    t_hi, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials,
                                    static_cast<const uint32_t *>(nullptr), static_cast<const TsWalkRange *>(nullptr),
-                                   static_cast<const unsigned int *>(nullptr));
+                                   static_cast<const unsigned int *>(nullptr), indexed_piece_base);
             } else {
                 LaunchTimer timer(ctx, "k_agg_segments");
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,
@@ -606,6 +618,14 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             host.min = totals.min < host.min ? totals.min : host.min;
             host.max = totals.max > host.max ? totals.max : host.max;
         }
+    }
+    if (indexed_piece_base) {
+        DeferredTotals by_pieces;
+        if (mv_index_range_totals(ctx, s, TimeRange{t_lo, t_hi, 1}, *range_index, &by_pieces)) return 1;
+        host.sum += by_pieces.sum;
+        host.count += by_pieces.count;
+        host.min = by_pieces.min < host.min ? by_pieces.min : host.min;
+        host.max = by_pieces.max > host.max ? by_pieces.max : host.max;
     }
     // Fold into the caller's running state exactly as update_batch would continue it.
     if (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG)) inout->count += host.count;
@@ -678,11 +698,17 @@ int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t
 int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                         uint32_t which_mask, mdb_agg_state *inout) {
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
+    // (cursors into the long MacaqueV streams that reach into the range, by host threads: see mdb_agg_batch)
+    MvCallIndex index;
+    const MvHostRange host_range{t_lo, t_hi};
+    mv_call_index_build(in, &index, &host_range);
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
-    int rc = agg_run(ctx, &dev->seg, true, t_lo, t_hi, which_mask, inout);
+    int rc = mv_call_index_use(ctx, dev->seg, index);
+    if (!rc) rc = agg_run(ctx, &dev->seg, true, t_lo, t_hi, which_mask, inout);
+    mv_call_index_done();
     mdb_segments_free(dev);
     return rc;
 }

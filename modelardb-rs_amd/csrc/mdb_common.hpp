@@ -284,6 +284,7 @@ uint32_t macaque_parallel_min_values(bool *forced);
 struct DevSegments;
 // (with a cursor index into the batch's MacaqueV streams, MvIndex: their f32 sums, 2 per segment)
 int mv_index_ensure(mdb_ctx *ctx, const mdb_segments *in);
+int mv_index_for_range(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvIndex> *index, const unsigned long long **piece_base);
 int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, const uint32_t *known_totals,
                          const float **stream_sums, const unsigned long long **only_with_pieces);
 

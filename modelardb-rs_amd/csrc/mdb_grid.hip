@@ -3198,9 +3198,12 @@ struct DeferredItem {
     DevSegments s;
     uint32_t min_values;
     TimeRange range;
+    const unsigned long long *by_pieces; // (under a time range: the index whose segments k_agg_mv_range takes, or nullptr)
     __device__ uint64_t operator()(uint64_t i) const {
         if (s.model_type_id[i] != MDB_MACAQUE_V_ID) return 0;
-        const uint32_t values = mv_deferred_values(s, i, analyse_segment(s, i), min_values, range);
+        const SegInfo info = analyse_segment(s, i);
+        if (by_pieces && by_pieces[i + 1] > by_pieces[i] && mv_range_by_pieces(s, i, info)) return 0;
+        const uint32_t values = mv_deferred_values(s, i, info, min_values, range);
         return values ? (DEFERRED_ONE | values) : 0;
     }
 };
@@ -3479,6 +3482,56 @@ __global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_range_finish(const Ran
     }
 }
 
+// Aggregates under a time range over a batch with cursors into its MacaqueV streams (a resident batch's sidecar, or
+// what the call's host threads left): one lane per piece of 64 values, as k_grid_mv_pieces - but only the pieces that
+// reach into the range are decoded, and only as far as it goes; what the points inside it contribute (GridExec +
+// filter + aggregate: f64 sum of the f32 values, count, extremes) is reduced per wave. Taken are the MacaqueV
+// segments with regular timestamps, no residuals and pieces in the index - the ones k_agg_range leaves out by the
+// same test (mv_range_by_pieces).
+__global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRange range, const MvCursor *__restrict__ cursors,
+                                                           unsigned long long n_pieces, RangePartial *__restrict__ partials) {
+    const int lane = threadIdx.x;
+    const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
+    RangePartial mine;
+    mine.clear();
+    uint32_t to_decode = 0, to_skip = 0;
+    LeanReaderDev reader;
+    MvPieceState state;
+    state.last = 0; state.leading = 255; state.trailing = 0; state.raw = false;
+    if (piece < n_pieces) {
+        const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
+        const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
+        const uint32_t i = c0.z, point_index = c0.w, n_values = c1.x, window = c1.y;
+        if (!(window & MV_WINDOW_RESIDUAL) && !(s.end_time[i] < range.lo || s.start_time[i] > range.hi)) {
+            SegInfo info = analyse_segment(s, i);
+            if (mv_range_by_pieces(s, i, info)) {
+                apply_time_range(s, i, info, range);
+                const uint32_t from = max(point_index, info.desc.first);
+                const uint32_t upto = min(point_index + n_values, info.desc.first + info.desc.n_visible);
+                if (info.desc.n_visible > 0 && from < upto) {
+                    to_decode = upto - point_index;
+                    to_skip = from - point_index;
+                    const uint4 view = s.values.views[i];
+                    reader.open(view_data(s.values, i, view), (uint64_t)view.x, c0.x);
+                    state.last = c0.y;
+                    state.leading = window & 255u;
+                    state.trailing = (window >> 8) & 255u;
+                    state.raw = (window & MV_WINDOW_RAW) != 0;
+                }
+            }
+        }
+    }
+    for (uint32_t k = 0; __any(k < to_decode); k++) {
+        if (k < to_decode) {
+            const uint32_t bits = lean_decode_value(reader, state);
+            if (k >= to_skip) mine.point(__uint_as_float(bits));
+        }
+    }
+#pragma unroll
+    for (int delta = MDB_WAVE / 2; delta > 0; delta >>= 1) mine.merge(shfl_down_partial(mine, delta));
+    if (lane == 0) partials[blockIdx.x] = mine;
+}
+
 // One workgroup, fixed order (strided partial sums, then a fixed tree): the result does not depend
 // on how the work was scheduled.
 __global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_sums_finish(const float *__restrict__ sums, uint64_t n_slots,
@@ -3507,7 +3560,7 @@ uint32_t macaque_parallel_min_values(bool *forced) {
 // false only when the counts are beyond what the scan item can carry.
 int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,
                      uint64_t n_streams, uint64_t n_values, uint64_t n_bytes, bool *handled,
-                     DeferredTotals *totals) {
+                     DeferredTotals *totals, const unsigned long long *by_pieces) {
     *handled = false;
     if (n_streams == 0 || n_values >= DEFERRED_ONE) return 0;
     // Few enough streams for the parallel decoder (the gate of mv_pipeline)? Then their values go to
@@ -3532,7 +3585,7 @@ int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32
     at += per_stream_bytes;
     DeferredResult *result = reinterpret_cast<DeferredResult *>(at);
     MDB_HIP_CHECK(hipMemsetAsync(result, 0, sizeof(DeferredResult), ctx->stream));
-    if (device_exclusive_scan(ctx, DeferredItem{s, min_values, range}, s.n, scan, block_sums, "k_mv_deferred_scan"))
+    if (device_exclusive_scan(ctx, DeferredItem{s, min_values, range, by_pieces}, s.n, scan, block_sums, "k_mv_deferred_scan"))
         return 1;
     auto select = [&](MvSeg *segs) {
         LaunchTimer timer(ctx, "k_mv_select");
@@ -3581,6 +3634,48 @@ int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32
     MDB_HIP_CHECK(hipGetLastError());
     if (host.error) return fail(describe_error(host.error));
     *handled = true;
+    totals->sum = host.sum;
+    totals->count = host.count;
+    totals->min = host.min;
+    totals->max = host.max;
+    return 0;
+}
+
+// For agg_run under a time range: the batch's cursor index if it has a usable one (*piece_base stays nullptr
+// otherwise) - call it before the aggregates lay out their scratch, a resident batch's index is built here - ...
+int mv_index_for_range(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvIndex> *index, const unsigned long long **piece_base) {
+    *piece_base = nullptr;
+    if (mv_index_prepare(ctx, in, index)) return 1;
+    if (!*index) return 0;
+    std::lock_guard<std::mutex> lock((*index)->mutex);
+    if (!(*index)->built || !(*index)->usable || (*index)->n_pieces == 0) {
+        index->reset();
+        return 0;
+    }
+    *piece_base = static_cast<const unsigned long long *>((*index)->piece_base);
+    return 0;
+}
+// ... and what the indexed MacaqueV segments' points inside the range add up to (k_agg_mv_range).
+int mv_index_range_totals(mdb_ctx *ctx, const DevSegments &s, TimeRange range, const MvIndex &index, DeferredTotals *totals) {
+    const uint32_t n_blocks = (uint32_t)((index.n_pieces + MDB_WAVE - 1) / MDB_WAVE);
+    void *p = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_AGG_MV, (uint64_t)n_blocks * sizeof(RangePartial) + 256, &p)) return 1;
+    RangePartial *partials = static_cast<RangePartial *>(p);
+    DeferredResult *result = reinterpret_cast<DeferredResult *>(reinterpret_cast<uint8_t *>(p) + align_up((uint64_t)n_blocks * sizeof(RangePartial), 256));
+    MDB_HIP_CHECK(hipMemsetAsync(result, 0, sizeof(DeferredResult), ctx->stream));
+    {
+        LaunchTimer timer(ctx, "k_agg_mv_range");
+        hipLaunchKernelGGL(k_agg_mv_range, dim3(n_blocks), dim3(MDB_WAVE), 0, ctx->stream, s, range,
+                           static_cast<const MvCursor *>(index.cursors), index.n_pieces, partials);
+    }
+    {
+        LaunchTimer timer(ctx, "k_mv_range_finish");
+        hipLaunchKernelGGL(k_mv_range_finish, dim3(1), dim3(MV_FINISH_THREADS), 0, ctx->stream, partials, (uint64_t)n_blocks, result);
+    }
+    DeferredResult host;
+    MDB_HIP_CHECK(hipMemcpyAsync(&host, result, sizeof(DeferredResult), hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MDB_HIP_CHECK(hipGetLastError());
     totals->sum = host.sum;
     totals->count = host.count;
     totals->min = host.min;
@@ -3934,8 +4029,8 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
 } // namespace
 
 // For mdb_agg.hip: the same around an aggregate call over one host batch.
-void mdb::mv_call_index_build(const mdb_segments *in, MvCallIndex *out) {
-    mv_host_index(&in, 1, &out->piece_base, &out->cursors);
+void mdb::mv_call_index_build(const mdb_segments *in, MvCallIndex *out, const MvHostRange *range) {
+    mv_host_index(&in, 1, &out->piece_base, &out->cursors, range);
 }
 int mdb::mv_call_index_use(mdb_ctx *ctx, const mdb_segments &uploaded, const MvCallIndex &index) {
     if (mv_host_index_attach(ctx, uploaded, index.piece_base, index.cursors, &t_call_index)) return 1;

@@ -92,9 +92,12 @@ struct MvCallIndex {
     std::vector<MvCursor> cursors;
 };
 // mdb_mv_host_index.cpp: piece_base (rows + 1) and cursors of the long MacaqueV streams of a list of host batches.
+struct MvHostRange { // (optional) only the segments with a point in [lo, hi], by their start and end time
+    int64_t lo, hi;
+};
 void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
-                   std::vector<MvCursor> *cursors);
-void mv_call_index_build(const mdb_segments *in, MvCallIndex *out);
+                   std::vector<MvCursor> *cursors, const MvHostRange *range = nullptr);
+void mv_call_index_build(const mdb_segments *in, MvCallIndex *out, const MvHostRange *range = nullptr);
 int mv_call_index_use(mdb_ctx *ctx, const mdb_segments &uploaded, const MvCallIndex &index);
 void mv_call_index_done();
 

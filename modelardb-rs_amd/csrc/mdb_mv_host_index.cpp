@@ -218,7 +218,7 @@ void host_index_share(unsigned, void *arg) {
 // piece_base (rows + 1) and cursors of the call's long streams; both stay empty when there is nothing to index
 // (MDB_GRID_MV_INDEX=0 included).
 void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
-                          std::vector<MvCursor> *cursors) {
+                          std::vector<MvCursor> *cursors, const MvHostRange *range) {
     piece_base->clear();
     cursors->clear();
     const char *setting = std::getenv("MDB_GRID_MV_INDEX");
@@ -256,6 +256,7 @@ void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<u
         const mdb_segments &seg = *ins[h];
         for (uint64_t i = 0; i < seg.n; i++) {
             if (seg.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
+            if (range && (seg.end_time[i] < range->lo || seg.start_time[i] > range->hi)) continue;
             const HostViewBytes ts = host_view_bytes(seg.timestamps, i);
             if (ts.length > 0 && (ts.data[0] & 0x80u) != 0 && ts.length * 8 + 1 >= min_values) counting.segments.push_back({h, i});
         }
@@ -278,6 +279,8 @@ void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<u
         const mdb_segments &seg = *ins[h];
         for (uint64_t i = 0; i < seg.n; i++) {
             if (seg.model_type_id[i] != MDB_MACAQUE_V_ID) continue; // (residual tails alone are short: at most 255 values)
+            // (a call under a time range, the aggregates': the segments that do not reach into it are nobody's)
+            if (range && (seg.end_time[i] < range->lo || seg.start_time[i] > range->hi)) continue;
             uint32_t n_total = 0;
             if (next_counted < counting.segments.size() && counting.segments[next_counted] == std::make_pair(h, i)) {
                 n_total = counting.points[next_counted++];

@@ -815,6 +815,15 @@ __device__ __forceinline__ uint32_t mv_deferred_values(const DevSegments &s, uin
     return mv_qualifies(info, bytes, min_values) ? info.desc.n_visible : 0u;
 }
 
+// Under a time range, with cursors into the batch's MacaqueV streams: is segment i (analysed: `info`) aggregated piece
+// by piece (k_agg_mv_range, mdb_grid.hip) rather than by k_agg_range's lane? Evaluated identically by both; the
+// caller adds that the segment has pieces in the index.
+__device__ __forceinline__ bool mv_range_by_pieces(const DevSegments &s, uint64_t i, const SegInfo &info) {
+    const SegDesc &d = info.desc;
+    return !info.error && (d.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID && (d.flags & FLAG_REGULAR) &&
+           !(d.flags & FLAG_HAS_RESIDUALS) && d.n_model == d.n_total;
+}
+
 // Does the walk of the irregular timestamp streams (k_grid_ts_count<SUMS>, mdb_grid.hip) add up segment i's
 // values for the aggregates? A Swing segment without residuals: swing::sum needs every timestamp of such a
 // segment (swing.rs:283-299) and nothing else. Evaluated identically by the walk and by k_agg_segments.
@@ -840,8 +849,9 @@ int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegmen
                            const uint32_t **totals, const double **sums, const TsWalkRange **ranges,
                            const unsigned int **error_word);
 
+int mv_index_range_totals(mdb_ctx *ctx, const DevSegments &s, TimeRange range, const MvIndex &index, DeferredTotals *totals);
 int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,
                      uint64_t n_streams, uint64_t n_values, uint64_t n_bytes, bool *handled,
-                     DeferredTotals *totals);
+                     DeferredTotals *totals, const unsigned long long *by_pieces = nullptr);
 
 } // namespace mdb

@@ -4,6 +4,7 @@
 // fitter stores them; from every cursor the values of its piece are decoded again by the few lines below - a
 // restatement of what k_grid_mv_pieces does with a cursor - and have to be the oracle's own decode of the stream,
 // bit for bit. Built by tests/test_mv_host_index_cpu.py, plain and under AddressSanitizer / UBSan / ThreadSanitizer.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -246,6 +247,28 @@ int main() {
         }
     }
     const size_t n_cursors = cursors.size();
+    // Under a time range (the range aggregates' call): the segments that do not reach into it get no pieces, the
+    // others exactly the ones they have without it.
+    {
+        std::vector<int64_t> sorted_starts(starts.begin(), starts.end());
+        std::sort(sorted_starts.begin(), sorted_starts.end());
+        const mdb::MvHostRange range{sorted_starts[n_segments / 3], sorted_starts[2 * n_segments / 3]};
+        std::vector<unsigned long long> ranged_base;
+        std::vector<mdb::MvCursor> ranged_cursors;
+        mdb::mv_host_index(list, 2, &ranged_base, &ranged_cursors, &range);
+        expect(ranged_base.size() == n_segments + 1, "piece_base under a range has rows + 1 entries", ranged_base.size(), n_segments + 1);
+        size_t outside = 0;
+        for (size_t i = 0; i < n_segments && ranged_base.size() == n_segments + 1; i++) {
+            const bool reaches = !(ends[i] < range.lo || starts[i] > range.hi);
+            const uint64_t expected = reaches ? piece_base[i + 1] - piece_base[i] : 0;
+            expect(ranged_base[i + 1] - ranged_base[i] == expected, "pieces of a segment under a time range", i, expected);
+            outside += reaches ? 0 : 1;
+            for (uint64_t q = 0; q < expected && ranged_base[i + 1] - ranged_base[i] == expected; q++)
+                expect(std::memcmp(&ranged_cursors[ranged_base[i] + q], &cursors[piece_base[i] + q], sizeof(mdb::MvCursor)) == 0,
+                       "a cursor under a time range", i, q);
+        }
+        expect(outside > 0 && outside < n_segments, "the range leaves some segments out", outside, n_segments);
+    }
     // A malformed stream (a window that cannot be: `11`, 31 leading zeros, 63 meaningful bits): no index at all.
     size_t victim = 0;
     while (models[victim].n < 2) victim++;

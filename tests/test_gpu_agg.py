@@ -160,16 +160,24 @@ def test_sum_of_long_lossless_streams(hip, macaque_decoder, monkeypatch):
     assert abs(state.sum - per_stream) <= 1e-12 * abs(per_stream)
     # The same under a time range (what the reference computes with GridExec + filter + aggregate):
     # the values with index 300 000 .. 700 000, which lie in 8 of the 16 streams.
+    # With the host threads' cursors: the pieces that reach into the range (k_agg_mv_range); without: the parallel decoder.
     lo, hi = 300_000, 700_000
-    hip.profile_enable(True)
-    hip.profile_reset()
-    ranged = hip.agg_batch_range(segments, int(timestamps[lo]), int(timestamps[hi]), ALL)
-    kernels = hip.profile()
-    hip.profile_enable(False)
-    assert ("k_mv_range_finish" in kernels) == (macaque_decoder != "off")
     inside = values[lo:hi + 1]
-    assert (ranged.count, ranged.min, ranged.max) == (len(inside), inside.min(), inside.max())
-    assert abs(ranged.sum - float(inside.astype(np.float64).sum())) <= 1e-9 * abs(float(inside.astype(np.float64).sum()))
+    for index in ("on", "off"):
+        if index == "off":
+            monkeypatch.setenv("MDB_GRID_MV_INDEX", "0")
+        hip.profile_enable(True)
+        hip.profile_reset()
+        ranged = hip.agg_batch_range(segments, int(timestamps[lo]), int(timestamps[hi]), ALL)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        if index == "on":
+            assert "k_agg_mv_range" in kernels and "k_mv_range_partials" not in kernels
+        else:
+            assert "k_agg_mv_range" not in kernels and ("k_mv_range_finish" in kernels) == (macaque_decoder != "off")
+        assert (ranged.count, ranged.min, ranged.max) == (len(inside), inside.min(), inside.max())
+        assert abs(ranged.sum - float(inside.astype(np.float64).sum())) <= 1e-9 * abs(float(inside.astype(np.float64).sum()))
+    monkeypatch.delenv("MDB_GRID_MV_INDEX")
     monkeypatch.setenv("MDB_GRID_MV_MIN_VALUES", "off")
     serial = hip.agg_batch(segments, ALL)
     assert abs(state.sum - serial.sum) <= 1e-12 * abs(serial.sum)
@@ -429,4 +437,54 @@ def test_a_resident_batch_keeps_what_the_walk_of_its_timestamps_found(hip, monke
     again, kernels = call(ALL)
     assert "k_grid_ts_count" in kernels
     assert np.float64(again.sum).tobytes() == np.float64(transient.sum).tobytes()
+    resident.free()
+
+
+def test_range_aggregates_over_long_lossless_streams_go_piece_by_piece(hip, monkeypatch):
+    # WHERE timestamp BETWEEN over MacaqueV segments with cursors into their streams (a resident batch's sidecar, or the
+    # ones the call's host threads leave): only the pieces of 64 values that reach into the range are decoded
+    # (k_agg_mv_range). COUNT / MIN / MAX as GridExec + filter + aggregate, SUM to its tolerance; and the same as without
+    # the cursors (MDB_AGG_RANGE_PIECES=0).
+    import datagen
+    monkeypatch.delenv("MDB_AGG_RANGE_PIECES", raising=False)
+    n = 400_000
+    timestamps, values = datagen.sine_series(5, n)
+    offsets = np.arange(0, n + 50_000, 50_000, dtype=np.uint64)
+    offsets[-1] = n
+    segments = ora.compress_chunks(timestamps, values, offsets, cases.LOSSLESS)
+    assert (segments.model_type_id == mdb.MDB_MACAQUE_V_ID).sum() >= 8
+    resident = hip.upload_segments(segments)
+    ranges = [(int(timestamps[n // 4]), int(timestamps[3 * n // 4])),          # whole segments and two cut ones
+              (int(timestamps[70_001]), int(timestamps[70_130])),              # inside three pieces of one stream
+              (int(timestamps[99_990]) + 1, int(timestamps[100_010]) - 1),      # across two segments
+              (int(timestamps[0]) - 10, int(timestamps[0])),                   # the first point alone
+              (int(timestamps[-1]) + 1, int(timestamps[-1]) + 100),            # behind everything
+              (int(timestamps[0]) - 10, int(timestamps[-1]) + 10)]             # everything
+    for t_lo, t_hi in ranges:
+        expected = ora.agg_batch_range(segments, t_lo, t_hi, ALL)
+        inside = (timestamps >= t_lo) & (timestamps <= t_hi)
+        assert expected.count == int(inside.sum())
+        for where in ("resident", "host"):
+            call = ((lambda: hip.agg_batch_range_dev(resident, t_lo, t_hi, ALL)) if where == "resident"
+                    else (lambda: hip.agg_batch_range(segments, t_lo, t_hi, ALL)))
+            hip.profile_enable(True)
+            hip.profile_reset()
+            by_pieces = call()
+            kernels = hip.profile()
+            hip.profile_enable(False)
+            if where == "resident" or int(inside.sum()) > 0:
+                assert "k_agg_mv_range" in kernels, (where, t_lo, t_hi, sorted(kernels))
+            _assert_state(by_pieces, expected)
+            if expected.count:
+                assert np.float32(by_pieces.min) == values[inside].min() and np.float32(by_pieces.max) == values[inside].max()
+            monkeypatch.setenv("MDB_AGG_RANGE_PIECES", "0")
+            hip.profile_enable(True)
+            hip.profile_reset()
+            without = call()
+            kernels = hip.profile()
+            hip.profile_enable(False)
+            monkeypatch.delenv("MDB_AGG_RANGE_PIECES")
+            assert "k_agg_mv_range" not in kernels
+            assert (without.count, without.min, without.max) == (by_pieces.count, by_pieces.min, by_pieces.max)
+            assert abs(without.sum - by_pieces.sum) <= 1e-9 * max(abs(by_pieces.sum), 1e-30)
     resident.free()
