@@ -258,9 +258,10 @@ __device__ __forceinline__ float model_value_at(const SegDesc &d, uint32_t type,
 }
 
 // Aggregate the points of segment i whose timestamp lies in [t_lo, t_hi].
+// tail_by_pieces: the residual tail's points are k_agg_mv_range's (regular timestamps only).
 __device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, const SegInfo &info,
                                               int64_t t_lo, int64_t t_hi, RangeAcc &acc,
-                                              uint32_t *error) {
+                                              uint32_t *error, bool tail_by_pieces = false) {
     const SegDesc &d = info.desc;
     const uint32_t type = d.flags & FLAG_TYPE_MASK;
     const int64_t end = s.end_time[i];
@@ -320,33 +321,7 @@ __device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, 
 
     // Regular timestamps start + k * delta: the in-range indices are an interval [k_lo, k_hi].
     uint32_t k_lo = 0, k_hi = 0;
-    if (d.n_total <= 2 || d.delta <= 0) {
-        // One or two points (or a degenerate interval): test them one by one.
-        bool any = false;
-        for (uint32_t k = 0; k < d.n_total; k++) {
-            int64_t t = d.start + (int64_t)((uint64_t)k * (uint64_t)d.delta);
-            if (t < t_lo || t > t_hi) continue;
-            if (!any) { k_lo = k; any = true; }
-            k_hi = k;
-        }
-        if (!any) return;
-    } else {
-        const int64_t last_t = d.start + (int64_t)((uint64_t)(d.n_total - 1) * (uint64_t)d.delta);
-        if (last_t < t_lo || d.start > t_hi) return;
-        const uint64_t delta = (uint64_t)d.delta;
-        if (t_lo > d.start) {
-            uint64_t gap = (uint64_t)t_lo - (uint64_t)d.start;
-            uint64_t k = (gap + delta - 1) / delta;
-            if (k > d.n_total - 1) return;
-            k_lo = (uint32_t)k;
-        }
-        if (t_hi >= last_t) {
-            k_hi = d.n_total - 1;
-        } else {
-            k_hi = (uint32_t)(((uint64_t)t_hi - (uint64_t)d.start) / delta);
-        }
-        if (k_hi < k_lo) return;
-    }
+    if (!regular_index_interval(d.start, d.delta, d.n_total, t_lo, t_hi, &k_lo, &k_hi)) return;
 
     // Model part [a, b] of the interval.
     if (type != MDB_MACAQUE_V_ID && k_lo < d.n_model) {
@@ -408,7 +383,7 @@ __device__ __forceinline__ void segment_range(const DevSegments &s, uint64_t i, 
         }
         seed = __uint_as_float(last_bits);
     }
-    if (n_res > 0 && k_hi >= d.n_model) {
+    if (n_res > 0 && k_hi >= d.n_model && !tail_by_pieces) {
         const uint4 vr = s.residuals.views[i];
         const uint32_t upto = k_hi - d.n_model + 1;
         decode_macaque_v(view_data(s.residuals, i, vr), vr.x - 1, upto, true, __float_as_uint(seed),
@@ -442,7 +417,9 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
         SegInfo info = analyse_segment(s, i, walked_totals);
         uint32_t error = info.error;
         // MacaqueV segments with cursors into their stream: piece by piece (k_agg_mv_range, mdb_grid.hip).
-        if (indexed_piece_base && indexed_piece_base[i + 1] > indexed_piece_base[i] && mv_range_by_pieces(s, i, info)) continue;
+        const bool has_pieces = indexed_piece_base && indexed_piece_base[i + 1] > indexed_piece_base[i];
+        if (has_pieces && mv_range_by_pieces(s, i, info)) continue;
+        const bool tail_by_pieces = has_pieces && mv_range_tail_by_pieces(s, i, info);
         // Long MacaqueV streams are left to the decoders of mdb_grid.hip (see AGG_SUM_DEFER).
         const uint32_t deferred_values =
             (mode != AGG_SUM_ALL && !error && s.model_type_id[i] == MDB_MACAQUE_V_ID)
@@ -463,7 +440,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
                 acc.min = walked.min;
                 acc.max = walked.max;
             } else {
-                segment_range(s, i, info, t_lo, t_hi, acc, &error);
+                segment_range(s, i, info, t_lo, t_hi, acc, &error, tail_by_pieces);
             }
             p.sum += acc.sum;
             p.count += acc.count;

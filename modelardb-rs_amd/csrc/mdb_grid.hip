@@ -3487,7 +3487,9 @@ __global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_range_finish(const Ran
 // reach into the range are decoded, and only as far as it goes; what the points inside it contribute (GridExec +
 // filter + aggregate: f64 sum of the f32 values, count, extremes) is reduced per wave. Taken are the MacaqueV
 // segments with regular timestamps, no residuals and pieces in the index - the ones k_agg_range leaves out by the
-// same test (mv_range_by_pieces).
+// same test (mv_range_by_pieces) - and the residual tails of PMC-Mean and Swing segments with regular timestamps
+// (mv_range_tail_by_pieces; a resident batch's index has their cursors: in k_agg_range a tenth of the lanes of a
+// wave would each decode one while the others wait).
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRange range, const MvCursor *__restrict__ cursors,
                                                            unsigned long long n_pieces, RangePartial *__restrict__ partials) {
     const int lane = threadIdx.x;
@@ -3502,18 +3504,22 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRa
         const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
         const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
         const uint32_t i = c0.z, point_index = c0.w, n_values = c1.x, window = c1.y;
-        if (!(window & MV_WINDOW_RESIDUAL) && !(s.end_time[i] < range.lo || s.start_time[i] > range.hi)) {
+        if (!(s.end_time[i] < range.lo || s.start_time[i] > range.hi)) {
             SegInfo info = analyse_segment(s, i);
-            if (mv_range_by_pieces(s, i, info)) {
+            const bool residual = (window & MV_WINDOW_RESIDUAL) != 0;
+            if (residual ? mv_range_tail_by_pieces(s, i, info) : mv_range_by_pieces(s, i, info)) {
+                // (a tail is XOR-seeded with the model's last RECONSTRUCTED value, models/mod.rs:241-249: what grid() sees)
+                const uint32_t seed = residual ? __float_as_uint(info.desc.value) : 0u;
                 apply_time_range(s, i, info, range);
                 const uint32_t from = max(point_index, info.desc.first);
                 const uint32_t upto = min(point_index + n_values, info.desc.first + info.desc.n_visible);
                 if (info.desc.n_visible > 0 && from < upto) {
                     to_decode = upto - point_index;
                     to_skip = from - point_index;
-                    const uint4 view = s.values.views[i];
-                    reader.open(view_data(s.values, i, view), (uint64_t)view.x, c0.x);
-                    state.last = c0.y;
+                    const DevCol &column = residual ? s.residuals : s.values;
+                    const uint4 view = column.views[i];
+                    reader.open(view_data(column, i, view), residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
+                    state.last = seed ^ c0.y;
                     state.leading = window & 255u;
                     state.trailing = (window >> 8) & 255u;
                     state.raw = (window & MV_WINDOW_RAW) != 0;

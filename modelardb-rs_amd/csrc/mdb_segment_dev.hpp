@@ -95,6 +95,11 @@ __device__ __forceinline__ bool regular_index_interval(int64_t start, int64_t de
     }
     const int64_t last_t = start + (int64_t)((uint64_t)(n - 1) * (uint64_t)delta);
     if (last_t < lo || start > hi) return false;
+    if (lo <= start && hi >= last_t) { // the whole segment (most of the segments a range reaches into): no division
+        *k_lo = 0;
+        *k_hi = n - 1;
+        return true;
+    }
     uint32_t a = 0, b;
     if (lo > start) {
         uint64_t k = ((uint64_t)lo - (uint64_t)start + (uint64_t)delta - 1) / (uint64_t)delta;
@@ -822,6 +827,14 @@ __device__ __forceinline__ bool mv_range_by_pieces(const DevSegments &s, uint64_
     const SegDesc &d = info.desc;
     return !info.error && (d.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID && (d.flags & FLAG_REGULAR) &&
            !(d.flags & FLAG_HAS_RESIDUALS) && d.n_model == d.n_total;
+}
+
+// ... and the residual tail of a PMC-Mean or Swing segment (k_agg_range then takes the model's points only)?
+__device__ __forceinline__ bool mv_range_tail_by_pieces(const DevSegments &s, uint64_t i, const SegInfo &info) {
+    const SegDesc &d = info.desc;
+    const uint32_t type = d.flags & FLAG_TYPE_MASK;
+    return !info.error && (type == MDB_PMC_MEAN_ID || type == MDB_SWING_ID) && (d.flags & FLAG_REGULAR) &&
+           (d.flags & FLAG_HAS_RESIDUALS) && d.n_model < d.n_total;
 }
 
 // Does the walk of the irregular timestamp streams (k_grid_ts_count<SUMS>, mdb_grid.hip) add up segment i's
