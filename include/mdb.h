@@ -203,7 +203,8 @@ int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t
 /* Extension (BASELINE config 3): aggregates over the data points with
  * t_lo <= timestamp <= t_hi without materialising them. The reference has no such operator: any
  * WHERE on the timestamp falls back to GridExec + filter + AggregateExec
- * (model_simple_aggregates.rs:284-302), and that result is the parity oracle. */
+ * (model_simple_aggregates.rs:284-302), and that result is the parity oracle: COUNT / MIN / MAX of the
+ * reconstructed points inside the range, SUM their f64 sum. */
 int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                         uint32_t which_mask, mdb_agg_state *inout);
 int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,

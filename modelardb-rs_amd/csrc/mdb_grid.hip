@@ -735,17 +735,20 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(7
                                                               float *__restrict__ out_val, uint32_t *__restrict__ rows_per_segment,
                                                               uint64_t cap, TileDesc *__restrict__ desc,
                                                               unsigned long long *__restrict__ offsets,
-                                                              uint32_t *__restrict__ serial_ids) {
+                                                              uint32_t *__restrict__ serial_ids, bool list_serial) {
     __shared__ __attribute__((aligned(16))) TileDesc lds_desc[FUSED_THREADS];
     __shared__ uint32_t rel[FUSED_THREADS + 1]; // rel[k]: where segment k's points begin among the round's
     __shared__ uint64_t scan_lds[17];
     __shared__ unsigned long long lds_metrics[12];
     __shared__ unsigned long long block_base;
+    __shared__ uint32_t serial_in_round;
+    __shared__ uint32_t serial_of_round[FUSED_THREADS];
     __shared__ __attribute__((aligned(16))) longlong2 ts_slab[FUSED_THREADS / MDB_WAVE][2 * MDB_WAVE];
     const int lane = threadIdx.x & (MDB_WAVE - 1);
     const int wave = threadIdx.x / MDB_WAVE;
     constexpr int FUSED_SEGMENTS = FUSED_THREADS * FUSED_ROUNDS;
     if (threadIdx.x < 12) lds_metrics[threadIdx.x] = 0;
+    if (threadIdx.x == 12) serial_in_round = 0;
     const uint64_t block_first = (uint64_t)blockIdx.x * FUSED_SEGMENTS;
 
     // ---- how many points the workgroup's segments have, and where they begin in the output ---------------------
@@ -837,22 +840,39 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(7
         rel[threadIdx.x] = (uint32_t)exclusive;
         if (error) atomicOr(&header->error, error);
         if (rows_per_segment && i < s.n) rows_per_segment[i] = count;
-        // (the kernels behind this one look the segments with serial work up; a place in their list for each of the
-        // wave's with ONE atomic - one per segment on the one counter took 2 ms for a million of them)
+        // (the kernels behind this one look the segments with serial work up: a place in their list for each of the
+        // round's with ONE atomic - one per segment on the one counter took 2 ms for a million of them, one per wave
+        // 1 ms for the 160 000 waves of ten million short segments with residual tails; a plain store of a flag to
+        // one address by every wave, tried for the case below, 4.6 ms)
+        // With cursors into every stream of the batch (a resident batch's index) nobody reads the list: k_grid_mv_pieces
+        // goes by the cursors and needs the descriptors and offsets only. Otherwise the round's segments with serial
+        // work are gathered in LDS and the first wave moves them to the list with one atomic on its counter.
         const unsigned long long serial_lanes = __ballot(serial);
         if (serial_lanes) {
-            unsigned long long first_place = 0;
-            if (lane == __ffsll((long long)serial_lanes) - 1)
-                first_place = atomicAdd(&header->n_serial, (unsigned long long)__popcll(serial_lanes));
-            first_place = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(first_place >> 32), __ffsll((long long)serial_lanes) - 1) << 32) |
-                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)first_place, __ffsll((long long)serial_lanes) - 1);
+            const int first_lane = __ffsll((long long)serial_lanes) - 1;
+            uint32_t place = 0;
+            if (list_serial) {
+                if (lane == first_lane) place = atomicAdd(&serial_in_round, (uint32_t)__popcll(serial_lanes));
+                place = (uint32_t)__builtin_amdgcn_readlane((int)place, first_lane) + (uint32_t)__popcll(serial_lanes & ((1ull << lane) - 1ull));
+            }
             if (serial) {
                 desc[i] = mine;
                 offsets[i] = running + exclusive;
-                serial_ids[first_place + __popcll(serial_lanes & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                if (list_serial) serial_of_round[place] = (uint32_t)i;
             }
         }
         __syncthreads();
+        if (list_serial && wave == 0) {
+            const uint32_t listed = serial_in_round;
+            if (listed) {
+                unsigned long long first_place = 0;
+                if (lane == 0) first_place = atomicAdd(&header->n_serial, (unsigned long long)listed);
+                first_place = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(first_place >> 32), 0) << 32) |
+                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)first_place, 0);
+                for (uint32_t k = lane; k < listed; k += MDB_WAVE) serial_ids[first_place + k] = serial_of_round[k];
+                if (lane == 0) serial_in_round = 0; // (for the next round, which starts behind a barrier)
+            }
+        }
 
         // The round's points [base, end) of the output, four consecutive ones per lane and step; the groups of four
         // are aligned in the OUTPUT (16-byte stores), so the first and the last group may be shared with the
@@ -3860,11 +3880,13 @@ int grid_fused(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out
     MDB_HIP_CHECK(hipMemsetAsync(lookback, 0, n_blocks * 8, ctx->stream));
     MDB_HIP_CHECK(hipMemsetAsync(plan.header, 0, sizeof(GridHeader), ctx->stream));
     const DevSegments s = to_dev(in);
+    // (the list of segments with serial work is k_grid_serial's: not needed where cursors cover every stream)
+    const bool list_serial = !(plan.mv_index && !plan.mv_index->of_one_call);
     {
         LaunchTimer timer(ctx, "k_grid_fused");
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3((uint32_t)n_blocks), dim3(FUSED_THREADS), 0, ctx->stream, s, lookback, plan.header,
-                               out_ts, out_val, out_rows, cap, plan.desc, plan.offsets, plan.serial_ids);
+                               out_ts, out_val, out_rows, cap, plan.desc, plan.offsets, plan.serial_ids, list_serial);
         };
         if (rounds == 2) launch(k_grid_fused<2>);
         else if (rounds == 4) launch(k_grid_fused<4>);
@@ -3882,7 +3904,7 @@ int grid_fused(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out
     if (host.total_points > cap)
         return fail("Output buffers too small: " + std::to_string(host.total_points) + " data points but capacity " +
                     std::to_string(cap) + ".");
-    if (host.n_serial > 0) {
+    if (host.n_serial > 0 || (!list_serial && plan.mv_index->n_pieces > 0)) { // (without the list: the cursors say what there is)
         plan.mv_min_values = 0xffffffffu; // (the speculative decoder is for a few long streams: not this path's batches)
         plan.mv_forced = false;
         if (grid_launch_streams(ctx, s, TimeRange{0, 0, 0}, plan, out_ts, out_val)) return 1;
