@@ -2853,22 +2853,82 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_timestamps(FitArgs args, const
     if (carry_bits && lane == 0) dst[written] = (uint8_t)((buffer[0] >> 24) | ((1u << (8u - carry_bits)) - 1u));
 }
 
-__global__ __launch_bounds__(256) void k_fit_size(FitArgs args, const unsigned long long *__restrict__ record_base,
+// A lane of the two kernels below encodes what its segment holds of MacaqueV codes one value after the other: a
+// residual tail of up to 255 values (types.rs:224-262), or a gap shorter than the wave encoder's threshold. A wave is
+// done when its longest is - and in noisy data the tails run from nothing to 255 values (the reference's acceptance
+// series under 1 %: two thirds of them under 16 values, one in a hundred over 190), so that nearly every wave of 64
+// consecutive segments waited for a long one. The workgroup therefore deals its 1 024 segments to its lanes by that
+// length (a counting sort in LDS, classes of 16 values, the longest first): one wave takes the long ones, most take
+// segments with nothing of the kind. Every segment's results go to its own places: the order changes nothing else.
+constexpr int FIT_SEGMENT_THREADS = 1024;
+constexpr int FIT_WORK_CLASSES = 17; // 16 x 16 values (longest first), then: nothing
+
+__device__ __forceinline__ uint32_t serial_values_of(const FitArgs &args, const unsigned long long *record_base,
+                                                     const ModelRec *records, const SegItem &item) {
+    if (item.record == 0xffffffffu) return gap_goes_to_a_wave(args, item) ? 0u : item.last - item.first + 1;
+    const uint32_t model_end = records[record_base[item.chunk] + item.record].end;
+    return model_end < item.last ? item.last - model_end : 0u;
+}
+
+// The segment this lane takes (>= n_segments: none).
+__device__ __forceinline__ uint64_t segment_by_serial_work(const FitArgs &args, const unsigned long long *record_base,
+                                                           const ModelRec *records, const SegItem *items, uint64_t n_segments) {
+    __shared__ uint32_t class_count[FIT_WORK_CLASSES], class_next[FIT_WORK_CLASSES];
+    __shared__ uint16_t order[FIT_SEGMENT_THREADS];
+    const uint64_t block_first = (uint64_t)blockIdx.x * FIT_SEGMENT_THREADS;
+    const uint64_t mine = block_first + threadIdx.x;
+    const int lane = threadIdx.x & (MDB_WAVE - 1);
+    if (threadIdx.x < FIT_WORK_CLASSES) class_count[threadIdx.x] = 0;
+    __syncthreads();
+    int my_class = FIT_WORK_CLASSES - 1;
+    if (mine < n_segments) {
+        const uint32_t work = serial_values_of(args, record_base, records, items[mine]);
+        if (work > 0) my_class = 15 - (int)min(work >> 4, 15u);
+    }
+    // (a place per wave and class with one LDS atomic: the lanes of a class are counted with a ballot)
+    uint32_t rank_in_wave = 0, place = 0;
+#pragma unroll 1
+    for (int c = 0; c < FIT_WORK_CLASSES; c++) {
+        const unsigned long long lanes = __ballot(my_class == c);
+        if (lanes == 0) continue;
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(&class_count[c], (uint32_t)__popcll(lanes));
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        if (my_class == c) {
+            place = first;
+            rank_in_wave = (uint32_t)__popcll(lanes & ((1ull << lane) - 1ull));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t running = 0;
+        for (int c = 0; c < FIT_WORK_CLASSES; c++) {
+            class_next[c] = running;
+            running += class_count[c];
+        }
+    }
+    __syncthreads();
+    order[class_next[my_class] + place + rank_in_wave] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    return block_first + order[threadIdx.x];
+}
+
+__global__ __launch_bounds__(FIT_SEGMENT_THREADS) void k_fit_size(FitArgs args, const unsigned long long *__restrict__ record_base,
                                                   const ModelRec *__restrict__ records,
                                                   const SegItem *__restrict__ items, uint64_t n_segments,
                                                   SegSizes *__restrict__ sizes) {
-    const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t segment = segment_by_serial_work(args, record_base, records, items, n_segments);
     if (segment >= n_segments) return;
     SegSizes s = {0, 0, 0, 0};
     process_segment<false>(args, record_base, records, items[segment], segment, &s, nullptr);
     sizes[segment] = s;
 }
 
-__global__ __launch_bounds__(256) void k_fit_encode(FitArgs args, const unsigned long long *__restrict__ record_base,
+__global__ __launch_bounds__(FIT_SEGMENT_THREADS) void k_fit_encode(FitArgs args, const unsigned long long *__restrict__ record_base,
                                                     const ModelRec *__restrict__ records,
                                                     const SegItem *__restrict__ items, uint64_t n_segments,
                                                     const SegSizes *__restrict__ sizes, EncodeTargets targets) {
-    const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t segment = segment_by_serial_work(args, record_base, records, items, n_segments);
     if (segment >= n_segments) return;
     SegSizes s = sizes[segment];
     process_segment<true>(args, record_base, records, items[segment], segment, &s, &targets);
@@ -3300,7 +3360,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_size");
-            hipLaunchKernelGGL(k_fit_size, dim3(segment_blocks), dim3(256), 0, ctx->stream, args,
+            hipLaunchKernelGGL(k_fit_size, dim3((uint32_t)((n_segments + FIT_SEGMENT_THREADS - 1) / FIT_SEGMENT_THREADS)),
+                               dim3(FIT_SEGMENT_THREADS), 0, ctx->stream, args,
                                record_base, records, items, (uint64_t)n_segments, sizes);
         }
         unsigned long long data_bytes[3] = {0, 0, 0};
@@ -3399,7 +3460,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         }
         if (n_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_encode");
-            hipLaunchKernelGGL(k_fit_encode, dim3(segment_blocks), dim3(256), 0, ctx->stream, args,
+            hipLaunchKernelGGL(k_fit_encode, dim3((uint32_t)((n_segments + FIT_SEGMENT_THREADS - 1) / FIT_SEGMENT_THREADS)),
+                               dim3(FIT_SEGMENT_THREADS), 0, ctx->stream, args,
                                record_base, records, items, (uint64_t)n_segments, sizes, targets);
         }
         FIT_CHECK(hipStreamSynchronize(ctx->stream));
