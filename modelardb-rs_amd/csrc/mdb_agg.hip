@@ -15,6 +15,7 @@
 #include "mdb_segment_dev.hpp"
 
 #include <cfloat>
+#include <thread>
 
 namespace mdb {
 
@@ -618,6 +619,20 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
 
 using namespace mdb;
 
+// The host threads' walk of a call's long MacaqueV streams (mv_host_index) on a thread of its own, so that it runs
+// while the calling thread stages the batch and sends it across PCIe: a fold of 262 144 segments of the mixed series is
+// 9 ms of walking and 4 ms of upload. Joined before the index is used and on every way out.
+namespace {
+struct HostWalk {
+    std::thread thread;
+    template <typename Work> void start(Work work) { thread = std::thread(work); }
+    void finish() {
+        if (thread.joinable()) thread.join();
+    }
+    ~HostWalk() { finish(); }
+};
+} // namespace
+
 extern "C" {
 
 int mdb_agg_batch_dev(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask,
@@ -640,12 +655,15 @@ int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb
     if (!ctx || !in || !inout) return fail("ctx, in and inout must not be NULL.");
     // SUM decodes every value of a MacaqueV stream: the long ones piece by piece from cursors that host threads
     // leave while the batch is on its way (mdb_grid.hip, mv_host_index).
+    // (they walk while the batch is staged and crosses PCIe: HostWalk)
     MvCallIndex index;
-    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) mv_call_index_build(in, &index);
+    HostWalk walk;
+    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) walk.start([&index, in] { mv_call_index_build(in, &index); });
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
+    walk.finish();
     int rc = mv_call_index_use(ctx, dev->seg, index);
     if (!rc) rc = agg_run(ctx, &dev->seg, false, 0, 0, which_mask, inout);
     mv_call_index_done();
@@ -660,11 +678,14 @@ int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t
     for (uint32_t k = 0; k < n_inputs; k++)
         if (!inputs[k]) return fail("A batch of the list is NULL.");
     MvCallIndex index;
-    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) mv_host_index(inputs, n_inputs, &index.piece_base, &index.cursors);
+    HostWalk walk;
+    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG))
+        walk.start([&index, inputs, n_inputs] { mv_host_index(inputs, n_inputs, &index.piece_base, &index.cursors); });
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segment_list_locked(ctx, inputs, n_inputs, true, &dev)) return 1;
+    walk.finish();
     int rc = mv_call_index_use(ctx, dev->seg, index);
     if (!rc) rc = agg_run(ctx, &dev->seg, false, 0, 0, which_mask, inout);
     mv_call_index_done();
@@ -678,11 +699,13 @@ int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int6
     // (cursors into the long MacaqueV streams that reach into the range, by host threads: see mdb_agg_batch)
     MvCallIndex index;
     const MvHostRange host_range{t_lo, t_hi};
-    mv_call_index_build(in, &index, &host_range);
+    HostWalk walk;
+    walk.start([&index, in, &host_range] { mv_call_index_build(in, &index, &host_range); });
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segments_locked(ctx, in, true, &dev)) return 1;
+    walk.finish();
     int rc = mv_call_index_use(ctx, dev->seg, index);
     if (!rc) rc = agg_run(ctx, &dev->seg, true, t_lo, t_hi, which_mask, inout);
     mv_call_index_done();
