@@ -43,6 +43,8 @@ CHUNK_POINTS = 65536    # ingest buffer of the reference server (storage/mod.rs:
 SEED = 0x4D44425F52454631
 INTERVAL_US = 1000
 GRID_KERNEL_SOURCES = ("mdb_grid.hip", "mdb_segment_dev.hpp", "mdb_common.hpp")
+FIT_KERNEL_SOURCES = ("mdb_fit.hip", "mdb_segment_dev.hpp", "mdb_common.hpp")
+SHADER_CLOCK_MHZ = 2400.0  # hipDeviceAttributeClockRate of the MI355X (s_memtime against the host clock: 2.37-2.40 GHz under load)
 
 
 def parse_args():
@@ -76,6 +78,12 @@ def parse_args():
                         help="run the step untimed for this long before the warmup (lets clocks settle)")
     parser.add_argument("--fit-group-points", type=int, default=13_000_000_000,
                         help="at most this many raw points (4 B each) are resident per fit launch")
+    parser.add_argument("--timed", choices=("grid", "fit"), default="grid",
+                        help="what one timed step is: grid() of the rank's resident segments (BASELINE configs 2 / 5, "
+                             "the default) or the PMC-Mean / Swing / MacaqueV fit of the rank's resident values "
+                             "(BASELINE config 4: one mdb_compress_chunks_dev per step)")
+    parser.add_argument("--fit-repetitions", type=int, default=5,
+                        help="timed repetitions of every fit that is not the timed step (median, min, max reported)")
     return parser.parse_args()
 
 
@@ -185,16 +193,49 @@ def summary(seconds, units):
     return {"median": statistics.median(rates), "min": rates[0], "max": rates[-1], "repetitions": len(rates)}
 
 
+def fit_kernel_name(kernel_ms):
+    """The kernel that fitted the models of a call: the one of the k_fit_models family with the most time."""
+    family = {name: ms for name, ms in kernel_ms.items() if name.startswith("k_fit_models")}
+    return max(family, key=family.get) if family else "k_fit_models"
+
+
+def spread(seconds):
+    """{median, min, max, repetitions} of a repeated timing, in seconds."""
+    return {"median": statistics.median(seconds), "min": min(seconds), "max": max(seconds), "repetitions": len(seconds)}
+
+
+def timed_fit(context, call, repetitions):
+    """`call()` (a fit that returns device segments) once untimed - the context's scratch grows -, then `repetitions`
+    times under the wall clock with the kernels' HIP-event times; returns (segments of the last call, seconds[],
+    {kernel: mean ms per call})."""
+    call().free()
+    context.sync()
+    context.profile_enable(True)
+    context.profile_reset()
+    seconds, segments = [], None
+    for _ in range(max(1, repetitions)):
+        if segments is not None:
+            segments.free()
+        context.sync()
+        started = time.perf_counter()
+        segments = call()
+        context.sync()
+        seconds.append(time.perf_counter() - started)
+    kernels = {name: ms / len(seconds) for name, (launches, ms) in context.profile().items() if name.startswith("k_fit")}
+    context.profile_enable(False)
+    return segments, seconds, kernels
+
+
 def fit_on_gpu(context, mdb, np, args, rank, keep_series):
     """Generate this rank's series on the device and compress them with the HIP fitter, in groups of
     series so that raw values never need more than a few GB of HBM at once. Returns the device
-    batches, the timing of the (second, warm) fit call of every group with its k_fit_models kernel
-    time, and the raw values of the first `keep_series` series exactly as the fitter read them."""
+    batches, the wall-clock seconds of every repetition (summed over the groups) with the mean HIP-event
+    time of every fit kernel, and the raw values of the first `keep_series` series exactly as the fitter read them."""
     eb = mdb.error_bound("relative", args.error_bound)
     chunks_per_series = (args.points + CHUNK_POINTS - 1) // CHUNK_POINTS
     # All series of the rank in one launch when they fit (one lane per chunk: occupancy = chunks).
     group = max(1, min(args.series, args.fit_group_points // max(args.points, 1)))
-    parts, fit_seconds, fit_points, kernel_ms, kept = [], 0.0, 0, {}, None
+    parts, fit_seconds, fit_points, kernel_ms, kept = [], None, 0, {}, None
     first_series_of_rank = rank * args.series
     for first in range(0, args.series, group):
         n_series = min(group, args.series - first)
@@ -208,20 +249,13 @@ def fit_on_gpu(context, mdb, np, args, rank, keep_series):
         k = n_series * chunks_per_series
         offsets_dev = context.upload_array(offsets)
         first_index_dev = context.upload_array(first_index)
-        # The first call grows the context's scratch (tens of GB of hipMalloc); time the second.
-        context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US, first_index_dev).free()
-        context.sync()
-        context.profile_enable(True)
-        context.profile_reset()
-        t0 = time.perf_counter()
-        parts.append(context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US,
-                                                 first_index_dev))
-        context.sync()
-        fit_seconds += time.perf_counter() - t0
-        for name, (launches, ms) in context.profile().items():
-            if name.startswith("k_fit"):
-                kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
-        context.profile_enable(False)
+        segments, seconds, kernels = timed_fit(
+            context, lambda: context.compress_chunks_dev(0, values, offsets_dev, k, eb, 0, INTERVAL_US, first_index_dev),
+            args.fit_repetitions)
+        parts.append(segments)
+        fit_seconds = seconds if fit_seconds is None else [a + b for a, b in zip(fit_seconds, seconds)]
+        for name, ms in kernels.items():
+            kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
         fit_points += total
         if first == 0 and keep_series > 0:
             kept = context.download_array(values, min(keep_series, n_series) * args.points, np.float32)
@@ -360,10 +394,9 @@ def irregular_timestamps(context, mdb, np, args):
     for label, one in shapes:
         timestamps = np.tile(one, series)
         ts_dev = context.upload_array(timestamps)
-        context.compress_chunks_dev(ts_dev, values, offsets_dev, len(offsets) - 1, eb, 0, 0, 0).free()
-        context.sync(); started = time.perf_counter()
-        segments = context.compress_chunks_dev(ts_dev, values, offsets_dev, len(offsets) - 1, eb, 0, 0, 0)
-        context.sync(); fit_seconds = time.perf_counter() - started
+        segments, fit_seconds, fit_kernels = timed_fit(
+            context, lambda: context.compress_chunks_dev(ts_dev, values, offsets_dev, len(offsets) - 1, eb, 0, 0, 0),
+            args.fit_repetitions)
         n = context.grid_count_dev(segments)
         if n != total:
             raise SystemExit(f"VERIFICATION FAILED: {label}: {n} points in the segments, {total} fitted")
@@ -372,7 +405,9 @@ def irregular_timestamps(context, mdb, np, args):
         calls = (("grid", lambda: context.grid_batch_dev(segments, out_ts, out_val, n)),
                  ("aggregates", lambda: context.agg_batch_dev(segments, mask)),
                  ("aggregates_between_quartiles", lambda: context.agg_batch_range_dev(segments, t_lo, t_hi, mask)))
-        shape = {"fit_ms": 1e3 * fit_seconds, "segments": len(segments)}
+        shape = {"fit_ms": 1e3 * statistics.median(fit_seconds), "fit_ms_min": 1e3 * min(fit_seconds),
+                 "fit_ms_max": 1e3 * max(fit_seconds), "fit_repetitions": len(fit_seconds),
+                 "fit_kernels_ms": {k: round(v, 3) for k, v in fit_kernels.items() if v > 0.05}, "segments": len(segments)}
         for name, call in calls:
             context.sync(); started = time.perf_counter()
             call()
@@ -452,21 +487,18 @@ def mixed_models(context, mdb, np, ora, args):
     out = {"points": total, "series": series, "distinct_series": distinct,
            "note": "the reference's acceptance recipe (compression.rs:733-863): runs of 50..500 points, Constant / Linear "
                    "/ Random(100..200), every second series with noise 1.0..1.05 added, regular timestamps; chunks of "
-                   "65 536 points; fit: second of two calls; grid and aggregates (all points; the middle half of the "
+                   "65 536 points; fit: median of 5 calls after a first one; grid and aggregates (all points; the middle half of the "
                    "time axis): median of 5 calls on the resident segments; bytes: 4 B/point read by the fit, 73 B/segment + out-of-line payloads + 12 B/point for "
                    "grid, 73 B/segment + out-of-line payloads for the aggregates; checked: the first two series "
                    "(one without, one with noise) fitted by the oracle == the GPU's segments, their grid == the "
-                   "oracle's, COUNT == points"}
+                   "oracle's, COUNT == points; COUNT / MIN / MAX of the two series' segments, plain and BETWEEN the quartiles, == "
+                   "the oracle's (bit patterns), SUM within 0.001 %"}
     for label, eb in (("lossless", mdb.error_bound("lossless")), ("relative_1_percent", mdb.error_bound("relative", 1.0))):
-        context.compress_chunks_dev(0, values, offsets_dev, n_chunks, eb, 0, 100, first_index_dev).free()
-        context.sync()
-        context.profile_enable(True); context.profile_reset()
-        started = time.perf_counter()
-        segments = context.compress_chunks_dev(0, values, offsets_dev, n_chunks, eb, 0, 100, first_index_dev)
-        context.sync()
-        fit_seconds = time.perf_counter() - started
-        fit_kernels = {k: round(v[1], 3) for k, v in context.profile().items() if v[1] > 0.05}
-        context.profile_enable(False)
+        segments, fit_timings, fit_kernels = timed_fit(
+            context, lambda: context.compress_chunks_dev(0, values, offsets_dev, n_chunks, eb, 0, 100, first_index_dev),
+            args.fit_repetitions)
+        fit_seconds = statistics.median(fit_timings)
+        fit_kernels = {k: round(v, 3) for k, v in fit_kernels.items() if v > 0.05}
         n = context.grid_count_dev(segments)
         if n != total:
             raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: {n} points in the segments, {total} fitted")
@@ -475,7 +507,8 @@ def mixed_models(context, mdb, np, ora, args):
                             for b in range(col.n_buffers))
         out_ts, out_val = context.dev_alloc(8 * n), context.dev_alloc(4 * n)
         shape = {"segments": len(segments), "out_of_line_payload_bytes": payload_bytes,
-                 "fit": {"ms": 1e3 * fit_seconds, "points_per_s": total / fit_seconds, "kernels_ms": fit_kernels,
+                 "fit": {"ms": 1e3 * fit_seconds, "ms_min": 1e3 * min(fit_timings), "ms_max": 1e3 * max(fit_timings),
+                         "repetitions": len(fit_timings), "points_per_s": total / fit_seconds, "kernels_ms": fit_kernels,
                          "GB_per_s": 4.0 * total / fit_seconds / 1e9, "frac_of_hbm_peak": 4.0 * total / fit_seconds / 1e9 / HBM_PEAK_GBPS}}
         # (WHERE timestamp BETWEEN the quartiles of the series' common time axis, N1: half of every series' points)
         t_lo, t_hi = int(sample_ts[points // 4]), int(sample_ts[3 * points // 4])
@@ -521,6 +554,9 @@ def mixed_models(context, mdb, np, ora, args):
             got_values = context.download_array(out_val, points, np.float32, offset_elements=s * points)
             if not (np.array_equal(got_ts, expected_ts) and np.array_equal(got_values.view(np.uint32), expected_values.view(np.uint32))):
                 raise SystemExit(f"VERIFICATION FAILED: mixed models, {label}: the grid of series {s} differs from the oracle's")
+        two_series = downloaded.take(np.nonzero(downloaded.chunk_index < 2 * chunks_per_series)[0])
+        shape["aggregates_verified"] = verified_aggregates(context, mdb, np, ora, two_series, t_lo, t_hi)
+        shape["aggregates_verified"]["sample"] = f"the first two series ({len(two_series)} segments)"
         if not args.no_host_path:
             # The same segments as host batches through the pipelined grid of the boundary (the patched GridStream's
             # call sequence, PCIe included): all three model types, MacaqueV streams without the resident batch's
@@ -546,6 +582,86 @@ def mixed_models(context, mdb, np, ora, args):
     for pointer in (values, offsets_dev, first_index_dev):
         context.dev_free(pointer)
     return out
+
+
+def fit_counters():
+    """Vector / scalar instructions per data point and wave of the fit's model kernel from the committed SQ counter
+    passes (bench.py cannot collect counters itself), valid while the fit kernel's source is the one measured."""
+    path = os.path.join(REPO_ROOT, "profiles", "pmc_fit_models.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_fit_models.json is missing"
+    with open(path) as f:
+        pmc = json.load(f)
+    if pmc.get("source_hash") != source_hash(FIT_KERNEL_SOURCES):
+        return None, (f"the fit kernel sources changed since the SQ counter passes (measured {pmc.get('source_hash')}, "
+                      f"now {source_hash(FIT_KERNEL_SOURCES)}): rerun scripts/r04/pmc_fit.sh")
+    return pmc, None
+
+
+def fit_roofline(kernel_ms, points, info):
+    """Both bounds of the model kernel of a fit: the HBM figure the contract names (4 B per point read: regular
+    timestamps are synthesised) and the one that binds - vector instruction issue: a wave of 64 chunks issues
+    `valu_per_point` vector instructions per step of 64 points, 4 cycles each on its SIMD, so the floor of a launch is
+    points / 64 x valu_per_point x 4 cycles / (SIMDs x clock)."""
+    name = fit_kernel_name(kernel_ms)
+    model_ms = sum(ms for kernel, ms in kernel_ms.items() if kernel.startswith("k_fit_models") or kernel == "k_fit_walk")
+    gbps = 4.0 * points / (model_ms * 1e-3) / 1e9 if model_ms > 0 else 0.0
+    out = {"bound": "hbm", "kernel": name, "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": gbps / HBM_PEAK_GBPS, "kernel_ms": model_ms, "algorithmic_bytes_per_launch": 4.0 * points,
+           "note": "4 B/point read (regular timestamps are synthesised, not loaded); the greedy fit is a sequential "
+                   "dependency per chunk - HBM is the contract's bound, not the one that binds: see valu_issue"}
+    pmc, why_not = fit_counters()
+    if pmc is None or pmc.get("kernel") != name:
+        out["valu_issue"] = None
+        out["valu_issue_note"] = why_not or f"the SQ counter passes measured {pmc.get('kernel')}, this launch ran {name}"
+        return out
+    simds = 4 * int(info.get("compute_units", 256))
+    clock_hz = SHADER_CLOCK_MHZ * 1e6
+    floor_ms = 1e3 * (points / 64.0) * pmc["valu_per_point"] * 4.0 / (simds * clock_hz)
+    out["valu_issue"] = {"valu_per_point": pmc["valu_per_point"], "salu_per_point": pmc.get("salu_per_point"),
+                         "simds": simds, "clock_mhz": SHADER_CLOCK_MHZ, "floor_ms": floor_ms,
+                         "frac": floor_ms / model_ms if model_ms > 0 else 0.0,
+                         "note": "vector instructions per step of one wave (64 chunks, one point each) from "
+                                 "profiles/pmc_fit_models.json (SQ_INSTS_VALU / steps), 4 cycles per instruction and "
+                                 "wave on a SIMD; frac = floor / measured kernel time"}
+    return out
+
+
+def fit_check_and_cpu(args, np, mdb, ora, rank, cores, fit_sample_values, n_fit, gpu_fitted):
+    """The oracle's greedy compression of the very bytes the GPU fitted (the first `n_fit` series of the rank): the
+    segments must be identical in every column; the same calls, timed, are the CPU baseline of the fit (the port on
+    `cores` pinned threads, chunks sharded, and on one thread). Also checks the device generator against its host
+    definition. Returns (cpu baseline, oracle segments, host timestamps, chunk offsets, generator points checked)."""
+    import datagen
+    eb = mdb.error_bound("relative", args.error_bound)
+    host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
+    offsets = np.array([s * args.points + c for s in range(n_fit)
+                        for c in range(0, args.points, CHUNK_POINTS)] + [n_fit * args.points], dtype=np.uint64)
+    host_defined = np.concatenate([datagen.bench_series(rank * args.series + s, min(args.points, 1 << 20), SEED)
+                                   for s in range(n_fit)])
+    device_made = np.concatenate([fit_sample_values[s * args.points: s * args.points + min(args.points, 1 << 20)]
+                                  for s in range(n_fit)])
+    if not np.array_equal(host_defined.view(np.uint32), device_made.view(np.uint32)):
+        raise SystemExit("VERIFICATION FAILED: the device generator differs from tests/datagen.bench_series")
+    fitted, fit_cpu_seconds = ora.compress_chunks_timed(host_ts, fit_sample_values, offsets, eb, cores, repetitions=3)
+    single_chunks = min(len(offsets) - 1, 64)
+    single_offsets = offsets[:single_chunks + 1]
+    _, fit_single_seconds = ora.compress_chunks_timed(host_ts[:int(single_offsets[-1])], fit_sample_values[:int(single_offsets[-1])],
+                                                      single_offsets, eb, 1, repetitions=3)
+    if not fitted.identical(gpu_fitted):
+        raise SystemExit("VERIFICATION FAILED: GPU segments differ from the oracle's")
+    fit_rates = summary(fit_cpu_seconds, n_fit * args.points)
+    fit_single_rate = summary(fit_single_seconds, int(single_offsets[-1]))["median"]
+    fit_cpu = {"value": fit_rates["median"], "unit": "points/s",
+               "points_per_s": fit_rates["median"], "min": fit_rates["min"], "max": fit_rates["max"],
+               "repetitions": fit_rates["repetitions"],
+               "segments_per_s": len(fitted) / statistics.median(fit_cpu_seconds), "cores": cores,
+               "kind": "port", "single_thread_points_per_s": fit_single_rate,
+               "parallel_efficiency": fit_rates["median"] / cores / fit_single_rate if fit_single_rate > 0 else None,
+               "sample": f"the fit of {n_fit} series x {args.points} points of the same workload (the oracle's "
+                         f"try_compress_univariate_time_series per 65 536-point chunk), chunks sharded over a standing "
+                         f"pool of {cores} pinned threads; median of 3 timed passes"}
+    return fit_cpu, fitted, host_ts, offsets, len(host_defined)
 
 
 PHASES = {}
@@ -812,36 +928,11 @@ class GpuWorkload:
             # fit verification: the oracle's greedy compression of the very bytes the GPU fitted.
             n_fit = self.n_fit_sample
             fit_sample_values = self.fit_sample_values
-            host_ts = np.tile(np.arange(args.points, dtype=np.int64) * INTERVAL_US, n_fit)
-            offsets = np.array([s * args.points + c for s in range(n_fit)
-                                for c in range(0, args.points, CHUNK_POINTS)] + [n_fit * args.points],
-                               dtype=np.uint64)
-            import datagen
-            host_defined = np.concatenate([datagen.bench_series(rank * args.series + s, min(args.points, 1 << 20), SEED)
-                                           for s in range(n_fit)])
-            device_made = np.concatenate([fit_sample_values[s * args.points: s * args.points + min(args.points, 1 << 20)]
-                                          for s in range(n_fit)])
-            if not np.array_equal(host_defined.view(np.uint32), device_made.view(np.uint32)):
-                raise SystemExit("VERIFICATION FAILED: the device generator differs from tests/datagen.bench_series")
-            fitted, fit_cpu_seconds = ora.compress_chunks_timed(host_ts, fit_sample_values, offsets, eb, cores,
-                                                                repetitions=3)
-            single_chunks = min(len(offsets) - 1, 64)
-            single_offsets = offsets[:single_chunks + 1]
-            _, fit_single_seconds = ora.compress_chunks_timed(host_ts[:int(single_offsets[-1])], fit_sample_values[:int(single_offsets[-1])],
-                                                              single_offsets, eb, 1, repetitions=3)
             gpu_fitted = downloaded.take(np.nonzero(downloaded.chunk_index < n_fit * chunks_per_series)[0])
-            if not fitted.identical(gpu_fitted):
-                raise SystemExit("VERIFICATION FAILED: GPU segments differ from the oracle's")
-            fit_rates = summary(fit_cpu_seconds, n_fit * args.points)
-            fit_single_rate = summary(fit_single_seconds, int(single_offsets[-1]))["median"]
-            fit_cpu = {"points_per_s": fit_rates["median"], "min": fit_rates["min"], "max": fit_rates["max"],
-                       "repetitions": fit_rates["repetitions"],
-                       "segments_per_s": len(fitted) / statistics.median(fit_cpu_seconds), "cores": cores,
-                       "kind": "port", "single_thread_points_per_s": fit_single_rate,
-                       "parallel_efficiency": fit_rates["median"] / cores / fit_single_rate if fit_single_rate > 0 else None,
-                       "sample": f"{n_fit} series x {args.points} points, chunks sharded over a standing pool of {cores} pinned threads"}
+            fit_cpu, fitted, host_ts, offsets, host_defined = fit_check_and_cpu(
+                args, np, mdb, ora, rank, cores, fit_sample_values, n_fit, gpu_fitted)
             verified = {"fit_segments": len(fitted), "fit_points": n_fit * args.points,
-                        "grid_points": grid_points_verified, "generator_points": len(host_defined),
+                        "grid_points": grid_points_verified, "generator_points": host_defined,
                         "series_blocks": args.series, "aggregates": aggregates["verified"],
                         "how": "after the timed region: oracle fit of the sample series' exact bytes == GPU "
                                "segments (all columns, bit patterns); oracle grid of the sample == the device "
@@ -867,9 +958,8 @@ class GpuWorkload:
                     mixed_result = mixed_models(context, mdb, np, ora, args)
 
         value = world * points_per_step * args.steps / elapsed
-        fit_kernel_ms, fit_points, fit_seconds = self.fit_kernel_ms, self.fit_points, self.fit_seconds
-        fit_models_ms = fit_kernel_ms.get("k_fit_models", 0.0) + fit_kernel_ms.get("k_fit_models_split", 0.0)
-        fit_gbps = 4.0 * fit_points / (fit_models_ms * 1e-3) / 1e9 if fit_models_ms > 0 else 0.0
+        fit_kernel_ms, fit_points, fit_timings = self.fit_kernel_ms, self.fit_points, self.fit_seconds
+        fit_seconds = statistics.median(fit_timings)
         return {
             "metric": "gridded values/sec",
             "value": value,
@@ -927,16 +1017,12 @@ class GpuWorkload:
                 "points_per_s": fit_points / fit_seconds if fit_seconds > 0 else None,
                 "segments_per_s": n_segments / fit_seconds if fit_seconds > 0 else None,
                 "seconds": fit_seconds,
-                "roofline": {"bound": "hbm", "kernel": "k_fit_models", "achieved": fit_gbps,
-                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fit_gbps / HBM_PEAK_GBPS,
-                             "kernel_ms": fit_models_ms,
-                             "algorithmic_bytes_per_launch": 4.0 * fit_points,
-                             "note": "4 B/point read (regular timestamps are synthesised, not loaded); the "
-                                     "greedy fit is a sequential dependency per chunk, so this kernel is "
-                                     "latency/issue-bound, far from the HBM roofline by nature"},
+                "seconds_spread": spread(fit_timings),
+                "roofline": fit_roofline(fit_kernel_ms, fit_points, self.info),
                 "kernels_ms": fit_kernel_ms,
                 "note": "PMC-Mean/Swing/MacaqueV fit of this rank's series on the GPU (setup, not "
-                        "in the timed region), regular timestamps synthesised on the fly",
+                        "in the timed region; `--timed fit` makes it the timed step), regular timestamps synthesised "
+                        "on the fly; median of the repetitions after one untimed call",
             },
         }
 
@@ -954,55 +1040,253 @@ class GpuWorkload:
         self.context.close()  # (mdb_comm_close first, then the stream and the scratch)
 
 
+class FitWorkload:
+    """BASELINE configs[3] (the compression path) on one rank's GPU, `--timed fit`: build = this rank's series
+    generated into HBM, step = ONE mdb_compress_chunks_dev over all of them (PMC-Mean / Swing / MacaqueV fit of every
+    65 536-point chunk, segments written as Arrow columns in HBM; the previous step's segments are freed first),
+    report = both rooflines of the model kernel from HIP events, and - on rank 0 - the CPU baseline (the fit port)
+    and the verification of a sample of the series against the oracle. Series shard over the ranks (weak scaling),
+    no data-path collective; the aggregates of the fitted segments are merged over RCCL once, as in the grid run."""
+
+    def __init__(self, args, rank, local_rank, world, dist):
+        import numpy as np
+        import modelardb_rs_amd as mdb
+        from modelardb_rs_amd import sharding
+        self.args, self.rank, self.local_rank, self.world, self.dist = args, rank, local_rank, world, dist
+        self.np, self.mdb = np, mdb
+        self.context = mdb.Context(local_rank)
+        self.info = self.context.device_info()
+        with phase("comm_init"):
+            sharding.init_comm(self.context, dist)
+        self.verify = rank == 0 and not args.no_cpu_baseline
+        self.values = self.offsets_dev = self.first_index_dev = self.segments = None
+
+    def sync(self):
+        import torch
+        self.context.sync()
+        torch.cuda.synchronize()
+
+    def build(self):
+        args, context, np = self.args, self.context, self.np
+        if args.series * args.points > args.fit_group_points:
+            raise SystemExit(f"--timed fit keeps the rank's {args.series * args.points} points resident in one launch; "
+                             f"raise --fit-group-points (now {args.fit_group_points}) or lower --series / --points")
+        self.eb = self.mdb.error_bound("relative", args.error_bound)
+        self.total = args.series * args.points
+        with phase("generate"):
+            self.values = context.dev_alloc(4 * self.total)
+            context.synth_values_dev(self.values, self.rank * args.series, args.series, args.points, SEED)
+            starts = np.arange(0, args.points, CHUNK_POINTS, dtype=np.uint64)
+            offsets = (np.arange(args.series, dtype=np.uint64)[:, None] * np.uint64(args.points) + starts[None, :]).reshape(-1)
+            offsets = np.concatenate([offsets, np.array([self.total], dtype=np.uint64)])
+            self.n_chunks = len(offsets) - 1
+            self.chunks_per_series = len(starts)
+            self.offsets_dev = context.upload_array(offsets)
+            self.first_index_dev = context.upload_array(np.tile(starts, args.series))
+            context.sync()
+        with phase("first_fit"):  # (the context's scratch grows: tens of GB of hipMalloc)
+            self.step()
+            context.sync()
+
+    def step(self):
+        if self.segments is not None:
+            self.segments.free()
+        self.segments = self.context.compress_chunks_dev(0, self.values, self.offsets_dev, self.n_chunks, self.eb, 0,
+                                                         INTERVAL_US, self.first_index_dev)
+        return self.total
+
+    def report(self, elapsed, per_rank_seconds):
+        args, context, np, mdb = self.args, self.context, self.np, self.mdb
+        rank, world = self.rank, self.world
+        n_segments = len(self.segments)
+        # ---- the kernels of a step: HIP events on the launch stream ------------------------------------
+        context.profile_enable(True)
+        context.profile_reset()
+        call_seconds = []
+        for _ in range(args.steps):
+            context.sync(); started = time.perf_counter()
+            self.step()
+            context.sync(); call_seconds.append(time.perf_counter() - started)
+        kernel_ms = {name: ms / args.steps for name, (launches, ms) in context.profile().items() if name.startswith("k_fit")}
+        context.profile_enable(False)
+        if context.grid_count_dev(self.segments) != self.total:
+            raise SystemExit("VERIFICATION FAILED: the fitted segments do not hold the points that were fitted")
+        # ---- the one exchange step of the path, on the fitted segments ----------------------------------
+        mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+        state = context.agg_batch_dev(self.segments, mask)
+        context.agg_all_reduce(state)
+        state, ranks_seen = context.agg_all_reduce(mdb._abi.AggStateC(state.sum, state.count, state.min, state.max))
+        assert ranks_seen == world and state.count == world * self.total, (ranks_seen, state.count)
+        if rank != 0:
+            return None
+        cpu_baseline = verified = None
+        if self.verify:
+            import oracle_lib as ora
+            cores, cores_how = usable_cores()
+            n_fit = min(args.fit_sample_series, args.series)
+            with phase("download_sample"):
+                sample_values = context.download_array(self.values, n_fit * args.points, np.float32)
+                downloaded = self.segments.download()
+                gpu_fitted = downloaded.take(np.nonzero(downloaded.chunk_index < n_fit * self.chunks_per_series)[0])
+                del downloaded
+            with phase("verify_fit_and_cpu_baseline_fit"):
+                cpu_baseline, fitted, _, _, generator_points = fit_check_and_cpu(
+                    args, np, mdb, ora, rank, cores, sample_values, n_fit, gpu_fitted)
+                cpu_baseline["threads"] = f"a standing pool of {cores} worker threads ({cores_how}), worker w pinned to the w-th allowed CPU"
+            verified = {"fit_segments": len(fitted), "fit_points": n_fit * args.points, "generator_points": generator_points,
+                        "grid_count": self.total,
+                        "how": "after the timed region: the oracle's fit of the sample series' exact bytes == the segments "
+                               "of the last timed step (all columns, bit patterns); the segments of the rank hold exactly "
+                               "the points that were fitted (mdb_grid_count); device generator == host definition"}
+        value = world * self.total * args.steps / elapsed
+        mix = context.grid_count_dev(self.segments)
+        return {
+            "metric": "fit points/sec",
+            "value": value,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "rccl_ranks_seen": ranks_seen,
+            "segments_per_s": world * n_segments * args.steps / elapsed,
+            "ms_per_step_per_rank": {"min": 1e3 * min(per_rank_seconds) / args.steps,
+                                     "max": 1e3 * max(per_rank_seconds) / args.steps},
+            "config": {
+                "workload": f"{args.series} series x {args.points} points sine+noise per GPU, relative error bound "
+                            f"{args.error_bound} %, PMC-Mean / Swing / MacaqueV fit of every {CHUNK_POINTS}-point chunk "
+                            f"(values resident in HBM, regular timestamps, segments written as Arrow columns in HBM)",
+                "series_per_gpu": args.series,
+                "points_per_series": args.points,
+                "chunks_per_gpu": self.n_chunks,
+                "segments_per_gpu": n_segments,
+                "points_in_segments": mix,
+                "parallelism": f"series-sharded x{world}, no data-path collective",
+                "arithmetic": "Swing in f64 (no contraction), PMC-Mean f64 sum / f32 tests, MacaqueV u32 bit streams",
+                "device": self.info["name"],
+            },
+            "roofline": fit_roofline(kernel_ms, self.total, self.info),
+            "kernels_ms": {name: round(ms, 3) for name, ms in kernel_ms.items()},
+            "call_ms": {"median": 1e3 * statistics.median(call_seconds), "min": 1e3 * min(call_seconds),
+                        "max": 1e3 * max(call_seconds)},
+            "cpu_baseline": cpu_baseline,
+            "verified": verified,
+            "aggregates_of_fitted_segments": {"count": state.count, "min": state.min, "max": state.max, "sum": state.sum},
+            "phases_s": {name: round(seconds, 2) for name, seconds in PHASES.items()},
+        }
+
+    def close(self):
+        if self.segments is not None:
+            self.segments.free()
+            self.segments = None
+        for pointer in (self.values, self.offsets_dev, self.first_index_dev):
+            if pointer:
+                self.context.dev_free(pointer)
+        self.values = self.offsets_dev = self.first_index_dev = None
+        self.context.close()
+
+
+def control_group(dist, backend):
+    """The group the ranks' checkpoints run on: gloo over loopback next to an RCCL job (a rank that waits for rank 0's
+    tail sleeps in a socket instead of spinning on a stream, and a checkpoint can never be mismatched with a
+    collective of the data path), the job's own group when that is gloo already."""
+    if backend != "nccl":
+        return None
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    return dist.new_group(backend="gloo")
+
+
 def orchestrate(args, make_workload, backend="nccl", result_fd=1):
     """The rank protocol of the contract, for any workload object with build / step / sync / report / close:
     W untimed steps, a barrier + device sync, K timed steps, a barrier + device sync, the MAX over ranks; then the
-    report (its collectives on every rank, rank 0's tail alone) and - whatever happened in the tail of whichever
-    rank - ONE meeting point: every rank says whether it is fine, all of them close their communicators and the
-    process group in the same order, rank 0 prints the line only if every rank was fine, and every rank exits
-    non-zero otherwise. A rank that dies is noticed by the others through the process group's timeout."""
+    report (its collectives on every rank, rank 0's tail alone) and ONE meeting point: all ranks close their
+    communicators and the process group in the same order, rank 0 prints the line only if every rank was fine, and
+    every rank exits non-zero otherwise.
+    Every rank issues the SAME sequence of collectives whatever happens to it: each phase ends in a checkpoint - an
+    all-reduce (MIN) of "I am fine" on the control group, which is also the barrier of the contract - and a rank
+    that has failed keeps taking part in the checkpoints with 0, so that all ranks skip the rest together instead
+    of meeting in different collectives. A rank that dies is noticed through the process group's timeout."""
     import datetime
+    import traceback
     with phase("init_distributed"):
         rank, local_rank, world, dist = init_distributed(args, backend, datetime.timedelta(seconds=args.collective_timeout))
     import torch
-    device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
-    workload, line, failure = None, None, None
+    state = {"failure": None}
     try:
-        workload = make_workload(args, rank, local_rank, world, dist)
-        workload.build()
+        control = control_group(dist, backend)
+    except BaseException as error:  # noqa: BLE001
+        traceback.print_exc(file=sys.stderr)
+        control, state["failure"] = None, error
+
+    def attempt(what):
+        """Run `what()` unless this rank has failed already; a failure is reported and remembered."""
+        if state["failure"] is not None:
+            return None
+        try:
+            return what()
+        except BaseException as error:  # noqa: BLE001 - reported, then the job ends non-zero on every rank
+            traceback.print_exc(file=sys.stderr)
+            state["failure"] = error
+            return None
+
+    def checkpoint():
+        """True if every rank is fine. (Also a barrier.)"""
+        fine = torch.tensor([0 if state["failure"] is not None else 1], dtype=torch.int32)
+        if backend == "nccl" and control is None:
+            fine = fine.to(torch.device("cuda", local_rank))
+        try:
+            dist.all_reduce(fine, op=dist.ReduceOp.MIN, group=control)
+            return bool(fine.item())
+        except BaseException as error:  # noqa: BLE001 - a rank is gone: leave with an error, do not hang
+            traceback.print_exc(file=sys.stderr)
+            state["failure"] = state["failure"] or error
+            return False
+
+    workload_box, line = [None], None
+
+    def build_and_warm_up():
+        workload_box[0] = make_workload(args, rank, local_rank, world, dist)
+        workload_box[0].build()
         for _ in range(args.warmup):
-            workload.step()
-        workload.sync(); dist.barrier(); workload.sync()
-        t0 = time.perf_counter()
+            workload_box[0].step()
+        workload_box[0].sync()
+
+    def timed_steps():
         for _ in range(args.steps):
-            workload.step()
-        workload.sync(); dist.barrier(); workload.sync()
+            workload_box[0].step()
+        workload_box[0].sync()
+
+    attempt(build_and_warm_up)
+    everyone_fine = checkpoint()                  # barrier + (above) device sync in front of the timed region
+    if everyone_fine:
+        attempt(lambda: workload_box[0].sync())
+        t0 = time.perf_counter()
+        attempt(timed_steps)                      # K steps, then the device sync
+        everyone_fine = checkpoint()              # the barrier behind it
+        attempt(lambda: workload_box[0].sync())
         own_elapsed = time.perf_counter() - t0
+    if everyone_fine:
         # MAX over ranks (and every rank's own time, for the min/max on the line).
-        t = torch.tensor([own_elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([own_elapsed], dtype=torch.float64)
         gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
+        attempt(lambda: dist.all_gather(gathered, t, group=control))
+        everyone_fine = checkpoint()
+    if everyone_fine:
         per_rank_seconds = [float(x.item()) for x in gathered]
-        line = workload.report(max(per_rank_seconds), per_rank_seconds)
-    except BaseException as error:  # noqa: BLE001 - reported, then the job ends non-zero on every rank
-        import traceback
-        traceback.print_exc(file=sys.stderr)
-        failure = error
+        line = attempt(lambda: workload_box[0].report(max(per_rank_seconds), per_rank_seconds))
     # The meeting point (the ranks other than 0 have been here since their report() returned).
-    fine = torch.tensor([0 if failure else 1], dtype=torch.int32, device=device)
-    everyone_fine = False
+    everyone_fine = checkpoint() and everyone_fine
     try:
-        dist.all_reduce(fine, op=dist.ReduceOp.MIN)
-        everyone_fine = bool(fine.item())
-        dist.barrier()
-    except BaseException:  # noqa: BLE001 - a rank is gone: leave with an error, do not hang
-        import traceback
-        traceback.print_exc(file=sys.stderr)
-    try:
-        if workload is not None:
-            workload.close()
+        if workload_box[0] is not None:
+            workload_box[0].close()
         dist.destroy_process_group()
     except BaseException:  # noqa: BLE001
+        traceback.print_exc(file=sys.stderr)
         everyone_fine = False
     if rank == 0 and everyone_fine and line is not None:
         os.write(result_fd, (json.dumps(line) + "\n").encode())
@@ -1013,7 +1297,7 @@ def main():
     args = parse_args()
     launch_ranks_if_needed(args)
     result_fd = claim_stdout()
-    sys.exit(orchestrate(args, GpuWorkload, "nccl", result_fd))
+    sys.exit(orchestrate(args, FitWorkload if args.timed == "fit" else GpuWorkload, "nccl", result_fd))
 
 
 if __name__ == "__main__":

@@ -1164,6 +1164,21 @@ __device__ __forceinline__ LaneMask lean_passes(const PmcFast &f, float real_val
     return usable & lanes_where(difference <= pass_bound - average_error);
 }
 
+// MDB_FIT_TIMING=N (a build of its own, scripts/r04/build_timing.sh; never defined in the product): shader clock
+// cycles (s_memtime) a wave of k_fit_models_lean<false, RELATIVE, false> spends in region N of a step, summed over
+// all waves into g_fit_timing[0] (cycles), [1] (passes through the region), [2] (whole loop, cycles), [3] (steps),
+// [4] (s_memrealtime ticks of the whole loop, 100 MHz). Regions: 0 nothing (two clock reads back to back), 1 the
+// ring's top-up, 2 the LDS read of the step's value, 3 PMC-Mean, 4 Swing, 5 finishing models.
+#ifdef MDB_FIT_TIMING
+__device__ unsigned long long g_fit_timing[8];
+__device__ unsigned long long g_fit_waves[4 * 65536]; // MDB_FIT_TIMING=6: per wave {loop ticks, HW_ID, XCC_ID, start tick}
+#define FIT_TIMING_BEGIN(N) unsigned long long timing_t0_##N = 0; if (TIMED && MDB_FIT_TIMING == N) timing_t0_##N = __builtin_amdgcn_s_memtime()
+#define FIT_TIMING_END(N) if (TIMED && MDB_FIT_TIMING == N) { timing_cycles += __builtin_amdgcn_s_memtime() - timing_t0_##N; timing_passes += 1; }
+#else
+#define FIT_TIMING_BEGIN(N)
+#define FIT_TIMING_END(N)
+#endif
+
 template <int GROUPS>
 __device__ __forceinline__ float ring_value(const float4 (*ring)[MDB_WAVE], int lane, uint32_t position) {
     return reinterpret_cast<const float *>(&ring[(position >> 2) % GROUPS][lane])[position & 3u];
@@ -1256,8 +1271,17 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     LaneMask active_m = lanes_where(active);
     LaneMask pmc_fits_m = ~0ull, swing_fits_m = ~0ull, swing_finite_m = 0;
     const LaneMask pmc_fast_m = pmc_fast.enabled ? ~0ull : 0ull;
+#ifdef MDB_FIT_TIMING
+    constexpr bool TIMED = !SPLIT && KIND == MDB_EB_RELATIVE && !HAS_TS;
+    unsigned long long timing_cycles = 0, timing_passes = 0, timing_steps = 0;
+    const unsigned long long timing_loop_t0 = __builtin_amdgcn_s_memtime(), timing_real_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     while (active_m != 0) {
+#ifdef MDB_FIT_TIMING
+        timing_steps += 1;
+        { FIT_TIMING_BEGIN(0); FIT_TIMING_END(0) }
+#endif
         if (KIND == MDB_EB_LOSSLESS) {
             // Noise under a lossless bound: a start point whose next value differs (PMC-Mean ends at one point) and
             // whose third one is off the line through the first two (Swing ends at two) is rejected, which the three
@@ -1312,6 +1336,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         const uint32_t position = j + misalign; // of point j, counted from the 16-byte boundary
         const uint32_t group = position >> 2;
         if (feeding_m & (lanes_where(group >= loaded_group) | lanes_where(group < low_group))) {
+            FIT_TIMING_BEGIN(1);
             // Normally the ring is extended at loaded_group. A lane whose next point fell out of the back
             // of its ring (PMC-Mean chosen although Swing had run far ahead, types.rs:84-101) or lies
             // beyond it restarts the ring at that point's group.
@@ -1352,9 +1377,19 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             }
             loaded_group = max(first_group, end_group);
             if (loaded_group > low_group + LEAN_GROUPS) low_group = loaded_group - LEAN_GROUPS;
+#ifdef MDB_FIT_TIMING
+            if (TIMED && MDB_FIT_TIMING == 1) __builtin_amdgcn_s_waitcnt(0); // (the ring's stores have left)
+#endif
+            FIT_TIMING_END(1)
         }
+        FIT_TIMING_BEGIN(2);
         const float value32 = ring_value<LEAN_GROUPS>(ring, lane, position);
+#ifdef MDB_FIT_TIMING
+        if (TIMED && MDB_FIT_TIMING == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(value32));
+#endif
+        FIT_TIMING_END(2)
         const double value = (double)value32;
+        FIT_TIMING_BEGIN(3);
 
         // ---- PMC-Mean: PMCMean::fit_value (pmc_mean.rs:58-76), decided as in pmc_fit_fast ----
         const LaneMask pmc_steps_m = feeding_m & pmc_fits_m;
@@ -1408,6 +1443,11 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             pmc_length = next_length;
         }
         pmc_fits_m &= ~pmc_steps_m | pmc_accepts_m;
+#ifdef MDB_FIT_TIMING
+        if (TIMED && MDB_FIT_TIMING == 3) asm volatile("" ::"v"(pmc_min), "v"(pmc_max), "v"(pmc_sum), "v"(pmc_length), "s"(pmc_fits_m));
+#endif
+        FIT_TIMING_END(3)
+        FIT_TIMING_BEGIN(4);
 
         // ---- Swing: Swing::fit_data_point (swing.rs:101-198) on exact f64 timestamps (SwingFast) ----
         const LaneMask swing_steps_m = feeding_m & swing_fits_m;
@@ -1504,9 +1544,14 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         swing_length += in_lanes(swing_keeps_m) ? 1u : 0u;
         swing_fits_m &= ~swing_steps_m | swing_accepts_m;
         j += in_lanes(feeding_m) ? 1u : 0u;
+#ifdef MDB_FIT_TIMING
+        if (TIMED && MDB_FIT_TIMING == 4) asm volatile("" ::"v"(upper_slope), "v"(upper_intercept), "v"(lower_slope), "v"(lower_intercept), "v"(numerator), "v"(denominator), "v"(swing_length), "s"(swing_fits_m));
+#endif
+        FIT_TIMING_END(4)
 
         const LaneMask finishing_m = active_m & ~feeding_m;
         if (finishing_m) {
+            FIT_TIMING_BEGIN(5);
             bool ends = false; // this lane has no model left to fit
             if (in_lanes(finishing_m)) {
                 // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
@@ -1575,8 +1620,25 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             pmc_fits_m |= next_model_m;
             swing_fits_m |= next_model_m;
             swing_finite_m &= ~next_model_m;
+            FIT_TIMING_END(5)
         }
     }
+#ifdef MDB_FIT_TIMING
+    if (TIMED && lane == 0) {
+        atomicAdd(&g_fit_timing[0], timing_cycles);
+        atomicAdd(&g_fit_timing[1], timing_passes);
+        atomicAdd(&g_fit_timing[2], __builtin_amdgcn_s_memtime() - timing_loop_t0);
+        atomicAdd(&g_fit_timing[3], timing_steps);
+        atomicAdd(&g_fit_timing[4], __builtin_amdgcn_s_memrealtime() - timing_real_t0);
+        atomicAdd(&g_fit_timing[5], 1ull);
+        if (MDB_FIT_TIMING == 6 && blockIdx.x < 65536) {
+            g_fit_waves[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime() - timing_real_t0;
+            g_fit_waves[4 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+            g_fit_waves[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+            g_fit_waves[4 * blockIdx.x + 3] = timing_real_t0;
+        }
+    }
+#endif
 }
 
 // ---- k_fit_models_wave: one WAVE per chunk ---------------------------------------------------------------------
@@ -3209,7 +3271,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             }
         }
         if (!wave && piece_points == 0) {
-            LaunchTimer timer(ctx, "k_fit_models");
+            LaunchTimer timer(ctx, (lean_ts || (!ts && lean)) ? "k_fit_models_lean" : "k_fit_models");
             const uint32_t fit_blocks = (uint32_t)((n_chunks + FIT_THREADS - 1) / FIT_THREADS);
 #define MDB_LAUNCH_LEAN(SPLIT, SPLIT_ARGS, HAS_TS)                                                                          \
     do {                                                                                                                   \
@@ -3237,6 +3299,31 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 hipLaunchKernelGGL((k_fit_models<false, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
         }
+#ifdef MDB_FIT_TIMING
+        if (!wave && piece_points == 0 && lean && !ts && eb.kind == MDB_EB_RELATIVE) {
+            unsigned long long t[8] = {};
+            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            FIT_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fit_timing), sizeof(t)));
+            const unsigned long long zero[8] = {};
+            FIT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fit_timing), zero, sizeof(zero)));
+            const double waves = (double)t[5], steps = (double)t[3];
+            std::fprintf(stderr, "[fit timing] region %d: %.1f cycles per pass, %.4f passes per step = %.1f cycles per step; loop %.1f cycles per step "
+                         "(%.0f waves, %.0f steps per wave, shader clock %.0f MHz)\n", (int)MDB_FIT_TIMING,
+                         t[1] ? (double)t[0] / (double)t[1] : 0.0, (double)t[1] / steps, (double)t[0] / steps, (double)t[2] / steps, waves,
+                         steps / waves, t[4] ? (double)t[2] / ((double)t[4] / 100.0) : 0.0);
+            if (MDB_FIT_TIMING == 6) {
+                const size_t n_waves = std::min<size_t>((size_t)t[5], 65536);
+                std::vector<unsigned long long> w(4 * n_waves);
+                FIT_CHECK(hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(g_fit_waves), 32 * n_waves));
+                if (FILE *f = std::fopen(std::getenv("MDB_FIT_TIMING_FILE") ? std::getenv("MDB_FIT_TIMING_FILE") : "/tmp/fit_waves.csv", "w")) {
+                    std::fprintf(f, "wave,ticks,hw_id,xcc_id,start\n");
+                    for (size_t k = 0; k < n_waves; k++)
+                        std::fprintf(f, "%zu,%llu,%llu,%llu,%llu\n", k, w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+                    std::fclose(f);
+                }
+            }
+        }
+#endif
         if (split_mode) {
             // Split mode: pieces of every chunk fitted speculatively, then the real chain is walked.
             SplitArgs split{};
