@@ -74,6 +74,7 @@ enum ScratchSlot {
     SCRATCH_FIT_IN_OFFSETS,
     SCRATCH_FIT_WAVE,
     SCRATCH_MV_HOST_INDEX,
+    SCRATCH_FIT_SMALL,
     SCRATCH_SLOT_COUNT
 };
 

@@ -780,6 +780,11 @@ struct FitArgs {
     // Timestamps of segments inside irregular chunks are sized and written by one WAVE each
     // (k_fit_timestamps); ts_results[segment].bytes == 0xffffffff: not this one. May be nullptr.
     const struct TsResult *ts_results;
+    // The call of a handful of chunks (fit_few_chunks) never asks the device how far it is: the number of segments
+    // and where the encoders write are read from device memory by the kernels behind k_fit_walk, which are launched
+    // over upper bounds. nullptr: the values the kernels are passed.
+    const unsigned long long *n_segments_dev = nullptr;
+    const struct EncodeTargets *targets_dev = nullptr;
 };
 
 __device__ __forceinline__ uint64_t chunk_record_capacity(uint64_t length) { return length / 8 + 1; }
@@ -1782,8 +1787,13 @@ constexpr uint32_t WAVE_PASS_POINTS = 1024; // start points a pass over rejected
 constexpr uint32_t WAVE_PASS_STEPS = 4;     // what its second stage costs, in blocks of a model
 
 // HAS_TS: the timestamps are loaded (some chunk is irregular; all of them within +-2^52, so exact as f64).
-template <int KIND, bool HAS_TS = false>
-__global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, WaveLeave leave,
+// PIECES: one wave per PIECE of a chunk (split mode's speculation, SplitArgs, with a wave instead of a lane): the wave
+// starts its greedy chain at the piece's first point, records what it fits in the per-point table instead of the
+// chunk's record list and stops at the first start point past its piece that some wave has been at; k_fit_walk
+// then collects the chunk's real chain. For calls of a handful of chunks (a server's finished buffer): a chunk's
+// latency becomes a piece's plus the stretch the chains need to meet.
+template <int KIND, bool HAS_TS = false, bool PIECES = false>
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, WaveLeave leave, SplitArgs split,
                                                              const unsigned long long *__restrict__ record_base,
                                                              ModelRec *__restrict__ records,
                                                              ChunkPlan *__restrict__ plans,
@@ -1791,10 +1801,24 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     __shared__ PendingSwing pending[MDB_WAVE];
     __shared__ uint32_t survivors[2 * MDB_WAVE];
     const int lane = threadIdx.x;
-    const uint64_t chunk = blockIdx.x;
+    uint64_t chunk = blockIdx.x;
+    uint32_t first_point = 0;
+    if (PIECES) {
+        // The chunk of this piece: the last c with piece_base[c] <= the piece's number (the same for all lanes).
+        const uint64_t unit = blockIdx.x;
+        if (unit >= split.n_pieces) return;
+        uint64_t lo = 0, hi = args.n_chunks;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (split.piece_base[mid] <= unit) lo = mid;
+            else hi = mid;
+        }
+        chunk = lo;
+        first_point = (uint32_t)(unit - split.piece_base[chunk]) * split.piece_points;
+    }
     const uint64_t base = args.chunk_offsets[chunk];
     const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
-    if (length64 > COUNT_MASK - ENTRY_END_BIAS) {
+    if (length64 > COUNT_MASK - ENTRY_END_BIAS) { // (pieces: such a chunk has none, PieceCount)
         if (lane == 0) {
             atomicOr(error, ERR_TOO_LONG);
             plans[chunk] = {0, 0};
@@ -1803,9 +1827,20 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     }
     const uint32_t n = (uint32_t)length64;
     if (n == 0) {
-        if (lane == 0) plans[chunk] = {0, 0};
+        if (lane == 0 && !PIECES) plans[chunk] = {0, 0};
         return;
     }
+    const uint32_t piece_end = PIECES ? first_point + split.piece_points : 0u;
+    // (pieces) Has some wave been at start point `at` already? Asked once the wave is past its own piece.
+    auto visited = [&](uint32_t at) -> bool {
+        return PIECES && at >= piece_end && at < n &&
+               __hip_atomic_load(&split.entry[base + at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    };
+    // (pieces) Start points [from, from + count) are rejected: no model stands on them.
+    auto mark_rejected = [&](uint32_t from, uint32_t count) {
+        for (uint32_t k = lane; k < count; k += MDB_WAVE)
+            __hip_atomic_store(&split.entry[base + from + k], ENTRY_REJECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     const float *__restrict__ values = args.values + base;
     const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, chunk, base);
     const double first_time = (double)regular_ts.first, interval = (double)regular_ts.interval; // exact
@@ -1822,7 +1857,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 
     uint32_t n_models = 0, n_pending = 0;
     GapCounter gaps;
-    uint32_t current = 0;
+    uint32_t current = first_point;
     bool after_rejection = false;
     uint32_t half_steps = 0, next_look = leave.window_points, looked_at = 0; // (WaveLeave)
     uint32_t counted[WAVE_COUNTS] = {};
@@ -1831,14 +1866,14 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         if (leave.counts && lane == 0)
             for (int k = 0; k < WAVE_COUNTS; k++) atomicAdd(leave.counts + k, (unsigned long long)counted[k]);
     };
-    if (leave.chunk_left && n > leave.max_chunk_points) {
+    if (!PIECES && leave.chunk_left && n > leave.max_chunk_points) {
         if (lane == 0) {
             leave.chunk_left[chunk] = 1u;
             atomicAdd(leave.n_left, 1u);
         }
         return;
     }
-    if (leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
+    if (!PIECES && leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
 
     // The sums of the queued Swing models, one lane per model, and with them the models' last values.
     auto flush_pending = [&]() {
@@ -1871,13 +1906,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             const double span = HAS_TS ? time_at(item.start + item.length - 1) - start_time
                                        : (double)(item.length - 1) * interval;
             const double last_value = slope * span + first_value;
-            out[item.record].p1 = (float)last_value;
+            if (PIECES) split.p1[base + item.start] = (float)last_value;
+            else out[item.record].p1 = (float)last_value;
         }
         n_pending = 0;
     };
 
     while (current < n) {
-        if (leave.chunk_left && current >= next_look) {
+        if (visited(current)) break; // (pieces) the chain from here on is in the table
+        if (!PIECES && leave.chunk_left && current >= next_look) {
             // (what is left of the chunk at the pace of this window against the whole chunk in split mode)
             if ((uint64_t)half_steps * leave.points_per_step * (n - current) > 2ull * (current - looked_at) * n) {
                 if (lane == 0) {
@@ -1960,10 +1997,12 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             __syncthreads();
             if (standing) { // the first start point a model stands on: everything in front of it is rejected
                 const uint32_t skipped = read_lane(offset, __builtin_ctzll(standing));
+                if (PIECES) mark_rejected(current, skipped);
                 current += skipped;
                 counted[WAVE_REJECTED] += skipped;
                 after_rejection = false;
             } else {
+                if (PIECES) mark_rejected(current, covered);
                 current += covered;
                 counted[WAVE_REJECTED] += covered;
             }
@@ -2152,7 +2191,14 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             accepted_model = __shfl(accepted_flag, 0) != 0;
             rec.start_and_type = __shfl(rec.start_and_type, 0);
             rec.end = __shfl(rec.end, 0);
-            if (accepted_model && lane == 0) out[n_models] = rec;
+            if (accepted_model && lane == 0) {
+                if (PIECES) {
+                    split.p0[base + current] = rec.p0;
+                    split.p1[base + current] = rec.p1;
+                } else {
+                    out[n_models] = rec;
+                }
+            }
         } else {
             // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
             const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc_length;
@@ -2172,7 +2218,10 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     if (lane == 0) pending[n_pending] = {n_models, current, swing_length, lower_slope, upper_slope};
                     n_pending += 1;
                 }
-                if (lane == 0) {
+                if (lane == 0 && PIECES) {
+                    split.p0[base + current] = rec.p0;
+                    if (choose_pmc) split.p1[base + current] = rec.p1;
+                } else if (lane == 0) {
                     // (p1 of a queued Swing model is flush_pending's to write: some lane's, some time later)
                     out[n_models].start_and_type = rec.start_and_type;
                     out[n_models].end = rec.end;
@@ -2183,7 +2232,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         }
         if (accepted_model) {
             rejections_in_a_row = 0;
-            gaps.on_model(current, rec.end);
+            if (PIECES) {
+                // (the entry says "a wave has been here" and where its model ends; p0 / p1 are read by k_fit_walk,
+                // a kernel later)
+                if (lane == 0)
+                    __hip_atomic_store(&split.entry[base + current], (rec.end + ENTRY_END_BIAS) | (rec.start_and_type & 0x80000000u),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                gaps.on_model(current, rec.end);
+            }
             n_models += 1;
             current = rec.end + 1;
             if (n_pending == (uint32_t)MDB_WAVE) {
@@ -2192,6 +2249,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                 __syncthreads();
             }
         } else {
+            if (PIECES) mark_rejected(current, 1);
             current += 1; // the point becomes a residual (compression.rs:258-262)
             counted[WAVE_REJECTED] += 1;
             // (a lone rejected point between two models is cheaper found by the next model's step than by a pass
@@ -2202,7 +2260,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     }
     __syncthreads();
     flush_pending();
-    if (lane == 0) plans[chunk] = {n_models, gaps.finish(n)};
+    if (lane == 0 && !PIECES) plans[chunk] = {n_models, gaps.finish(n)};
     counted[WAVE_MODELS] = n_models;
     report_counts();
 }
@@ -2595,6 +2653,7 @@ constexpr int GAP_BUFFER_WORDS = 96; // 64 codes x 45 bits + a carried partial b
 __global__ __launch_bounds__(256) void k_fit_gap_select(FitArgs args, const SegItem *__restrict__ items,
                                                         uint64_t n_segments, uint32_t *__restrict__ gap_ids,
                                                         uint32_t *__restrict__ n_gaps) {
+    if (args.n_segments_dev) n_segments = *args.n_segments_dev;
     const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (segment >= n_segments) return;
     if (gap_goes_to_a_wave(args, items[segment])) gap_ids[atomicAdd(n_gaps, 1u)] = (uint32_t)segment;
@@ -2645,6 +2704,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
                                                       GapResult *__restrict__ results, EncodeTargets targets) {
     __shared__ uint32_t buffer[GAP_BUFFER_WORDS];
     if (blockIdx.x >= *n_gaps) return;
+    if (WRITE && args.targets_dev) targets = *args.targets_dev;
     const uint32_t segment = gap_ids[blockIdx.x];
     const SegItem item = items[segment];
     const int lane = threadIdx.x;
@@ -2979,6 +3039,8 @@ __global__ __launch_bounds__(FIT_SEGMENT_THREADS) void k_fit_size(FitArgs args, 
                                                   const ModelRec *__restrict__ records,
                                                   const SegItem *__restrict__ items, uint64_t n_segments,
                                                   SegSizes *__restrict__ sizes) {
+    if (args.n_segments_dev) n_segments = *args.n_segments_dev;
+    if ((uint64_t)blockIdx.x * FIT_SEGMENT_THREADS >= n_segments) return; // (a launch over an upper bound)
     const uint64_t segment = segment_by_serial_work(args, record_base, records, items, n_segments);
     if (segment >= n_segments) return;
     SegSizes s = {0, 0, 0, 0};
@@ -2990,10 +3052,117 @@ __global__ __launch_bounds__(FIT_SEGMENT_THREADS) void k_fit_encode(FitArgs args
                                                     const ModelRec *__restrict__ records,
                                                     const SegItem *__restrict__ items, uint64_t n_segments,
                                                     const SegSizes *__restrict__ sizes, EncodeTargets targets) {
+    if (args.n_segments_dev) n_segments = *args.n_segments_dev;
+    if ((uint64_t)blockIdx.x * FIT_SEGMENT_THREADS >= n_segments) return;
+    if (args.targets_dev) targets = *args.targets_dev;
     const uint64_t segment = segment_by_serial_work(args, record_base, records, items, n_segments);
     if (segment >= n_segments) return;
     SegSizes s = sizes[segment];
     process_segment<true>(args, record_base, records, items[segment], segment, &s, &targets);
+}
+
+// ---- a handful of chunks: no question to the device between the upload and the download -----------------------
+//
+// The reference's server compresses ONE finished buffer of 65 536 points per call (uncompressed_data_manager.rs:
+// 530-596, storage/mod.rs:58). The general driver below asks the device eight times how much it has made so far
+// (records, pieces, segments, gaps, three payload sizes, the tables) to size what comes next, allocates the batch
+// with hipMalloc and downloads it column by column: 2.5 ms for a buffer one CPU thread fits in 0.8. Here everything
+// is sized by upper bounds the host can know (a model has at least 8 points: at most n / 8 + n / 256 + 2 segments per
+// chunk; a MacaqueV code at most 45 bits), the kernels read the counts the kernels before them left in device memory,
+// the last ones write all columns packed behind a header into one block, and the host copies that block once.
+// Models: one wave per PIECE of a chunk (k_fit_models_wave<.., PIECES>), so that a chunk's latency is a piece's.
+struct SmallHeader {
+    unsigned long long n_segments;
+    unsigned long long blob_bytes;   // header included
+    unsigned long long offsets[13];  // into the block: type, start, end, min, max, error, chunk, views x 3, data x 3
+    unsigned long long data_bytes[3];
+    unsigned int error;              // ERR_* of the fit, or SMALL_OVERFLOW
+    unsigned int pad;
+};
+constexpr unsigned int SMALL_OVERFLOW = 0x40000000u;
+constexpr uint64_t SMALL_HEADER_BYTES = 256;
+static_assert(sizeof(SmallHeader) <= SMALL_HEADER_BYTES, "the header's place in the block");
+
+// Segments per chunk -> first segment of every chunk, and the call's number of segments.
+__global__ __launch_bounds__(64) void k_small_segments(const ChunkPlan *__restrict__ plans, uint64_t n_chunks,
+                                                       unsigned long long *__restrict__ segment_base,
+                                                       unsigned long long *__restrict__ n_segments) {
+    if (threadIdx.x != 0) return;
+    unsigned long long running = 0;
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        segment_base[c] = running;
+        running += plans[c].n_segments;
+    }
+    segment_base[n_chunks] = running;
+    *n_segments = running;
+}
+
+// Where every out-of-line payload goes (three exclusive scans over the segments), where every column goes in the
+// block, and the header the host reads.
+__global__ __launch_bounds__(1024) void k_small_layout(const SegSizes *__restrict__ sizes,
+                                                       unsigned long long *__restrict__ n_segments_dev,
+                                                       unsigned long long *__restrict__ data_offsets, uint64_t offsets_stride,
+                                                       const unsigned long long *__restrict__ zero_base, uint8_t *__restrict__ blob,
+                                                       uint64_t blob_capacity, const unsigned int *__restrict__ fit_error,
+                                                       EncodeTargets *__restrict__ targets_out) {
+    __shared__ uint64_t lds[17];
+    __shared__ unsigned long long totals[3];
+    const uint64_t n = *n_segments_dev;
+    for (int c = 0; c < 3; c++) {
+        unsigned long long *out = data_offsets + c * offsets_stride;
+        const OutOfLineBytes bytes{sizes, c};
+        uint64_t carry = 0;
+        for (uint64_t first = 0; first < n; first += 1024) {
+            const uint64_t i = first + threadIdx.x;
+            const uint64_t mine = i < n ? bytes(i) : 0;
+            uint64_t total;
+            const uint64_t before = block_exclusive_scan_u64(mine, lds, &total);
+            if (i < n) out[i] = carry + before;
+            carry += total;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            out[n] = carry;
+            totals[c] = carry;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    SmallHeader header{};
+    uint64_t cursor = SMALL_HEADER_BYTES;
+    auto carve = [&](int k, uint64_t bytes) {
+        header.offsets[k] = cursor;
+        cursor = (cursor + bytes + 63) / 64 * 64;
+    };
+    carve(0, n); carve(1, 8 * n); carve(2, 8 * n); carve(3, 4 * n); carve(4, 4 * n); carve(5, 4 * n); carve(6, 4 * n);
+    for (int c = 0; c < 3; c++) carve(7 + c, 16 * n);
+    for (int c = 0; c < 3; c++) carve(10 + c, totals[c]);
+    header.n_segments = n;
+    header.blob_bytes = cursor;
+    for (int c = 0; c < 3; c++) header.data_bytes[c] = totals[c];
+    header.error = *fit_error | (cursor > blob_capacity ? SMALL_OVERFLOW : 0u);
+    EncodeTargets t{};
+    if (cursor <= blob_capacity) {
+        t.model_type_id = reinterpret_cast<int8_t *>(blob + header.offsets[0]);
+        t.start_time = reinterpret_cast<int64_t *>(blob + header.offsets[1]);
+        t.end_time = reinterpret_cast<int64_t *>(blob + header.offsets[2]);
+        t.min_value = reinterpret_cast<float *>(blob + header.offsets[3]);
+        t.max_value = reinterpret_cast<float *>(blob + header.offsets[4]);
+        t.error = reinterpret_cast<float *>(blob + header.offsets[5]);
+        t.chunk_index = reinterpret_cast<uint32_t *>(blob + header.offsets[6]);
+        for (int c = 0; c < 3; c++) {
+            t.views[c] = reinterpret_cast<uint4 *>(blob + header.offsets[7 + c]);
+            t.data[c] = blob + header.offsets[10 + c];
+            t.data_offsets[c] = data_offsets + c * offsets_stride;
+            t.data_bases[c] = zero_base; // one data buffer per column
+            t.n_data_buffers[c] = 1;
+        }
+    } else {
+        header.n_segments = 0;
+        *n_segments_dev = 0; // (the encoders behind this kernel find nothing to do)
+    }
+    *targets_out = t;
+    *reinterpret_cast<SmallHeader *>(blob) = header;
 }
 
 // ---- host driver ----------------------------------------------------------------------------------------------
@@ -3231,7 +3400,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 LaunchTimer timer(ctx, "k_fit_models_wave");
 #define MDB_LAUNCH_WAVE(KIND, HAS_TS)                                                                                    \
     hipLaunchKernelGGL((k_fit_models_wave<KIND, HAS_TS>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream, args, \
-                       leave, record_base, records, plans, error_flag)
+                       leave, SplitArgs{}, record_base, records, plans, error_flag)
                 if (eb.kind == MDB_EB_RELATIVE) {
                     if (ts) MDB_LAUNCH_WAVE(MDB_EB_RELATIVE, true);
                     else MDB_LAUNCH_WAVE(MDB_EB_RELATIVE, false);
@@ -3588,6 +3757,242 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
 #undef FIT_TRY
 }
 
+// MDB_FIT_SMALL=0: never the path of a handful of chunks; N >= 1: for calls of up to N chunks (default 64). Calls
+// with any other MDB_FIT_* switch set take the general driver (the switches select among ITS kernels).
+static uint64_t fit_small_max_chunks() {
+    for (const char *name : {"MDB_FIT_WAVE", "MDB_FIT_PIECE_POINTS", "MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_GAP_MIN_VALUES",
+                             "MDB_FIT_DATA_BUFFER_BYTES", "MDB_FIT_DEBUG"})
+        if (std::getenv(name)) return 0;
+    if (const char *text = std::getenv("MDB_FIT_SMALL")) return (uint64_t)std::max(0ll, std::atoll(text));
+    return 64;
+}
+constexpr uint64_t FIT_SMALL_MAX_POINTS = 1ull << 22;
+
+// The fit of a handful of chunks whose values lie in HOST memory, to segments in host memory (file comment above
+// k_small_segments). Returns 0: done, *out is the batch; 1: failed (fail() has the text); 2: not a call for this path
+// (too large, timestamps that are not equally spaced or not exact as f64): the general driver takes it.
+int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb_error_bound eb, mdb_segments_owned **out) {
+    const uint64_t max_chunks = fit_small_max_chunks();
+    if (n_chunks == 0 || n_chunks > max_chunks) return 2;
+    if (!valid_error_bound(eb)) return 2; // (the general driver has the message)
+    uint64_t total = 0;
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        if (chunks[c].n > COUNT_MASK - ENTRY_END_BIAS) return 2;
+        total += chunks[c].n;
+    }
+    if (total == 0 || total > FIT_SMALL_MAX_POINTS) return 2;
+    // Equally spaced, and exact as f64 (k_fit_exact_double_timestamps)? One pass over the timestamps of every chunk.
+    std::vector<long long> first(n_chunks, 0), interval(n_chunks, 0);
+    const uint64_t limit = 1ull << 52;
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        const uint64_t n = chunks[c].n;
+        if (n == 0) continue;
+        const int64_t *t = chunks[c].ts;
+        const int64_t step = n > 1 ? (int64_t)((uint64_t)t[1] - (uint64_t)t[0]) : 0;
+        bool differs = false;
+        for (uint64_t j = 2; j < n; j++) differs |= (int64_t)((uint64_t)t[j] - (uint64_t)t[j - 1]) != step;
+        if (differs) return 2;
+        first[c] = t[0];
+        interval[c] = step;
+        const uint64_t magnitude = t[0] < 0 ? 0ull - (uint64_t)t[0] : (uint64_t)t[0];
+        const uint64_t stride = step < 0 ? 0ull - (uint64_t)step : (uint64_t)step;
+        if (!(magnitude <= limit && (stride == 0 || n <= limit / stride))) return 2;
+    }
+
+    // ---- sizes the host can know ----
+    const uint32_t piece_points = (uint32_t)std::max<uint64_t>(2048, align_up(total / 2048 + 1, 64));
+    std::vector<unsigned long long> offsets(n_chunks + 1, 0), piece_base(n_chunks + 1, 0), record_base(n_chunks + 1, 0);
+    uint64_t segment_bound = 0;
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        const uint64_t n = chunks[c].n;
+        offsets[c + 1] = offsets[c] + n;
+        piece_base[c + 1] = piece_base[c] + (n + piece_points - 1) / piece_points;
+        record_base[c + 1] = record_base[c] + (n / 8 + 1);
+        segment_bound += n / 8 + n / 256 + 2;
+    }
+    const uint64_t n_pieces = piece_base[n_chunks], total_records = record_base[n_chunks];
+    const uint64_t gap_bound = total / GAP_DEFAULT_MIN_VALUES + n_chunks;
+    const uint64_t blob_capacity = align_up(SMALL_HEADER_BYTES + 128 * segment_bound + 6 * total + 16 * segment_bound + 4096, 4096);
+
+    // ---- the page-locked block: [meta | values] go up in one copy, [header | columns] come down into the rest ----
+    uint64_t cursor = 0;
+    auto carve = [&](uint64_t bytes) {
+        const uint64_t at = cursor;
+        cursor = align_up(cursor + bytes, 256);
+        return at;
+    };
+    const uint64_t m_offsets = carve(8 * (n_chunks + 1)), m_first = carve(8 * n_chunks), m_interval = carve(8 * n_chunks);
+    const uint64_t m_piece_base = carve(8 * (n_chunks + 1)), m_record_base = carve(8 * (n_chunks + 1));
+    const uint64_t m_values = carve(4 * total);
+    const uint64_t upload_bytes = cursor;
+    // (device only, behind the upload; the zeroed part first)
+    const uint64_t d_zero = cursor;
+    const uint64_t d_error = carve(64), d_n_gaps = carve(64), d_n_segments = carve(64), d_zero_base = carve(64);
+    const uint64_t d_entry = carve(4 * total);
+    const uint64_t zero_bytes = cursor - d_zero;
+    const uint64_t d_p0 = carve(4 * total), d_p1 = carve(4 * total);
+    const uint64_t d_records = carve(sizeof(ModelRec) * total_records), d_plans = carve(sizeof(ChunkPlan) * n_chunks);
+    const uint64_t d_segment_base = carve(8 * (n_chunks + 1)), d_items = carve(sizeof(SegItem) * segment_bound);
+    const uint64_t d_sizes = carve(sizeof(SegSizes) * segment_bound), d_data_offsets = carve(3 * 8 * (segment_bound + 1));
+    const uint64_t d_gap_results = carve(sizeof(GapResult) * segment_bound), d_gap_ids = carve(4 * gap_bound);
+    const uint64_t d_targets = carve(sizeof(EncodeTargets));
+    const uint64_t d_blob = carve(blob_capacity);
+    const uint64_t device_bytes = cursor;
+
+    mdb::CallGuard lock(ctx);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    void *pinned = nullptr, *device = nullptr;
+    const uint64_t pinned_down = align_up(upload_bytes, 4096);
+    if (pinned_reserve(ctx, pinned_down + blob_capacity, &pinned)) return 1;
+    if (scratch_reserve(ctx, SCRATCH_FIT_SMALL, device_bytes, &device)) return 1;
+    uint8_t *host = static_cast<uint8_t *>(pinned), *dev = static_cast<uint8_t *>(device);
+    std::memcpy(host + m_offsets, offsets.data(), 8 * (n_chunks + 1));
+    std::memcpy(host + m_first, first.data(), 8 * n_chunks);
+    std::memcpy(host + m_interval, interval.data(), 8 * n_chunks);
+    std::memcpy(host + m_piece_base, piece_base.data(), 8 * (n_chunks + 1));
+    std::memcpy(host + m_record_base, record_base.data(), 8 * (n_chunks + 1));
+    {
+        // (the values: by the host's threads when there is more than a buffer or two of them)
+        struct Gather {
+            const mdb_chunk *chunks;
+            const unsigned long long *offsets;
+            float *to;
+        } gather{chunks, offsets.data(), reinterpret_cast<float *>(host + m_values)};
+        auto one = [](unsigned c, void *arg) {
+            const Gather &g = *static_cast<Gather *>(arg);
+            if (g.chunks[c].n) std::memcpy(g.to + g.offsets[c], g.chunks[c].values, 4 * g.chunks[c].n);
+        };
+        if (n_chunks >= 4 && total >= (1u << 18)) host_parallel((unsigned)n_chunks, one, &gather);
+        else
+            for (unsigned c = 0; c < (unsigned)n_chunks; c++) one(c, &gather);
+    }
+    hipStream_t stream = ctx->stream;
+    MDB_HIP_CHECK(hipMemcpyAsync(dev, host, upload_bytes, hipMemcpyHostToDevice, stream));
+    MDB_HIP_CHECK(hipMemsetAsync(dev + d_zero, 0, zero_bytes, stream));
+
+    FitArgs args;
+    args.values = reinterpret_cast<const float *>(dev + m_values);
+    args.timestamps = {nullptr, 0, 0, nullptr, reinterpret_cast<const long long *>(dev + m_first),
+                       reinterpret_cast<const long long *>(dev + m_interval), nullptr};
+    args.chunk_offsets = reinterpret_cast<const unsigned long long *>(dev + m_offsets);
+    args.n_chunks = n_chunks;
+    args.eb = eb;
+    args.gap_min_values = GAP_DEFAULT_MIN_VALUES;
+    args.gap_results = reinterpret_cast<const GapResult *>(dev + d_gap_results);
+    args.ts_results = nullptr;
+    args.n_segments_dev = reinterpret_cast<const unsigned long long *>(dev + d_n_segments);
+    args.targets_dev = reinterpret_cast<const EncodeTargets *>(dev + d_targets);
+    SplitArgs split{};
+    split.piece_base = reinterpret_cast<const unsigned long long *>(dev + m_piece_base);
+    split.n_pieces = n_pieces;
+    split.piece_points = piece_points;
+    split.entry = reinterpret_cast<unsigned int *>(dev + d_entry);
+    split.p0 = reinterpret_cast<float *>(dev + d_p0);
+    split.p1 = reinterpret_cast<float *>(dev + d_p1);
+    split.chunk_left = nullptr;
+    const unsigned long long *record_base_dev = reinterpret_cast<const unsigned long long *>(dev + m_record_base);
+    ModelRec *records = reinterpret_cast<ModelRec *>(dev + d_records);
+    ChunkPlan *plans = reinterpret_cast<ChunkPlan *>(dev + d_plans);
+    unsigned long long *segment_base = reinterpret_cast<unsigned long long *>(dev + d_segment_base);
+    SegItem *items = reinterpret_cast<SegItem *>(dev + d_items);
+    SegSizes *sizes = reinterpret_cast<SegSizes *>(dev + d_sizes);
+    unsigned int *error_flag = reinterpret_cast<unsigned int *>(dev + d_error);
+    uint32_t *n_gaps = reinterpret_cast<uint32_t *>(dev + d_n_gaps), *gap_ids = reinterpret_cast<uint32_t *>(dev + d_gap_ids);
+    unsigned long long *n_segments_dev = reinterpret_cast<unsigned long long *>(dev + d_n_segments);
+    GapResult *gap_results = reinterpret_cast<GapResult *>(dev + d_gap_results);
+    {
+        LaunchTimer timer(ctx, "k_fit_models_wave_pieces");
+#define MDB_LAUNCH_PIECES(KIND)                                                                                              \
+    hipLaunchKernelGGL((k_fit_models_wave<KIND, false, true>), dim3((uint32_t)n_pieces), dim3(MDB_WAVE), 0, stream, args,    \
+                       WaveLeave{}, split, record_base_dev, records, plans, error_flag)
+        if (eb.kind == MDB_EB_RELATIVE) MDB_LAUNCH_PIECES(MDB_EB_RELATIVE);
+        else if (eb.kind == MDB_EB_ABSOLUTE) MDB_LAUNCH_PIECES(MDB_EB_ABSOLUTE);
+        else MDB_LAUNCH_PIECES(MDB_EB_LOSSLESS);
+#undef MDB_LAUNCH_PIECES
+    }
+    {
+        LaunchTimer timer(ctx, "k_fit_walk");
+        hipLaunchKernelGGL(k_fit_walk, dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, stream, args.chunk_offsets, n_chunks, split,
+                           record_base_dev, records, plans, error_flag);
+    }
+    {
+        LaunchTimer timer(ctx, "k_fit_plan");
+        hipLaunchKernelGGL(k_small_segments, dim3(1), dim3(64), 0, stream, plans, n_chunks, segment_base, n_segments_dev);
+        hipLaunchKernelGGL(k_fit_plan, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, stream, args.chunk_offsets,
+                           n_chunks, record_base_dev, records, plans, segment_base, items);
+    }
+    {
+        LaunchTimer timer(ctx, "k_fit_gap_size");
+        hipLaunchKernelGGL(k_fit_gap_select, dim3((uint32_t)((segment_bound + 255) / 256)), dim3(256), 0, stream, args, items,
+                           (uint64_t)0, gap_ids, n_gaps);
+        hipLaunchKernelGGL(k_fit_gap<false>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
+                           gap_results, EncodeTargets{});
+    }
+    const uint32_t segment_blocks = (uint32_t)((segment_bound + FIT_SEGMENT_THREADS - 1) / FIT_SEGMENT_THREADS);
+    {
+        LaunchTimer timer(ctx, "k_fit_size");
+        hipLaunchKernelGGL(k_fit_size, dim3(segment_blocks), dim3(FIT_SEGMENT_THREADS), 0, stream, args, record_base_dev, records,
+                           items, (uint64_t)0, sizes);
+    }
+    {
+        LaunchTimer timer(ctx, "k_small_layout");
+        hipLaunchKernelGGL(k_small_layout, dim3(1), dim3(1024), 0, stream, sizes, n_segments_dev,
+                           reinterpret_cast<unsigned long long *>(dev + d_data_offsets), segment_bound + 1,
+                           reinterpret_cast<const unsigned long long *>(dev + d_zero_base), dev + d_blob, blob_capacity, error_flag,
+                           reinterpret_cast<EncodeTargets *>(dev + d_targets));
+    }
+    {
+        LaunchTimer timer(ctx, "k_fit_encode");
+        hipLaunchKernelGGL(k_fit_gap<true>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
+                           gap_results, EncodeTargets{});
+        hipLaunchKernelGGL(k_fit_encode, dim3(segment_blocks), dim3(FIT_SEGMENT_THREADS), 0, stream, args, record_base_dev, records,
+                           items, (uint64_t)0, sizes, EncodeTargets{});
+    }
+    // ---- one copy down: the header and what usually is the whole block; the rest if there is more ----
+    uint8_t *down = host + pinned_down;
+    const uint64_t first_copy = std::min<uint64_t>(blob_capacity, 192u << 10);
+    MDB_HIP_CHECK(hipMemcpyAsync(down, dev + d_blob, first_copy, hipMemcpyDeviceToHost, stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(stream));
+    MDB_HIP_CHECK(hipGetLastError());
+    const SmallHeader header = *reinterpret_cast<const SmallHeader *>(down);
+    if (header.error & ERR_SPLIT_CHAIN) return fail("Internal error: the split fit left a gap in a chunk's model chain.");
+    if (header.error & SMALL_OVERFLOW) return 2; // (cannot happen: the block is sized for the worst case)
+    if (header.error) return fail("A chunk holds more than 2^31-3 data points.");
+    if (header.blob_bytes > first_copy) {
+        MDB_HIP_CHECK(hipMemcpyAsync(down + first_copy, dev + d_blob + first_copy, header.blob_bytes - first_copy,
+                                     hipMemcpyDeviceToHost, stream));
+        MDB_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    // ---- the batch in host memory: one allocation, the columns where the kernels packed them ----
+    OwnedSegments *owned = new OwnedSegments();
+    owned->host_allocs.resize(1);
+    owned->host_allocs[0].assign(down, down + header.blob_bytes);
+    const uint8_t *blob = owned->host_allocs[0].data();
+    const uint64_t n = header.n_segments;
+    mdb_segments &seg = owned->c.seg;
+    seg.n = n;
+    seg.model_type_id = reinterpret_cast<const int8_t *>(blob + header.offsets[0]);
+    seg.start_time = reinterpret_cast<const int64_t *>(blob + header.offsets[1]);
+    seg.end_time = reinterpret_cast<const int64_t *>(blob + header.offsets[2]);
+    seg.min_value = reinterpret_cast<const float *>(blob + header.offsets[3]);
+    seg.max_value = reinterpret_cast<const float *>(blob + header.offsets[4]);
+    mdb_binview_col *cols[3] = {&seg.timestamps, &seg.values, &seg.residuals};
+    for (int c = 0; c < 3; c++) {
+        owned->buffer_ptrs[c].push_back(blob + header.offsets[10 + c]);
+        owned->buffer_sizes[c].push_back((int64_t)header.data_bytes[c]);
+        cols[c]->views = reinterpret_cast<const mdb_view16 *>(blob + header.offsets[7 + c]);
+        cols[c]->buffers = owned->buffer_ptrs[c].data();
+        cols[c]->buffer_sizes = owned->buffer_sizes[c].data();
+        cols[c]->n_buffers = 1;
+    }
+    owned->c.error = reinterpret_cast<const float *>(blob + header.offsets[5]);
+    owned->c.chunk_index = reinterpret_cast<const uint32_t *>(blob + header.offsets[6]);
+    owned->c.on_device = 0;
+    owned->c.priv_ = owned;
+    *out = &owned->c;
+    return 0;
+}
+
 } // namespace mdb
 
 using namespace mdb;
@@ -3616,6 +4021,13 @@ int mdb_compress_chunks(mdb_ctx *ctx, const int64_t *ts, const float *values,
     if (total > 0 && (!ts || !values)) return fail("ts and values must not be NULL.");
     for (uint64_t c = 0; c < n_chunks; c++)
         if (chunk_offsets[c] > chunk_offsets[c + 1]) return fail("chunk_offsets must be non-decreasing.");
+    if (n_chunks > 0 && n_chunks <= 4096 && total <= FIT_SMALL_MAX_POINTS) { // (a handful of chunks: fit_few_chunks)
+        std::vector<mdb_chunk> list(n_chunks);
+        for (uint64_t c = 0; c < n_chunks; c++)
+            list[c] = {ts + chunk_offsets[c], values + chunk_offsets[c], chunk_offsets[c + 1] - chunk_offsets[c]};
+        const int small = fit_few_chunks(ctx, list.data(), n_chunks, error_bound, out);
+        if (small != 2) return small;
+    }
     mdb_segments_owned *dev = nullptr;
     int rc = 0;
     {
@@ -3756,6 +4168,12 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
         }
     }
     const uint64_t total = offsets[n_chunks];
+    {
+        // A handful of chunks (the server's call: one finished buffer): upload, kernels, download without a question
+        // to the device in between.
+        const int small = fit_few_chunks(ctx, chunks, n_chunks, error_bound, out);
+        if (small != 2) return small;
+    }
     mdb_segments_owned *dev = nullptr;
     int rc = 0;
     // MDB_FIT_DEBUG: where the call's time goes, on stderr
