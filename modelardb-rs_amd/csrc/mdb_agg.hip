@@ -658,7 +658,8 @@ int mdb_agg_batch(mdb_ctx *ctx, const mdb_segments *in, uint32_t which_mask, mdb
     // (they walk while the batch is staged and crosses PCIe: HostWalk)
     MvCallIndex index;
     HostWalk walk;
-    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) walk.start([&index, in] { mv_call_index_build(in, &index); });
+    if ((which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) && mv_host_index_worthwhile(&in, 1))
+        walk.start([&index, in] { mv_call_index_build(in, &index); });
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
@@ -679,7 +680,7 @@ int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t
         if (!inputs[k]) return fail("A batch of the list is NULL.");
     MvCallIndex index;
     HostWalk walk;
-    if (which_mask & (MDB_AGG_SUM | MDB_AGG_AVG))
+    if ((which_mask & (MDB_AGG_SUM | MDB_AGG_AVG)) && mv_host_index_worthwhile(inputs, n_inputs))
         walk.start([&index, inputs, n_inputs] { mv_host_index(inputs, n_inputs, &index.piece_base, &index.cursors); });
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
@@ -700,7 +701,9 @@ int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int6
     MvCallIndex index;
     const MvHostRange host_range{t_lo, t_hi};
     HostWalk walk;
-    walk.start([&index, in, &host_range] { mv_call_index_build(in, &index, &host_range); });
+    // (COUNT alone reads no value; MIN / MAX / SUM of a segment the range cuts do)
+    if ((which_mask & ~(uint32_t)MDB_AGG_COUNT) != 0 && mv_host_index_worthwhile(&in, 1))
+        walk.start([&index, in, &host_range] { mv_call_index_build(in, &index, &host_range); });
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;

@@ -98,6 +98,10 @@ struct MvHostRange { // (optional) only the segments with a point in [lo, hi], b
 void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
                    std::vector<MvCursor> *cursors, const MvHostRange *range = nullptr);
 void mv_call_index_build(const mdb_segments *in, MvCallIndex *out, const MvHostRange *range = nullptr);
+// Is there a row the walk could be for: a MacaqueV segment whose values payload can hold a long stream? Looks at the
+// type column and the lengths in the views only (a batch without either: no): what a caller asks before it starts a
+// thread for the walk.
+bool mv_host_index_worthwhile(const mdb_segments *const *ins, uint32_t n_ins);
 int mv_call_index_use(mdb_ctx *ctx, const mdb_segments &uploaded, const MvCallIndex &index);
 void mv_call_index_done();
 

@@ -207,6 +207,7 @@ void host_index_share(unsigned, void *arg) {
                 position += 1;
                 remaining -= 1;
                 in_stream += 1;
+                if (bits.used > bytes.length * 8) { job.malformed = 1; return; } // (past the end: not another code)
             }
             if (bits.used > bytes.length * 8 || bits.used > 0xffffffffull) { job.malformed = 1; return; }
         }
@@ -217,16 +218,50 @@ void host_index_share(unsigned, void *arg) {
 
 // piece_base (rows + 1) and cursors of the call's long streams; both stay empty when there is nothing to index
 // (MDB_GRID_MV_INDEX=0 included).
+static void mv_host_index_or_throw(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
+                                   std::vector<MvCursor> *cursors, const MvHostRange *range);
+
+static uint32_t mv_host_min_values() {
+    // (MDB_GRID_MV_HOST_MIN_VALUES: streams from that many values on: tests index short ones too)
+    const char *text = std::getenv("MDB_GRID_MV_HOST_MIN_VALUES");
+    const long long wanted = text ? std::atoll(text) : 0;
+    return wanted > 0 ? (uint32_t)std::min<long long>(wanted, 1 << 30) : MV_HOST_MIN_VALUES;
+}
+
+bool mv_host_index_worthwhile(const mdb_segments *const *ins, uint32_t n_ins) {
+    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    if (setting && std::strcmp(setting, "0") == 0) return false;
+    // (a stream of k values: the first raw, every further one at least two bits)
+    const uint64_t least_bytes = (32ull + 2ull * (mv_host_min_values() - 1) + 7) / 8;
+    for (uint32_t h = 0; h < n_ins; h++) {
+        const mdb_segments &seg = *ins[h];
+        if (seg.n == 0) continue;
+        if (!seg.model_type_id || !seg.values.views) return false;
+        for (uint64_t i = 0; i < seg.n; i++)
+            if (seg.model_type_id[i] == MDB_MACAQUE_V_ID && (uint64_t)(uint32_t)seg.values.views[i].length >= least_bytes) return true;
+    }
+    return false;
+}
+
+// (an allocation that fails - the cursors of a huge batch - means "no index", never an exception through the C ABI or
+// a terminated process when the walk runs on a thread of its own)
 void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
-                          std::vector<MvCursor> *cursors, const MvHostRange *range) {
+                   std::vector<MvCursor> *cursors, const MvHostRange *range) {
+    try {
+        mv_host_index_or_throw(ins, n_ins, piece_base, cursors, range);
+    } catch (...) {
+        piece_base->clear();
+        cursors->clear();
+    }
+}
+
+static void mv_host_index_or_throw(const mdb_segments *const *ins, uint32_t n_ins, std::vector<unsigned long long> *piece_base,
+                                   std::vector<MvCursor> *cursors, const MvHostRange *range) {
     piece_base->clear();
     cursors->clear();
     const char *setting = std::getenv("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return;
-    // (MDB_GRID_MV_HOST_MIN_VALUES: streams from that many values on: tests index short ones too)
-    const char *text = std::getenv("MDB_GRID_MV_HOST_MIN_VALUES");
-    const long long wanted = text ? std::atoll(text) : 0;
-    const uint32_t min_values = wanted > 0 ? (uint32_t)std::min<long long>(wanted, 1 << 30) : MV_HOST_MIN_VALUES;
+    const uint32_t min_values = mv_host_min_values();
     HostIndexJob job;
     job.ins = ins;
     uint64_t rows = 0;
@@ -293,6 +328,12 @@ void mv_host_index(const mdb_segments *const *ins, uint32_t n_ins, std::vector<u
             if (n_res > n_total || residuals.length == 1) continue;
             const uint32_t n_model = n_total - n_res;
             if (n_model < min_values) continue;
+            // The point count comes from the metadata (start, end, the length field): a row whose payload cannot hold
+            // that many codes - the first value raw, every further one at least two bits - is malformed and not worth a
+            // walk of 2^31 steps and a cursor array to match; the kernels that report it take the segment.
+            const HostViewBytes stream = host_view_bytes(seg.values, i);
+            if (32ull + 2ull * (n_model - 1) > 8ull * stream.length) continue;
+            if (n_res > 0 && 2ull * n_res > 8ull * (residuals.length - 1)) continue;
             job.chosen.push_back(job.first_row[h] + i);
             job.chosen_input.push_back(h);
             job.n_values.push_back(n_model);

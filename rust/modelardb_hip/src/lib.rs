@@ -356,7 +356,7 @@ impl Context {
         })?;
         let owned = Arc::new(OwnedSegments(NonNull::new(raw).expect("success with a null result")));
         let rows = unsafe { owned.0.as_ref() }.seg.n as usize;
-        owned.to_record_batch(0, rows, compressed_schema, tag_values, field_column_index)
+        record_batch_of_rows(&owned.whole_columns()?, 0, rows, compressed_schema, tag_values, field_column_index)
     }
 
     /// Compresses MANY univariate time series with one launch per distinct error bound and returns one
@@ -405,6 +405,7 @@ impl Context {
                 }
                 (c.seg.n as usize, std::slice::from_raw_parts(c.chunk_index, c.seg.n as usize))
             };
+            let whole = owned.whole_columns()?; // (validated once; every chunk's batch is a slice of it)
             let mut row = 0;
             for (position, &index) in group.iter().enumerate() {
                 let begin = row;
@@ -412,7 +413,8 @@ impl Context {
                     row += 1;
                 }
                 let chunk = &chunks[index];
-                compressed[index] = Some(owned.to_record_batch(
+                compressed[index] = Some(record_batch_of_rows(
+                    &whole,
                     begin,
                     row - begin,
                     chunk.compressed_schema.clone(),
@@ -677,21 +679,14 @@ impl Drop for OwnedSegments {
 }
 
 impl OwnedSegments {
-    /// Rows `[first, first + length)` as a batch with `compressed_schema`
-    /// (`CompressedSegmentBatchBuilder::finish`, types.rs:492-516). The columns wrap the library's memory
-    /// (kept alive by `self`), so cutting one result into a batch per chunk copies nothing.
-    fn to_record_batch(
-        self: &Arc<Self>,
-        first: usize,
-        length: usize,
-        compressed_schema: Arc<Schema>,
-        tag_values: &[String],
-        field_column_index: i16,
-    ) -> Result<RecordBatch> {
+    /// The nine segment columns over ALL rows of the result, wrapping the library's memory (kept alive by
+    /// `self`). Built - and the three BinaryView columns validated - ONCE per result: a result of one launch
+    /// is cut into a batch per chunk, and validating every view of the joint result for every chunk would
+    /// cost (chunks x segments) view checks where (segments) suffice.
+    fn whole_columns(self: &Arc<Self>) -> Result<Vec<ArrayRef>> {
         let owned = unsafe { self.0.as_ref() };
         let segments = &owned.seg;
         let n = segments.n as usize;
-        assert!(first + length <= n);
         if n > 0 && owned.error.is_null() {
             return Err(HipError("The library returned segments without their error column.".to_owned()));
         }
@@ -710,27 +705,55 @@ impl OwnedSegments {
                 let (pointer, size) = unsafe { (*column.buffers.add(index), *column.buffer_sizes.add(index)) };
                 buffers.push(wrap(pointer, size as usize));
             }
-            let views = ScalarBuffer::<u128>::new(wrap(column.views.cast(), 16 * n), 0, n);
+            // A ScalarBuffer<u128> must be 16-byte aligned. The library's views are (every column of a result
+            // begins on a 16-byte boundary of an allocation of the C++ runtime or at a multiple of 64 bytes in
+            // one); a pointer that is not is copied instead of trusted.
+            let view_bytes = if (column.views as usize) % std::mem::align_of::<u128>() == 0 {
+                wrap(column.views.cast(), 16 * n)
+            } else {
+                let copied: Vec<u128> = (0..n)
+                    .map(|row| unsafe { ptr::read_unaligned(column.views.cast::<u128>().add(row)) })
+                    .collect();
+                Buffer::from_vec(copied)
+            };
+            let views = ScalarBuffer::<u128>::new(view_bytes, 0, n);
             // try_new checks every view against `buffers` (length, buffer index, offset, prefix).
             let array = BinaryViewArray::try_new(views, buffers, None).map_err(|error| HipError(error.to_string()))?;
-            Ok(Arc::new(array.slice(first, length)))
+            Ok(Arc::new(array))
         };
-        let mut columns: Vec<ArrayRef> = Vec::with_capacity(compressed_schema.fields().len());
-        columns.push(Arc::new(Int8Array::new(ScalarBuffer::new(wrap(segments.model_type_id.cast(), n), first, length), None)));
-        columns.push(Arc::new(TimestampArray::new(ScalarBuffer::new(wrap(segments.start_time.cast(), 8 * n), first, length), None)));
-        columns.push(Arc::new(TimestampArray::new(ScalarBuffer::new(wrap(segments.end_time.cast(), 8 * n), first, length), None)));
-        columns.push(binary_view(&segments.timestamps)?);
-        columns.push(Arc::new(ValueArray::new(ScalarBuffer::new(wrap(segments.min_value.cast(), 4 * n), first, length), None)));
-        columns.push(Arc::new(ValueArray::new(ScalarBuffer::new(wrap(segments.max_value.cast(), 4 * n), first, length), None)));
-        columns.push(binary_view(&segments.values)?);
-        columns.push(binary_view(&segments.residuals)?);
-        columns.push(Arc::new(Float32Array::new(ScalarBuffer::new(wrap(owned.error.cast(), 4 * n), first, length), None)));
-        columns.push(Arc::new(iter::repeat_n(field_column_index, length).collect::<Int16Array>()));
-        for tag_value in tag_values {
-            columns.push(Arc::new(iter::repeat_n(Some(tag_value), length).collect::<StringViewArray>()));
-        }
-        RecordBatch::try_new(compressed_schema, columns).map_err(|error| HipError(error.to_string()))
+        Ok(vec![
+            Arc::new(Int8Array::new(ScalarBuffer::new(wrap(segments.model_type_id.cast(), n), 0, n), None)) as ArrayRef,
+            Arc::new(TimestampArray::new(ScalarBuffer::new(wrap(segments.start_time.cast(), 8 * n), 0, n), None)) as ArrayRef,
+            Arc::new(TimestampArray::new(ScalarBuffer::new(wrap(segments.end_time.cast(), 8 * n), 0, n), None)) as ArrayRef,
+            binary_view(&segments.timestamps)?,
+            Arc::new(ValueArray::new(ScalarBuffer::new(wrap(segments.min_value.cast(), 4 * n), 0, n), None)) as ArrayRef,
+            Arc::new(ValueArray::new(ScalarBuffer::new(wrap(segments.max_value.cast(), 4 * n), 0, n), None)) as ArrayRef,
+            binary_view(&segments.values)?,
+            binary_view(&segments.residuals)?,
+            Arc::new(Float32Array::new(ScalarBuffer::new(wrap(owned.error.cast(), 4 * n), 0, n), None)) as ArrayRef,
+        ])
     }
+}
+
+/// Rows `[first, first + length)` of `whole` (see [`OwnedSegments::whole_columns`]) as a batch with
+/// `compressed_schema` (`CompressedSegmentBatchBuilder::finish`, types.rs:492-516): slices of the arrays over
+/// the whole result, so cutting one result into a batch per chunk copies and checks nothing.
+fn record_batch_of_rows(
+    whole: &[ArrayRef],
+    first: usize,
+    length: usize,
+    compressed_schema: Arc<Schema>,
+    tag_values: &[String],
+    field_column_index: i16,
+) -> Result<RecordBatch> {
+    assert!(whole.iter().all(|column| first + length <= column.len()));
+    let mut columns: Vec<ArrayRef> = Vec::with_capacity(compressed_schema.fields().len());
+    columns.extend(whole.iter().map(|column| column.slice(first, length)));
+    columns.push(Arc::new(iter::repeat_n(field_column_index, length).collect::<Int16Array>()));
+    for tag_value in tag_values {
+        columns.push(Arc::new(iter::repeat_n(Some(tag_value), length).collect::<StringViewArray>()));
+    }
+    RecordBatch::try_new(compressed_schema, columns).map_err(|error| HipError(error.to_string()))
 }
 
 /// A process-wide context for call sites that have no natural owner for one (the accumulators are
