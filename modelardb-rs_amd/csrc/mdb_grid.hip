@@ -1333,6 +1333,142 @@ __device__ __forceinline__ uint32_t lean_decode_value(LeanReaderDev &reader, MvP
     return bits;
 }
 
+// ---- the same step for the kernels that decode one PIECE per lane, on 32-bit words -------------------------------
+//
+// lean_decode_value costs the wave 104 vector instructions per value: a 64-bit buffer (every shift, add and compare on
+// it is two or three instructions), two refills per code that each rotate four words through registers, a 64-bit bit
+// position. Here a lane keeps the three big-endian words its next code can reach into (a code is at most 45 bits:
+// 13 of header, 32 of payload) and the bit offset into the first; header and payload come out of them with one funnel
+// shift each, and the words behind them come from a ring of the lane's stream in LDS ([word][lane]: the lanes of a
+// wave read different rows of their own column, two lanes per bank at worst), read at the top of the step and needed
+// at its end. The ring is topped up for the whole wave from 16-byte chunks that were loaded one top-up earlier.
+constexpr int PIECE_RING_WORDS = 16;
+constexpr int PIECE_RING_ROWS = PIECE_RING_WORDS + 4; // (and four rows nobody reads: where a lane without room puts its chunk)
+struct PieceReader {
+    const uint4 *chunks; // 16-byte aligned; chunk k holds words [4 k, 4 k + 4) of the stream as this reader counts them
+    uint32_t last_chunk; // the last one that holds payload (loads never go behind it)
+    uint32_t loaded;     // words [.., loaded) have been put into the ring; a multiple of 4
+    uint32_t word;       // index of w0
+    uint32_t w0, w1, w2; // words word, word + 1, word + 2 (big endian: the stream's first bit on top)
+    uint32_t shift;      // bits of w0 already consumed (0..31)
+    uint4 ahead, further, beyond, last; // chunks loaded / 4 .. loaded / 4 + 3, on their way from memory
+
+    __device__ __forceinline__ uint4 load(uint32_t index) const { return load_global(chunks + min(index, last_chunk)); }
+    // nbytes > 0
+    __device__ __forceinline__ void open(const uint8_t *bytes, uint64_t nbytes, uint64_t start_bit) {
+        const uintptr_t address = reinterpret_cast<uintptr_t>(bytes);
+        const uint32_t misalign = (uint32_t)(address & 15u);
+        const uint64_t first_bit = 8ull * misalign + start_bit; // counted from the aligned base
+        const uint64_t skipped = first_bit >> 7;                // whole chunks in front of it
+        const uint64_t all_chunks = (nbytes + misalign + 15u) >> 4;
+        chunks = reinterpret_cast<const uint4 *>(address - misalign) + skipped;
+        last_chunk = (uint32_t)(all_chunks > skipped ? all_chunks - skipped - 1 : 0u);
+        word = (uint32_t)((first_bit >> 5) & 3u);
+        shift = (uint32_t)(first_bit & 31u);
+    }
+    // A lane without a piece runs through the same straight-line code as the others (nothing it makes is looked at):
+    // its reader reads `anywhere`, 16 bytes that may be read.
+    __device__ __forceinline__ void idle(const void *anywhere) {
+        chunks = reinterpret_cast<const uint4 *>(reinterpret_cast<uintptr_t>(anywhere) & ~(uintptr_t)15u);
+        last_chunk = 0;
+        word = shift = 0;
+    }
+    __device__ __forceinline__ void begin() { // (every lane, after open() or idle())
+        loaded = 0;
+        w0 = w1 = w2 = 0;
+        ahead = load(0);
+        further = load(1);
+        beyond = load(2);
+        last = load(3);
+    }
+    // Can the next TWO values be decoded without another look? (a value moves up at most two words; the second one's
+    // words behind w2 are rows word + 5 and word + 6 then)
+    __device__ __forceinline__ bool hungry() const { return loaded < word + 7u; }
+    // The whole wave, without a branch: every lane puts the chunk it has waited for into its column - behind what it
+    // has there, or into rows nobody reads when there is no room for it (a lane far ahead of the hungry one) - and
+    // asks for another one (the same one again when it could not place this one). Four chunks are under way: the one
+    // placed now was asked for four top-ups - the time of a dozen values - ago.
+    __device__ __forceinline__ void top_up(uint32_t (*ring)[MDB_WAVE], int lane) {
+        const bool room = loaded <= word + ((uint32_t)PIECE_RING_WORDS - 4u);
+        const uint32_t row = room ? loaded & (uint32_t)(PIECE_RING_WORDS - 1) : (uint32_t)PIECE_RING_WORDS;
+        ring[row + 0][lane] = ahead.x;
+        ring[row + 1][lane] = ahead.y;
+        ring[row + 2][lane] = ahead.z;
+        ring[row + 3][lane] = ahead.w;
+        loaded += room ? 4u : 0u;
+        auto move_up = [room](uint4 &to, const uint4 &from) {
+            to.x = room ? from.x : to.x;
+            to.y = room ? from.y : to.y;
+            to.z = room ? from.z : to.z;
+            to.w = room ? from.w : to.w;
+        };
+        move_up(ahead, further);
+        move_up(further, beyond);
+        move_up(beyond, last);
+        last = load((loaded >> 2) + 3u);
+    }
+    // After the first top-ups: the three words the first code can reach into.
+    __device__ __forceinline__ void start(const uint32_t (*ring)[MDB_WAVE], int lane) {
+        w0 = __builtin_bswap32(ring[word][lane]);
+        w1 = __builtin_bswap32(ring[word + 1u][lane]);
+        w2 = __builtin_bswap32(ring[word + 2u][lane]);
+    }
+};
+
+struct PieceState {
+    uint32_t last;        // bits of the previous value
+    uint32_t trailing;    // of the window the last `11` code opened
+    uint32_t window_bits; // 32 - leading - trailing of that window (0: none yet - the index has seen every code: there is)
+    bool raw;             // the next value is 32 raw bits (macaque_v.rs:289-293)
+};
+
+// The 32 bits that begin `shift` (0..31) bits into the 64 bits high:low.
+__device__ __forceinline__ uint32_t bits_at(uint32_t high, uint32_t low, uint32_t shift) {
+    return (uint32_t)(((((uint64_t)high) << 32) | low) << shift >> 32);
+}
+
+// One value (macaque_v.rs:297-322; the cursor index has seen every window of the stream: they are possible ones).
+__device__ __forceinline__ uint32_t piece_decode_value(PieceReader &reader, PieceState &state, const uint32_t (*ring)[MDB_WAVE], int lane) {
+    // (the two words that may move up, asked for now, needed last)
+    const uint32_t behind0 = ring[(reader.word + 3u) & (uint32_t)(PIECE_RING_WORDS - 1)][lane];
+    const uint32_t behind1 = ring[(reader.word + 4u) & (uint32_t)(PIECE_RING_WORDS - 1)][lane];
+    const uint32_t head = bits_at(reader.w0, reader.w1, reader.shift); // the next 32 bits of the stream
+    const uint32_t code = head >> 30;                                  // 0x: `0`, 2: `10`, 3: `11`
+    const bool raw = state.raw;
+    const bool opens = !raw && code == 3u, repeats = !raw && code == 2u;
+    const uint32_t header_bits = raw ? 0u : ((0x0d020101u >> (code << 3)) & 15u);
+    const uint32_t leading = (head >> 25) & 31u, length = (head >> 19) & 63u;
+    state.trailing = opens ? (32u - length - leading) & 31u : state.trailing;
+    state.window_bits = opens ? min(length, 32u) : state.window_bits;
+    const uint32_t meaningful = raw ? 32u : (repeats ? 0u : state.window_bits);
+    const uint32_t at = reader.shift + header_bits; // 0..44: where the payload begins, in bits from the top of w0
+    const bool in_first = at < 32u;
+    const uint32_t body = bits_at(in_first ? reader.w0 : reader.w1, in_first ? reader.w1 : reader.w2, at & 31u);
+    const uint32_t payload = meaningful ? body >> ((32u - meaningful) & 31u) : 0u;
+    const uint32_t bits = raw ? payload : (state.last ^ (payload << state.trailing));
+    state.last = bits;
+    state.raw = false;
+    const uint32_t end = at + meaningful; // 0..76
+    const uint32_t taken = end >> 5;      // whole words consumed: 0, 1 or 2
+    reader.shift = end & 31u;
+    reader.word += taken;
+    const uint32_t up0 = __builtin_bswap32(behind0), up1 = __builtin_bswap32(behind1);
+    const uint32_t n0 = taken == 0u ? reader.w0 : (taken == 1u ? reader.w1 : reader.w2);
+    const uint32_t n1 = taken == 0u ? reader.w1 : (taken == 1u ? reader.w2 : up0);
+    const uint32_t n2 = taken == 0u ? reader.w2 : (taken == 1u ? up0 : up1);
+    reader.w0 = n0;
+    reader.w1 = n1;
+    reader.w2 = n2;
+    return bits;
+}
+
+// The largest of the lanes' values, in every lane.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+#pragma unroll
+    for (int step = 1; step < MDB_WAVE; step <<= 1) x = max(x, (uint32_t)__shfl_xor((int)x, step, MDB_WAVE));
+    return x;
+}
+
 // The one kind of stream of an indexed batch that k_grid_serial keeps (see k_grid_mv_pieces).
 __device__ __forceinline__ bool mv_left_to_serial(uint32_t tile_flags) {
     return (tile_flags & FLAG_JUMPS) && (tile_flags & FLAG_TYPE_MASK) == MDB_SWING_ID;
@@ -1344,6 +1480,15 @@ __device__ __forceinline__ bool mv_left_to_serial(uint32_t tile_flags) {
 // SQ_INSTS_VALU x 4 = SQ_WAVE_CYCLES - so neither more waves per SIMD (16 / 32 / 64 values per round: 15.3 / 13.8
 // / 16.3 ms for 5 x 10^9 values) nor staging the streams in LDS (25.7 ms: more instructions, and pieces 48 words
 // apart meet in two banks) changes it; 32 values per round are whole 128-byte lines per row.)
+// MDB_MVP_TIMING (a build of its own, never the product's): shader clock cycles of k_grid_mv_pieces' waves in [0] the
+// whole kernel, [1] the decode loops with [2] their top-ups (and [3] how many), [4] the rows written out; [5] waves.
+#ifdef MDB_MVP_TIMING
+__device__ unsigned long long g_mvp_timing[8];
+#define MVP_CLOCK() __builtin_amdgcn_s_memtime()
+#else
+#define MVP_CLOCK() 0ull
+#endif
+
 template <int ROUND>
 __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, TimeRange range, const TileDesc *__restrict__ desc,
                                                              const unsigned long long *__restrict__ offsets,
@@ -1352,13 +1497,19 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
                                                              float *__restrict__ out_val, GridHeader *__restrict__ header) {
     constexpr int STRIDE = ROUND + 1; // (a row per lane: an odd stride keeps the banks apart)
     __shared__ uint32_t stage[MDB_WAVE * STRIDE];
+    __shared__ uint32_t ring[PIECE_RING_ROWS][MDB_WAVE];
+    __shared__ uint32_t row_count[MDB_WAVE];
+    __shared__ unsigned long long row_out[MDB_WAVE];
     const int lane = threadIdx.x;
+    const unsigned long long t_kernel = MVP_CLOCK();
+    unsigned long long t_decode = 0, t_top_up = 0, n_top_up = 0, t_out = 0;
     const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
     uint32_t count = 0, skip = 0; // values of this lane's piece to write, and how many in front of them are not wanted
     unsigned long long out_at = 0;
-    LeanReaderDev reader;
-    MvPieceState state;
-    state.last = 0; state.leading = 255; state.trailing = 0; state.raw = false;
+    PieceReader reader;
+    PieceState state;
+    reader.idle(cursors);
+    state.last = 0; state.trailing = 0; state.window_bits = 0; state.raw = false;
     if (piece < n_pieces) {
         const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
         const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
@@ -1389,35 +1540,88 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
             reader.open(view_data(column, i, view), nbytes, c0.x);
             const bool macaque = (t.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID;
             state.last = (macaque ? c1.z : __float_as_uint(t.value)) ^ c0.y;
-            state.leading = window & 255u;
-            state.trailing = (window >> 8) & 255u;
+            // (no window yet - leading 255 - is a window of no bits: the stream's first code opens one)
+            const uint32_t leading = window & 255u, trailing = (window >> 8) & 255u;
+            state.trailing = trailing & 31u;
+            state.window_bits = leading + trailing <= 32u ? 32u - leading - trailing : 0u;
             state.raw = (window & MV_WINDOW_RAW) != 0;
         }
     }
+    // (every lane decodes in every step, wanted or not: straight-line code; a lane that is through with its piece
+    // makes values nobody looks at from bytes it may read)
+    reader.begin();
+    reader.top_up(ring, lane);
+    reader.top_up(ring, lane);
+    reader.start(ring, lane);
     // The values in front of the wanted ones are decoded (the chain runs through them) and dropped.
-    for (uint32_t k = 0; __any(k < skip); k++)
-        if (k < skip) (void)lean_decode_value(reader, state);
+    for (uint32_t k = 0, most = wave_max_u32(skip); k < most; k++) {
+        if (__any(reader.hungry())) reader.top_up(ring, lane);
+        const PieceReader reader_before = reader;
+        const PieceState state_before = state;
+        (void)piece_decode_value(reader, state, ring, lane);
+        if (k >= skip) { // (not one of this lane's: it stays where it was)
+            reader = reader_before;
+            state = state_before;
+        }
+    }
     for (uint32_t done = 0; __any(done < count); done += ROUND) {
         const uint32_t mine = done < count ? min(count - done, (uint32_t)ROUND) : 0u;
-        for (uint32_t k = 0; __any(k < mine); k++)
-            if (k < mine) stage[lane * STRIDE + k] = lean_decode_value(reader, state);
-        __builtin_amdgcn_wave_barrier();
+        static_assert(ROUND % 2 == 0, "values are decoded in pairs");
+        const unsigned long long t_loop = MVP_CLOCK();
+        for (uint32_t k = 0, most = wave_max_u32(mine); k < most; k += 2) {
+            if (__any(reader.hungry())) {
+                const unsigned long long t0 = MVP_CLOCK();
+                reader.top_up(ring, lane);
+#ifdef MDB_MVP_TIMING
+                __builtin_amdgcn_s_waitcnt(0);
+#endif
+                t_top_up += MVP_CLOCK() - t0;
+                n_top_up += 1;
+            }
+            stage[lane * STRIDE + k] = piece_decode_value(reader, state, ring, lane);
+            stage[lane * STRIDE + k + 1] = piece_decode_value(reader, state, ring, lane); // (k + 1 == ROUND: the row's spare word)
+        }
+        t_decode += MVP_CLOCK() - t_loop;
+        const unsigned long long t_rows = MVP_CLOCK();
         // Row r = this round's values of lane r's piece: consecutive floats, (64 / ROUND) rows per store instruction.
+        // (how many, and where to: through LDS, read by the lanes of a store without waiting for each other)
+        row_count[lane] = mine;
+        row_out[lane] = out_at + done;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         constexpr int ROWS_PER_STORE = MDB_WAVE / ROUND;
         const int sub_row = lane / ROUND, column_of_lane = lane % ROUND;
-        for (int r0 = 0; r0 < MDB_WAVE; r0 += ROWS_PER_STORE) {
-            const int r = r0 + sub_row;
-            // (every lane needs its own row's numbers: a permute, not a broadcast, when a store covers several rows)
-            const uint32_t row_mine = __shfl(mine, r, MDB_WAVE);
-            const uint32_t row_lo = __shfl((uint32_t)(out_at + done), r, MDB_WAVE);
-            const uint32_t row_hi = __shfl((uint32_t)((out_at + done) >> 32), r, MDB_WAVE);
-            if ((uint32_t)column_of_lane < row_mine) {
-                const unsigned long long row_at = ((unsigned long long)row_hi << 32) | row_lo;
-                out_val[row_at + column_of_lane] = __uint_as_float(stage[r * STRIDE + column_of_lane]);
+        // (eight stores' rows read from LDS together, then the stores: one wait for eight, not two for each)
+        constexpr int BATCH = 8;
+        static_assert(MDB_WAVE % (BATCH * ROWS_PER_STORE) == 0, "whole batches of stores");
+        for (int r0 = 0; r0 < MDB_WAVE; r0 += BATCH * ROWS_PER_STORE) {
+            uint32_t counts[BATCH], staged[BATCH];
+            unsigned long long to[BATCH];
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) {
+                const int r = r0 + q * ROWS_PER_STORE + sub_row;
+                counts[q] = row_count[r];
+                to[q] = row_out[r];
+                staged[q] = stage[r * STRIDE + column_of_lane];
             }
+#pragma unroll
+            for (int q = 0; q < BATCH; q++)
+                if ((uint32_t)column_of_lane < counts[q]) out_val[to[q] + column_of_lane] = __uint_as_float(staged[q]);
         }
         __builtin_amdgcn_wave_barrier();
+        t_out += MVP_CLOCK() - t_rows;
     }
+#ifdef MDB_MVP_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_mvp_timing[0], MVP_CLOCK() - t_kernel);
+        atomicAdd(&g_mvp_timing[1], t_decode);
+        atomicAdd(&g_mvp_timing[2], t_top_up);
+        atomicAdd(&g_mvp_timing[3], n_top_up);
+        atomicAdd(&g_mvp_timing[4], t_out);
+        atomicAdd(&g_mvp_timing[5], 1ull);
+    }
+#endif
 }
 
 // ---- the same cursors for SUM: macaque_v::sum adds a stream's values one after the other in f32 --------------
@@ -3712,29 +3916,44 @@ int mv_index_range_totals(mdb_ctx *ctx, const DevSegments &s, TimeRange range, c
 // What k_grid_tiles (or k_grid_fused) leaves: MacaqueV values and residual tails - piece by piece when the batch has
 // a cursor index, else by the speculative decoder and one lane per stream - and the irregular timestamps that live
 // inside their views.
+// A resident batch with cursors into its MacaqueV streams: every piece of 64 values by a lane of its own.
+static void launch_mv_pieces(mdb_ctx *ctx, const DevSegments &s, TimeRange range, GridPlan &plan, float *out_val, hipStream_t stream) {
+    const MvIndex *index = plan.mv_index.get();
+    LaunchTimer timer(ctx, "k_grid_mv_pieces");
+    // (MDB_GRID_MV_ROUND: values a lane stages per round, 16 / 32 / 64: A/B)
+    static const int round = [] {
+        const char *text = std::getenv("MDB_GRID_MV_ROUND");
+        const int value = text ? std::atoi(text) : 0;
+        return value == 64 || value == 16 ? value : 32;
+    }();
+    const dim3 blocks((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE));
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, blocks, dim3(MDB_WAVE), 0, stream, s, range, plan.desc, plan.offsets,
+                           plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val,
+                           plan.header);
+    };
+    if (round == 64) launch(k_grid_mv_pieces<64>);
+    else if (round == 16) launch(k_grid_mv_pieces<16>);
+    else launch(k_grid_mv_pieces<32>);
+#ifdef MDB_MVP_TIMING
+    {
+        unsigned long long t[8] = {};
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_mvp_timing), sizeof(t));
+        const unsigned long long zero[8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mvp_timing), zero, sizeof(zero));
+        const double waves = (double)t[5];
+        std::fprintf(stderr, "[mv pieces timing] per wave: kernel %.0f cycles, decode loops %.0f of which top-ups %.0f (%.1f of them, %.0f each), rows out %.0f; %.0f waves\n",
+                     t[0] / waves, t[1] / waves, t[2] / waves, t[3] / waves, t[3] ? (double)t[2] / (double)t[3] : 0.0, t[4] / waves, waves);
+    }
+#endif
+}
+
 int grid_launch_streams(mdb_ctx *ctx, const DevSegments &s, TimeRange range, GridPlan &plan, int64_t *out_ts, float *out_val) {
     const uint64_t n_serial = plan.host_header.n_serial;
     const MvSeg *mv_segs = nullptr;
     const MvIndex *index = plan.mv_index.get();
-    if (index) {
-        // A resident batch with cursors into its MacaqueV streams: every piece of 64 values by a lane of its own.
-        LaunchTimer timer(ctx, "k_grid_mv_pieces");
-        // (MDB_GRID_MV_ROUND: values a lane stages per round, 16 / 32 / 64: A/B)
-        static const int round = [] {
-            const char *text = std::getenv("MDB_GRID_MV_ROUND");
-            const int value = text ? std::atoi(text) : 0;
-            return value == 64 || value == 16 ? value : 32;
-        }();
-        const dim3 blocks((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE));
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, blocks, dim3(MDB_WAVE), 0, ctx->stream, s, range, plan.desc, plan.offsets,
-                               plan.irregular_first, static_cast<const MvCursor *>(index->cursors), index->n_pieces, out_val,
-                               plan.header);
-        };
-        if (round == 64) launch(k_grid_mv_pieces<64>);
-        else if (round == 16) launch(k_grid_mv_pieces<16>);
-        else launch(k_grid_mv_pieces<32>);
-    }
+    if (index) launch_mv_pieces(ctx, s, range, plan, out_val, ctx->stream);
     // (the index of one call covers its long streams with regular timestamps: the others are still this decoder's)
     if ((!index || index->of_one_call) && n_serial > 0 && plan.host_header.metrics[9] > 0) {
         MvSeg *segs = nullptr;
