@@ -1304,40 +1304,11 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_mv_index_walk(DevSegments s,
     if (walked) atomicAdd(verdict + 1, walked);
 }
 
-// The decode step of ring_decode_value over a lane's own reader (LeanReaderDev: 16-byte chunks, one ahead).
-struct MvPieceState {
-    uint32_t last, leading, trailing;
-    bool raw;
-};
-__device__ __forceinline__ uint32_t lean_decode_value(LeanReaderDev &reader, MvPieceState &state) {
-    reader.refill();
-    const uint32_t top = (uint32_t)(reader.buffer >> 51); // 13 bits: c0 c1 lz[5] len[6]
-    const bool raw = state.raw;
-    const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
-    const bool opens = !raw && c0 && c1;
-    const bool repeats = !raw && c0 && !c1;
-    const uint32_t header_bits = raw ? 0u : (c0 ? (c1 ? 13u : 2u) : 1u);
-    const uint32_t leading = opens ? ((top >> 6) & 31u) : state.leading;
-    const uint32_t trailing = opens ? 32u - (top & 63u) - leading : state.trailing;
-    uint32_t meaningful = (32u - leading - trailing) & 63u; // (the index has seen every window: it is a possible one)
-    state.leading = leading;
-    state.trailing = trailing;
-    state.raw = false;
-    meaningful = raw ? 32u : (repeats ? 0u : min(meaningful, 32u));
-    reader.consume(header_bits);
-    reader.refill();
-    const uint32_t payload = (uint32_t)((reader.buffer >> 1) >> (63u - meaningful)); // 0 bits: 0
-    reader.consume(meaningful);
-    const uint32_t bits = raw ? payload : (state.last ^ (payload << (trailing & 31u)));
-    state.last = bits;
-    return bits;
-}
-
 // ---- the same step for the kernels that decode one PIECE per lane, on 32-bit words -------------------------------
 //
-// lean_decode_value costs the wave 104 vector instructions per value: a 64-bit buffer (every shift, add and compare on
-// it is two or three instructions), two refills per code that each rotate four words through registers, a 64-bit bit
-// position. Here a lane keeps the three big-endian words its next code can reach into (a code is at most 45 bits:
+// ring_decode_value's step over a 64-bit buffer with a reader of its own per lane cost the wave 104 vector instructions
+// per value (every shift, add and compare on 64 bits is two or three instructions, two refills per code each rotated
+// four words through registers, the bit position was 64 bits wide). Here a lane keeps the three big-endian words its next code can reach into (a code is at most 45 bits:
 // 13 of header, 32 of payload) and the bit offset into the first; header and payload come out of them with one funnel
 // shift each, and the words behind them come from a ring of the lane's stream in LDS ([word][lane]: the lanes of a
 // wave read different rows of their own column, two lanes per bank at worst), read at the top of the step and needed
@@ -1633,24 +1604,46 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
 // every stream up with one lane. stream_sums[2 i] = the sum of MacaqueV segment i's values (macaque_v.rs:228-235:
 // it starts AS the first value), [2 i + 1] = the sum of segment i's residual tail.
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const MvCursor *__restrict__ cursors,
-                                                            unsigned long long n_pieces, uint32_t *__restrict__ values) {
-    // (32 values per lane and round, as k_grid_mv_pieces: a row of 64 values per lane is 16.6 KB of LDS per wave,
-    // which leaves room for 2.4 waves per SIMD where the decoding needs the vector ALU busy)
-    constexpr int ROUND = 32, STRIDE = ROUND + 1; // (an odd stride keeps the banks apart)
+                                                            unsigned long long n_pieces, uint32_t *__restrict__ values,
+                                                            float *__restrict__ stream_sums, unsigned char *__restrict__ stream_done) {
+    // All 64 values of every piece staged in LDS (a row per lane): a stream whose pieces all lie in this wave - most
+    // of a batch's streams are a few pieces long - is added up right here, by the lane of its first piece, in stream
+    // order (stream_done[2 i + tail] = 1, the sum in stream_sums); only the pieces of streams that reach beyond the
+    // wave go to `values` for k_agg_mv_chains. (A round trip of 4 bytes per value through memory otherwise: 2.5 GB
+    // written and read again for the mixed series.)
+    constexpr int STRIDE = MV_PIECE_VALUES + 1; // (an odd stride keeps the banks apart)
     __shared__ uint32_t stage[MDB_WAVE * STRIDE];
+    __shared__ uint32_t ring[PIECE_RING_ROWS][MDB_WAVE];
+    __shared__ uint32_t row_count[MDB_WAVE];
     const int lane = threadIdx.x;
     const unsigned long long first_piece = (unsigned long long)blockIdx.x * MDB_WAVE;
     const unsigned long long piece = first_piece + lane;
-    uint32_t to_decode = 0;
-    LeanReaderDev reader;
-    MvPieceState state;
-    state.last = 0; state.leading = 255; state.trailing = 0; state.raw = false;
+    uint32_t to_decode = 0, segment = 0xffffffffu;
+    bool residual = false, is_head = false, is_tail = false;
+    PieceReader reader;
+    PieceState state;
+    reader.idle(cursors);
+    state.last = 0; state.trailing = 0; state.window_bits = 0; state.raw = false;
     if (piece < n_pieces) {
         const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
         const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
         const uint32_t i = c0.z, window = c1.y;
+        segment = i;
         to_decode = c1.x;
-        const bool residual = (window & MV_WINDOW_RESIDUAL) != 0;
+        residual = (window & MV_WINDOW_RESIDUAL) != 0;
+        // (the pieces in front and behind: of the same stream?)
+        if (piece == 0) {
+            is_head = true;
+        } else {
+            const MvCursor *before = cursors + piece - 1;
+            is_head = load_global(&before->segment) != i || ((load_global(&before->window) & MV_WINDOW_RESIDUAL) != 0) != residual;
+        }
+        if (piece + 1 == n_pieces) {
+            is_tail = true;
+        } else {
+            const MvCursor *behind = cursors + piece + 1;
+            is_tail = load_global(&behind->segment) != i || ((load_global(&behind->window) & MV_WINDOW_RESIDUAL) != 0) != residual;
+        }
         const DevCol &column = residual ? s.residuals : s.values;
         const uint4 view = column.views[i];
         reader.open(view_data(column, i, view), residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
@@ -1670,36 +1663,83 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
             }
         }
         state.last = seed ^ c0.y;
-        state.leading = window & 255u;
-        state.trailing = (window >> 8) & 255u;
+        const uint32_t leading = window & 255u, trailing = (window >> 8) & 255u;
+        state.trailing = trailing & 31u;
+        state.window_bits = leading + trailing <= 32u ? 32u - leading - trailing : 0u;
         state.raw = (window & MV_WINDOW_RAW) != 0;
     }
-    // The wave's 64 pieces are 16 KB in a row in `values` (what lies behind a stream's last value is not read).
-    const unsigned long long rows = min((unsigned long long)MDB_WAVE, n_pieces > first_piece ? n_pieces - first_piece : 0ull);
-    for (uint32_t done = 0; __any(done < to_decode); done += ROUND) {
-        const uint32_t mine = done < to_decode ? min(to_decode - done, (uint32_t)ROUND) : 0u;
-        for (uint32_t k = 0; __any(k < mine); k++)
-            if (k < mine) stage[lane * STRIDE + k] = lean_decode_value(reader, state);
-        __builtin_amdgcn_wave_barrier();
-        // (two rows of 32 values - two 128-byte lines - per store instruction)
-        const unsigned long long sub_row = (unsigned long long)(lane / ROUND);
-        const int column = lane % ROUND;
-        for (unsigned long long r0 = 0; r0 < rows; r0 += MDB_WAVE / ROUND) {
-            const unsigned long long r = r0 + sub_row;
-            if (r < rows) values[(first_piece + r) * MV_PIECE_VALUES + done + column] = stage[r * STRIDE + column];
+    reader.begin();
+    reader.top_up(ring, lane);
+    reader.top_up(ring, lane);
+    reader.start(ring, lane);
+    static_assert(MV_PIECE_VALUES % 2 == 0, "values are decoded in pairs");
+    for (uint32_t k = 0, most = wave_max_u32(to_decode); k < most; k += 2) {
+        if (__any(reader.hungry())) reader.top_up(ring, lane);
+        stage[lane * STRIDE + k] = piece_decode_value(reader, state, ring, lane);
+        stage[lane * STRIDE + k + 1] = piece_decode_value(reader, state, ring, lane); // (k + 1 == 64: the row's spare word)
+    }
+    row_count[lane] = to_decode;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Which pieces belong to a stream that begins AND ends in this wave: the lane of a first piece whose stream's
+    // last piece is one of the lanes behind it (pieces of a stream follow each other).
+    const unsigned long long heads = __ballot(is_head), tails = __ballot(is_tail);
+    const unsigned long long heads_up_to_me = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int my_head = heads_up_to_me ? 63 - __builtin_clzll(heads_up_to_me) : -1; // (none: the stream began in a wave before)
+    const unsigned long long tails_from_head = my_head >= 0 ? tails >> my_head : 0ull;
+    const int my_tail = tails_from_head ? my_head + __builtin_ctzll(tails_from_head) : -1; // (none: it ends in a wave behind)
+    const bool here = piece < n_pieces && my_head >= 0 && my_tail >= 0; // (then my_tail >= lane: no tail between the head and me)
+    if (here && is_head) {
+        // macaque_v.rs:220-265: a segment's values are added to the first one, a tail's to 0, one after the other.
+        float sum = 0.0f;
+        bool starts = !residual;
+        for (int row = lane; row <= my_tail; row++) {
+            const uint32_t n = row_count[row];
+            const uint32_t *from = stage + row * STRIDE;
+            uint32_t k = 0;
+            if (starts && n > 0) {
+                sum = __uint_as_float(from[0]);
+                k = 1;
+                starts = false;
+            }
+            for (; k + 8 <= n; k += 8) { // (eight reads under way, then the chain of additions)
+                uint32_t v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = from[k + q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) sum += __uint_as_float(v[q]);
+            }
+            for (; k < n; k++) sum += __uint_as_float(from[k]);
         }
-        __builtin_amdgcn_wave_barrier();
+        stream_sums[2ull * segment + (residual ? 1u : 0u)] = sum;
+        stream_done[2ull * segment + (residual ? 1u : 0u)] = 1;
+    }
+    // The other pieces' values: to `values`, a row of 64 values (two 128-byte lines) per lane pair of store instructions.
+    const unsigned long long spilled = __ballot(piece < n_pieces && !here);
+    if (spilled) {
+        const int half = lane >> 5, column = lane & 31;
+        for (int r0 = 0; r0 < MDB_WAVE; r0 += 2) {
+            const int r = r0 + half;
+            if (!((spilled >> r) & 1ull)) continue;
+            uint32_t *to = values + (first_piece + (unsigned long long)r) * MV_PIECE_VALUES;
+            to[column] = stage[r * STRIDE + column];
+            to[32 + column] = stage[r * STRIDE + 32 + column];
+        }
     }
 }
 
 template <int LOADS> // 16-byte loads a lane has in flight per round of a long stream: 8, 16 or 32
 __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint32_t *__restrict__ known_totals,
                                                        const unsigned long long *__restrict__ piece_base,
-                                                       const uint32_t *__restrict__ values, float *__restrict__ stream_sums) {
+                                                       const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
+                                                       const unsigned char *__restrict__ stream_done) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     const unsigned long long first_piece = piece_base[i];
     if (piece_base[i + 1] == first_piece) return; // (no stream: nobody reads this segment's sums)
+    // (streams that lay inside one wave of k_agg_mv_pieces have their sums already)
+    const bool values_done = stream_done[2 * i] != 0, tail_done = stream_done[2 * i + 1] != 0;
     uint32_t n_values, n_res, n_model, error;
     mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
     // (cursors left by host threads: should they ever disagree with this analysis about the segment's streams, the
@@ -1754,8 +1794,8 @@ __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint
         return sum;
     };
     const unsigned long long value_pieces = (n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES;
-    stream_sums[2 * i] = n_values ? chain(first_piece, n_values, true) : 0.0f;
-    stream_sums[2 * i + 1] = n_res ? chain(first_piece + value_pieces, n_res, false) : 0.0f;
+    if (!values_done) stream_sums[2 * i] = n_values ? chain(first_piece, n_values, true) : 0.0f;
+    if (!tail_done) stream_sums[2 * i + 1] = n_res ? chain(first_piece + value_pieces, n_res, false) : 0.0f;
 }
 
 // ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
@@ -3053,13 +3093,15 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
     // (the index of one call covers its long streams only: the sums of a segment without pieces are nobody's)
     if (index->of_one_call) *only_with_pieces = static_cast<const unsigned long long *>(index->piece_base);
     void *p = nullptr;
-    if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 8 + 256, &p)) return 1;
+    if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 10 + 256, &p)) return 1;
     uint32_t *values = static_cast<uint32_t *>(p);
     float *sums = reinterpret_cast<float *>(values + index->n_pieces * MV_PIECE_VALUES);
+    unsigned char *done = reinterpret_cast<unsigned char *>(sums + 2 * in->n);
+    MDB_HIP_CHECK(hipMemsetAsync(done, 0, 2 * in->n, ctx->stream));
     {
         LaunchTimer timer(ctx, "k_agg_mv_pieces");
         hipLaunchKernelGGL(k_agg_mv_pieces, dim3((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE)), dim3(MDB_WAVE), 0,
-                           ctx->stream, s, static_cast<const MvCursor *>(index->cursors), index->n_pieces, values);
+                           ctx->stream, s, static_cast<const MvCursor *>(index->cursors), index->n_pieces, values, sums, done);
     }
     {
         LaunchTimer timer(ctx, "k_agg_mv_chains");
@@ -3070,7 +3112,7 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
         const int loads = text ? std::atoi(text) : (in->n <= 512 ? 32 : 8);
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums);
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums, done);
         };
         if (loads == 32) launch(k_agg_mv_chains<32>);
         else if (loads == 16) launch(k_agg_mv_chains<16>);
@@ -3716,14 +3758,16 @@ __global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_range_finish(const Ran
 // wave would each decode one while the others wait).
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRange range, const MvCursor *__restrict__ cursors,
                                                            unsigned long long n_pieces, RangePartial *__restrict__ partials) {
+    __shared__ uint32_t ring[PIECE_RING_ROWS][MDB_WAVE];
     const int lane = threadIdx.x;
     const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
     RangePartial mine;
     mine.clear();
     uint32_t to_decode = 0, to_skip = 0;
-    LeanReaderDev reader;
-    MvPieceState state;
-    state.last = 0; state.leading = 255; state.trailing = 0; state.raw = false;
+    PieceReader reader;
+    PieceState state;
+    reader.idle(cursors);
+    state.last = 0; state.trailing = 0; state.window_bits = 0; state.raw = false;
     if (piece < n_pieces) {
         const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
         const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
@@ -3744,18 +3788,29 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRa
                     const uint4 view = column.views[i];
                     reader.open(view_data(column, i, view), residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
                     state.last = seed ^ c0.y;
-                    state.leading = window & 255u;
-                    state.trailing = (window >> 8) & 255u;
+                    const uint32_t leading = window & 255u, trailing = (window >> 8) & 255u;
+                    state.trailing = trailing & 31u;
+                    state.window_bits = leading + trailing <= 32u ? 32u - leading - trailing : 0u;
                     state.raw = (window & MV_WINDOW_RAW) != 0;
                 }
             }
         }
     }
-    for (uint32_t k = 0; __any(k < to_decode); k++) {
-        if (k < to_decode) {
-            const uint32_t bits = lean_decode_value(reader, state);
-            if (k >= to_skip) mine.point(__uint_as_float(bits));
-        }
+    if (!__any(to_decode > 0)) { // (no piece of the wave reaches into the range)
+        if (lane == 0) partials[blockIdx.x] = mine;
+        return;
+    }
+    reader.begin();
+    reader.top_up(ring, lane);
+    reader.top_up(ring, lane);
+    reader.start(ring, lane);
+    // (every lane decodes in every step - straight-line code -, the values wanted are taken)
+    for (uint32_t k = 0, most = wave_max_u32(to_decode); k < most; k += 2) {
+        if (__any(reader.hungry())) reader.top_up(ring, lane);
+        const uint32_t even = piece_decode_value(reader, state, ring, lane);
+        const uint32_t odd = piece_decode_value(reader, state, ring, lane);
+        if (k >= to_skip && k < to_decode) mine.point(__uint_as_float(even));
+        if (k + 1 >= to_skip && k + 1 < to_decode) mine.point(__uint_as_float(odd));
     }
 #pragma unroll
     for (int delta = MDB_WAVE / 2; delta > 0; delta >>= 1) mine.merge(shfl_down_partial(mine, delta));
