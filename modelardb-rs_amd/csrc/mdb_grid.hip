@@ -286,17 +286,60 @@ __device__ __forceinline__ void grid_tile(
     const uint64_t tile_end = min(total_points, tile_start + TILE_POINTS);
     const uint32_t s0 = tile_first[tile];
     const uint32_t s1 = (tile + 1 < n_tiles) ? tile_first[tile + 1] : (uint32_t)(n_segments - 1);
-    const uint32_t n_in_tile = s1 - s0 + 1;
-    const bool use_lds = n_in_tile <= TILE_LDS_SEGMENTS;
+    uint32_t n_in_tile = s1 - s0 + 1;
+    bool use_lds = n_in_tile <= TILE_LDS_SEGMENTS;
     const uint64_t s0_offset = offsets[s0];
     if (use_lds)
         for (uint32_t k = 1 + threadIdx.x; k < n_in_tile; k += TILE_THREADS)
             rel[k] = (uint32_t)(offsets[s0 + k] - tile_start);
+    // A tile with a run of segments WITHOUT a visible point in its middle (a query over a time range: the segments
+    // behind the range of one series and in front of the range of the next, hundreds of them between the two that
+    // the tile's points belong to): the segments that do have points in the tile, a handful, are put in front of
+    // the table, and the tile is an ordinary one - its descriptors in LDS, a few steps per search - instead of one
+    // that reads descriptors from memory point by point. (thin_segment[k]: which segment of the tile entry k is.)
+    // (both live where the timestamps are transposed later: the barrier behind the descriptors lies in between)
+    uint32_t *kept_rel = reinterpret_cast<uint32_t *>(&ts_slab[0][0]);
+    uint32_t *thin_segment = kept_rel + TILE_LDS_DESCS;
+    __shared__ uint32_t n_kept;
+    bool thinned = false;
+    if (!JUMPS && n_in_tile > (uint32_t)TILE_LDS_DESCS) {
+        if (threadIdx.x < MDB_WAVE) {
+            // (the offsets from memory, 64 at a time: the run may be longer than `rel`)
+            const uint32_t tile_points = (uint32_t)(tile_end - tile_start);
+            uint32_t running = 0;
+            for (uint32_t base = 0; base < n_in_tile && running <= (uint32_t)TILE_LDS_DESCS; base += MDB_WAVE) {
+                const uint32_t k = base + threadIdx.x;
+                bool keep = false;
+                uint32_t begins = 0;
+                if (k < n_in_tile) {
+                    begins = k == 0 ? 0u : (uint32_t)min(offsets[s0 + k] - tile_start, (unsigned long long)tile_points);
+                    const uint32_t ends = k + 1 < n_in_tile ? (uint32_t)min(offsets[s0 + k + 1] - tile_start, (unsigned long long)tile_points)
+                                                            : tile_points; // (the last one reaches the tile's end)
+                    keep = k == 0 || (begins < tile_points && ends > begins);
+                }
+                const unsigned long long keepers = __ballot(keep);
+                const uint32_t at = running + (uint32_t)__popcll(keepers & ((1ull << threadIdx.x) - 1ull));
+                if (keep && at < (uint32_t)TILE_LDS_DESCS) {
+                    thin_segment[at] = k;
+                    kept_rel[at] = begins;
+                }
+                running += (uint32_t)__popcll(keepers);
+            }
+            if (threadIdx.x == 0) n_kept = running;
+        }
+        __syncthreads();
+        thinned = n_kept <= (uint32_t)TILE_LDS_DESCS;
+        if (thinned) {
+            n_in_tile = n_kept;
+            use_lds = true;
+            for (uint32_t k = 1 + threadIdx.x; k < n_in_tile; k += TILE_THREADS) rel[k] = kept_rel[k];
+        }
+    }
     // A tile all of whose segments have their timestamps decoded by k_grid_timestamps is written there,
     // values included: nothing to do here.
     bool mine_are_left = n_in_tile <= (uint32_t)TILE_LDS_DESCS;
     for (uint32_t k = threadIdx.x; k < min(n_in_tile, (uint32_t)TILE_LDS_DESCS); k += TILE_THREADS) {
-        const TileDesc d = desc[s0 + k];
+        const TileDesc d = desc[s0 + (thinned ? thin_segment[k] : k)];
         lds_desc[k] = d;
         mine_are_left = mine_are_left && (d.flags & FLAG_CHECKPOINTS) != 0;
     }
