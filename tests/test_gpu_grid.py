@@ -336,6 +336,34 @@ def test_grid_with_pushed_down_time_range(hip, eb_name, irregular):
         assert metrics["rows_created"] == len(exp_ts)
 
 
+@pytest.mark.parametrize("points_per_series, n_series", [(9_000, 12), (250_000, 4)])
+def test_time_range_with_runs_of_segments_without_a_visible_point(hip, points_per_series, n_series):
+    """A query over a thin slice of the time axis of several series (BASELINE config 5's shape): between the visible
+    parts of two series lie the segments behind the range of the one and in front of the range of the other - about a
+    thousand, and about thirty thousand (more than the tile kernel's table of offsets holds) - inside ONE output tile,
+    which keeps the handful of segments that have points in it."""
+    eb = mdb.error_bound("absolute", 0.25)
+    timestamps = np.arange(points_per_series, dtype=np.int64) * 1000
+    parts = []
+    for series in range(n_series):
+        # a level every 8 points: segments of 8 points (PMC-Mean), with a linear stretch (Swing) now and then
+        levels = np.repeat(np.arange(points_per_series // 8 + 1) % 7 * 3.0 + series, 8)[:points_per_series]
+        values = levels.astype(np.float32)
+        values[1000:1400] = np.linspace(0.0, 50.0, 400, dtype=np.float32)
+        parts.append(ora.try_compress_univariate_time_series(timestamps, values, eb))
+    batch = mdb.SegmentBatch.concat(parts)
+    assert len(batch) > n_series * points_per_series // 10
+    n = points_per_series
+    for first, last in ((n // 2, n // 2 + n // 20), (1100, 1300), (n - 300, n - 1), (3, 5)):
+        t_lo, t_hi = int(timestamps[first]) - 1, int(timestamps[last]) + 1
+        exp_ts, exp_values, exp_rows = _expected_range(batch, t_lo, t_hi)
+        ts, values, rows, metrics = hip.grid_batch_range(batch, t_lo, t_hi)
+        assert len(exp_ts) == n_series * (last - first + 1)
+        assert np.array_equal(ts, exp_ts), (first, last)
+        assert np.array_equal(values.view(np.uint32), exp_values.view(np.uint32)), (first, last)
+        assert np.array_equal(rows, exp_rows)
+
+
 @pytest.mark.parametrize("gap_probability", [0.0005, 0.005, 0.01, 0.02, 0.5])
 def test_mostly_regular_timestamps_with_gaps(hip, gap_probability):
     # What irregular timestamps usually are: a fixed sampling interval with a sample missing now and
