@@ -145,6 +145,17 @@ int mdb_grid_batch_owned(mdb_ctx *ctx, const mdb_segments *in, uint32_t flags, i
                          int64_t t_hi, uint64_t reserve_front, mdb_grid_result **out);
 void mdb_grid_result_free(mdb_grid_result *result);
 
+/* The library's switches (the MDB_* names of INTEGRATION.md 2.6: A/B timings and the scheduling modes the tests force;
+ * the defaults are what a deployment runs). The process's environment is read ONCE, by the first call that asks for a
+ * switch: no getenv() inside a call. mdb_set_option sets one switch for the whole process without touching the
+ * environment (value NULL: back to "not set"); mdb_reload_options reads the environment again (what a test that has
+ * changed it calls - not while other calls are running). No counterpart in the reference (its settings are
+ * crates/modelardb_server/src/configuration.rs, none of which reaches this path). */
+int mdb_set_option(const char *name, const char *value);
+int mdb_reload_options(void);
+/* What a switch is set to (NULL: not set). The text stays valid until the switch is set again or the table reloaded. */
+const char *mdb_option(const char *name);
+
 /* Pipelined form, for an operator that is polled (GridStream::poll_next, grid_exec.rs:402-429): submit
  * returns at once with a ticket, a worker thread of the library reconstructs the batch on the context or
  * on a clone of it that the library keeps (submits alternate between the two), so the kernels of one

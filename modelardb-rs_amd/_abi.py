@@ -229,9 +229,36 @@ _HIP_SYMBOLS = {
     "mdb_profile_names": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "mdb_synth_values_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.c_uint64]),
+    "mdb_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "mdb_reload_options": (C.c_int, []),
+    "mdb_option": (C.c_char_p, [C.c_char_p]),
 }
 
 _hip_library = None
+
+# The library reads its switches (the MDB_* environment variables) once per process. Tests change os.environ from one
+# call to the next: with this set (tests/conftest.py) every call through the binding is preceded by
+# mdb_reload_options(), so that a test's monkeypatch.setenv() is seen by the call behind it.
+RELOAD_OPTIONS_BEFORE_EVERY_CALL = False
+
+
+class _ReloadingLibrary:
+    """The ctypes library with mdb_reload_options() in front of every call while RELOAD_OPTIONS_BEFORE_EVERY_CALL."""
+
+    def __init__(self, library):
+        self._library = library
+
+    def __getattr__(self, name):
+        function = getattr(self._library, name)
+        if not RELOAD_OPTIONS_BEFORE_EVERY_CALL or name in ("mdb_reload_options", "mdb_set_option", "mdb_option", "mdb_last_error"):
+            return function
+        reload_options = self._library.mdb_reload_options
+
+        def call(*args):
+            reload_options()
+            return function(*args)
+
+        return call
 
 
 def hip_symbol_names():
@@ -256,5 +283,5 @@ def load_hip_library():
         function = getattr(library, name)  # AttributeError if the library lacks a declared symbol
         function.restype = restype
         function.argtypes = argtypes
-    _hip_library = library
-    return library
+    _hip_library = _ReloadingLibrary(library) if hasattr(library, "mdb_reload_options") else library
+    return _hip_library

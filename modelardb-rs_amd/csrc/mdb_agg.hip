@@ -482,16 +482,16 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     // one lane per stream, or the parallel decoder for the long ones).
     std::shared_ptr<MvIndex> range_index;
     const unsigned long long *indexed_piece_base = nullptr;
-    const char *range_pieces_setting = std::getenv("MDB_AGG_RANGE_PIECES");
+    const char *range_pieces_setting = option_text("MDB_AGG_RANGE_PIECES");
     if (range && !(range_pieces_setting && std::strcmp(range_pieces_setting, "0") == 0) &&
         mv_index_for_range(ctx, in, &range_index, &indexed_piece_base))
         return 1;
     // What that walk finds is the same for every call without a time range: a batch that stays on the device keeps it
     // (MvIndex::agg_walk_*, as the grid path keeps its cursors; MDB_GRID_TS_CACHE=0: walk every time).
     const bool walk_wanted = range || (which_mask & (MDB_AGG_COUNT | MDB_AGG_AVG | MDB_AGG_SUM));
-    const char *cache_setting = std::getenv("MDB_GRID_TS_CACHE");
+    const char *cache_setting = option_text("MDB_GRID_TS_CACHE");
     std::shared_ptr<MvIndex> resident;
-    const char *walk_setting = std::getenv("MDB_AGG_TS_WALK"); // (0: no walk, every lane for itself - nothing to keep)
+    const char *walk_setting = option_text("MDB_AGG_TS_WALK"); // (0: no walk, every lane for itself - nothing to keep)
     if (walk_wanted && !range && !(cache_setting && std::strcmp(cache_setting, "0") == 0) &&
         !(walk_setting && std::strcmp(walk_setting, "0") == 0))
         resident = owned_segments_index(in);

@@ -750,7 +750,7 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
     std::vector<size_t> buffer_slots[3];
     // (MDB_SEGMENTS_MERGE_LIMIT, read once per download: tests of the several-buffers path without 2 GiB of payloads)
     uint64_t merge_limit = 0x7fffffffull;
-    if (const char *text = std::getenv("MDB_SEGMENTS_MERGE_LIMIT"))
+    if (const char *text = option_text("MDB_SEGMENTS_MERGE_LIMIT"))
         merge_limit = std::min<uint64_t>(merge_limit, (uint64_t)std::max(0ll, std::atoll(text)));
     for (int c = 0; c < 3 && !rc; c++) {
         uint64_t total = 0;

@@ -3177,7 +3177,7 @@ static bool valid_error_bound(mdb_error_bound eb) { // crates/modelardb_types/sr
 // MDB_FIT_GAP_MIN_VALUES: "off" keeps one lane per MacaqueV-only segment, a number sets the length
 // from which a lossless one gets a wave of its own.
 static uint32_t gap_min_values_setting() {
-    if (const char *text = std::getenv("MDB_FIT_GAP_MIN_VALUES")) {
+    if (const char *text = option_text("MDB_FIT_GAP_MIN_VALUES")) {
         if (std::strcmp(text, "off") == 0) return 0xffffffffu;
         const long long value = std::atoll(text);
         if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
@@ -3187,7 +3187,7 @@ static uint32_t gap_min_values_setting() {
 
 // MDB_FIT_FAST=0: the plain forms of PMC-Mean and Swing in k_fit_models even where the fast ones apply.
 static bool fit_fast_setting() {
-    const char *text = std::getenv("MDB_FIT_FAST");
+    const char *text = option_text("MDB_FIT_FAST");
     return !(text && std::strcmp(text, "0") == 0);
 }
 
@@ -3195,7 +3195,7 @@ static bool fit_fast_setting() {
 // that a buffer with the payload that ends it stays below the 2 GiB a view can address).
 constexpr uint64_t MAX_DATA_BUFFERS = 4096;
 static uint64_t data_buffer_bytes_setting() {
-    if (const char *text = std::getenv("MDB_FIT_DATA_BUFFER_BYTES")) {
+    if (const char *text = option_text("MDB_FIT_DATA_BUFFER_BYTES")) {
         const long long value = std::atoll(text);
         if (value >= 16) return (uint64_t)std::min<long long>(value, 1ll << 30);
     }
@@ -3204,7 +3204,7 @@ static uint64_t data_buffer_bytes_setting() {
 
 // MDB_FIT_LEAN=0: k_fit_models (its fast form) even where k_fit_models_lean applies.
 static bool fit_lean_setting() {
-    const char *text = std::getenv("MDB_FIT_LEAN");
+    const char *text = option_text("MDB_FIT_LEAN");
     return !(text && std::strcmp(text, "0") == 0);
 }
 
@@ -3215,7 +3215,7 @@ static bool fit_lean_setting() {
 // mode is possible (also with a forced piece size), chunks with short models left to split mode; otherwise 2's
 // behaviour for the calls the library would have given to split mode by itself.
 static int fit_wave_setting() {
-    const char *setting = std::getenv("MDB_FIT_WAVE");
+    const char *setting = option_text("MDB_FIT_WAVE");
     if (!setting || !*setting) return -1;
     const int value = std::atoi(setting);
     return value == 1 || value == 2 ? value : 0;
@@ -3223,16 +3223,17 @@ static int fit_wave_setting() {
 
 // One wave per chunk takes about 2 200 cycles per 64 points with every SIMD busy, one lane per chunk about 800 per
 // point with one wave per 64 chunks: beyond some 24 000 chunks the latter has enough waves to be the faster one.
-constexpr uint64_t FIT_WAVE_MAX_CHUNKS = 24576;
+// (24 576 on the MI355X's 256 compute units: 96 chunks - waves - per compute unit)
+static uint64_t fit_wave_max_chunks(const mdb_ctx *ctx) { return 96ull * (uint64_t)std::max(ctx->compute_units, 1); }
 
 static uint32_t fit_wave_number(const char *name, uint32_t otherwise) {
-    const char *setting = std::getenv(name);
+    const char *setting = option_text(name);
     if (!setting || !*setting) return otherwise;
     return (uint32_t)std::min<long long>(std::max<long long>(std::atoll(setting), 1), 1ll << 30);
 }
 
 static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64_t total_points) {
-    if (const char *forced = std::getenv("MDB_FIT_PIECE_POINTS")) {
+    if (const char *forced = option_text("MDB_FIT_PIECE_POINTS")) {
         const long long value = std::atoll(forced);
         if (value == 1) return 0;
         if (value >= 64) return (uint32_t)std::min<long long>(value, 1 << 30);
@@ -3373,7 +3374,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         const bool wave = ((fast && !ts) || exact_loaded_timestamps) && fit_lean_setting() && wave_setting != 0 &&
                           (wave_setting == 1 ||
                            (piece_points != 0 &&
-                            (wave_setting == 2 || (n_chunks <= FIT_WAVE_MAX_CHUNKS && !std::getenv("MDB_FIT_PIECE_POINTS")))));
+                            (wave_setting == 2 || (n_chunks <= fit_wave_max_chunks(ctx) && !option_text("MDB_FIT_PIECE_POINTS")))));
         bool split_mode = !wave && piece_points != 0;
         const unsigned int *split_only = nullptr; // (per chunk: 1 = left to split mode by k_fit_models_wave)
         if (wave) {
@@ -3391,7 +3392,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 3 : 20);
                 FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 4, ctx->stream));
             }
-            static const bool count_steps = std::getenv("MDB_FIT_DEBUG") != nullptr;
+            const bool count_steps = option_text("MDB_FIT_DEBUG") != nullptr;
             if (count_steps) {
                 FIT_CHECK(hipMalloc(reinterpret_cast<void **>(&leave.counts), WAVE_COUNTS * 8));
                 FIT_CHECK(hipMemsetAsync(leave.counts, 0, WAVE_COUNTS * 8, ctx->stream));
@@ -3432,7 +3433,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                     split_mode = true;
                     split_only = leave.chunk_left;
                     // (pieces sized for the chunks that are left, taken to be as long as the others)
-                    if (!std::getenv("MDB_FIT_PIECE_POINTS")) {
+                    if (!option_text("MDB_FIT_PIECE_POINTS")) {
                         const uint32_t for_these = split_piece_points(ctx, n_left, points_end / n_chunks * n_left);
                         if (for_these != 0) piece_points = for_these;
                     }
@@ -3762,8 +3763,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
 static uint64_t fit_small_max_chunks() {
     for (const char *name : {"MDB_FIT_WAVE", "MDB_FIT_PIECE_POINTS", "MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_GAP_MIN_VALUES",
                              "MDB_FIT_DATA_BUFFER_BYTES", "MDB_FIT_DEBUG"})
-        if (std::getenv(name)) return 0;
-    if (const char *text = std::getenv("MDB_FIT_SMALL")) return (uint64_t)std::max(0ll, std::atoll(text));
+        if (option_text(name)) return 0;
+    if (const char *text = option_text("MDB_FIT_SMALL")) return (uint64_t)std::max(0ll, std::atoll(text));
     return 64;
 }
 constexpr uint64_t FIT_SMALL_MAX_POINTS = 1ull << 22;
@@ -4177,7 +4178,7 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
     mdb_segments_owned *dev = nullptr;
     int rc = 0;
     // MDB_FIT_DEBUG: where the call's time goes, on stderr
-    static const bool debug = std::getenv("MDB_FIT_DEBUG") != nullptr;
+    const bool debug = option_text("MDB_FIT_DEBUG") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since_start = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     double t_gathered = 0.0, t_uploaded = 0.0, t_fitted = 0.0;

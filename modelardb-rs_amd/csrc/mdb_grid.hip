@@ -1515,8 +1515,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
     __shared__ uint32_t row_count[MDB_WAVE];
     __shared__ unsigned long long row_out[MDB_WAVE];
     const int lane = threadIdx.x;
-    const unsigned long long t_kernel = MVP_CLOCK();
-    unsigned long long t_decode = 0, t_top_up = 0, n_top_up = 0, t_out = 0;
+    [[maybe_unused]] const unsigned long long t_kernel = MVP_CLOCK();
+    [[maybe_unused]] unsigned long long t_decode = 0, t_top_up = 0, n_top_up = 0, t_out = 0;
     const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
     uint32_t count = 0, skip = 0; // values of this lane's piece to write, and how many in front of them are not wanted
     unsigned long long out_at = 0;
@@ -2968,7 +2968,7 @@ struct GridPlan {
 // MDB_GRID_MV_MIN_VALUES: "off" disables the parallel MacaqueV decoder, a number sets the stream
 // length from which it is used (tests force it down so that short streams exercise it).
 static uint32_t mv_min_values_setting() {
-    if (const char *text = std::getenv("MDB_GRID_MV_MIN_VALUES")) {
+    if (const char *text = option_text("MDB_GRID_MV_MIN_VALUES")) {
         if (std::strcmp(text, "off") == 0) return 0xffffffffu;
         const long long value = std::atoll(text);
         if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
@@ -3014,7 +3014,7 @@ int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegmen
     uint64_t ts_payload = 0;
     for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
         ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
-    const char *setting = std::getenv("MDB_AGG_TS_WALK");
+    const char *setting = option_text("MDB_AGG_TS_WALK");
     if (ts_payload == 0 || n == 0 || n > 0xfffffff0ull || (setting && std::strcmp(setting, "0") == 0)) return 0;
     void *p;
     // sums or range aggregates, totals, the order, the classes of the sort, an error word
@@ -3067,7 +3067,7 @@ thread_local const void *t_call_index_views = nullptr;
 
 int mv_index_prepare(mdb_ctx *ctx, const mdb_segments *in, std::shared_ptr<MvIndex> *out) {
     out->reset();
-    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    const char *setting = option_text("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return 0;
     if (t_call_index && t_call_index_views == in->values.views) {
         *out = t_call_index;
@@ -3124,7 +3124,7 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
                          const float **stream_sums, const unsigned long long **only_with_pieces) {
     *stream_sums = nullptr;
     *only_with_pieces = nullptr;
-    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    const char *setting = option_text("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return 0;
     const bool of_this_call = t_call_index && t_call_index_views == in->values.views;
     std::shared_ptr<MvIndex> index = of_this_call ? t_call_index : owned_segments_index(in);
@@ -3151,7 +3151,7 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
         // 16-byte loads in flight per lane: many while the batch has few streams (16 streams of 65 536 values: 0.82 / 0.51 /
         // 0.43 ms with 8 / 16 / 32), few when every lane of every wave has one (100 000 streams of 50 000 values: 4.2 / 4.7 /
         // 5.7 ms). MDB_AGG_CHAIN_LOADS: A/B.
-        const char *text = std::getenv("MDB_AGG_CHAIN_LOADS");
+        const char *text = option_text("MDB_AGG_CHAIN_LOADS");
         const int loads = text ? std::atoi(text) : (in->n <= 512 ? 32 : 8);
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
@@ -3203,7 +3203,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     MDB_HIP_CHECK(hipMemsetAsync(plan->header, 0, sizeof(GridHeader), ctx->stream));
     std::memset(&plan->host_header, 0, sizeof(GridHeader));
     plan->mv_min_values = mv_min_values_setting();
-    plan->mv_forced = std::getenv("MDB_GRID_MV_MIN_VALUES") != nullptr;
+    plan->mv_forced = option_text("MDB_GRID_MV_MIN_VALUES") != nullptr;
     plan->checkpoints = TsCheckpoints{nullptr, nullptr, nullptr, nullptr, nullptr};
     plan->n_ts_pieces = 0;
     if (n == 0) return 0;
@@ -3216,10 +3216,10 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     uint32_t *ts_order = nullptr;       // by the length of their streams
     for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
         ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
-    const char *pieces_setting = std::getenv("MDB_GRID_TS_PIECES");
+    const char *pieces_setting = option_text("MDB_GRID_TS_PIECES");
     if (pieces_setting && std::strcmp(pieces_setting, "off") == 0) ts_payload = 0;
     // (MDB_GRID_TS_JUMPS=0: no jump lists, every such stream is decoded piece by piece)
-    const char *jumps_setting = std::getenv("MDB_GRID_TS_JUMPS");
+    const char *jumps_setting = option_text("MDB_GRID_TS_JUMPS");
     const bool jumps = !range.enabled && !(jumps_setting && std::strcmp(jumps_setting, "0") == 0);
     auto point_checkpoints_into = [&](void *block, unsigned long long *piece_base, unsigned long long n_pieces) {
         plan->checkpoints.piece_base = piece_base;
@@ -3234,7 +3234,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     const uint64_t per_piece = sizeof(TsCursor) + sizeof(uint2) + (jumps ? TS_JUMPS_PER_PIECE * sizeof(TsJump) + 4 : 0);
     // A batch that stays on the device keeps what the walk below leaves (MvIndex::ts_*): the walk is the same
     // every time, and for randomly spaced timestamps it is a third of the call (MDB_GRID_TS_CACHE=0: walk every time).
-    const char *cache_setting = std::getenv("MDB_GRID_TS_CACHE");
+    const char *cache_setting = option_text("MDB_GRID_TS_CACHE");
     std::shared_ptr<MvIndex> resident;
     if (ts_payload > 0 && !range.enabled && !(cache_setting && std::strcmp(cache_setting, "0") == 0)) resident = owned_segments_index(in);
     bool from_cache = false;
@@ -3256,7 +3256,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         unsigned long long *piece_base = static_cast<unsigned long long *>(p);
         if (device_exclusive_scan(ctx, TsPieceCount{s}, n, piece_base, piece_base + n + 1, "k_grid_ts_scan")) return 1;
         // The streams by length (MDB_GRID_TS_SORT=0: as they come).
-        const char *sort_setting = std::getenv("MDB_GRID_TS_SORT");
+        const char *sort_setting = option_text("MDB_GRID_TS_SORT");
         const bool sorted = !(sort_setting && std::strcmp(sort_setting, "0") == 0);
         uint32_t *sort_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(p) + scan_bytes);
         if (sorted) {
@@ -3303,7 +3303,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
     }
     // Simple segments (PMC-Mean / Swing, regular timestamps, no residuals) first, through the trimmed
     // analysis; what that leaves, through the generic one (MDB_GRID_PREPASS_SPLIT=0: everything generic).
-    const char *split_setting = std::getenv("MDB_GRID_PREPASS_SPLIT");
+    const char *split_setting = option_text("MDB_GRID_PREPASS_SPLIT");
     const bool split = !range.enabled && !(split_setting && std::strcmp(split_setting, "0") == 0);
     unsigned long long *pending = nullptr;
     uint32_t *block_pending = nullptr;
@@ -3348,7 +3348,7 @@ int grid_plan(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan *p
         plan->ts_cache_pending.reset();
     }
     if (plan->host_header.error) return fail(describe_error(plan->host_header.error));
-    if (std::getenv("MDB_GRID_DEBUG"))
+    if (option_text("MDB_GRID_DEBUG"))
         std::fprintf(stderr, "grid: %llu points, %llu segments with jump lists, %llu points in %llu of %llu pieces left to checkpoints (%llu listed)\n",
                      plan->host_header.total_points, plan->host_header.jump_segments, plan->host_header.checkpointed_points,
                      plan->host_header.checkpointed_pieces, (unsigned long long)plan->n_ts_pieces, plan->host_header.live_pieces);
@@ -3877,7 +3877,7 @@ __global__ __launch_bounds__(MV_FINISH_THREADS) void k_mv_sums_finish(const floa
 }
 
 uint32_t macaque_parallel_min_values(bool *forced) {
-    *forced = std::getenv("MDB_GRID_MV_MIN_VALUES") != nullptr;
+    *forced = option_text("MDB_GRID_MV_MIN_VALUES") != nullptr;
     return mv_min_values_setting();
 }
 
@@ -4019,8 +4019,8 @@ static void launch_mv_pieces(mdb_ctx *ctx, const DevSegments &s, TimeRange range
     const MvIndex *index = plan.mv_index.get();
     LaunchTimer timer(ctx, "k_grid_mv_pieces");
     // (MDB_GRID_MV_ROUND: values a lane stages per round, 16 / 32 / 64: A/B)
-    static const int round = [] {
-        const char *text = std::getenv("MDB_GRID_MV_ROUND");
+    const int round = [] {
+        const char *text = option_text("MDB_GRID_MV_ROUND");
         const int value = text ? std::atoi(text) : 0;
         return value == 64 || value == 16 ? value : 32;
     }();
@@ -4120,7 +4120,7 @@ int grid_launch(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, GridPlan 
         const uint32_t ts_blocks = (uint32_t)((n_lanes + TS_THREADS - 1) / TS_THREADS);
         // Few points per piece (randomly sampled series): the sparse flavour, then the general one for the
         // waves it has listed. Many (a fixed rate with gaps), or MDB_GRID_TS_SPARSE=0: the general one.
-        const char *sparse_setting = std::getenv("MDB_GRID_TS_SPARSE");
+        const char *sparse_setting = option_text("MDB_GRID_TS_SPARSE");
         const bool sparse = !(sparse_setting && std::strcmp(sparse_setting, "0") == 0) &&
                             plan.host_header.checkpointed_points <= (uint64_t)(TS_STAGE_POINTS / MDB_WAVE) * plan.host_header.checkpointed_pieces &&
                             n_waves < 0xffffffffull;
@@ -4163,7 +4163,7 @@ int grid_fused(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out
     *done = false;
     const uint64_t n = in->n;
     // (MDB_GRID_FUSED=0: never; =1: whenever the batch has no out-of-line timestamps, whatever its segments' lengths)
-    const char *setting = std::getenv("MDB_GRID_FUSED");
+    const char *setting = option_text("MDB_GRID_FUSED");
     const bool forced = setting && std::strcmp(setting, "1") == 0;
     if (setting && std::strcmp(setting, "0") == 0) return 0;
     if (!out_ts || !out_val || n == 0 || n > 0xfffffff0ull) return 0;
@@ -4173,8 +4173,8 @@ int grid_fused(mdb_ctx *ctx, const mdb_segments *in, int64_t *out_ts, float *out
     if ((reinterpret_cast<uintptr_t>(out_ts) & 15u) || (reinterpret_cast<uintptr_t>(out_val) & 15u)) return 0;
     GridPlan plan;
     if (mv_index_prepare(ctx, in, &plan.mv_index)) return 1; // (before the scratch below is laid out)
-    static const int rounds = [] { // (MDB_GRID_FUSED_ROUNDS: 256-segment rounds per workgroup, 2 / 4 / 8 / 16: A/B; 2.0 / 1.8 / 1.6 / 2.4 ms at 8 points per segment)
-        const char *text = std::getenv("MDB_GRID_FUSED_ROUNDS");
+    const int rounds = [] { // (MDB_GRID_FUSED_ROUNDS: 256-segment rounds per workgroup, 2 / 4 / 8 / 16: A/B; 2.0 / 1.8 / 1.6 / 2.4 ms at 8 points per segment)
+        const char *text = option_text("MDB_GRID_FUSED_ROUNDS");
         const int value = text ? std::atoi(text) : 0;
         return value == 2 || value == 4 || value == 16 ? value : 8;
     }();

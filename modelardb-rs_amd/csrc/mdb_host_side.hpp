@@ -65,6 +65,13 @@ int grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uint32_t
 // allocation per batch and tag column is 22 000 page faults - and the pool of host threads that fills them.
 int host_block_take(uint64_t bytes, void **out, uint64_t *capacity);
 void host_block_give(void *block, uint64_t capacity);
+// The library's switches (the MDB_* names of INTEGRATION.md: A/B timings, the scheduling modes the tests force). The
+// environment is read ONCE - by the first look-up of the process, or again by mdb_reload_options() - into a table that
+// every call looks its switches up in: no getenv() inside a call (getenv races a host's setenv), and a host sets a
+// switch without touching its environment: mdb_set_option(). nullptr: not set. The text stays valid until the switch is
+// set again or the table reloaded (a test's business, not done while calls run). (mdb_pipeline.cpp)
+const char *option_text(const char *name);
+
 void host_parallel(unsigned n_shares, void (*share)(unsigned index, void *arg), void *arg);
 unsigned host_parallel_width();
 constexpr uint32_t MV_PIECE_VALUES = 64;

@@ -223,13 +223,13 @@ static void mv_host_index_or_throw(const mdb_segments *const *ins, uint32_t n_in
 
 static uint32_t mv_host_min_values() {
     // (MDB_GRID_MV_HOST_MIN_VALUES: streams from that many values on: tests index short ones too)
-    const char *text = std::getenv("MDB_GRID_MV_HOST_MIN_VALUES");
+    const char *text = option_text("MDB_GRID_MV_HOST_MIN_VALUES");
     const long long wanted = text ? std::atoll(text) : 0;
     return wanted > 0 ? (uint32_t)std::min<long long>(wanted, 1 << 30) : MV_HOST_MIN_VALUES;
 }
 
 bool mv_host_index_worthwhile(const mdb_segments *const *ins, uint32_t n_ins) {
-    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    const char *setting = option_text("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return false;
     // (a stream of k values: the first raw, every further one at least two bits)
     const uint64_t least_bytes = (32ull + 2ull * (mv_host_min_values() - 1) + 7) / 8;
@@ -259,7 +259,7 @@ static void mv_host_index_or_throw(const mdb_segments *const *ins, uint32_t n_in
                                    std::vector<MvCursor> *cursors, const MvHostRange *range) {
     piece_base->clear();
     cursors->clear();
-    const char *setting = std::getenv("MDB_GRID_MV_INDEX");
+    const char *setting = option_text("MDB_GRID_MV_INDEX");
     if (setting && std::strcmp(setting, "0") == 0) return;
     const uint32_t min_values = mv_host_min_values();
     HostIndexJob job;

@@ -17,9 +17,60 @@
 #include <deque>
 #include <thread>
 
+#include <map>
+#include <mutex>
+#include <string>
+
 #include "mdb_host_side.hpp"
 
+extern char **environ;
+
 namespace mdb {
+
+// ---- the library's switches -----------------------------------------------------------------------------------
+//
+// One table per process: the MDB_* variables of the environment as they were when the table was first asked (or last
+// reloaded), and what mdb_set_option() has put on top. Entries are never erased while the table stands (a switch that
+// is unset keeps its node with `set` false), so the text a look-up returned stays where it is until that switch is set
+// again or the table reloaded.
+namespace {
+
+struct Options {
+    struct Entry {
+        std::string text;
+        bool set = false;
+    };
+    std::mutex mutex;
+    std::map<std::string, Entry> entries;
+    bool loaded = false;
+    void load_locked() {
+        for (auto &entry : entries) entry.second.set = false;
+        for (char **variable = environ; variable && *variable; variable++) {
+            if (std::strncmp(*variable, "MDB_", 4) != 0) continue;
+            const char *equals = std::strchr(*variable, '=');
+            if (!equals) continue;
+            Entry &entry = entries[std::string(*variable, (size_t)(equals - *variable))];
+            entry.text = equals + 1;
+            entry.set = true;
+        }
+        loaded = true;
+    }
+};
+
+Options &options() {
+    static Options *table = new Options(); // (never destroyed: worker threads may ask while the process exits)
+    return *table;
+}
+
+} // namespace
+
+const char *option_text(const char *name) {
+    Options &table = options();
+    std::lock_guard<std::mutex> lock(table.mutex);
+    if (!table.loaded) table.load_locked();
+    const auto found = table.entries.find(name);
+    return found != table.entries.end() && found->second.set ? found->second.text.c_str() : nullptr;
+}
 
 // ---- host threads -------------------------------------------------------------------------------------------
 
@@ -358,6 +409,26 @@ using namespace mdb;
 
 extern "C" {
 
+int mdb_set_option(const char *name, const char *value) {
+    if (!name || std::strncmp(name, "MDB_", 4) != 0) return fail("The name of a switch begins with MDB_.");
+    Options &table = options();
+    std::lock_guard<std::mutex> lock(table.mutex);
+    if (!table.loaded) table.load_locked();
+    Options::Entry &entry = table.entries[name];
+    entry.set = value != nullptr;
+    if (value) entry.text = value;
+    return 0;
+}
+
+const char *mdb_option(const char *name) { return name ? option_text(name) : nullptr; }
+
+int mdb_reload_options(void) {
+    Options &table = options();
+    std::lock_guard<std::mutex> lock(table.mutex);
+    table.load_locked();
+    return 0;
+}
+
 int mdb_replicate_views(const mdb_view16 *views, const uint32_t *rows_per_segment, uint64_t n_segments,
                         int32_t buffer_shift, mdb_view16 *out, uint64_t out_cap) {
     if (n_segments > 0 && (!views || !rows_per_segment)) return fail("views and rows_per_segment must not be NULL.");
@@ -425,7 +496,7 @@ int mdb_grid_submit(mdb_ctx *ctx, const mdb_grid_input *inputs, uint32_t n_input
         std::unique_ptr<GridPipeline> fresh(new GridPipeline());
         fresh->contexts[0] = ctx;
         // MDB_GRID_PIPELINE_CONTEXTS=1: every job on the context itself (A/B: what the second context buys)
-        const char *setting = std::getenv("MDB_GRID_PIPELINE_CONTEXTS");
+        const char *setting = option_text("MDB_GRID_PIPELINE_CONTEXTS");
         if (!(setting && std::strcmp(setting, "1") == 0) && mdb_clone(ctx, &fresh->contexts[1])) return 1;
         for (int w = 0; w < 2; w++)
             if (fresh->contexts[w]) fresh->workers[w] = std::thread(pipeline_worker, fresh.get(), w);

@@ -219,6 +219,11 @@ unsafe extern "C" {
     pub fn mdb_replicate_views(views: *const mdb_view16, rows_per_segment: *const u32, n_segments: u64,
                                buffer_shift: i32, out: *mut mdb_view16, out_cap: u64) -> c_int;
 
+    // ---- the library's switches (read from the environment once per process; include/mdb.h) ----
+    pub fn mdb_set_option(name: *const c_char, value: *const c_char) -> c_int;
+    pub fn mdb_reload_options() -> c_int;
+    pub fn mdb_option(name: *const c_char) -> *const c_char;
+
     // ---- aggregates (replace Model*Accumulator::update_batch, model_simple_aggregates.rs:345-587) ----
     pub fn mdb_agg_batch(ctx: *mut mdb_ctx, input: *const mdb_segments, which_mask: u32,
                          inout: *mut mdb_agg_state) -> c_int;

@@ -6,6 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import modelardb_rs_amd as mdb  # noqa: E402
+from modelardb_rs_amd import _abi  # noqa: E402
+_abi.RELOAD_OPTIONS_BEFORE_EVERY_CALL = True  # (the switches change between calls)
 import datagen  # noqa: E402
 import oracle_lib as ora  # noqa: E402
 

@@ -11,6 +11,10 @@ for path in (REPO_ROOT, os.path.join(REPO_ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The library reads its MDB_* switches once per process; the tests set them per test (monkeypatch.setenv): every
+    # call through the binding asks the library to read the environment again first.
+    from modelardb_rs_amd import _abi
+    _abi.RELOAD_OPTIONS_BEFORE_EVERY_CALL = True
 
 
 @pytest.fixture(scope="session")

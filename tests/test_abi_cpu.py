@@ -201,3 +201,29 @@ def test_segment_batch_arrow_round_trip():
         assert got[:4] == expected[:4] and got[6:] == expected[6:]
         assert np.float32(got[4]) == np.float32(expected[4])
     assert np.isnan(back.error).all()
+
+
+def test_switches_are_read_from_the_environment_once_and_set_without_it(monkeypatch):
+    """mdb_option / mdb_set_option / mdb_reload_options (include/mdb.h): the table of MDB_* switches is a snapshot of
+    the environment - a later setenv is not seen until the table is reloaded - and a host sets a switch without
+    touching its environment."""
+    library = ctypes.CDLL(_abi.HIP_LIBRARY_PATH)
+    library.mdb_option.restype = ctypes.c_char_p
+    library.mdb_option.argtypes = [ctypes.c_char_p]
+    library.mdb_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    monkeypatch.setenv("MDB_TEST_SWITCH", "first")
+    assert library.mdb_reload_options() == 0
+    assert library.mdb_option(b"MDB_TEST_SWITCH") == b"first"
+    monkeypatch.setenv("MDB_TEST_SWITCH", "second")
+    assert library.mdb_option(b"MDB_TEST_SWITCH") == b"first"          # (a snapshot: no getenv per call)
+    assert library.mdb_reload_options() == 0
+    assert library.mdb_option(b"MDB_TEST_SWITCH") == b"second"
+    assert library.mdb_set_option(b"MDB_TEST_SWITCH", b"third") == 0
+    assert library.mdb_option(b"MDB_TEST_SWITCH") == b"third"
+    assert library.mdb_set_option(b"MDB_TEST_SWITCH", None) == 0
+    assert library.mdb_option(b"MDB_TEST_SWITCH") is None
+    assert library.mdb_option(b"MDB_NEVER_SET") is None
+    assert library.mdb_set_option(b"PATH", b"x") == 1                   # (only the library's own names)
+    monkeypatch.delenv("MDB_TEST_SWITCH")
+    assert library.mdb_reload_options() == 0
+    assert library.mdb_option(b"MDB_TEST_SWITCH") is None
