@@ -405,7 +405,9 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
                                                            const uint32_t *__restrict__ walked_totals,
                                                            const TsWalkRange *__restrict__ walked_ranges,
                                                            const unsigned int *__restrict__ walked_error,
-                                                           const unsigned long long *__restrict__ indexed_piece_base) {
+                                                           const unsigned long long *__restrict__ indexed_piece_base,
+                                                           const TsWalkRange *__restrict__ whole_in,
+                                                           TsWalkRange *__restrict__ whole_out) {
     __shared__ AggPartial lds[AGG_THREADS / MDB_WAVE];
     AggPartial p = empty_partial();
     if (walked_error && blockIdx.x == 0 && threadIdx.x == 0) p.error |= *walked_error;
@@ -413,7 +415,23 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
     for (uint64_t i = (uint64_t)blockIdx.x * AGG_THREADS + threadIdx.x; i < s.n;
          i += (uint64_t)gridDim.x * AGG_THREADS) {
         // Cheap rejection on the two columns the reference prunes on (start_time / end_time).
-        if (s.end_time[i] < t_lo || s.start_time[i] > t_hi) continue;
+        const int64_t start_time = s.start_time[i], end_time = s.end_time[i];
+        if (end_time < t_lo || start_time > t_hi) continue;
+        // `whole_in` (a batch that stays on the device): what this loop made of every point of the segment when it
+        // ran over the whole time axis (count < 0: nothing - left to the decoders then, as it is now). A range that
+        // contains the segment asks for the same points in the same order.
+        if (whole_in && start_time >= t_lo && end_time <= t_hi) {
+            const TsWalkRange whole = whole_in[i];
+            if (whole.count >= 0) {
+                if (mode != AGG_SUM_ONLY_DEFERRED) {
+                    p.sum += whole.sum;
+                    p.count += whole.count;
+                    p.min = min_num(p.min, whole.min);
+                    p.max = max_num(p.max, whole.max);
+                }
+                continue;
+            }
+        }
         if (mode == AGG_SUM_ONLY_DEFERRED && s.model_type_id[i] != MDB_MACAQUE_V_ID) continue;
         SegInfo info = analyse_segment(s, i, walked_totals);
         uint32_t error = info.error;
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_range(DevSegments s, int64_
             p.count += acc.count;
             p.min = min_num(p.min, acc.min);
             p.max = max_num(p.max, acc.max);
+            if (whole_out && !error) whole_out[i] = TsWalkRange{acc.sum, (long long)acc.count, acc.min, acc.max};
         }
         p.error |= error;
     }
@@ -504,7 +523,51 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             walked_sums = sums_wanted ? static_cast<const double *>(resident->agg_walk_sums) : nullptr;
         }
     }
-    if (walk_wanted && !walk_kept) {
+    // Under a time range a batch that stays on the device keeps what a walk over the WHOLE time axis found: the
+    // segments a query's range contains whole take that, only the ones it cuts are walked (MDB_GRID_TS_CACHE=0: all
+    // of them that reach into the range, every time).
+    bool range_from_kept = false;
+    if (range && !(cache_setting && std::strcmp(cache_setting, "0") == 0) && !(walk_setting && std::strcmp(walk_setting, "0") == 0)) {
+        if (std::shared_ptr<MvIndex> kept = owned_segments_index(in)) {
+            if (ts_range_from_kept(ctx, in, s, TimeRange{t_lo, t_hi, 1}, *kept, &walked_totals, &walked_ranges, &walked_error,
+                                   &range_from_kept))
+                return 1;
+        }
+    }
+    // ... and what k_agg_range itself makes of every point of a segment (the ones it leaves to the decoders aside):
+    // the same for every range that contains the segment (MvIndex::range_acc; made by a pass over the whole time
+    // axis when the batch is first asked about a range, again if a switch has moved the line to the decoders).
+    const TsWalkRange *whole_acc = nullptr;
+    if (range && !(cache_setting && std::strcmp(cache_setting, "0") == 0)) {
+        if (std::shared_ptr<MvIndex> kept = owned_segments_index(in)) {
+            const uint64_t key = ((uint64_t)mv_min_values << 2) | (indexed_piece_base ? 2u : 0u) | 1u;
+            std::lock_guard<std::mutex> lock(kept->mutex);
+            // (needs the walk over the whole axis where there are streams to walk: range_from_kept or none at all)
+            uint64_t ts_payload = 0;
+            for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
+                ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
+            const bool walkable = range_from_kept || ts_payload == 0;
+            if (walkable && kept->range_acc_key != key) {
+                if (!kept->range_acc) MDB_HIP_CHECK(hipMalloc(&kept->range_acc, in->n * sizeof(TsWalkRange)));
+                MDB_HIP_CHECK(hipMemsetAsync(kept->range_acc, 0xff, in->n * sizeof(TsWalkRange), ctx->stream)); // (count -1)
+                {
+                    LaunchTimer timer(ctx, "k_agg_range");
+                    hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, INT64_MIN, INT64_MAX,
+                                       AGG_SUM_DEFER, mv_min_values, partials, static_cast<const uint32_t *>(kept->range_whole_totals),
+                                       static_cast<const TsWalkRange *>(kept->range_whole), static_cast<const unsigned int *>(nullptr),
+                                       indexed_piece_base, static_cast<const TsWalkRange *>(nullptr),
+                                       static_cast<TsWalkRange *>(kept->range_acc));
+                    hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(AGG_THREADS), 0, ctx->stream, partials, n_blocks, result);
+                }
+                AggPartial made;
+                MDB_HIP_CHECK(hipMemcpyAsync(&made, result, sizeof(AggPartial), hipMemcpyDeviceToHost, ctx->stream));
+                MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                kept->range_acc_key = made.error ? 0 : key; // (a fault: every call finds and reports it itself)
+            }
+            if (walkable && kept->range_acc_key == key) whole_acc = static_cast<const TsWalkRange *>(kept->range_acc);
+        }
+    }
+    if (walk_wanted && !walk_kept && !range_from_kept) {
         if (ts_walk_for_aggregates(ctx, in, s, sums_wanted, TimeRange{t_lo, t_hi, range ? 1 : 0}, &walked_totals, &walked_sums,
                                    &walked_ranges, &walked_error))
             return 1;
@@ -525,7 +588,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
         LaunchTimer timer(ctx, "k_agg_range");
         hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
                            t_hi, AGG_SUM_DEFER, mv_min_values, partials, walked_totals, walked_ranges, walked_error,
-                           indexed_piece_base);
+                           indexed_piece_base, whole_acc, static_cast<TsWalkRange *>(nullptr));
     } else {
         const float *stream_sums = nullptr;
         const unsigned long long *only_with_pieces = nullptr;
@@ -565,7 +628,8 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                 hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, t_lo,
                                    t_hi, AGG_SUM_ONLY_DEFERRED, mv_min_values, partials,
                                    static_cast<const uint32_t *>(nullptr), static_cast<const TsWalkRange *>(nullptr),
-                                   static_cast<const unsigned int *>(nullptr), indexed_piece_base);
+                                   static_cast<const unsigned int *>(nullptr), indexed_piece_base, whole_acc,
+                                   static_cast<TsWalkRange *>(nullptr));
             } else {
                 LaunchTimer timer(ctx, "k_agg_segments");
                 hipLaunchKernelGGL(k_agg_segments, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s,

@@ -185,15 +185,28 @@ struct MvIndex {
     bool agg_walk_built = false, agg_walk_with_sums = false;
     void *agg_walk_totals = nullptr; // uint32_t[n]
     void *agg_walk_sums = nullptr;   // double[n]
+    // And for the aggregates UNDER a time range: what ALL points of every PMC-Mean / Swing segment with irregular
+    // timestamps and no residuals add up to (k_grid_ts_count<WALK_RANGE> over the whole time axis, once) with every
+    // irregular segment's number of points: a query then walks only the segments its range cuts
+    // (ts_range_from_kept, mdb_grid.hip).
+    bool range_whole_built = false;
+    void *range_whole = nullptr;        // TsWalkRange[n]
+    void *range_whole_totals = nullptr; // uint32_t[n]
+    // ... and what k_agg_range makes of ALL points of a segment (count < 0: leaves to the decoders), for the ranges
+    // that contain it; `range_acc_key`: the line to the decoders it was made under (0: not made).
+    void *range_acc = nullptr; // TsWalkRange[n]
+    uint64_t range_acc_key = 0;
     // The index of ONE call over host batches (mv_host_index, mdb_grid.hip): made by host threads while the batches
     // are on their way, for the long streams only - a segment without pieces is the serial kernel's - and living in
     // the context's scratch.
     bool of_one_call = false;
     ~MvIndex() {
         if (of_one_call) return;
-        if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals || agg_walk_totals || agg_walk_sums) {
+        if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals || agg_walk_totals || agg_walk_sums || range_whole ||
+            range_whole_totals || range_acc) {
             (void)hipSetDevice(device);
-            for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals, agg_walk_totals, agg_walk_sums})
+            for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals, agg_walk_totals, agg_walk_sums,
+                                     range_whole, range_whole_totals, range_acc})
                 if (allocation) (void)hipFree(allocation);
         }
     }

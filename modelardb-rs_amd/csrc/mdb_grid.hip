@@ -3056,6 +3056,90 @@ int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegmen
     return 0;
 }
 
+// One lane per segment: what `whole` (the walk over the whole time axis) says of the segments the range contains, an
+// empty answer for the ones it misses, and the list of the ones it cuts (for the walk behind this kernel).
+__global__ __launch_bounds__(256) void k_ts_range_select(DevSegments s, TimeRange range, const TsWalkRange *__restrict__ whole,
+                                                         const uint32_t *__restrict__ whole_totals, TsWalkRange *__restrict__ ranges,
+                                                         uint32_t *__restrict__ totals, uint32_t *__restrict__ cut,
+                                                         uint32_t *__restrict__ n_cut) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    totals[i] = whole_totals[i];
+    const uint4 view = s.timestamps.views[i];
+    const bool irregular = (int32_t)view.x > 0 && (view_inline_byte(view, 0) & 0x80u) != 0;
+    if (!irregular) return;
+    const int64_t start = s.start_time[i], end = s.end_time[i];
+    if (end < range.lo || start > range.hi) return; // (nobody asks about it)
+    if (start >= range.lo && end <= range.hi) {
+        ranges[i] = whole[i]; // (every point: what the walk with this range would add up, term by term)
+        return;
+    }
+    // (cut by the range: walked - every irregular segment, as the walk of all of them does: the others' number of
+    // points is there already, and walking them again changes nothing)
+    cut[atomicAdd(n_cut, 1u)] = (uint32_t)i;
+}
+
+int ts_range_from_kept(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, TimeRange range, MvIndex &kept,
+                       const uint32_t **totals, const TsWalkRange **ranges, const unsigned int **error_word_out, bool *available) {
+    *available = false;
+    const uint64_t n = in->n;
+    if (n == 0 || n > 0xfffffff0ull) return 0;
+    {
+        std::lock_guard<std::mutex> lock(kept.mutex);
+        if (!kept.range_whole_built) {
+            // Once: every irregular stream walked with the whole time axis as the range.
+            const uint32_t *walk_totals = nullptr;
+            const double *walk_sums = nullptr;
+            const TsWalkRange *walk_ranges = nullptr;
+            const unsigned int *walk_error = nullptr;
+            if (ts_walk_for_aggregates(ctx, in, s, false, TimeRange{INT64_MIN, INT64_MAX, 1}, &walk_totals, &walk_sums, &walk_ranges,
+                                       &walk_error))
+                return 1;
+            if (!walk_totals || !walk_ranges) return 0; // (no out-of-line timestamp streams: nothing to keep, nothing to walk)
+            unsigned int found = 0;
+            MDB_HIP_CHECK(hipMemcpyAsync(&found, walk_error, 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (!kept.range_whole) MDB_HIP_CHECK(hipMalloc(&kept.range_whole, n * sizeof(TsWalkRange)));
+            if (!kept.range_whole_totals) MDB_HIP_CHECK(hipMalloc(&kept.range_whole_totals, n * 4));
+            MDB_HIP_CHECK(hipMemcpyAsync(kept.range_whole, walk_ranges, n * sizeof(TsWalkRange), hipMemcpyDeviceToDevice, ctx->stream));
+            MDB_HIP_CHECK(hipMemcpyAsync(kept.range_whole_totals, walk_totals, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (found) return 0; // (a malformed stream: the walk of every call reports it)
+            kept.range_whole_built = true;
+        }
+    }
+    void *p;
+    const uint64_t n_padded = (n + 15) & ~15ull;
+    if (scratch_reserve(ctx, SCRATCH_COUNTS, n_padded * (sizeof(TsWalkRange) + 4 + 4) + (TS_SORT_CLASSES + 32) * 4, &p)) return 1;
+    TsWalkRange *walk_ranges = static_cast<TsWalkRange *>(p);
+    uint32_t *walk_totals = reinterpret_cast<uint32_t *>(walk_ranges + n_padded);
+    uint32_t *cut = walk_totals + n_padded;
+    uint32_t *counters = cut + n_padded;
+    unsigned int *error_word = counters + TS_SORT_CLASSES + 16;
+    MDB_HIP_CHECK(hipMemsetAsync(counters, 0, 4, ctx->stream));
+    MDB_HIP_CHECK(hipMemsetAsync(error_word, 0, 4, ctx->stream));
+    uint32_t n_cut = 0;
+    {
+        LaunchTimer timer(ctx, "k_ts_range_select");
+        hipLaunchKernelGGL(k_ts_range_select, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, s, range,
+                           static_cast<const TsWalkRange *>(kept.range_whole), static_cast<const uint32_t *>(kept.range_whole_totals),
+                           walk_ranges, walk_totals, cut, counters);
+    }
+    MDB_HIP_CHECK(hipMemcpyAsync(&n_cut, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n_cut > 0) {
+        LaunchTimer timer(ctx, "k_grid_ts_count");
+        const TsCheckpoints none{nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(k_grid_ts_count<WALK_RANGE>, dim3((n_cut + SERIAL_THREADS - 1) / SERIAL_THREADS), dim3(SERIAL_THREADS), 0,
+                           ctx->stream, s, none, walk_totals, reinterpret_cast<GridHeader *>(error_word), cut, (uint64_t)n_cut,
+                           static_cast<double *>(nullptr), range, walk_ranges);
+    }
+    *error_word_out = error_word;
+    *totals = walk_totals;
+    *ranges = walk_ranges;
+    *available = true;
+    return 0;
+}
+
 // The cursor index of a batch the library owns on the device (see k_mv_index_walk), built by the first call that
 // asks for it. *out stays empty for a foreign or transient batch, for one without MacaqueV streams, for one with a
 // malformed stream (the serial kernel reports it) and with MDB_GRID_MV_INDEX=0 (A/B, tests). Uses the counting
@@ -3815,7 +3899,11 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRa
         const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
         const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
         const uint32_t i = c0.z, point_index = c0.w, n_values = c1.x, window = c1.y;
-        if (!(s.end_time[i] < range.lo || s.start_time[i] > range.hi)) {
+        // (a segment with irregular timestamps is not this kernel's, mv_range_by_pieces: it is left before the analysis,
+        // which would walk its timestamp stream to count its points - 0.9 ms per 10^9 points of such series)
+        const uint4 ts_view = s.timestamps.views[i];
+        const bool irregular = (int32_t)ts_view.x > 0 && (view_inline_byte(ts_view, 0) & 0x80u) != 0;
+        if (!irregular && !(s.end_time[i] < range.lo || s.start_time[i] > range.hi)) {
             SegInfo info = analyse_segment(s, i);
             const bool residual = (window & MV_WINDOW_RESIDUAL) != 0;
             if (residual ? mv_range_tail_by_pieces(s, i, info) : mv_range_by_pieces(s, i, info)) {

@@ -861,6 +861,11 @@ struct TsWalkRange { // the points of a segment inside a time range, as GridExec
 int ts_walk_for_aggregates(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, bool with_sums, TimeRange range,
                            const uint32_t **totals, const double **sums, const TsWalkRange **ranges,
                            const unsigned int **error_word);
+// The same under a time range for a batch that stays on the device (`kept`: its sidecar): the segments the range
+// contains whole take what a walk over the whole time axis found once, only the ones it cuts are walked.
+// *available = false: nothing was kept and nothing can be (a malformed stream: the caller walks as for any batch).
+int ts_range_from_kept(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &s, TimeRange range, MvIndex &kept,
+                       const uint32_t **totals, const TsWalkRange **ranges, const unsigned int **error_word_out, bool *available);
 
 int mv_index_range_totals(mdb_ctx *ctx, const DevSegments &s, TimeRange range, const MvIndex &index, DeferredTotals *totals);
 int macaque_deferred(mdb_ctx *ctx, const DevSegments &s, TimeRange range, uint32_t min_values, bool forced,

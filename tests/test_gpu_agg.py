@@ -440,6 +440,63 @@ def test_a_resident_batch_keeps_what_the_walk_of_its_timestamps_found(hip, monke
     resident.free()
 
 
+def test_a_resident_batch_walks_only_the_segments_a_time_range_cuts(hip, monkeypatch):
+    # WHERE timestamp BETWEEN over segments with irregular timestamps: a batch that stays on the device keeps what a
+    # walk over the whole time axis found, a query takes that for the segments its range contains and walks the ones
+    # it cuts - and must say what the walk of every segment (a batch on the host, or MDB_GRID_TS_CACHE=0) says.
+    monkeypatch.delenv("MDB_AGG_TS_WALK", raising=False)
+    monkeypatch.delenv("MDB_GRID_TS_CACHE", raising=False)
+    rng = np.random.default_rng(31)
+    series, points = 6, 40_000
+    one = 1_600_000_000_000_000 + np.cumsum(rng.integers(900, 1100, points).astype(np.int64))
+    timestamps = np.tile(one, series)
+    values = np.concatenate([(np.linspace(-5.0, 9.0, points) * (k + 1) + 2 * np.sin(np.arange(points) / (300.0 + 90 * k))
+                              + (rng.normal(0, 0.3, points) if k % 3 == 2 else 0)).astype(np.float32) for k in range(series)])
+    offsets = np.array([k * points + c for k in range(series) for c in range(0, points, 4000)] + [series * points], dtype=np.uint64)
+    for eb_name in ("rel5", "lossless"):
+        segments = hip.compress_chunks(timestamps, values, offsets, cases.error_bounds()[eb_name])
+        resident = hip.upload_segments(segments)
+        ranges = [(int(one[0]), int(one[-1])), (int(one[0]) - 5, int(one[-1]) + 5), (int(one[123]), int(one[123])),
+                  (int(one[-1]) + 1, int(one[-1]) + 100), (int(one[0]) - 100, int(one[0]) - 1)]
+        for _ in range(6):
+            a, b = sorted(int(x) for x in rng.integers(0, points, 2))
+            ranges.append((int(one[a]) + int(rng.integers(-2, 3)), int(one[b]) + int(rng.integers(-2, 3))))
+        first = True
+        for t_lo, t_hi in ranges:
+            if t_lo > t_hi:
+                continue
+            hip.profile_enable(True)
+            hip.profile_reset()
+            got = hip.agg_batch_range_dev(resident, t_lo, t_hi, ALL)
+            kernels = hip.profile()
+            hip.profile_enable(False)
+            assert "k_ts_range_select" in kernels
+            if not first and (t_lo, t_hi) == ranges[0]:
+                assert "k_grid_ts_count" not in kernels
+            first = False
+            transient = hip.agg_batch_range(segments, t_lo, t_hi, ALL)
+            assert (got.count, got.min, got.max) == (transient.count, transient.min, transient.max), (eb_name, t_lo, t_hi)
+            assert np.float64(got.sum).tobytes() == np.float64(transient.sum).tobytes(), (eb_name, t_lo, t_hi)
+            _assert_state(got, ora.agg_batch_range(segments, t_lo, t_hi, ALL))
+        # (the whole range a second time: nothing is cut, nothing is walked)
+        hip.profile_enable(True)
+        hip.profile_reset()
+        hip.agg_batch_range_dev(resident, *ranges[0], ALL)
+        assert "k_grid_ts_count" not in hip.profile()
+        hip.profile_enable(False)
+        monkeypatch.setenv("MDB_GRID_TS_CACHE", "0")
+        hip.profile_enable(True)
+        hip.profile_reset()
+        again = hip.agg_batch_range_dev(resident, *ranges[-1], ALL)
+        kernels = hip.profile()
+        hip.profile_enable(False)
+        assert "k_ts_range_select" not in kernels
+        transient = hip.agg_batch_range(segments, *ranges[-1], ALL)
+        assert np.float64(again.sum).tobytes() == np.float64(transient.sum).tobytes()
+        monkeypatch.delenv("MDB_GRID_TS_CACHE")
+        resident.free()
+
+
 def test_range_aggregates_over_long_lossless_streams_go_piece_by_piece(hip, monkeypatch):
     # WHERE timestamp BETWEEN over MacaqueV segments with cursors into their streams (a resident batch's sidecar, or the
     # ones the call's host threads leave): only the pieces of 64 values that reach into the range are decoded
