@@ -1048,3 +1048,49 @@ def test_short_simple_segments_in_one_pass(hip, fused, monkeypatch, macaque_deco
     hip.profile_enable(False)
     assert "k_grid_tiles" in kernels
     cases.assert_grid_equal(got, ora.grid_batch(batch))
+
+
+def test_resident_batches_of_short_segments_with_residual_tails(hip):
+    # The fitter's own segments of series that break into short models with residual tails of every length (a few values
+    # inside the view, a couple of hundred behind it) and MacaqueV segments between them, as a resident batch: the tails
+    # are pieces of the batch's cursor index like the MacaqueV streams. Whole, under a time range, and counted.
+    rng = np.random.default_rng(113)
+
+    def series(kinds, n_runs):
+        parts = []
+        for _ in range(n_runs):
+            kind = kinds[int(rng.integers(0, len(kinds)))]
+            level = float(rng.uniform(-50, 50))
+            if kind == "short":     # a constant run, a few values of noise behind it
+                parts += [np.full(int(rng.integers(9, 30)), level), rng.uniform(-1e3, 1e3, int(rng.integers(1, 9)))]
+            elif kind == "line":    # a line, some values of noise
+                parts += [level + 0.5 * np.arange(int(rng.integers(9, 40))), rng.uniform(-1e3, 1e3, int(rng.integers(1, 40)))]
+            elif kind == "long":    # ... and tails of a couple of hundred values
+                parts += [np.full(int(rng.integers(9, 20)), level), rng.uniform(-1e3, 1e3, int(rng.integers(150, 250)))]
+            else:                   # noise alone: MacaqueV segments of their own
+                parts += [rng.uniform(-1e3, 1e3, int(rng.integers(300, 900)))]
+        return np.concatenate(parts).astype(np.float32)
+
+    for kinds, n_runs in ((("short", "line"), 3000), (("short", "noise", "long", "line"), 1500), (("noise",), 300)):
+        values = series(kinds, n_runs)
+        timestamps = 1_700_000_000_000 + 100 * np.arange(len(values), dtype=np.int64)
+        offsets = np.array(list(range(0, len(values), 50_000)) + [len(values)], dtype=np.uint64)
+        for eb in (cases.LOSSLESS, cases.error_bounds()["rel1"]):
+            segments = hip.compress_chunks(timestamps, values, offsets, eb)
+            expected = ora.grid_batch(segments)
+            resident = hip.upload_segments(segments)
+            hip.profile_enable(True)
+            hip.profile_reset()
+            got = hip.grid_resident(resident)
+            kernels = hip.profile()
+            hip.profile_enable(False)
+            assert "k_grid_mv_pieces" in kernels
+            cases.assert_grid_equal(got, expected)
+            cases.assert_grid_equal(hip.grid_resident(resident), expected)
+            middle = (int(timestamps[len(values) // 3]), int(timestamps[2 * len(values) // 3]))
+            keep = (expected[0] >= middle[0]) & (expected[0] <= middle[1])
+            cases.assert_grid_equal(hip.grid_resident(resident, middle), (expected[0][keep], expected[1][keep]))
+            _assert = hip.agg_batch_dev(resident, mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX)
+            want = ora.agg_batch(segments, mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX)
+            assert (_assert.count, _assert.min, _assert.max) == (want.count, want.min, want.max)
+            resident.free()
