@@ -388,8 +388,9 @@ def irregular_timestamps(context, mdb, np, args):
            "note": "timestamps materialised on the device; randomly spaced (every delta different) and a fixed "
                    "rate with 1 % of the samples missing, next to the same series equally spaced; grid and "
                    "aggregates: mean of 3 calls on resident segments after a first one, which is timed by itself (a "
-                   "resident batch keeps what the walk of its timestamp streams found; the aggregates under a time "
-                   "range walk every time); the first million reconstructed timestamps "
+                   "resident batch keeps what the walk of its timestamp streams found, and for the aggregates under "
+                   "a time range what a pass over the whole time axis made of every segment: later calls walk only "
+                   "the segments their range cuts); the first million reconstructed timestamps "
                    "and the counts are checked"}
     for label, one in shapes:
         timestamps = np.tile(one, series)
@@ -821,16 +822,22 @@ class GpuWorkload:
         assert state.count == world * total_points, (state.count, world * total_points)
         self.ranks_seen = ranks_seen
 
-        def aggregate_roofline(seconds, kernels, name):
+        # Under a time range a resident batch keeps what a pass over the whole time axis made of every segment
+        # (DESIGN.md section 3c): the timed calls read start and end time of every segment (16 B), the kept 24 B of the
+        # ones the range contains (here: half of them) and the whole row only of the ones it cuts (two per series).
+        range_bytes = 16.0 * n_segments + 24.0 * n_segments * ((t_hi - t_lo) / (args.points * INTERVAL_US))
+
+        def aggregate_roofline(seconds, kernels, name, bytes_read=None, note=None):
             median = statistics.median(seconds)
             kernel = kernels.get(name, 0.0)
-            return {"bound": "hbm", "kernel": name, "achieved": agg_bytes / (kernel * 1e-3) / 1e9 if kernel > 0 else 0.0,
+            bytes_read = agg_bytes if bytes_read is None else bytes_read
+            return {"bound": "hbm", "kernel": name, "achieved": bytes_read / (kernel * 1e-3) / 1e9 if kernel > 0 else 0.0,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": agg_bytes / (kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel > 0 else 0.0,
+                    "frac": bytes_read / (kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel > 0 else 0.0,
                     "kernel_ms": kernel, "call_ms": {"median": 1e3 * median, "min": 1e3 * min(seconds), "max": 1e3 * max(seconds)},
-                    "algorithmic_bytes_per_launch": agg_bytes,
-                    "note": "73 B per segment (the columns a SUM reads) + out-of-line payloads, output O(1); "
-                            "kernel time from HIP events over 5 calls, call time = wall clock of the calls"}
+                    "algorithmic_bytes_per_launch": bytes_read,
+                    "note": note or ("73 B per segment (the columns a SUM reads) + out-of-line payloads, output O(1); "
+                                     "kernel time from HIP events over 5 calls, call time = wall clock of the calls")}
 
         aggregates = {
             "segments_per_s": n_segments / statistics.median(agg_seconds),
@@ -842,7 +849,12 @@ class GpuWorkload:
             "range": {"t_lo": t_lo, "t_hi": t_hi, "seconds": statistics.median(range_seconds),
                       "segments_per_s": n_segments / statistics.median(range_seconds),
                       "kernel_ms": range_kernels.get("k_agg_range", 0.0),
-                      "roofline": aggregate_roofline(range_seconds, range_kernels, "k_agg_range"),
+                      "roofline": aggregate_roofline(
+                          range_seconds, range_kernels, "k_agg_range", range_bytes,
+                          "16 B per segment (start and end time) + 24 B per segment the range contains (what the batch "
+                          "keeps of it: sum, count, min, max; built by the first call, which is not among the timed ones) "
+                          "- not the 73 B row, which only the segments the range cuts are read for; kernel time from "
+                          "HIP events over 5 calls, call time = wall clock of the calls"),
                       "count": range_state.count, "min": range_state.min, "max": range_state.max, "sum": range_state.sum},
             "final_reduce_seconds": reduce_seconds,
             "note": "COUNT/MIN/MAX/SUM on the resident segments (BASELINE config 3: no grid); the range "
