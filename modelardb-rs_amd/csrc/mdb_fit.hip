@@ -1397,12 +1397,17 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         FIT_TIMING_BEGIN(3);
 
         // ---- PMC-Mean: PMCMean::fit_value (pmc_mean.rs:58-76), decided as in pmc_fit_fast ----
+        // (What the two fitters compute for a step does not depend on each other: PMC-Mean's certain test and Swing's
+        // lines stand next to each other in one stretch of straight-line code, so that one's instructions fill the
+        // waits of the other's; what is rare for the whole wave - the exact PMC-Mean test, Swing's second line - and
+        // what is kept of the step comes behind both.)
         const LaneMask pmc_steps_m = feeding_m & pmc_fits_m;
         const float next_min = min_num(pmc_min, value32);
         const float next_max = max_num(pmc_max, value32);
         const double next_sum = pmc_sum + value;
         const uint32_t next_length = pmc_length + 1;
-        LaneMask pmc_accepts_m;
+        LaneMask pmc_accepts_m, doubtful_m;
+        float approximate = 0.0f, average_error = 0.0f;
         if (KIND == MDB_EB_LOSSLESS) {
             // Within a lossless bound of the average are a minimum and a maximum that both equal it. Certain: every
             // value so far and this one are the same finite number and few enough for every partial sum to be
@@ -1410,49 +1415,16 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             // a minimum below the maximum. Anything else (NaNs, infinities, very long models): the exact test.
             pmc_accepts_m = lanes_where(__builtin_amdgcn_classf(value32, 0x1f8)) & lanes_where(next_length < (1u << 24)) &
                             (lanes_where(pmc_length == 0) | (lanes_where(pmc_min == value32) & lanes_where(pmc_max == value32)));
-            const LaneMask doubtful_m = pmc_steps_m & ~pmc_accepts_m & ~lanes_where(next_min < next_max);
-            if (doubtful_m) {
-                bool exactly_within = false;
-                if (in_lanes(doubtful_m)) {
-                    const float average = (float)(next_sum / (double)next_length);
-                    exactly_within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
-                }
-                pmc_accepts_m |= lanes_where(exactly_within);
-            }
+            doubtful_m = pmc_steps_m & ~pmc_accepts_m & ~lanes_where(next_min < next_max);
         } else {
-            const float approximate = (float)next_sum * __builtin_amdgcn_rcpf((float)next_length);
-            const float average_error = fmaxf(fabsf(approximate) * 0x1p-20f, 0x1p-120f);
+            approximate = (float)next_sum * __builtin_amdgcn_rcpf((float)next_length);
+            average_error = fmaxf(fabsf(approximate) * 0x1p-20f, 0x1p-120f);
             pmc_accepts_m = pmc_fast_m & lean_passes<KIND>(pmc_fast, next_min, approximate, average_error) &
                             lean_passes<KIND>(pmc_fast, next_max, approximate, average_error);
             // Not certainly within the bound: certainly outside it (the step that ends a PMC-Mean model,
             // once per model), or too close to call and decided by the exact test.
-            const LaneMask doubtful_m = pmc_steps_m & ~pmc_accepts_m;
-            if (doubtful_m) {
-                bool exactly_within = false;
-                if (in_lanes(doubtful_m)) {
-                    const int low = pmc_fast.enabled ? pmc_fast_within(pmc_fast, next_min, approximate, average_error) : 0;
-                    const int high = pmc_fast.enabled ? pmc_fast_within(pmc_fast, next_max, approximate, average_error) : 0;
-                    if (low >= 0 && high >= 0) {
-                        const float average = (float)(next_sum / (double)next_length);
-                        exactly_within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
-                    }
-                }
-                pmc_accepts_m |= lanes_where(exactly_within);
-            }
+            doubtful_m = pmc_steps_m & ~pmc_accepts_m;
         }
-        if (in_lanes(pmc_steps_m & pmc_accepts_m)) { // (kept under the lanes' mask: no select per register)
-            keep_under_mask();
-            pmc_min = next_min;
-            pmc_max = next_max;
-            pmc_sum = next_sum;
-            pmc_length = next_length;
-        }
-        pmc_fits_m &= ~pmc_steps_m | pmc_accepts_m;
-#ifdef MDB_FIT_TIMING
-        if (TIMED && MDB_FIT_TIMING == 3) asm volatile("" ::"v"(pmc_min), "v"(pmc_max), "v"(pmc_sum), "v"(pmc_length), "s"(pmc_fits_m));
-#endif
-        FIT_TIMING_END(3)
-        FIT_TIMING_BEGIN(4);
 
         // ---- Swing: Swing::fit_data_point (swing.rs:101-198) on exact f64 timestamps (SwingFast) ----
         const LaneMask swing_steps_m = feeding_m & swing_fits_m;
@@ -1493,6 +1465,35 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         const LaneMask level_m = swing_steps_m & (lanes_where(swing_first == target) | lanes_where(swing_first == value));
         const LaneMask special_steps_m = swing_steps_m & special_m;
         double weighted = (value - swing_first) * elapsed, squared = elapsed * elapsed;
+
+        // ---- PMC-Mean, the rest: the exact test where the certain one does not say, and what is kept ----
+        if (doubtful_m) {
+            bool exactly_within = false;
+            if (in_lanes(doubtful_m)) {
+                const int low = (KIND != MDB_EB_LOSSLESS && pmc_fast.enabled) ? pmc_fast_within(pmc_fast, next_min, approximate, average_error) : 0;
+                const int high = (KIND != MDB_EB_LOSSLESS && pmc_fast.enabled) ? pmc_fast_within(pmc_fast, next_max, approximate, average_error) : 0;
+                if (low >= 0 && high >= 0) {
+                    const float average = (float)(next_sum / (double)next_length);
+                    exactly_within = within_error_bound(eb, next_min, average) && within_error_bound(eb, next_max, average);
+                }
+            }
+            pmc_accepts_m |= lanes_where(exactly_within);
+        }
+        if (in_lanes(pmc_steps_m & pmc_accepts_m)) { // (kept under the lanes' mask: no select per register)
+            keep_under_mask();
+            pmc_min = next_min;
+            pmc_max = next_max;
+            pmc_sum = next_sum;
+            pmc_length = next_length;
+        }
+        pmc_fits_m &= ~pmc_steps_m | pmc_accepts_m;
+#ifdef MDB_FIT_TIMING
+        if (TIMED && MDB_FIT_TIMING == 3) asm volatile("" ::"v"(pmc_min), "v"(pmc_max), "v"(pmc_sum), "v"(pmc_length), "s"(pmc_fits_m));
+#endif
+        FIT_TIMING_END(3)
+        FIT_TIMING_BEGIN(4);
+
+        // ---- Swing, the rest ----
         if (moves_both_m | level_m | special_steps_m) {
             if (in_lanes(moves_both_m)) {
                 const LineDev line = line_through_exact(swing_start, swing_first, time, value - deviation);
