@@ -14,7 +14,7 @@
 //                  once per ~24 points instead of once per point. Emits 16-byte model records and
 //                  the chunk's segment count.
 //   (scan)         chunk -> first segment.
-//   k_fit_plan     1 lane / chunk: model records -> per-segment work items (model + residual tail,
+//   k_fit_plan     1 wave / chunk: model records -> per-segment work items (model + residual tail,
 //                  or a MacaqueV-only run), the rules of compression.rs:310-362.
 //   k_fit_size     1 lane / segment: exact byte length of the timestamps / values / residuals payloads
 //                  (encoders run with a counting sink).
@@ -2268,15 +2268,29 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 
 // ---- k_fit_walk (split mode) ---------------------------------------------------------------------------------
 //
-// One wave per chunk follows the table from point 0. The wave keeps the entries of 64 consecutive
-// points in registers (one coalesced load) and steps through them with a uniform cursor, so a run of
-// rejected points costs a register read per point rather than a memory round trip.
+// One wave per chunk follows the table from point 0. What it reads decides where it reads next, so every look at the
+// table is a trip to memory the wave waits for - and that, not bandwidth, was the kernel: a chunk of nothing but
+// rejected points cost 1 024 trips of 64 entries, a chunk of 26-point models a trip for the entries and another for the
+// two parameters of EVERY model. Now:
+//   * the entries are staged in LDS a stretch at a time, the stretch as long as the walk is dense: 64 entries behind a
+//     jump far past what was staged (a model much longer than the stretch: sine data pays one trip per model as
+//     before, not kilobytes per model), twice as many every time the walk leaves its stretch by less than four times
+//     its length, up to WALK_STRETCH;
+//   * a model costs no trip: its start, end and type go to a list in LDS, and when 64 are listed (or the chunk is
+//     through) every lane fetches one model's parameters and writes its record.
+constexpr uint32_t WALK_STRETCH = 2048; // entries staged at most (8 KB of LDS per wave)
+#ifdef MDB_WALK_DEBUG
+__device__ unsigned long long g_walk_counts[8];
+#endif
+
 __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long *__restrict__ chunk_offsets,
                                                        uint64_t n_chunks, SplitArgs split,
                                                        const unsigned long long *__restrict__ record_base,
                                                        ModelRec *__restrict__ records,
                                                        ChunkPlan *__restrict__ plans,
                                                        unsigned int *__restrict__ error) {
+    __shared__ uint32_t staged[WALK_STRETCH];
+    __shared__ uint32_t listed_start[MDB_WAVE], listed_end[MDB_WAVE]; // (start with the type in its top bit)
     const uint64_t chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
     if (split.chunk_left && split.chunk_left[chunk] == 0u) return;
@@ -2292,44 +2306,83 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
     }
     const uint32_t n = (uint32_t)length64;
     ModelRec *__restrict__ out = records + record_base[chunk];
-    uint32_t n_models = 0;
+    uint32_t n_models = 0, n_listed = 0;
     GapCounter gaps;
     uint32_t position = 0;
-    uint32_t window_first = 0;
-    uint32_t window = 0;
-    bool window_valid = false;
-    while (position < n) {
-        if (!window_valid || position - window_first >= MDB_WAVE) {
-            window_first = position;
-            window = (position + lane < n) ? split.entry[base + position + lane] : 0u;
-            window_valid = true;
+    uint32_t stretch_first = 0, stretch_size = 0, next_size = MDB_WAVE;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // The listed models' records: lane k fetches the parameters of the k-th and writes record n_models - n_listed + k.
+    auto write_listed = [&]() {
+        wave_sync();
+        if ((uint32_t)lane < n_listed) {
+            const uint32_t start = listed_start[lane];
+            ModelRec rec;
+            rec.start_and_type = start;
+            rec.end = listed_end[lane];
+            rec.p0 = split.p0[base + (start & COUNT_MASK)];
+            rec.p1 = split.p1[base + (start & COUNT_MASK)];
+            out[n_models - n_listed + (uint32_t)lane] = rec;
         }
-        const uint32_t entry = read_lane(window, (int)(position - window_first));
+        wave_sync();
+        n_listed = 0;
+    };
+#ifdef MDB_WALK_DEBUG
+    unsigned long long dbg_iter = 0, dbg_reload = 0, dbg_flush = 0, dbg_rej = 0;
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    while (position < n) {
+#ifdef MDB_WALK_DEBUG
+        dbg_iter++;
+        if (position < stretch_first || position - stretch_first >= stretch_size) dbg_reload++;
+#endif
+        if (position < stretch_first || position - stretch_first >= stretch_size) {
+            // (dense: the walk has come no further than four stretches from where the last one began - rejected points,
+            // or models that are short against what is staged)
+            const bool dense = stretch_size > 0 && position >= stretch_first && position - stretch_first <= 4u * stretch_size;
+            next_size = dense ? min(2u * next_size, WALK_STRETCH) : (uint32_t)MDB_WAVE;
+            stretch_first = position;
+            stretch_size = min(next_size, n - position);
+            wave_sync(); // (nobody reads the old stretch any more)
+            for (uint32_t k = lane; k < stretch_size; k += MDB_WAVE) staged[k] = split.entry[base + position + k];
+            wave_sync();
+        }
+        const uint32_t at = position - stretch_first;
+        const uint32_t entry = staged[at];
         if (entry == ENTRY_REJECTED) {
-            // A run of rejected points (noise under a lossless bound rejects every point) is skipped
-            // in one step: to the first entry of the window that is something else.
-            const unsigned long long others = __ballot(window != ENTRY_REJECTED && window_first + lane < n) &
-                                              (~0ull << (position - window_first));
-            position = others ? window_first + (uint32_t)__ffsll((long long)others) - 1u
-                              : min(n, window_first + (uint32_t)MDB_WAVE);
+            // A run of rejected points (noise under a lossless bound rejects every point) is skipped 64 at a
+            // time: to the first entry of the next 64 staged ones that is something else.
+            const uint32_t mine = at + (uint32_t)lane;
+            const unsigned long long others = __ballot(mine < stretch_size && staged[mine] != ENTRY_REJECTED);
+            position = others ? position + (uint32_t)__ffsll((long long)others) - 1u
+                              : min(stretch_first + stretch_size, position + (uint32_t)MDB_WAVE);
         } else if (entry == 0u) { // cannot happen: every point on the chain was visited by some lane
             if (lane == 0) atomicOr(error, ERR_SPLIT_CHAIN);
             break;
         } else {
             const uint32_t end = (entry & COUNT_MASK) - ENTRY_END_BIAS;
             if (lane == 0) {
-                ModelRec rec;
-                rec.start_and_type = position | (entry & 0x80000000u);
-                rec.end = end;
-                rec.p0 = split.p0[base + position];
-                rec.p1 = split.p1[base + position];
-                out[n_models] = rec;
+                listed_start[n_listed] = position | (entry & 0x80000000u);
+                listed_end[n_listed] = end;
             }
             gaps.on_model(position, end);
             n_models += 1;
+            n_listed += 1;
+            if (n_listed == (uint32_t)MDB_WAVE) write_listed();
             position = end + 1;
         }
     }
+    if (n_listed) write_listed();
+#ifdef MDB_WALK_DEBUG
+    if (lane == 0) {
+        atomicAdd(&g_walk_counts[0], dbg_iter); atomicAdd(&g_walk_counts[1], dbg_reload); atomicAdd(&g_walk_counts[2], (unsigned long long)n_models);
+        atomicAdd(&g_walk_counts[3], 1ull); atomicAdd(&g_walk_counts[4], __builtin_amdgcn_s_memrealtime() - dbg_t0);
+        atomicMax(&g_walk_counts[5], __builtin_amdgcn_s_memrealtime() - dbg_t0);
+    }
+#endif
     if (lane == 0) plans[chunk] = n == 0 ? ChunkPlan{0, 0} : ChunkPlan{n_models, gaps.finish(n)};
 }
 
@@ -2347,48 +2400,66 @@ struct SegmentCount {
     __device__ uint64_t operator()(uint64_t c) const { return plans[c].n_segments; }
 };
 
-__global__ __launch_bounds__(256) void k_fit_plan(const unsigned long long *__restrict__ chunk_offsets,
-                                                  uint64_t n_chunks,
-                                                  const unsigned long long *__restrict__ record_base,
-                                                  const ModelRec *__restrict__ records,
-                                                  const ChunkPlan *__restrict__ plans,
-                                                  const unsigned long long *__restrict__ segment_base,
-                                                  SegItem *__restrict__ items) {
-    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per chunk (one lane per chunk walked its models one after the other: 2.4 ms for 4 096 chunks of 2 500 models
+// each). Producer j of a chunk with M models: j = 0 the points in front of the first model (a MacaqueV-only segment, if
+// there are any), j = 1 .. M - 1 the segment of model j - 1 with the points between it and model j as its residuals - or,
+// if they are more than a residual tail holds (compression.rs:310-400), without them and a MacaqueV-only segment for
+// them -, j = M the same for the last model and the end of the chunk. Every lane takes a producer, a scan over the
+// wave says where its items go.
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_plan(const unsigned long long *__restrict__ chunk_offsets,
+                                                       uint64_t n_chunks,
+                                                       const unsigned long long *__restrict__ record_base,
+                                                       const ModelRec *__restrict__ records,
+                                                       const ChunkPlan *__restrict__ plans,
+                                                       const unsigned long long *__restrict__ segment_base,
+                                                       SegItem *__restrict__ items) {
+    const uint64_t chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
+    const int lane = threadIdx.x;
     const uint32_t n = (uint32_t)(chunk_offsets[chunk + 1] - chunk_offsets[chunk]);
     const ModelRec *__restrict__ recs = records + record_base[chunk];
     const uint32_t n_models = plans[chunk].n_models;
     SegItem *__restrict__ out = items + segment_base[chunk];
-    uint32_t k = 0;
     if (n == 0) return;
     if (n_models == 0) {
-        out[k++] = {(uint32_t)chunk, 0, n - 1, 0xffffffffu};
+        if (lane == 0) out[0] = {(uint32_t)chunk, 0, n - 1, 0xffffffffu};
         return;
     }
-    for (uint32_t m = 0; m < n_models; m++) {
-        const uint32_t start = recs[m].start_and_type & COUNT_MASK;
-        if (m == 0) {
-            if (start > 0) out[k++] = {(uint32_t)chunk, 0, start - 1, 0xffffffffu};
-            continue;
+    uint32_t placed = 0; // items of the producers in front of this round's
+    for (uint32_t first = 0; first <= n_models; first += MDB_WAVE) {
+        const uint32_t j = first + (uint32_t)lane;
+        uint32_t count = 0;
+        SegItem one = {}, two = {};
+        if (j == 0) {
+            const uint32_t start = recs[0].start_and_type & COUNT_MASK;
+            if (start > 0) {
+                one = {(uint32_t)chunk, 0, start - 1, 0xffffffffu};
+                count = 1;
+            }
+        } else if (j <= n_models) {
+            const uint32_t previous_start = recs[j - 1].start_and_type & COUNT_MASK;
+            const uint32_t previous_end = recs[j - 1].end;
+            const uint32_t residuals_end = j < n_models ? (recs[j].start_and_type & COUNT_MASK) - 1 : n - 1;
+            if (residuals_end - previous_end <= MDB_RESIDUAL_VALUES_MAX_LENGTH) {
+                one = {(uint32_t)chunk, previous_start, residuals_end, j - 1};
+                count = 1;
+            } else {
+                one = {(uint32_t)chunk, previous_start, previous_end, j - 1};
+                two = {(uint32_t)chunk, previous_end + 1, residuals_end, 0xffffffffu};
+                count = 2;
+            }
         }
-        const uint32_t previous_start = recs[m - 1].start_and_type & COUNT_MASK;
-        const uint32_t previous_end = recs[m - 1].end;
-        const uint32_t residuals_end = start - 1;
-        if (residuals_end - previous_end <= MDB_RESIDUAL_VALUES_MAX_LENGTH) {
-            out[k++] = {(uint32_t)chunk, previous_start, residuals_end, m - 1};
-        } else {
-            out[k++] = {(uint32_t)chunk, previous_start, previous_end, m - 1};
-            out[k++] = {(uint32_t)chunk, previous_end + 1, residuals_end, 0xffffffffu};
+        uint32_t before = count;
+#pragma unroll
+        for (int delta = 1; delta < MDB_WAVE; delta <<= 1) {
+            const uint32_t up = __shfl_up(before, delta, MDB_WAVE);
+            if (lane >= delta) before += up;
         }
-    }
-    const uint32_t last_start = recs[n_models - 1].start_and_type & COUNT_MASK;
-    const uint32_t last_end = recs[n_models - 1].end;
-    if (n - 1 - last_end <= MDB_RESIDUAL_VALUES_MAX_LENGTH) {
-        out[k++] = {(uint32_t)chunk, last_start, n - 1, n_models - 1};
-    } else {
-        out[k++] = {(uint32_t)chunk, last_start, last_end, n_models - 1};
-        out[k++] = {(uint32_t)chunk, last_end + 1, n - 1, 0xffffffffu};
+        const uint32_t round_total = __shfl(before, MDB_WAVE - 1, MDB_WAVE);
+        before -= count;
+        if (count >= 1) out[placed + before] = one;
+        if (count == 2) out[placed + before + 1] = two;
+        placed += round_total;
     }
 }
 
@@ -3367,7 +3438,6 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         ChunkPlan *plans = static_cast<ChunkPlan *>(p);
         FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_D, (n_chunks + 1) * 8, &p));
         unsigned long long *segment_base = static_cast<unsigned long long *>(p);
-        const uint32_t chunk_blocks = (uint32_t)((n_chunks + 255) / 256);
         // Few chunks: one wave per chunk, which leaves the chunks whose models turn out short to split mode
         // (forced piece sizes are the tests' way to ask for split mode alone; MDB_FIT_WAVE=1: every chunk, to the end).
         const int wave_setting = fit_wave_setting();
@@ -3535,6 +3605,17 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             LaunchTimer timer(ctx, "k_fit_walk");
             hipLaunchKernelGGL(k_fit_walk, dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream,
                                args.chunk_offsets, n_chunks, split, record_base, records, plans, error_flag);
+#ifdef MDB_WALK_DEBUG
+            {
+                unsigned long long c[8] = {};
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_walk_counts), sizeof(c));
+                const unsigned long long zero[8] = {};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_counts), zero, sizeof(zero));
+                std::fprintf(stderr, "[walk] %llu chunks: iterations %llu, reloads %llu, models %llu; per chunk %.0f iterations %.0f reloads; mean %.1f us max %.1f us\n",
+                             c[3], c[0], c[1], c[2], c[3] ? (double)c[0] / c[3] : 0.0, c[3] ? (double)c[1] / c[3] : 0.0, c[3] ? c[4] / 100.0 / c[3] : 0.0, c[5] / 100.0);
+            }
+#endif
         }
         FIT_TRY(device_exclusive_scan(ctx, SegmentCount{plans}, n_chunks, segment_base, block_sums,
                                       "k_fit_scan"));
@@ -3570,7 +3651,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         unsigned long long *seg_block_sums = data_offsets[2] + n_segments + 1;
         {
             LaunchTimer timer(ctx, "k_fit_plan");
-            hipLaunchKernelGGL(k_fit_plan, dim3(chunk_blocks), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_fit_plan, dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream,
                                args.chunk_offsets, n_chunks, record_base, records, plans, segment_base,
                                items);
         }
@@ -3920,7 +4001,7 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
     {
         LaunchTimer timer(ctx, "k_fit_plan");
         hipLaunchKernelGGL(k_small_segments, dim3(1), dim3(64), 0, stream, plans, n_chunks, segment_base, n_segments_dev);
-        hipLaunchKernelGGL(k_fit_plan, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, stream, args.chunk_offsets,
+        hipLaunchKernelGGL(k_fit_plan, dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, stream, args.chunk_offsets,
                            n_chunks, record_base_dev, records, plans, segment_base, items);
     }
     {
