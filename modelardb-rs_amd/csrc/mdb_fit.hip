@@ -1277,7 +1277,11 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     LaneMask pmc_fits_m = ~0ull, swing_fits_m = ~0ull, swing_finite_m = 0;
     const LaneMask pmc_fast_m = pmc_fast.enabled ? ~0ull : 0ull;
 #ifdef MDB_FIT_TIMING
+#ifdef MDB_FIT_TIMING_SPLIT // (the same regions in split mode: scripts/r04/build_timing.sh with -DMDB_FIT_TIMING_SPLIT)
+    constexpr bool TIMED = SPLIT && KIND == MDB_EB_RELATIVE && !HAS_TS;
+#else
     constexpr bool TIMED = !SPLIT && KIND == MDB_EB_RELATIVE && !HAS_TS;
+#endif
     unsigned long long timing_cycles = 0, timing_passes = 0, timing_steps = 0;
     const unsigned long long timing_loop_t0 = __builtin_amdgcn_s_memtime(), timing_real_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1770,7 +1774,7 @@ struct ValueRange {
 // (chunk_left[chunk] = 1, counted in *n_left; nothing the wave has written for the chunk is used then).
 struct WaveLeave {
     unsigned int *chunk_left; // nullptr: never leave
-    unsigned int *n_left;
+    unsigned int *n_left; // [0] chunks left, [1] how many of them for their length alone
     uint32_t window_points;
     uint32_t points_per_step;
     // A chunk longer than this is left at once: one wave walks 65 536 points in a millisecond, a million (a whole
@@ -1871,6 +1875,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         if (lane == 0) {
             leave.chunk_left[chunk] = 1u;
             atomicAdd(leave.n_left, 1u);
+            atomicAdd(leave.n_left + 1, 1u); // (... for its length, whatever its models are like)
         }
         return;
     }
@@ -3322,6 +3327,8 @@ static uint32_t fit_wave_number(const char *name, uint32_t otherwise) {
     return (uint32_t)std::min<long long>(std::max<long long>(std::atoll(setting), 1), 1ll << 30);
 }
 
+constexpr uint32_t FIT_LEFT_PIECE_POINTS = 512; // pieces of the chunks k_fit_models_wave leaves to split mode
+
 static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64_t total_points) {
     if (const char *forced = option_text("MDB_FIT_PIECE_POINTS")) {
         const long long value = std::atoll(forced);
@@ -3469,7 +3476,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         if (wave) {
             WaveLeave leave{};
             if (wave_setting != 1 && piece_points != 0) {
-                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_WAVE, (n_chunks + 1) * 4, &p));
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_WAVE, (n_chunks + 2) * 4, &p));
                 leave.chunk_left = static_cast<unsigned int *>(p);
                 leave.n_left = leave.chunk_left + n_chunks;
                 leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 1024);
@@ -3479,7 +3486,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 // moved chunks to the slower side: 41 ms at 3, 54 at 12, 81 at 45 - measured with k_fit_models as
                 // split mode's fitter; the lean one that has replaced it is a fifth faster, which does not turn that.)
                 leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 3 : 20);
-                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 4, ctx->stream));
+                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 8, ctx->stream));
             }
             const bool count_steps = option_text("MDB_FIT_DEBUG") != nullptr;
             if (count_steps) {
@@ -3515,16 +3522,27 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                              counts[WAVE_SWING_SCANS], counts[WAVE_BY_ONE_LANE]);
             }
             if (leave.chunk_left) {
-                unsigned int n_left = 0;
-                FIT_CHECK(hipMemcpyAsync(&n_left, leave.n_left, 4, hipMemcpyDeviceToHost, ctx->stream));
+                unsigned int left[2] = {0, 0};
+                FIT_CHECK(hipMemcpyAsync(left, leave.n_left, 8, hipMemcpyDeviceToHost, ctx->stream));
                 FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                const unsigned int n_left = left[0];
                 if (n_left > 0) {
                     split_mode = true;
                     split_only = leave.chunk_left;
-                    // (pieces sized for the chunks that are left, taken to be as long as the others)
+                    // (the chunks that are left are the ones whose models are short: chains that start at different
+                    // points of such a chunk meet within a few models, so short pieces cost little twice-fitted ground and
+                    // give every SIMD many waves - the mixed series' left half in pieces of 3 712 / 1 280 / 512 / 256 / 128
+                    // points: 21.0 / 17.0 / 15.5 / 15.5 / 17.8 ms, 26-point models 21.9 / - / 19.0 / 18.1 / - ms)
+                    // (a chunk left for its length alone - a whole series handed over as one chunk - may have models of any
+                    // length, and chains through long models meet late: pieces sized for the chunks that are left, taken to
+                    // be as long as the others, as for a call that goes to split mode by itself)
                     if (!option_text("MDB_FIT_PIECE_POINTS")) {
-                        const uint32_t for_these = split_piece_points(ctx, n_left, points_end / n_chunks * n_left);
-                        if (for_these != 0) piece_points = for_these;
+                        if (left[1] == 0) {
+                            piece_points = std::min<uint32_t>(piece_points, FIT_LEFT_PIECE_POINTS);
+                        } else {
+                            const uint32_t for_these = split_piece_points(ctx, n_left, points_end / n_chunks * n_left);
+                            if (for_these != 0) piece_points = for_these;
+                        }
                     }
                 }
             }
@@ -3620,6 +3638,20 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                     hipLaunchKernelGGL((k_fit_models<false, true, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                        ctx->stream, args, split, record_base, records, plans, error_flag);
             }
+#if defined(MDB_FIT_TIMING) && defined(MDB_FIT_TIMING_SPLIT)
+            if (n_pieces > 0 && lean && !ts && eb.kind == MDB_EB_RELATIVE) {
+                unsigned long long t[8] = {};
+                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                FIT_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fit_timing), sizeof(t)));
+                const unsigned long long zero[8] = {};
+                FIT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fit_timing), zero, sizeof(zero)));
+                const double waves = (double)t[5], steps = (double)t[3];
+                std::fprintf(stderr, "[fit timing, split] region %d: %.1f cycles per pass, %.4f passes per step = %.1f cycles per step; loop %.1f cycles per step "
+                             "(%.0f waves, %.0f steps per wave, %llu pieces of %u points)\n", (int)MDB_FIT_TIMING,
+                             t[1] ? (double)t[0] / (double)t[1] : 0.0, (double)t[1] / steps, (double)t[0] / steps, (double)t[2] / steps, waves,
+                             steps / waves, n_pieces, piece_points);
+            }
+#endif
             LaunchTimer timer(ctx, "k_fit_walk");
             hipLaunchKernelGGL(k_fit_walk, dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream,
                                args.chunk_offsets, n_chunks, split, record_base, records, plans, error_flag);

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../../modelardb-rs_amd/csrc"
 make -s all
-flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero -Wno-unused-function"
+flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-gpu-flush-denormals-to-zero -Wno-unused-function $EXTRA_FLAGS"
 for n in "$@"; do
   /opt/rocm/bin/hipcc $flags -DMDB_FIT_TIMING=$n -c mdb_fit.hip -o /tmp/timing_fit_$n.o &
 done
