@@ -75,6 +75,7 @@ enum ScratchSlot {
     SCRATCH_FIT_WAVE,
     SCRATCH_MV_HOST_INDEX,
     SCRATCH_FIT_SMALL,
+    SCRATCH_AGG_CHAIN_LIST,
     SCRATCH_SLOT_COUNT
 };
 

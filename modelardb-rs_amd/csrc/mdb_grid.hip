@@ -1776,7 +1776,9 @@ template <int LOADS> // 16-byte loads a lane has in flight per round of a long s
 __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint32_t *__restrict__ known_totals,
                                                        const unsigned long long *__restrict__ piece_base,
                                                        const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
-                                                       const unsigned char *__restrict__ stream_done) {
+                                                       const unsigned char *__restrict__ stream_done,
+                                                       uint32_t long_min, uint32_t *__restrict__ long_items,
+                                                       unsigned int *__restrict__ n_long) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     const unsigned long long first_piece = piece_base[i];
@@ -1837,8 +1839,57 @@ __global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint
         return sum;
     };
     const unsigned long long value_pieces = (n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES;
-    if (!values_done) stream_sums[2 * i] = n_values ? chain(first_piece, n_values, true) : 0.0f;
+    // (a stream of long_min values or more: listed for k_agg_mv_chains_long, where nobody waits for it)
+    if (!values_done && long_items && n_values >= long_min) long_items[atomicAdd(n_long, 1u)] = (uint32_t)(i << 1);
+    else if (!values_done) stream_sums[2 * i] = n_values ? chain(first_piece, n_values, true) : 0.0f;
     if (!tail_done) stream_sums[2 * i + 1] = n_res ? chain(first_piece + value_pieces, n_res, false) : 0.0f;
+}
+
+// The long streams k_agg_mv_chains has listed (item: segment << 1 | 1 for its residual tail - which is never long -, 0 for
+// its MacaqueV values), a lane each, 32 loads of 16 bytes in flight per round: beside lanes with a few hundred values
+// a 65 536-value chain kept its wave for a millisecond, eight loads and a trip to memory per 32 additions.
+// (LOADS: 32 where a handful of streams has the GPU to itself, 8 where every lane of every wave has one - 100 000 streams
+// of 50 000 values: 4.2 / 5.7 ms with 8 / 32 -: both are launched, the number of listed streams says which one runs)
+constexpr unsigned int CHAIN_FEW_LONG = 65536;
+template <int LOADS>
+__global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chains_long(DevSegments s, const uint32_t *__restrict__ known_totals,
+                                                                 const unsigned long long *__restrict__ piece_base,
+                                                                 const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
+                                                                 const uint32_t *__restrict__ items, const unsigned int *__restrict__ n_items) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int listed = *n_items;
+    if (k >= listed || (listed <= CHAIN_FEW_LONG) != (LOADS == 32)) return;
+    const uint32_t item = items[k];
+    const uint64_t i = item >> 1;
+    uint32_t n_values, n_res, n_model, error;
+    mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
+    const bool tail = (item & 1u) != 0;
+    const unsigned long long at_piece = piece_base[i] + (tail ? (n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES : 0u);
+    const uint32_t n = tail ? n_res : n_values;
+    const uint4 *from = reinterpret_cast<const uint4 *>(values + at_piece * MV_PIECE_VALUES);
+    // (k_agg_mv_chains' additions, in stream order: macaque_v.rs:228-235 - the sum of a MacaqueV segment starts AS its
+    // first value, a tail's at zero)
+    float sum = 0.0f;
+    uint32_t done = 0;
+    if (!tail && n > 0) {
+        sum = __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES));
+        done = 1;
+    }
+    for (; done < n && (done & 31u) != 0; done++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + done));
+    for (; done + 4 * LOADS <= n; done += 4 * LOADS) {
+        uint4 v[LOADS];
+#pragma unroll
+        for (int q = 0; q < LOADS; q++) v[q] = load_global(from + (done >> 2) + q);
+#pragma unroll
+        for (int q = 0; q < LOADS; q++) {
+            sum += __uint_as_float(v[q].x);
+            sum += __uint_as_float(v[q].y);
+            sum += __uint_as_float(v[q].z);
+            sum += __uint_as_float(v[q].w);
+        }
+    }
+    for (; done < n; done++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + done));
+    stream_sums[2 * i + (tail ? 1 : 0)] = sum;
 }
 
 // ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
@@ -3230,6 +3281,21 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
         hipLaunchKernelGGL(k_agg_mv_pieces, dim3((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE)), dim3(MDB_WAVE), 0,
                            ctx->stream, s, static_cast<const MvCursor *>(index->cursors), index->n_pieces, values, sums, done);
     }
+    // Streams of CHAIN_LONG_VALUES values or more are listed by k_agg_mv_chains and added up behind it, a lane each
+    // (MDB_AGG_CHAIN_LIST=0: never; for batches of more than 512 segments: a handful of streams has the lanes to itself).
+    constexpr uint32_t CHAIN_LONG_VALUES = 4096;
+    const char *list_setting = option_text("MDB_AGG_CHAIN_LIST");
+    const bool list_long = !(list_setting && std::strcmp(list_setting, "0") == 0) && in->n > 512 && in->n <= 0x7ffffff0ull;
+    const uint64_t long_bound = list_long ? index->n_pieces * MV_PIECE_VALUES / CHAIN_LONG_VALUES + 1 : 0; // (how many there can be)
+    uint32_t *long_items = nullptr;
+    unsigned int *n_long = nullptr;
+    if (list_long) {
+        void *q = nullptr;
+        if (scratch_reserve(ctx, SCRATCH_AGG_CHAIN_LIST, long_bound * 4 + 64, &q)) return 1;
+        n_long = static_cast<unsigned int *>(q);
+        long_items = reinterpret_cast<uint32_t *>(n_long + 16);
+        MDB_HIP_CHECK(hipMemsetAsync(n_long, 0, 4, ctx->stream));
+    }
     {
         LaunchTimer timer(ctx, "k_agg_mv_chains");
         // 16-byte loads in flight per lane: many while the batch has few streams (16 streams of 65 536 values: 0.82 / 0.51 /
@@ -3239,11 +3305,19 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
         const int loads = text ? std::atoi(text) : (in->n <= 512 ? 32 : 8);
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums, done);
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums, done, CHAIN_LONG_VALUES,
+                               long_items, n_long);
         };
         if (loads == 32) launch(k_agg_mv_chains<32>);
         else if (loads == 16) launch(k_agg_mv_chains<16>);
         else launch(k_agg_mv_chains<8>);
+        if (list_long) {
+            const dim3 long_blocks((uint32_t)((long_bound + MDB_WAVE - 1) / MDB_WAVE));
+            hipLaunchKernelGGL(k_agg_mv_chains_long<32>, long_blocks, dim3(MDB_WAVE), 0, ctx->stream, s, known_totals,
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long);
+            hipLaunchKernelGGL(k_agg_mv_chains_long<8>, long_blocks, dim3(MDB_WAVE), 0, ctx->stream, s, known_totals,
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long);
+        }
     }
     *stream_sums = sums;
     return 0;
