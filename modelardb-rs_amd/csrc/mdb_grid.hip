@@ -1855,10 +1855,11 @@ template <int LOADS>
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chains_long(DevSegments s, const uint32_t *__restrict__ known_totals,
                                                                  const unsigned long long *__restrict__ piece_base,
                                                                  const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
-                                                                 const uint32_t *__restrict__ items, const unsigned int *__restrict__ n_items) {
+                                                                 const uint32_t *__restrict__ items, const unsigned int *__restrict__ n_items,
+                                                                 unsigned int few_long) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned int listed = *n_items;
-    if (k >= listed || (listed <= CHAIN_FEW_LONG) != (LOADS == 32)) return;
+    if (k >= listed || (listed <= few_long) != (LOADS == 32)) return;
     const uint32_t item = items[k];
     const uint64_t i = item >> 1;
     uint32_t n_values, n_res, n_model, error;
@@ -3313,10 +3314,13 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
         else launch(k_agg_mv_chains<8>);
         if (list_long) {
             const dim3 long_blocks((uint32_t)((long_bound + MDB_WAVE - 1) / MDB_WAVE));
+            // (MDB_AGG_CHAIN_FEW_LONG: up to how many listed streams the 32 loads are taken - tests reach the other kernel with 0)
+            const char *few_text = option_text("MDB_AGG_CHAIN_FEW_LONG");
+            const unsigned int few_long = few_text ? (unsigned int)std::max(0ll, std::atoll(few_text)) : CHAIN_FEW_LONG;
             hipLaunchKernelGGL(k_agg_mv_chains_long<32>, long_blocks, dim3(MDB_WAVE), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long);
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long, few_long);
             hipLaunchKernelGGL(k_agg_mv_chains_long<8>, long_blocks, dim3(MDB_WAVE), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long);
+                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long, few_long);
         }
     }
     *stream_sums = sums;

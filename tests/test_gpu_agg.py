@@ -545,3 +545,42 @@ def test_range_aggregates_over_long_lossless_streams_go_piece_by_piece(hip, monk
             assert (without.count, without.min, without.max) == (by_pieces.count, by_pieces.min, by_pieces.max)
             assert abs(without.sum - by_pieces.sum) <= 1e-9 * max(abs(by_pieces.sum), 1e-30)
     resident.free()
+
+
+@pytest.mark.parametrize("mode", ["default", "eight-loads", "never"])
+def test_long_macaque_streams_are_added_up_by_lanes_of_their_own(hip, mode, monkeypatch):
+    # SUM over a resident batch of many segments with a few long MacaqueV streams among them (lossless noise: a chunk is
+    # one stream): k_agg_mv_chains lists the streams of 4 096 values or more, k_agg_mv_chains_long adds each of them up
+    # with a lane of its own - 32 loads in flight, or 8 where there are many (MDB_AGG_CHAIN_FEW_LONG=0 takes that kernel) -
+    # in the same order of additions as the one kernel does with MDB_AGG_CHAIN_LIST=0: the same f32 sums bit for bit.
+    if mode == "eight-loads":
+        monkeypatch.setenv("MDB_AGG_CHAIN_FEW_LONG", "0")
+    elif mode == "never":
+        monkeypatch.setenv("MDB_AGG_CHAIN_LIST", "0")
+    rng = np.random.default_rng(47)
+    parts, offsets = [], [0]
+    for length in (70_000, 4_096, 4_095, 12_345, 5_000, 65_536):   # noise: one MacaqueV segment per chunk
+        parts.append(rng.uniform(-1e3, 1e3, length).astype(np.float32))
+        offsets.append(offsets[-1] + length)
+    for _ in range(40):                                            # ... and chunks of many short segments
+        runs = [np.full(int(rng.integers(9, 40)), float(rng.uniform(-50, 50)), dtype=np.float32) for _ in range(60)]
+        runs += [rng.uniform(-1e3, 1e3, int(rng.integers(1, 300))).astype(np.float32) for _ in range(20)]
+        order = rng.permutation(len(runs))
+        parts.append(np.concatenate([runs[k] for k in order]))
+        offsets.append(offsets[-1] + len(parts[-1]))
+    values = np.concatenate(parts)
+    timestamps = 1_700_000_000_000 + 100 * np.arange(len(values), dtype=np.int64)
+    segments = hip.compress_chunks(timestamps, values, np.array(offsets, dtype=np.uint64), cases.LOSSLESS)
+    assert len(segments) > 512 and int((segments.model_type_id == 2).sum()) >= 6
+    resident = hip.upload_segments(segments)
+    hip.profile_enable(True)
+    hip.profile_reset()
+    state = hip.agg_batch_dev(resident, ALL)
+    kernels = hip.profile()
+    hip.profile_enable(False)
+    assert "k_agg_mv_chains" in kernels
+    _assert_state(state, ora.agg_batch(segments, ALL))
+    monkeypatch.setenv("MDB_AGG_CHAIN_LIST", "0")
+    plain = hip.agg_batch_dev(resident, ALL)
+    assert np.float64(plain.sum).tobytes() == np.float64(state.sum).tobytes() and plain.count == state.count
+    resident.free()
