@@ -563,14 +563,30 @@ struct MacaqueState {
     uint32_t last_trailing = 0;
 };
 
-__device__ __forceinline__ float rewrite_least_mantissa_bits(mdb_error_bound eb, float value) {
+// (`deviation`: deviation_factor(eb) - max_allowed_deviation's division once per stream, not per value, as in the
+// fitters; the division by 2^exponent as a scaling by 2^-exponent: the same real number, rounded the same way)
+__device__ __forceinline__ float rewrite_least_mantissa_bits(mdb_error_bound eb, const DeviationFactor &deviation, float value) {
     if (fabsf(value) == 0.0f || value != value || isinf(value)) return value;
     uint32_t bits = __float_as_uint(value);
-    float abs_error_bound = (float)max_allowed_deviation(eb, (double)value);
+    float abs_error_bound = (float)deviation.of((double)value);
     int exponent = (int)((bits >> 23) & 0xffu) - 127;
-    float factorized_epsilon = abs_error_bound / ldexpf(1.0f, exponent);
-    // (float)log2((double)x): correctly rounded log2f, the same definition the oracle uses.
-    float magnitude = floorf(fabsf((float)log2((double)factorized_epsilon)));
+    float factorized_epsilon = ldexpf(abs_error_bound, -exponent);
+    // (float)log2((double)x): correctly rounded log2f, the same definition the oracle uses - and a hundred instructions
+    // per value of a noisy stream. All that is kept of it is floor(|.|), which for x = 2^E m, 1 <= m < 2, is E or -E - 1
+    // unless the logarithm lies so close to a whole number that its rounding to f32 reaches it: farther than 256 of m's
+    // steps of 2^-23 from 1 and from 2 the logarithm is more than 2 x 10^-5 from E and E + 1, a float of its size (below
+    // 150) less than 8 x 10^-6 from it. The values in between (one in 16 000), zeros, subnormals, infinities, NaNs and
+    // negative ones take the function itself.
+    float magnitude;
+    const uint32_t epsilon_bits = __float_as_uint(factorized_epsilon);
+    const uint32_t epsilon_exponent = (epsilon_bits >> 23) & 0xffu, epsilon_fraction = epsilon_bits & 0x7fffffu;
+    if ((epsilon_bits >> 31) == 0u && epsilon_exponent != 0u && epsilon_exponent != 255u && epsilon_fraction >= 256u &&
+        epsilon_fraction < (1u << 23) - 256u) {
+        const int e = (int)epsilon_exponent - 127;
+        magnitude = (float)(e >= 0 ? e : -e - 1);
+    } else {
+        magnitude = floorf(fabsf((float)log2((double)factorized_epsilon)));
+    }
     long long wide_position = 23ll - (long long)saturating_f32_to_i32(magnitude);
     int position = wide_position < -2147483647ll ? -2147483647 : (int)wide_position;
     auto rewrite = [](uint32_t b, int pos) -> uint32_t {
@@ -595,10 +611,10 @@ __device__ __forceinline__ void macaque_update(MacaqueState &m, float value) {
 
 template <typename Sink>
 __device__ __forceinline__ void macaque_xor_value(MacaqueState &m, Sink &sink, mdb_error_bound eb,
-                                                  float value) {
+                                                  const DeviationFactor &deviation, float value) {
     if (eb.kind != MDB_EB_LOSSLESS) {
         if (within_error_bound(eb, value, m.last_value)) value = m.last_value;
-        else value = rewrite_least_mantissa_bits(eb, value);
+        else value = rewrite_least_mantissa_bits(eb, deviation, value);
     }
     uint32_t x = __float_as_uint(value) ^ __float_as_uint(m.last_value);
     if (x == 0) {
@@ -634,7 +650,8 @@ __device__ __forceinline__ void macaque_encode(MacaqueState &m, Sink &sink, mdb_
         macaque_update<Sink>(m, values[0]);
         i = 1;
     }
-    for (; i < n; i++) macaque_xor_value(m, sink, eb, values[i]);
+    const DeviationFactor deviation = deviation_factor(eb);
+    for (; i < n; i++) macaque_xor_value(m, sink, eb, deviation, values[i]);
 }
 
 // ---- MacaqueTS encoder (models/timestamps.rs:56-155) ----------------------------------------------------
@@ -2824,6 +2841,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
     }
     uint32_t window_leading = 255, window_trailing = 0; // uniform: macaque_v.rs:63-64
     const mdb_error_bound eb = args.eb;
+    const DeviationFactor deviation = deviation_factor(eb);
     float carried_in = values[0];  // uniform: the value stored last (the first one is stored as it is)
     float last_stored = values[0];
     // While sizing, the wave also checks whether the timestamps are equally spaced, which the one-lane
@@ -2843,7 +2861,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         float stored = active ? values[i] : 0.0f;
         if (eb.kind != MDB_EB_LOSSLESS) {
             const float raw = stored;
-            const float rewritten = active ? rewrite_least_mantissa_bits(eb, raw) : 0.0f;
+            const float rewritten = active ? rewrite_least_mantissa_bits(eb, deviation, raw) : 0.0f;
             // Where nearly every value breaks away from the one stored before it (noise under a tight bound), one
             // trip per breaker is 64 trips per batch. If lane i - 1 stores its own value, lane i is compared with
             // that: whether it then breaks too is known up front for all lanes at once, so a run of breakers
