@@ -220,6 +220,13 @@ int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int6
                         uint32_t which_mask, mdb_agg_state *inout);
 int mdb_agg_batch_range_dev(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int64_t t_hi,
                             uint32_t which_mask, mdb_agg_state *inout);
+/* The list form (mdb_agg_batch_list under a time range): what the accumulators of a ranged query fold their
+ * gathered batches with. The patched optimizer rule (rust/patches/0002) accepts AggregateExec <- FilterExec(a
+ * conjunction of comparisons of the timestamp column with literals) <- SortedJoinExec <- GridExec <-
+ * DataSourceExec(the start_time / end_time filter TimeSeriesTable::scan derived from the same comparisons,
+ * query/time_series_table.rs:290-373) and hands [t_lo, t_hi] to the accumulators it creates. */
+int mdb_agg_batch_range_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t n_inputs, int64_t t_lo,
+                             int64_t t_hi, uint32_t which_mask, mdb_agg_state *inout);
 
 /* ---- fit: replaces try_compress_univariate_time_series
  *      (crates/modelardb_compression/src/compression.rs:191-275), called per field column by

@@ -200,6 +200,8 @@ _HIP_SYMBOLS = {
                                       C.c_uint32, C.POINTER(AggStateC)]),
     "mdb_agg_batch_range_dev": (C.c_int, [C.c_void_p, C.POINTER(SegmentsC), C.c_int64, C.c_int64,
                                           C.c_uint32, C.POINTER(AggStateC)]),
+    "mdb_agg_batch_range_list": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(SegmentsC)), C.c_uint32, C.c_int64,
+                                           C.c_int64, C.c_uint32, C.POINTER(AggStateC)]),
     "mdb_compress_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, ErrorBoundC,
                                       C.POINTER(C.POINTER(SegmentsOwnedC))]),
     "mdb_compress_chunks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,

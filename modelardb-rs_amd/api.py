@@ -388,6 +388,16 @@ class Context:
                                                  C.byref(state)))
         return state
 
+    def agg_batch_range_list(self, batches, t_lo, t_hi, which_mask, state=None):
+        """Several host batches folded as one under a time range (mdb_agg_batch_range_list): what the accumulators
+        of a ranged query pass (rust/patches/0002)."""
+        views = [batch.as_c() for batch in batches]
+        pointers = (C.POINTER(_abi.SegmentsC) * len(views))(*[C.pointer(view) for view in views])
+        state = state or _abi.AggStateC.fresh()
+        self._check(self.lib.mdb_agg_batch_range_list(self.handle, pointers, len(views), t_lo, t_hi, which_mask,
+                                                      C.byref(state)))
+        return state
+
     def agg_batch_dev(self, dev_segments, which_mask, state=None):
         state = state or _abi.AggStateC.fresh()
         self._check(self.lib.mdb_agg_batch_dev(self.handle, C.byref(dev_segments.seg), which_mask,

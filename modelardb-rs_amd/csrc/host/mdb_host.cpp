@@ -437,13 +437,12 @@ void GridStreamMetrics::add(const mdb_grid_metrics &m) {
     }
 }
 
-std::shared_ptr<GridExec> GridExec::make(mdb_ctx *ctx, std::vector<Field> schema,
-                                         std::optional<TimestampPredicate> maybe_predicate,
+std::shared_ptr<GridExec> GridExec::make(mdb_ctx *ctx, std::vector<Field> schema, ExprPtr maybe_predicate,
                                          std::optional<size_t> limit, std::shared_ptr<ExecutionPlan> input) {
     auto exec = std::make_shared<GridExec>();
     exec->ctx_ = ctx;
     exec->schema_ = std::move(schema);
-    exec->maybe_predicate_ = maybe_predicate;
+    exec->maybe_predicate_ = std::move(maybe_predicate);
     exec->limit_ = limit;
     exec->input_ = std::move(input);
     return exec;
@@ -474,13 +473,17 @@ std::string GridExec::fmt_as() const {
     return std::string("GridExec: limit=") + (limit_ ? "Some(" + std::to_string(*limit_) + ")" : "None");
 }
 
-GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<TimestampPredicate> maybe_predicate,
+GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, ExprPtr maybe_predicate,
                        std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
                        std::shared_ptr<GridStreamMetrics> metrics, bool values_only)
-    : ctx_(ctx), schema_(std::move(schema)), maybe_predicate_(maybe_predicate), input_(std::move(input)),
+    : ctx_(ctx), schema_(std::move(schema)), maybe_predicate_(std::move(maybe_predicate)), input_(std::move(input)),
       batch_size_(limit ? std::min(*limit, batch_size) : batch_size), // grid_exec.rs:239-246
       metrics_(std::move(metrics)), values_only_(values_only) {
     if (schema_.size() < 2) throw Error("GridStream should use a static schema.");
+    // (rust/patches/0001: GridStream::new works the range out of maybe_predicate once)
+    if (maybe_predicate_) pushed_range_ = time_range_of_predicate(*maybe_predicate_, schema_[0].name);
+    if (values_only_ && maybe_predicate_ && !(pushed_range_ && pushed_range_->exact))
+        throw Error("A values-only GridStream cannot evaluate a predicate that is not a time range.");
     if (values_only_) schema_ = {schema_[1]};
     current_batch_ = RecordBatch::new_empty(schema_);
     // MDB_HOST_GRID_PREFETCH=0: grid a batch when it is polled for and not before (A/B, tests).
@@ -523,10 +526,10 @@ PollState GridStream::poll_input_and_submit(std::optional<Ticket> *out) {
     }
     if (state == PollState::ReadyNone) input_finished_ = true;
     if (ticket.batches.empty()) return state; // ReadyNone or Pending
-    // One library call replaces the per-row loop of grid_exec.rs:323-356 for all gathered batches. A timestamp
-    // predicate is pushed down so out-of-range points are neither reconstructed nor copied over PCIe (the
-    // leftovers were filtered when they were created), which makes the filter step of grid_exec.rs:366-387 a
-    // no-op here. The points arrive in page-locked memory owned by the library with room in front for the
+    // One library call replaces the per-row loop of grid_exec.rs:323-356 for all gathered batches. The range the
+    // predicate puts on the timestamps is pushed down so out-of-range points are neither reconstructed nor copied
+    // over PCIe (the leftovers were filtered when they were created); if the predicate IS that range the filter
+    // step of grid_exec.rs:366-387 has nothing left to remove and is skipped, otherwise it runs on what came back. The points arrive in page-locked memory owned by the library with room in front for the
     // leftovers (fewer than batch_size of them); the columns alias it. Tag views are repeated per created row
     // by the library (grid_exec.rs:339-346); the strings stay where they are: an output tag column lists one
     // buffer of its own (long leftover strings) and then the data buffers of every gathered batch.
@@ -551,12 +554,12 @@ PollState GridStream::poll_input_and_submit(std::optional<Ticket> *out) {
         inputs[b].tag_views = n_tags ? tag_views.data() + b * n_tags : nullptr;
         inputs[b].tag_buffer_shift = n_tags ? tag_shifts.data() + b * n_tags : nullptr;
     }
-    const bool pushdown = maybe_predicate_.has_value();
+    const bool pushdown = pushed_range_.has_value();
     mdb_grid_request request{};
     request.flags = (pushdown ? MDB_GRID_HAS_RANGE : 0u) | (values_only_ ? MDB_GRID_VALUES_ONLY : 0u);
     request.n_tag_columns = static_cast<uint32_t>(n_tags);
-    request.t_lo = pushdown && maybe_predicate_->lower ? *maybe_predicate_->lower : INT64_MIN;
-    request.t_hi = pushdown && maybe_predicate_->upper ? *maybe_predicate_->upper : INT64_MAX;
+    request.t_lo = pushdown ? pushed_range_->range.lo : INT64_MIN;
+    request.t_hi = pushdown ? pushed_range_->range.hi : INT64_MAX;
     request.reserve_front = batch_size_;
     check(mdb_grid_submit(ctx_, inputs.data(), static_cast<uint32_t>(inputs.size()), &request, &ticket.raw));
     *out = std::move(ticket);
@@ -653,6 +656,13 @@ void GridStream::wait_and_append_to_leftovers_in_current_batch(Ticket ticket) {
     if (!values_only_) current.columns.push_back(aliased(Type::Timestamp, timestamps));
     current.columns.push_back(aliased(Type::Float32, values));
     for (ColumnPtr &column : tag_columns) current.columns.push_back(column);
+    // grid_exec.rs:366-387: "all data points are reconstructed and then pruned by time" - here only what the pushed
+    // range did not already decide. The leftovers in front passed the predicate when they were created.
+    if (maybe_predicate_ && !(pushed_range_ && pushed_range_->exact)) {
+        std::vector<uint8_t> mask = evaluate_predicate(*maybe_predicate_, current);
+        std::fill(mask.begin(), mask.begin() + leftovers, 1);
+        current = filter_record_batch(current, mask);
+    }
     current_batch_ = std::move(current);
     current_batch_offset_ = 0; // grid_exec.rs:389-390
     metrics_->elapsed_compute_ns += static_cast<uint64_t>(
@@ -817,7 +827,11 @@ constexpr size_t PENDING_SEGMENTS_PER_CALL = 262144;
 
 class ModelAccumulator : public Accumulator {
   public:
-    ModelAccumulator(mdb_ctx *ctx, uint32_t mask) : ctx_(ctx), mask_(mask) { reset(); }
+    // Under a range COUNT is always asked for as well: a range without a data point gives NULL, not the identity.
+    ModelAccumulator(mdb_ctx *ctx, uint32_t mask, std::optional<TimeRange> range)
+        : ctx_(ctx), mask_(range ? (mask | MDB_AGG_COUNT) : mask), range_(range) {
+        reset();
+    }
     // (PendingSegments::push of the patched accumulators: the columns are kept, not copied, until enough segments are
     // pending or the state is read - nobody can observe it in between)
     void update_batch(const std::vector<ColumnPtr> &arrays) override {
@@ -837,7 +851,11 @@ class ModelAccumulator : public Accumulator {
             fill_segments_view(pending_[k], &views[k]);
             inputs[k] = &views[k].seg;
         }
-        const int code = mdb_agg_batch_list(ctx_, inputs.data(), static_cast<uint32_t>(inputs.size()), mask_, &state_);
+        // (PendingSegments::fold_into of rust/patches/0002: aggregate_list, or aggregate_range_list under a range)
+        const int code =
+            range_ ? mdb_agg_batch_range_list(ctx_, inputs.data(), static_cast<uint32_t>(inputs.size()), range_->lo,
+                                              range_->hi, mask_, &state_)
+                   : mdb_agg_batch_list(ctx_, inputs.data(), static_cast<uint32_t>(inputs.size()), mask_, &state_);
         pending_.clear();
         pending_segments_ = 0;
         check(code);
@@ -848,15 +866,19 @@ class ModelAccumulator : public Accumulator {
         state_.min = std::numeric_limits<float>::max();    // f32::MAX (:413)
         state_.max = std::numeric_limits<float>::lowest(); // f32::MIN (:456)
     }
+    // MIN / MAX / SUM over no data point at all: NULL under a range (see make_model_*_accumulator), the identity
+    // element without one (the reference's own behaviour for an empty table, :410-415, 453-458, 523-528).
+    bool nothing_in_range() const { return range_ && state_.count == 0; }
     mdb_ctx *ctx_;
     uint32_t mask_;
+    std::optional<TimeRange> range_;
     mdb_agg_state state_;
     std::vector<std::vector<ColumnPtr>> pending_;
     size_t pending_segments_ = 0;
 };
 
 struct ModelCountAccumulator : ModelAccumulator {
-    explicit ModelCountAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_COUNT) {}
+    ModelCountAccumulator(mdb_ctx *ctx, std::optional<TimeRange> range) : ModelAccumulator(ctx, MDB_AGG_COUNT, range) {}
     std::vector<ScalarValue> state() override { // :367-372
         fold_pending();
         ScalarValue v{ScalarValue::Kind::Int64};
@@ -867,40 +889,43 @@ struct ModelCountAccumulator : ModelAccumulator {
 };
 
 struct ModelMinAccumulator : ModelAccumulator {
-    explicit ModelMinAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_MIN) {}
+    ModelMinAccumulator(mdb_ctx *ctx, std::optional<TimeRange> range) : ModelAccumulator(ctx, MDB_AGG_MIN, range) {}
     std::vector<ScalarValue> state() override { // :410-415
         fold_pending();
         ScalarValue v{ScalarValue::Kind::Float32};
         v.f32 = state_.min;
+        v.null = nothing_in_range();
         reset();
         return {v};
     }
 };
 
 struct ModelMaxAccumulator : ModelAccumulator {
-    explicit ModelMaxAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_MAX) {}
+    ModelMaxAccumulator(mdb_ctx *ctx, std::optional<TimeRange> range) : ModelAccumulator(ctx, MDB_AGG_MAX, range) {}
     std::vector<ScalarValue> state() override { // :453-458
         fold_pending();
         ScalarValue v{ScalarValue::Kind::Float32};
         v.f32 = state_.max;
+        v.null = nothing_in_range();
         reset();
         return {v};
     }
 };
 
 struct ModelSumAccumulator : ModelAccumulator {
-    explicit ModelSumAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_SUM) {}
+    ModelSumAccumulator(mdb_ctx *ctx, std::optional<TimeRange> range) : ModelAccumulator(ctx, MDB_AGG_SUM, range) {}
     std::vector<ScalarValue> state() override { // :523-528
         fold_pending();
         ScalarValue v{ScalarValue::Kind::Float64};
         v.f64 = state_.sum;
+        v.null = nothing_in_range();
         reset();
         return {v};
     }
 };
 
 struct ModelAvgAccumulator : ModelAccumulator {
-    explicit ModelAvgAccumulator(mdb_ctx *ctx) : ModelAccumulator(ctx, MDB_AGG_AVG) {}
+    ModelAvgAccumulator(mdb_ctx *ctx, std::optional<TimeRange> range) : ModelAccumulator(ctx, MDB_AGG_AVG, range) {}
     std::vector<ScalarValue> state() override { // :597-606: [UInt64 count, Float64 sum]
         fold_pending();
         ScalarValue count{ScalarValue::Kind::UInt64};
@@ -914,11 +939,21 @@ struct ModelAvgAccumulator : ModelAccumulator {
 
 } // namespace
 
-std::unique_ptr<Accumulator> make_model_count_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelCountAccumulator>(ctx); }
-std::unique_ptr<Accumulator> make_model_min_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelMinAccumulator>(ctx); }
-std::unique_ptr<Accumulator> make_model_max_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelMaxAccumulator>(ctx); }
-std::unique_ptr<Accumulator> make_model_sum_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelSumAccumulator>(ctx); }
-std::unique_ptr<Accumulator> make_model_avg_accumulator(mdb_ctx *ctx) { return std::make_unique<ModelAvgAccumulator>(ctx); }
+std::unique_ptr<Accumulator> make_model_count_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range) {
+    return std::make_unique<ModelCountAccumulator>(ctx, range);
+}
+std::unique_ptr<Accumulator> make_model_min_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range) {
+    return std::make_unique<ModelMinAccumulator>(ctx, range);
+}
+std::unique_ptr<Accumulator> make_model_max_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range) {
+    return std::make_unique<ModelMaxAccumulator>(ctx, range);
+}
+std::unique_ptr<Accumulator> make_model_sum_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range) {
+    return std::make_unique<ModelSumAccumulator>(ctx, range);
+}
+std::unique_ptr<Accumulator> make_model_avg_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range) {
+    return std::make_unique<ModelAvgAccumulator>(ctx, range);
+}
 
 // ---- compression ------------------------------------------------------------------------------------------------
 
@@ -1268,6 +1303,11 @@ struct JoinHandle {
 extern "C" {
 
 const char *mdbh_last_error(void) { return g_host_error.c_str(); }
+/* (for the other translation units of the library: sets the calling thread's error text) */
+int mdbh_fail(const char *message) {
+    g_host_error = message ? message : "";
+    return 1;
+}
 
 int mdbh_grid_exec_create(mdb_ctx *ctx, const char *const *tag_names, int32_t n_tags, int64_t limit,
                           int32_t has_lower, int64_t lower, int32_t has_upper, int64_t upper,
@@ -1279,13 +1319,29 @@ int mdbh_grid_exec_create(mdb_ctx *ctx, const char *const *tag_names, int32_t n_
         for (const std::string &tag : tags) input_schema.push_back({tag, Type::Utf8View});
         auto handle = std::make_unique<GridHandle>();
         handle->input = std::make_shared<QueueExec>(input_schema);
-        std::optional<TimestampPredicate> predicate;
-        if (has_lower || has_upper) {
-            predicate = TimestampPredicate{};
-            if (has_lower) predicate->lower = lower;
-            if (has_upper) predicate->upper = upper;
-        }
+        ExprPtr predicate = timestamp_range_predicate(has_lower ? std::optional<int64_t>(lower) : std::nullopt,
+                                                      has_upper ? std::optional<int64_t>(upper) : std::nullopt);
         handle->exec = GridExec::make(ctx, grid_schema(tags), predicate,
+                                      limit >= 0 ? std::optional<size_t>(static_cast<size_t>(limit)) : std::nullopt,
+                                      handle->input);
+        handle->stream = handle->exec->execute(0, batch_size);
+        *out = handle.release();
+    });
+}
+
+/* The same with the predicate GridExec is handed as an expression over (timestamp, value, tags...), in the text form
+ * of mdbhost::parse_expr (NULL or "": none). */
+int mdbh_grid_exec_create_expr(mdb_ctx *ctx, const char *const *tag_names, int32_t n_tags, int64_t limit,
+                               const char *predicate, uint64_t batch_size, void **out) {
+    return guarded([&] {
+        using namespace mdbhost;
+        std::vector<std::string> tags(tag_names, tag_names + n_tags);
+        std::vector<Field> input_schema = query_compressed_schema();
+        for (const std::string &tag : tags) input_schema.push_back({tag, Type::Utf8View});
+        auto handle = std::make_unique<GridHandle>();
+        handle->input = std::make_shared<QueueExec>(input_schema);
+        ExprPtr expr = predicate && *predicate ? parse_expr(predicate) : nullptr;
+        handle->exec = GridExec::make(ctx, grid_schema(tags), expr,
                                       limit >= 0 ? std::optional<size_t>(static_cast<size_t>(limit)) : std::nullopt,
                                       handle->input);
         handle->stream = handle->exec->execute(0, batch_size);
@@ -1385,12 +1441,8 @@ int mdbh_sorted_join_create(mdb_ctx *ctx, int32_t n_fields, const char *const *t
         std::vector<std::string> tags(tag_names, tag_names + n_tags);
         std::vector<Field> segment_schema = query_compressed_schema();
         for (const std::string &tag : tags) segment_schema.push_back({tag, Type::Utf8View});
-        std::optional<TimestampPredicate> predicate;
-        if (has_lower || has_upper) {
-            predicate = TimestampPredicate{};
-            if (has_lower) predicate->lower = lower;
-            if (has_upper) predicate->upper = upper;
-        }
+        ExprPtr predicate = timestamp_range_predicate(has_lower ? std::optional<int64_t>(lower) : std::nullopt,
+                                                      has_upper ? std::optional<int64_t>(upper) : std::nullopt);
         auto handle = std::make_unique<JoinHandle>();
         std::vector<std::shared_ptr<ExecutionPlan>> inputs;
         for (int32_t f = 0; f < n_fields; f++) {
@@ -1486,20 +1538,26 @@ int mdbh_sorted_join_describe(void *handle, char *out, uint64_t cap) {
 
 void mdbh_sorted_join_free(void *handle) { delete static_cast<JoinHandle *>(handle); }
 
-/* kind: 0 count, 1 min, 2 max, 3 sum, 4 avg */
-int mdbh_accumulator_create(mdb_ctx *ctx, int32_t kind, void **out) {
+/* kind: 0 count, 1 min, 2 max, 3 sum, 4 avg; has_range: only the data points with t_lo <= timestamp <= t_hi */
+int mdbh_accumulator_create_range(mdb_ctx *ctx, int32_t kind, int32_t has_range, int64_t t_lo, int64_t t_hi, void **out) {
     return guarded([&] {
         std::unique_ptr<mdbhost::Accumulator> acc;
+        std::optional<mdbhost::TimeRange> range;
+        if (has_range) range = mdbhost::TimeRange{t_lo, t_hi};
         switch (kind) {
-        case 0: acc = mdbhost::make_model_count_accumulator(ctx); break;
-        case 1: acc = mdbhost::make_model_min_accumulator(ctx); break;
-        case 2: acc = mdbhost::make_model_max_accumulator(ctx); break;
-        case 3: acc = mdbhost::make_model_sum_accumulator(ctx); break;
-        case 4: acc = mdbhost::make_model_avg_accumulator(ctx); break;
+        case 0: acc = mdbhost::make_model_count_accumulator(ctx, range); break;
+        case 1: acc = mdbhost::make_model_min_accumulator(ctx, range); break;
+        case 2: acc = mdbhost::make_model_max_accumulator(ctx, range); break;
+        case 3: acc = mdbhost::make_model_sum_accumulator(ctx, range); break;
+        case 4: acc = mdbhost::make_model_avg_accumulator(ctx, range); break;
         default: throw mdbhost::Error("Aggregate expression is not supported.");
         }
         *out = acc.release();
     });
+}
+
+int mdbh_accumulator_create(mdb_ctx *ctx, int32_t kind, void **out) {
+    return mdbh_accumulator_create_range(ctx, kind, 0, 0, 0, out);
 }
 
 int mdbh_accumulator_update_batch(void *acc, ArrowArray *array, ArrowSchema *schema) {
@@ -1509,14 +1567,17 @@ int mdbh_accumulator_update_batch(void *acc, ArrowArray *array, ArrowSchema *sch
     });
 }
 
-/* Writes up to two state values: kinds[i] (0 i64, 1 u64, 2 f32, 3 f64) and the value as f64 /
- * i64 bit patterns in values_f64 / values_i64. Returns how many via n_values. */
-int mdbh_accumulator_state(void *acc, int32_t *kinds, double *values_f64, int64_t *values_i64, int32_t *n_values) {
+/* Writes up to two state values: kinds[i] (0 i64, 1 u64, 2 f32, 3 f64), the value as f64 /
+ * i64 bit patterns in values_f64 / values_i64 and, if nulls is not NULL, whether it is NULL. Returns how many via
+ * n_values. */
+int mdbh_accumulator_state(void *acc, int32_t *kinds, double *values_f64, int64_t *values_i64, int32_t *n_values,
+                           int32_t *nulls) {
     return guarded([&] {
         auto state = static_cast<mdbhost::Accumulator *>(acc)->state();
         *n_values = static_cast<int32_t>(state.size());
         for (size_t i = 0; i < state.size(); i++) {
             kinds[i] = static_cast<int32_t>(state[i].kind);
+            if (nulls) nulls[i] = state[i].null ? 1 : 0;
             switch (state[i].kind) {
             case mdbhost::ScalarValue::Kind::Int64: values_i64[i] = state[i].i64; values_f64[i] = 0; break;
             case mdbhost::ScalarValue::Kind::UInt64: values_i64[i] = static_cast<int64_t>(state[i].u64); values_f64[i] = 0; break;

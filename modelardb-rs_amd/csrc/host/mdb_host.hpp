@@ -111,6 +111,10 @@ struct ExecutionPlan { // the slice of datafusion's ExecutionPlan that GridExec 
     virtual std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t /*batch_size*/) {
         return execute_segments(partition);
     }
+    // ExecutionPlan::with_new_children as the optimizer rules use it (a copy of this node over other inputs).
+    virtual std::shared_ptr<ExecutionPlan> with_new_children_dyn(std::vector<std::shared_ptr<ExecutionPlan>>) const {
+        throw Error(std::string(name()) + " does not support new children.");
+    }
 };
 
 // A child plan fed by hand: batches are pushed, then the input is finished (used by tests and by
@@ -135,15 +139,75 @@ class QueueExec : public ExecutionPlan {
     std::shared_ptr<State> state_ = std::make_shared<State>();
 };
 
+// ---- expressions: the slice of datafusion's Expr / PhysicalExpr the path's predicates are made of ------------------
+
+enum class Operator { Lt, LtEq, Gt, GtEq, Eq, NotEq, And, Or };
+const char *operator_text(Operator op); // "<", "<=", ..., "AND", "OR"
+
+struct Scalar { // ScalarValue of a literal
+    enum class Kind { TimestampMicrosecond, Int64, Float32, Utf8 } kind = Kind::Int64;
+    int64_t i64 = 0;
+    float f32 = 0.0f;
+    std::string utf8;
+};
+
+struct Expr;
+using ExprPtr = std::shared_ptr<const Expr>;
+struct Expr { // Expr::Column | Expr::Literal | Expr::BinaryExpr
+    enum class Kind { Column, Literal, BinaryExpr } kind = Kind::Column;
+    std::string column; // Column
+    Scalar literal;     // Literal
+    Operator op = Operator::Eq;
+    ExprPtr left, right; // BinaryExpr
+    static ExprPtr col(std::string name);
+    static ExprPtr lit(Scalar value);
+    static ExprPtr lit_timestamp(int64_t microseconds);
+    static ExprPtr binary(ExprPtr left, Operator op, ExprPtr right);
+    std::string to_string() const; // "timestamp >= TimestampMicrosecond(1000)"
+};
+// "(and (>= timestamp ts:1000) (< timestamp ts:5000))": columns by name, literals as ts:<i64>, i64:<i64>,
+// f32:<float>, str:<text>; operators < <= > >= = != and or. What the C surface and the tests write predicates in.
+ExprPtr parse_expr(const std::string &text);
+// utils::conjunction: None for no expressions, otherwise e0 AND e1 AND ...
+ExprPtr conjunction(const std::vector<ExprPtr> &exprs);
+// One byte per row: does the row satisfy `predicate` (columns looked up by name in batch.schema).
+std::vector<uint8_t> evaluate_predicate(const Expr &predicate, const struct RecordBatch &batch);
+// arrow::compute::filter_record_batch: the rows whose mask byte is set, in order. All set: the batch itself.
+RecordBatch filter_record_batch(const RecordBatch &batch, const std::vector<uint8_t> &mask);
+
+// The inclusive range of timestamps a predicate lets through, as mdb_grid_submit / mdb_agg_batch_range_list take it.
+struct TimeRange {
+    int64_t lo = INT64_MIN, hi = INT64_MAX;
+    bool empty() const { return lo > hi; }
+};
+struct PredicateRange {
+    TimeRange range;
+    // true: the predicate IS the range (a conjunction of comparisons of the timestamp column with timestamp
+    // literals - the only shape rewrite_filter emits for GridExec, query/time_series_table.rs:290-373), so rows the
+    // library returns under the range need no filter behind them. false: the range is only implied by the predicate
+    // (some conjuncts are something else) and the predicate is still evaluated on what comes back.
+    bool exact = true;
+};
+// None if no conjunct of `predicate` is a comparison (<, <=, >, >=, =) of column `timestamp_column` with a
+// TimestampMicrosecond literal (either side); anything that is not such a comparison or an AND of them makes the
+// result inexact, an OR / != anywhere above a comparison keeps it out of the range.
+std::optional<PredicateRange> time_range_of_predicate(const Expr &predicate, const std::string &timestamp_column);
+
+// rewrite_filter / rewrite_and_combine_filters (query/time_series_table.rs:269-373): the filters of a query, written
+// over the table's query schema, as (a filter over the segments' start_time / end_time for the Parquet scan, a filter
+// over `timestamp` for GridExec); filters on anything but the timestamp column are not rewritten (None).
+struct RewrittenFilters {
+    ExprPtr parquet; // may be null
+    ExprPtr grid;    // may be null
+};
+std::optional<std::pair<ExprPtr, ExprPtr>> rewrite_filter(const std::vector<Field> &query_schema, const Expr &filter);
+RewrittenFilters rewrite_and_combine_filters(const std::vector<Field> &query_schema, const std::vector<ExprPtr> &filters);
+
 // ---- GridExec ------------------------------------------------------------------------------------------------
 
-// The only predicate TimeSeriesTable::scan pushes into GridExec is a range on `timestamp`
-// (query/time_series_table.rs:269-373); it is evaluated after reconstruction (grid_exec.rs:366-387).
-struct TimestampPredicate {
-    std::optional<int64_t> lower; // inclusive
-    std::optional<int64_t> upper; // inclusive
-    bool matches(int64_t t) const { return (!lower || t >= *lower) && (!upper || t <= *upper); }
-};
+// The predicate TimeSeriesTable::scan hands GridExec (`maybe_predicate`, grid_exec.rs:60, 370-387) for the two-sided
+// range lower <= timestamp <= upper, either side optional: what the older C surface passes as two integers.
+ExprPtr timestamp_range_predicate(std::optional<int64_t> lower, std::optional<int64_t> upper);
 
 struct GridStreamMetrics { // grid_exec.rs:441-518 (+ BaselineMetrics' output_rows / elapsed_compute)
     uint64_t rows_created = 0;
@@ -164,8 +228,7 @@ class GridStream;
 class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridExec> {
   public:
     // GridExec::new (grid_exec.rs:76-109). `schema` is the grid schema (timestamp, value, tags...).
-    static std::shared_ptr<GridExec> make(mdb_ctx *ctx, std::vector<Field> schema,
-                                          std::optional<TimestampPredicate> maybe_predicate,
+    static std::shared_ptr<GridExec> make(mdb_ctx *ctx, std::vector<Field> schema, ExprPtr maybe_predicate,
                                           std::optional<size_t> limit,
                                           std::shared_ptr<ExecutionPlan> input);
     const char *name() const override { return "GridExec"; }
@@ -173,6 +236,10 @@ class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridE
     std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {input_}; }
     // Err(Plan("Exactly one child must be provided")) unless children.size() == 1 (:142-160).
     std::shared_ptr<GridExec> with_new_children(std::vector<std::shared_ptr<ExecutionPlan>> children) const;
+    std::shared_ptr<ExecutionPlan> with_new_children_dyn(std::vector<std::shared_ptr<ExecutionPlan>> children) const override {
+        return with_new_children(std::move(children));
+    }
+    ExprPtr maybe_predicate() const { return maybe_predicate_; }
     // execute(partition, task_context): batch_size comes from the session config (:165-182).
     std::unique_ptr<GridStream> execute(size_t partition, size_t batch_size);
     std::unique_ptr<SegmentStream> execute_segments(size_t) override {
@@ -192,7 +259,7 @@ class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridE
   private:
     mdb_ctx *ctx_ = nullptr;
     std::vector<Field> schema_;
-    std::optional<TimestampPredicate> maybe_predicate_;
+    ExprPtr maybe_predicate_;
     std::optional<size_t> limit_;
     std::shared_ptr<ExecutionPlan> input_;
     std::shared_ptr<GridStreamMetrics> metrics_ = std::make_shared<GridStreamMetrics>();
@@ -201,8 +268,7 @@ class GridExec : public ExecutionPlan, public std::enable_shared_from_this<GridE
 
 class GridStream : public SegmentStream { // grid_exec.rs:213-437
   public:
-    GridStream(mdb_ctx *ctx, std::vector<Field> schema, std::optional<TimestampPredicate> maybe_predicate,
-               std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
+    GridStream(mdb_ctx *ctx, std::vector<Field> schema, ExprPtr maybe_predicate, std::optional<size_t> limit, std::unique_ptr<SegmentStream> input, size_t batch_size,
                std::shared_ptr<GridStreamMetrics> metrics, bool values_only = false);
     // Stream::poll_next (:402-429)
     PollState poll_next(RecordBatch *out) override;
@@ -235,7 +301,11 @@ class GridStream : public SegmentStream { // grid_exec.rs:213-437
     uint64_t seen_segments_ = 0, seen_points_ = 0;
     size_t coalesce_segments_ = 0; // (MDB_HOST_GRID_COALESCE_SEGMENTS: a fixed number, 0: learned)
     std::vector<Field> schema_;
-    std::optional<TimestampPredicate> maybe_predicate_;
+    ExprPtr maybe_predicate_;
+    // What maybe_predicate_ says about the timestamps (time_range_of_predicate, worked out once when the stream is
+    // made): handed to every mdb_grid_submit, so points outside it are neither reconstructed nor copied; if it is
+    // not the whole predicate the predicate is evaluated on what comes back (grid_exec.rs:366-387).
+    std::optional<PredicateRange> pushed_range_;
     std::unique_ptr<SegmentStream> input_;
     size_t batch_size_;
     RecordBatch current_batch_;
@@ -271,6 +341,9 @@ class SortedJoinExec : public ExecutionPlan {
     std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return inputs_; }
     // Err(Plan("At least one child must be provided ...")) if children is empty (:131-147).
     std::shared_ptr<SortedJoinExec> with_new_children(std::vector<std::shared_ptr<ExecutionPlan>> children) const;
+    std::shared_ptr<ExecutionPlan> with_new_children_dyn(std::vector<std::shared_ptr<ExecutionPlan>> children) const override {
+        return with_new_children(std::move(children));
+    }
     std::unique_ptr<SortedJoinStream> execute(size_t partition, size_t batch_size); // :151-168
     std::unique_ptr<SegmentStream> execute_segments(size_t) override {
         throw Error("SortedJoinExec produces data points, not segments.");
@@ -317,6 +390,7 @@ struct ScalarValue {
     uint64_t u64 = 0;
     float f32 = 0.0f;
     double f64 = 0.0;
+    bool null = false; // ScalarValue::Float32(None), ...
 };
 
 class Accumulator {
@@ -326,15 +400,172 @@ class Accumulator {
     virtual void update_batch(const std::vector<ColumnPtr> &arrays) = 0;
     virtual std::vector<ScalarValue> state() = 0; // also resets, like the reference
     virtual size_t size() const = 0;
-    void merge_batch(const std::vector<ColumnPtr> &) { throw std::logic_error("unreachable"); }
-    ScalarValue evaluate() { throw std::logic_error("unreachable"); }
+    // The model-based accumulators only ever run in the Partial aggregate (unreachable!() in the reference,
+    // model_simple_aggregates.rs:374-384); DataFusion's own accumulators (query plans below) merge and evaluate.
+    virtual void merge_batch(const std::vector<ScalarValue> &) { throw std::logic_error("unreachable"); }
+    virtual ScalarValue evaluate() { throw std::logic_error("unreachable"); }
 };
 
-std::unique_ptr<Accumulator> make_model_count_accumulator(mdb_ctx *ctx);
-std::unique_ptr<Accumulator> make_model_min_accumulator(mdb_ctx *ctx);
-std::unique_ptr<Accumulator> make_model_max_accumulator(mdb_ctx *ctx);
-std::unique_ptr<Accumulator> make_model_sum_accumulator(mdb_ctx *ctx);
-std::unique_ptr<Accumulator> make_model_avg_accumulator(mdb_ctx *ctx);
+// `range`: the accumulators of a query the patched rule rewrote although it has a range on the timestamp (SURVEY
+// 8(f) N1): only the data points inside it count, folded by mdb_agg_batch_range_list; MIN, MAX and SUM of a range
+// without a data point are NULL, as DataFusion's are over the empty input the reference's plan would give them.
+std::unique_ptr<Accumulator> make_model_count_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range = std::nullopt);
+std::unique_ptr<Accumulator> make_model_min_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range = std::nullopt);
+std::unique_ptr<Accumulator> make_model_max_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range = std::nullopt);
+std::unique_ptr<Accumulator> make_model_sum_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range = std::nullopt);
+std::unique_ptr<Accumulator> make_model_avg_accumulator(mdb_ctx *ctx, std::optional<TimeRange> range = std::nullopt);
+
+// ---- query plans: what stands around GridExec in a plan, as far as the ModelSimpleAggregates rule looks ------------
+
+// DataSourceExec over the Parquet files of one field column (new_data_source_exec, query/time_series_table.rs:412-451)
+// with the batches handed over by the caller instead of read from files. `filter`: the ParquetSource's predicate
+// (pushdown_filters = true: applied row by row to the segments).
+class DataSourceExec : public ExecutionPlan {
+  public:
+    struct Source { // the "files" of one field column: shared by every plan that scans it
+        std::vector<RecordBatch> batches;
+    };
+    DataSourceExec(std::vector<Field> schema, std::shared_ptr<Source> source, ExprPtr filter, std::optional<size_t> limit)
+        : schema_(std::move(schema)), source_(std::move(source)), filter_(std::move(filter)), limit_(limit) {}
+    const char *name() const override { return "DataSourceExec"; }
+    std::vector<Field> schema() const override { return schema_; }
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {}; }
+    std::unique_ptr<SegmentStream> execute_segments(size_t partition) override;
+    ExprPtr filter() const { return filter_; } // parquet_source.filter()
+
+  private:
+    std::vector<Field> schema_;
+    std::shared_ptr<Source> source_;
+    ExprPtr filter_;
+    std::optional<size_t> limit_;
+};
+
+// RepartitionExec / CoalescePartitionsExec / CoalesceBatchesExec: one partition here, so they pass batches through;
+// they are in the plans because the rule has to look past them.
+class PassThroughExec : public ExecutionPlan {
+  public:
+    PassThroughExec(const char *name, std::shared_ptr<ExecutionPlan> input) : name_(name), input_(std::move(input)) {}
+    const char *name() const override { return name_; }
+    std::vector<Field> schema() const override { return input_->schema(); }
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {input_}; }
+    std::unique_ptr<SegmentStream> execute_segments(size_t partition) override { return input_->execute_segments(partition); }
+    std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t batch_size) override {
+        return input_->execute_stream(partition, batch_size);
+    }
+    std::shared_ptr<ExecutionPlan> with_new_children_dyn(std::vector<std::shared_ptr<ExecutionPlan>> children) const override {
+        if (children.size() != 1) throw Error(std::string(name_) + " needs exactly one child.");
+        return std::make_shared<PassThroughExec>(name_, children[0]);
+    }
+
+  private:
+    const char *name_;
+    std::shared_ptr<ExecutionPlan> input_;
+};
+
+// FilterExec: predicate over the input's schema, then an optional projection (indices into the input's schema).
+class FilterExec : public ExecutionPlan {
+  public:
+    FilterExec(ExprPtr predicate, std::shared_ptr<ExecutionPlan> input, std::optional<std::vector<size_t>> projection)
+        : predicate_(std::move(predicate)), input_(std::move(input)), projection_(std::move(projection)) {}
+    const char *name() const override { return "FilterExec"; }
+    std::vector<Field> schema() const override;
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {input_}; }
+    std::unique_ptr<SegmentStream> execute_segments(size_t) override { throw Error("FilterExec produces data points."); }
+    std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t batch_size) override;
+    std::shared_ptr<ExecutionPlan> with_new_children_dyn(std::vector<std::shared_ptr<ExecutionPlan>> children) const override {
+        if (children.size() != 1) throw Error("FilterExec needs exactly one child.");
+        return std::make_shared<FilterExec>(predicate_, children[0], projection_);
+    }
+    ExprPtr predicate() const { return predicate_; }
+    const std::optional<std::vector<size_t>> &projection() const { return projection_; }
+
+  private:
+    ExprPtr predicate_;
+    std::shared_ptr<ExecutionPlan> input_;
+    std::optional<std::vector<size_t>> projection_;
+};
+
+// One aggregate of an AggregateExec: name() is "count(field_1)" for DataFusion's own functions (the rule takes the
+// function from the text before the parenthesis, model_simple_aggregates.rs:311-331) and "model_count" etc. for the
+// model-based ones; `column` is the input column a DataFusion function reads (the model-based ones read the segment
+// columns); `create` makes its accumulator.
+struct AggregateFunctionExpr {
+    std::string name;
+    size_t column = 0;
+    std::function<std::unique_ptr<Accumulator>()> create;
+    std::optional<TimeRange> range; // model-based under a time range (what fmt shows)
+};
+AggregateFunctionExpr datafusion_aggregate(const std::string &function, const std::string &column_name, size_t column);
+AggregateFunctionExpr model_aggregate(mdb_ctx *ctx, const std::string &function, std::optional<TimeRange> range);
+
+enum class AggregateMode { Partial, Final };
+
+class AggregateExec : public ExecutionPlan {
+  public:
+    AggregateExec(AggregateMode mode, std::vector<AggregateFunctionExpr> aggr_expr, std::shared_ptr<ExecutionPlan> input,
+                  std::vector<Field> input_schema)
+        : mode_(mode), aggr_expr_(std::move(aggr_expr)), input_(std::move(input)), input_schema_(std::move(input_schema)) {}
+    const char *name() const override { return "AggregateExec"; }
+    std::vector<Field> schema() const override; // Partial: the state fields; Final: one column per aggregate
+    std::vector<std::shared_ptr<ExecutionPlan>> children() const override { return {input_}; }
+    std::unique_ptr<SegmentStream> execute_segments(size_t) override { throw Error("AggregateExec produces aggregates."); }
+    std::unique_ptr<SegmentStream> execute_stream(size_t partition, size_t batch_size) override;
+    std::shared_ptr<ExecutionPlan> with_new_children_dyn(std::vector<std::shared_ptr<ExecutionPlan>> children) const override {
+        if (children.size() != 1) throw Error("AggregateExec needs exactly one child.");
+        return std::make_shared<AggregateExec>(mode_, aggr_expr_, children[0], input_schema_);
+    }
+    AggregateMode mode() const { return mode_; }
+    const std::vector<AggregateFunctionExpr> &aggr_expr() const { return aggr_expr_; }
+    const std::vector<Field> &input_schema() const { return input_schema_; } // of the ORIGINAL input (:253-255)
+    // The results of a Final aggregate polled to its end: one ScalarValue per aggregate.
+    static std::vector<ScalarValue> collect(ExecutionPlan &final_aggregate, size_t batch_size);
+
+  private:
+    AggregateMode mode_;
+    std::vector<AggregateFunctionExpr> aggr_expr_;
+    std::shared_ptr<ExecutionPlan> input_;
+    std::vector<Field> input_schema_;
+};
+
+// TimeSeriesTable as a TableProvider, as far as scan() goes (query/time_series_table.rs:494-671): a timestamp
+// column, n field columns (f32) and tag columns; per field column the segments the Delta table holds for it.
+class TimeSeriesTable {
+  public:
+    TimeSeriesTable(mdb_ctx *ctx, size_t n_fields, std::vector<std::string> tag_names);
+    std::vector<Field> query_schema() const { return query_schema_; } // timestamp, field_1.., tags..
+    void push_segments(size_t field, RecordBatch batch);              // QUERY_COMPRESSED_SCHEMA + tags
+    // scan(state, projection, filters, limit): DataSourceExec -> GridExec per stored field column in the projection
+    // (the first field column if none), zipped by a SortedJoinExec; the filters rewritten and pushed both ways.
+    std::shared_ptr<ExecutionPlan> scan(const std::vector<size_t> &projection, const std::vector<ExprPtr> &filters,
+                                        std::optional<size_t> limit) const;
+
+  private:
+    mdb_ctx *ctx_;
+    std::vector<std::string> tag_names_;
+    std::vector<Field> query_schema_;
+    std::vector<std::shared_ptr<DataSourceExec::Source>> sources_;
+};
+
+// The physical plan DataFusion makes of SELECT agg(field), ... FROM table [WHERE filters] (the shapes the reference's
+// tests assert, model_simple_aggregates.rs:637-719): AggregateExec(Final) <- CoalescePartitionsExec <-
+// AggregateExec(Partial) <- [FilterExec <-] RepartitionExec <- scan(). `aggregates`: (function, field column index).
+std::shared_ptr<ExecutionPlan> plan_aggregate_query(const TimeSeriesTable &table,
+                                                    const std::vector<std::pair<std::string, size_t>> &aggregates,
+                                                    const std::vector<ExprPtr> &filters);
+
+// ModelSimpleAggregates (optimizer/model_simple_aggregates.rs:176-302) with the extension of SURVEY 8(f) N1, as
+// rust/patches/0002 makes it: besides AggregateExec <- [RepartitionExec] <- SortedJoinExec <- GridExec <-
+// DataSourceExec(no filter) it accepts a FilterExec between the aggregate and the join whose predicate IS a time range
+// (time_range_of_predicate: exact) over a DataSourceExec whose filter only reads start_time / end_time, and gives
+// the range to the model-based accumulators it puts in.
+struct ModelSimpleAggregates {
+    mdb_ctx *ctx;
+    std::shared_ptr<ExecutionPlan> optimize(std::shared_ptr<ExecutionPlan> execution_plan) const;
+    const char *name() const { return "model_simple_aggregates"; }
+    bool schema_check() const { return true; }
+};
+// The plan level by level, names separated by commas within a level (assert_eq_physical_plan_expected, :765-790).
+std::string plan_levels(const std::shared_ptr<ExecutionPlan> &plan);
 
 // ---- compression (compression.rs:42-275) -----------------------------------------------------------------------
 

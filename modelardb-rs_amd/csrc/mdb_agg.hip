@@ -780,4 +780,30 @@ int mdb_agg_batch_range(mdb_ctx *ctx, const mdb_segments *in, int64_t t_lo, int6
     return rc;
 }
 
+int mdb_agg_batch_range_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t n_inputs, int64_t t_lo,
+                             int64_t t_hi, uint32_t which_mask, mdb_agg_state *inout) {
+    if (!ctx || !inputs || !inout) return fail("ctx, inputs and inout must not be NULL.");
+    if (n_inputs == 0) return 0;
+    for (uint32_t k = 0; k < n_inputs; k++)
+        if (!inputs[k]) return fail("A batch of the list is NULL.");
+    // (the list form of mdb_agg_batch_range: cursors into the long MacaqueV streams that reach into the range)
+    MvCallIndex index;
+    const MvHostRange host_range{t_lo, t_hi};
+    HostWalk walk;
+    if ((which_mask & ~(uint32_t)MDB_AGG_COUNT) != 0 && mv_host_index_worthwhile(inputs, n_inputs))
+        walk.start([&index, inputs, n_inputs, &host_range] {
+            mv_host_index(inputs, n_inputs, &index.piece_base, &index.cursors, &host_range);
+        });
+    mdb::CallGuard lock(ctx);
+    MDB_HIP_CHECK(hipSetDevice(ctx->device));
+    mdb_segments_owned *dev = nullptr;
+    if (upload_segment_list_locked(ctx, inputs, n_inputs, true, &dev)) return 1;
+    walk.finish();
+    int rc = mv_call_index_use(ctx, dev->seg, index);
+    if (!rc) rc = agg_run(ctx, &dev->seg, true, t_lo, t_hi, which_mask, inout);
+    mv_call_index_done();
+    mdb_segments_free(dev);
+    return rc;
+}
+
 } // extern "C"

@@ -52,6 +52,7 @@ def lib():
         _lib.mdbh_accumulator_free.restype = None
         _lib.mdbh_batches_free.restype = None
         _lib.mdbh_udm_free.restype = None
+        _lib.mdbh_query_free.restype = None
     return _lib
 
 
@@ -96,9 +97,17 @@ class GridStream:
     READY_SOME, READY_NONE, PENDING = 0, 1, 2
 
     def __init__(self, context, tag_names=(), limit=None, predicate=(None, None), batch_size=8192):
+        """predicate: (lower, upper) bounds on the timestamp, either may be None - or the expression GridExec is
+        handed (`maybe_predicate`, grid_exec.rs:60) as text, e.g. "(and (>= timestamp ts:100) (< timestamp ts:900))"
+        (mdbhost::parse_expr): the stream works the time range out of it and pushes it into the library."""
         self._context = context
         self.handle = C.c_void_p()
         names, self._keep = _strings(tag_names)
+        if isinstance(predicate, str):
+            _check(lib().mdbh_grid_exec_create_expr(
+                context.handle, names, C.c_int32(len(tag_names)), C.c_int64(-1 if limit is None else limit),
+                predicate.encode(), C.c_uint64(batch_size), C.byref(self.handle)))
+            return
         lower, upper = predicate
         _check(lib().mdbh_grid_exec_create(
             context.handle, names, C.c_int32(len(tag_names)), C.c_int64(-1 if limit is None else limit),
@@ -161,17 +170,18 @@ class GridStream:
             pass
 
 
-def measure_grid_stream(context, segments, batch_size, segments_per_batch=8192, tags=None):
+def measure_grid_stream(context, segments, batch_size, segments_per_batch=8192, tags=None, predicate=(None, None)):
     """The host operator end to end, for bench.py's host_path: `segments` (a SegmentBatch in host
     memory) handed to a GridStream `segments_per_batch` rows at a time - what the Parquet scan below a
     GridExec delivers - and the stream polled to its end in slices of `batch_size` data points. Every
     byte crosses PCIe: the segment columns up, 12 bytes per data point down into page-locked memory.
+    `predicate`: what GridExec is handed for a query with a range on the timestamp (see GridStream).
     Returns (data points, seconds, bytes copied down)."""
     import time
     arrow = segments.to_arrow()
     if tags:  # (tag columns: their value is repeated for every data point of a segment, grid_exec.rs:341-346)
         arrow = segments_with_tags(arrow, tags)
-    stream = GridStream(context, tag_names=tuple(tags or ()), batch_size=batch_size)
+    stream = GridStream(context, tag_names=tuple(tags or ()), batch_size=batch_size, predicate=predicate)
     for first in range(0, arrow.num_rows, segments_per_batch):
         stream.push(arrow.slice(first, min(segments_per_batch, arrow.num_rows - first)))
     stream.finish_input()
@@ -270,19 +280,23 @@ class SortedJoinStream:
 class _ModelAccumulator:
     KIND = None
 
-    def __init__(self, context):
+    def __init__(self, context, time_range=None):
+        """time_range: (t_lo, t_hi) for the accumulators of a query with a range on the timestamp (what the patched
+        ModelSimpleAggregates rule hands them, rust/patches/0002): only the data points inside it count."""
         self.handle = C.c_void_p()
-        _check(lib().mdbh_accumulator_create(context.handle, C.c_int32(self.KIND), C.byref(self.handle)))
+        lo, hi = time_range if time_range is not None else (0, 0)
+        _check(lib().mdbh_accumulator_create_range(context.handle, C.c_int32(self.KIND), C.c_int32(time_range is not None),
+                                                   C.c_int64(lo), C.c_int64(hi), C.byref(self.handle)))
 
     def update_batch(self, batch):
         array, schema = _export(batch)
         _check(lib().mdbh_accumulator_update_batch(self.handle, C.byref(array), C.byref(schema)))
 
     def state(self):
-        kinds, f64, i64 = (C.c_int32 * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
+        kinds, f64, i64, nulls = (C.c_int32 * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)(), (C.c_int32 * 2)()
         n = C.c_int32()
-        _check(lib().mdbh_accumulator_state(self.handle, kinds, f64, i64, C.byref(n)))
-        return [i64[k] if kinds[k] in (0, 1) else f64[k] for k in range(n.value)]
+        _check(lib().mdbh_accumulator_state(self.handle, kinds, f64, i64, C.byref(n), nulls))
+        return [None if nulls[k] else (i64[k] if kinds[k] in (0, 1) else f64[k]) for k in range(n.value)]
 
     def size(self):
         return lib().mdbh_accumulator_size(self.handle)
@@ -301,16 +315,16 @@ class _ModelAccumulator:
             pass
 
 
-def measure_accumulator(context, segments, accumulator_class, segments_per_batch=8192):
+def measure_accumulator(context, segments, accumulator_class, segments_per_batch=8192, time_range=None):
     """One of the five accumulators fed `segments` (a SegmentBatch in host memory) `segments_per_batch` rows at a
     time - the batches DataFusion hands update_batch; the accumulator keeps them until 262 144 segments are pending or
-    its state is read and folds them with ONE mdb_agg_batch_list, as rust/patches/0002 makes it - for bench.py.
-    Returns (state, seconds)."""
+    its state is read and folds them with ONE mdb_agg_batch_list (mdb_agg_batch_range_list under `time_range`), as
+    rust/patches/0002 makes it - for bench.py. Returns (state, seconds)."""
     import time
     arrow = segments.to_arrow()
     batches = [arrow.slice(first, min(segments_per_batch, arrow.num_rows - first))
                for first in range(0, arrow.num_rows, segments_per_batch)]
-    accumulator = accumulator_class(context)
+    accumulator = accumulator_class(context, time_range)
     started = time.perf_counter()
     for batch in batches:
         accumulator.update_batch(batch)
@@ -337,6 +351,76 @@ class ModelSumAccumulator(_ModelAccumulator):
 
 class ModelAvgAccumulator(_ModelAccumulator):
     KIND = 4
+
+
+def rewrite_filters(filters, n_fields=2):
+    """rewrite_and_combine_filters (query/time_series_table.rs:269-288) over the query schema (timestamp, field_1..,
+    tag): the filters as text (see GridStream) -> (parquet filter, grid filter) as text, None where the reference
+    returns None."""
+    parquet, grid = C.create_string_buffer(2048), C.create_string_buffer(2048)
+    _check(lib().mdbh_rewrite_filters(C.c_int32(n_fields), ";".join(filters).encode(), parquet, grid, C.c_uint64(2048)))
+    return parquet.value.decode() or None, grid.value.decode() or None
+
+
+def time_range_of_predicate(predicate):
+    """What the patched GridStream::new and the patched rule take from a predicate over `timestamp`: None, or
+    (t_lo, t_hi, exact) - exact: the predicate IS that range."""
+    found, exact, lo, hi = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+    _check(lib().mdbh_time_range_of_predicate(predicate.encode(), C.byref(found), C.byref(exact), C.byref(lo), C.byref(hi)))
+    return (lo.value, hi.value, bool(exact.value)) if found.value else None
+
+
+class AggregateQuery:
+    """SELECT agg(field), ... FROM table [WHERE ...] over a TimeSeriesTable fed by hand: the physical plan DataFusion
+    and TimeSeriesTable::scan make of it (query/time_series_table.rs:494-671), optionally rewritten by the
+    ModelSimpleAggregates rule (optimizer/model_simple_aggregates.rs:176-302 as rust/patches/0002 extends it), and run.
+    aggregates: [("sum", 0), ...] (function, field column); filters: expressions as text (see GridStream)."""
+
+    def __init__(self, context, n_fields=1, tag_names=()):
+        self._context = context
+        self.handle = C.c_void_p()
+        names, self._keep = _strings(tag_names)
+        _check(lib().mdbh_query_table_create(context.handle if context is not None else None, C.c_int32(n_fields),
+                                             names, C.c_int32(len(tag_names)), C.byref(self.handle)))
+
+    def push_segments(self, field, batch):
+        array, schema = _export(batch)
+        _check(lib().mdbh_query_table_push(self.handle, C.c_int32(field), C.byref(array), C.byref(schema)))
+
+    def plan(self, aggregates, filters=(), optimize=True):
+        text = ",".join(f"{function}:{field}" for function, field in aggregates)
+        context = self._context.handle if self._context is not None else None
+        _check(lib().mdbh_query_plan(self.handle, context, text.encode(), ";".join(filters).encode(),
+                                     C.c_int32(bool(optimize))))
+        return self
+
+    def describe(self):
+        out = C.create_string_buffer(4096)
+        _check(lib().mdbh_query_describe(self.handle, out, C.c_uint64(4096)))
+        return out.value.decode()
+
+    def levels(self):
+        """The plan level by level, like assert_eq_physical_plan_expected (model_simple_aggregates.rs:765-790)."""
+        return [line.split(",") for line in self.describe().splitlines() if not line.startswith("aggregate ")]
+
+    def aggregates(self):
+        return [line.split(" ", 1)[1] for line in self.describe().splitlines() if line.startswith("aggregate ")]
+
+    def execute(self, batch_size=8192):
+        values, nulls, n = (C.c_double * 16)(), (C.c_int32 * 16)(), C.c_int32()
+        _check(lib().mdbh_query_execute(self.handle, C.c_uint64(batch_size), values, nulls, C.byref(n)))
+        return [None if nulls[k] else values[k] for k in range(n.value)]
+
+    def close(self):
+        if self.handle:
+            lib().mdbh_query_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def try_compress_univariate_time_series(context, uncompressed_timestamps, uncompressed_values,

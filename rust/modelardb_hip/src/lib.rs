@@ -325,6 +325,23 @@ impl Context {
         check(unsafe { sys::mdb_agg_batch_range(self.raw(), &segments.raw, t_lo, t_hi, which_mask, state) })
     }
 
+    /// [`Context::aggregate_list`] restricted to `t_lo <= timestamp <= t_hi`: what the accumulators of a query
+    /// with a range on the timestamp fold their pending batches with
+    /// (patches/0002-model_simple_aggregates.patch: `PendingSegments::fold_into`).
+    pub fn aggregate_range_list(
+        &self,
+        segments: &[SegmentsView],
+        t_lo: i64,
+        t_hi: i64,
+        which_mask: u32,
+        state: &mut AggState,
+    ) -> Result<()> {
+        let inputs: Vec<*const sys::mdb_segments> = segments.iter().map(|view| &view.raw as *const _).collect();
+        check(unsafe {
+            sys::mdb_agg_batch_range_list(self.raw(), inputs.as_ptr(), inputs.len() as u32, t_lo, t_hi, which_mask, state)
+        })
+    }
+
     /// Replaces the body of `try_compress_univariate_time_series` after its two argument checks
     /// (compression.rs:202-211): fits PMC-Mean / Swing / MacaqueV on the GPU and builds the batch
     /// `CompressedSegmentBatchBuilder::finish` builds (types.rs:492-516).

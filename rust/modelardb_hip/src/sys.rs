@@ -235,6 +235,8 @@ unsafe extern "C" {
                                which_mask: u32, inout: *mut mdb_agg_state) -> c_int;
     pub fn mdb_agg_batch_range_dev(ctx: *mut mdb_ctx, input: *const mdb_segments, t_lo: i64, t_hi: i64,
                                    which_mask: u32, inout: *mut mdb_agg_state) -> c_int;
+    pub fn mdb_agg_batch_range_list(ctx: *mut mdb_ctx, inputs: *const *const mdb_segments, n_inputs: u32,
+                                    t_lo: i64, t_hi: i64, which_mask: u32, inout: *mut mdb_agg_state) -> c_int;
 
     // ---- fit (replaces try_compress_univariate_time_series, compression.rs:191-275) -----------------
     pub fn mdb_compress_series(ctx: *mut mdb_ctx, ts: *const i64, values: *const f32, n: u64,

@@ -448,6 +448,7 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
         uint64_t segments = 0;
         for (uint32_t k = 0; k < n_ins; k++) segments += ins[k]->n;
         log_call("grid", n_ins, segments, reserve_front);
+        if (ranged) log_call("grid_range", static_cast<uint64_t>(t_lo), static_cast<uint64_t>(t_hi));
     }
     // (one batch holding the rows of all inputs: the views keep pointing into their own batch's buffers)
     JoinedSegments joined(ins, n_ins);
@@ -570,6 +571,43 @@ int mdb_agg_batch_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t
     log_call("agg_list", n_inputs, which_mask);
     for (uint32_t k = 0; k < n_inputs; k++)
         if (mdb_agg_batch(ctx, inputs[k], which_mask, inout)) return 1;
+    return 0;
+}
+
+// (under a time range, again per batch: COUNT / MIN / MAX / SUM of the data points inside [t_lo, t_hi])
+int mdb_agg_batch_range_list(mdb_ctx *ctx, const mdb_segments *const *inputs, uint32_t n_inputs, int64_t t_lo, int64_t t_hi,
+                             uint32_t which_mask, mdb_agg_state *inout) {
+    if (!valid(ctx) || !inputs || !inout) return fail("mdb_agg_batch_range_list: NULL argument or closed context");
+    log_call("agg_range_list", n_inputs, which_mask);
+    log_call("agg_range", static_cast<uint64_t>(t_lo), static_cast<uint64_t>(t_hi));
+    for (uint32_t k = 0; k < n_inputs; k++) {
+        const mdb_segments *in = inputs[k];
+        if (!in) return fail("mdb_agg_batch_range_list: a batch of the list is NULL");
+        Hasher h;
+        if (!hash_segments(*in, h)) return fail("mdb_agg_batch_range_list: a view points outside its data buffers");
+        h.value(which_mask);
+        h.value<uint32_t>(0x72616e67); // "rang"
+        h.value(t_lo);
+        h.value(t_hi);
+#ifdef MDB_STUB_RECORD
+        {
+            mdb_agg_state fresh = {0.0, 0, FLT_MAX, -FLT_MAX};
+            if (ora_agg_batch_range(in, t_lo, t_hi, which_mask, &fresh)) return fail(ora_last_error());
+            Writer w;
+            w.value(fresh);
+            add_record(KIND_AGG, h.state, w.out);
+        }
+#endif
+        const std::vector<uint8_t> *payload = find_record(KIND_AGG, h.state);
+        if (!payload) return no_record("mdb_agg_batch_range_list", h.state);
+        Reader reader(*payload);
+        const mdb_agg_state batch = reader.value<mdb_agg_state>();
+        if (!reader.ok) return fail("mdb_stub: damaged aggregate record");
+        inout->sum += batch.sum;
+        inout->count += batch.count;
+        inout->min = std::fmin(inout->min, batch.min);
+        inout->max = std::fmax(inout->max, batch.max);
+    }
     return 0;
 }
 

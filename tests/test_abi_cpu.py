@@ -124,6 +124,49 @@ def test_rust_patches_apply_to_the_reference():
         assert "FAILED" not in done.stdout and "fuzz" not in done.stdout, done.stdout
 
 
+def test_patched_crates_depend_on_the_binding_they_use(tmp_path):
+    """The four patches applied IN SEQUENCE to a copy of the crates they touch (no toolchain can compile the result
+    here, so what can be checked is checked): every patch applies on top of the ones before it without fuzz, every crate
+    whose patched sources name `modelardb_hip::` lists the crate in its Cargo.toml, and every function of the binding
+    the patched sources call exists in rust/modelardb_hip/src/lib.rs."""
+    import glob
+    import shutil
+    import subprocess
+    reference = "/root/reference"
+    if not os.path.isdir(os.path.join(reference, "crates")):
+        pytest.skip("the reference tree is not present")
+    crates = ("modelardb_storage", "modelardb_compression", "modelardb_server")
+    for crate in crates:
+        shutil.copytree(os.path.join(reference, "crates", crate), tmp_path / "crates" / crate,
+                        ignore=shutil.ignore_patterns("target"))
+    for patch in sorted(glob.glob(os.path.join(REPO_ROOT, "rust", "patches", "*.patch"))):
+        with open(patch) as f:
+            done = subprocess.run(["patch", "-p1", "--force", "-d", str(tmp_path)], stdin=f, capture_output=True, text=True)
+        assert done.returncode == 0, done.stdout + done.stderr
+        assert "FAILED" not in done.stdout and "fuzz" not in done.stdout, done.stdout
+    binding = open(os.path.join(REPO_ROOT, "rust", "modelardb_hip", "src", "lib.rs")).read()
+    users = 0
+    for crate in crates:
+        sources = []
+        for directory, _, files in os.walk(tmp_path / "crates" / crate / "src"):
+            sources += [open(os.path.join(directory, name)).read() for name in files if name.endswith(".rs")]
+        uses = [source for source in sources if "modelardb_hip::" in source]
+        if not uses:
+            continue
+        users += 1
+        manifest = open(tmp_path / "crates" / crate / "Cargo.toml").read()
+        assert re.search(r'^modelardb_hip = \{ path = "\.\./modelardb_hip" \}$', manifest, re.M), \
+            f"{crate} uses modelardb_hip:: but its Cargo.toml does not depend on it"
+        for source in uses:   # free functions and associated items of the crate the sources name
+            for item in set(re.findall(r"modelardb_hip::([a-z_]+)\(", source)):
+                assert re.search(rf"pub fn {item}\(", binding), f"{crate} calls modelardb_hip::{item}, which the binding lacks"
+            for method in ("grid_submit", "aggregate_list", "aggregate_range_list", "compress_chunks", "split_and_compress",
+                           "compress_univariate"):
+                if f".{method}(" in source:
+                    assert re.search(rf"pub fn {method}\(", binding), f"{crate} calls .{method}(), which the binding lacks"
+    assert users == 3
+
+
 def test_version_string():
     assert b"gfx950" in mdb.load_hip_library().mdb_version()
 

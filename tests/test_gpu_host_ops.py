@@ -461,3 +461,157 @@ def test_sorted_join_of_three_field_columns(hip, predicate, monkeypatch):
     for column, (_, values, _, _) in zip(("field_0", "field_1", "field_2"), expected):
         assert np.array_equal(table.column(column).to_numpy().view(np.uint32), values[keep][:n].view(np.uint32))
     assert set(table.column("tag").to_pylist()) == {"wind-turbine-1234567"}
+
+
+# ---- SURVEY 8(f) N1 through the operators: a range on the timestamp pushed into the library by GridStream
+# (rust/patches/0001: time_range_of_predicate) and by the accumulators the extended ModelSimpleAggregates rule puts in
+# (rust/patches/0002), against grid + filter + aggregate - the plan the reference runs for such a query.
+
+def _stub_calls():
+    log = os.environ.get("MDB_STUB_CALL_LOG")
+    if not log or not os.path.exists(log):
+        return None
+    signed = lambda text: int(text) - (1 << 64) if int(text) >= (1 << 63) else int(text)
+    return [(what, signed(a), signed(b)) for what, a, b, _ in (line.split() for line in open(log))]
+
+
+def _clear_stub_calls():
+    log = os.environ.get("MDB_STUB_CALL_LOG")
+    if log and os.path.exists(log):
+        os.remove(log)
+
+
+@pytest.mark.parametrize("shape", ["inclusive", "strict", "literal-left", "one-sided", "equal", "nothing"])
+def test_grid_stream_pushes_the_range_of_its_predicate_into_the_library(hip, shape):
+    timestamps, _, batch = _series(68, irregular=True)
+    lower, upper = int(timestamps[_n(1230)]), int(timestamps[_n(20_000)])
+    predicate, keep_lower, keep_upper = {
+        "inclusive": (f"(and (>= timestamp ts:{lower}) (<= timestamp ts:{upper}))", lower, upper),
+        "strict": (f"(and (> timestamp ts:{lower}) (< timestamp ts:{upper}))", lower + 1, upper - 1),
+        "literal-left": (f"(and (<= ts:{lower} timestamp) (> ts:{upper} timestamp))", lower, upper - 1),
+        "one-sided": (f"(> timestamp ts:{upper})", upper + 1, (1 << 63) - 1),
+        "equal": (f"(= timestamp ts:{lower})", lower, lower),
+        "nothing": (f"(and (>= timestamp ts:{upper}) (< timestamp ts:{lower}))", (1 << 63) - 1, -(1 << 63)),
+    }[shape]
+    assert host.time_range_of_predicate(predicate) == (keep_lower, keep_upper, True)
+    _clear_stub_calls()
+    stream = host.GridStream(hip, tag_names=("tag",), predicate=predicate, batch_size=4096)
+    for part in _segment_batches(batch, {"tag": "x"}, 100):
+        stream.push(part)
+    stream.finish_input()
+    batches, state = stream.collect()
+    assert state == host.GridStream.READY_NONE
+    all_ts, all_values, _, _ = ora.grid_batch(batch)
+    keep = (all_ts >= keep_lower) & (all_ts <= keep_upper)
+    if shape == "nothing":
+        assert not keep.any() and sum(b.num_rows for b in batches) == 0
+    else:
+        ts, values, _ = _concat(batches)
+        assert np.array_equal(ts, all_ts[keep])
+        assert np.array_equal(values.view(np.uint32), all_values[keep].view(np.uint32))
+    # only the points inside the range were reconstructed at all (grid_exec.rs:366-387 reconstructs every point)
+    assert stream.metrics()["rows_created"] == int(keep.sum())
+    calls = _stub_calls()
+    if calls is not None:   # (under tests/stub: what the kernels' side saw)
+        assert [(lo, hi) for what, lo, hi in calls if what == "grid_range"] \
+            == [(keep_lower, keep_upper)] * len([1 for what, _, _ in calls if what == "grid"])
+
+
+def test_grid_stream_filters_behind_the_library_what_the_range_does_not_decide(hip):
+    timestamps, _, batch = _series(69, irregular=True)
+    lower, a, b = int(timestamps[_n(1000)]), int(timestamps[_n(9_000)]), int(timestamps[_n(15_000)])
+    # a range and a hole in it: the range is pushed down, the OR is evaluated on what comes back
+    predicate = f"(and (>= timestamp ts:{lower}) (or (< timestamp ts:{a}) (> timestamp ts:{b})))"
+    assert host.time_range_of_predicate(predicate) == (lower, (1 << 63) - 1, False)
+    for text in (predicate, f"(or (< timestamp ts:{a}) (> timestamp ts:{b}))"):   # (the second: nothing to push)
+        stream = host.GridStream(hip, tag_names=("tag",), predicate=text, batch_size=1000)
+        for part in _segment_batches(batch, {"tag": "a-tag-value-longer-than-12-bytes"}, 64):
+            stream.push(part)
+        stream.finish_input()
+        batches, _ = stream.collect()
+        ts, values, table = _concat(batches)
+        all_ts, all_values, _, _ = ora.grid_batch(batch)
+        keep = (all_ts < a) | (all_ts > b)
+        if text is predicate:
+            keep &= all_ts >= lower
+        assert np.array_equal(ts, all_ts[keep])
+        assert np.array_equal(values.view(np.uint32), all_values[keep].view(np.uint32))
+        assert set(table.column("tag").to_pylist()) == {"a-tag-value-longer-than-12-bytes"}
+
+
+def test_accumulators_under_a_time_range(hip):
+    timestamps, _, batch = _series(70, irregular=True)
+    lower, upper = int(timestamps[_n(4_321)]), int(timestamps[_n(22_222)])
+    parts = _segment_batches(batch, {}, 97)
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    expected = ora.agg_batch_range(batch, lower, upper, mask)
+    _clear_stub_calls()
+    accumulators = {name: cls(hip, (lower, upper)) for name, cls in (
+        ("count", host.ModelCountAccumulator), ("min", host.ModelMinAccumulator),
+        ("max", host.ModelMaxAccumulator), ("sum", host.ModelSumAccumulator),
+        ("avg", host.ModelAvgAccumulator))}
+    for part in parts:
+        for accumulator in accumulators.values():
+            accumulator.update_batch(part)
+    assert accumulators["count"].state() == [expected.count]
+    assert accumulators["min"].state() == [expected.min]
+    assert accumulators["max"].state() == [expected.max]
+    total = accumulators["sum"].state()[0]
+    assert abs(total - expected.sum) <= 1e-5 * abs(expected.sum)   # integration_test.rs:1155-1171
+    count, avg_sum = accumulators["avg"].state()
+    assert count == expected.count and abs(avg_sum - expected.sum) <= 1e-5 * abs(expected.sum)
+    calls = _stub_calls()
+    if calls is not None:   # ONE ranged call per accumulator for all its batches (PendingSegments::fold_into)
+        assert [n for what, n, _ in calls if what == "agg_range_list"] == [len(parts)] * 5
+        assert {(lo, hi) for what, lo, hi in calls if what == "agg_range"} == {(lower, upper)}
+        assert not [1 for what, _, _ in calls if what == "agg_list"]
+    # a range without a data point: COUNT 0, the others NULL (DataFusion's MIN / MAX / SUM over no rows)
+    empty = (int(timestamps[-1]) + 1, int(timestamps[-1]) + 1000)
+    for name, cls in (("count", host.ModelCountAccumulator), ("min", host.ModelMinAccumulator),
+                      ("max", host.ModelMaxAccumulator), ("sum", host.ModelSumAccumulator)):
+        accumulator = cls(hip, empty)
+        accumulator.update_batch(parts[-1])
+        assert accumulator.state() == ([0] if name == "count" else [None])
+    accumulator = host.ModelAvgAccumulator(hip, empty)
+    accumulator.update_batch(parts[-1])
+    assert accumulator.state() == [0, 0.0]   # (DataFusion's AVG is NULL for a count of zero whatever the sum)
+
+
+@pytest.mark.parametrize("irregular", [False, True], ids=["regular", "irregular"])
+def test_aggregate_query_under_a_time_range_through_the_rule(hip, irregular):
+    """SELECT COUNT, MIN, MAX, SUM (and AVG) of a field WHERE lower <= timestamp < upper: the plan the reference runs
+    (DataSourceExec -> GridExec -> SortedJoinExec -> FilterExec -> AggregateExec) and the plan the extended rule makes
+    of it (DataSourceExec -> AggregateExec over the segments) give the same answer, which is the oracle's."""
+    query = host.AggregateQuery(hip, n_fields=1, tag_names=("tag",))
+    batches = []
+    for seed, tag in ((71, "A"), (72, "B")):
+        timestamps, _, batch = _series(seed, irregular=irregular)
+        batches.append(batch)
+        for part in _segment_batches(batch, {"tag": tag}, 113):
+            query.push_segments(0, part)
+    lower, upper = int(timestamps[_n(3_000)]), int(timestamps[_n(17_000)])
+    filters = [f"(>= timestamp ts:{lower})", f"(< timestamp ts:{upper})"]
+    mask = mdb.MDB_AGG_COUNT | mdb.MDB_AGG_MIN | mdb.MDB_AGG_MAX | mdb.MDB_AGG_SUM
+    expected = ora.agg_batch_range(batches[1], lower, upper - 1, mask, ora.agg_batch_range(batches[0], lower, upper - 1, mask))
+    aggregates = [("count", 0), ("min", 0), ("max", 0), ("sum", 0)]
+    results = {}
+    for optimize in (False, True):
+        query.plan(aggregates, filters, optimize=optimize)
+        assert (query.levels()[3] == ["DataSourceExec"]) == optimize
+        results[optimize] = query.execute(batch_size=_n(8192))
+    for count, minimum, maximum, total in results.values():
+        assert count == expected.count and minimum == expected.min and maximum == expected.max
+        assert abs(total - expected.sum) <= 1e-5 * abs(expected.sum)
+    query.plan([("avg", 0)], filters, optimize=True)
+    assert query.aggregates() == [f"model_avg[{lower},{upper - 1}]"]
+    (average,) = query.execute()
+    assert abs(average - expected.sum / expected.count) <= 1e-5 * abs(expected.sum / expected.count)
+    # nothing in the range: COUNT 0 and NULLs from both plans
+    beyond = [f"(> timestamp ts:{int(timestamps[-1]) + 10})"]
+    for optimize in (False, True):
+        assert query.plan(aggregates, beyond, optimize=optimize).execute() == [0.0, None, None, None]
+    # without a predicate the rule's original case: the segments' own metadata (model_simple_aggregates.rs:336-618)
+    whole = ora.agg_batch(batches[1], mask, ora.agg_batch(batches[0], mask))
+    count, minimum, maximum, total = query.plan(aggregates, (), optimize=True).execute()
+    assert count == whole.count and minimum == whole.min and maximum == whole.max
+    assert abs(total - whole.sum) <= 1e-5 * abs(whole.sum)
