@@ -309,7 +309,47 @@ def host_path(context, mdb, np, sample, args):
     out["sum_accumulator_batch_8192"] = {"segments_per_s": len(sample) / seconds, "values_per_s": points / seconds,
                                          "seconds": seconds, "update_batch_calls": (len(sample) + 8191) // 8192,
                                          "library_calls": (len(sample) + 262143) // 262144, "sum": state[0]}
+    # The middle half of the time axis (BASELINE configs 3 and 5) through the same operators.
+    out["range_middle_half"] = host_range_rows(
+        context, mdb, host, sample, (args.points // 4) * INTERVAL_US, (3 * args.points // 4) * INTERVAL_US,
+        {"grid_seconds": out["batch_8192"]["seconds"], "grid_points": out["batch_8192"]["points"], "sum_seconds": seconds})
     return out
+
+
+def host_range_rows(context, mdb, host, sample, t_lo, t_hi, whole):
+    """BASELINE configs 3 and 5 through the operators: a query with `t_lo <= timestamp <= t_hi`. GridStream is handed
+    the predicate TimeSeriesTable::scan makes of it, takes the range out (rust/patches/0001: time_range_of_predicate)
+    and every mdb_grid_submit carries it; the SUM accumulator is the one the extended ModelSimpleAggregates rule
+    creates for such a query (rust/patches/0002) and folds its batches with ONE mdb_agg_batch_range_list. `whole`:
+    the same measurements without a range ({"grid_seconds", "grid_points", "sum_seconds"})."""
+    import numpy as np
+    predicate = f"(and (>= timestamp ts:{t_lo}) (<= timestamp ts:{t_hi}))"
+    assert host.time_range_of_predicate(predicate) == (t_lo, t_hi, True)
+    # What reaches the operators: TimeSeriesTable::scan also hands the range to the Parquet scan as a filter on the
+    # segments (start_time <= t_hi AND end_time >= t_lo, query/time_series_table.rs:290-331, pushdown_filters = true), so
+    # only segments with a point in the range are read at all. The filter is the scan's work, not the operators'.
+    all_segments = len(sample)
+    sample = sample.take(np.nonzero((sample.start_time <= t_hi) & (sample.end_time >= t_lo))[0])
+    host.measure_grid_stream(context, sample, 8192, predicate=predicate)
+    points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192, predicate=predicate)
+    host.measure_accumulator(context, sample, host.ModelSumAccumulator, time_range=(t_lo, t_hi))
+    state, sum_seconds = host.measure_accumulator(context, sample, host.ModelSumAccumulator, time_range=(t_lo, t_hi))
+    count_state, _ = host.measure_accumulator(context, sample, host.ModelCountAccumulator, time_range=(t_lo, t_hi))
+    if count_state[0] != points:
+        raise SystemExit(f"VERIFICATION FAILED: host path under a time range: GridStream returned {points} data points, "
+                         f"the COUNT accumulator counted {count_state[0]}")
+    one_call = context.agg_batch_range(sample, t_lo, t_hi, mdb.MDB_AGG_SUM | mdb.MDB_AGG_COUNT)
+    if one_call.count != points or abs(state[0] - one_call.sum) > 1e-9 * abs(one_call.sum):
+        raise SystemExit(f"VERIFICATION FAILED: host path under a time range: SUM through the accumulator {state[0]!r}, "
+                         f"through one call {one_call.sum!r}")
+    return {"t_lo": t_lo, "t_hi": t_hi, "predicate": predicate, "segments_of_the_table": all_segments,
+            "segments_the_parquet_filter_lets_through": len(sample),
+            "grid": {"points": points, "fraction_of_points": points / max(whole["grid_points"], 1), "seconds": seconds,
+                     "values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
+                     "seconds_over_unranged": seconds / whole["grid_seconds"]},
+            "sum_accumulator": {"seconds": sum_seconds, "sum": state[0], "points": points,
+                                "segments_per_s": len(sample) / sum_seconds,
+                                "ms_over_unranged": (sum_seconds - whole["sum_seconds"]) * 1e3}}
 
 
 def host_fit(context, mdb, np, ora, host_ts, values, offsets, eb, gpu_fitted):
@@ -575,6 +615,9 @@ def mixed_models(context, mdb, np, ora, args):
                                  f"of the resident segments {resident_sum!r}")
             shape["host_path"]["sum_accumulator"] = {"values_per_s": total / sum_seconds, "segments_per_s": len(downloaded) / sum_seconds,
                                                      "seconds": sum_seconds, "sum": state[0]}
+            shape["host_path"]["range_middle_half"] = host_range_rows(
+                context, mdb, host, downloaded, t_lo, t_hi,
+                {"grid_seconds": host_seconds, "grid_points": host_points, "sum_seconds": sum_seconds})
         del downloaded
         out[label] = shape
         for pointer in (out_ts, out_val):

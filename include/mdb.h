@@ -149,11 +149,13 @@ void mdb_grid_result_free(mdb_grid_result *result);
  * the defaults are what a deployment runs). The process's environment is read ONCE, by the first call that asks for a
  * switch: no getenv() inside a call. mdb_set_option sets one switch for the whole process without touching the
  * environment (value NULL: back to "not set"); mdb_reload_options reads the environment again (what a test that has
- * changed it calls - not while other calls are running). No counterpart in the reference (its settings are
+ * changed it calls). No counterpart in the reference (its settings are
  * crates/modelardb_server/src/configuration.rs, none of which reaches this path). */
 int mdb_set_option(const char *name, const char *value);
 int mdb_reload_options(void);
-/* What a switch is set to (NULL: not set). The text stays valid until the switch is set again or the table reloaded. */
+/* What a switch is set to (NULL: not set). The text stays valid for the life of the process (setting the switch again
+ * or reloading the table makes later look-ups return another text and leaves this one as it is), so mdb_set_option and
+ * mdb_reload_options may be called while other threads are inside calls: a call sees a switch as it was when it asked. */
 const char *mdb_option(const char *name);
 
 /* Pipelined form, for an operator that is polled (GridStream::poll_next, grid_exec.rs:402-429): submit

@@ -25,6 +25,7 @@
 // Algorithmic bytes: 4 B/point read (12 B/point when timestamps are materialised) + segments written.
 #include <type_traits>
 
+#include "mdb_floor_log2.hpp"
 #include "mdb_scan.hpp"
 #include "mdb_segment_dev.hpp"
 
@@ -572,21 +573,12 @@ __device__ __forceinline__ float rewrite_least_mantissa_bits(mdb_error_bound eb,
     int exponent = (int)((bits >> 23) & 0xffu) - 127;
     float factorized_epsilon = ldexpf(abs_error_bound, -exponent);
     // (float)log2((double)x): correctly rounded log2f, the same definition the oracle uses - and a hundred instructions
-    // per value of a noisy stream. All that is kept of it is floor(|.|), which for x = 2^E m, 1 <= m < 2, is E or -E - 1
-    // unless the logarithm lies so close to a whole number that its rounding to f32 reaches it: farther than 256 of m's
-    // steps of 2^-23 from 1 and from 2 the logarithm is more than 2 x 10^-5 from E and E + 1, a float of its size (below
-    // 150) less than 8 x 10^-6 from it. The values in between (one in 16 000), zeros, subnormals, infinities, NaNs and
-    // negative ones take the function itself.
+    // per value of a noisy stream. All that is kept of it is floor(|.|), which mdb_floor_log2.hpp reads off the float's
+    // exponent wherever that is certain (all but one value in 16 000; every such value checked on the CPU:
+    // tests/test_log2_shortcut_cpu.py).
     float magnitude;
-    const uint32_t epsilon_bits = __float_as_uint(factorized_epsilon);
-    const uint32_t epsilon_exponent = (epsilon_bits >> 23) & 0xffu, epsilon_fraction = epsilon_bits & 0x7fffffu;
-    if ((epsilon_bits >> 31) == 0u && epsilon_exponent != 0u && epsilon_exponent != 255u && epsilon_fraction >= 256u &&
-        epsilon_fraction < (1u << 23) - 256u) {
-        const int e = (int)epsilon_exponent - 127;
-        magnitude = (float)(e >= 0 ? e : -e - 1);
-    } else {
+    if (!mdb::floor_abs_log2_from_exponent(__float_as_uint(factorized_epsilon), &magnitude))
         magnitude = floorf(fabsf((float)log2((double)factorized_epsilon)));
-    }
     long long wide_position = 23ll - (long long)saturating_f32_to_i32(magnitude);
     int position = wide_position < -2147483647ll ? -2147483647 : (int)wide_position;
     auto rewrite = [](uint32_t b, int pos) -> uint32_t {

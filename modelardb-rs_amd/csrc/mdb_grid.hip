@@ -4495,7 +4495,10 @@ int grid_batch_host_impl(mdb_ctx *ctx, const mdb_segments *in, TimeRange range, 
     if (cap > 0 && (!out_ts || !out_val)) return fail("out_ts and out_val must not be NULL.");
     std::vector<unsigned long long> index_piece_base;
     std::vector<MvCursor> index_cursors;
-    mv_host_index(&in, 1, &index_piece_base, &index_cursors); // (cursors into the long MacaqueV streams, by host threads)
+    // (cursors into the long MacaqueV streams, by host threads; under a time range only into the streams of segments
+    // that reach into it: the others have no point to decode)
+    const MvHostRange host_range{range.lo, range.hi};
+    mv_host_index(&in, 1, &index_piece_base, &index_cursors, range.enabled ? &host_range : nullptr);
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
@@ -4565,7 +4568,8 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
     // of a pipelined stream has it while this one walks).
     std::vector<unsigned long long> index_piece_base;
     std::vector<MvCursor> index_cursors;
-    mv_host_index(ins, n_ins, &index_piece_base, &index_cursors);
+    const MvHostRange host_range{range.lo, range.hi}; // (under a time range: only the segments that reach into it)
+    mv_host_index(ins, n_ins, &index_piece_base, &index_cursors, range.enabled ? &host_range : nullptr);
     mdb::CallGuard lock(ctx);
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;

@@ -18,6 +18,7 @@
 #include <thread>
 
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 
@@ -30,19 +31,22 @@ namespace mdb {
 // ---- the library's switches -----------------------------------------------------------------------------------
 //
 // One table per process: the MDB_* variables of the environment as they were when the table was first asked (or last
-// reloaded), and what mdb_set_option() has put on top. Entries are never erased while the table stands (a switch that
-// is unset keeps its node with `set` false), so the text a look-up returned stays where it is until that switch is set
-// again or the table reloaded.
+// reloaded), and what mdb_set_option() has put on top. A text, once handed out, is never changed or freed: every
+// distinct value is kept once in `texts` for the life of the process (a switch has a handful of values) and an entry
+// only points at one, so a call that is still reading the text a look-up gave it is not disturbed by mdb_set_option /
+// mdb_reload_options on another thread (pipeline workers and the host walk ask while they run).
 namespace {
 
 struct Options {
     struct Entry {
-        std::string text;
+        const std::string *text = nullptr; // into `texts`
         bool set = false;
     };
     std::mutex mutex;
     std::map<std::string, Entry> entries;
+    std::set<std::string> texts; // (node based: the strings never move)
     bool loaded = false;
+    const std::string *keep(const char *value) { return &*texts.insert(value).first; }
     void load_locked() {
         for (auto &entry : entries) entry.second.set = false;
         for (char **variable = environ; variable && *variable; variable++) {
@@ -50,7 +54,7 @@ struct Options {
             const char *equals = std::strchr(*variable, '=');
             if (!equals) continue;
             Entry &entry = entries[std::string(*variable, (size_t)(equals - *variable))];
-            entry.text = equals + 1;
+            entry.text = keep(equals + 1);
             entry.set = true;
         }
         loaded = true;
@@ -69,7 +73,7 @@ const char *option_text(const char *name) {
     std::lock_guard<std::mutex> lock(table.mutex);
     if (!table.loaded) table.load_locked();
     const auto found = table.entries.find(name);
-    return found != table.entries.end() && found->second.set ? found->second.text.c_str() : nullptr;
+    return found != table.entries.end() && found->second.set ? found->second.text->c_str() : nullptr;
 }
 
 // ---- host threads -------------------------------------------------------------------------------------------
@@ -416,7 +420,7 @@ int mdb_set_option(const char *name, const char *value) {
     if (!table.loaded) table.load_locked();
     Options::Entry &entry = table.entries[name];
     entry.set = value != nullptr;
-    if (value) entry.text = value;
+    if (value) entry.text = table.keep(value);
     return 0;
 }
 

@@ -583,10 +583,11 @@ def test_aggregate_query_under_a_time_range_through_the_rule(hip, irregular):
     (DataSourceExec -> GridExec -> SortedJoinExec -> FilterExec -> AggregateExec) and the plan the extended rule makes
     of it (DataSourceExec -> AggregateExec over the segments) give the same answer, which is the oracle's."""
     query = host.AggregateQuery(hip, n_fields=1, tag_names=("tag",))
-    batches = []
+    batches, last = [], 0
     for seed, tag in ((71, "A"), (72, "B")):
         timestamps, _, batch = _series(seed, irregular=irregular)
         batches.append(batch)
+        last = max(last, int(timestamps[-1]))
         for part in _segment_batches(batch, {"tag": tag}, 113):
             query.push_segments(0, part)
     lower, upper = int(timestamps[_n(3_000)]), int(timestamps[_n(17_000)])
@@ -607,7 +608,7 @@ def test_aggregate_query_under_a_time_range_through_the_rule(hip, irregular):
     (average,) = query.execute()
     assert abs(average - expected.sum / expected.count) <= 1e-5 * abs(expected.sum / expected.count)
     # nothing in the range: COUNT 0 and NULLs from both plans
-    beyond = [f"(> timestamp ts:{int(timestamps[-1]) + 10})"]
+    beyond = [f"(> timestamp ts:{last + 10})"]
     for optimize in (False, True):
         assert query.plan(aggregates, beyond, optimize=optimize).execute() == [0.0, None, None, None]
     # without a predicate the rule's original case: the segments' own metadata (model_simple_aggregates.rs:336-618)
