@@ -538,6 +538,7 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     // the same for every range that contains the segment (MvIndex::range_acc; made by a pass over the whole time
     // axis when the batch is first asked about a range, again if a switch has moved the line to the decoders).
     const TsWalkRange *whole_acc = nullptr;
+    std::shared_ptr<void> whole_acc_held; // (the array stays this call's while its kernels read it)
     if (range && !(cache_setting && std::strcmp(cache_setting, "0") == 0)) {
         if (std::shared_ptr<MvIndex> kept = owned_segments_index(in)) {
             const uint64_t key = ((uint64_t)mv_min_values << 2) | (indexed_piece_base ? 2u : 0u) | 1u;
@@ -547,24 +548,42 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
                 ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
             const bool walkable = range_from_kept || ts_payload == 0;
-            if (walkable && kept->range_acc_key != key) {
-                if (!kept->range_acc) MDB_HIP_CHECK(hipMalloc(&kept->range_acc, in->n * sizeof(TsWalkRange)));
-                MDB_HIP_CHECK(hipMemsetAsync(kept->range_acc, 0xff, in->n * sizeof(TsWalkRange), ctx->stream)); // (count -1)
+            if (walkable && kept->range_acc_key != key && !kept->range_acc_failed) {
+                // A new array per key (another call may still be reading the one made under the last key); without the
+                // memory for it the query works every segment out itself, now and from now on.
+                void *fresh = nullptr;
+                if (hipMalloc(&fresh, in->n * sizeof(TsWalkRange)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    kept->range_acc_failed = true;
+                }
+                if (fresh) {
+                const int device = ctx->device;
+                std::shared_ptr<void> made_array(fresh, [device](void *allocation) {
+                    (void)hipSetDevice(device);
+                    (void)hipFree(allocation);
+                });
+                MDB_HIP_CHECK(hipMemsetAsync(fresh, 0xff, in->n * sizeof(TsWalkRange), ctx->stream)); // (count -1)
                 {
                     LaunchTimer timer(ctx, "k_agg_range");
                     hipLaunchKernelGGL(k_agg_range, dim3(n_blocks), dim3(AGG_THREADS), 0, ctx->stream, s, INT64_MIN, INT64_MAX,
                                        AGG_SUM_DEFER, mv_min_values, partials, static_cast<const uint32_t *>(kept->range_whole_totals),
                                        static_cast<const TsWalkRange *>(kept->range_whole), static_cast<const unsigned int *>(nullptr),
                                        indexed_piece_base, static_cast<const TsWalkRange *>(nullptr),
-                                       static_cast<TsWalkRange *>(kept->range_acc));
+                                       static_cast<TsWalkRange *>(fresh));
                     hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(AGG_THREADS), 0, ctx->stream, partials, n_blocks, result);
                 }
                 AggPartial made;
                 MDB_HIP_CHECK(hipMemcpyAsync(&made, result, sizeof(AggPartial), hipMemcpyDeviceToHost, ctx->stream));
                 MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 kept->range_acc_key = made.error ? 0 : key; // (a fault: every call finds and reports it itself)
+                if (made.error) kept->range_acc_failed = true;
+                else kept->range_acc = made_array;
+                }
             }
-            if (walkable && kept->range_acc_key == key) whole_acc = static_cast<const TsWalkRange *>(kept->range_acc);
+            if (walkable && kept->range_acc_key == key && kept->range_acc) {
+                whole_acc_held = kept->range_acc;
+                whole_acc = static_cast<const TsWalkRange *>(whole_acc_held.get());
+            }
         }
     }
     if (walk_wanted && !walk_kept && !range_from_kept) {

@@ -190,13 +190,20 @@ struct MvIndex {
     // timestamps and no residuals add up to (k_grid_ts_count<WALK_RANGE> over the whole time axis, once) with every
     // irregular segment's number of points: a query then walks only the segments its range cuts
     // (ts_range_from_kept, mdb_grid.hip).
+    // (24 B + 4 B per segment here, 24 B more for range_acc below: 52 B per segment for the life of the batch from its
+    // first aggregate under a range on - 440 MB for 8.5 M segments; MDB_GRID_TS_CACHE=0 keeps none of it. If the memory
+    // is not there the query walks what it needs every time: range_whole_failed.)
     bool range_whole_built = false;
+    bool range_whole_failed = false;    // a malformed stream or no memory: not tried again
     void *range_whole = nullptr;        // TsWalkRange[n]
     void *range_whole_totals = nullptr; // uint32_t[n]
     // ... and what k_agg_range makes of ALL points of a segment (count < 0: leaves to the decoders), for the ranges
     // that contain it; `range_acc_key`: the line to the decoders it was made under (0: not made).
-    void *range_acc = nullptr; // TsWalkRange[n]
+    // A query holds the array it reads (a copy of the pointer, taken under the mutex) for as long as its kernels run:
+    // a rebuild under another key on another context makes a NEW array and leaves this one to its readers.
+    std::shared_ptr<void> range_acc; // TsWalkRange[n] (freed by its deleter)
     uint64_t range_acc_key = 0;
+    bool range_acc_failed = false;   // no memory for it: not tried again
     // The index of ONE call over host batches (mv_host_index, mdb_grid.hip): made by host threads while the batches
     // are on their way, for the long streams only - a segment without pieces is the serial kernel's - and living in
     // the context's scratch.
@@ -204,10 +211,10 @@ struct MvIndex {
     ~MvIndex() {
         if (of_one_call) return;
         if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals || agg_walk_totals || agg_walk_sums || range_whole ||
-            range_whole_totals || range_acc) {
+            range_whole_totals) {
             (void)hipSetDevice(device);
             for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals, agg_walk_totals, agg_walk_sums,
-                                     range_whole, range_whole_totals, range_acc})
+                                     range_whole, range_whole_totals})
                 if (allocation) (void)hipFree(allocation);
         }
     }

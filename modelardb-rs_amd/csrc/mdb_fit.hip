@@ -3940,6 +3940,10 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
         const uint64_t magnitude = t[0] < 0 ? 0ull - (uint64_t)t[0] : (uint64_t)t[0];
         const uint64_t stride = step < 0 ? 0ull - (uint64_t)step : (uint64_t)step;
         if (!(magnitude <= limit && (stride == 0 || n <= limit / stride))) return 2;
+        // (and no timestamp beyond +-2^52 at all: the line k_fit_regular draws for the general driver - a chunk that
+        // begins below 2^52 and ends above it is "beyond" there and takes the careful fitter, so it does here)
+        const uint64_t last_magnitude = t[n - 1] < 0 ? 0ull - (uint64_t)t[n - 1] : (uint64_t)t[n - 1];
+        if (last_magnitude > limit) return 2;
     }
 
     // ---- sizes the host can know ----

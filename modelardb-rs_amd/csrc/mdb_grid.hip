@@ -3138,6 +3138,7 @@ int ts_range_from_kept(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &
     if (n == 0 || n > 0xfffffff0ull) return 0;
     {
         std::lock_guard<std::mutex> lock(kept.mutex);
+        if (kept.range_whole_failed) return 0; // (the walk of every call finds and reports what is wrong with a stream)
         if (!kept.range_whole_built) {
             // Once: every irregular stream walked with the whole time axis as the range.
             const uint32_t *walk_totals = nullptr;
@@ -3150,12 +3151,20 @@ int ts_range_from_kept(mdb_ctx *ctx, const mdb_segments *in, const DevSegments &
             if (!walk_totals || !walk_ranges) return 0; // (no out-of-line timestamp streams: nothing to keep, nothing to walk)
             unsigned int found = 0;
             MDB_HIP_CHECK(hipMemcpyAsync(&found, walk_error, 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (!kept.range_whole) MDB_HIP_CHECK(hipMalloc(&kept.range_whole, n * sizeof(TsWalkRange)));
-            if (!kept.range_whole_totals) MDB_HIP_CHECK(hipMalloc(&kept.range_whole_totals, n * 4));
+            // (no memory to keep it in: the query goes on without, walking what it needs - now and from now on)
+            if ((!kept.range_whole && hipMalloc(&kept.range_whole, n * sizeof(TsWalkRange)) != hipSuccess) ||
+                (!kept.range_whole_totals && hipMalloc(&kept.range_whole_totals, n * 4) != hipSuccess)) {
+                (void)hipGetLastError();
+                kept.range_whole_failed = true;
+                return 0;
+            }
             MDB_HIP_CHECK(hipMemcpyAsync(kept.range_whole, walk_ranges, n * sizeof(TsWalkRange), hipMemcpyDeviceToDevice, ctx->stream));
             MDB_HIP_CHECK(hipMemcpyAsync(kept.range_whole_totals, walk_totals, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
             MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if (found) return 0; // (a malformed stream: the walk of every call reports it)
+            if (found) { // (a malformed stream: the walk of every call reports it; this pass is not made again)
+                kept.range_whole_failed = true;
+                return 0;
+            }
             kept.range_whole_built = true;
         }
     }

@@ -115,3 +115,26 @@ def test_non_finite_values_and_signed_zeros(hip):
     for bound in (eb, cases.error_bounds()["lossless"]):
         expected = ora.try_compress_univariate_time_series(timestamps, values, bound)
         assert_same_segments(hip.compress_chunk_list([(timestamps, values)], bound), expected)
+
+
+@pytest.mark.parametrize("eb_name", ["rel1", "lossless"])
+def test_timestamps_around_two_to_the_52(hip, eb_name, monkeypatch):
+    """A chunk that begins below 2^52 and ends above it, one that ends exactly on it, and negative mirrors: the general
+    driver calls a chunk with ANY timestamp beyond +-2^52 "beyond" (k_fit_regular) and gives it the careful fitter, so
+    the few-chunks path must leave exactly those chunks alone; either way the segments are the oracle's and the two
+    drivers' are the same."""
+    eb = cases.error_bounds()[eb_name]
+    length, stride = 20_000, 250
+    _, values = series("mixed", length, 4)
+    limit = 1 << 52
+    firsts = (limit - length * stride // 2, limit - (length - 1) * stride, limit - (length - 1) * stride + 1,
+              -(limit - length * stride // 2), -limit, -limit - 1)
+    for first in firsts:
+        timestamps = first + np.arange(length, dtype=np.int64) * stride
+        expected = ora.try_compress_univariate_time_series(timestamps, values, eb)
+        monkeypatch.delenv("MDB_FIT_SMALL", raising=False)
+        small = hip.compress_chunk_list([(timestamps, values)], eb)
+        monkeypatch.setenv("MDB_FIT_SMALL", "0")
+        general = hip.compress_chunk_list([(timestamps, values)], eb)
+        assert_same_segments(small, expected)
+        assert_same_segments(general, expected)
