@@ -76,6 +76,8 @@ enum ScratchSlot {
     SCRATCH_MV_HOST_INDEX,
     SCRATCH_FIT_SMALL,
     SCRATCH_AGG_CHAIN_LIST,
+    SCRATCH_FIT_LONG_IDS,
+    SCRATCH_FIT_LONG,
     SCRATCH_SLOT_COUNT
 };
 

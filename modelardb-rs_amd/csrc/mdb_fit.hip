@@ -786,6 +786,8 @@ struct FitArgs {
     // process_segment needs to know about them.
     uint32_t gap_min_values;
     const struct GapResult *gap_results;
+    // ... and those of at least this many values are cut into blocks with a wave each (k_fit_long*); 0xffffffff: never.
+    uint32_t gap_long_min_values = 0xffffffffu;
     // Timestamps of segments inside irregular chunks are sized and written by one WAVE each
     // (k_fit_timestamps); ts_results[segment].bytes == 0xffffffff: not this one. May be nullptr.
     const struct TsResult *ts_results;
@@ -2745,7 +2747,9 @@ __global__ __launch_bounds__(256) void k_fit_gap_select(FitArgs args, const SegI
     if (args.n_segments_dev) n_segments = *args.n_segments_dev;
     const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x % MDB_WAVE, wave = threadIdx.x / MDB_WAVE;
-    const bool listed = segment < n_segments && gap_goes_to_a_wave(args, items[segment]);
+    // (the long ones are k_fit_long_select's)
+    const bool listed = segment < n_segments && gap_goes_to_a_wave(args, items[segment]) &&
+                        items[segment].last - items[segment].first + 1 < args.gap_long_min_values;
     const unsigned long long lanes = __ballot(listed);
     if (lane == 0) listed_by_wave[wave] = (uint32_t)__popcll(lanes);
     __syncthreads();
@@ -2968,6 +2972,546 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         result.regular = all_regular ? 1u : 0u;
         results[segment] = result;
     }
+}
+
+// ---- long MacaqueV-only segments: cut into blocks, a wave per block ----------------------------------------
+//
+// One wave encodes 64 values in about a microsecond, so a stream of 10^6 values - BASELINE's configuration 1, noise
+// under a lossless bound handed over as one series - took 2 x 17 ms behind a single wave (and a CPU core 25). What
+// runs from code to code is little: the value stored last (lossy bounds: macaque_v.rs:100-118) and the window of the
+// last `11` code (:120-164). Both are CHAINS OF RESETS - a value that is not within the bound of the one stored before
+// it stores its own rewritten self whatever was stored; a code whose bits do not fit the window opens its own whatever
+// the window was - so a wave that starts in the middle of a stream without knowing either falls in with the true chain:
+//   * windows: started with the empty window (255, 0) a wave opens one at its first non-zero XOR; from then on its
+//     window is never narrower than the true one (if the true encoder did not open where the wave did, the bits fit
+//     its window, so the wave's new one contains it; where the true encoder opens, the bits do not fit its window and
+//     so not the wave's wider one either), and at the first code the TRUE encoder opens in the block both hold the
+//     same window: from there to the end of the block the wave's codes are the stream's.
+//   * stored values: two chains hold the same value from the first value on that both of them store anew.
+// So every block of a long segment (GapBlock; 1 024 values or more, at most 256 blocks per segment) is sized by a wave
+// of its own from such a start (k_fit_long<LONG_SPEC_*>), keeping per batch of 64 values what a later look needs
+// (GapBatchNote: the bits before it, the wave's window in front of it, the widest code in it, how many codes are not
+// repeats); ONE wave per segment then walks the blocks in order with the true state (k_fit_long_stitch). Noise settles
+// on the widest window it needs and never opens another, so the true chain may not reset for a whole block: the walk
+// therefore goes over the NOTES, 64 batches per step - a batch in which no code opens a window costs
+// 2 x repeats + (33 - leading - trailing) x others bits whatever its values are - up to the first batch in front of
+// which the block's wave holds the true window (from there on its codes are the stream's) or in which the true chain
+// opens one (that batch alone is encoded again from its values). It leaves every block its true state and bit offset;
+// with those the blocks are written by a wave each (k_fit_long<LONG_WRITE>), the byte two blocks share ORed in by
+// both. The stream is the one-wave encoder's bit for bit.
+
+constexpr uint32_t GAP_LONG_DEFAULT_MIN_VALUES = 8192;  // (MDB_FIT_GAP_LONG_MIN_VALUES)
+constexpr uint32_t GAP_BLOCK_DEFAULT_MIN_VALUES = 1024; // (MDB_FIT_GAP_BLOCK_VALUES; a multiple of 64)
+constexpr uint32_t GAP_BLOCKS_PER_SEGMENT = 256;        // the stitch of a segment walks at most this many blocks
+
+// Values per block of a segment with n_codes values behind its first (raw) one.
+__host__ __device__ inline uint32_t gap_block_values(uint32_t n_codes, uint32_t block_min) {
+    uint64_t block = block_min;
+    while (block * GAP_BLOCKS_PER_SEGMENT < n_codes) block <<= 1;
+    return (uint32_t)block;
+}
+
+struct GapBlock { // 64 bytes, one per block of a long segment
+    uint32_t segment;    // index into the items
+    uint32_t first;      // index within the segment of the block's first value (>= 1: value 0 is stored raw)
+    uint32_t count;      // values of the block
+    uint32_t batch_base; // the block's first slot in the per-batch arrays
+    // k_fit_long<LONG_SPEC_VALUES>: what is stored last if nothing was stored before the block
+    float spec_stored_end;
+    // k_fit_long_stitch<STITCH_VALUES>: the value really stored before the block's first
+    float stored_in;
+    // k_fit_long<LONG_SPEC_SIZE>: the block's codes if the window is empty before it
+    uint32_t spec_bits;
+    uint32_t spec_end_window; // leading | trailing << 8 | (1 << 16 if a window was opened in the block)
+    float min_value, max_value;
+    uint32_t regular;
+    // k_fit_long_stitch<STITCH_WINDOWS>: the true window before the block, where its codes begin, how many bits
+    uint32_t in_window;
+    unsigned long long bit_offset;
+    uint32_t bits;
+    uint32_t reserved;
+};
+static_assert(sizeof(GapBlock) == 64, "GapBlock is laid out by hand");
+
+struct GapBatchNote { // 16 bytes, one per batch of 64 values of a block; by k_fit_long<LONG_SPEC_SIZE>
+    uint32_t prefix_bits;   // bits of the block's codes in front of the batch (from an empty window)
+    uint32_t windows;       // the wave's window in front of the batch: leading | trailing << 8; the least leading /
+                            // trailing zeros of the batch's non-zero XORs (32: none): << 16 / << 24
+    uint32_t others;        // codes of the batch that are not repeats (non-zero XORs)
+    float stored_before;    // the value stored in front of the batch's first
+};
+
+struct LongCounters { // (lives behind the gap list's counter: [0] ordinary gaps, [1] long segments, [2] blocks, [3] batches)
+    uint32_t n_gaps, n_long, n_blocks, n_batches;
+};
+
+struct LongArgs {
+    const LongCounters *counters;
+    uint32_t *long_ids;                    // segment of long segment g
+    uint32_t *long_block_base;             // its first block
+    uint32_t *long_batch_base;             // its first batch slot
+    GapBlock *blocks;
+    GapBatchNote *batch_notes;             // what the stitch needs to know of a batch
+    unsigned long long *batch_breakers;    // lanes that store themselves anew (from nothing stored); lossy bounds only
+    uint32_t long_min_values = 0xffffffffu;
+    uint32_t block_min_values = GAP_BLOCK_DEFAULT_MIN_VALUES;
+};
+
+__device__ __forceinline__ bool gap_is_long(const LongArgs &la, const SegItem &item) {
+    return item.last - item.first + 1 >= la.long_min_values;
+}
+
+// The long segments of the call, each with room for its blocks and their batches. (There are few: a lane per segment
+// looks, the ones that find one take their slots with atomics.)
+__global__ __launch_bounds__(256) void k_fit_long_select(FitArgs args, const SegItem *__restrict__ items, uint64_t n_segments,
+                                                         LongArgs la, LongCounters *__restrict__ counters) {
+    if (args.n_segments_dev) n_segments = *args.n_segments_dev;
+    const uint64_t segment = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (segment >= n_segments) return;
+    const SegItem item = items[segment];
+    if (!gap_goes_to_a_wave(args, item) || !gap_is_long(la, item)) return;
+    const uint32_t n_codes = item.last - item.first;
+    const uint32_t block_values = gap_block_values(n_codes, la.block_min_values);
+    const uint32_t n_blocks = (n_codes + block_values - 1) / block_values;
+    const uint32_t g = atomicAdd(&counters->n_long, 1u);
+    la.long_ids[g] = (uint32_t)segment;
+    la.long_block_base[g] = atomicAdd(&counters->n_blocks, n_blocks);
+    la.long_batch_base[g] = atomicAdd(&counters->n_batches, n_blocks * (block_values / MDB_WAVE));
+}
+
+// The headers of a long segment's blocks: one wave per long segment.
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_long_blocks(const SegItem *__restrict__ items, LongArgs la) {
+    if (blockIdx.x >= la.counters->n_long) return;
+    const uint32_t segment = la.long_ids[blockIdx.x];
+    const SegItem item = items[segment];
+    const uint32_t n_codes = item.last - item.first; // values behind the first
+    const uint32_t block_values = gap_block_values(n_codes, la.block_min_values);
+    const uint32_t n_blocks = (n_codes + block_values - 1) / block_values;
+    const uint32_t block_base = la.long_block_base[blockIdx.x], batch_base = la.long_batch_base[blockIdx.x];
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += MDB_WAVE) {
+        GapBlock block{};
+        block.segment = segment;
+        block.first = 1 + b * block_values;
+        block.count = min(block_values, n_codes - b * block_values);
+        block.batch_base = batch_base + b * (block_values / MDB_WAVE);
+        la.blocks[block_base + b] = block;
+    }
+}
+
+// What the lanes of a batch store (macaque_v.rs:100-118) given the value stored before the batch's first: the value
+// stored before it where that is within the bound, otherwise the lane's own value with its least mantissa bits
+// rewritten. `last_stored` (uniform) comes back as what the batch's last lane stores; *own: the lanes that store
+// themselves anew. (The loop of k_fit_gap.)
+__device__ __forceinline__ float gap_value_chain(const mdb_error_bound &eb, const DeviationFactor &deviation, bool active,
+                                                 float raw, int lane, int last_lane, float &last_stored,
+                                                 unsigned long long *own) {
+    float stored = raw;
+    unsigned long long anew = 0;
+    const float rewritten = active ? rewrite_least_mantissa_bits(eb, deviation, raw) : 0.0f;
+    const float rewritten_before = dpp_move<0x138>(rewritten); // wave_shr:1
+    const unsigned long long breaks_behind_a_breaker =
+        __ballot(active && lane > 0 && !within_error_bound(eb, raw, rewritten_before));
+    int cursor = 0;
+    while (true) {
+        const bool breaks = active && lane >= cursor && !within_error_bound(eb, raw, last_stored);
+        const unsigned long long mask = __ballot(breaks);
+        if (mask == 0) {
+            if (lane >= cursor) stored = last_stored;
+            break;
+        }
+        const int breaker = __ffsll((long long)mask) - 1;
+        if (lane >= cursor && lane < breaker) stored = last_stored;
+        const unsigned long long behind = breaker + 1 < MDB_WAVE ? breaks_behind_a_breaker >> (breaker + 1) : 0ull;
+        const int last_breaker = breaker + (~behind ? __builtin_ctzll(~behind) : MDB_WAVE - 1 - breaker);
+        if (lane >= breaker && lane <= last_breaker) stored = rewritten;
+        const unsigned long long up_to_last = last_breaker == MDB_WAVE - 1 ? ~0ull : (1ull << (last_breaker + 1)) - 1ull;
+        anew |= up_to_last & ~((1ull << breaker) - 1ull);
+        last_stored = read_lane(rewritten, last_breaker);
+        cursor = last_breaker + 1;
+    }
+    last_stored = read_lane(stored, last_lane);
+    *own = anew;
+    return stored;
+}
+
+// The window every lane's code is written with (macaque_v.rs:120-164) given the window before the batch's first
+// code; the window (uniform) comes back as the one behind the batch's last. Returns whether the lane opens one.
+// (The loop of k_fit_gap.)
+__device__ __forceinline__ bool gap_window_chain(bool active, bool repeat, uint32_t leading, uint32_t trailing, int lane,
+                                                 uint32_t &window_leading, uint32_t &window_trailing, uint32_t *my_leading,
+                                                 uint32_t *my_trailing) {
+    *my_leading = window_leading;
+    *my_trailing = window_trailing;
+    bool opens = false;
+    const uint32_t leading_before = dpp_move<0x138>(leading), trailing_before = dpp_move<0x138>(trailing);
+    const unsigned long long opens_behind_an_opener =
+        __ballot(active && lane > 0 && !repeat && !(leading >= leading_before && trailing >= trailing_before));
+    int cursor = 0;
+    while (true) {
+        const bool misfit = active && lane >= cursor && !repeat && !(leading >= window_leading && trailing >= window_trailing);
+        const unsigned long long mask = __ballot(misfit);
+        if (mask == 0) {
+            if (lane >= cursor) {
+                *my_leading = window_leading;
+                *my_trailing = window_trailing;
+            }
+            break;
+        }
+        const int opener = __ffsll((long long)mask) - 1;
+        if (lane >= cursor && lane < opener) {
+            *my_leading = window_leading;
+            *my_trailing = window_trailing;
+        }
+        const unsigned long long behind = opener + 1 < MDB_WAVE ? opens_behind_an_opener >> (opener + 1) : 0ull;
+        const int last_opener = opener + (~behind ? __builtin_ctzll(~behind) : MDB_WAVE - 1 - opener);
+        if (lane >= opener && lane <= last_opener) {
+            opens = true;
+            *my_leading = leading;
+            *my_trailing = trailing;
+        }
+        window_leading = read_lane(leading, last_opener);
+        window_trailing = read_lane(trailing, last_opener);
+        cursor = last_opener + 1;
+    }
+    return opens;
+}
+
+// One batch of 64 values of a stream: what each lane stores, its code, where the code lies in the batch.
+struct GapBatch {
+    float stored;
+    uint32_t x, code_bits, before_bits; // the XOR with the value stored before; the code's length; bits of the batch in front
+    uint32_t my_leading, my_trailing;
+    bool repeat, opens;
+    uint32_t batch_bits;
+    unsigned long long anew; // lanes that store themselves anew (lossy bounds)
+    bool any_opens;
+    uint32_t leading, trailing; // of the lane's XOR (32: a repeat)
+};
+
+// (the body of k_fit_gap's loop: `carried_in` / the window are the stream's state in front of the batch and behind it)
+__device__ __forceinline__ GapBatch gap_batch(const mdb_error_bound &eb, const DeviationFactor &deviation, bool active, float raw,
+                                              int lane, int last_lane, float &carried_in, uint32_t &window_leading,
+                                              uint32_t &window_trailing) {
+    GapBatch batch;
+    batch.anew = 0;
+    batch.stored = active ? raw : 0.0f;
+    const float stored_before_batch = carried_in;
+    if (eb.kind != MDB_EB_LOSSLESS) {
+        batch.stored = gap_value_chain(eb, deviation, active, raw, lane, last_lane, carried_in, &batch.anew);
+    } else {
+        carried_in = read_lane(batch.stored, last_lane);
+    }
+    const float before = dpp_move<0x138>(batch.stored); // wave_shr:1 (lane 0: not used)
+    const uint32_t current = active ? __float_as_uint(batch.stored) : 0u;
+    const uint32_t previous = active ? __float_as_uint(lane == 0 ? stored_before_batch : before) : 0u;
+    batch.x = current ^ previous;
+    batch.repeat = batch.x == 0;
+    const uint32_t leading = batch.repeat ? 32u : (uint32_t)__clz((int)batch.x);
+    const uint32_t trailing = batch.repeat ? 32u : (uint32_t)__ffs((int)batch.x) - 1u;
+    batch.leading = leading;
+    batch.trailing = trailing;
+    batch.opens = gap_window_chain(active, batch.repeat, leading, trailing, lane, window_leading, window_trailing,
+                                   &batch.my_leading, &batch.my_trailing);
+    batch.any_opens = __ballot(batch.opens) != 0;
+    const uint32_t meaningful = 32u - batch.my_leading - batch.my_trailing;
+    batch.code_bits = 0;
+    if (active) batch.code_bits = batch.repeat ? 2u : (batch.opens ? 13u + meaningful : 1u + meaningful);
+    const uint32_t inclusive = wave_inclusive_scan(batch.code_bits, lane, [](uint32_t a, uint32_t b) { return a + b; });
+    batch.batch_bits = read_lane(inclusive, MDB_WAVE - 1);
+    batch.before_bits = inclusive - batch.code_bits;
+    return batch;
+}
+
+// wave_flush_bits for a block whose first and last byte it shares with its neighbours: those are ORed into memory
+// that k_fit_long_clear has zeroed (a byte at a time through the aligned word around it), the bytes in between stored.
+__device__ __forceinline__ void or_byte(uint8_t *address, uint32_t byte) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(address);
+    atomicOr(reinterpret_cast<unsigned int *>(a & ~(uintptr_t)3), byte << (8u * (uint32_t)(a & 3u)));
+}
+
+__device__ __forceinline__ uint32_t wave_flush_bits_shared_first(uint32_t *buffer, int buffer_words, uint8_t *__restrict__ dst,
+                                                                 uint64_t *written, uint32_t buffered, int lane,
+                                                                 bool *first_byte_shared) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t whole_bytes = buffered >> 3;
+    for (uint32_t b = lane; b < whole_bytes; b += MDB_WAVE) {
+        const uint32_t byte = (buffer[b >> 2] >> (24u - 8u * (b & 3u))) & 0xffu;
+        if (b == 0 && *first_byte_shared) or_byte(dst + *written, byte);
+        else dst[*written + b] = (uint8_t)byte;
+    }
+    if (whole_bytes > 0) *first_byte_shared = false;
+    const uint32_t partial = (buffer[whole_bytes >> 2] >> (24u - 8u * (whole_bytes & 3u))) & 0xffu;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < buffer_words; k += MDB_WAVE) buffer[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t carry_bits = buffered & 7u;
+    if (lane == 0 && carry_bits) buffer[0] = partial << 24;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    *written += whole_bytes;
+    return carry_bits;
+}
+
+enum { LONG_SPEC_VALUES = 0, LONG_SPEC_SIZE = 1, LONG_WRITE = 2 };
+
+// One wave per block. LONG_SPEC_VALUES (lossy bounds): which lanes store themselves anew if nothing was stored
+// before the block. LONG_SPEC_SIZE: the codes' lengths from an empty window (stored values: the true ones, from
+// stored_in). LONG_WRITE: the block's codes, from its true state, where they belong.
+template <int MODE>
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_long(FitArgs args, const SegItem *__restrict__ items, LongArgs la,
+                                                       EncodeTargets targets) {
+    __shared__ uint32_t buffer[GAP_BUFFER_WORDS];
+    if (blockIdx.x >= la.counters->n_blocks) return;
+    if (MODE == LONG_WRITE && args.targets_dev) targets = *args.targets_dev;
+    GapBlock &block = la.blocks[blockIdx.x];
+    const uint32_t segment = block.segment, first = block.first, count = block.count;
+    const SegItem item = items[segment];
+    const int lane = threadIdx.x;
+    const float *__restrict__ values = args.values + args.chunk_offsets[item.chunk] + item.first;
+    const mdb_error_bound eb = args.eb;
+    const DeviationFactor deviation = deviation_factor(eb);
+    const float nan32 = __uint_as_float(0x7fc00000u);
+    const bool lossless = eb.kind == MDB_EB_LOSSLESS;
+
+    if (MODE == LONG_SPEC_VALUES) {
+        // (the segment's first block begins behind the first value, which is stored as it is)
+        float last_stored = first == 1 ? values[0] : nan32;
+        for (uint32_t base = first, k = 0; base < first + count; base += MDB_WAVE, k++) {
+            const uint32_t i = base + lane;
+            const bool active = i < first + count;
+            const int last_lane = (int)min((uint32_t)MDB_WAVE, first + count - base) - 1;
+            unsigned long long anew = 0;
+            (void)gap_value_chain(eb, deviation, active, active ? values[i] : 0.0f, lane, last_lane, last_stored, &anew);
+            if (lane == 0) la.batch_breakers[block.batch_base + k] = anew;
+        }
+        if (lane == 0) block.spec_stored_end = last_stored;
+        return;
+    }
+
+    float carried_in = lossless ? values[first - 1] : block.stored_in;
+    uint32_t window_leading = 255, window_trailing = 0; // macaque_v.rs:63-64
+    uint8_t *__restrict__ dst = nullptr;
+    uint64_t written = 0;
+    uint32_t carry_bits = 0;
+    bool first_byte_shared = false;
+    if (MODE == LONG_WRITE) {
+        window_leading = block.in_window & 0xffu;
+        window_trailing = (block.in_window >> 8) & 0xffu;
+        dst = targets.data[1] + targets.data_offsets[1][segment];
+        if (first == 1 && lane < 4) dst[lane] = (uint8_t)(__float_as_uint(values[0]) >> (24 - 8 * lane)); // the first value: raw
+        written = block.bit_offset >> 3;
+        carry_bits = (uint32_t)(block.bit_offset & 7u);
+        first_byte_shared = carry_bits != 0;
+        for (int k = lane; k < GAP_BUFFER_WORDS; k += MDB_WAVE) buffer[k] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // (as k_fit_gap: equally spaced timestamps are checked while sizing; min / max in the order of the values)
+    const ChunkTimestamps ts = chunk_timestamps(args.timestamps, item.chunk, args.chunk_offsets[item.chunk]);
+    const uint32_t n = item.last - item.first + 1;
+    bool regular = true;
+    const int64_t expected_delta = (MODE == LONG_SPEC_SIZE && ts.ts && n >= 2) ? ts.ts[item.first + 1] - ts.ts[item.first] : 0;
+    float min_value = nan32, max_value = nan32;
+    uint32_t bits = 0;
+    bool opened = false;
+    for (uint32_t base = first, k = 0; base < first + count; base += MDB_WAVE, k++) {
+        const uint32_t i = base + lane;
+        const bool active = i < first + count;
+        const int last_lane = (int)min((uint32_t)MDB_WAVE, first + count - base) - 1;
+        GapBatchNote note;
+        if (MODE == LONG_SPEC_SIZE) {
+            note.prefix_bits = bits;
+            note.windows = window_leading | (window_trailing << 8);
+            note.stored_before = carried_in;
+            if (ts.ts && active && ts.ts[item.first + i] - ts.ts[item.first + i - 1] != expected_delta) regular = false;
+        }
+        const GapBatch batch = gap_batch(eb, deviation, active, active ? values[i] : 0.0f, lane, last_lane, carried_in,
+                                         window_leading, window_trailing);
+        if (MODE == LONG_SPEC_SIZE) {
+            const bool other = active && !batch.repeat;
+            const uint32_t least_leading = wave_inclusive_scan(other ? batch.leading : 32u, lane, [](uint32_t a, uint32_t b) { return min(a, b); });
+            const uint32_t least_trailing = wave_inclusive_scan(other ? batch.trailing : 32u, lane, [](uint32_t a, uint32_t b) { return min(a, b); });
+            note.windows |= (read_lane(least_leading, MDB_WAVE - 1) << 16) | (read_lane(least_trailing, MDB_WAVE - 1) << 24);
+            note.others = (uint32_t)__popcll(__ballot(other));
+            if (lane == 0) la.batch_notes[block.batch_base + k] = note;
+        }
+        bits += batch.batch_bits;
+        opened = opened || batch.any_opens;
+        if (MODE == LONG_SPEC_SIZE) {
+            const float mine = active ? batch.stored : nan32;
+            const ValueRange range = read_lane(wave_inclusive_scan(ValueRange{mine, mine}, lane, [](ValueRange a, ValueRange b) {
+                return ValueRange{min_num(a.low, b.low), max_num(a.high, b.high)};
+            }), MDB_WAVE - 1);
+            min_value = min_num(min_value, range.low);
+            max_value = max_num(max_value, range.high);
+        } else {
+            if (active) {
+                const uint32_t at = carry_bits + batch.before_bits;
+                const uint32_t meaningful = 32u - batch.my_leading - batch.my_trailing;
+                if (batch.repeat) {
+                    gap_put(buffer, at, 0b10u, 2);
+                } else if (batch.opens) {
+                    gap_put(buffer, at, (0b11u << 11) | (batch.my_leading << 6) | meaningful, 13);
+                    gap_put(buffer, at + 13, batch.x >> batch.my_trailing, meaningful);
+                } else {
+                    gap_put(buffer, at, 0u, 1);
+                    gap_put(buffer, at + 1, batch.x >> batch.my_trailing, meaningful);
+                }
+            }
+            carry_bits = wave_flush_bits_shared_first(buffer, GAP_BUFFER_WORDS, dst, &written, carry_bits + batch.batch_bits, lane,
+                                                      &first_byte_shared);
+        }
+    }
+    if (MODE == LONG_SPEC_SIZE) {
+        const bool all_regular = __all(regular);
+        if (lane == 0) {
+            block.spec_bits = bits;
+            block.spec_end_window = window_leading | (window_trailing << 8) | (opened ? 1u << 16 : 0u);
+            block.min_value = min_value;
+            block.max_value = max_value;
+            block.regular = all_regular ? 1u : 0u;
+        }
+    } else if (carry_bits && lane == 0) {
+        or_byte(dst + written, buffer[0] >> 24); // the byte the next block's codes begin in (the last block: zero bits behind)
+    }
+}
+
+enum { STITCH_VALUES = 0, STITCH_WINDOWS = 1 };
+
+// One wave per long segment, its blocks in order. STITCH_VALUES (lossy bounds): the value really stored in front of
+// every block. STITCH_WINDOWS: every block's true window, bit offset and bit count; the segment's GapResult.
+template <int STAGE>
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_long_stitch(FitArgs args, const SegItem *__restrict__ items, LongArgs la,
+                                                              GapResult *__restrict__ results) {
+    if (blockIdx.x >= la.counters->n_long) return;
+    const uint32_t segment = la.long_ids[blockIdx.x];
+    const SegItem item = items[segment];
+    const int lane = threadIdx.x;
+    const float *__restrict__ values = args.values + args.chunk_offsets[item.chunk] + item.first;
+    const uint32_t n_codes = item.last - item.first;
+    const uint32_t block_values = gap_block_values(n_codes, la.block_min_values);
+    const uint32_t n_blocks = (n_codes + block_values - 1) / block_values;
+    GapBlock *__restrict__ blocks = la.blocks + la.long_block_base[blockIdx.x];
+    const mdb_error_bound eb = args.eb;
+    const DeviationFactor deviation = deviation_factor(eb);
+    if (STAGE == STITCH_VALUES) {
+        float stored = values[0];
+        for (uint32_t b = 0; b < n_blocks; b++) {
+            const uint32_t first = blocks[b].first, count = blocks[b].count, batch_base = blocks[b].batch_base;
+            const float spec_end = blocks[b].spec_stored_end;
+            if (lane == 0) blocks[b].stored_in = stored;
+            if (b == 0) { // (its wave began with the segment's first value: what it found is the stream's)
+                stored = spec_end;
+                continue;
+            }
+            // The true chain, a batch at a time, until it stores a value anew where the block's wave did too.
+            for (uint32_t base = first, k = 0; base < first + count; base += MDB_WAVE, k++) {
+                const uint32_t i = base + lane;
+                const bool active = i < first + count;
+                const int last_lane = (int)min((uint32_t)MDB_WAVE, first + count - base) - 1;
+                unsigned long long anew = 0;
+                (void)gap_value_chain(eb, deviation, active, active ? values[i] : 0.0f, lane, last_lane, stored, &anew);
+                if (anew & la.batch_breakers[batch_base + k]) {
+                    stored = spec_end;
+                    break;
+                }
+            }
+        }
+        return;
+    }
+
+    uint32_t window_leading = 255, window_trailing = 0;
+    unsigned long long offset = 32; // the first value: 32 raw bits
+    float min_value = values[0], max_value = values[0];
+    bool regular = true;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const GapBlock block = blocks[b];
+        const uint32_t in_window = window_leading | (window_trailing << 8);
+        uint32_t bits = 0;
+        bool joined = b == 0; // (the first block's wave began with the stream's own state)
+        if (b == 0) {
+            bits = block.spec_bits;
+        } else {
+            // Over the notes of the block's batches, 64 of them per step: the first batch in front of which the block's
+            // wave held the true window, or in which a code does not fit the true window.
+            const uint32_t n_batches = (block.count + MDB_WAVE - 1) / MDB_WAVE;
+            const GapBatchNote *__restrict__ notes = la.batch_notes + block.batch_base;
+            const uint32_t in_front = 33u - window_leading - window_trailing; // bits of a code that keeps the window (unused while it is empty)
+            for (uint32_t k0 = 0; k0 < n_batches && !joined; k0 += MDB_WAVE) {
+                const uint32_t k = k0 + lane;
+                const bool have = k < n_batches;
+                GapBatchNote note{};
+                if (have) note = notes[k];
+                const uint32_t in_batch = have ? min((uint32_t)MDB_WAVE, block.count - k * MDB_WAVE) : 0u;
+                const bool same_window = have && (note.windows & 0xffffu) == in_window;
+                const bool opens = have && note.others > 0 &&
+                                   (((note.windows >> 16) & 0xffu) < window_leading || (note.windows >> 24) < window_trailing);
+                const unsigned long long events = __ballot(same_window || opens);
+                const int event = events ? __ffsll((long long)events) - 1 : MDB_WAVE;
+                // (a batch in front of the event: its codes keep the window - two bits for a repeat, the window's for the others)
+                const uint32_t kept = lane < event ? 2u * (in_batch - note.others) + (note.others ? in_front * note.others : 0u) : 0u;
+                bits += read_lane(wave_inclusive_scan(kept, lane, [](uint32_t a, uint32_t b) { return a + b; }), MDB_WAVE - 1);
+                if (event == MDB_WAVE) continue;
+                joined = true;
+                const GapBatchNote at = read_lane(note, event);
+                const bool held_already = read_lane((uint32_t)same_window, event) != 0;
+                if (held_already) {
+                    bits += block.spec_bits - at.prefix_bits;
+                } else {
+                    // The batch in which the true chain opens a window, from its values.
+                    const uint32_t base = block.first + (k0 + (uint32_t)event) * MDB_WAVE;
+                    const uint32_t i = base + lane;
+                    const bool active = i < block.first + block.count;
+                    const int last_lane = (int)min((uint32_t)MDB_WAVE, block.first + block.count - base) - 1;
+                    float carried_in = at.stored_before;
+                    uint32_t leading_here = window_leading, trailing_here = window_trailing;
+                    const GapBatch batch = gap_batch(eb, deviation, active, active ? values[i] : 0.0f, lane, last_lane, carried_in,
+                                                     leading_here, trailing_here);
+                    const uint32_t next = k0 + (uint32_t)event + 1;
+                    const uint32_t behind = next < n_batches ? notes[next].prefix_bits : block.spec_bits;
+                    bits += batch.batch_bits + (block.spec_bits - behind);
+                }
+            }
+        }
+        // Behind the block: once the two chains agree, the window the block's wave ended with; if they never did - no code
+        // of the block opened a window for the true chain - the window in front.
+        if (joined) {
+            window_leading = block.spec_end_window & 0xffu;
+            window_trailing = (block.spec_end_window >> 8) & 0xffu;
+        }
+        if (lane == 0) {
+            blocks[b].in_window = in_window;
+            blocks[b].bit_offset = offset;
+            blocks[b].bits = bits;
+        }
+        offset += bits;
+        min_value = min_num(min_value, block.min_value);
+        max_value = max_num(max_value, block.max_value);
+        regular = regular && block.regular != 0;
+    }
+    if (lane == 0) {
+        GapResult result;
+        result.values_bytes = (uint32_t)((offset + 7) >> 3);
+        result.min_value = min_value;
+        result.max_value = max_value;
+        result.regular = regular ? 1u : 0u;
+        results[segment] = result;
+    }
+}
+
+// The bytes two blocks share (and the last byte of the stream, padded with zero bits): zeroed before the blocks OR
+// their codes into them. One thread per block.
+__global__ __launch_bounds__(256) void k_fit_long_clear(FitArgs args, LongArgs la, EncodeTargets targets) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= la.counters->n_blocks) return;
+    if (args.targets_dev) targets = *args.targets_dev;
+    const GapBlock &block = la.blocks[slot];
+    const unsigned long long end = block.bit_offset + block.bits;
+    if (end & 7ull) (targets.data[1] + targets.data_offsets[1][block.segment])[end >> 3] = 0;
 }
 
 // ---- k_fit_timestamps: one wave per segment of an irregular chunk -----------------------------------------
@@ -3288,6 +3832,48 @@ static uint32_t gap_min_values_setting() {
         if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
     }
     return GAP_DEFAULT_MIN_VALUES;
+}
+
+// MDB_FIT_GAP_LONG_MIN_VALUES: "off" keeps one wave per MacaqueV-only segment however long it is, a number sets the
+// length from which one is cut into blocks with a wave each (k_fit_long*). MDB_FIT_GAP_BLOCK_VALUES: the least number
+// of values per block (rounded up to whole batches of 64; the tests cut short streams into many blocks with it).
+static uint32_t gap_long_min_values_setting() {
+    if (const char *text = option_text("MDB_FIT_GAP_LONG_MIN_VALUES")) {
+        if (std::strcmp(text, "off") == 0) return 0xffffffffu;
+        const long long value = std::atoll(text);
+        if (value >= 2) return (uint32_t)std::min<long long>(value, 0x7fffffff);
+    }
+    return GAP_LONG_DEFAULT_MIN_VALUES;
+}
+static uint32_t gap_block_values_setting() {
+    if (const char *text = option_text("MDB_FIT_GAP_BLOCK_VALUES")) {
+        const long long value = std::atoll(text);
+        if (value >= 1) return (uint32_t)align_up((uint64_t)std::min<long long>(value, 1ll << 24), MDB_WAVE);
+    }
+    return GAP_BLOCK_DEFAULT_MIN_VALUES;
+}
+
+// The launches that size the long segments (behind k_fit_long_select and a look at its counters, or over upper bounds):
+// block headers, [lossy bounds: what every block stores from nothing, then the true value in front of every block,]
+// every block's codes from an empty window, then the true window, offset and bits of every block and the segments'
+// GapResults.
+static void launch_long_sizing(mdb_ctx *ctx, hipStream_t stream, const FitArgs &args, const SegItem *items, const LongArgs &la,
+                               GapResult *gap_results, uint32_t n_long, uint32_t n_blocks) {
+    LaunchTimer timer(ctx, "k_fit_long_size");
+    hipLaunchKernelGGL(k_fit_long_blocks, dim3(n_long), dim3(MDB_WAVE), 0, stream, items, la);
+    if (args.eb.kind != MDB_EB_LOSSLESS) {
+        hipLaunchKernelGGL(k_fit_long<LONG_SPEC_VALUES>, dim3(n_blocks), dim3(MDB_WAVE), 0, stream, args, items, la, EncodeTargets{});
+        hipLaunchKernelGGL(k_fit_long_stitch<STITCH_VALUES>, dim3(n_long), dim3(MDB_WAVE), 0, stream, args, items, la, gap_results);
+    }
+    hipLaunchKernelGGL(k_fit_long<LONG_SPEC_SIZE>, dim3(n_blocks), dim3(MDB_WAVE), 0, stream, args, items, la, EncodeTargets{});
+    hipLaunchKernelGGL(k_fit_long_stitch<STITCH_WINDOWS>, dim3(n_long), dim3(MDB_WAVE), 0, stream, args, items, la, gap_results);
+}
+
+static void launch_long_encode(mdb_ctx *ctx, hipStream_t stream, const FitArgs &args, const SegItem *items, const LongArgs &la,
+                               const EncodeTargets &targets, uint32_t n_blocks) {
+    LaunchTimer timer(ctx, "k_fit_long_encode");
+    hipLaunchKernelGGL(k_fit_long_clear, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, args, la, targets);
+    hipLaunchKernelGGL(k_fit_long<LONG_WRITE>, dim3(n_blocks), dim3(MDB_WAVE), 0, stream, args, items, la, targets);
 }
 
 // MDB_FIT_FAST=0: the plain forms of PMC-Mean and Swing in k_fit_models even where the fast ones apply.
@@ -3719,31 +4305,62 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         // Long lossless MacaqueV-only segments: one wave each (k_fit_gap), sized here, written below.
         uint32_t *gap_ids = nullptr, *n_gaps = nullptr;
         uint32_t gap_waves = 0;
+        LongArgs long_args;
+        uint32_t long_segments = 0, long_blocks = 0;
         const uint32_t gap_min_values = gap_min_values_setting();
         if (n_segments > 0 && gap_min_values != 0xffffffffu) {
             const uint64_t most = std::min<uint64_t>(n_segments, points_end / gap_min_values + 1);
-            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP, n_segments * sizeof(GapResult) + most * 4 + 256, &p));
+            FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP, n_segments * sizeof(GapResult) + most * 4 + 512, &p));
             GapResult *gap_results = static_cast<GapResult *>(p);
             gap_ids = reinterpret_cast<uint32_t *>(gap_results + n_segments);
             n_gaps = gap_ids + align_up(most, 64);
             gap_waves = (uint32_t)most;
             args.gap_min_values = gap_min_values;
             args.gap_results = gap_results;
-            FIT_CHECK(hipMemsetAsync(n_gaps, 0, 4, ctx->stream));
+            // The longest of them are cut into blocks (k_fit_long*): listed apart, with room for their blocks.
+            LongCounters *counters = reinterpret_cast<LongCounters *>(n_gaps); // ([0] is the gap list's counter)
+            long_args.long_min_values = std::max(gap_long_min_values_setting(), gap_min_values);
+            long_args.block_min_values = gap_block_values_setting();
+            args.gap_long_min_values = long_args.long_min_values;
+            const uint64_t most_long = long_args.long_min_values == 0xffffffffu
+                                           ? 0
+                                           : std::min<uint64_t>(n_segments, points_end / long_args.long_min_values + 1);
+            if (most_long > 0) {
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_LONG_IDS, 3 * 4 * most_long, &p));
+                long_args.long_ids = static_cast<uint32_t *>(p);
+                long_args.long_block_base = long_args.long_ids + most_long;
+                long_args.long_batch_base = long_args.long_block_base + most_long;
+            }
+            long_args.counters = counters;
+            FIT_CHECK(hipMemsetAsync(counters, 0, sizeof(LongCounters), ctx->stream));
             {
                 LaunchTimer timer(ctx, "k_fit_gap_select");
                 hipLaunchKernelGGL(k_fit_gap_select, dim3(segment_blocks), dim3(256), 0, ctx->stream, args, items,
                                    (uint64_t)n_segments, gap_ids, n_gaps);
+                if (most_long > 0)
+                    hipLaunchKernelGGL(k_fit_long_select, dim3(segment_blocks), dim3(256), 0, ctx->stream, args, items,
+                                       (uint64_t)n_segments, long_args, counters);
             }
-            // How many there are decides the launch (usually none, and then nothing is launched).
-            uint32_t found = 0;
-            FIT_CHECK(hipMemcpyAsync(&found, n_gaps, 4, hipMemcpyDeviceToHost, ctx->stream));
+            // How many there are decides the launches (usually none, and then nothing is launched).
+            LongCounters found{};
+            FIT_CHECK(hipMemcpyAsync(&found, counters, sizeof(LongCounters), hipMemcpyDeviceToHost, ctx->stream));
             FIT_CHECK(hipStreamSynchronize(ctx->stream));
-            gap_waves = found;
+            gap_waves = found.n_gaps;
+            long_segments = found.n_long;
+            long_blocks = found.n_blocks;
             if (gap_waves > 0) {
                 LaunchTimer timer(ctx, "k_fit_gap_size");
                 hipLaunchKernelGGL(k_fit_gap<false>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                    gap_ids, n_gaps, gap_results, EncodeTargets{});
+            }
+            if (long_segments > 0) {
+                const uint64_t block_bytes = align_up((uint64_t)long_blocks * sizeof(GapBlock), 256);
+                const uint64_t prefix_bytes = align_up((uint64_t)found.n_batches * sizeof(GapBatchNote), 256);
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_LONG, block_bytes + prefix_bytes + (uint64_t)found.n_batches * 8, &p));
+                long_args.blocks = static_cast<GapBlock *>(p);
+                long_args.batch_notes = reinterpret_cast<GapBatchNote *>(static_cast<uint8_t *>(p) + block_bytes);
+                long_args.batch_breakers = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(p) + block_bytes + prefix_bytes);
+                launch_long_sizing(ctx, ctx->stream, args, items, long_args, gap_results, long_segments, long_blocks);
             }
         }
         // Segments of irregular chunks: their timestamps are sized (and below, written) by a wave each.
@@ -3852,6 +4469,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                gap_ids, n_gaps, const_cast<GapResult *>(args.gap_results), targets);
         }
+        if (long_segments > 0) launch_long_encode(ctx, ctx->stream, args, items, long_args, targets, long_blocks);
         if (ts_by_wave) { // before k_fit_encode as well
             LaunchTimer timer(ctx, "k_fit_timestamps_encode");
             hipLaunchKernelGGL(k_fit_timestamps<true>, dim3((uint32_t)n_segments), dim3(MDB_WAVE), 0, ctx->stream, args,
@@ -3982,6 +4600,15 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
     const uint64_t d_segment_base = carve(8 * (n_chunks + 1)), d_items = carve(sizeof(SegItem) * segment_bound);
     const uint64_t d_sizes = carve(sizeof(SegSizes) * segment_bound), d_data_offsets = carve(3 * 8 * (segment_bound + 1));
     const uint64_t d_gap_results = carve(sizeof(GapResult) * segment_bound), d_gap_ids = carve(4 * gap_bound);
+    // (the long MacaqueV-only segments, cut into blocks: k_fit_long*; upper bounds again)
+    const uint32_t long_min_values = std::max(gap_long_min_values_setting(), GAP_DEFAULT_MIN_VALUES);
+    const uint32_t block_min_values = gap_block_values_setting();
+    const uint64_t long_bound = long_min_values == 0xffffffffu ? 0 : total / long_min_values + 1;
+    const uint64_t long_blocks_bound = long_bound ? total / block_min_values + long_bound : 0;
+    const uint64_t long_batches_bound = long_bound ? total / MDB_WAVE + total / 4096 + long_bound * (block_min_values / MDB_WAVE) + 64 : 0;
+    const uint64_t d_long_ids = carve(3 * 4 * long_bound), d_long_blocks = carve(sizeof(GapBlock) * long_blocks_bound);
+    const uint64_t d_long_prefix = carve(sizeof(GapBatchNote) * long_batches_bound);
+    const uint64_t d_long_breakers = carve(eb.kind != MDB_EB_LOSSLESS ? 8 * long_batches_bound : 0);
     const uint64_t d_targets = carve(sizeof(EncodeTargets));
     const uint64_t d_blob = carve(blob_capacity);
     const uint64_t device_bytes = cursor;
@@ -4026,6 +4653,7 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
     args.eb = eb;
     args.gap_min_values = GAP_DEFAULT_MIN_VALUES;
     args.gap_results = reinterpret_cast<const GapResult *>(dev + d_gap_results);
+    args.gap_long_min_values = long_min_values;
     args.ts_results = nullptr;
     args.n_segments_dev = reinterpret_cast<const unsigned long long *>(dev + d_n_segments);
     args.targets_dev = reinterpret_cast<const EncodeTargets *>(dev + d_targets);
@@ -4075,6 +4703,21 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
         hipLaunchKernelGGL(k_fit_gap<false>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
                            gap_results, EncodeTargets{});
     }
+    LongArgs long_args;
+    if (long_bound > 0) {
+        long_args.counters = reinterpret_cast<const LongCounters *>(n_gaps); // ([0] is the gap list's counter; zeroed)
+        long_args.long_ids = reinterpret_cast<uint32_t *>(dev + d_long_ids);
+        long_args.long_block_base = long_args.long_ids + long_bound;
+        long_args.long_batch_base = long_args.long_block_base + long_bound;
+        long_args.blocks = reinterpret_cast<GapBlock *>(dev + d_long_blocks);
+        long_args.batch_notes = reinterpret_cast<GapBatchNote *>(dev + d_long_prefix);
+        long_args.batch_breakers = reinterpret_cast<unsigned long long *>(dev + d_long_breakers);
+        long_args.long_min_values = long_min_values;
+        long_args.block_min_values = block_min_values;
+        hipLaunchKernelGGL(k_fit_long_select, dim3((uint32_t)((segment_bound + 255) / 256)), dim3(256), 0, stream, args, items,
+                           (uint64_t)0, long_args, reinterpret_cast<LongCounters *>(n_gaps));
+        launch_long_sizing(ctx, stream, args, items, long_args, gap_results, (uint32_t)long_bound, (uint32_t)long_blocks_bound);
+    }
     const uint32_t segment_blocks = (uint32_t)((segment_bound + FIT_SEGMENT_THREADS - 1) / FIT_SEGMENT_THREADS);
     {
         LaunchTimer timer(ctx, "k_fit_size");
@@ -4092,6 +4735,7 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
         LaunchTimer timer(ctx, "k_fit_encode");
         hipLaunchKernelGGL(k_fit_gap<true>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
                            gap_results, EncodeTargets{});
+        if (long_bound > 0) launch_long_encode(ctx, stream, args, items, long_args, EncodeTargets{}, (uint32_t)long_blocks_bound);
         hipLaunchKernelGGL(k_fit_encode, dim3(segment_blocks), dim3(FIT_SEGMENT_THREADS), 0, stream, args, record_base_dev, records,
                            items, (uint64_t)0, sizes, EncodeTargets{});
     }
