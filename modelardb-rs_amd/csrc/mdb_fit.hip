@@ -2293,7 +2293,10 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 //     before, not kilobytes per model), twice as many every time the walk leaves its stretch by less than four times
 //     its length, up to WALK_STRETCH;
 //   * a model costs no trip: its start, end and type go to a list in LDS, and when 64 are listed (or the chunk is
-//     through) every lane fetches one model's parameters and writes its record.
+//     through) every lane fetches one model's parameters and writes its record;
+//   * a walk that has reached the longest stretch asks for the stretch behind it while it walks this one (the entries
+//     wait in registers), and knows of every 64 staged entries whether any is something else than rejected: a chunk of
+//     10^6 points of noise - one MacaqueV segment - is 512 stretches that are looked at once each, not 16 384 groups.
 constexpr uint32_t WALK_STRETCH = 2048; // entries staged at most (8 KB of LDS per wave)
 #ifdef MDB_WALK_DEBUG
 __device__ unsigned long long g_walk_counts[8];
@@ -2326,6 +2329,10 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
     GapCounter gaps;
     uint32_t position = 0;
     uint32_t stretch_first = 0, stretch_size = 0, next_size = MDB_WAVE;
+    constexpr uint32_t GROUPS = WALK_STRETCH / MDB_WAVE;
+    uint32_t ahead[GROUPS];                 // the stretch behind the staged one, asked for while this one is walked
+    uint32_t ahead_first = 0xffffffffu, ahead_size = 0;
+    uint32_t live_groups = 0;               // bit g: entries [64 g, 64 g + 64) of the stretch hold something not rejected
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2363,7 +2370,29 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
             stretch_first = position;
             stretch_size = min(next_size, n - position);
             wave_sync(); // (nobody reads the old stretch any more)
-            for (uint32_t k = lane; k < stretch_size; k += MDB_WAVE) staged[k] = split.entry[base + position + k];
+            live_groups = 0;
+            if (position == ahead_first && stretch_size == ahead_size) { // (asked for a stretch ago)
+#pragma unroll
+                for (uint32_t g = 0; g < GROUPS; g++) {
+                    const uint32_t k = g * MDB_WAVE + lane;
+                    if (k < stretch_size) staged[k] = ahead[g];
+                    if (__ballot(k < stretch_size && ahead[g] != ENTRY_REJECTED)) live_groups |= 1u << g;
+                }
+            } else {
+                for (uint32_t g = 0; g * MDB_WAVE < stretch_size; g++) {
+                    const uint32_t k = g * MDB_WAVE + lane;
+                    const uint32_t entry = k < stretch_size ? split.entry[base + position + k] : ENTRY_REJECTED;
+                    if (k < stretch_size) staged[k] = entry;
+                    if (__ballot(entry != ENTRY_REJECTED)) live_groups |= 1u << g;
+                }
+            }
+            ahead_first = 0xffffffffu;
+            if (stretch_size == WALK_STRETCH && n - (position + WALK_STRETCH) >= WALK_STRETCH) {
+                ahead_first = position + WALK_STRETCH;
+                ahead_size = WALK_STRETCH;
+#pragma unroll
+                for (uint32_t g = 0; g < GROUPS; g++) ahead[g] = split.entry[base + ahead_first + g * MDB_WAVE + lane];
+            }
             wave_sync();
         }
         const uint32_t at = position - stretch_first;
@@ -2371,6 +2400,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
         if (entry == ENTRY_REJECTED) {
             // A run of rejected points (noise under a lossless bound rejects every point) is skipped 64 at a
             // time: to the first entry of the next 64 staged ones that is something else.
+            // (whole groups of nothing but rejected points first: one look at the stretch's mask)
+            if ((at & (MDB_WAVE - 1)) == 0u) {
+                const uint32_t from_here = live_groups >> (at / MDB_WAVE);
+                const uint32_t skipped = from_here ? (uint32_t)__ffs((int)from_here) - 1u : (stretch_size - at + MDB_WAVE - 1) / MDB_WAVE;
+                if (skipped > 0) {
+                    position = min(stretch_first + stretch_size, position + skipped * (uint32_t)MDB_WAVE);
+                    continue;
+                }
+            }
             const uint32_t mine = at + (uint32_t)lane;
             const unsigned long long others = __ballot(mine < stretch_size && staged[mine] != ENTRY_REJECTED);
             position = others ? position + (uint32_t)__ffsll((long long)others) - 1u
