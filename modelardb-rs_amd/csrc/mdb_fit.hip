@@ -2365,30 +2365,36 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
         if (position < stretch_first || position - stretch_first >= stretch_size) {
             // (dense: the walk has come no further than four stretches from where the last one began - rejected points,
             // or models that are short against what is staged)
-            const bool dense = stretch_size > 0 && position >= stretch_first && position - stretch_first <= 4u * stretch_size;
-            next_size = dense ? min(2u * next_size, WALK_STRETCH) : (uint32_t)MDB_WAVE;
-            stretch_first = position;
-            stretch_size = min(next_size, n - position);
+            const bool asked_for = ahead_first != 0xffffffffu && position >= ahead_first && position - ahead_first < ahead_size;
+            if (asked_for) { // (the stretch behind the last one, asked for while that one was walked)
+                stretch_first = ahead_first;
+                stretch_size = ahead_size;
+            } else {
+                const bool dense = stretch_size > 0 && position >= stretch_first && position - stretch_first <= 4u * stretch_size;
+                next_size = dense ? min(2u * next_size, WALK_STRETCH) : (uint32_t)MDB_WAVE;
+                stretch_first = position;
+                stretch_size = min(next_size, n - position);
+            }
             wave_sync(); // (nobody reads the old stretch any more)
             live_groups = 0;
-            if (position == ahead_first && stretch_size == ahead_size) { // (asked for a stretch ago)
+            if (!asked_for) { // (all loads first, then what depends on them)
 #pragma unroll
                 for (uint32_t g = 0; g < GROUPS; g++) {
                     const uint32_t k = g * MDB_WAVE + lane;
+                    ahead[g] = k < stretch_size ? split.entry[base + stretch_first + k] : ENTRY_REJECTED;
+                }
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < GROUPS; g++) {
+                const uint32_t k = g * MDB_WAVE + lane;
+                if (g * MDB_WAVE < stretch_size) { // (uniform)
                     if (k < stretch_size) staged[k] = ahead[g];
                     if (__ballot(k < stretch_size && ahead[g] != ENTRY_REJECTED)) live_groups |= 1u << g;
                 }
-            } else {
-                for (uint32_t g = 0; g * MDB_WAVE < stretch_size; g++) {
-                    const uint32_t k = g * MDB_WAVE + lane;
-                    const uint32_t entry = k < stretch_size ? split.entry[base + position + k] : ENTRY_REJECTED;
-                    if (k < stretch_size) staged[k] = entry;
-                    if (__ballot(entry != ENTRY_REJECTED)) live_groups |= 1u << g;
-                }
             }
             ahead_first = 0xffffffffu;
-            if (stretch_size == WALK_STRETCH && n - (position + WALK_STRETCH) >= WALK_STRETCH) {
-                ahead_first = position + WALK_STRETCH;
+            if (stretch_size == WALK_STRETCH && n - stretch_first >= 2u * WALK_STRETCH) {
+                ahead_first = stretch_first + WALK_STRETCH;
                 ahead_size = WALK_STRETCH;
 #pragma unroll
                 for (uint32_t g = 0; g < GROUPS; g++) ahead[g] = split.entry[base + ahead_first + g * MDB_WAVE + lane];
@@ -4345,6 +4351,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         uint32_t gap_waves = 0;
         LongArgs long_args;
         uint32_t long_segments = 0, long_blocks = 0;
+        bool long_in_blocks = false; // (false: the long ones take a wave each like the others, listed apart)
         const uint32_t gap_min_values = gap_min_values_setting();
         if (n_segments > 0 && gap_min_values != 0xffffffffu) {
             const uint64_t most = std::min<uint64_t>(n_segments, points_end / gap_min_values + 1);
@@ -4391,7 +4398,19 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 hipLaunchKernelGGL(k_fit_gap<false>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                    gap_ids, n_gaps, gap_results, EncodeTargets{});
             }
-            if (long_segments > 0) {
+            // Blocks are for calls with too few streams to occupy the device with a wave each: 10^3 streams of 50 000
+            // values are fitted in 1.7 ms cut into blocks and 2.7 ms with a wave each, 10^4 in 7.2 against 6.7 (the
+            // blocks' notes and the second look at every block's first batch are work the one wave does not do).
+            // (MDB_FIT_GAP_LONG_BELOW_WAVES: the number of streams from which a wave each is enough; default 16 per compute unit)
+            uint64_t enough_waves = (uint64_t)std::max(ctx->compute_units, 1) * 16u;
+            if (const char *text = option_text("MDB_FIT_GAP_LONG_BELOW_WAVES")) enough_waves = (uint64_t)std::max(0ll, std::atoll(text));
+            long_in_blocks = long_segments > 0 && (uint64_t)gap_waves + long_segments < enough_waves;
+            if (long_segments > 0 && !long_in_blocks) {
+                LaunchTimer timer(ctx, "k_fit_gap_size");
+                hipLaunchKernelGGL(k_fit_gap<false>, dim3(long_segments), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                                   long_args.long_ids, &counters->n_long, gap_results, EncodeTargets{});
+            }
+            if (long_in_blocks) {
                 const uint64_t block_bytes = align_up((uint64_t)long_blocks * sizeof(GapBlock), 256);
                 const uint64_t prefix_bytes = align_up((uint64_t)found.n_batches * sizeof(GapBatchNote), 256);
                 FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_LONG, block_bytes + prefix_bytes + (uint64_t)found.n_batches * 8, &p));
@@ -4507,7 +4526,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                gap_ids, n_gaps, const_cast<GapResult *>(args.gap_results), targets);
         }
-        if (long_segments > 0) launch_long_encode(ctx, ctx->stream, args, items, long_args, targets, long_blocks);
+        if (long_in_blocks) {
+            launch_long_encode(ctx, ctx->stream, args, items, long_args, targets, long_blocks);
+        } else if (long_segments > 0) {
+            LaunchTimer timer(ctx, "k_fit_gap_encode");
+            hipLaunchKernelGGL(k_fit_gap<true>, dim3(long_segments), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                               long_args.long_ids, &long_args.counters->n_long, const_cast<GapResult *>(args.gap_results), targets);
+        }
         if (ts_by_wave) { // before k_fit_encode as well
             LaunchTimer timer(ctx, "k_fit_timestamps_encode");
             hipLaunchKernelGGL(k_fit_timestamps<true>, dim3((uint32_t)n_segments), dim3(MDB_WAVE), 0, ctx->stream, args,

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 SWITCHES = ("MDB_FIT_WAVE", "MDB_FIT_PIECE_POINTS", "MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_GAP_MIN_VALUES",
             "MDB_FIT_DATA_BUFFER_BYTES", "MDB_FIT_DEBUG", "MDB_FIT_SMALL", "MDB_FIT_GAP_LONG_MIN_VALUES",
-            "MDB_FIT_GAP_BLOCK_VALUES")
+            "MDB_FIT_GAP_BLOCK_VALUES", "MDB_FIT_GAP_LONG_BELOW_WAVES")
 
 
 @pytest.fixture(autouse=True)
@@ -145,3 +145,13 @@ def test_irregular_timestamps_of_a_long_segment(hip, monkeypatch):
 def test_the_switch_that_turns_the_blocks_off(hip, driver, monkeypatch):
     monkeypatch.setenv("MDB_FIT_GAP_LONG_MIN_VALUES", "off")
     check(hip, [(timestamps_of(20_000), stream("noise", 20_000, 1))], cases.LOSSLESS)
+
+
+def test_enough_streams_for_a_wave_each(hip, monkeypatch):
+    """A call with so many MacaqueV-only segments that a wave each occupies the device leaves the long ones whole (the
+    general driver decides by the count; here the line is moved so that two streams are "enough")."""
+    monkeypatch.setenv("MDB_FIT_SMALL", "0")
+    monkeypatch.setenv("MDB_FIT_GAP_LONG_BELOW_WAVES", "2")
+    chunks = [(timestamps_of(n), stream(kind, n, n)) for kind, n in (("noise", 20_000), ("coarse", 9000), ("runs", 300), ("noise", 8192))]
+    for eb in (cases.LOSSLESS, cases.error_bounds()["abs0.01"]):
+        check(hip, chunks, eb)
