@@ -560,15 +560,22 @@ def mixed_models(context, mdb, np, ora, args):
                 ("aggregates_between_quartiles", lambda: context.agg_batch_range_dev(segments, t_lo, t_hi, mask),
                  73.0 * len(segments) + payload_bytes / 2.0)):
             result = call()
-            context.profile_enable(True); context.profile_reset()
+            # The call as a caller gets it, then - its kernels bracketed by events one by one - where its time goes.
             timings = []
             for _ in range(5):
                 context.sync(); started = time.perf_counter()
                 result = call()
                 context.sync(); timings.append(time.perf_counter() - started)
             seconds = statistics.median(timings)
+            context.profile_enable(True); context.profile_reset()
+            profiled = []
+            for _ in range(3):
+                context.sync(); started = time.perf_counter()
+                call()
+                context.sync(); profiled.append(time.perf_counter() - started)
             shape[name] = {"ms": 1e3 * seconds, "values_per_s": n / seconds, "GB_per_s": algorithmic / seconds / 1e9,
                            "frac_of_hbm_peak": algorithmic / seconds / 1e9 / HBM_PEAK_GBPS,
+                           "ms_kernels_timed_one_by_one": 1e3 * statistics.median(profiled),
                            "kernels_ms": {k: round(v[1] / v[0], 3) for k, v in context.profile().items() if v[1] / v[0] > 0.05}}
             context.profile_enable(False)
             if name == "grid":

@@ -275,6 +275,7 @@ __device__ __forceinline__ uint4 load_global(const uint4 *pointer) { // (uint4 i
 struct DevCol {
     const uint4 *views;
     const uint8_t *const *buffers;
+    uint32_t n_buffers;
 };
 
 // Global-memory pointer to the bytes of row `row` (inline bytes live inside the view itself).
@@ -282,6 +283,17 @@ __device__ __forceinline__ const uint8_t *view_data(const DevCol &col, uint64_t 
                                                     const uint4 &view) {
     int32_t length = (int32_t)view.x;
     if (length <= 12) return reinterpret_cast<const uint8_t *>(col.views + row) + 4;
+    return col.buffers[(int32_t)view.z] + (int32_t)view.w;
+}
+
+// The same with the column's first data buffer already in hand (first_buffer(): a uniform load at the top of a kernel
+// that waits for nothing): most columns have ONE buffer, and looking its address up in the table only once the view is
+// known is a trip to memory in the middle of a chain of trips (cursor -> view -> table -> stream bytes).
+__device__ __forceinline__ const uint8_t *first_buffer(const DevCol &col) { return col.n_buffers > 0 ? col.buffers[0] : nullptr; }
+__device__ __forceinline__ const uint8_t *view_data(const DevCol &col, uint64_t row, const uint4 &view, const uint8_t *first) {
+    int32_t length = (int32_t)view.x;
+    if (length <= 12) return reinterpret_cast<const uint8_t *>(col.views + row) + 4;
+    if ((int32_t)view.z == 0) return first + (int32_t)view.w;
     return col.buffers[(int32_t)view.z] + (int32_t)view.w;
 }
 
@@ -318,11 +330,13 @@ inline DevSegments to_dev(const mdb_segments *s) {
     d.model_type_id = s->model_type_id;
     d.start_time = s->start_time;
     d.end_time = s->end_time;
-    d.timestamps = {reinterpret_cast<const uint4 *>(s->timestamps.views), s->timestamps.buffers};
+    d.timestamps = {reinterpret_cast<const uint4 *>(s->timestamps.views), s->timestamps.buffers,
+                    (uint32_t)std::max(s->timestamps.n_buffers, 0)};
     d.min_value = s->min_value;
     d.max_value = s->max_value;
-    d.values = {reinterpret_cast<const uint4 *>(s->values.views), s->values.buffers};
-    d.residuals = {reinterpret_cast<const uint4 *>(s->residuals.views), s->residuals.buffers};
+    d.values = {reinterpret_cast<const uint4 *>(s->values.views), s->values.buffers, (uint32_t)std::max(s->values.n_buffers, 0)};
+    d.residuals = {reinterpret_cast<const uint4 *>(s->residuals.views), s->residuals.buffers,
+                   (uint32_t)std::max(s->residuals.n_buffers, 0)};
     return d;
 }
 

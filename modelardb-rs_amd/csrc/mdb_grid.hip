@@ -1518,6 +1518,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
     [[maybe_unused]] const unsigned long long t_kernel = MVP_CLOCK();
     [[maybe_unused]] unsigned long long t_decode = 0, t_top_up = 0, n_top_up = 0, t_out = 0;
     const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
+    // (the columns' first data buffers, asked for before anything else: see view_data())
+    const uint8_t *values_first = first_buffer(s.values), *residuals_first = first_buffer(s.residuals);
     uint32_t count = 0, skip = 0; // values of this lane's piece to write, and how many in front of them are not wanted
     unsigned long long out_at = 0;
     PieceReader reader;
@@ -1551,7 +1553,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
             const DevCol &column = residual ? s.residuals : s.values;
             const uint4 view = column.views[i];
             const uint64_t nbytes = residual ? (uint64_t)view.x - 1u : (uint64_t)view.x;
-            reader.open(view_data(column, i, view), nbytes, c0.x);
+            reader.open(view_data(column, i, view, residual ? residuals_first : values_first), nbytes, c0.x);
             const bool macaque = (t.flags & FLAG_TYPE_MASK) == MDB_MACAQUE_V_ID;
             state.last = (macaque ? c1.z : __float_as_uint(t.value)) ^ c0.y;
             // (no window yet - leading 255 - is a window of no bits: the stream's first code opens one)
@@ -1661,6 +1663,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
     const int lane = threadIdx.x;
     const unsigned long long first_piece = (unsigned long long)blockIdx.x * MDB_WAVE;
     const unsigned long long piece = first_piece + lane;
+    const uint8_t *values_first = first_buffer(s.values), *residuals_first = first_buffer(s.residuals); // (see view_data())
     uint32_t to_decode = 0, segment = 0xffffffffu;
     bool residual = false, is_head = false, is_tail = false;
     PieceReader reader;
@@ -1689,7 +1692,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
         }
         const DevCol &column = residual ? s.residuals : s.values;
         const uint4 view = column.views[i];
-        reader.open(view_data(column, i, view), residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
+        reader.open(view_data(column, i, view, residual ? residuals_first : values_first),
+                    residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
         uint32_t seed = 0;
         if (residual) {
             const int32_t type = s.model_type_id[i];
@@ -3975,6 +3979,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRa
     __shared__ uint32_t ring[PIECE_RING_ROWS][MDB_WAVE];
     const int lane = threadIdx.x;
     const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
+    const uint8_t *values_first = first_buffer(s.values), *residuals_first = first_buffer(s.residuals); // (see view_data())
     RangePartial mine;
     mine.clear();
     uint32_t to_decode = 0, to_skip = 0;
@@ -4004,7 +4009,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_range(DevSegments s, TimeRa
                     to_skip = from - point_index;
                     const DevCol &column = residual ? s.residuals : s.values;
                     const uint4 view = column.views[i];
-                    reader.open(view_data(column, i, view), residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
+                    reader.open(view_data(column, i, view, residual ? residuals_first : values_first),
+                                residual ? (uint64_t)view.x - 1u : (uint64_t)view.x, c0.x);
                     state.last = seed ^ c0.y;
                     const uint32_t leading = window & 255u, trailing = (window >> 8) & 255u;
                     state.trailing = trailing & 31u;
