@@ -78,6 +78,7 @@ enum ScratchSlot {
     SCRATCH_AGG_CHAIN_LIST,
     SCRATCH_FIT_LONG_IDS,
     SCRATCH_FIT_LONG,
+    SCRATCH_FIT_ROTATION,
     SCRATCH_SLOT_COUNT
 };
 

@@ -1204,21 +1204,159 @@ __device__ __forceinline__ float ring_value(const float4 (*ring)[MDB_WAVE], int 
 // (f64)t and differences of such are exact: SwingFast's arithmetic on SwingDev's inputs). Their ring holds
 // pairs; with 24 bytes per point and lane instead of 4 the rings are half as long, so that as many waves
 // fit into a CU.
-template <bool SPLIT, int KIND, bool HAS_TS = false>
-__global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, SplitArgs split,
-                                                                const unsigned long long *__restrict__ record_base,
-                                                                ModelRec *__restrict__ records,
-                                                                ChunkPlan *__restrict__ plans,
-                                                                unsigned int *__restrict__ error) {
+//
+// ROTATE: a lane is a chunk, a wave 64 chunks that it steps through from their first point to their last - so a call's
+// waves are indivisible, and 2 391 of them (the bench's 153 000 chunks) on 1 024 SIMDs mean that 343 SIMDs hold three
+// and 681 two: a wave that shares its SIMD with two others steps at 0.85 of the rate of one that shares it with one
+// (measured: 2 048 waves take the 2 391 groups through in 62.9 ms, 2 391 waves in 63.7), the call lasts as long as
+// the slow ones, and the fast ones' SIMDs idle at its end. With ROTATE a wave works on a group for a STRETCH of steps
+// only: it then writes the lanes' fitters to memory (LeanSaved: 120 bytes a lane), puts the group at the tail of a
+// queue and takes the one at its head - the one that has waited longest. There are a few waves fewer than groups, so
+// no wave ever waits and a handful of groups do: every group is on a slow SIMD for its share of stretches and on a
+// fast one for the rest, and they all end together (63.9 -> 54.4 ms for the bench's call, stretches of 512 steps;
+// docs/NOTES_r05.md has the sweep). The ring needs no saving: a lane whose next point lies outside what its ring
+// holds starts the ring again at that point.
+struct LeanSaved { // one lane's state between two stretches
+    uint32_t n_models, current, j, pmc_length, swing_length;
+    uint32_t gaps_have_previous, gaps_previous_end, gaps_segments;
+    float pmc_min, pmc_max;
+    double pmc_sum, swing_start, swing_first, upper_slope, upper_intercept, lower_slope, lower_intercept, numerator,
+        denominator, swing_end;
+};
+static_assert(sizeof(LeanSaved) == 120, "LeanSaved is sized by hand");
+constexpr int LEAN_SAVED_WORDS = sizeof(LeanSaved) / 8;
+
+// A group's saved state goes from one wave to another - on another XCD with an L2 of its own, as likely as not - many
+// times a kernel. It is written and read as 64-bit words with device-scope atomic stores and loads (written through the
+// L2, read past what the L2 holds), so that a handover needs no write-back and no invalidation of a whole L2 (that is
+// what a device-scope fence is on this part: with one on either side of every handover the L2s were emptied every few
+// microseconds, and the kernel's other waves paid for it). Laid out [group][word][lane]: a wave's store of one word is
+// 512 consecutive bytes.
+__device__ __forceinline__ void lean_saved_store(unsigned long long *saved, uint32_t group, int lane, const LeanSaved &state) {
+    unsigned long long words[LEAN_SAVED_WORDS];
+    __builtin_memcpy(words, &state, sizeof(LeanSaved));
+    unsigned long long *at = saved + (uint64_t)group * (LEAN_SAVED_WORDS * MDB_WAVE) + lane;
+#pragma unroll
+    for (int w = 0; w < LEAN_SAVED_WORDS; w++) __hip_atomic_store(at + w * MDB_WAVE, words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ LeanSaved lean_saved_load(const unsigned long long *saved, uint32_t group, int lane) {
+    unsigned long long words[LEAN_SAVED_WORDS];
+    const unsigned long long *at = saved + (uint64_t)group * (LEAN_SAVED_WORDS * MDB_WAVE) + lane;
+#pragma unroll
+    for (int w = 0; w < LEAN_SAVED_WORDS; w++) words[w] = __hip_atomic_load(at + w * MDB_WAVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    LeanSaved state;
+    __builtin_memcpy(&state, words, sizeof(LeanSaved));
+    return state;
+}
+
+struct LeanRotation {
+    unsigned int *ready = nullptr;          // the queue's slots: a group's number + 1, or 0
+    uint32_t slot_mask = 0;                 // slots - 1 (a power of two, more than groups + waves)
+    unsigned int *counters = nullptr;       // [0] places taken at the queue's head, [1] places given at its tail, [2] groups through
+    uint32_t n_groups = 0;
+    uint32_t stretch_steps = 0;
+    unsigned long long *saved = nullptr;    // [group][word of LeanSaved][lane]
+    unsigned long long *masks = nullptr;    // [group][4]: active, PMC-Mean fits, Swing fits, Swing's first value finite
+};
+constexpr int LEAN_MASK_WORDS = 4;
+constexpr uint32_t LEAN_STRETCH_STEPS = 512; // (256 to 1 024 are within a percent of each other; 128 and 4 096 cost 6 %)
+
+// The queue begins with every group in it, in order.
+__global__ void k_fit_rotation_begin(LeanRotation rotation) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot <= rotation.slot_mask) rotation.ready[slot] = slot < rotation.n_groups ? slot + 1u : 0u;
+    if (slot < rotation.n_groups) {
+        unsigned long long *group_masks = rotation.masks + (uint64_t)slot * LEAN_MASK_WORDS;
+        group_masks[0] = ~0ull; // (of the lanes that have points: the kernel knows which)
+        group_masks[1] = ~0ull;
+        group_masks[2] = ~0ull;
+        group_masks[3] = 0ull;
+    }
+    // Every lane's fitters as they are before a chunk's first point: a group is "restored" the first time as well
+    // (one way into the kernel's loop, not two).
+    if (slot < (uint64_t)rotation.n_groups * MDB_WAVE) {
+        const double nan64 = __longlong_as_double(0x7ff8000000000000ll);
+        const float nan32 = __uint_as_float(0x7fc00000u);
+        LeanSaved fresh;
+        fresh.n_models = fresh.current = fresh.j = fresh.pmc_length = fresh.swing_length = 0u;
+        fresh.gaps_have_previous = fresh.gaps_previous_end = fresh.gaps_segments = 0u;
+        fresh.pmc_min = fresh.pmc_max = nan32;
+        fresh.pmc_sum = 0.0;
+        fresh.swing_start = 0.0;
+        fresh.swing_first = nan64;
+        fresh.upper_slope = fresh.upper_intercept = fresh.lower_slope = fresh.lower_intercept = nan64;
+        fresh.numerator = fresh.denominator = 0.0;
+        fresh.swing_end = 0.0;
+        lean_saved_store(rotation.saved, slot / MDB_WAVE, (int)(slot % MDB_WAVE), fresh);
+    }
+
+    if (slot == 0) {
+        rotation.counters[0] = 0u;
+        rotation.counters[1] = rotation.n_groups;
+        rotation.counters[2] = 0u;
+    }
+}
+
+// The queue, a place at a time: a wave takes the next place at the head and waits for the group that is - or will be -
+// put there (0xffffffff: every group is through); a wave that has worked on a group for a stretch puts it at the tail.
+// (Functions of their own, not inlined: the loop they are called from is long enough.)
+__device__ __noinline__ uint32_t rotation_take(const LeanRotation rotation) {
+    unsigned int taken = 0;
+    if (threadIdx.x % MDB_WAVE == 0) {
+        const unsigned int place = atomicAdd(&rotation.counters[0], 1u);
+        unsigned int *slot = rotation.ready + (place & rotation.slot_mask);
+        for (;;) {
+            // (a look, not an atomic, while there is nothing: hundreds of waves wait at any time, and a stretch takes
+            // milliseconds - a look every few microseconds is early enough and leaves the memory system alone)
+            if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                taken = atomicExch(slot, 0u); // (nobody else waits at this place)
+                break;
+            }
+            if (__hip_atomic_load(&rotation.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rotation.n_groups) break;
+            for (int nap = 0; nap < 4; nap++) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    taken = (unsigned int)__builtin_amdgcn_readfirstlane((int)taken);
+    // (No fence: what the wave that had the group before wrote about it is read with device-scope loads, and those
+    // are issued after the look at the slot has come back.)
+    return taken - 1u;
+}
+
+__device__ __noinline__ void rotation_give(const LeanRotation rotation, uint32_t group) {
+    // Everything written about the group (device-scope stores, written through) has arrived before it can be taken
+    // again: the wave waits for its stores, no more (see lean_saved_store for the fence this is instead of).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x % MDB_WAVE == 0) {
+        const unsigned int place = atomicAdd(&rotation.counters[1], 1u);
+        __hip_atomic_store(rotation.ready + (place & rotation.slot_mask), group + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ LaneMask uniform_mask(unsigned long long loaded) {
+    const uint32_t low = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)loaded);
+    const uint32_t high = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(loaded >> 32));
+    return ((LaneMask)high << 32) | low;
+}
+
+// One group of 64 chunks (ROTATE: for a stretch): the kernel's body; the plain kernel is this function and nothing
+// else, the rotating one calls it for group after group. Its loop over the steps has to come out of the compiler as
+// in the plain kernel, and three things see to that (each of them cost a fifth to a half of the kernel's time while it
+// was missing): the group's number and the lane masks read from memory go through readfirstlane (they are in scalar
+// registers as blockIdx.x and constants are), the state is loaded whether the group has been begun or not (one way
+// into the loop: k_fit_rotation_begin writes a fresh state for every group), and the loop has ONE exit, its condition
+// (a `break` at the stretch's end made the compiler copy the lanes' whole state from register to register every step).
+template <bool SPLIT, int KIND, bool HAS_TS, bool ROTATE>
+__device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs &split,
+                                           const unsigned long long *__restrict__ record_base, ModelRec *__restrict__ records,
+                                           ChunkPlan *__restrict__ plans, unsigned int *__restrict__ error,
+                                           const LeanRotation &rotation, float4 (*ring)[MDB_WAVE], longlong2 (*ring_ts)[MDB_WAVE],
+                                           const int lane, const uint32_t group_of_wave) {
     static_assert(KIND == MDB_EB_RELATIVE || KIND == MDB_EB_ABSOLUTE || KIND == MDB_EB_LOSSLESS, "an error bound's kind");
     constexpr int LEAN_GROUPS = HAS_TS ? 4 : mdb::LEAN_GROUPS; // (shadow the constants of the values-only form)
     constexpr int LEAN_LOADS = HAS_TS ? 2 : mdb::LEAN_LOADS;
     constexpr int LEAN_TRASH = LEAN_GROUPS;
-    __shared__ float4 ring[LEAN_GROUPS + 1][MDB_WAVE];
-    // Timestamps of the points of value group g: pairs 2g and 2g + 1 (row 2 * LEAN_GROUPS and the one behind it: trash).
-    __shared__ longlong2 ring_ts[HAS_TS ? 2 * LEAN_GROUPS + 2 : 1][MDB_WAVE];
-    const int lane = threadIdx.x;
-    const uint64_t unit = (uint64_t)blockIdx.x * FIT_THREADS + lane;
+    static_assert(!(ROTATE && SPLIT), "split mode's pieces are not rotated");
+    const uint64_t unit = (uint64_t)group_of_wave * FIT_THREADS + lane;
     uint64_t chunk = unit;
     bool active = unit < (SPLIT ? split.n_pieces : args.n_chunks);
     uint32_t first_point = 0;
@@ -1287,6 +1425,41 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     LaneMask active_m = lanes_where(active);
     LaneMask pmc_fits_m = ~0ull, swing_fits_m = ~0ull, swing_finite_m = 0;
     const LaneMask pmc_fast_m = pmc_fast.enabled ? ~0ull : 0ull;
+    uint32_t steps_left = ROTATE ? rotation.stretch_steps : 0u;
+    if (ROTATE) {
+        // The group goes on where it was left (the first time: where k_fit_rotation_begin says; the ring starts at the lane's next point).
+        const unsigned long long *group_masks = rotation.masks + (uint64_t)group_of_wave * LEAN_MASK_WORDS;
+        {
+            const LeanSaved from = lean_saved_load(rotation.saved, group_of_wave, lane);
+            n_models = from.n_models;
+            current = from.current;
+            j = from.j;
+            pmc_length = from.pmc_length;
+            swing_length = from.swing_length;
+            gaps.have_previous = from.gaps_have_previous != 0u;
+            gaps.previous_end = from.gaps_previous_end;
+            gaps.n_segments = from.gaps_segments;
+            pmc_min = from.pmc_min;
+            pmc_max = from.pmc_max;
+            pmc_sum = from.pmc_sum;
+            swing_start = from.swing_start;
+            swing_first = from.swing_first;
+            upper_slope = from.upper_slope;
+            upper_intercept = from.upper_intercept;
+            lower_slope = from.lower_slope;
+            lower_intercept = from.lower_intercept;
+            numerator = from.numerator;
+            denominator = from.denominator;
+            swing_end = from.swing_end;
+            // (the same for every lane, and the compiler is to know it)
+            active_m &= uniform_mask(__hip_atomic_load(group_masks + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            pmc_fits_m = uniform_mask(__hip_atomic_load(group_masks + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            swing_fits_m = uniform_mask(__hip_atomic_load(group_masks + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            swing_finite_m = uniform_mask(__hip_atomic_load(group_masks + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            loaded_group = (j + misalign) >> 2;
+            low_group = loaded_group;
+        }
+    }
 #ifdef MDB_FIT_TIMING
 #ifdef MDB_FIT_TIMING_SPLIT // (the same regions in split mode: scripts/r04/build_timing.sh with -DMDB_FIT_TIMING_SPLIT)
     constexpr bool TIMED = SPLIT && KIND == MDB_EB_RELATIVE && !HAS_TS;
@@ -1297,7 +1470,7 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
     const unsigned long long timing_loop_t0 = __builtin_amdgcn_s_memtime(), timing_real_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    while (active_m != 0) {
+    while (active_m != 0 && (!ROTATE || steps_left != 0u)) { // (ROTATE: or the stretch is over)
 #ifdef MDB_FIT_TIMING
         timing_steps += 1;
         { FIT_TIMING_BEGIN(0); FIT_TIMING_END(0) }
@@ -1643,6 +1816,44 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
             swing_finite_m &= ~next_model_m;
             FIT_TIMING_END(5)
         }
+        if (ROTATE) steps_left -= 1u;
+    }
+    if (ROTATE) {
+        if (active_m != 0) {
+            // Not through: the lanes' fitters go to memory, the group to the end of the queue.
+            LeanSaved to;
+            to.n_models = n_models;
+            to.current = current;
+            to.j = j;
+            to.pmc_length = pmc_length;
+            to.swing_length = swing_length;
+            to.gaps_have_previous = gaps.have_previous ? 1u : 0u;
+            to.gaps_previous_end = gaps.previous_end;
+            to.gaps_segments = gaps.n_segments;
+            to.pmc_min = pmc_min;
+            to.pmc_max = pmc_max;
+            to.pmc_sum = pmc_sum;
+            to.swing_start = swing_start;
+            to.swing_first = swing_first;
+            to.upper_slope = upper_slope;
+            to.upper_intercept = upper_intercept;
+            to.lower_slope = lower_slope;
+            to.lower_intercept = lower_intercept;
+            to.numerator = numerator;
+            to.denominator = denominator;
+            to.swing_end = swing_end;
+            lean_saved_store(rotation.saved, group_of_wave, lane, to);
+            unsigned long long *group_masks = rotation.masks + (uint64_t)group_of_wave * LEAN_MASK_WORDS;
+            if (lane == 0) {
+                __hip_atomic_store(group_masks + 0, active_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(group_masks + 1, pmc_fits_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(group_masks + 2, swing_fits_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(group_masks + 3, swing_finite_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            rotation_give(rotation, group_of_wave);
+        } else if (lane == 0) {
+            atomicAdd(&rotation.counters[2], 1u);
+        }
     }
 #ifdef MDB_FIT_TIMING
     if (TIMED && lane == 0) {
@@ -1660,6 +1871,26 @@ __global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(FitArgs args, S
         }
     }
 #endif
+}
+
+template <bool SPLIT, int KIND, bool HAS_TS = false, bool ROTATE = false>
+__global__ __launch_bounds__(FIT_THREADS) void k_fit_models_lean(
+    FitArgs args, SplitArgs split, const unsigned long long *__restrict__ record_base, ModelRec *__restrict__ records,
+    ChunkPlan *__restrict__ plans, unsigned int *__restrict__ error, LeanRotation rotation) {
+    constexpr int LEAN_GROUPS = HAS_TS ? 4 : mdb::LEAN_GROUPS;
+    __shared__ float4 ring[LEAN_GROUPS + 1][MDB_WAVE];
+    // Timestamps of the points of value group g: pairs 2g and 2g + 1 (row 2 * LEAN_GROUPS and the one behind it: trash).
+    __shared__ longlong2 ring_ts[HAS_TS ? 2 * LEAN_GROUPS + 2 : 1][MDB_WAVE];
+    const int lane = threadIdx.x;
+    if (!ROTATE) {
+        lean_group<SPLIT, KIND, HAS_TS, false>(args, split, record_base, records, plans, error, rotation, ring, ring_ts, lane, blockIdx.x);
+        return;
+    }
+    for (;;) { // (group after group from the queue)
+        const uint32_t group_of_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)rotation_take(rotation)); // (in a scalar register, as blockIdx.x is)
+        if (group_of_wave == 0xffffffffu) return; // (every group is through)
+        lean_group<SPLIT, KIND, HAS_TS, ROTATE>(args, split, record_base, records, plans, error, rotation, ring, ring_ts, lane, group_of_wave);
+    }
 }
 
 // ---- k_fit_models_wave: one WAVE per chunk ---------------------------------------------------------------------
@@ -4194,22 +4425,63 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     do {                                                                                                                   \
         if (eb.kind == MDB_EB_RELATIVE)                                                                                    \
             hipLaunchKernelGGL((k_fit_models_lean<SPLIT, MDB_EB_RELATIVE, HAS_TS>), dim3(fit_blocks), dim3(FIT_THREADS), 0, \
-                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag);                    \
+                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag, LeanRotation{});    \
         else if (eb.kind == MDB_EB_ABSOLUTE)                                                                               \
             hipLaunchKernelGGL((k_fit_models_lean<SPLIT, MDB_EB_ABSOLUTE, HAS_TS>), dim3(fit_blocks), dim3(FIT_THREADS), 0, \
-                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag);                    \
+                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag, LeanRotation{});    \
         else                                                                                                               \
             hipLaunchKernelGGL((k_fit_models_lean<SPLIT, MDB_EB_LOSSLESS, HAS_TS>), dim3(fit_blocks), dim3(FIT_THREADS), 0, \
-                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag);                    \
+                               ctx->stream, args, SPLIT_ARGS, record_base, records, plans, error_flag, LeanRotation{});    \
     } while (0)
             if (lean_ts)
                 MDB_LAUNCH_LEAN(false, SplitArgs{}, true);
             else if (ts)
                 hipLaunchKernelGGL((k_fit_models<true, false, false>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
-            else if (lean)
-                MDB_LAUNCH_LEAN(false, SplitArgs{}, false);
-            else if (fast)
+            else if (lean) {
+                // Rotation (see k_fit_models_lean): when the groups of 64 chunks are not a whole number per SIMD, they
+                // are taken by a few waves fewer, in stretches. MDB_FIT_ROTATE: 0 never, 1 whenever it can be done;
+                // MDB_FIT_ROTATE_STEPS: steps per stretch.
+                const uint64_t simds = (uint64_t)std::max(ctx->compute_units, 1) * 4u, groups = fit_blocks;
+                const uint64_t per_simd = (groups + simds - 1) / simds; // waves the fullest SIMDs hold
+                const char *rotate_setting = option_text("MDB_FIT_ROTATE");
+                const bool forced = rotate_setting && std::strcmp(rotate_setting, "1") == 0;
+                const bool rotate = !(rotate_setting && std::strcmp(rotate_setting, "0") == 0) && groups >= 2 &&
+                                    (forced || (groups > simds && per_simd <= 4 && per_simd * simds - groups >= simds / 8));
+                LeanRotation rotation;
+                // A few waves fewer than groups: every wave has a group at all times, and the few groups that wait at
+                // any moment are what makes the groups change places.
+                const uint32_t rotating_blocks = (uint32_t)(groups - std::max<uint64_t>(1, groups / 128));
+                if (rotate) {
+                    rotation.n_groups = (uint32_t)groups;
+                    rotation.stretch_steps = LEAN_STRETCH_STEPS;
+                    if (const char *text = option_text("MDB_FIT_ROTATE_STEPS")) rotation.stretch_steps = (uint32_t)std::max(1ll, std::atoll(text));
+                    uint64_t slots = 64;
+                    while (slots < 2 * (groups + rotating_blocks)) slots <<= 1;
+                    rotation.slot_mask = (uint32_t)(slots - 1);
+                    const uint64_t ready_bytes = align_up(slots * 4, 256), saved_bytes = align_up(groups * MDB_WAVE * sizeof(LeanSaved), 256);
+                    const uint64_t mask_bytes = align_up(groups * LEAN_MASK_WORDS * 8, 256);
+                    void *q = nullptr;
+                    FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_ROTATION, 256 + ready_bytes + saved_bytes + mask_bytes, &q));
+                    uint8_t *at = static_cast<uint8_t *>(q);
+                    rotation.counters = reinterpret_cast<unsigned int *>(at);
+                    rotation.ready = reinterpret_cast<unsigned int *>(at + 256);
+                    rotation.saved = reinterpret_cast<unsigned long long *>(at + 256 + ready_bytes);
+                    rotation.masks = reinterpret_cast<unsigned long long *>(at + 256 + ready_bytes + saved_bytes);
+
+                    const uint64_t begin_threads = std::max<uint64_t>((uint64_t)rotation.slot_mask + 1, groups * MDB_WAVE);
+                    hipLaunchKernelGGL(k_fit_rotation_begin, dim3((uint32_t)((begin_threads + 255) / 256)), dim3(256), 0, ctx->stream, rotation);
+#define MDB_LAUNCH_ROTATING(KIND)                                                                                              \
+    hipLaunchKernelGGL((k_fit_models_lean<false, KIND, false, true>), dim3(rotating_blocks), dim3(FIT_THREADS), 0,             \
+                       ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag, rotation)
+                    if (eb.kind == MDB_EB_RELATIVE) MDB_LAUNCH_ROTATING(MDB_EB_RELATIVE);
+                    else if (eb.kind == MDB_EB_ABSOLUTE) MDB_LAUNCH_ROTATING(MDB_EB_ABSOLUTE);
+                    else MDB_LAUNCH_ROTATING(MDB_EB_LOSSLESS);
+#undef MDB_LAUNCH_ROTATING
+                } else {
+                    MDB_LAUNCH_LEAN(false, SplitArgs{}, false);
+                }
+            } else if (fast)
                 hipLaunchKernelGGL((k_fit_models<false, false, true>), dim3(fit_blocks), dim3(FIT_THREADS), 0,
                                    ctx->stream, args, SplitArgs{}, record_base, records, plans, error_flag);
             else
