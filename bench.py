@@ -364,12 +364,24 @@ def host_fit(context, mdb, np, ora, host_ts, values, offsets, eb, gpu_fitted):
     seconds = context.last_call_seconds
     if from_host.rows() != gpu_fitted.rows():
         raise SystemExit("VERIFICATION FAILED: the fit through host pointers differs from the device-resident one")
+    # Where such a call spends its time: a third call with the library's profile on (mdb_profile_get, "host:" names).
+    context.profile_enable(True)
+    context.profile_reset()
+    context.compress_chunk_list(chunks, eb)
+    phases = {name[len("host:chunk_list_"):] + "_ms": round(ms, 3) for name, (_, ms) in context.profile().items()
+              if name.startswith("host:chunk_list_")}
+    phases["kernels_ms"] = round(sum(ms for name, (_, ms) in context.profile().items() if not name.startswith("host:")), 3)
+    phases["call_ms"] = round(1e3 * context.last_call_seconds, 3)
+    context.profile_enable(False)
+    context.profile_reset()
     out = {"points_per_s": points / seconds, "segments_per_s": len(from_host) / seconds, "seconds": seconds,
-           "points": points, "chunks": n_chunks,
+           "points": points, "chunks": n_chunks, "phases_of_a_profiled_call": phases,
            "note": "mdb_compress_chunk_list over the chunks where they lie in host memory (12 B per point handed "
-                   "over; host threads gather the values into page-locked memory slice by slice while the previous "
-                   "slice crosses PCIe and find every chunk's timestamps equally spaced, so the timestamps never "
-                   "cross), segments downloaded; second of two calls; segments == the device-resident fit's"}
+                   "over; host threads gather the values into page-locked memory with streaming stores, slice by "
+                   "slice while the previous slice crosses PCIe, and find every chunk's timestamps equally spaced, so "
+                   "the timestamps never cross), segments downloaded; phases_of_a_profiled_call: gather = the threads' "
+                   "copies (the slices' copies to the device run behind them), upload_tail = what of those is left "
+                   "after the last slice, fit = kernels with their waits, download = the segments to the host; second of two calls; segments == the device-resident fit's"}
     # The reference's call shape: one call per finished buffer (uncompressed_data_manager.rs:505-596).
     per_buffer = chunks[:64]
     context.compress_chunk_list(per_buffer[:1], eb)

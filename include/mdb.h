@@ -315,7 +315,11 @@ int mdb_agg_merge(mdb_agg_state *into, const mdb_agg_state *from);
 /* When enabled every kernel launch is bracketed with hipEvents on the context's stream. */
 int mdb_profile_enable(mdb_ctx *ctx, int enabled);
 int mdb_profile_reset(mdb_ctx *ctx);
-/* Accumulated launches and milliseconds of kernel `name` since the last reset. */
+/* Accumulated launches and milliseconds of kernel `name` since the last reset. mdb_compress_chunk_list adds the host
+ * side of its calls under names that begin with "host:" (calls and wall-clock milliseconds): host:chunk_list_gather
+ * (the host threads' copies into page-locked memory, the copies to the device running behind them),
+ * host:chunk_list_upload_tail (what is left of those copies when the last slice is gathered), host:chunk_list_fit,
+ * host:chunk_list_download. */
 int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *total_ms);
 /* Names of all profiled kernels, '\n' separated. */
 int mdb_profile_names(mdb_ctx *ctx, char *out, uint64_t cap);

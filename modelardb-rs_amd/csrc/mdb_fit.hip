@@ -5260,10 +5260,10 @@ void gather_share(unsigned index, void *arg) {
         const mdb_chunk &chunk = job.chunks[c];
         if (chunk.n == 0) continue;
         if (job.stage_ts) {
-            std::memcpy(job.stage_ts + job.offsets[c], chunk.ts, 8 * chunk.n);
+            host_copy_streaming(job.stage_ts + job.offsets[c], chunk.ts, 8 * chunk.n);
             continue;
         }
-        std::memcpy(job.stage_values + job.offsets[c], chunk.values, 4 * chunk.n);
+        host_copy_streaming(job.stage_values + job.offsets[c], chunk.values, 4 * chunk.n);
         if (job.same_ts_as[c] != c) continue; // (checked with the chunk that had this array first)
         const int64_t *t = chunk.ts;
         job.first[c] = t[0];
@@ -5306,7 +5306,7 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
     const bool debug = option_text("MDB_FIT_DEBUG") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since_start = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    double t_gathered = 0.0, t_uploaded = 0.0, t_fitted = 0.0;
+    double t_gathered = 0.0, t_uploaded = 0.0, t_fitted = 0.0, t_in_gather = 0.0, t_in_copy_calls = 0.0;
     {
         mdb::CallGuard lock(ctx);
         MDB_HIP_CHECK(hipSetDevice(ctx->device));
@@ -5331,8 +5331,10 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
                 if (c == slice_first) c++; // (one chunk longer than a slice)
                 const uint64_t slice_end = offsets[c], slice_chunks = c - slice_first;
                 job.shares.clear();
-                const unsigned n_shares = (unsigned)std::min<uint64_t>(
-                    std::min<uint64_t>(width, slice_chunks), std::max<uint64_t>(1, (slice_end - slice_begin) >> 16));
+                // (Shares of about 128 K points, many more than threads: they are handed out one by one, and a thread
+                // that shares its core with something else for a while takes fewer.)
+                const unsigned n_shares = width <= 1 ? 1u : (unsigned)std::min<uint64_t>(
+                    slice_chunks, std::max<uint64_t>(1, (slice_end - slice_begin) >> 17));
                 uint64_t next = slice_first;
                 for (unsigned w = 0; w < n_shares; w++) {
                     const uint64_t target = slice_begin + (slice_end - slice_begin) * (w + 1) / n_shares;
@@ -5341,8 +5343,12 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
                     job.shares.push_back({next, last});
                     next = last;
                 }
+                const double t0 = since_start();
                 host_parallel((unsigned)job.shares.size(), gather_share, &job);
+                const double t1 = since_start();
                 copy_slice(slice_begin, slice_end);
+                t_in_gather += t1 - t0;
+                t_in_copy_calls += since_start() - t1;
             }
         };
         gather([&](uint64_t begin, uint64_t end) {
@@ -5395,9 +5401,27 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
     if (rc) return 1;
     rc = mdb_segments_download(ctx, dev, out);
     mdb_segments_free(dev);
+    {
+        // The call's host-side phases next to the kernels' times (mdb_profile_get, names with "host:").
+        mdb::CallGuard lock(ctx);
+        if (ctx->profiling) {
+            const double t_done = since_start();
+            const std::pair<const char *, double> phases[] = {
+                {"host:chunk_list_gather", t_in_gather},                  // the threads' copies into page-locked memory (the slices' copies to the device run behind them)
+                {"host:chunk_list_upload_tail", t_uploaded - t_gathered}, // what of the copies to the device is left when the last slice is gathered
+                {"host:chunk_list_fit", t_fitted - t_uploaded},
+                {"host:chunk_list_download", t_done - t_fitted}};
+            for (const auto &phase : phases) {
+                auto &entry = ctx->kernel_times[phase.first];
+                entry.launches += 1;
+                entry.total_ms += phase.second;
+            }
+        }
+    }
     if (debug)
-        std::fprintf(stderr, "mdb_compress_chunk_list: %llu chunks, %llu points: gathered %.2f ms, on the device %.2f, fitted %.2f, "
-                             "downloaded %.2f\n", (unsigned long long)n_chunks, (unsigned long long)total, t_gathered, t_uploaded,
+        std::fprintf(stderr, "mdb_compress_chunk_list: %llu chunks, %llu points: gathered %.2f ms (%.2f in the threads' copies, %.2f in "
+                             "the calls that start the slices' copies to the device), on the device %.2f, fitted %.2f, downloaded %.2f\n",
+                     (unsigned long long)n_chunks, (unsigned long long)total, t_gathered, t_in_gather, t_in_copy_calls, t_uploaded,
                      t_fitted, since_start());
     return rc;
 }

@@ -74,6 +74,8 @@ const char *option_text(const char *name);
 
 void host_parallel(unsigned n_shares, void (*share)(unsigned index, void *arg), void *arg);
 unsigned host_parallel_width();
+// memcpy with streaming stores: for blocks a core will not read again (staging for the copy engine). (mdb_pipeline.cpp)
+void host_copy_streaming(void *to, const void *from, size_t n_bytes);
 constexpr uint32_t MV_PIECE_VALUES = 64;
 constexpr uint32_t MV_WINDOW_RESIDUAL = 1u << 16; // the piece belongs to the residual tail
 constexpr uint32_t MV_WINDOW_RAW = 1u << 17;      // its first value is the stream's raw first value

@@ -171,6 +171,29 @@ void host_parallel(unsigned n_shares, void (*share)(unsigned, void *), void *arg
     HostPool::instance().run(n_shares, share, arg);
 }
 
+// A copy that leaves the caches alone (the staging block is read next by the copy engine, not by a core; and the lines
+// of a plain store would be read from memory first): 16-byte streaming stores, what every x86-64 has.
+void host_copy_streaming(void *to_bytes, const void *from_bytes, size_t n_bytes) {
+    unsigned char *to = static_cast<unsigned char *>(to_bytes);
+    const unsigned char *from = static_cast<const unsigned char *>(from_bytes);
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(to) & 15)) & 15;
+    if (head > n_bytes) head = n_bytes;
+    std::memcpy(to, from, head);
+    size_t i = head;
+    for (; i + 64 <= n_bytes; i += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(from + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(from + i + 16));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(from + i + 32));
+        const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(from + i + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i *>(to + i), a);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(to + i + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(to + i + 32), c);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(to + i + 48), d);
+    }
+    std::memcpy(to + i, from + i, n_bytes - i);
+    _mm_sfence();
+}
+
 int host_block_take(uint64_t bytes, void **out, uint64_t *capacity) {
     if (bytes == 0) bytes = 64;
     HostBlocks &pool = HostBlocks::instance();

@@ -444,3 +444,34 @@ def test_fit_chunk_list_gathers_chunks_where_they_lie(hip):
     assert len(hip.compress_chunk_list([], eb)) == 0
     with pytest.raises(mdb.HipError):
         hip.compress_chunk_list([(np.arange(3), np.zeros(2, np.float32))], eb)
+
+
+def test_fit_chunk_list_of_many_chunks_and_its_host_phases(hip, monkeypatch):
+    """More chunks than the few-chunks path takes, at odd addresses and lengths (the gather copies with 16-byte
+    streaming stores from wherever the chunks lie: heads and tails that are not 16 bytes), in slices; with the profile
+    on, the call's host-side phases are on record under "host:" names (include/mdb.h, mdb_profile_get)."""
+    monkeypatch.setenv("MDB_FIT_SMALL", "4")
+    eb = cases.error_bounds()["rel1"]
+    rng = np.random.default_rng(77)
+    backing = np.concatenate([datagen.sine_series(s, 40_000)[1] for s in range(12)])
+    chunks, at = [], 0
+    for k in range(150):
+        n = int(rng.integers(1, 6000))
+        at += int(rng.integers(0, 5))                      # (chunks begin at any multiple of four bytes)
+        if at + n > len(backing):
+            at = int(rng.integers(0, 7))
+        chunks.append((np.arange(n, dtype=np.int64) * 100 + k, backing[at:at + n]))
+        at += n
+    flat_ts = np.concatenate([ts for ts, _ in chunks])
+    flat_values = np.concatenate([v for _, v in chunks])
+    offsets = np.concatenate([[0], np.cumsum([len(v) for _, v in chunks])]).astype(np.uint64)
+    hip.profile_enable(True)
+    hip.profile_reset()
+    got = hip.compress_chunk_list(chunks, eb)
+    recorded = hip.profile()
+    hip.profile_enable(False)
+    hip.profile_reset()
+    assert_same_segments(got, ora.compress_chunks(flat_ts, flat_values, offsets, eb))
+    for phase in ("gather", "upload_tail", "fit", "download"):
+        calls, ms = recorded["host:chunk_list_" + phase]
+        assert calls == 1 and ms >= 0.0
