@@ -657,7 +657,7 @@ def fit_counters():
         pmc = json.load(f)
     if pmc.get("source_hash") != source_hash(FIT_KERNEL_SOURCES):
         return None, (f"the fit kernel sources changed since the SQ counter passes (measured {pmc.get('source_hash')}, "
-                      f"now {source_hash(FIT_KERNEL_SOURCES)}): rerun scripts/r04/pmc_fit.sh")
+                      f"now {source_hash(FIT_KERNEL_SOURCES)}): rerun scripts/r05/pmc_fit.sh")
     return pmc, None
 
 

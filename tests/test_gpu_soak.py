@@ -177,6 +177,41 @@ def test_cases_that_once_failed(hip):
         run_case(hip, index)
 
 
+# ---- calls of many chunks: the groups of 64 chunks rotating over the waves, long MacaqueV segments in blocks ----------
+
+ROTATING_CASES = int(os.environ.get("MDB_SOAK_ROTATING_CASES", "6"))
+
+
+def run_rotating_case(hip, index, monkeypatch):
+    """A call of 65 to 400 chunks with regular timestamps (k_fit_models_lean's regime: two to seven groups of 64
+    chunks) fitted in stretches of a random number of steps, the MacaqueV-only segments from 64 values on cut into
+    blocks of 64 - against the oracle, byte for byte."""
+    rng = np.random.default_rng([0x524F54, index])
+    n_chunks = int(rng.integers(65, 400))
+    lengths = [int(rng.choice([0, 1, 3, 40, 300, 2500]) * rng.uniform(0.3, 1.0)) for _ in range(n_chunks)]
+    values = np.concatenate([random_values(rng, n) if n else np.zeros(0, np.float32) for n in lengths] + [np.zeros(0, np.float32)])
+    interval = int(rng.choice([1, 1000, 60_000_000]))
+    timestamps = np.concatenate([int(rng.integers(0, 1 << 40)) + np.arange(n, dtype=np.int64) * interval for n in lengths]
+                                + [np.zeros(0, np.int64)])
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    eb = random_error_bound(rng)
+    monkeypatch.setenv("MDB_FIT_SMALL", "0")
+    monkeypatch.setenv("MDB_FIT_WAVE", "0")
+    monkeypatch.setenv("MDB_FIT_PIECE_POINTS", "1")
+    monkeypatch.setenv("MDB_FIT_ROTATE", "1")
+    monkeypatch.setenv("MDB_FIT_ROTATE_STEPS", str(int(rng.choice([1, 2, 9, 100, 512]))))
+    monkeypatch.setenv("MDB_FIT_GAP_LONG_MIN_VALUES", "64")
+    monkeypatch.setenv("MDB_FIT_GAP_BLOCK_VALUES", "64")
+    expected = ora.compress_chunks(timestamps, values, offsets, eb)
+    got = hip.compress_chunks(timestamps, values, offsets, eb)
+    assert_same_segments(got, expected)
+
+
+def test_soak_rotating_groups_and_blocks(hip, monkeypatch):
+    for index in range(ROTATING_CASES):
+        run_rotating_case(hip, index, monkeypatch)
+
+
 # ---- the host operators under random batching ------------------------------------------------------------
 
 HOST_CASES = int(os.environ.get("MDB_SOAK_HOST_CASES", "24"))
