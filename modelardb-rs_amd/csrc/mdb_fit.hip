@@ -2608,19 +2608,28 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
             }
             wave_sync(); // (nobody reads the old stretch any more)
             live_groups = 0;
-            if (!asked_for) { // (all loads first, then what depends on them)
+            if (stretch_size <= (uint32_t)MDB_WAVE) {
+                // (the stretch behind a long model - sine data pays this once per model: one load, not the unrolled
+                // thirty-two of the long stretch with all but one masked off; a lone wave issues an instruction every
+                // five cycles or so, and a 65 536-point buffer's walk was 0.18 ms instead of 0.08)
+                const uint32_t one = (uint32_t)lane < stretch_size ? split.entry[base + stretch_first + lane] : ENTRY_REJECTED;
+                if ((uint32_t)lane < stretch_size) staged[lane] = one;
+                live_groups = __ballot(one != ENTRY_REJECTED) ? 1u : 0u;
+            } else {
+                if (!asked_for) { // (all loads first, then what depends on them)
+#pragma unroll
+                    for (uint32_t g = 0; g < GROUPS; g++) {
+                        const uint32_t k = g * MDB_WAVE + lane;
+                        ahead[g] = k < stretch_size ? split.entry[base + stretch_first + k] : ENTRY_REJECTED;
+                    }
+                }
 #pragma unroll
                 for (uint32_t g = 0; g < GROUPS; g++) {
                     const uint32_t k = g * MDB_WAVE + lane;
-                    ahead[g] = k < stretch_size ? split.entry[base + stretch_first + k] : ENTRY_REJECTED;
-                }
-            }
-#pragma unroll
-            for (uint32_t g = 0; g < GROUPS; g++) {
-                const uint32_t k = g * MDB_WAVE + lane;
-                if (g * MDB_WAVE < stretch_size) { // (uniform)
-                    if (k < stretch_size) staged[k] = ahead[g];
-                    if (__ballot(k < stretch_size && ahead[g] != ENTRY_REJECTED)) live_groups |= 1u << g;
+                    if (g * MDB_WAVE < stretch_size) { // (uniform)
+                        if (k < stretch_size) staged[k] = ahead[g];
+                        if (__ballot(k < stretch_size && ahead[g] != ENTRY_REJECTED)) live_groups |= 1u << g;
+                    }
                 }
             }
             ahead_first = 0xffffffffu;

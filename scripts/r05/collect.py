@@ -27,6 +27,8 @@ if os.path.exists(log):
     if lines:
         open(os.path.join(TO, "bench_timed_fit_under_rocprof.json"), "w").write(lines[-1])
 for path in sorted(glob.glob(os.path.join(OUT, "bench_*.json"))):
+    if os.path.basename(path).startswith("bench_n"):
+        continue  # (scratch runs of the round)
     lines = [l for l in open(path) if l.startswith('{"metric"')]
     if not lines:
         continue
