@@ -27,6 +27,55 @@ int scratch_reserve(mdb_ctx *ctx, ScratchSlot slot, uint64_t bytes, void **out) 
     return 0;
 }
 
+// (made by the first small copy of the context: a context that only ever grids never pays for it)
+static void mail_make(mdb_ctx *ctx) {
+    if (ctx->mail || ctx->mail_failed) return;
+    void *block = nullptr;
+    if (hipHostMalloc(&block, MAIL_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->mail_failed = true;
+        return;
+    }
+    ctx->mail = static_cast<unsigned char *>(block);
+}
+
+hipError_t mail_read(mdb_ctx *ctx, void *host_to, const void *dev_from, uint64_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    mail_make(ctx);
+    const uint64_t at = (ctx->mail_used + 15u) & ~15ull;
+    if (!ctx->mail || bytes > MAIL_COPY_LIMIT || at + bytes > MAIL_BYTES)
+        return hipMemcpyAsync(host_to, dev_from, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    ctx->mail_used = at + bytes;
+    ctx->mail_reads.push_back({host_to, at, bytes});
+    return hipMemcpyAsync(ctx->mail + at, dev_from, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+
+hipError_t mail_write(mdb_ctx *ctx, void *dev_to, const void *host_from, uint64_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    mail_make(ctx);
+    const uint64_t at = (ctx->mail_used + 15u) & ~15ull;
+    if (!ctx->mail || bytes > MAIL_COPY_LIMIT || at + bytes > MAIL_BYTES)
+        return hipMemcpyAsync(dev_to, host_from, bytes, hipMemcpyHostToDevice, ctx->stream);
+    ctx->mail_used = at + bytes;
+    std::memcpy(ctx->mail + at, host_from, bytes);
+    return hipMemcpyAsync(dev_to, ctx->mail + at, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+
+hipError_t mail_sync(mdb_ctx *ctx) {
+    const hipError_t status = hipStreamSynchronize(ctx->stream);
+    if (status == hipSuccess)
+        for (const mdb_ctx::MailRead &read : ctx->mail_reads) std::memcpy(read.to, ctx->mail + read.at, read.bytes);
+    ctx->mail_reads.clear();
+    ctx->mail_used = 0; // (everything that was written from here has been read by the copy engine)
+    return status;
+}
+
+void mail_drop(mdb_ctx *ctx) {
+    (void)hipStreamSynchronize(ctx->stream); // (copies into the mailbox may still be under way)
+    ctx->mail_reads.clear();
+    ctx->mail_used = 0;
+}
+
 int pinned_reserve(mdb_ctx *ctx, uint64_t bytes, void **out) {
     if (bytes == 0) bytes = 256;
     if (ctx->pinned_bytes < bytes) {
@@ -382,6 +431,7 @@ int mdb_close(mdb_ctx *ctx) {
     for (int i = 0; i < SCRATCH_SLOT_COUNT; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->mail) (void)hipHostFree(ctx->mail);
     if (ctx->owns_pinned_pool) ctx->pinned_pool->close();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -722,8 +772,7 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
     auto fetch = [&](int slot, const void *src, uint64_t bytes) -> int {
         owned->host_allocs[slot].resize(bytes);
         if (bytes == 0 || !src) return 0;
-        MDB_HIP_CHECK(hipMemcpyAsync(owned->host_allocs[slot].data(), src, bytes,
-                                     hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP_CHECK(mail_read(ctx, owned->host_allocs[slot].data(), src, bytes));
         return 0;
     };
     int rc = 0;
@@ -739,11 +788,10 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
         rc |= fetch(5 + c, cols[c]->views, 16 * n);
         tables[c].resize((size_t)cols[c]->n_buffers);
         if (cols[c]->n_buffers > 0 &&
-            hipMemcpyAsync(tables[c].data(), cols[c]->buffers, 8 * (size_t)cols[c]->n_buffers,
-                           hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            mail_read(ctx, tables[c].data(), cols[c]->buffers, 8 * (size_t)cols[c]->n_buffers) != hipSuccess)
             rc = fail("hipMemcpy of the buffer table failed.");
     }
-    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+    if (!rc && mail_sync(ctx) != hipSuccess) rc = fail("stream sync failed.");
     // The data buffers of each column: one host buffer with the views rebased onto it while everything
     // fits below 2 GiB (what most consumers prefer), else buffer by buffer as they are on the device.
     // host_allocs[8 + c] is the single buffer, or the first of several; further ones go to the end.
@@ -780,8 +828,7 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
                 buffer_slots[c].push_back(slot);
                 to = owned->host_allocs[slot].data();
             }
-            if (bytes && hipMemcpyAsync(to, reinterpret_cast<const void *>(tables[c][b]), bytes, hipMemcpyDeviceToHost,
-                                        ctx->stream) != hipSuccess)
+            if (bytes && mail_read(ctx, to, reinterpret_cast<const void *>(tables[c][b]), bytes) != hipSuccess)
                 rc = fail("hipMemcpy of a data buffer failed.");
         }
         if (!rc) {
@@ -804,8 +851,9 @@ int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segme
     }
     if (!rc && dev->error) rc |= fetch(11, dev->error, 4 * n);
     if (!rc && dev->chunk_index) rc |= fetch(12, dev->chunk_index, 4 * n);
-    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("stream sync failed.");
+    if (!rc && mail_sync(ctx) != hipSuccess) rc = fail("stream sync failed.");
     if (rc) {
+        mail_drop(ctx); // (small columns may be on their way into this frame's vectors)
         delete owned;
         return 1;
     }

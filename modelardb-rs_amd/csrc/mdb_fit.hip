@@ -4250,6 +4250,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
     owned->device = ctx->device;
     owned->host_allocs.resize(3);
     auto release = [&]() {
+        mail_drop(ctx); // (small reads that were under way: their destinations are this frame's)
         for (void *p : owned->device_allocs) (void)hipFree(p);
         delete owned;
     };
@@ -4301,15 +4302,13 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                                    args.chunk_offsets, n_chunks, chunk_first, chunk_interval, chunk_irregular,
                                    counter);
             }
-            FIT_CHECK(hipMemcpyAsync(regular_verdict, counter, 8, hipMemcpyDeviceToHost, ctx->stream));
+            FIT_CHECK(mail_read(ctx, regular_verdict, counter, 8));
         }
         FIT_TRY(device_exclusive_scan(ctx, RecordCapacity{args.chunk_offsets}, n_chunks, record_base,
                                       block_sums, "k_fit_scan"));
-        FIT_CHECK(hipMemcpyAsync(&total_records, record_base + n_chunks, 8, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-        FIT_CHECK(hipMemcpyAsync(&points_end, args.chunk_offsets + n_chunks, 8, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-        FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        FIT_CHECK(mail_read(ctx, &total_records, record_base + n_chunks, 8));
+        FIT_CHECK(mail_read(ctx, &points_end, args.chunk_offsets + n_chunks, 8));
+        FIT_CHECK(mail_sync(ctx));
         const unsigned int n_irregular_chunks = regular_verdict[0];
         if (ts && n_irregular_chunks == 0) {
             // Every chunk is regular: from here on timestamps are computed, not loaded.
@@ -4328,8 +4327,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             FIT_CHECK(hipMemsetAsync(error_flag + 1, 0, 4, ctx->stream));
             hipLaunchKernelGGL(k_fit_exact_double_timestamps, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0,
                                ctx->stream, args.timestamps, args.chunk_offsets, n_chunks, error_flag + 1);
-            FIT_CHECK(hipMemcpyAsync(&inexact, error_flag + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            FIT_CHECK(mail_read(ctx, &inexact, error_flag + 1, 4));
+            FIT_CHECK(mail_sync(ctx));
             fast = inexact == 0;
         }
         const bool lean = fast && fit_lean_setting();
@@ -4392,8 +4391,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             }
             if (leave.counts) {
                 unsigned long long counts[WAVE_COUNTS] = {};
-                FIT_CHECK(hipMemcpyAsync(counts, leave.counts, sizeof(counts), hipMemcpyDeviceToHost, ctx->stream));
-                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                FIT_CHECK(mail_read(ctx, counts, leave.counts, sizeof(counts)));
+                FIT_CHECK(mail_sync(ctx));
                 FIT_CHECK(hipFree(leave.counts));
                 std::fprintf(stderr, "[fit] k_fit_models_wave: %llu chunks, %llu points: %llu models, %llu rejected start points, "
                              "%llu passes over 64 start points, %llu blocks (%llu with PMC-Mean alive, %llu in which no bound of Swing moves), %llu Swing scans, %llu models by one lane\n",
@@ -4403,8 +4402,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             }
             if (leave.chunk_left) {
                 unsigned int left[2] = {0, 0};
-                FIT_CHECK(hipMemcpyAsync(left, leave.n_left, 8, hipMemcpyDeviceToHost, ctx->stream));
-                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                FIT_CHECK(mail_read(ctx, left, leave.n_left, 8));
+                FIT_CHECK(mail_sync(ctx));
                 const unsigned int n_left = left[0];
                 if (n_left > 0) {
                     split_mode = true;
@@ -4500,7 +4499,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
 #ifdef MDB_FIT_TIMING
         if (!wave && piece_points == 0 && lean && !ts && eb.kind == MDB_EB_RELATIVE) {
             unsigned long long t[8] = {};
-            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            FIT_CHECK(mail_sync(ctx));
             FIT_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fit_timing), sizeof(t)));
             const unsigned long long zero[8] = {};
             FIT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fit_timing), zero, sizeof(zero)));
@@ -4539,8 +4538,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             FIT_TRY(device_exclusive_scan(ctx, PieceCount{args.chunk_offsets, piece_points, split_only}, n_chunks, piece_base,
                                           block_sums, "k_fit_scan"));
             unsigned long long n_pieces = 0;
-            FIT_CHECK(hipMemcpyAsync(&n_pieces, piece_base + n_chunks, 8, hipMemcpyDeviceToHost, ctx->stream));
-            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            FIT_CHECK(mail_read(ctx, &n_pieces, piece_base + n_chunks, 8));
+            FIT_CHECK(mail_sync(ctx));
             split.n_pieces = n_pieces;
             if (n_pieces > 0) {
                 LaunchTimer timer(ctx, "k_fit_models_split");
@@ -4562,7 +4561,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
 #if defined(MDB_FIT_TIMING) && defined(MDB_FIT_TIMING_SPLIT)
             if (n_pieces > 0 && lean && !ts && eb.kind == MDB_EB_RELATIVE) {
                 unsigned long long t[8] = {};
-                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                FIT_CHECK(mail_sync(ctx));
                 FIT_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fit_timing), sizeof(t)));
                 const unsigned long long zero[8] = {};
                 FIT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fit_timing), zero, sizeof(zero)));
@@ -4579,7 +4578,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
 #ifdef MDB_WALK_DEBUG
             {
                 unsigned long long c[8] = {};
-                (void)hipStreamSynchronize(ctx->stream);
+                (void)mail_sync(ctx);
                 (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_walk_counts), sizeof(c));
                 const unsigned long long zero[8] = {};
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_counts), zero, sizeof(zero));
@@ -4591,10 +4590,9 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         FIT_TRY(device_exclusive_scan(ctx, SegmentCount{plans}, n_chunks, segment_base, block_sums,
                                       "k_fit_scan"));
         unsigned int error = 0;
-        FIT_CHECK(hipMemcpyAsync(&n_segments, segment_base + n_chunks, 8, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-        FIT_CHECK(hipMemcpyAsync(&error, error_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        FIT_CHECK(mail_read(ctx, &n_segments, segment_base + n_chunks, 8));
+        FIT_CHECK(mail_read(ctx, &error, error_flag, 4));
+        FIT_CHECK(mail_sync(ctx));
         FIT_CHECK(hipGetLastError());
         if (error & ERR_SPLIT_CHAIN) {
             release();
@@ -4669,8 +4667,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             }
             // How many there are decides the launches (usually none, and then nothing is launched).
             LongCounters found{};
-            FIT_CHECK(hipMemcpyAsync(&found, counters, sizeof(LongCounters), hipMemcpyDeviceToHost, ctx->stream));
-            FIT_CHECK(hipStreamSynchronize(ctx->stream));
+            FIT_CHECK(mail_read(ctx, &found, counters, sizeof(LongCounters)));
+            FIT_CHECK(mail_sync(ctx));
             gap_waves = found.n_gaps;
             long_segments = found.n_long;
             long_blocks = found.n_blocks;
@@ -4722,9 +4720,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         for (int c = 0; c < 3; c++) {
             FIT_TRY(device_exclusive_scan(ctx, OutOfLineBytes{sizes, c}, n_segments, data_offsets[c],
                                           seg_block_sums, "k_fit_scan"));
-            FIT_CHECK(hipMemcpyAsync(&data_bytes[c], data_offsets[c] + n_segments, 8,
-                                     hipMemcpyDeviceToHost, ctx->stream));
-            FIT_CHECK(hipStreamSynchronize(ctx->stream)); // seg_block_sums is reused by the next scan
+            FIT_CHECK(mail_read(ctx, &data_bytes[c], data_offsets[c] + n_segments, 8));
+            FIT_CHECK(mail_sync(ctx)); // seg_block_sums is reused by the next scan
         }
         // A column's payloads become several data buffers when they add up to more than one buffer may
         // hold (arrow's builders roll over the same way, types.rs:444-516). MDB_FIT_DATA_BUFFER_BYTES: the
@@ -4746,9 +4743,8 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             if (wanted > 1) {
                 hipLaunchKernelGGL(k_fit_data_bases, dim3(1), dim3(64), 0, ctx->stream, data_offsets[c],
                                    (uint64_t)n_segments, buffer_bytes, n_data_buffers[c], bases_dev + c * MAX_DATA_BUFFERS);
-                FIT_CHECK(hipMemcpyAsync(data_bases[c].data(), bases_dev + c * MAX_DATA_BUFFERS, 8 * wanted,
-                                         hipMemcpyDeviceToHost, ctx->stream));
-                FIT_CHECK(hipStreamSynchronize(ctx->stream));
+                FIT_CHECK(mail_read(ctx, data_bases[c].data(), bases_dev + c * MAX_DATA_BUFFERS, 8 * wanted));
+                FIT_CHECK(mail_sync(ctx));
             } else {
                 FIT_CHECK(hipMemsetAsync(bases_dev + c * MAX_DATA_BUFFERS, 0, 8, ctx->stream));
             }
@@ -4798,10 +4794,9 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             tables[c].assign(n_data_buffers[c] + 1, 0);
             for (uint32_t k = 0; k < n_data_buffers[c]; k++)
                 tables[c][k] = reinterpret_cast<uint64_t>(dev + off_data[c] + data_bases[c][k]);
-            FIT_CHECK(hipMemcpyAsync(dev + off_table[c], tables[c].data(), 8 * tables[c].size(), hipMemcpyHostToDevice,
-                                     ctx->stream));
+            FIT_CHECK(mail_write(ctx, dev + off_table[c], tables[c].data(), 8 * tables[c].size()));
         }
-        FIT_CHECK(hipStreamSynchronize(ctx->stream)); // (`tables` is pageable memory of this frame)
+        FIT_CHECK(mail_sync(ctx)); // (`tables` is pageable memory of this frame)
         if (gap_waves > 0) { // before k_fit_encode, which reads the first payload bytes for the views
             LaunchTimer timer(ctx, "k_fit_gap_encode");
             hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
@@ -4825,7 +4820,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                                dim3(FIT_SEGMENT_THREADS), 0, ctx->stream, args,
                                record_base, records, items, (uint64_t)n_segments, sizes, targets);
         }
-        FIT_CHECK(hipStreamSynchronize(ctx->stream));
+        FIT_CHECK(mail_sync(ctx));
         FIT_CHECK(hipGetLastError());
 
         mdb_segments &s = owned->c.seg;
@@ -5327,7 +5322,7 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
         std::vector<unsigned char> irregular(n_chunks, 0);
         GatherJob job{chunks, offsets.data(), same_ts_as.data(), static_cast<float *>(stage), nullptr,
                       both.data(), both.data() + n_chunks, irregular.data(), {}};
-        MDB_HIP_CHECK(hipMemcpyAsync(dev_offsets, offsets.data(), (n_chunks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        MDB_HIP_CHECK(mail_write(ctx, dev_offsets, offsets.data(), (n_chunks + 1) * 8));
         // The gather in slices of about 64 MB of values, each slice by all host threads, and behind every slice its
         // copy to the device: the copy of one slice runs while the threads gather the next.
         const uint64_t slice_points = 16u << 20;
@@ -5380,8 +5375,7 @@ int mdb_compress_chunk_list(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_ch
         if (!rc && regular) {
             void *dev_first = nullptr;
             if (scratch_reserve(ctx, SCRATCH_FIT_IN_TS, 16 * n_chunks, &dev_first)) return 1;
-            if (hipMemcpyAsync(dev_first, both.data(), 16 * n_chunks, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess)
+            if (mail_write(ctx, dev_first, both.data(), 16 * n_chunks) != hipSuccess)
                 rc = fail("hipMemcpy host to device failed.");
             if (!rc)
                 rc = compress_chunks_dev_locked(ctx, nullptr, static_cast<const float *>(dev_values),
