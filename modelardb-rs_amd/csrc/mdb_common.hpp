@@ -79,6 +79,8 @@ enum ScratchSlot {
     SCRATCH_FIT_LONG_IDS,
     SCRATCH_FIT_LONG,
     SCRATCH_FIT_ROTATION,
+    SCRATCH_FIT_GAP_STAGE_OFFSETS,
+    SCRATCH_FIT_GAP_STAGE,
     SCRATCH_SLOT_COUNT
 };
 

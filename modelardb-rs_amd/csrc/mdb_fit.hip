@@ -2835,7 +2835,7 @@ struct TsResult { // of k_fit_timestamps<false>, indexed by segment
     uint32_t regular;
 };
 
-struct GapResult { // of k_fit_gap<false>, indexed by segment
+struct GapResult { // of k_fit_gap<GAP_SIZE>, indexed by segment
     uint32_t values_bytes;
     float min_value;
     float max_value;
@@ -3089,23 +3089,51 @@ __device__ __forceinline__ uint32_t wave_flush_bits(uint32_t *buffer, int buffer
     return carry_bits;
 }
 
-template <bool WRITE>
+// GAP_SIZE: the stream is measured (its bytes, min / max, whether the timestamps are equally spaced); GAP_WRITE: it is
+// written where the scan over the sizes has put it; GAP_STAGE: both at once - measured, and written to a staging place
+// found from an upper bound (45 bits a value), from where k_fit_gap_place copies it once the scan has run: the codes are
+// worked out once, not twice (the copy is a quarter of what the second encoding was).
+enum GapMode { GAP_SIZE = 0, GAP_WRITE = 1, GAP_STAGE = 2 };
+struct GapStage {
+    uint8_t *bytes = nullptr;                    // 16-byte aligned places, in the order of the list of segments
+    const unsigned long long *offsets = nullptr; // [position in the list]
+};
+// Staging bytes of a MacaqueV-only segment of n values: 32 raw bits, at most 2 + 5 + 6 + 32 bits for every other value
+// (macaque_v.rs:120-164), up to the next multiple of 16 and 16 more (the copy reads whole words past the end).
+__host__ __device__ inline unsigned long long gap_stage_bytes(uint32_t n) {
+    return ((4ull + ((unsigned long long)(n - 1) * 45u + 7u) / 8u + 15u) & ~15ull) + 16u;
+}
+struct GapStageBytes {
+    const SegItem *items;
+    const uint32_t *gap_ids;
+    __device__ uint64_t operator()(uint64_t g) const {
+        const SegItem item = items[gap_ids[g]];
+        return gap_stage_bytes(item.last - item.first + 1);
+    }
+};
+
+template <int MODE>
 __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegItem *__restrict__ items,
                                                       const uint32_t *__restrict__ gap_ids,
                                                       const uint32_t *__restrict__ n_gaps,
-                                                      GapResult *__restrict__ results, EncodeTargets targets) {
+                                                      GapResult *__restrict__ results, EncodeTargets targets,
+                                                      GapStage stage = GapStage{}) {
+    constexpr bool WRITE = MODE != GAP_SIZE;    // the codes go to memory
+    constexpr bool MEASURE = MODE != GAP_WRITE; // the segment's GapResult is made here
     __shared__ uint32_t buffer[GAP_BUFFER_WORDS];
     if (blockIdx.x >= *n_gaps) return;
-    if (WRITE && args.targets_dev) targets = *args.targets_dev;
+    if (MODE == GAP_WRITE && args.targets_dev) targets = *args.targets_dev;
     const uint32_t segment = gap_ids[blockIdx.x];
     const SegItem item = items[segment];
     const int lane = threadIdx.x;
     const uint32_t n = item.last - item.first + 1;
     const float *__restrict__ values = args.values + args.chunk_offsets[item.chunk] + item.first;
     uint8_t *__restrict__ dst = nullptr;
-    if (WRITE) {
+    if (MODE == GAP_WRITE) {
         if (results[segment].values_bytes <= 12) return; // lives inside the view: k_fit_encode writes it
         dst = targets.data[1] + targets.data_offsets[1][segment];
+    } else if (MODE == GAP_STAGE) {
+        dst = stage.bytes + stage.offsets[blockIdx.x];
     }
 
     // The first value: 32 raw bits.
@@ -3128,11 +3156,11 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
     // path (chunk_range_regular) would otherwise do point by point.
     const ChunkTimestamps ts = chunk_timestamps(args.timestamps, item.chunk, args.chunk_offsets[item.chunk]);
     bool regular = true;
-    const int64_t expected_delta = (!WRITE && ts.ts && n >= 2) ? ts.ts[item.first + 1] - ts.ts[item.first] : 0;
+    const int64_t expected_delta = (MEASURE && ts.ts && n >= 2) ? ts.ts[item.first + 1] - ts.ts[item.first] : 0;
     for (uint32_t base = 1; base < n; base += MDB_WAVE) {
         const uint32_t i = base + lane;
         const bool active = i < n;
-        if (!WRITE && ts.ts && active && ts.ts[item.first + i] - ts.ts[item.first + i - 1] != expected_delta)
+        if (MEASURE && ts.ts && active && ts.ts[item.first + i] - ts.ts[item.first + i - 1] != expected_delta)
             regular = false;
         // What is stored for value i (macaque_v.rs:100-118). Lossless: the value. Otherwise the value
         // stored before it if that is within the bound of value i, else value i with its least
@@ -3248,7 +3276,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
     const bool all_regular = __all(regular);
     if (WRITE) {
         if (carry_bits && lane == 0) dst[written] = (uint8_t)(buffer[0] >> 24); // padded with zero bits
-    } else if (lane == 0) {
+    }
+    if (MEASURE && lane == 0) {
         GapResult result;
         result.values_bytes = (uint32_t)((total_bits + 7) >> 3);
         result.min_value = min_value;
@@ -3256,6 +3285,34 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         result.regular = all_regular ? 1u : 0u;
         results[segment] = result;
     }
+}
+
+// The staged streams to their places (GAP_STAGE): a wave per segment copies values_bytes bytes from a 16-byte aligned
+// place to one of any alignment - aligned words read, shifted by the difference, aligned words written; the few bytes
+// in front of the first and behind the last whole word of the destination one by one. (Streams of up to 12 bytes live in
+// their views: k_fit_encode writes those.)
+__global__ __launch_bounds__(MDB_WAVE) void k_fit_gap_place(const uint32_t *__restrict__ gap_ids, const uint32_t *__restrict__ n_gaps,
+                                                            const GapResult *__restrict__ results, EncodeTargets targets,
+                                                            GapStage stage) {
+    if (blockIdx.x >= *n_gaps) return;
+    const uint32_t segment = gap_ids[blockIdx.x];
+    const uint32_t n_bytes = results[segment].values_bytes;
+    if (n_bytes <= 12) return;
+    const int lane = threadIdx.x;
+    const uint8_t *__restrict__ from = stage.bytes + stage.offsets[blockIdx.x];
+    uint8_t *__restrict__ to = targets.data[1] + targets.data_offsets[1][segment];
+    const uint32_t head = (uint32_t)((4u - (reinterpret_cast<uintptr_t>(to) & 3u)) & 3u); // (n_bytes > 12 > head)
+    if ((uint32_t)lane < head) to[lane] = from[lane];
+    const uint32_t n_words = (n_bytes - head) >> 2;
+    const uint32_t *__restrict__ from_words = reinterpret_cast<const uint32_t *>(from);
+    uint32_t *__restrict__ to_words = reinterpret_cast<uint32_t *>(to + head);
+    const uint32_t shift = head & 3u, first_word = head >> 2; // (head < 4: first_word is 0; kept for the form's sake)
+    for (uint32_t w = lane; w < n_words; w += MDB_WAVE) {
+        const uint32_t low = from_words[first_word + w], high = from_words[first_word + w + 1];
+        to_words[w] = __builtin_amdgcn_alignbyte(high, low, shift);
+    }
+    const uint32_t done = head + 4u * n_words;
+    if ((uint32_t)lane < n_bytes - done) to[done + lane] = from[done + lane];
 }
 
 // ---- long MacaqueV-only segments: cut into blocks, a wave per block ----------------------------------------
@@ -4118,6 +4175,16 @@ static uint32_t gap_min_values_setting() {
     return GAP_DEFAULT_MIN_VALUES;
 }
 
+// MDB_FIT_GAP_ONCE: 0 - the waves' MacaqueV-only segments are sized by one kernel and encoded again by another; 1 - they
+// are encoded once into staging places and copied (GAP_STAGE); not set: once under a lossy bound, twice under a lossless
+// one (see where it is asked).
+static bool gap_once_setting(const mdb_error_bound &eb) {
+    const char *text = option_text("MDB_FIT_GAP_ONCE");
+    if (text && std::strcmp(text, "0") == 0) return false;
+    if (text && std::strcmp(text, "1") == 0) return true;
+    return eb.kind != MDB_EB_LOSSLESS;
+}
+
 // MDB_FIT_GAP_LONG_MIN_VALUES: "off" keeps one wave per MacaqueV-only segment however long it is, a number sets the
 // length from which one is cut into blocks with a wave each (k_fit_long*). MDB_FIT_GAP_BLOCK_VALUES: the least number
 // of values per block (rounded up to whole batches of 64; the tests cut short streams into many blocks with it).
@@ -4628,6 +4695,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         // Long lossless MacaqueV-only segments: one wave each (k_fit_gap), sized here, written below.
         uint32_t *gap_ids = nullptr, *n_gaps = nullptr;
         uint32_t gap_waves = 0;
+        GapStage gap_stage; // (bytes: the listed segments are encoded once, into staging places)
         LongArgs long_args;
         uint32_t long_segments = 0, long_blocks = 0;
         bool long_in_blocks = false; // (false: the long ones take a wave each like the others, listed apart)
@@ -4672,10 +4740,38 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             gap_waves = found.n_gaps;
             long_segments = found.n_long;
             long_blocks = found.n_blocks;
+            // Encoded once (GAP_STAGE; MDB_FIT_GAP_ONCE=0: sized, then encoded again; =1: under a lossless bound too):
+            // every listed segment gets a staging place from an upper bound of its bytes, unless those add up to more
+            // than the device has to spare. Under a lossy bound, where measuring a stream is all of encoding it but the
+            // stores (the mixed series at 1 %: 2.54 + 2.68 ms -> 3.46 + 0.43 for the copy); under a lossless bound the
+            // measuring pass is the cheaper one and staging gains nothing (2.79 + 3.46 -> 4.47 + 1.03).
+            if (gap_waves > 0 && gap_once_setting(eb)) {
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP_STAGE_OFFSETS, ((uint64_t)gap_waves + 1) * 8, &p));
+                unsigned long long *stage_offsets = static_cast<unsigned long long *>(p);
+                FIT_TRY(device_exclusive_scan(ctx, GapStageBytes{items, gap_ids}, gap_waves, stage_offsets, seg_block_sums, "k_fit_scan"));
+                unsigned long long stage_bytes = 0;
+                FIT_CHECK(mail_read(ctx, &stage_bytes, stage_offsets + gap_waves, 8));
+                FIT_CHECK(mail_sync(ctx));
+                size_t device_free = 0, device_total = 0;
+                if (hipMemGetInfo(&device_free, &device_total) != hipSuccess) {
+                    (void)hipGetLastError();
+                    device_free = 0;
+                }
+                // (what is reserved already counts as free for this: the slot grows, it is not added to)
+                if (stage_bytes <= ctx->scratch_bytes[SCRATCH_FIT_GAP_STAGE] || stage_bytes <= device_free / 4) {
+                    FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP_STAGE, stage_bytes, &p));
+                    gap_stage.bytes = static_cast<uint8_t *>(p);
+                    gap_stage.offsets = stage_offsets;
+                }
+            }
             if (gap_waves > 0) {
                 LaunchTimer timer(ctx, "k_fit_gap_size");
-                hipLaunchKernelGGL(k_fit_gap<false>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
-                                   gap_ids, n_gaps, gap_results, EncodeTargets{});
+                if (gap_stage.bytes)
+                    hipLaunchKernelGGL(k_fit_gap<GAP_STAGE>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                                       gap_ids, n_gaps, gap_results, EncodeTargets{}, gap_stage);
+                else
+                    hipLaunchKernelGGL(k_fit_gap<GAP_SIZE>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                                       gap_ids, n_gaps, gap_results, EncodeTargets{}, GapStage{});
             }
             // Blocks are for calls with too few streams to occupy the device with a wave each: 10^3 streams of 50 000
             // values are fitted in 1.7 ms cut into blocks and 2.7 ms with a wave each, 10^4 in 7.2 against 6.7 (the
@@ -4686,7 +4782,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             long_in_blocks = long_segments > 0 && (uint64_t)gap_waves + long_segments < enough_waves;
             if (long_segments > 0 && !long_in_blocks) {
                 LaunchTimer timer(ctx, "k_fit_gap_size");
-                hipLaunchKernelGGL(k_fit_gap<false>, dim3(long_segments), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                hipLaunchKernelGGL(k_fit_gap<GAP_SIZE>, dim3(long_segments), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                    long_args.long_ids, &counters->n_long, gap_results, EncodeTargets{});
             }
             if (long_in_blocks) {
@@ -4797,16 +4893,20 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             FIT_CHECK(mail_write(ctx, dev + off_table[c], tables[c].data(), 8 * tables[c].size()));
         }
         FIT_CHECK(mail_sync(ctx)); // (`tables` is pageable memory of this frame)
-        if (gap_waves > 0) { // before k_fit_encode, which reads the first payload bytes for the views
+        if (gap_waves > 0 && gap_stage.bytes) { // before k_fit_encode, which reads the first payload bytes for the views
+            LaunchTimer timer(ctx, "k_fit_gap_place");
+            hipLaunchKernelGGL(k_fit_gap_place, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, gap_ids, n_gaps,
+                               args.gap_results, targets, gap_stage);
+        } else if (gap_waves > 0) {
             LaunchTimer timer(ctx, "k_fit_gap_encode");
-            hipLaunchKernelGGL(k_fit_gap<true>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
-                               gap_ids, n_gaps, const_cast<GapResult *>(args.gap_results), targets);
+            hipLaunchKernelGGL(k_fit_gap<GAP_WRITE>, dim3(gap_waves), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+                               gap_ids, n_gaps, const_cast<GapResult *>(args.gap_results), targets, GapStage{});
         }
         if (long_in_blocks) {
             launch_long_encode(ctx, ctx->stream, args, items, long_args, targets, long_blocks);
         } else if (long_segments > 0) {
             LaunchTimer timer(ctx, "k_fit_gap_encode");
-            hipLaunchKernelGGL(k_fit_gap<true>, dim3(long_segments), dim3(MDB_WAVE), 0, ctx->stream, args, items,
+            hipLaunchKernelGGL(k_fit_gap<GAP_WRITE>, dim3(long_segments), dim3(MDB_WAVE), 0, ctx->stream, args, items,
                                long_args.long_ids, &long_args.counters->n_long, const_cast<GapResult *>(args.gap_results), targets);
         }
         if (ts_by_wave) { // before k_fit_encode as well
@@ -5039,7 +5139,7 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
         LaunchTimer timer(ctx, "k_fit_gap_size");
         hipLaunchKernelGGL(k_fit_gap_select, dim3((uint32_t)((segment_bound + 255) / 256)), dim3(256), 0, stream, args, items,
                            (uint64_t)0, gap_ids, n_gaps);
-        hipLaunchKernelGGL(k_fit_gap<false>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
+        hipLaunchKernelGGL(k_fit_gap<GAP_SIZE>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
                            gap_results, EncodeTargets{});
     }
     LongArgs long_args;
@@ -5072,7 +5172,7 @@ int fit_few_chunks(mdb_ctx *ctx, const mdb_chunk *chunks, uint64_t n_chunks, mdb
     }
     {
         LaunchTimer timer(ctx, "k_fit_encode");
-        hipLaunchKernelGGL(k_fit_gap<true>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
+        hipLaunchKernelGGL(k_fit_gap<GAP_WRITE>, dim3((uint32_t)gap_bound), dim3(MDB_WAVE), 0, stream, args, items, gap_ids, n_gaps,
                            gap_results, EncodeTargets{});
         if (long_bound > 0) launch_long_encode(ctx, stream, args, items, long_args, EncodeTargets{}, (uint32_t)long_blocks_bound);
         hipLaunchKernelGGL(k_fit_encode, dim3(segment_blocks), dim3(FIT_SEGMENT_THREADS), 0, stream, args, record_base_dev, records,

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 SWITCHES = ("MDB_FIT_WAVE", "MDB_FIT_PIECE_POINTS", "MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_GAP_MIN_VALUES",
             "MDB_FIT_DATA_BUFFER_BYTES", "MDB_FIT_DEBUG", "MDB_FIT_SMALL", "MDB_FIT_GAP_LONG_MIN_VALUES",
-            "MDB_FIT_GAP_BLOCK_VALUES", "MDB_FIT_GAP_LONG_BELOW_WAVES")
+            "MDB_FIT_GAP_BLOCK_VALUES", "MDB_FIT_GAP_LONG_BELOW_WAVES", "MDB_FIT_GAP_ONCE")
 
 
 @pytest.fixture(autouse=True)
@@ -154,4 +154,20 @@ def test_enough_streams_for_a_wave_each(hip, monkeypatch):
     monkeypatch.setenv("MDB_FIT_GAP_LONG_BELOW_WAVES", "2")
     chunks = [(timestamps_of(n), stream(kind, n, n)) for kind, n in (("noise", 20_000), ("coarse", 9000), ("runs", 300), ("noise", 8192))]
     for eb in (cases.LOSSLESS, cases.error_bounds()["abs0.01"]):
+        check(hip, chunks, eb)
+
+
+@pytest.mark.parametrize("once", ["0", "1"])
+def test_macaque_v_segments_encoded_once_or_twice(hip, monkeypatch, once):
+    """The general driver's waves encode a MacaqueV-only segment into a staging place and copy it once its place is
+    known (MDB_FIT_GAP_ONCE=1; what the library does under a lossy bound), or size it and encode it again (=0; under a
+    lossless bound): the same bytes either way, for streams of every length around the copy's word boundaries (the
+    copy moves aligned words; 13 bytes is the shortest stream that does not live in its view) and next to short ones
+    that one lane encodes."""
+    monkeypatch.setenv("MDB_FIT_SMALL", "0")
+    monkeypatch.setenv("MDB_FIT_GAP_ONCE", once)
+    monkeypatch.setenv("MDB_FIT_GAP_MIN_VALUES", "2")
+    lengths = list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 300, 1000, 4097, 0, 20_000]
+    chunks = [(timestamps_of(n), stream(("noise", "coarse", "runs", "specials")[k % 4], n, 100 + k)) for k, n in enumerate(lengths)]
+    for eb in (cases.LOSSLESS, cases.error_bounds()["abs0.01"], cases.error_bounds()["rel1"]):
         check(hip, chunks, eb)
