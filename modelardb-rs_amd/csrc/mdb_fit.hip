@@ -4961,7 +4961,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
 // with any other MDB_FIT_* switch set take the general driver (the switches select among ITS kernels).
 static uint64_t fit_small_max_chunks() {
     for (const char *name : {"MDB_FIT_WAVE", "MDB_FIT_PIECE_POINTS", "MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_GAP_MIN_VALUES",
-                             "MDB_FIT_DATA_BUFFER_BYTES", "MDB_FIT_DEBUG"})
+                             "MDB_FIT_DATA_BUFFER_BYTES", "MDB_FIT_DEBUG", "MDB_FIT_ROTATE", "MDB_FIT_GAP_ONCE"})
         if (option_text(name)) return 0;
     if (const char *text = option_text("MDB_FIT_SMALL")) return (uint64_t)std::max(0ll, std::atoll(text));
     return 64;
