@@ -2,7 +2,7 @@
 160 M points in 2 448 chunks of 65 536, every chunk with a timestamp array of its own. usage: python fit_host_phases.py [series]"""
 import os, sys, time
 sys.path[:0] = ["/root/repo", "/root/repo/tests"]
-os.environ["MDB_FIT_DEBUG"] = "1"
+if os.environ.get("NO_DEBUG") != "1": os.environ["MDB_FIT_DEBUG"] = "1"
 import numpy as np
 import modelardb_rs_amd as mdb, datagen
 n_series = int(sys.argv[1]) if len(sys.argv) > 1 else 16
