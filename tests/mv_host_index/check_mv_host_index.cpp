@@ -77,7 +77,30 @@ std::vector<float> make_values(std::mt19937 &rng, uint32_t n, int kind) {
 
 } // namespace
 
+// host_copy_streaming (mdb_pipeline.cpp: the gather of mdb_compress_chunk_list): every length up to a few hundred bytes
+// from and to every alignment, guard bytes on either side untouched (and the sanitizers' eyes on the loads).
+static int check_streaming_copy() {
+    std::vector<uint8_t> from(1024), to(1024);
+    for (size_t i = 0; i < from.size(); i++) from[i] = (uint8_t)(i * 131 + 7);
+    for (size_t n : {size_t(0), size_t(1), size_t(3), size_t(15), size_t(16), size_t(17), size_t(63), size_t(64), size_t(65), size_t(127),
+                     size_t(200), size_t(333)})
+        for (size_t a = 0; a < 32; a += 3)
+            for (size_t b = 0; b < 32; b += 5) {
+                std::fill(to.begin(), to.end(), (uint8_t)0x5c);
+                mdb::host_copy_streaming(to.data() + 64 + b, from.data() + a, n);
+                for (size_t i = 0; i < to.size(); i++) {
+                    const bool inside = i >= 64 + b && i < 64 + b + n;
+                    if (to[i] != (inside ? from[a + i - 64 - b] : (uint8_t)0x5c)) {
+                        std::fprintf(stderr, "host_copy_streaming: %zu bytes from +%zu to +%zu: byte %zu\n", n, a, b, i);
+                        return 1;
+                    }
+                }
+            }
+    return 0;
+}
+
 int main() {
+    if (check_streaming_copy()) return 3;
     setenv("MDB_GRID_MV_HOST_MIN_VALUES", "1", 1); // every stream, not only the long ones
     std::mt19937 rng(20261003);
     const mdb_error_bound lossless{MDB_EB_LOSSLESS, 0.0f};
