@@ -82,6 +82,9 @@ def parse_args():
                         help="what one timed step is: grid() of the rank's resident segments (BASELINE configs 2 / 5, "
                              "the default) or the PMC-Mean / Swing / MacaqueV fit of the rank's resident values "
                              "(BASELINE config 4: one mdb_compress_chunks_dev per step)")
+    parser.add_argument("--detail-file", default=None,
+                        help="where everything that was measured goes as one JSON object (default: bench_detail.json "
+                             "beside bench.py); stdout carries the compact line only")
     parser.add_argument("--fit-repetitions", type=int, default=5,
                         help="timed repetitions of every fit that is not the timed step (median, min, max reported)")
     return parser.parse_args()
@@ -1064,6 +1067,7 @@ class GpuWorkload:
                 "arithmetic": "Swing values as (f64 slope * f64 t + f64 intercept) -> f32, timestamps i64; "
                               "output columns i64 + f32 (12 B/point)",
                 "device": self.info["name"],
+                "libraries": loaded_runtime_libraries(),
             },
             "roofline": {
                 "bound": "hbm",
@@ -1243,6 +1247,7 @@ class FitWorkload:
                 "parallelism": f"series-sharded x{world}, no data-path collective",
                 "arithmetic": "Swing in f64 (no contraction), PMC-Mean f64 sum / f32 tests, MacaqueV u32 bit streams",
                 "device": self.info["name"],
+                "libraries": loaded_runtime_libraries(),
             },
             "roofline": fit_roofline(kernel_ms, self.total, self.info),
             "kernels_ms": {name: round(ms, 3) for name, ms in kernel_ms.items()},
@@ -1263,6 +1268,118 @@ class FitWorkload:
                 self.context.dev_free(pointer)
         self.values = self.offsets_dev = self.first_index_dev = None
         self.context.close()
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "rccl_ranks_seen")
+COMPACT_LIMIT_BYTES = 4096
+DETAIL_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_detail.json")
+
+
+def _dig(tree, *path):
+    """tree[path[0]][path[1]]... or None wherever a step is missing."""
+    for key in path:
+        if not isinstance(tree, dict) or key not in tree:
+            return None
+        tree = tree[key]
+    return tree
+
+
+def _short(value, digits=5):
+    """Floats to `digits` significant figures (the detail file keeps them whole), strings cut at 300 characters."""
+    if isinstance(value, bool) or value is None:
+        return value
+    if isinstance(value, float):
+        if value != value or value in (float("inf"), float("-inf")):
+            return None  # (strict JSON has no NaN / Infinity)
+        return float(f"{value:.{digits}g}")
+    if isinstance(value, str):
+        return value if len(value) <= 300 else value[:297] + "..."
+    if isinstance(value, dict):
+        return {key: _short(item, digits) for key, item in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_short(item, digits) for item in value]
+    return value
+
+
+def loaded_runtime_libraries():
+    """Which HIP / RCCL files this process has mapped (/proc/self/maps): the first thing to look at when an N > 1 run
+    misbehaves (torch bundles its own copies next to /opt/rocm's)."""
+    seen = {}
+    try:
+        with open("/proc/self/maps") as maps:
+            for row in maps:
+                path = row.rstrip("\n").rpartition(" ")[2]
+                base = os.path.basename(path)
+                for stem in ("libamdhip64", "librccl", "libhsa-runtime64", "libmdb_hip", "libmdb_host"):
+                    if base.startswith(stem):
+                        seen.setdefault(stem, set()).add(path)
+    except OSError:
+        return None
+    return {stem: sorted(paths) for stem, paths in sorted(seen.items())}
+
+
+def compact_line(line, detail_name="bench_detail.json"):
+    """The ONE line the driver parses: the contract's keys, `config` (what the workload was), `roofline` and
+    `cpu_baseline` of the timed kernel, and a dozen scalars of the secondary blocks under `also` - everything else is
+    in the detail file. Kept under COMPACT_LIMIT_BYTES (asserted here and in tests/test_bench_cpu.py): the 21.9 KB
+    line of round 5 was more than the driver reads back."""
+    out = {key: line[key] for key in CONTRACT_KEYS if key in line}
+    config = line.get("config") or {}
+    out["config"] = {key: config[key] for key in ("workload", "series_per_gpu", "points_per_series", "chunks_per_gpu",
+                                                  "segments_per_gpu", "segment_mix", "parallelism", "device",
+                                                  "libraries") if key in config}
+    roofline = line.get("roofline")
+    if isinstance(roofline, dict):
+        out["roofline"] = {key: roofline[key] for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                          "kernel_ms", "algorithmic_bytes_per_launch") if key in roofline}
+    else:
+        out["roofline"] = roofline
+    cpu = line.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        out["cpu_baseline"] = {key: cpu[key] for key in ("value", "unit", "cores", "kind", "single_thread_value", "sample")
+                               if key in cpu}
+    else:
+        out["cpu_baseline"] = cpu
+    also = {
+        # the other rows of the path, each next to the roofline that bounds it (fractions of the 8 TB/s HBM peak)
+        "fit_points_per_s": _dig(line, "fit", "points_per_s"),
+        "fit_kernel": _dig(line, "fit", "roofline", "kernel"),
+        "fit_kernel_ms": _dig(line, "fit", "roofline", "kernel_ms"),
+        "fit_frac_of_hbm": _dig(line, "fit", "roofline", "frac"),
+        "fit_cpu_points_per_s": _dig(line, "fit", "cpu_baseline", "value"),
+        "aggregates_frac_of_hbm": _dig(line, "aggregates", "roofline", "frac"),
+        "range_aggregates_frac_of_hbm": _dig(line, "aggregates", "range", "roofline", "frac"),
+        # the series with all three model types (MacaqueV decode runs HERE, not in the headline's segments)
+        "mixed_grid_frac_lossless": _dig(line, "mixed_models", "lossless", "grid", "frac_of_hbm_peak"),
+        "mixed_grid_frac_1pct": _dig(line, "mixed_models", "relative_1_percent", "grid", "frac_of_hbm_peak"),
+        "mixed_grid_ms_lossless": _dig(line, "mixed_models", "lossless", "grid", "ms"),
+        "mixed_grid_ms_1pct": _dig(line, "mixed_models", "relative_1_percent", "grid", "ms"),
+        "mixed_aggregates_frac_lossless": _dig(line, "mixed_models", "lossless", "aggregates", "frac_of_hbm_peak"),
+        "mixed_aggregates_frac_1pct": _dig(line, "mixed_models", "relative_1_percent", "aggregates", "frac_of_hbm_peak"),
+        "mixed_aggregates_ms_lossless": _dig(line, "mixed_models", "lossless", "aggregates", "ms"),
+        "mixed_aggregates_ms_1pct": _dig(line, "mixed_models", "relative_1_percent", "aggregates", "ms"),
+        "mixed_fit_ms_lossless": _dig(line, "mixed_models", "lossless", "fit", "ms"),
+        "mixed_fit_ms_1pct": _dig(line, "mixed_models", "relative_1_percent", "fit", "ms"),
+        "host_path_values_per_s": _dig(line, "host_path", "batch_8192", "values_per_s"),
+        "host_path_GB_per_s_pcie": _dig(line, "host_path", "batch_8192", "GB_per_s_pcie"),
+        "segments_per_s": line.get("segments_per_s"),
+        "aggregates_count": _dig(line, "aggregates", "result", "count"),
+    }
+    out["also"] = {key: value for key, value in also.items() if value is not None}
+    verified = line.get("verified")
+    if isinstance(verified, dict):
+        out["verified"] = {key: value for key, value in verified.items() if isinstance(value, (int, float))}
+    out["ms_per_step_per_rank"] = line.get("ms_per_step_per_rank")
+    out["detail"] = detail_name
+    out = _short(out, 6)
+    for key in ("value", "ms_per_step"):  # (the contract's two numbers stay whole)
+        if key in line:
+            out[key] = line[key]
+    text = json.dumps(out, allow_nan=False)
+    if len(text) > COMPACT_LIMIT_BYTES:
+        raise SystemExit(f"bench.py's line is {len(text)} bytes, over the {COMPACT_LIMIT_BYTES} it is held to")
+    return text
 
 
 def control_group(dist, backend):
@@ -1363,7 +1480,16 @@ def orchestrate(args, make_workload, backend="nccl", result_fd=1):
         traceback.print_exc(file=sys.stderr)
         everyone_fine = False
     if rank == 0 and everyone_fine and line is not None:
-        os.write(result_fd, (json.dumps(line) + "\n").encode())
+        # Everything that was measured: into the detail file (and onto stderr); the compact line ALONE on stdout.
+        detail_path = getattr(args, "detail_file", None) or DETAIL_FILE
+        detail = json.dumps(line)
+        try:
+            with open(detail_path, "w") as sink:
+                sink.write(detail + "\n")
+        except OSError as error:
+            print(f"[bench] could not write {detail_path}: {error}", file=sys.stderr, flush=True)
+        print(f"[bench] detail: {detail}", file=sys.stderr, flush=True)
+        os.write(result_fd, (compact_line(line, os.path.basename(detail_path)) + "\n").encode())
     return 0 if everyone_fine else 1
 
 

@@ -60,5 +60,6 @@ class CannedWorkload:
 
 
 if __name__ == "__main__":
-    arguments = types.SimpleNamespace(gpus=int(os.environ["WORLD_SIZE"]), steps=3, warmup=1, collective_timeout=20.0)
+    arguments = types.SimpleNamespace(gpus=int(os.environ["WORLD_SIZE"]), steps=3, warmup=1, collective_timeout=20.0,
+                                      detail_file=os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_detail_stub.json"))
     sys.exit(bench.orchestrate(arguments, CannedWorkload, backend="gloo", result_fd=1))

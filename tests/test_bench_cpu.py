@@ -65,6 +65,42 @@ def test_world_size_must_match_gpus(monkeypatch):
         bench.init_distributed(_args(8))
 
 
+def _no_constants(name):
+    raise AssertionError(f"{name} on the bench line: not strict JSON")
+
+
+def test_the_line_of_a_full_run_is_compact_and_strict_json():
+    """compact_line() over everything a default run measures (round 5's detail, 21.9 KB): the contract's keys, `config`,
+    `roofline`, `cpu_baseline` and the scalars of the secondary blocks in under 4 KB, no NaN / Infinity."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("bench_default.json", "bench_timed_fit.json", "bench_config5_shape_1gpu.json"):
+        detail = json.load(open(os.path.join(root, "tests", "golden", "bench_detail_r05", name)))
+        detail["config"]["libraries"] = {"libamdhip64": ["/opt/rocm-7.2.0/lib/libamdhip64.so.7.2.70200",
+                                                         "/usr/local/lib/python3.10/dist-packages/torch/lib/libamdhip64.so"],
+                                         "librccl": ["/usr/local/lib/python3.10/dist-packages/torch/lib/librccl.so"]}
+        detail["aggregates_nan_probe"] = float("nan")
+        text = bench.compact_line(detail)
+        assert len(text.encode()) <= bench.COMPACT_LIMIT_BYTES <= 4096 and "\n" not in text
+        line = json.loads(text, parse_constant=_no_constants)
+        for key in bench.CONTRACT_KEYS:
+            assert line[key] == detail[key], key
+        assert line["config"]["workload"] == detail["config"]["workload"]
+        assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "kernel_ms"}
+        assert abs(line["roofline"]["frac"] - detail["roofline"]["frac"]) < 1e-5
+        assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+        if name == "bench_default.json":
+            assert line["config"]["segment_mix"] == detail["config"]["segment_mix"]
+            assert line["roofline"]["traffic"] is not None
+            assert {"fit_points_per_s", "fit_kernel_ms", "fit_frac_of_hbm", "mixed_grid_frac_lossless", "mixed_grid_frac_1pct",
+                    "mixed_aggregates_frac_lossless", "range_aggregates_frac_of_hbm"} <= set(line["also"])
+
+
+def test_an_overlong_line_is_refused():
+    with pytest.raises(SystemExit, match="bytes"):
+        bench.compact_line({"metric": "m", "config": {"workload": "w", "segment_mix": {f"k{i}": i for i in range(600)}}})
+
+
 def _run_two_ranks(fail_on=None):
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -89,9 +125,14 @@ def test_two_ranks_over_gloo_meet_close_in_order_and_print_one_line():
     assert done.returncode == 0, done.stderr[-3000:]
     lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1, done.stdout
-    line = json.loads(lines[0])
+    assert done.stdout.strip().splitlines()[-1] == lines[0]      # the LAST line of stdout is the line
+    assert len(lines[0].encode()) <= 6000                         # (round 5's 21.9 KB line was not read back)
+    line = json.loads(lines[0], parse_constant=_no_constants)
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["steps"] == 3
-    assert line["aggregates"]["result"]["count"] == 2_000_000
+    assert line["also"]["aggregates_count"] == 2_000_000
+    # everything that was measured is in the detail file the line names
+    detail = json.load(open(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "tests", "stub", line["detail"])))
+    assert detail["aggregates"]["result"]["count"] == 2_000_000 and detail["value"] == line["value"]
     assert line["value"] > 0 and line["ms_per_step_per_rank"]["max"] >= line["ms_per_step_per_rank"]["min"]
     assert "rank 0 closed" in done.stderr and "rank 1 closed" in done.stderr
 
