@@ -2028,7 +2028,19 @@ struct WaveLeave {
 };
 
 enum WaveCount { WAVE_MODELS, WAVE_REJECTED, WAVE_START_PASSES, WAVE_BLOCKS, WAVE_SWING_SCANS, WAVE_BY_ONE_LANE,
-                 WAVE_QUIET_BLOCKS, WAVE_PMC_BLOCKS, WAVE_COUNTS };
+                 WAVE_QUIET_BLOCKS, WAVE_PMC_BLOCKS,
+#ifdef MDB_WAVE_TIMING // (a build of its own, never the product's: shader clock cycles by region, summed over the waves)
+                 WAVE_T_FIRST_STAGE, WAVE_T_SECOND_STAGE, WAVE_T_BLOCK_LOAD, WAVE_T_PMC, WAVE_T_SWING, WAVE_T_FINISH,
+                 WAVE_T_FLUSH, WAVE_T_TOTAL, WAVE_N_FIRST_STAGE,
+#endif
+                 WAVE_COUNTS };
+#ifdef MDB_WAVE_TIMING
+#define WAVE_TIMED_BEGIN() const uint64_t timed_from = __builtin_amdgcn_s_memtime()
+#define WAVE_TIMED_END(REGION) timed[(REGION) - WAVE_T_FIRST_STAGE] += __builtin_amdgcn_s_memtime() - timed_from
+#else
+#define WAVE_TIMED_BEGIN() do {} while (0)
+#define WAVE_TIMED_END(REGION) do {} while (0)
+#endif
 
 constexpr uint32_t WAVE_PASS_POINTS = 1024; // start points a pass over rejected start points looks at, at most
 constexpr uint32_t WAVE_PASS_STEPS = 4;     // what its second stage costs, in blocks of a model
@@ -2109,9 +2121,20 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     uint32_t half_steps = 0, next_look = leave.window_points, looked_at = 0; // (WaveLeave)
     uint32_t counted[WAVE_COUNTS] = {};
     uint32_t rejections_in_a_row = 0;
+#ifdef MDB_WAVE_TIMING
+    uint64_t timed[WAVE_COUNTS - WAVE_T_FIRST_STAGE] = {};
+    const uint64_t timed_start = __builtin_amdgcn_s_memtime();
+#endif
     auto report_counts = [&]() {
-        if (leave.counts && lane == 0)
+        if (leave.counts && lane == 0) {
+#ifdef MDB_WAVE_TIMING
+            timed[WAVE_T_TOTAL - WAVE_T_FIRST_STAGE] = __builtin_amdgcn_s_memtime() - timed_start;
+            for (int k = 0; k < WAVE_T_FIRST_STAGE; k++) atomicAdd(leave.counts + k, (unsigned long long)counted[k]);
+            for (int k = WAVE_T_FIRST_STAGE; k < WAVE_COUNTS; k++) atomicAdd(leave.counts + k, (unsigned long long)timed[k - WAVE_T_FIRST_STAGE]);
+#else
             for (int k = 0; k < WAVE_COUNTS; k++) atomicAdd(leave.counts + k, (unsigned long long)counted[k]);
+#endif
+        }
     };
     if (!PIECES && leave.chunk_left && n > leave.max_chunk_points) {
         if (lane == 0) {
@@ -2125,6 +2148,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 
     // The sums of the queued Swing models, one lane per model, and with them the models' last values.
     auto flush_pending = [&]() {
+        WAVE_TIMED_BEGIN();
         if (lane < (int)n_pending) {
             const PendingSwing item = pending[lane];
             const float *__restrict__ v = values + item.start;
@@ -2158,7 +2182,238 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             else out[item.record].p1 = (float)last_value;
         }
         n_pending = 0;
+        WAVE_TIMED_END(WAVE_T_FLUSH);
     };
+
+    // One model from `current` by the plain fitters, lane 0 alone (non-finite values, sums that may round). Writes the
+    // record (or the table's parameters); true: accepted.
+    auto fit_by_one_lane = [&](ModelRec &rec) -> bool {
+            counted[WAVE_BY_ONE_LANE] += 1;
+            int accepted_flag = 0;
+            if (lane == 0) {
+                PmcDev pmc;
+                SwingFast swing;
+                pmc.reset();
+                swing.reset();
+                bool pmc_fits = true, swing_fits = true;
+                for (uint32_t j = current; j < n && (pmc_fits || swing_fits); j++) {
+                    const float v = values[j];
+                    const double t = time_at(j);
+                    if (pmc_fits) pmc_fits = pmc.fit(eb, v);
+                    if (swing_fits) swing_fits = swing.fit(dev, t, v);
+                }
+                const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc.length;
+                const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing.length;
+                const bool choose_pmc = pmc_bpv <= swing_bpv;
+                if ((choose_pmc ? pmc_bpv : swing_bpv) <= (float)MDB_VALUE_SIZE_IN_BYTES) {
+                    accepted_flag = 1;
+                    if (choose_pmc) {
+                        rec.start_and_type = current;
+                        rec.end = current + pmc.length - 1;
+                        rec.p0 = (float)(pmc.sum / (double)pmc.length);
+                        rec.p1 = rec.p0;
+                    } else {
+                        rec.start_and_type = current | 0x80000000u;
+                        rec.end = current + swing.length - 1;
+                        if (HAS_TS) { // SwingFast::model with the span from the timestamps (swing.rs:246-259)
+                            const double projected = swing.numerator / swing.denominator;
+                            const double slope = max_num(swing.lower.slope, min_num(projected, swing.upper.slope));
+                            const double span = time_at(rec.end) - swing.start_time;
+                            rec.p0 = (float)swing.first_value;
+                            rec.p1 = (float)(slope * span + swing.first_value);
+                        } else {
+                            swing.model(interval, &rec.p0, &rec.p1);
+                        }
+                    }
+                }
+            }
+            const bool accepted_model = __shfl(accepted_flag, 0) != 0;
+            rec.start_and_type = __shfl(rec.start_and_type, 0);
+            rec.end = __shfl(rec.end, 0);
+            if (accepted_model && lane == 0) {
+                if (PIECES) {
+                    split.p0[base + current] = rec.p0;
+                    split.p1[base + current] = rec.p1;
+                } else {
+                    out[n_models] = rec;
+                }
+            }
+            return accepted_model;
+    };
+
+    // Does a model stand on start point `start` (PMC-Mean or Swing gets to 8 points: ModelBuilder::finish accepts it,
+    // types.rs:84-101 with compression.rs:238)? The two fitters step by step, this lane alone; the eight values are
+    // asked for up front (a model of fewer than 8 points is never accepted, so a start within 7 points of the end falls).
+    auto stands_by_steps = [&](uint32_t start) -> bool {
+        if (start + 7 >= n) return false;
+        float window[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) window[k] = values[start + k];
+        PmcDev pmc;
+        SwingFast swing;
+        pmc.reset();
+        swing.reset();
+        bool pmc_fits = true, swing_fits = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (pmc_fits || swing_fits) {
+                const double t = time_at(start + k);
+                if (pmc_fits) pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, window[k]);
+                if (swing_fits) swing_fits = swing.fit(dev, t, window[k]);
+            }
+        }
+        return pmc_fits || swing_fits;
+    };
+
+    // ---- a lossless bound: both fitters decide by equality, and nothing of them moves ------------------------------
+    // PMC-Mean accepts a value iff it equals the values before it (minimum and maximum must both equal the average,
+    // pmc_mean.rs:58-75; the f64 sum of up to 2^29 equal f32 values is exact, so the average IS the value). Swing's
+    // two bounds are one line - the one through the model's first two points, swing.rs:126-143 with a deviation of 0 -
+    // which accepts a point iff slope * t + intercept == value and never moves (swing.rs:144-197: neither bound is
+    // ever beside the value). So a model stands on a start point iff its first 8 values are equal (PMC-Mean; Swing
+    // then draws the line of slope 0 through them, accepts exactly the same points and loses the tie, types.rs:84-101)
+    // or lie on that line (Swing; PMC-Mean has ended at the second point), and it runs as far as that holds. 64 start
+    // points are decided per round, one lane each; a round in which no lane's third point is anywhere near its line
+    // does not divide. Windows with a NaN or an infinity in them (runs of which both fitters accept) go the long way.
+    if (KIND == MDB_EB_LOSSLESS) {
+        const double unit = 0x1p-53;
+        const double per_interval = HAS_TS ? 0.0 : 1.0 / interval; // (an interval of 0: infinite - every margin is, the exact test runs)
+        while (current < n) {
+            if (visited(current)) break; // (pieces) the chain from here on is in the table
+            counted[WAVE_START_PASSES] += 1;
+            const uint32_t start = current + (uint32_t)lane;
+            bool stands = false, by_pmc = false, long_way = false;
+            double slope = 0.0, intercept = 0.0;
+            float window[8] = {};
+            if (start + 7 < n) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) window[k] = values[start + k];
+                uint32_t largest = 0;
+                bool all_equal = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    largest = max(largest, __float_as_uint(window[k]) & 0x7fffffffu);
+                    all_equal = all_equal && window[k] == window[0];
+                }
+                if (largest >= 0x7f800000u) {
+                    long_way = true;
+                } else if (window[0] == window[1]) {
+                    by_pmc = all_equal;
+                    stands = all_equal;
+                } else {
+                    // Is the third point within the rounding of the reference's arithmetic of the line through the first
+                    // two? |slope * t2 + (v0 - slope * t0) - (v0 + (v1 - v0) k)| <= 2^-53 (4 |slope| (|t0| + |t2|) + |v0| +
+                    // |v2|) (1 + ...), k = (t2 - t0) / (t1 - t0): four times that, and this test's own roundings, are
+                    // covered; with loaded timestamps k comes from a 32-bit reciprocal, which costs another 2^-20 of it.
+                    const double v0 = (double)window[0], v1 = (double)window[1], v2 = (double)window[2];
+                    const double t0 = time_at(start);
+                    const double t1 = HAS_TS ? time_at(start + 1) : t0 + interval; // (exact, as every timestamp here)
+                    const double t2 = HAS_TS ? time_at(start + 2) : t1 + interval;
+                    const double rise = v1 - v0;
+                    double k = 2.0, per_step = per_interval, slack = 0.0;
+                    if (HAS_TS) {
+                        const float reciprocal = __builtin_amdgcn_rcpf((float)(t1 - t0));
+                        k = (double)((float)(t2 - t0) * reciprocal);
+                        per_step = (double)reciprocal;
+                        slack = fabs(rise) * k * 0x1p-19;
+                    }
+                    const double expected = v0 + rise * k;
+                    const double margin = 16.0 * unit * (fabs(rise) * ((fabs(t0) + fabs(t2)) * per_step) * 1.001 + fabs(v0) + fabs(v1) + fabs(v2)) + slack;
+                    if (!(fabs(expected - v2) > margin)) { // (also when the margin is not a number)
+                        slope = rise / (t1 - t0); // line_through_exact (swing.rs:323-340)
+                        intercept = v0 - slope * t0;
+                        bool on_the_line = slope * t2 + intercept == v2;
+#pragma unroll
+                        for (int j = 3; j < 8; j++) {
+                            const double t = HAS_TS ? time_at(start + j) : __builtin_fma((double)(start + j), interval, first_time);
+                            on_the_line = on_the_line && slope * t + intercept == (double)window[j];
+                        }
+                        stands = on_the_line;
+                    }
+                }
+            }
+            if (__ballot(long_way)) {
+                if (long_way) stands = stands_by_steps(start);
+            }
+            const unsigned long long standing = __ballot(stands);
+            if (!standing) { // nothing stands on these start points: they are residuals (compression.rs:258-262)
+                const uint32_t covered = min((uint32_t)MDB_WAVE, n - current);
+                if (PIECES) mark_rejected(current, covered);
+                current += covered;
+                counted[WAVE_REJECTED] += covered;
+                continue;
+            }
+            const int first = __builtin_ctzll(standing);
+            if (first > 0) {
+                if (PIECES) mark_rejected(current, (uint32_t)first);
+                current += (uint32_t)first;
+                counted[WAVE_REJECTED] += (uint32_t)first;
+            }
+            ModelRec rec{};
+            if (read_lane((int)long_way, first) != 0) {
+                if (!fit_by_one_lane(rec)) { // (it stands, so this is not expected: the start point is a residual then)
+                    if (PIECES) mark_rejected(current, 1);
+                    current += 1;
+                    counted[WAVE_REJECTED] += 1;
+                    continue;
+                }
+            } else {
+                const bool pmc_model = read_lane((int)by_pmc, first) != 0;
+                const float first_value32 = read_lane(window[0], first);
+                const double model_slope = read_lane(slope, first), model_intercept = read_lane(intercept, first);
+                uint32_t length = 8;
+                bool alive = true;
+                for (uint32_t position = current + 8; alive && position < n; position += MDB_WAVE) {
+                    counted[WAVE_BLOCKS] += 1;
+                    const uint32_t index = position + (uint32_t)lane;
+                    const bool valid = index < n;
+                    const float v = valid ? values[index] : 0.0f;
+                    bool differs; // (a NaN or an infinity differs from everything finite, as in both fitters)
+                    if (pmc_model) differs = v != first_value32;
+                    else differs = model_slope * time_at(valid ? index : position) + model_intercept != (double)v;
+                    const unsigned long long stops = __ballot(valid && differs);
+                    const uint32_t n_valid = min((uint32_t)MDB_WAVE, n - position);
+                    length += stops ? (uint32_t)__builtin_ctzll(stops) : n_valid;
+                    alive = !stops;
+                }
+                rec.end = current + length - 1;
+                if (pmc_model) {
+                    // (the sum starts at +0.0: of zeros of either sign it is +0.0, of anything else length * value)
+                    rec.start_and_type = current;
+                    rec.p0 = first_value32 == 0.0f ? 0.0f : first_value32;
+                    rec.p1 = rec.p0;
+                } else {
+                    // SwingFast::model (swing.rs:246-259): the slope between two bounds that are the same line
+                    const double start_time = time_at(current);
+                    const double span = HAS_TS ? time_at(rec.end) - start_time : (double)(length - 1) * interval;
+                    rec.start_and_type = current | 0x80000000u;
+                    rec.p0 = first_value32;
+                    rec.p1 = (float)(model_slope * span + (double)first_value32);
+                }
+                if (lane == 0) {
+                    if (PIECES) {
+                        split.p0[base + current] = rec.p0;
+                        split.p1[base + current] = rec.p1;
+                    } else {
+                        out[n_models] = rec;
+                    }
+                }
+            }
+            if (PIECES) {
+                if (lane == 0)
+                    __hip_atomic_store(&split.entry[base + current], (rec.end + ENTRY_END_BIAS) | (rec.start_and_type & 0x80000000u),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                gaps.on_model(current, rec.end);
+            }
+            n_models += 1;
+            current = rec.end + 1;
+        }
+        if (lane == 0 && !PIECES) plans[chunk] = {n_models, gaps.finish(n)};
+        counted[WAVE_MODELS] = n_models;
+        report_counts();
+        return;
+    }
 
     while (current < n) {
         if (visited(current)) break; // (pieces) the chain from here on is in the table
@@ -2183,6 +2438,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             // the next start points are first tried on three points, 64 at a time, and those that survive - up to
             // 64 of them, from up to 1 024 start points - are collected ...
             uint32_t n_survivors = 0, scanned = 0;
+            WAVE_TIMED_BEGIN();
             while (n_survivors < (uint32_t)MDB_WAVE && scanned < WAVE_PASS_POINTS && current + scanned < n) {
                 const uint32_t start = current + scanned + lane;
                 bool early = false;
@@ -2214,7 +2470,14 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                 n_survivors += (uint32_t)__popcll(survivors_here);
                 scanned += MDB_WAVE;
                 half_steps += 1; // (a look at 64 start points costs about half of what a block of a model costs)
+#ifdef MDB_WAVE_TIMING
+                timed[WAVE_N_FIRST_STAGE - WAVE_T_FIRST_STAGE] += 1;
+#endif
             }
+            WAVE_TIMED_END(WAVE_T_FIRST_STAGE);
+#ifdef MDB_WAVE_TIMING
+            const uint64_t second_from = __builtin_amdgcn_s_memtime();
+#endif
             if (n_survivors > 0) half_steps += 2 * WAVE_PASS_STEPS;
             __syncthreads();
             // ... and taken through the 8 points that decide it (neither fitter gets to 8: rejected), one lane each.
@@ -2225,21 +2488,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             uint32_t offset = 0;
             if ((uint32_t)lane < n_survivors) { // (nobody: the branch is not taken)
                 offset = survivors[lane];
-                const uint32_t start = current + offset;
-                PmcDev pmc;
-                SwingFast swing;
-                pmc.reset();
-                swing.reset();
-                bool pmc_fits = true, swing_fits = true;
-                for (uint32_t k = 0; k < 8; k++) {
-                    const uint32_t j = start + k;
-                    if (j >= n || !(pmc_fits || swing_fits)) break;
-                    const float v = values[j];
-                    const double t = time_at(j);
-                    if (pmc_fits) pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v);
-                    if (swing_fits) swing_fits = swing.fit(dev, t, v);
-                }
-                stands = pmc.length >= 8 || swing.length >= 8;
+                stands = stands_by_steps(current + offset);
             }
             const unsigned long long standing = __ballot(stands);
             __syncthreads();
@@ -2254,6 +2503,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                 current += covered;
                 counted[WAVE_REJECTED] += covered;
             }
+#ifdef MDB_WAVE_TIMING
+            timed[WAVE_T_SECOND_STAGE - WAVE_T_FIRST_STAGE] += __builtin_amdgcn_s_memtime() - second_from;
+#endif
             continue;
         }
 
@@ -2273,8 +2525,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             const uint32_t index = position + lane;
             const int n_valid = (int)min((uint32_t)MDB_WAVE, n - position);
             const bool valid = lane < n_valid;
+#ifdef MDB_WAVE_TIMING
+            const uint64_t load_from = __builtin_amdgcn_s_memtime();
+#endif
             const float v = valid ? values[index] : 0.0f;
-            if (__ballot(valid && !isfinite(v))) {
+            const bool not_finite = __ballot(valid && !isfinite(v)) != 0;
+#ifdef MDB_WAVE_TIMING
+            timed[WAVE_T_BLOCK_LOAD - WAVE_T_FIRST_STAGE] += __builtin_amdgcn_s_memtime() - load_from;
+#endif
+            if (not_finite) {
                 by_one_lane = true;
                 break;
             }
@@ -2282,6 +2541,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             if (position == current) first_value = read_lane(value, 0);
 
             if (pmc_alive) {
+                WAVE_TIMED_BEGIN();
                 counted[WAVE_PMC_BLOCKS] += 1;
                 // Up to which lane is every partial sum exact (file comment)? The exponents met so far, per lane.
                 const uint32_t bits = __float_as_uint(v);
@@ -2323,6 +2583,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     by_one_lane = true;
                     break;
                 }
+                WAVE_TIMED_END(WAVE_T_PMC);
                 if (accepted > 0) {
                     pmc_min = read_lane(next_min, accepted - 1);
                     pmc_max = read_lane(next_max, accepted - 1);
@@ -2336,6 +2597,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             }
 
             if (swing_alive) {
+                WAVE_TIMED_BEGIN();
                 const double t = valid ? time_at(index) : 0.0;
                 const double deviation = lean_deviation<KIND>(dev.factor, value);
                 // Every bound is a line through the model's first point, so its slope says it all: the intercept of
@@ -2389,64 +2651,18 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                         first_lane = at + 1;
                     }
                 }
+                WAVE_TIMED_END(WAVE_T_SWING);
             }
             position += MDB_WAVE;
         }
 
+#ifdef MDB_WAVE_TIMING
+        const uint64_t finish_from = __builtin_amdgcn_s_memtime();
+#endif
         bool accepted_model = false;
         ModelRec rec{};
         if (by_one_lane) {
-            counted[WAVE_BY_ONE_LANE] += 1;
-            // The plain fitters, lane 0 alone (non-finite values, sums that may round).
-            int accepted_flag = 0;
-            if (lane == 0) {
-                PmcDev pmc;
-                SwingFast swing;
-                pmc.reset();
-                swing.reset();
-                bool pmc_fits = true, swing_fits = true;
-                for (uint32_t j = current; j < n && (pmc_fits || swing_fits); j++) {
-                    const float v = values[j];
-                    const double t = time_at(j);
-                    if (pmc_fits) pmc_fits = pmc.fit(eb, v);
-                    if (swing_fits) swing_fits = swing.fit(dev, t, v);
-                }
-                const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc.length;
-                const float swing_bpv = ((float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES + 1.0f) / (float)swing.length;
-                const bool choose_pmc = pmc_bpv <= swing_bpv;
-                if ((choose_pmc ? pmc_bpv : swing_bpv) <= (float)MDB_VALUE_SIZE_IN_BYTES) {
-                    accepted_flag = 1;
-                    if (choose_pmc) {
-                        rec.start_and_type = current;
-                        rec.end = current + pmc.length - 1;
-                        rec.p0 = (float)(pmc.sum / (double)pmc.length);
-                        rec.p1 = rec.p0;
-                    } else {
-                        rec.start_and_type = current | 0x80000000u;
-                        rec.end = current + swing.length - 1;
-                        if (HAS_TS) { // SwingFast::model with the span from the timestamps (swing.rs:246-259)
-                            const double projected = swing.numerator / swing.denominator;
-                            const double slope = max_num(swing.lower.slope, min_num(projected, swing.upper.slope));
-                            const double span = time_at(rec.end) - swing.start_time;
-                            rec.p0 = (float)swing.first_value;
-                            rec.p1 = (float)(slope * span + swing.first_value);
-                        } else {
-                            swing.model(interval, &rec.p0, &rec.p1);
-                        }
-                    }
-                }
-            }
-            accepted_model = __shfl(accepted_flag, 0) != 0;
-            rec.start_and_type = __shfl(rec.start_and_type, 0);
-            rec.end = __shfl(rec.end, 0);
-            if (accepted_model && lane == 0) {
-                if (PIECES) {
-                    split.p0[base + current] = rec.p0;
-                    split.p1[base + current] = rec.p1;
-                } else {
-                    out[n_models] = rec;
-                }
-            }
+            accepted_model = fit_by_one_lane(rec);
         } else {
             // ModelBuilder::finish (types.rs:84-101): fewest bytes per value, PMC-Mean wins ties.
             const float pmc_bpv = (float)MDB_COMPRESSED_METADATA_SIZE_IN_BYTES / (float)pmc_length;
@@ -2505,6 +2721,9 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             rejections_in_a_row += 1;
             after_rejection = rejections_in_a_row >= 2;
         }
+#ifdef MDB_WAVE_TIMING
+        timed[WAVE_T_FINISH - WAVE_T_FIRST_STAGE] += __builtin_amdgcn_s_memtime() - finish_from;
+#endif
     }
     __syncthreads();
     flush_pending();
@@ -4466,6 +4685,12 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                              (unsigned long long)n_chunks, (unsigned long long)points_end, counts[WAVE_MODELS], counts[WAVE_REJECTED],
                              counts[WAVE_START_PASSES], counts[WAVE_BLOCKS], counts[WAVE_PMC_BLOCKS], counts[WAVE_QUIET_BLOCKS],
                              counts[WAVE_SWING_SCANS], counts[WAVE_BY_ONE_LANE]);
+#ifdef MDB_WAVE_TIMING
+                std::fprintf(stderr, "[fit] k_fit_models_wave cycles: total %llu; first stage %llu (%llu rounds), second stage %llu, block load %llu, "
+                             "PMC-Mean %llu, Swing %llu, finish %llu, flush %llu\n", counts[WAVE_T_TOTAL], counts[WAVE_T_FIRST_STAGE],
+                             counts[WAVE_N_FIRST_STAGE], counts[WAVE_T_SECOND_STAGE], counts[WAVE_T_BLOCK_LOAD], counts[WAVE_T_PMC],
+                             counts[WAVE_T_SWING], counts[WAVE_T_FINISH], counts[WAVE_T_FLUSH]);
+#endif
             }
             if (leave.chunk_left) {
                 unsigned int left[2] = {0, 0};
