@@ -1257,6 +1257,8 @@ struct LeanRotation {
     uint32_t stretch_steps = 0;
     unsigned long long *saved = nullptr;    // [group][word of LeanSaved][lane]
     unsigned long long *masks = nullptr;    // [group][4]: active, PMC-Mean fits, Swing fits, Swing's first value finite
+    unsigned int *error = nullptr;          // the call's error word (ERR_ROTATION_STALL)
+    uint32_t max_naps = 0;                  // naps a wave takes at an empty place before it gives the call up
 };
 constexpr int LEAN_MASK_WORDS = 4;
 constexpr uint32_t LEAN_STRETCH_STEPS = 512; // (256 to 1 024 are within a percent of each other; 128 and 4 096 cost 6 %)
@@ -1299,13 +1301,78 @@ __global__ void k_fit_rotation_begin(LeanRotation rotation) {
 
 // The queue, a place at a time: a wave takes the next place at the head and waits for the group that is - or will be -
 // put there (0xffffffff: every group is through); a wave that has worked on a group for a stretch puts it at the tail.
-// (Functions of their own, not inlined: the loop they are called from is long enough.)
-__device__ __noinline__ uint32_t rotation_take(const LeanRotation rotation) {
+//
+// What orders a handover. The state of a group (LeanSaved, the four masks) is written with RELAXED device-scope stores
+// and read with relaxed device-scope loads; the handover itself is a relaxed store to / load of the group's place in
+// the queue. Nothing here is a release or an acquire (at device scope those are a write-back and an invalidation of an
+// XCD's whole L2, see lean_saved_store), so the order rests on two things that have to be stated:
+//   * the HARDWARE: on gfx942 / gfx950 a wave's vector memory operations are counted by ONE counter (vmcnt) that
+//     covers the sc1 write-through stores, so `s_waitcnt vmcnt(0)` in rotation_give means "my stores have reached the
+//     memory side" (targets with a separate store counter - gfx10 and later - would need s_waitcnt_vscnt: refused
+//     below), and loads are issued in program order, so the taker's loads of the state leave after its look at the
+//     place has come back;
+//   * the COMPILER, which must leave the queue's operations where they are written. With BOTH functions inlined into
+//     k_fit_models_lean (ROCm 7.2's clang) the kernel is wrong - deterministically: the first rotation test fails in half a
+//     second, the headline fit "takes" 42 ms instead of 54 because groups are dropped - and its code has a loop level
+//     the source does not have (the queue's "nothing taken" path threaded into lean_group's loop). Measured in round 6
+//     (scripts/r06/rotation_inline.sh, docs/rotation_inline/): either function inlined alone is right; both inlined are
+//     right again with ANY `asm volatile(... ::: "memory")` at rotation_take's entry - an s_waitcnt of either counter,
+//     or no instruction at all - and wrong with one at its exit or at rotation_give's entry only. So it is a
+//     transformation across the top of rotation_take, not the hardware's order, and a barrier for the compiler there is
+//     what keeps it out; a function call did the same by accident. Both functions carry the barriers at entry and exit
+//     now and stay calls (the loop they are called from is long enough as it is; same speed either way, 54.0-54.9 ms).
+// A wave that waits at a place for longer than any kernel runs (max_naps naps of some 14 us) sets ERR_ROTATION_STALL
+// and reports "every group is through": the call fails instead of hanging.
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx942__) || defined(__gfx950__)
+#define MDB_ROTATION_ORDERED_BY_VMCNT 1
+#else
+#error "rotation_give orders its stores with s_waitcnt vmcnt(0): valid where one counter covers loads and stores (gfx942, gfx950)"
+#endif
+#ifdef MDB_ROTATION_NO_BARRIER
+__device__ __forceinline__ void compiler_barrier() {}
+#else
+__device__ __forceinline__ void compiler_barrier() { asm volatile("" ::: "memory"); }
+#endif
+// (scripts/r06/rotation_inline.sh: the experiments behind the paragraph above, never the product. MDB_ROTATION_INLINE: 1 = take
+// inlined, 2 = give inlined, 3 = both; MDB_ROTATION_ENTRY_WAIT: the s_waitcnt a function's entry has, at the inlined places)
+#ifndef MDB_ROTATION_INLINE
+#define MDB_ROTATION_INLINE 0
+#endif
+#if MDB_ROTATION_INLINE & 1
+#define MDB_ROTATION_TAKE_CALL __forceinline__
+#else
+#define MDB_ROTATION_TAKE_CALL __noinline__
+#endif
+#if MDB_ROTATION_INLINE & 2
+#define MDB_ROTATION_GIVE_CALL __forceinline__
+#else
+#define MDB_ROTATION_GIVE_CALL __noinline__
+#endif
+// MDB_ROTATION_ENTRY_WAIT: bit 0 = at take's entry, bit 1 = at give's; MDB_ROTATION_ENTRY_WAIT_KIND: 0 all counters, 1 vmcnt, 2 lgkmcnt, 3 none (a barrier for the compiler only)
+#ifndef MDB_ROTATION_ENTRY_WAIT
+#define MDB_ROTATION_ENTRY_WAIT 0
+#endif
+#ifndef MDB_ROTATION_ENTRY_WAIT_KIND
+#define MDB_ROTATION_ENTRY_WAIT_KIND 0
+#endif
+template <int PLACE> __device__ __forceinline__ void entry_wait() {
+    if ((MDB_ROTATION_ENTRY_WAIT & PLACE) == 0) return;
+    if (MDB_ROTATION_ENTRY_WAIT_KIND == 0) asm volatile("s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" ::: "memory");
+    if (MDB_ROTATION_ENTRY_WAIT_KIND == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MDB_ROTATION_ENTRY_WAIT_KIND == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (MDB_ROTATION_ENTRY_WAIT_KIND == 3) asm volatile("" ::: "memory"); // (no instruction: the compiler alone)
+}
+
+__device__ MDB_ROTATION_TAKE_CALL uint32_t rotation_take(const LeanRotation rotation) {
+    entry_wait<1>();
+#if MDB_ROTATION_INLINE == 0
+    compiler_barrier();
+#endif
     unsigned int taken = 0;
     if (threadIdx.x % MDB_WAVE == 0) {
         const unsigned int place = atomicAdd(&rotation.counters[0], 1u);
         unsigned int *slot = rotation.ready + (place & rotation.slot_mask);
-        for (;;) {
+        for (uint32_t naps = 0;; naps++) {
             // (a look, not an atomic, while there is nothing: hundreds of waves wait at any time, and a stretch takes
             // milliseconds - a look every few microseconds is early enough and leaves the memory system alone)
             if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -1313,23 +1380,31 @@ __device__ __noinline__ uint32_t rotation_take(const LeanRotation rotation) {
                 break;
             }
             if (__hip_atomic_load(&rotation.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rotation.n_groups) break;
+            if (naps >= rotation.max_naps) {
+                atomicOr(rotation.error, ERR_ROTATION_STALL);
+                break;
+            }
             for (int nap = 0; nap < 4; nap++) __builtin_amdgcn_s_sleep(127);
         }
     }
     taken = (unsigned int)__builtin_amdgcn_readfirstlane((int)taken);
     // (No fence: what the wave that had the group before wrote about it is read with device-scope loads, and those
-    // are issued after the look at the slot has come back.)
+    // are issued after the look at the slot has come back - the barrier keeps the compiler to that.)
+    compiler_barrier();
     return taken - 1u;
 }
 
-__device__ __noinline__ void rotation_give(const LeanRotation rotation, uint32_t group) {
+__device__ MDB_ROTATION_GIVE_CALL void rotation_give(const LeanRotation rotation, uint32_t group) {
+    entry_wait<2>();
     // Everything written about the group (device-scope stores, written through) has arrived before it can be taken
     // again: the wave waits for its stores, no more (see lean_saved_store for the fence this is instead of).
+    compiler_barrier();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x % MDB_WAVE == 0) {
         const unsigned int place = atomicAdd(&rotation.counters[1], 1u);
         __hip_atomic_store(rotation.ready + (place & rotation.slot_mask), group + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    compiler_barrier();
 }
 
 __device__ __forceinline__ LaneMask uniform_mask(unsigned long long loaded) {
@@ -2265,6 +2340,10 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         return pmc_fits || swing_fits;
     };
 
+    // (for the margins within which a third point is near a line; an interval of 0: infinite - every margin is)
+    const double unit = 0x1p-53;
+    const double per_interval = HAS_TS ? 0.0 : 1.0 / interval;
+
     // ---- a lossless bound: both fitters decide by equality, and nothing of them moves ------------------------------
     // PMC-Mean accepts a value iff it equals the values before it (minimum and maximum must both equal the average,
     // pmc_mean.rs:58-75; the f64 sum of up to 2^29 equal f32 values is exact, so the average IS the value). Swing's
@@ -2276,8 +2355,6 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     // points are decided per round, one lane each; a round in which no lane's third point is anywhere near its line
     // does not divide. Windows with a NaN or an infinity in them (runs of which both fitters accept) go the long way.
     if (KIND == MDB_EB_LOSSLESS) {
-        const double unit = 0x1p-53;
-        const double per_interval = HAS_TS ? 0.0 : 1.0 / interval; // (an interval of 0: infinite - every margin is, the exact test runs)
         while (current < n) {
             if (visited(current)) break; // (pieces) the chain from here on is in the table
             counted[WAVE_START_PASSES] += 1;
@@ -2441,26 +2518,37 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             WAVE_TIMED_BEGIN();
             while (n_survivors < (uint32_t)MDB_WAVE && scanned < WAVE_PASS_POINTS && current + scanned < n) {
                 const uint32_t start = current + scanned + lane;
-                bool early = false;
-                if (start + 2 < n) {
+                // (a start within 7 points of the end never stands: nothing of fewer than 8 points is accepted)
+                bool early = start < n && start + 7 >= n;
+                if (start + 7 < n) {
                     const float v0 = values[start], v1 = values[start + 1], v2 = values[start + 2];
                     if (isfinite(v0) && isfinite(v1) && isfinite(v2)) {
                         PmcDev pmc;
                         pmc.reset();
                         const bool pmc_fits = pmc_fit_fast(pmc, pmc_fast, eb, v0) && pmc_fit_fast(pmc, pmc_fast, eb, v1) &&
                                               pmc_fit_fast(pmc, pmc_fast, eb, v2);
-                        // swing.rs:126-143 for the second point, :144-160 for the third
+                        // Swing (swing.rs:126-143 for the second point, :144-160 for the third) is CERTAINLY out at the
+                        // third point when the value lies beyond both bounds by more than the reference's own arithmetic
+                        // can be off: its bounds at t2 are within 2^-53 (4 |slope| (|t0| + |t2|) + |v0| + |bound|) of
+                        // v0 + (v1 +- deviation1 - v0) k, k = (t2 - t0) / (t1 - t0) - no division here, the survivors get
+                        // the fitters themselves. (Loaded timestamps: k from a 32-bit reciprocal, another 2^-20 of it.)
                         const double t0 = time_at(start);
-                        const double t1 = HAS_TS ? time_at(start + 1) : t0 + interval; // (exact, as every timestamp here)
-                        const double t2 = HAS_TS ? time_at(start + 2) : t1 + interval;
-                        const double deviation1 = dev.of((double)v1), deviation2 = dev.of((double)v2);
-                        const LineDev above = line_through_exact(t0, (double)v0, t1, (double)v1 + deviation1);
-                        const LineDev below = line_through_exact(t0, (double)v0, t1, (double)v1 - deviation1);
-                        const double upper_approximation = above.slope * t2 + above.intercept;
-                        const double lower_approximation = below.slope * t2 + below.intercept;
-                        const bool swing_fits = !(upper_approximation + deviation2 < (double)v2 ||
-                                                  lower_approximation - deviation2 > (double)v2);
-                        early = !pmc_fits && !swing_fits;
+                        const double t2 = HAS_TS ? time_at(start + 2) : t0 + 2.0 * interval; // (exact, as every timestamp here)
+                        const double w0 = (double)v0, w1 = (double)v1, w2 = (double)v2;
+                        const double deviation1 = dev.of(w1), deviation2 = dev.of(w2);
+                        const double rise_above = (w1 + deviation1) - w0, rise_below = (w1 - deviation1) - w0;
+                        double k = 2.0, per_step = per_interval, slack = 0.0;
+                        if (HAS_TS) {
+                            const float reciprocal = __builtin_amdgcn_rcpf((float)(time_at(start + 1) - t0));
+                            k = (double)((float)(t2 - t0) * reciprocal);
+                            per_step = (double)reciprocal;
+                            slack = (fabs(rise_above) + fabs(rise_below)) * k * 0x1p-19;
+                        }
+                        const double margin = 16.0 * unit * ((fabs(rise_above) + fabs(rise_below)) * ((fabs(t0) + fabs(t2)) * per_step) * 1.001 +
+                                                             fabs(w0) + fabs(w1) + fabs(w2) + deviation1 + deviation2) + slack;
+                        const bool swing_out = (w0 + rise_above * k) + deviation2 < w2 - margin ||
+                                               (w0 + rise_below * k) - deviation2 > w2 + margin; // (false when anything is not a number)
+                        early = !pmc_fits && swing_out;
                     }
                 }
                 const bool survives = start < n && !early;
@@ -2478,11 +2566,17 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 #ifdef MDB_WAVE_TIMING
             const uint64_t second_from = __builtin_amdgcn_s_memtime();
 #endif
-            if (n_survivors > 0) half_steps += 2 * WAVE_PASS_STEPS;
+            uint32_t covered = min(scanned, n - current);
+            if (n_survivors == 0) { // nobody: all of them are residuals (compression.rs:258-262)
+                if (PIECES) mark_rejected(current, covered);
+                current += covered;
+                counted[WAVE_REJECTED] += covered;
+                continue;
+            }
+            half_steps += 2 * WAVE_PASS_STEPS;
             __syncthreads();
             // ... and taken through the 8 points that decide it (neither fitter gets to 8: rejected), one lane each.
             // What lies behind the 64th survivor is the next pass's.
-            uint32_t covered = min(scanned, n - current);
             if (n_survivors > (uint32_t)MDB_WAVE) covered = survivors[MDB_WAVE];
             bool stands = false;
             uint32_t offset = 0;
@@ -4754,6 +4848,9 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 const uint32_t rotating_blocks = (uint32_t)(groups - std::max<uint64_t>(1, groups / 128));
                 if (rotate) {
                     rotation.n_groups = (uint32_t)groups;
+                    rotation.error = error_flag;
+                    // (a nap is 4 x s_sleep(127), some 14 us: a minute by default; MDB_FIT_ROTATE_MAX_NAPS for the test of it)
+                    rotation.max_naps = fit_wave_number("MDB_FIT_ROTATE_MAX_NAPS", 1u << 22);
                     rotation.stretch_steps = LEAN_STRETCH_STEPS;
                     if (const char *text = option_text("MDB_FIT_ROTATE_STEPS")) rotation.stretch_steps = (uint32_t)std::max(1ll, std::atoll(text));
                     uint64_t slots = 64;
@@ -4889,6 +4986,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         if (error & ERR_SPLIT_CHAIN) {
             release();
             return fail("Internal error: the split fit left a gap in a chunk's model chain.");
+        }
+        if (error & ERR_ROTATION_STALL) {
+            release();
+            return fail("Internal error: a wave of the rotating fit waited for a group of chunks that was never handed over.");
         }
         if (error) {
             release();

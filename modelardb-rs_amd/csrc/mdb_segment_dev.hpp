@@ -30,6 +30,7 @@ enum : uint32_t {
     ERR_TOO_LONG = 1u << 5,
     ERR_SPLIT_CHAIN = 1u << 6, // fit, split mode: the walk reached a point no lane visited (a bug)
     ERR_HOST_INDEX = 1u << 7,  // grid: the cursors host threads left disagree with the kernels' analysis (a bug)
+    ERR_ROTATION_STALL = 1u << 8, // fit, rotating groups: a wave waited for a group longer than any kernel runs (a bug)
 };
 
 struct SegDesc { // what one lane knows about a segment (registers only)

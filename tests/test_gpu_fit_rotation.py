@@ -18,7 +18,7 @@ from test_gpu_fit import assert_same_segments
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ("MDB_FIT_WAVE", "MDB_FIT_PIECE_POINTS", "MDB_FIT_LEAN", "MDB_FIT_FAST", "MDB_FIT_SMALL", "MDB_FIT_ROTATE",
-            "MDB_FIT_ROTATE_STEPS", "MDB_FIT_GAP_MIN_VALUES")
+            "MDB_FIT_ROTATE_STEPS", "MDB_FIT_ROTATE_MAX_NAPS", "MDB_FIT_GAP_MIN_VALUES")
 
 
 @pytest.fixture(autouse=True)
@@ -97,3 +97,39 @@ def test_rotation_chosen_by_the_library(hip, monkeypatch):
     assert len(expected) > 0
     got = hip.compress_chunks(timestamps[:64 * sample], values[:64 * sample], offsets[:sample + 1], eb)
     assert_same_segments(got, expected)
+
+
+def test_the_bench_shape_with_stretches_of_one_step(hip, monkeypatch):
+    """The headline's call in groups - 2 391 of them (153 000 chunks), which is what rotates by itself on 1 024 SIMDs -
+    with every fitter through memory between any two points (stretches of ONE step: some 150 handovers per group and
+    2 391 groups in the queue at once): identical to the plain kernel's columns, and to the oracle's on a sample."""
+    n_chunks = 153_000
+    eb = cases.error_bounds()["rel1"]
+    timestamps, values, offsets = call_of([150 - (k % 5) for k in range(n_chunks)], 11)
+    monkeypatch.setenv("MDB_FIT_ROTATE", "0")
+    plain = hip.compress_chunks(timestamps, values, offsets, eb)
+    monkeypatch.setenv("MDB_FIT_ROTATE", "1")
+    monkeypatch.setenv("MDB_FIT_ROTATE_STEPS", "1")
+    rotated = hip.compress_chunks(timestamps, values, offsets, eb)
+    assert rotated.identical(plain)
+    sample = 500
+    end = int(offsets[sample])
+    assert_same_segments(hip.compress_chunks(timestamps[:end], values[:end], offsets[:sample + 1], eb),
+                         ora.compress_chunks(timestamps[:end], values[:end], offsets[:sample + 1], eb))
+
+
+def test_a_wave_that_waits_too_long_fails_the_call(hip, monkeypatch):
+    """rotation_take's wait is bounded: with a bound of ONE nap (some 14 us; a minute by default) the waves that wait
+    at the queue's end for the last groups give up, and the call fails with the library's error text instead of
+    hanging - and the next call on the same context works."""
+    eb = cases.error_bounds()["rel1"]
+    timestamps, values, offsets = call_of([60_000] * 200, 5)  # 4 groups, 3 waves: the last stretches leave waves waiting
+    monkeypatch.setenv("MDB_FIT_ROTATE", "1")
+    monkeypatch.setenv("MDB_FIT_ROTATE_STEPS", "50000")
+    monkeypatch.setenv("MDB_FIT_ROTATE_MAX_NAPS", "1")
+    with pytest.raises(mdb.HipError, match="rotating fit waited"):
+        hip.compress_chunks(timestamps, values, offsets, eb)
+    monkeypatch.delenv("MDB_FIT_ROTATE_MAX_NAPS")
+    again = hip.compress_chunks(timestamps, values, offsets, eb)
+    monkeypatch.setenv("MDB_FIT_ROTATE", "0")
+    assert again.identical(hip.compress_chunks(timestamps, values, offsets, eb))
