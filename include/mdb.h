@@ -155,7 +155,9 @@ int mdb_set_option(const char *name, const char *value);
 int mdb_reload_options(void);
 /* What a switch is set to (NULL: not set). The text stays valid for the life of the process (setting the switch again
  * or reloading the table makes later look-ups return another text and leaves this one as it is), so mdb_set_option and
- * mdb_reload_options may be called while other threads are inside calls: a call sees a switch as it was when it asked. */
+ * mdb_reload_options may be called while other threads are inside calls: a call sees a switch as it was when it asked.
+ * The price of that: every DISTINCT value a switch has ever had is kept (a few bytes each, never freed) - switches are
+ * for deployments and tests, not a per-query channel; a caller that sets one to ever-changing values grows the table. */
 const char *mdb_option(const char *name);
 
 /* Pipelined form, for an operator that is polled (GridStream::poll_next, grid_exec.rs:402-429): submit

@@ -539,8 +539,13 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
     // axis when the batch is first asked about a range, again if a switch has moved the line to the decoders).
     const TsWalkRange *whole_acc = nullptr;
     std::shared_ptr<void> whole_acc_held; // (the array stays this call's while its kernels read it)
+    std::shared_ptr<void> retired;        // (an array a switch has made stale: let go of after the lock, hipFree waits for the device)
     if (range && !(cache_setting && std::strcmp(cache_setting, "0") == 0)) {
         if (std::shared_ptr<MvIndex> kept = owned_segments_index(in)) {
+            // One array per kind of call - with cursors made for this call (host batches) and without - so that calls of
+            // both kinds on one batch do not make each other's array again and again; within a kind the key is the line to
+            // the decoders (a switch that tests move).
+            const int slot = indexed_piece_base ? 1 : 0;
             const uint64_t key = ((uint64_t)mv_min_values << 2) | (indexed_piece_base ? 2u : 0u) | 1u;
             std::lock_guard<std::mutex> lock(kept->mutex);
             // (needs the walk over the whole axis where there are streams to walk: range_from_kept or none at all)
@@ -548,13 +553,13 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
             for (int32_t b = 0; b < in->timestamps.n_buffers && in->timestamps.buffer_sizes; b++)
                 ts_payload += (uint64_t)std::max<int64_t>(in->timestamps.buffer_sizes[b], 0);
             const bool walkable = range_from_kept || ts_payload == 0;
-            if (walkable && kept->range_acc_key != key && !kept->range_acc_failed) {
+            if (walkable && kept->range_acc_key[slot] != key && !kept->range_acc_failed[slot]) {
                 // A new array per key (another call may still be reading the one made under the last key); without the
                 // memory for it the query works every segment out itself, now and from now on.
                 void *fresh = nullptr;
                 if (hipMalloc(&fresh, in->n * sizeof(TsWalkRange)) != hipSuccess) {
                     (void)hipGetLastError();
-                    kept->range_acc_failed = true;
+                    kept->range_acc_failed[slot] = true;
                 }
                 if (fresh) {
                 const int device = ctx->device;
@@ -575,13 +580,17 @@ int agg_run(mdb_ctx *ctx, const mdb_segments *in, bool range, int64_t t_lo, int6
                 AggPartial made;
                 MDB_HIP_CHECK(hipMemcpyAsync(&made, result, sizeof(AggPartial), hipMemcpyDeviceToHost, ctx->stream));
                 MDB_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                kept->range_acc_key = made.error ? 0 : key; // (a fault: every call finds and reports it itself)
-                if (made.error) kept->range_acc_failed = true;
-                else kept->range_acc = made_array;
+                if (made.error) { // (a fault in the streams: every call finds and reports it itself; not tried again for this kind)
+                    kept->range_acc_failed[slot] = true;
+                } else {
+                    retired = std::move(kept->range_acc[slot]);
+                    kept->range_acc[slot] = made_array;
+                    kept->range_acc_key[slot] = key;
+                }
                 }
             }
-            if (walkable && kept->range_acc_key == key && kept->range_acc) {
-                whole_acc_held = kept->range_acc;
+            if (walkable && kept->range_acc_key[slot] == key && kept->range_acc[slot]) {
+                whole_acc_held = kept->range_acc[slot];
                 whole_acc = static_cast<const TsWalkRange *>(whole_acc_held.get());
             }
         }

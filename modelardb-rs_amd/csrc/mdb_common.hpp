@@ -225,9 +225,10 @@ struct MvIndex {
     // that contain it; `range_acc_key`: the line to the decoders it was made under (0: not made).
     // A query holds the array it reads (a copy of the pointer, taken under the mutex) for as long as its kernels run:
     // a rebuild under another key on another context makes a NEW array and leaves this one to its readers.
-    std::shared_ptr<void> range_acc; // TsWalkRange[n] (freed by its deleter)
-    uint64_t range_acc_key = 0;
-    bool range_acc_failed = false;   // no memory for it: not tried again
+    // ([0]: calls on the resident batch, [1]: calls with cursors of their own - one array each, so they do not evict each other)
+    std::shared_ptr<void> range_acc[2]; // TsWalkRange[n] (freed by its deleter)
+    uint64_t range_acc_key[2] = {0, 0};
+    bool range_acc_failed[2] = {false, false}; // no memory for it / a fault in the streams: not tried again
     // The index of ONE call over host batches (mv_host_index, mdb_grid.hip): made by host threads while the batches
     // are on their way, for the long streams only - a segment without pieces is the serial kernel's - and living in
     // the context's scratch.

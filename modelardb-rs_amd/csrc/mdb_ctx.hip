@@ -54,8 +54,12 @@ hipError_t mail_write(mdb_ctx *ctx, void *dev_to, const void *host_from, uint64_
     if (bytes == 0) return hipSuccess;
     mail_make(ctx);
     const uint64_t at = (ctx->mail_used + 15u) & ~15ull;
-    if (!ctx->mail || bytes > MAIL_COPY_LIMIT || at + bytes > MAIL_BYTES)
-        return hipMemcpyAsync(dev_to, host_from, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (!ctx->mail || bytes > MAIL_COPY_LIMIT || at + bytes > MAIL_BYTES) {
+        // Too large for the mailbox (or none): straight from the caller's pageable memory - and waited for, because
+        // the contract is "`host_from` may be changed or freed at once" (mdb_common.hpp) whichever way the bytes go.
+        const hipError_t status = hipMemcpyAsync(dev_to, host_from, bytes, hipMemcpyHostToDevice, ctx->stream);
+        return status != hipSuccess ? status : hipStreamSynchronize(ctx->stream);
+    }
     ctx->mail_used = at + bytes;
     std::memcpy(ctx->mail + at, host_from, bytes);
     return hipMemcpyAsync(dev_to, ctx->mail + at, bytes, hipMemcpyHostToDevice, ctx->stream);

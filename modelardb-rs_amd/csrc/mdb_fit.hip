@@ -5075,19 +5075,28 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP_STAGE_OFFSETS, ((uint64_t)gap_waves + 1) * 8, &p));
                 unsigned long long *stage_offsets = static_cast<unsigned long long *>(p);
                 FIT_TRY(device_exclusive_scan(ctx, GapStageBytes{items, gap_ids}, gap_waves, stage_offsets, seg_block_sums, "k_fit_scan"));
-                unsigned long long stage_bytes = 0;
-                FIT_CHECK(mail_read(ctx, &stage_bytes, stage_offsets + gap_waves, 8));
-                FIT_CHECK(mail_sync(ctx));
-                size_t device_free = 0, device_total = 0;
-                if (hipMemGetInfo(&device_free, &device_total) != hipSuccess) {
-                    (void)hipGetLastError();
-                    device_free = 0;
-                }
-                // (what is reserved already counts as free for this: the slot grows, it is not added to)
-                if (stage_bytes <= ctx->scratch_bytes[SCRATCH_FIT_GAP_STAGE] || stage_bytes <= device_free / 4) {
-                    FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP_STAGE, stage_bytes, &p));
-                    gap_stage.bytes = static_cast<uint8_t *>(p);
+                // What the places add up to at most is known here (gap_stage_bytes: every listed segment's values are among
+                // the call's points): while the slot holds that much the call asks neither the device for the sum nor the
+                // driver for its free memory - the steady state of a server's calls.
+                const unsigned long long at_most = points_end * 45u / 8u + 48ull * gap_waves;
+                if (at_most <= ctx->scratch_bytes[SCRATCH_FIT_GAP_STAGE] && ctx->scratch[SCRATCH_FIT_GAP_STAGE]) {
+                    gap_stage.bytes = static_cast<uint8_t *>(ctx->scratch[SCRATCH_FIT_GAP_STAGE]);
                     gap_stage.offsets = stage_offsets;
+                } else {
+                    unsigned long long stage_bytes = 0;
+                    FIT_CHECK(mail_read(ctx, &stage_bytes, stage_offsets + gap_waves, 8));
+                    FIT_CHECK(mail_sync(ctx));
+                    size_t device_free = 0, device_total = 0;
+                    if (stage_bytes > ctx->scratch_bytes[SCRATCH_FIT_GAP_STAGE] && hipMemGetInfo(&device_free, &device_total) != hipSuccess) {
+                        (void)hipGetLastError();
+                        device_free = 0;
+                    }
+                    // (what is reserved already counts as free for this: the slot grows, it is not added to)
+                    if (stage_bytes <= ctx->scratch_bytes[SCRATCH_FIT_GAP_STAGE] || stage_bytes <= device_free / 4) {
+                        FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_GAP_STAGE, stage_bytes, &p));
+                        gap_stage.bytes = static_cast<uint8_t *>(p);
+                        gap_stage.offsets = stage_offsets;
+                    }
                 }
             }
             if (gap_waves > 0) {

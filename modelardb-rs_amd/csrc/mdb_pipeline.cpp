@@ -174,6 +174,7 @@ void host_parallel(unsigned n_shares, void (*share)(unsigned, void *), void *arg
 // A copy that leaves the caches alone (the staging block is read next by the copy engine, not by a core; and the lines
 // of a plain store would be read from memory first): 16-byte streaming stores, what every x86-64 has.
 void host_copy_streaming(void *to_bytes, const void *from_bytes, size_t n_bytes) {
+#if defined(__SSE2__)
     unsigned char *to = static_cast<unsigned char *>(to_bytes);
     const unsigned char *from = static_cast<const unsigned char *>(from_bytes);
     size_t head = (16 - (reinterpret_cast<uintptr_t>(to) & 15)) & 15;
@@ -192,6 +193,9 @@ void host_copy_streaming(void *to_bytes, const void *from_bytes, size_t n_bytes)
     }
     std::memcpy(to + i, from + i, n_bytes - i);
     _mm_sfence();
+#else // (a host without SSE2: the plain copy - the streaming stores are a speed-up, not a requirement)
+    std::memcpy(to_bytes, from_bytes, n_bytes);
+#endif
 }
 
 int host_block_take(uint64_t bytes, void **out, uint64_t *capacity) {
