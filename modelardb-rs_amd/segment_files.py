@@ -12,8 +12,15 @@ one copy, so the GPU sees millions of segments per launch instead of 8 192.
 
 Only the Parquet layer is implemented (pyarrow does the ZSTD/PLAIN decoding); the Delta log is out
 of scope.
+
+Decoding is the host's work and the slowest leg by far (26 of 31 ms for 857 000 segments, profiles/r05/
+segment_files_e2e.txt), so the streaming form overlaps it with everything behind it: row groups - the
+unit the reference's scan hands on (65 536 rows, lib.rs:248-261) - are decoded by a pool of threads
+(pyarrow releases the GIL) and yielded IN FILE ORDER, so that the upload and the grid() of group k run
+while groups k + 1 .. are being decoded (``iter_segment_batches``, ``load_segments_pipelined``).
 """
 
+import concurrent.futures
 import os
 
 import numpy as np
@@ -63,8 +70,18 @@ def read_segment_files(paths, columns=None):
     """Read whole segment files into ONE Arrow table with BinaryView / Utf8View columns."""
     if isinstance(paths, (str, os.PathLike)):
         paths = [paths]
-    tables = [pq.read_table(p, columns=columns) for p in paths]
-    table = pa.concat_tables(tables).combine_chunks()
+    # (Arrow's dataset reader: files, row groups and columns decoded at once, by as many threads as the process may
+    # use - its default is every core of the machine, which a container with a CPU quota pays for in throttling)
+    import pyarrow.dataset as ds
+    workers = min(usable_cpus(), 16)
+    if pa.cpu_count() != workers:
+        pa.set_cpu_count(workers)
+    return _with_view_columns(ds.dataset([os.fspath(p) for p in paths], format="parquet").to_table(columns=columns))
+
+
+def _with_view_columns(table):
+    """One RecordBatch with BinaryView / Utf8View columns from a decoded table (the bytes are identical)."""
+    table = table.combine_chunks()
     arrays = []
     for column in table.columns:
         array = column.chunk(0) if column.num_chunks else pa.array([], type=column.type)
@@ -74,6 +91,95 @@ def read_segment_files(paths, columns=None):
             array = array.cast(pa.string_view())
         arrays.append(array)
     return pa.RecordBatch.from_arrays(arrays, names=table.schema.names)
+
+
+def usable_cpus():
+    """CPUs this process may use at once: its affinity mask, cut down to the cgroup's quota (cpu.max) - a container
+    sees every core of the machine and may run on a few of them."""
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cpus = min(cpus, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(cpus, 1)
+
+
+def iter_segment_batches(paths, columns=None, workers=None, ahead=None, then=None, files_ahead=None):
+    """The files' row groups as RecordBatches with view columns, in file order (the order GridExec needs: the files
+    are sorted by (tags..., start_time)), decoded ahead of the consumer: what the consumer does with group k - upload,
+    grid() - overlaps the decoding of the groups behind it. The decoding is Arrow's dataset scanner (C++ threads over
+    files, row groups and columns at once - a pool of Python threads calling the reader got 2.3x out of 8 cores);
+    `workers` of them, by default as many as the process may use (Arrow's own default is every core of the MACHINE,
+    which a container with a CPU quota pays for in throttling). The cast to view types and `then(batch)`, if given, run
+    in up to four more threads, and the results come out in order."""
+    import pyarrow.dataset as ds
+    import queue
+    import threading
+    if isinstance(paths, (str, os.PathLike)):
+        paths = [paths]
+    paths = [os.fspath(p) for p in paths]
+    workers = workers or min(usable_cpus(), 16)
+    ahead = ahead or 2 * workers
+    if pa.cpu_count() != workers:
+        pa.set_cpu_count(workers)
+    scanner = ds.dataset(paths, format="parquet").scanner(columns=columns, batch_size=65536, use_threads=True,
+                                                          fragment_readahead=files_ahead or 2, batch_readahead=ahead)
+
+    def finish(batch):
+        batch = _with_view_columns(pa.Table.from_batches([batch]))
+        return then(batch) if then else batch
+
+    handed_on = queue.Queue(maxsize=ahead)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(workers, 4)) as pool:
+        def produce():
+            try:
+                for batch in scanner.to_batches():
+                    if batch.num_rows:
+                        handed_on.put(pool.submit(finish, batch))
+                handed_on.put(None)
+            except BaseException as error:  # noqa: BLE001 - handed to the consumer, which raises it
+                handed_on.put(error)
+
+        producer = threading.Thread(target=produce, daemon=True)
+        producer.start()
+        try:
+            while True:
+                item = handed_on.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item.result()
+        finally:
+            # (a consumer that stops early: let the producer run out, its results are dropped)
+            while producer.is_alive():
+                try:
+                    handed_on.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            producer.join()
+
+
+def load_segments_pipelined(context, paths, workers=None):
+    """Files -> (DeviceSegments, tag columns) per row group, in order. A group is uploaded by the thread that decoded
+    it, through a context of its own (mdb_clone: its own stream; one upload at a time), so the caller's launches on
+    group k overlap both the decoding and the upload of the groups behind it. The caller frees each batch when it is
+    through with it (hipFree waits for the device: best left until the last launch has been issued)."""
+    import threading
+    uploader, one_at_a_time = context.clone(), threading.Lock()
+
+    def upload(batch):
+        tag_names = [n for n in batch.schema.names if n not in SEGMENT_COLUMN_NAMES]
+        host_segments = SegmentBatch.from_arrow(batch)
+        with one_at_a_time:
+            return uploader.upload_segments(host_segments), batch.select(tag_names)
+
+    try:
+        yield from iter_segment_batches(paths, workers=workers, then=upload)
+    finally:
+        uploader.close()
 
 
 def load_segments(context, paths):

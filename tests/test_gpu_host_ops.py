@@ -417,6 +417,22 @@ def test_segment_files_to_device_and_grid(hip, tmp_path):
     assert np.array_equal(hip.download_array(out_ts, total, np.int64), expected[0])
     assert np.array_equal(hip.download_array(out_val, total, np.float32).view(np.uint32),
                           expected[1].view(np.uint32))
+    # ... and row group after row group (decoded by threads while the one before is uploaded and reconstructed):
+    # the same points, each group's behind the last one's
+    done = 0
+    for group, group_tags in segment_files.load_segments_pipelined(hip, paths, workers=2):
+        n = hip.grid_count_dev(group)
+        group_ts, group_val = hip.dev_alloc(8 * n), hip.dev_alloc(4 * n)
+        hip.grid_batch_dev(group, group_ts, group_val, n)
+        assert group_tags.column("tag").to_pylist() == ["T"] * len(group)
+        assert np.array_equal(hip.download_array(group_ts, n, np.int64), expected[0][done:done + n])
+        assert np.array_equal(hip.download_array(group_val, n, np.float32).view(np.uint32),
+                              expected[1][done:done + n].view(np.uint32))
+        done += n
+        hip.dev_free(group_ts)
+        hip.dev_free(group_val)
+        group.free()
+    assert done == total
     hip.dev_free(out_ts)
     hip.dev_free(out_val)
     device_segments.free()

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as pq
+import pytest
 
 import cases
 import oracle_lib as ora
@@ -64,3 +65,24 @@ def test_file_round_trip_preserves_every_segment(tmp_path):
     # and the oracle reconstructs the same points from the loaded segments
     a, b = ora.grid_batch(back), ora.grid_batch(original)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_row_groups_streamed_in_order_are_the_files_rows(tmp_path, workers, monkeypatch):
+    """iter_segment_batches: the row groups decoded by a pool of threads, handed on in file order - the same rows as
+    the whole-file read, group after group (small groups here: four per file)."""
+    import pyarrow.parquet as pq
+    segments = _segments_with_tags()
+    half = segments.num_rows // 2
+    real_write = pq.write_table
+    monkeypatch.setattr(pq, "write_table", lambda table, path, **kw: real_write(table, path, **{**kw, "row_group_size": max(half // 4, 1)}))
+    paths = [segment_files.write_segment_file(str(tmp_path / f"part-{k}.parquet"), part)
+             for k, part in enumerate((segments.slice(0, half), segments.slice(half)))]
+    whole = mdb.SegmentBatch.from_arrow(segment_files.read_segment_files(paths))
+    groups = list(segment_files.iter_segment_batches(paths, workers=workers, ahead=2))
+    assert len(groups) >= 8 and all(str(g.schema.field("values").type) == "binary_view" for g in groups)
+    streamed = mdb.SegmentBatch.concat([mdb.SegmentBatch.from_arrow(g) for g in groups])
+    assert len(streamed) == len(whole)
+    for got, expected in zip(streamed.rows(), whole.rows()):
+        assert got[:4] == expected[:4] and got[6:8] == expected[6:8]
+    assert sum((g.column("tag").to_pylist() for g in groups), []) == segments.column("tag").to_pylist()
