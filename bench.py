@@ -1333,6 +1333,8 @@ def compact_line(line, detail_name="bench_detail.json"):
     if isinstance(roofline, dict):
         out["roofline"] = {key: roofline[key] for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                           "kernel_ms", "algorithmic_bytes_per_launch") if key in roofline}
+        if isinstance(roofline.get("valu_issue"), dict):  # (the fit's own bound: vector issue, not HBM)
+            out["roofline"]["valu_issue_frac"] = roofline["valu_issue"].get("frac")
     else:
         out["roofline"] = roofline
     cpu = line.get("cpu_baseline")
@@ -1347,6 +1349,7 @@ def compact_line(line, detail_name="bench_detail.json"):
         "fit_kernel": _dig(line, "fit", "roofline", "kernel"),
         "fit_kernel_ms": _dig(line, "fit", "roofline", "kernel_ms"),
         "fit_frac_of_hbm": _dig(line, "fit", "roofline", "frac"),
+        "fit_frac_of_valu_issue": _dig(line, "fit", "roofline", "valu_issue", "frac"),
         "fit_cpu_points_per_s": _dig(line, "fit", "cpu_baseline", "value"),
         "aggregates_frac_of_hbm": _dig(line, "aggregates", "roofline", "frac"),
         "range_aggregates_frac_of_hbm": _dig(line, "aggregates", "range", "roofline", "frac"),
