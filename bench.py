@@ -267,6 +267,38 @@ def fit_on_gpu(context, mdb, np, args, rank, keep_series):
     return parts, fit_seconds, fit_points, kernel_ms, kept
 
 
+def link_rates(local_rank=0, nbytes=1 << 30, repetitions=3):
+    """What the box's PCIe link gives a plain copy between page-locked host memory and HBM, each way (GB/s, best of a few
+    1-GiB copies on torch's stream): the yardstick for the host path's rates - the link's paper peak (PCIe 5.0 x16: 63
+    GB/s) is not what a copy engine reaches."""
+    import torch
+    device = torch.device("cuda", local_rank)
+    host_block = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    device_block = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    rates = {}
+    for name, copy in (("h2d_GB_per_s", lambda: device_block.copy_(host_block, non_blocking=True)),
+                       ("d2h_GB_per_s", lambda: host_block.copy_(device_block, non_blocking=True))):
+        copy()
+        torch.cuda.synchronize(device)
+        best = float("inf")
+        for _ in range(repetitions):
+            started = time.perf_counter()
+            copy()
+            torch.cuda.synchronize(device)
+            best = min(best, time.perf_counter() - started)
+        rates[name] = nbytes / best / 1e9
+    del host_block, device_block
+    torch.cuda.empty_cache()
+    return rates
+
+
+def segment_bytes_up(batch):
+    """What mdb_grid_submit sends to the device for these host segments: 57 B of fixed columns and three 16-byte views a
+    row is not counted finer than that - 73 B a segment - plus the out-of-line payloads."""
+    payload = sum(int(buffer.size) for column in (batch.timestamps, batch.values, batch.residuals) for buffer in column.buffers)
+    return 73 * len(batch) + payload
+
+
 def host_path(context, mdb, np, sample, args):
     """The drop-in path end to end: the C++ GridExec / GridStream of libmdb_host over HOST segment
     batches (what DataFusion would hand it), PCIe included: upload of the segments, kernels, copy of
@@ -284,12 +316,23 @@ def host_path(context, mdb, np, sample, args):
                    "and the copy of 12 B per data point into page-locked host memory included"}
     # The first pass over the sample is the cold one: the context's pool of page-locked blocks grows to the sizes
     # the batches need (a hipHostMalloc of 70 MB takes 13 ms). A server's pool is warm; both are reported.
+    try:
+        out["link"] = link_rates(context.device)
+    except Exception as error:  # noqa: BLE001 - a yardstick, not a measurement of the path
+        out["link"] = {"error": str(error)}
+    d2h_rate = out["link"].get("d2h_GB_per_s")
     points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192)
     out["first_pass_cold_pool"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9}
+    try:
+        bytes_up = segment_bytes_up(sample)
+    except Exception:  # noqa: BLE001
+        bytes_up = None
     for batch_size in (8192, 65536):
         points, seconds, bytes_down = host.measure_grid_stream(context, sample, batch_size)
         out[f"batch_{batch_size}"] = {"values_per_s": points / seconds, "GB_per_s_pcie": bytes_down / seconds / 1e9,
-                                      "points": points, "segments": len(sample), "seconds": seconds}
+                                      "points": points, "segments": len(sample), "seconds": seconds,
+                                      "fraction_of_a_plain_d2h_copy": bytes_down / seconds / 1e9 / d2h_rate if d2h_rate else None,
+                                      "GB_per_s_up": bytes_up / seconds / 1e9 if bytes_up else None}
     # With a tag column (grid_exec.rs:341-346): a 16-byte view per data point, written by host threads.
     host.measure_grid_stream(context, sample, 8192, tags={"tag": "wind-turbine-0042"})
     points, seconds, bytes_down = host.measure_grid_stream(context, sample, 8192, tags={"tag": "wind-turbine-0042"})
@@ -629,6 +672,10 @@ def mixed_models(context, mdb, np, ora, args):
             host_points, host_seconds, host_bytes = host.measure_grid_stream(context, downloaded, 8192)
             shape["host_path"] = {"values_per_s": host_points / host_seconds, "GB_per_s_pcie": host_bytes / host_seconds / 1e9,
                                   "seconds": host_seconds, "segments": len(downloaded)}
+            try:  # (the link carries the segments one way while the points come back the other)
+                shape["host_path"]["GB_per_s_up"] = segment_bytes_up(downloaded) / host_seconds / 1e9
+            except Exception:  # noqa: BLE001
+                pass
             # SUM through the patched accumulator (rust/patches/0002): 8 192-row batches gathered into mdb_agg_batch_list.
             host.measure_accumulator(context, downloaded, host.ModelSumAccumulator)
             state, sum_seconds = host.measure_accumulator(context, downloaded, host.ModelSumAccumulator)
@@ -1366,6 +1413,7 @@ def compact_line(line, detail_name="bench_detail.json"):
         "mixed_fit_ms_1pct": _dig(line, "mixed_models", "relative_1_percent", "fit", "ms"),
         "host_path_values_per_s": _dig(line, "host_path", "batch_8192", "values_per_s"),
         "host_path_GB_per_s_pcie": _dig(line, "host_path", "batch_8192", "GB_per_s_pcie"),
+        "host_path_fraction_of_plain_d2h": _dig(line, "host_path", "batch_8192", "fraction_of_a_plain_d2h_copy"),
         "segments_per_s": line.get("segments_per_s"),
         "aggregates_count": _dig(line, "aggregates", "result", "count"),
     }
