@@ -45,6 +45,17 @@ struct HostStreamBits { // MSB-first bits of a byte string; zeros behind its end
         }
         return shift ? (window << shift) | ((uint64_t)next >> (8u - shift)) : window;
     }
+    // The next 57 bits at least, on top of the word (the bits below them are not the stream's): ONE unaligned load
+    // where eight bytes are left, which is enough for a whole MacaqueV code (13 bits of header, 32 of payload).
+    uint64_t peek57() const {
+        const uint64_t byte = used >> 3;
+        if (byte + 8 <= n_bytes) {
+            uint64_t window;
+            std::memcpy(&window, bytes + byte, 8);
+            return __builtin_bswap64(window) << (used & 7u);
+        }
+        return peek64();
+    }
 };
 
 struct HostViewBytes {
@@ -186,8 +197,8 @@ void host_index_share(unsigned, void *arg) {
                     cursor.pad = remaining <= MV_PIECE_VALUES ? MV_CURSOR_LAST_OF_STREAM : 0u; // (checked by k_grid_mv_pieces)
                     *out++ = cursor;
                 }
-                // one code (ring_decode_value)
-                const uint64_t window = bits.peek64();
+                // one code (ring_decode_value): header and payload out of one look at the stream (45 bits at most)
+                const uint64_t window = bits.peek57();
                 const uint32_t top = (uint32_t)(window >> 51);
                 const bool c0 = (top >> 12) != 0u, c1 = ((top >> 11) & 1u) != 0u;
                 const bool opens = !raw && c0 && c1, repeats = !raw && c0 && !c1;
@@ -199,9 +210,8 @@ void host_index_share(unsigned, void *arg) {
                 uint32_t meaningful = 32u - leading - trailing;
                 if (!raw && !repeats && (meaningful > 32u || trailing > 31u)) { job.malformed = 1; return; }
                 meaningful = raw ? 32u : (repeats ? 0u : meaningful);
-                bits.used += header_bits;
-                const uint32_t payload = meaningful ? (uint32_t)(bits.peek64() >> (64u - meaningful)) : 0u;
-                bits.used += meaningful;
+                const uint32_t payload = meaningful ? (uint32_t)((window << header_bits) >> (64u - meaningful)) : 0u;
+                bits.used += header_bits + meaningful;
                 last = raw ? payload : (last ^ (payload << (trailing & 31u)));
                 raw = false;
                 position += 1;
