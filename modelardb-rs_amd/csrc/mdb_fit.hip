@@ -2399,11 +2399,15 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     if (!(fabs(expected - v2) > margin)) { // (also when the margin is not a number)
                         slope = rise / (t1 - t0); // line_through_exact (swing.rs:323-340)
                         intercept = v0 - slope * t0;
-                        bool on_the_line = slope * t2 + intercept == v2;
+                        // (the reference's own two comparisons, swing.rs:161-166 with a deviation of 0: a point is
+                        // rejected when the line's value is below or above it - which a line that is not a number, two
+                        // points with ONE timestamp, never is)
+                        auto off_the_line = [](double approximation, double value) { return approximation < value || approximation > value; };
+                        bool on_the_line = !off_the_line(slope * t2 + intercept, v2);
 #pragma unroll
                         for (int j = 3; j < 8; j++) {
                             const double t = HAS_TS ? time_at(start + j) : __builtin_fma((double)(start + j), interval, first_time);
-                            on_the_line = on_the_line && slope * t + intercept == (double)window[j];
+                            on_the_line = on_the_line && !off_the_line(slope * t + intercept, (double)window[j]);
                         }
                         stands = on_the_line;
                     }
@@ -2446,8 +2450,12 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
                     const bool valid = index < n;
                     const float v = valid ? values[index] : 0.0f;
                     bool differs; // (a NaN or an infinity differs from everything finite, as in both fitters)
-                    if (pmc_model) differs = v != first_value32;
-                    else differs = model_slope * time_at(valid ? index : position) + model_intercept != (double)v;
+                    if (pmc_model) {
+                        differs = v != first_value32;
+                    } else { // (swing.rs:152-166: not finite, or the line's value below or above it)
+                        const double approximation = model_slope * time_at(valid ? index : position) + model_intercept;
+                        differs = !isfinite(v) || approximation < (double)v || approximation > (double)v;
+                    }
                     const unsigned long long stops = __ballot(valid && differs);
                     const uint32_t n_valid = min((uint32_t)MDB_WAVE, n - position);
                     length += stops ? (uint32_t)__builtin_ctzll(stops) : n_valid;

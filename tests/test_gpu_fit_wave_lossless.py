@@ -144,3 +144,16 @@ def test_many_chunks_of_the_acceptance_recipe(hip, mode):
     offsets = (np.arange(n_chunks + 1) * length).astype(np.uint64)
     expected = fit_and_compare(hip, timestamps, values, offsets)
     assert set(expected.model_type_id.tolist()) == {0, 1, 2}
+
+
+@pytest.mark.parametrize("kinds", ["lines", "zeros-and-constants"])
+def test_one_timestamp_for_every_point(hip, kinds):
+    """Chunks whose points all carry the same timestamp (equally spaced, by an interval of 0): the line through two such
+    points is not a number, and the reference's comparisons reject nothing against it (swing.rs:161-166) - whatever
+    that makes of the chunk, the same here."""
+    rng = np.random.default_rng(3)
+    lengths = [300, 40, 9, 8]
+    values = np.concatenate([runs(rng, n, KINDS[kinds]) for n in lengths])
+    timestamps = np.concatenate([np.full(n, 1_000_000 * (k + 1), dtype=np.int64) for k, n in enumerate(lengths)])
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    fit_and_compare(hip, timestamps, values, offsets)
