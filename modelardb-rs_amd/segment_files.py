@@ -174,7 +174,11 @@ def load_segments_pipelined(context, paths, workers=None):
         tag_names = [n for n in batch.schema.names if n not in SEGMENT_COLUMN_NAMES]
         host_segments = SegmentBatch.from_arrow(batch)
         with one_at_a_time:
-            return uploader.upload_segments(host_segments), batch.select(tag_names)
+            uploaded = uploader.upload_segments(host_segments)
+        # (the batch is the CALLER's from here on: its context outlives the uploader's, which is closed below)
+        handed_over = type(uploaded)(context, uploaded.pointer)
+        uploaded.pointer = None
+        return handed_over, batch.select(tag_names)
 
     try:
         yield from iter_segment_batches(paths, workers=workers, then=upload)

@@ -425,6 +425,7 @@ def test_segment_files_to_device_and_grid(hip, tmp_path):
         group_ts, group_val = hip.dev_alloc(8 * n), hip.dev_alloc(4 * n)
         hip.grid_batch_dev(group, group_ts, group_val, n)
         assert group_tags.column("tag").to_pylist() == ["T"] * len(group)
+        assert len(group.download()) == len(group)  # (the batch is the caller's context's: the uploader's is closed by then or soon)
         assert np.array_equal(hip.download_array(group_ts, n, np.int64), expected[0][done:done + n])
         assert np.array_equal(hip.download_array(group_val, n, np.float32).view(np.uint32),
                               expected[1][done:done + n].view(np.uint32))
