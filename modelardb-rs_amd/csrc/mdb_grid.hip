@@ -1648,12 +1648,19 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
 // (models/mod.rs:145-181: the model's last DECODED value, NaN behind a MacaqueV model), and k_agg_mv_chains adds
 // every stream up with one lane. stream_sums[2 i] = the sum of MacaqueV segment i's values (macaque_v.rs:228-235:
 // it starts AS the first value), [2 i + 1] = the sum of segment i's residual tail.
+struct ChainItem { // 16 bytes; one per wave of k_agg_mv_pieces: the stream that begins in it and goes on behind it
+    uint32_t segment_and_kind; // segment << 1 | 1 for its residual tail; CHAIN_NONE: no such stream in this wave
+    uint32_t pad;
+    unsigned long long first_piece;
+};
+constexpr uint32_t CHAIN_NONE = 0xffffffffu;
+
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const MvCursor *__restrict__ cursors,
                                                             unsigned long long n_pieces, uint32_t *__restrict__ values,
-                                                            float *__restrict__ stream_sums, unsigned char *__restrict__ stream_done) {
+                                                            float *__restrict__ stream_sums, ChainItem *__restrict__ chain_items) {
     // All 64 values of every piece staged in LDS (a row per lane): a stream whose pieces all lie in this wave - most
     // of a batch's streams are a few pieces long - is added up right here, by the lane of its first piece, in stream
-    // order (stream_done[2 i + tail] = 1, the sum in stream_sums); only the pieces of streams that reach beyond the
+    // order (the sum in stream_sums); only the pieces of streams that reach beyond the
     // wave go to `values` for k_agg_mv_chains. (A round trip of 4 bytes per value through memory otherwise: 2.5 GB
     // written and read again for the mixed series.)
     constexpr int STRIDE = MV_PIECE_VALUES + 1; // (an odd stride keeps the banks apart)
@@ -1760,7 +1767,17 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
             for (; k < n; k++) sum += __uint_as_float(from[k]);
         }
         stream_sums[2ull * segment + (residual ? 1u : 0u)] = sum;
-        stream_done[2ull * segment + (residual ? 1u : 0u)] = 1;
+    }
+    // The stream that begins in this wave and goes on behind it (the wave's last stream, if any does: every other one
+    // that begins here ends here) is k_agg_mv_chain_groups': listed in the wave's own place, no counter to queue at.
+    {
+        const bool goes_on = piece < n_pieces && is_head && my_tail < 0;
+        const unsigned long long going_on = __ballot(goes_on);
+        if (going_on == 0) {
+            if (lane == 0) chain_items[blockIdx.x] = {CHAIN_NONE, 0u, 0ull};
+        } else if (goes_on) {
+            chain_items[blockIdx.x] = {(segment << 1) | (residual ? 1u : 0u), 0u, piece};
+        }
     }
     // The other pieces' values: to `values`, a row of 64 values (two 128-byte lines) per lane pair of store instructions.
     const unsigned long long spilled = __ballot(piece < n_pieces && !here);
@@ -1776,125 +1793,125 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
     }
 }
 
-template <int LOADS> // 16-byte loads a lane has in flight per round of a long stream: 8, 16 or 32
-__global__ __launch_bounds__(256) void k_agg_mv_chains(DevSegments s, const uint32_t *__restrict__ known_totals,
-                                                       const unsigned long long *__restrict__ piece_base,
-                                                       const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
-                                                       const unsigned char *__restrict__ stream_done,
-                                                       uint32_t long_min, uint32_t *__restrict__ long_items,
-                                                       unsigned int *__restrict__ n_long) {
+// A stream whose pieces reach beyond one wave of k_agg_mv_pieces: its values lie in `values` (piece p at 64 p), and its
+// f32 additions are one chain, in stream order (macaque_v.rs:228-235). A chain is 4 cycles an addition; what it waited
+// for was memory - a lane of its own kept 128 bytes of its stream in flight, a round trip per 32 additions (round 6's
+// counters: 65 % of the kernel's wave-cycles waiting, the vector ALU busy 5 %; a 65 536-value stream 0.7 ms) - and, in
+// front of that, a thread per SEGMENT that looked for the streams not summed yet (0.75 ms for 8.5 M segments). Now the
+// wave of k_agg_mv_pieces in which such a stream begins says so in its own place of a list (one stream per wave at
+// most), and k_agg_mv_chain_groups gives every listed stream EIGHT lanes: together they keep 2 KB of it in flight - a
+// round of 512 values, 16 chunks of 16 bytes per lane, the eight lanes' chunks side by side in memory - park a round in
+// LDS, ask for the next one, and the first of the eight adds the parked round up, value after value.
+constexpr int CHAIN_GROUP_LANES = 8;
+constexpr int CHAIN_GROUPS_PER_WAVE = MDB_WAVE / CHAIN_GROUP_LANES;
+constexpr int CHAIN_LOADS = 16;                                    // 16-byte loads a lane has in flight
+constexpr int CHAIN_ROUND_CHUNKS = CHAIN_LOADS * CHAIN_GROUP_LANES; // 128 chunks = 512 values = 2 KB a round
+constexpr int CHAIN_GROUP_STRIDE = CHAIN_ROUND_CHUNKS + 1;          // (in chunks: the eight adding lanes read eight banks)
+
+// Cursors left by host threads (the index of one call): should they ever disagree with the kernels' own analysis about
+// a segment's streams, its sums are made unusable rather than a little wrong. (A resident batch's cursors come from
+// that same analysis, k_mv_index_walk: nothing to compare.)
+__global__ __launch_bounds__(256) void k_agg_mv_check_cursors(DevSegments s, const uint32_t *__restrict__ known_totals,
+                                                              const unsigned long long *__restrict__ piece_base,
+                                                              float *__restrict__ stream_sums) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     const unsigned long long first_piece = piece_base[i];
     if (piece_base[i + 1] == first_piece) return; // (no stream: nobody reads this segment's sums)
-    // (streams that lay inside one wave of k_agg_mv_pieces have their sums already)
-    const bool values_done = stream_done[2 * i] != 0, tail_done = stream_done[2 * i + 1] != 0;
     uint32_t n_values, n_res, n_model, error;
     mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
-    // (cursors left by host threads: should they ever disagree with this analysis about the segment's streams, the
-    // sum is made unusable rather than a little wrong)
     if ((unsigned long long)((n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES + (n_res + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES) !=
-        piece_base[i + 1] - first_piece) {
+        piece_base[i + 1] - first_piece)
         stream_sums[2 * i] = stream_sums[2 * i + 1] = __uint_as_float(0x7fc00000u);
-        return;
-    }
-    // 32 values per round: eight independent 16-byte loads (a lane that waited for one load per four additions
-    // spent its time waiting - 3.4 ms for a 50 000-value chain), then the additions, in stream order.
-    auto chain = [&](unsigned long long at_piece, uint32_t n, bool starts_as_first) {
-        const uint4 *from = reinterpret_cast<const uint4 *>(values + at_piece * MV_PIECE_VALUES);
-        float sum = 0.0f;
-        uint32_t k = 0;
-        if (starts_as_first && n > 0) { // macaque_v.rs:228-235: the sum starts AS the first value
-            sum = __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES));
-            k = 1;
-        }
-        // (up to the next multiple of 32, one value at a time)
-        for (; k < n && (k & 31u) != 0; k++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + k));
-        // (a lane's trip to memory is what a round costs, not its additions: LOADS loads in flight while the stream is
-        // long. Tried: the next round's loads under way during the additions, 2.6 -> 3.0 ms on the mixed series; the
-        // wave fetching whole lines together through LDS, 2.6 -> 5.1 ms)
-        if (LOADS > 8) {
-            for (; k + 4 * LOADS <= n; k += 4 * LOADS) {
-                uint4 v[LOADS];
-#pragma unroll
-                for (int q = 0; q < LOADS; q++) v[q] = load_global(from + (k >> 2) + q);
-#pragma unroll
-                for (int q = 0; q < LOADS; q++) {
-                    sum += __uint_as_float(v[q].x);
-                    sum += __uint_as_float(v[q].y);
-                    sum += __uint_as_float(v[q].z);
-                    sum += __uint_as_float(v[q].w);
-                }
-            }
-        }
-        for (; k + 32 <= n; k += 32) {
-            uint4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = load_global(from + (k >> 2) + q);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                sum += __uint_as_float(v[q].x);
-                sum += __uint_as_float(v[q].y);
-                sum += __uint_as_float(v[q].z);
-                sum += __uint_as_float(v[q].w);
-            }
-        }
-        for (; k < n; k++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + k));
-        return sum;
-    };
-    const unsigned long long value_pieces = (n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES;
-    // (a stream of long_min values or more: listed for k_agg_mv_chains_long, where nobody waits for it)
-    if (!values_done && long_items && n_values >= long_min) long_items[atomicAdd(n_long, 1u)] = (uint32_t)(i << 1);
-    else if (!values_done) stream_sums[2 * i] = n_values ? chain(first_piece, n_values, true) : 0.0f;
-    if (!tail_done) stream_sums[2 * i + 1] = n_res ? chain(first_piece + value_pieces, n_res, false) : 0.0f;
 }
 
-// The long streams k_agg_mv_chains has listed (item: segment << 1 | 1 for its residual tail - which is never long -, 0 for
-// its MacaqueV values), a lane each, 32 loads of 16 bytes in flight per round: beside lanes with a few hundred values
-// a 65 536-value chain kept its wave for a millisecond, eight loads and a trip to memory per 32 additions.
-// (LOADS: 32 where a handful of streams has the GPU to itself, 8 where every lane of every wave has one - 100 000 streams
-// of 50 000 values: 4.2 / 5.7 ms with 8 / 32 -: both are launched, the number of listed streams says which one runs)
-constexpr unsigned int CHAIN_FEW_LONG = 65536;
-template <int LOADS>
-__global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chains_long(DevSegments s, const uint32_t *__restrict__ known_totals,
-                                                                 const unsigned long long *__restrict__ piece_base,
-                                                                 const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
-                                                                 const uint32_t *__restrict__ items, const unsigned int *__restrict__ n_items,
-                                                                 unsigned int few_long) {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned int listed = *n_items;
-    if (k >= listed || (listed <= few_long) != (LOADS == 32)) return;
-    const uint32_t item = items[k];
-    const uint64_t i = item >> 1;
-    uint32_t n_values, n_res, n_model, error;
-    mv_stream_lengths(s, i, known_totals, &n_values, &n_res, &n_model, &error);
-    const bool tail = (item & 1u) != 0;
-    const unsigned long long at_piece = piece_base[i] + (tail ? (n_values + MV_PIECE_VALUES - 1) / MV_PIECE_VALUES : 0u);
-    const uint32_t n = tail ? n_res : n_values;
-    const uint4 *from = reinterpret_cast<const uint4 *>(values + at_piece * MV_PIECE_VALUES);
-    // (k_agg_mv_chains' additions, in stream order: macaque_v.rs:228-235 - the sum of a MacaqueV segment starts AS its
-    // first value, a tail's at zero)
-    float sum = 0.0f;
-    uint32_t done = 0;
-    if (!tail && n > 0) {
-        sum = __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES));
-        done = 1;
+__global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chain_groups(DevSegments s, const uint32_t *__restrict__ known_totals,
+                                                                  const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
+                                                                  const ChainItem *__restrict__ items, unsigned int n_items) {
+    __shared__ uint4 parked[CHAIN_GROUPS_PER_WAVE * CHAIN_GROUP_STRIDE];
+    const int lane = threadIdx.x, group = lane / CHAIN_GROUP_LANES, member = lane % CHAIN_GROUP_LANES;
+    const unsigned int mine = blockIdx.x * CHAIN_GROUPS_PER_WAVE + (unsigned int)group;
+    ChainItem item{CHAIN_NONE, 0u, 0ull};
+    if (mine < n_items) item = items[mine];
+    const bool listed = item.segment_and_kind != CHAIN_NONE;
+    if (!__any(listed)) return;
+    // How many values the stream has: the analysis of its segment, by the group's first lane.
+    uint32_t n = 0;
+    const bool tail = (item.segment_and_kind & 1u) != 0u;
+    if (listed && member == 0) {
+        uint32_t n_values, n_res, n_model, error;
+        mv_stream_lengths(s, item.segment_and_kind >> 1, known_totals, &n_values, &n_res, &n_model, &error);
+        n = tail ? n_res : n_values;
     }
-    for (; done < n && (done & 31u) != 0; done++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + done));
-    for (; done + 4 * LOADS <= n; done += 4 * LOADS) {
-        uint4 v[LOADS];
+    n = (uint32_t)__shfl((int)n, group * CHAIN_GROUP_LANES, MDB_WAVE);
+    const uint32_t n_chunks = (n + 3u) >> 2;
+    const uint4 *__restrict__ from = reinterpret_cast<const uint4 *>(values + item.first_piece * MV_PIECE_VALUES);
+    uint4 *mine_parked = parked + group * CHAIN_GROUP_STRIDE;
+    auto ask = [&](uint32_t round, uint4 (&into)[CHAIN_LOADS]) { // chunk j * 8 + member of the round: the group's lanes side by side
 #pragma unroll
-        for (int q = 0; q < LOADS; q++) v[q] = load_global(from + (done >> 2) + q);
-#pragma unroll
-        for (int q = 0; q < LOADS; q++) {
-            sum += __uint_as_float(v[q].x);
-            sum += __uint_as_float(v[q].y);
-            sum += __uint_as_float(v[q].z);
-            sum += __uint_as_float(v[q].w);
+        for (int j = 0; j < CHAIN_LOADS; j++) {
+            const uint32_t chunk = round * CHAIN_ROUND_CHUNKS + (uint32_t)(j * CHAIN_GROUP_LANES + member);
+            into[j] = chunk < n_chunks ? load_global(from + chunk) : make_uint4(0u, 0u, 0u, 0u);
         }
+    };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const uint32_t rounds = (n_chunks + CHAIN_ROUND_CHUNKS - 1) / CHAIN_ROUND_CHUNKS;
+    const uint32_t most_rounds = wave_max_u32(rounds);
+    // macaque_v.rs:228-235: the sum of a MacaqueV segment's values starts AS the first of them, a tail's at zero.
+    const bool starts_as_first = !tail;
+    float sum = 0.0f;
+    uint4 asked[CHAIN_LOADS];
+    ask(0, asked);
+    for (uint32_t round = 0; round < most_rounds; round++) {
+#pragma unroll
+        for (int j = 0; j < CHAIN_LOADS; j++) mine_parked[j * CHAIN_GROUP_LANES + member] = asked[j];
+        wave_sync();
+        if (round + 1 < most_rounds) ask(round + 1, asked); // (under way while the round that is parked is added up)
+        if (member == 0 && round < rounds) {
+            const uint32_t first_value = round * (uint32_t)(4 * CHAIN_ROUND_CHUNKS);
+            const uint32_t here = min(n - first_value, (uint32_t)(4 * CHAIN_ROUND_CHUNKS)); // values of this round
+            uint32_t k = 0;
+            if (round == 0 && starts_as_first) {
+                const uint4 q = mine_parked[0];
+                sum = __uint_as_float(q.x);
+                if (here > 1) sum += __uint_as_float(q.y);
+                if (here > 2) sum += __uint_as_float(q.z);
+                if (here > 3) sum += __uint_as_float(q.w);
+                k = 4;
+            }
+            for (; k + 32 <= here; k += 32) { // (eight reads of the parked round under way, then the chain of additions)
+                uint4 q[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) q[j] = mine_parked[(k >> 2) + (uint32_t)j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    sum += __uint_as_float(q[j].x);
+                    sum += __uint_as_float(q[j].y);
+                    sum += __uint_as_float(q[j].z);
+                    sum += __uint_as_float(q[j].w);
+                }
+            }
+            for (; k + 4 <= here; k += 4) {
+                const uint4 q = mine_parked[k >> 2];
+                sum += __uint_as_float(q.x);
+                sum += __uint_as_float(q.y);
+                sum += __uint_as_float(q.z);
+                sum += __uint_as_float(q.w);
+            }
+            if (k < here) { // (the stream's last, partial chunk)
+                const uint4 q = mine_parked[k >> 2];
+                sum += __uint_as_float(q.x);
+                if (k + 1 < here) sum += __uint_as_float(q.y);
+                if (k + 2 < here) sum += __uint_as_float(q.z);
+            }
+        }
+        wave_sync(); // (the next round overwrites what was parked)
     }
-    for (; done < n; done++) sum += __uint_as_float(load_global(values + at_piece * MV_PIECE_VALUES + done));
-    stream_sums[2 * i + (tail ? 1 : 0)] = sum;
+    if (member == 0 && listed && n > 0) stream_sums[2ull * (item.segment_and_kind >> 1) + (tail ? 1u : 0u)] = sum;
 }
 
 // ---- the order in which k_grid_ts_count takes the streams ----------------------------------------------------
@@ -3285,56 +3302,29 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
     // (the index of one call covers its long streams only: the sums of a segment without pieces are nobody's)
     if (index->of_one_call) *only_with_pieces = static_cast<const unsigned long long *>(index->piece_base);
     void *p = nullptr;
-    if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 10 + 256, &p)) return 1;
+    if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 8 + 256, &p)) return 1;
     uint32_t *values = static_cast<uint32_t *>(p);
     float *sums = reinterpret_cast<float *>(values + index->n_pieces * MV_PIECE_VALUES);
-    unsigned char *done = reinterpret_cast<unsigned char *>(sums + 2 * in->n);
-    MDB_HIP_CHECK(hipMemsetAsync(done, 0, 2 * in->n, ctx->stream));
+    // (a stream without values - the tail of a segment that has none - sums to 0: the kernels write the others)
+    MDB_HIP_CHECK(hipMemsetAsync(sums, 0, 8 * in->n, ctx->stream));
+    const uint64_t piece_waves = (index->n_pieces + MDB_WAVE - 1) / MDB_WAVE;
+    if (piece_waves > 0xfffffff0ull) return fail("Too many MacaqueV streams for one batch.");
+    void *q = nullptr;
+    if (scratch_reserve(ctx, SCRATCH_AGG_CHAIN_LIST, piece_waves * sizeof(ChainItem) + 64, &q)) return 1;
+    ChainItem *items = static_cast<ChainItem *>(q);
     {
         LaunchTimer timer(ctx, "k_agg_mv_pieces");
-        hipLaunchKernelGGL(k_agg_mv_pieces, dim3((uint32_t)((index->n_pieces + MDB_WAVE - 1) / MDB_WAVE)), dim3(MDB_WAVE), 0,
-                           ctx->stream, s, static_cast<const MvCursor *>(index->cursors), index->n_pieces, values, sums, done);
-    }
-    // Streams of CHAIN_LONG_VALUES values or more are listed by k_agg_mv_chains and added up behind it, a lane each
-    // (MDB_AGG_CHAIN_LIST=0: never; for batches of more than 512 segments: a handful of streams has the lanes to itself).
-    constexpr uint32_t CHAIN_LONG_VALUES = 4096;
-    const char *list_setting = option_text("MDB_AGG_CHAIN_LIST");
-    const bool list_long = !(list_setting && std::strcmp(list_setting, "0") == 0) && in->n > 512 && in->n <= 0x7ffffff0ull;
-    const uint64_t long_bound = list_long ? index->n_pieces * MV_PIECE_VALUES / CHAIN_LONG_VALUES + 1 : 0; // (how many there can be)
-    uint32_t *long_items = nullptr;
-    unsigned int *n_long = nullptr;
-    if (list_long) {
-        void *q = nullptr;
-        if (scratch_reserve(ctx, SCRATCH_AGG_CHAIN_LIST, long_bound * 4 + 64, &q)) return 1;
-        n_long = static_cast<unsigned int *>(q);
-        long_items = reinterpret_cast<uint32_t *>(n_long + 16);
-        MDB_HIP_CHECK(hipMemsetAsync(n_long, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_agg_mv_pieces, dim3((uint32_t)piece_waves), dim3(MDB_WAVE), 0, ctx->stream, s,
+                           static_cast<const MvCursor *>(index->cursors), index->n_pieces, values, sums, items);
     }
     {
+        // The streams that reach beyond a wave of k_agg_mv_pieces, eight lanes each (one place per wave of pieces).
         LaunchTimer timer(ctx, "k_agg_mv_chains");
-        // 16-byte loads in flight per lane: many while the batch has few streams (16 streams of 65 536 values: 0.82 / 0.51 /
-        // 0.43 ms with 8 / 16 / 32), few when every lane of every wave has one (100 000 streams of 50 000 values: 4.2 / 4.7 /
-        // 5.7 ms). MDB_AGG_CHAIN_LOADS: A/B.
-        const char *text = option_text("MDB_AGG_CHAIN_LOADS");
-        const int loads = text ? std::atoi(text) : (in->n <= 512 ? 32 : 8);
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums, done, CHAIN_LONG_VALUES,
-                               long_items, n_long);
-        };
-        if (loads == 32) launch(k_agg_mv_chains<32>);
-        else if (loads == 16) launch(k_agg_mv_chains<16>);
-        else launch(k_agg_mv_chains<8>);
-        if (list_long) {
-            const dim3 long_blocks((uint32_t)((long_bound + MDB_WAVE - 1) / MDB_WAVE));
-            // (MDB_AGG_CHAIN_FEW_LONG: up to how many listed streams the 32 loads are taken - tests reach the other kernel with 0)
-            const char *few_text = option_text("MDB_AGG_CHAIN_FEW_LONG");
-            const unsigned int few_long = few_text ? (unsigned int)std::max(0ll, std::atoll(few_text)) : CHAIN_FEW_LONG;
-            hipLaunchKernelGGL(k_agg_mv_chains_long<32>, long_blocks, dim3(MDB_WAVE), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long, few_long);
-            hipLaunchKernelGGL(k_agg_mv_chains_long<8>, long_blocks, dim3(MDB_WAVE), 0, ctx->stream, s, known_totals,
-                               static_cast<const unsigned long long *>(index->piece_base), values, sums, long_items, n_long, few_long);
-        }
+        hipLaunchKernelGGL(k_agg_mv_chain_groups, dim3((uint32_t)((piece_waves + CHAIN_GROUPS_PER_WAVE - 1) / CHAIN_GROUPS_PER_WAVE)),
+                           dim3(MDB_WAVE), 0, ctx->stream, s, known_totals, values, sums, items, (unsigned int)piece_waves);
+        if (index->of_one_call)
+            hipLaunchKernelGGL(k_agg_mv_check_cursors, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
+                               static_cast<const unsigned long long *>(index->piece_base), sums);
     }
     *stream_sums = sums;
     return 0;

@@ -547,16 +547,12 @@ def test_range_aggregates_over_long_lossless_streams_go_piece_by_piece(hip, monk
     resident.free()
 
 
-@pytest.mark.parametrize("mode", ["default", "eight-loads", "never"])
-def test_long_macaque_streams_are_added_up_by_lanes_of_their_own(hip, mode, monkeypatch):
-    # SUM over a resident batch of many segments with a few long MacaqueV streams among them (lossless noise: a chunk is
-    # one stream): k_agg_mv_chains lists the streams of 4 096 values or more, k_agg_mv_chains_long adds each of them up
-    # with a lane of its own - 32 loads in flight, or 8 where there are many (MDB_AGG_CHAIN_FEW_LONG=0 takes that kernel) -
-    # in the same order of additions as the one kernel does with MDB_AGG_CHAIN_LIST=0: the same f32 sums bit for bit.
-    if mode == "eight-loads":
-        monkeypatch.setenv("MDB_AGG_CHAIN_FEW_LONG", "0")
-    elif mode == "never":
-        monkeypatch.setenv("MDB_AGG_CHAIN_LIST", "0")
+def test_macaque_streams_that_reach_beyond_a_wave_are_added_up_in_stream_order(hip):
+    # SUM over a resident batch of many segments with long MacaqueV streams among them (lossless noise: a chunk is one
+    # stream) and short ones cut by the ends of the piece kernel's waves: k_agg_mv_chain_list lists the streams that
+    # k_agg_mv_pieces could not sum inside one wave, k_agg_mv_chain_groups adds each of them up with eight lanes loading
+    # and one adding - value after value, as macaque_v::sum does (macaque_v.rs:228-235): every segment's f32 sum is
+    # numpy's sequential f32 sum of its values bit for bit, the f64 total the oracle's, and the same on every call.
     rng = np.random.default_rng(47)
     parts, offsets = [], [0]
     for length in (70_000, 4_096, 4_095, 12_345, 5_000, 65_536):   # noise: one MacaqueV segment per chunk
@@ -580,7 +576,15 @@ def test_long_macaque_streams_are_added_up_by_lanes_of_their_own(hip, mode, monk
     hip.profile_enable(False)
     assert "k_agg_mv_chains" in kernels
     _assert_state(state, ora.agg_batch(segments, ALL))
-    monkeypatch.setenv("MDB_AGG_CHAIN_LIST", "0")
-    plain = hip.agg_batch_dev(resident, ALL)
-    assert np.float64(plain.sum).tobytes() == np.float64(state.sum).tobytes() and plain.count == state.count
+    # every MacaqueV segment's values added up one after the other in f32 (the first one IS the sum's start), the
+    # segments' sums in f64: what the reference's accumulator makes of them
+    total = 0.0
+    for row in np.nonzero(segments.model_type_id == 2)[0]:
+        first = int(np.searchsorted(timestamps, segments.start_time[row]))
+        last = int(np.searchsorted(timestamps, segments.end_time[row]))
+        total += float(np.cumsum(values[first:last + 1], dtype=np.float32)[-1])
+    others = hip.agg_batch(segments.take(np.nonzero(segments.model_type_id != 2)[0]), ALL)
+    assert abs(state.sum - (total + others.sum)) <= 1e-12 * abs(state.sum)
+    again = hip.agg_batch_dev(resident, ALL)
+    assert np.float64(again.sum).tobytes() == np.float64(state.sum).tobytes() and again.count == state.count
     resident.free()
