@@ -1648,22 +1648,91 @@ __global__ __launch_bounds__(MDB_WAVE) void k_grid_mv_pieces(DevSegments s, Time
 // (models/mod.rs:145-181: the model's last DECODED value, NaN behind a MacaqueV model), and k_agg_mv_chains adds
 // every stream up with one lane. stream_sums[2 i] = the sum of MacaqueV segment i's values (macaque_v.rs:228-235:
 // it starts AS the first value), [2 i + 1] = the sum of segment i's residual tail.
-struct ChainItem { // 16 bytes; one per wave of k_agg_mv_pieces: the stream that begins in it and goes on behind it
-    uint32_t segment_and_kind; // segment << 1 | 1 for its residual tail; CHAIN_NONE: no such stream in this wave
-    uint32_t pad;
+struct ChainItem { // 16 bytes: a stream of two pieces or more, listed by the wave of k_agg_mv_pieces it begins in
+    uint32_t segment_and_kind; // segment << 1 | 1 for its residual tail
+    uint32_t n;                // its values, if it ends in the wave it begins in (0: it goes on - its segment's analysis knows)
     unsigned long long first_piece;
 };
-constexpr uint32_t CHAIN_NONE = 0xffffffffu;
 
+// Is piece `piece` (of segment i's values or of its tail) the first / the last of its stream? (The pieces of a stream
+// follow each other in the cursor index.)
+__device__ __forceinline__ void piece_neighbours(const MvCursor *__restrict__ cursors, unsigned long long piece, unsigned long long n_pieces,
+                                                 uint32_t i, bool residual, bool *is_head, bool *is_tail) {
+    if (piece == 0) {
+        *is_head = true;
+    } else {
+        const MvCursor *before = cursors + piece - 1;
+        *is_head = load_global(&before->segment) != i || ((load_global(&before->window) & MV_WINDOW_RESIDUAL) != 0) != residual;
+    }
+    if (piece + 1 == n_pieces) {
+        *is_tail = true;
+    } else {
+        const MvCursor *behind = cursors + piece + 1;
+        *is_tail = load_global(&behind->segment) != i || ((load_global(&behind->window) & MV_WINDOW_RESIDUAL) != 0) != residual;
+    }
+}
+
+// Which lanes of a wave of pieces list a stream - the first pieces of streams of two pieces or more -, of which kind
+// (short: up to CHAIN_SHORT_VALUES values; long: more, or going on behind the wave, where only the segment's analysis
+// knows how many), with how many values, and the lane's place among the wave's listed streams of its kind.
+constexpr uint32_t CHAIN_SHORT_VALUES = 1024;
+struct ChainListing {
+    bool lists, is_long;
+    uint32_t n;                // values of the stream; 0: it goes on behind the wave
+    uint32_t rank;             // among the wave's listed streams of the same kind
+    uint32_t n_short, n_long;  // of the wave
+};
+__device__ __forceinline__ ChainListing chain_listing(bool present, bool is_head, bool is_tail, uint32_t to_decode, int lane) {
+    ChainListing out;
+    out.lists = present && is_head && !is_tail;
+    const unsigned long long tails = __ballot(present && is_tail);
+    const unsigned long long tails_behind = lane == 63 ? 0ull : (tails >> (lane + 1));
+    const int my_tail = tails_behind ? lane + 1 + __builtin_ctzll(tails_behind) : -1; // (none: the stream goes on behind the wave)
+    const uint32_t last_count = (uint32_t)__shfl((int)to_decode, my_tail >= 0 ? my_tail : lane, MDB_WAVE);
+    out.n = my_tail >= 0 ? (uint32_t)(my_tail - lane) * MV_PIECE_VALUES + last_count : 0u; // (64 a piece but the last)
+    out.is_long = out.n == 0u || out.n > CHAIN_SHORT_VALUES;
+    const unsigned long long shorts = __ballot(out.lists && !out.is_long), longs = __ballot(out.lists && out.is_long);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    out.rank = (uint32_t)__popcll((out.is_long ? longs : shorts) & below);
+    out.n_short = (uint32_t)__popcll(shorts);
+    out.n_long = (uint32_t)__popcll(longs);
+    return out;
+}
+
+// How many streams of either kind every wave of pieces lists: long << 32 | short (the scan over these says where).
+__global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chain_count(const MvCursor *__restrict__ cursors, unsigned long long n_pieces,
+                                                                 unsigned long long *__restrict__ counts) {
+    const int lane = threadIdx.x;
+    const unsigned long long piece = (unsigned long long)blockIdx.x * MDB_WAVE + lane;
+    bool is_head = false, is_tail = false;
+    uint32_t to_decode = 0;
+    if (piece < n_pieces) {
+        const uint4 c0 = load_global(reinterpret_cast<const uint4 *>(cursors + piece));
+        const uint4 c1 = load_global(reinterpret_cast<const uint4 *>(cursors + piece) + 1);
+        to_decode = c1.x;
+        piece_neighbours(cursors, piece, n_pieces, c0.z, (c1.y & MV_WINDOW_RESIDUAL) != 0, &is_head, &is_tail);
+    }
+    const ChainListing listing = chain_listing(piece < n_pieces, is_head, is_tail, to_decode, lane);
+    if (lane == 0) counts[blockIdx.x] = ((unsigned long long)listing.n_long << 32) | listing.n_short;
+}
+struct ChainCount {
+    const unsigned long long *counts;
+    __device__ uint64_t operator()(uint64_t wave) const { return counts[wave]; }
+};
+
+// One lane per piece, as k_grid_mv_pieces (the same decoder, rounds of ROUND values staged in LDS): a piece that is a
+// whole stream - most residual tails are - is added up by its own lane while it is decoded (its values ARE the stream,
+// in order); the pieces of longer streams go to `values` (piece p at 64 p, rows of ROUND consecutive values per store)
+// and the stream is listed for k_agg_mv_chain_groups by the lane of its first piece. (Round 5's kernel staged all 64
+// values of every piece - 22 KB of LDS a wave, 1.75 waves a SIMD - so that the lane of a stream's first piece could add
+// up the stream inside the wave while the other 63 waited: 2.7 / 2.3 ms where this decoder needs 2.0 / 1.45 for grid().)
+template <int ROUND>
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const MvCursor *__restrict__ cursors,
                                                             unsigned long long n_pieces, uint32_t *__restrict__ values,
-                                                            float *__restrict__ stream_sums, ChainItem *__restrict__ chain_items) {
-    // All 64 values of every piece staged in LDS (a row per lane): a stream whose pieces all lie in this wave - most
-    // of a batch's streams are a few pieces long - is added up right here, by the lane of its first piece, in stream
-    // order (the sum in stream_sums); only the pieces of streams that reach beyond the
-    // wave go to `values` for k_agg_mv_chains. (A round trip of 4 bytes per value through memory otherwise: 2.5 GB
-    // written and read again for the mixed series.)
-    constexpr int STRIDE = MV_PIECE_VALUES + 1; // (an odd stride keeps the banks apart)
+                                                            float *__restrict__ stream_sums, ChainItem *__restrict__ short_items,
+                                                            ChainItem *__restrict__ long_items,
+                                                            const unsigned long long *__restrict__ chain_offsets) {
+    constexpr int STRIDE = ROUND + 1; // (a row per lane: an odd stride keeps the banks apart)
     __shared__ uint32_t stage[MDB_WAVE * STRIDE];
     __shared__ uint32_t ring[PIECE_RING_ROWS][MDB_WAVE];
     __shared__ uint32_t row_count[MDB_WAVE];
@@ -1684,19 +1753,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
         segment = i;
         to_decode = c1.x;
         residual = (window & MV_WINDOW_RESIDUAL) != 0;
-        // (the pieces in front and behind: of the same stream?)
-        if (piece == 0) {
-            is_head = true;
-        } else {
-            const MvCursor *before = cursors + piece - 1;
-            is_head = load_global(&before->segment) != i || ((load_global(&before->window) & MV_WINDOW_RESIDUAL) != 0) != residual;
-        }
-        if (piece + 1 == n_pieces) {
-            is_tail = true;
-        } else {
-            const MvCursor *behind = cursors + piece + 1;
-            is_tail = load_global(&behind->segment) != i || ((load_global(&behind->window) & MV_WINDOW_RESIDUAL) != 0) != residual;
-        }
+        piece_neighbours(cursors, piece, n_pieces, i, residual, &is_head, &is_tail);
         const DevCol &column = residual ? s.residuals : s.values;
         const uint4 view = column.views[i];
         reader.open(view_data(column, i, view, residual ? residuals_first : values_first),
@@ -1722,91 +1779,86 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_pieces(DevSegments s, const
         state.window_bits = leading + trailing <= 32u ? 32u - leading - trailing : 0u;
         state.raw = (window & MV_WINDOW_RAW) != 0;
     }
+    const bool present = piece < n_pieces;
+    const bool whole = present && is_head && is_tail; // the piece is its stream: summed here
+    const bool spilled = present && !whole;           // a piece of a longer stream: its values go to memory
+    // The streams of two pieces or more that begin in this wave, listed where the scan says (k_agg_mv_chain_count made
+    // the same tests): the short ones in one list, the long ones in another.
+    {
+        const ChainListing listing = chain_listing(present, is_head, is_tail, to_decode, lane);
+        if (listing.lists) {
+            const unsigned long long where = chain_offsets[blockIdx.x];
+            ChainItem *to = listing.is_long ? long_items + (where >> 32) : short_items + (where & 0xffffffffull);
+            to[listing.rank] = {(segment << 1) | (residual ? 1u : 0u), listing.n, piece};
+        }
+    }
     reader.begin();
     reader.top_up(ring, lane);
     reader.top_up(ring, lane);
     reader.start(ring, lane);
-    static_assert(MV_PIECE_VALUES % 2 == 0, "values are decoded in pairs");
-    for (uint32_t k = 0, most = wave_max_u32(to_decode); k < most; k += 2) {
-        if (__any(reader.hungry())) reader.top_up(ring, lane);
-        stage[lane * STRIDE + k] = piece_decode_value(reader, state, ring, lane);
-        stage[lane * STRIDE + k + 1] = piece_decode_value(reader, state, ring, lane); // (k + 1 == 64: the row's spare word)
-    }
-    row_count[lane] = to_decode;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // Which pieces belong to a stream that begins AND ends in this wave: the lane of a first piece whose stream's
-    // last piece is one of the lanes behind it (pieces of a stream follow each other).
-    const unsigned long long heads = __ballot(is_head), tails = __ballot(is_tail);
-    const unsigned long long heads_up_to_me = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int my_head = heads_up_to_me ? 63 - __builtin_clzll(heads_up_to_me) : -1; // (none: the stream began in a wave before)
-    const unsigned long long tails_from_head = my_head >= 0 ? tails >> my_head : 0ull;
-    const int my_tail = tails_from_head ? my_head + __builtin_ctzll(tails_from_head) : -1; // (none: it ends in a wave behind)
-    const bool here = piece < n_pieces && my_head >= 0 && my_tail >= 0; // (then my_tail >= lane: no tail between the head and me)
-    if (here && is_head) {
-        // macaque_v.rs:220-265: a segment's values are added to the first one, a tail's to 0, one after the other.
-        float sum = 0.0f;
-        bool starts = !residual;
-        for (int row = lane; row <= my_tail; row++) {
-            const uint32_t n = row_count[row];
-            const uint32_t *from = stage + row * STRIDE;
-            uint32_t k = 0;
-            if (starts && n > 0) {
-                sum = __uint_as_float(from[0]);
-                k = 1;
-                starts = false;
-            }
-            for (; k + 8 <= n; k += 8) { // (eight reads under way, then the chain of additions)
-                uint32_t v[8];
+    // macaque_v.rs:220-265: a segment's values are added to the first one, a tail's to 0, one after the other.
+    float own = 0.0f;
+    const bool starts_as_first = !residual;
+    for (uint32_t done = 0; __any(done < to_decode); done += ROUND) {
+        const uint32_t mine = done < to_decode ? min(to_decode - done, (uint32_t)ROUND) : 0u;
+        static_assert(ROUND % 2 == 0, "values are decoded in pairs");
+        for (uint32_t k = 0, most = wave_max_u32(mine); k < most; k += 2) {
+            if (__any(reader.hungry())) reader.top_up(ring, lane);
+            const uint32_t even = piece_decode_value(reader, state, ring, lane);
+            const uint32_t odd = piece_decode_value(reader, state, ring, lane);
+            stage[lane * STRIDE + k] = even;
+            stage[lane * STRIDE + k + 1] = odd; // (k + 1 == ROUND: the row's spare word)
+            // (the running sum of the lane's own piece: what a piece that is a whole stream reports)
+            const float with_even = (starts_as_first && done + k == 0u) ? __uint_as_float(even) : own + __uint_as_float(even);
+            own = k < mine ? with_even : own;
+            own = k + 1 < mine ? own + __uint_as_float(odd) : own;
+        }
+        // Row r = this round's values of lane r's piece, for the pieces that go to memory: consecutive values,
+        // (64 / ROUND) rows per store instruction.
+        row_count[lane] = spilled ? mine : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int ROWS_PER_STORE = MDB_WAVE / ROUND;
+        const int sub_row = lane / ROUND, column_of_lane = lane % ROUND;
+        constexpr int BATCH = 8;
+        static_assert(MDB_WAVE % (BATCH * ROWS_PER_STORE) == 0, "whole batches of stores");
+        for (int r0 = 0; r0 < MDB_WAVE; r0 += BATCH * ROWS_PER_STORE) {
+            uint32_t counts[BATCH], staged[BATCH];
 #pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = from[k + q];
-#pragma unroll
-                for (int q = 0; q < 8; q++) sum += __uint_as_float(v[q]);
+            for (int q = 0; q < BATCH; q++) {
+                const int r = r0 + q * ROWS_PER_STORE + sub_row;
+                counts[q] = row_count[r];
+                staged[q] = stage[r * STRIDE + column_of_lane];
             }
-            for (; k < n; k++) sum += __uint_as_float(from[k]);
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) {
+                const int r = r0 + q * ROWS_PER_STORE + sub_row;
+                if ((uint32_t)column_of_lane < counts[q])
+                    values[(first_piece + (unsigned long long)r) * MV_PIECE_VALUES + done + (uint32_t)column_of_lane] = staged[q];
+            }
         }
-        stream_sums[2ull * segment + (residual ? 1u : 0u)] = sum;
+        __builtin_amdgcn_wave_barrier();
     }
-    // The stream that begins in this wave and goes on behind it (the wave's last stream, if any does: every other one
-    // that begins here ends here) is k_agg_mv_chain_groups': listed in the wave's own place, no counter to queue at.
-    {
-        const bool goes_on = piece < n_pieces && is_head && my_tail < 0;
-        const unsigned long long going_on = __ballot(goes_on);
-        if (going_on == 0) {
-            if (lane == 0) chain_items[blockIdx.x] = {CHAIN_NONE, 0u, 0ull};
-        } else if (goes_on) {
-            chain_items[blockIdx.x] = {(segment << 1) | (residual ? 1u : 0u), 0u, piece};
-        }
-    }
-    // The other pieces' values: to `values`, a row of 64 values (two 128-byte lines) per lane pair of store instructions.
-    const unsigned long long spilled = __ballot(piece < n_pieces && !here);
-    if (spilled) {
-        const int half = lane >> 5, column = lane & 31;
-        for (int r0 = 0; r0 < MDB_WAVE; r0 += 2) {
-            const int r = r0 + half;
-            if (!((spilled >> r) & 1ull)) continue;
-            uint32_t *to = values + (first_piece + (unsigned long long)r) * MV_PIECE_VALUES;
-            to[column] = stage[r * STRIDE + column];
-            to[32 + column] = stage[r * STRIDE + 32 + column];
-        }
-    }
+    if (whole && to_decode > 0) stream_sums[2ull * segment + (residual ? 1u : 0u)] = own;
 }
 
-// A stream whose pieces reach beyond one wave of k_agg_mv_pieces: its values lie in `values` (piece p at 64 p), and its
-// f32 additions are one chain, in stream order (macaque_v.rs:228-235). A chain is 4 cycles an addition; what it waited
-// for was memory - a lane of its own kept 128 bytes of its stream in flight, a round trip per 32 additions (round 6's
-// counters: 65 % of the kernel's wave-cycles waiting, the vector ALU busy 5 %; a 65 536-value stream 0.7 ms) - and, in
-// front of that, a thread per SEGMENT that looked for the streams not summed yet (0.75 ms for 8.5 M segments). Now the
-// wave of k_agg_mv_pieces in which such a stream begins says so in its own place of a list (one stream per wave at
-// most), and k_agg_mv_chain_groups gives every listed stream EIGHT lanes: together they keep 2 KB of it in flight - a
-// round of 512 values, 16 chunks of 16 bytes per lane, the eight lanes' chunks side by side in memory - park a round in
-// LDS, ask for the next one, and the first of the eight adds the parked round up, value after value.
+// A stream of two pieces or more: its values lie in `values` (piece p at 64 p), and its f32 additions are one chain,
+// in stream order (macaque_v.rs:228-235). A chain is 4 cycles an addition; what it waited for was memory - a lane of
+// its own kept 128 bytes of its stream in flight, a round trip per 32 additions (round 6's counters: 65 % of the
+// kernel's wave-cycles waiting, the vector ALU busy 5 %; a 65 536-value stream 0.7 ms) - and, in front of that, a thread
+// per SEGMENT that looked for the streams not summed yet (0.75 ms for 8.5 M segments). Now the waves of k_agg_mv_pieces
+// list the streams that begin in them (k_agg_mv_chain_count + a scan say where), and k_agg_mv_chain_groups gives every
+// listed stream EIGHT lanes: together they keep 2 KB of it in flight - a round of 512 values, 16 chunks of 16 bytes per
+// lane, the eight lanes' chunks side by side in memory - park a round in LDS, ask for the next one, and the first of
+// the eight adds the parked round up, value after value.
+// Two sizes of round: most listed streams are a few pieces long (a stretch of rejected points between two models) and
+// want many waves in flight more than bytes - 4 loads a lane, 128 values a round, 4 KB of LDS a wave; the long ones
+// (a whole chunk of noise is one stream of 65 536 values) want the bytes - 16 loads a lane, 512 values a round. A list
+// of its own for each kind (a stream that goes on behind its wave counts as long): the long chains begin at once
+// instead of behind the dispatch of the short ones' hundred thousand waves.
 constexpr int CHAIN_GROUP_LANES = 8;
 constexpr int CHAIN_GROUPS_PER_WAVE = MDB_WAVE / CHAIN_GROUP_LANES;
-constexpr int CHAIN_LOADS = 16;                                    // 16-byte loads a lane has in flight
-constexpr int CHAIN_ROUND_CHUNKS = CHAIN_LOADS * CHAIN_GROUP_LANES; // 128 chunks = 512 values = 2 KB a round
-constexpr int CHAIN_GROUP_STRIDE = CHAIN_ROUND_CHUNKS + 1;          // (in chunks: the eight adding lanes read eight banks)
 
 // Cursors left by host threads (the index of one call): should they ever disagree with the kernels' own analysis about
 // a segment's streams, its sums are made unusable rather than a little wrong. (A resident batch's cursors come from
@@ -1825,20 +1877,23 @@ __global__ __launch_bounds__(256) void k_agg_mv_check_cursors(DevSegments s, con
         stream_sums[2 * i] = stream_sums[2 * i + 1] = __uint_as_float(0x7fc00000u);
 }
 
+template <int CHAIN_LOADS> // 16-byte loads a lane has in flight: 4 for the list of short streams, 16 for the long ones
 __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chain_groups(DevSegments s, const uint32_t *__restrict__ known_totals,
                                                                   const uint32_t *__restrict__ values, float *__restrict__ stream_sums,
                                                                   const ChainItem *__restrict__ items, unsigned int n_items) {
+    constexpr int CHAIN_ROUND_CHUNKS = CHAIN_LOADS * CHAIN_GROUP_LANES; // chunks of 16 bytes = 4 values a round
+    constexpr int CHAIN_GROUP_STRIDE = CHAIN_ROUND_CHUNKS + 1;          // (in chunks: the eight adding lanes read eight banks)
     __shared__ uint4 parked[CHAIN_GROUPS_PER_WAVE * CHAIN_GROUP_STRIDE];
     const int lane = threadIdx.x, group = lane / CHAIN_GROUP_LANES, member = lane % CHAIN_GROUP_LANES;
     const unsigned int mine = blockIdx.x * CHAIN_GROUPS_PER_WAVE + (unsigned int)group;
-    ChainItem item{CHAIN_NONE, 0u, 0ull};
-    if (mine < n_items) item = items[mine];
-    const bool listed = item.segment_and_kind != CHAIN_NONE;
-    if (!__any(listed)) return;
-    // How many values the stream has: the analysis of its segment, by the group's first lane.
-    uint32_t n = 0;
+    const bool listed = mine < n_items;
+    ChainItem item{0u, 1u, 0ull}; // (a group without a stream: one value of the scratch's first piece, nobody's sum)
+    if (listed) item = items[mine];
+    // How many values the stream has: its pieces said so if it ended in the wave it began in, else the analysis of
+    // its segment, by the group's first lane.
+    uint32_t n = item.n;
     const bool tail = (item.segment_and_kind & 1u) != 0u;
-    if (listed && member == 0) {
+    if (listed && member == 0 && n == 0) {
         uint32_t n_values, n_res, n_model, error;
         mv_stream_lengths(s, item.segment_and_kind >> 1, known_totals, &n_values, &n_res, &n_model, &error);
         n = tail ? n_res : n_values;
@@ -1883,7 +1938,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_agg_mv_chain_groups(DevSegments s,
                 if (here > 3) sum += __uint_as_float(q.w);
                 k = 4;
             }
-            for (; k + 32 <= here; k += 32) { // (eight reads of the parked round under way, then the chain of additions)
+            for (; k + 32 <= here; k += 32) { // (eight reads of the parked round under way, then the chain of additions;
+                                              // the next batch's reads under way during the additions: slower, 0.77 -> 0.92 ms)
                 uint4 q[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) q[j] = mine_parked[(k >> 2) + (uint32_t)j];
@@ -3301,27 +3357,54 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
     }
     // (the index of one call covers its long streams only: the sums of a segment without pieces are nobody's)
     if (index->of_one_call) *only_with_pieces = static_cast<const unsigned long long *>(index->piece_base);
+    const uint64_t piece_waves = (index->n_pieces + MDB_WAVE - 1) / MDB_WAVE;
+    if (piece_waves > 0x7ffffff0ull) return fail("Too many MacaqueV streams for one batch.");
+    // (every listed stream has two pieces or more)
+    const uint64_t most_items = index->n_pieces / 2 + 1;
+    const uint64_t counts_bytes = align_up(piece_waves * 8, 256), offsets_bytes = align_up((piece_waves + 1) * 8, 256);
+    const uint64_t block_sums_bytes = align_up(scan_block_sums_bytes(piece_waves), 256);
     void *p = nullptr;
     if (scratch_reserve(ctx, SCRATCH_AGG_MV, index->n_pieces * MV_PIECE_VALUES * 4 + in->n * 8 + 256, &p)) return 1;
     uint32_t *values = static_cast<uint32_t *>(p);
     float *sums = reinterpret_cast<float *>(values + index->n_pieces * MV_PIECE_VALUES);
     // (a stream without values - the tail of a segment that has none - sums to 0: the kernels write the others)
     MDB_HIP_CHECK(hipMemsetAsync(sums, 0, 8 * in->n, ctx->stream));
-    const uint64_t piece_waves = (index->n_pieces + MDB_WAVE - 1) / MDB_WAVE;
-    if (piece_waves > 0xfffffff0ull) return fail("Too many MacaqueV streams for one batch.");
     void *q = nullptr;
-    if (scratch_reserve(ctx, SCRATCH_AGG_CHAIN_LIST, piece_waves * sizeof(ChainItem) + 64, &q)) return 1;
-    ChainItem *items = static_cast<ChainItem *>(q);
+    if (scratch_reserve(ctx, SCRATCH_AGG_CHAIN_LIST, counts_bytes + offsets_bytes + block_sums_bytes + 2 * most_items * sizeof(ChainItem) + 64, &q)) return 1;
+    uint8_t *at = static_cast<uint8_t *>(q);
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(at);
+    unsigned long long *offsets = reinterpret_cast<unsigned long long *>(at + counts_bytes);
+    unsigned long long *block_sums = reinterpret_cast<unsigned long long *>(at + counts_bytes + offsets_bytes);
+    ChainItem *short_items = reinterpret_cast<ChainItem *>(at + counts_bytes + offsets_bytes + block_sums_bytes);
+    ChainItem *long_items = short_items + most_items;
+    const MvCursor *cursors = static_cast<const MvCursor *>(index->cursors);
+    {
+        // Where every wave of pieces lists the streams of two pieces or more that begin in it.
+        LaunchTimer timer(ctx, "k_agg_mv_chain_count");
+        hipLaunchKernelGGL(k_agg_mv_chain_count, dim3((uint32_t)piece_waves), dim3(MDB_WAVE), 0, ctx->stream, cursors, index->n_pieces, counts);
+    }
+    if (device_exclusive_scan(ctx, ChainCount{counts}, piece_waves, offsets, block_sums, "k_agg_mv_chain_scan")) return 1;
+    // (how many are listed sizes the launches behind the piece kernel: a wave that finds nothing to do still costs a
+    // third of a microsecond, and the most there can be is 5.4 M groups for the mixed series' 10.8 M pieces)
+    unsigned long long listed = 0;
+    MDB_HIP_CHECK(mail_read(ctx, &listed, offsets + piece_waves, 8));
+    MDB_HIP_CHECK(mail_sync(ctx));
+    const uint64_t n_short = listed & 0xffffffffull, n_long = listed >> 32;
+    if (n_short > most_items || n_long > most_items) return fail("Internal error: more MacaqueV streams listed than there are pieces for.");
     {
         LaunchTimer timer(ctx, "k_agg_mv_pieces");
-        hipLaunchKernelGGL(k_agg_mv_pieces, dim3((uint32_t)piece_waves), dim3(MDB_WAVE), 0, ctx->stream, s,
-                           static_cast<const MvCursor *>(index->cursors), index->n_pieces, values, sums, items);
+        hipLaunchKernelGGL(k_agg_mv_pieces<32>, dim3((uint32_t)piece_waves), dim3(MDB_WAVE), 0, ctx->stream, s, cursors, index->n_pieces,
+                           values, sums, short_items, long_items, static_cast<const unsigned long long *>(offsets));
     }
     {
-        // The streams that reach beyond a wave of k_agg_mv_pieces, eight lanes each (one place per wave of pieces).
+        // The listed streams, eight lanes each: the long kind first (they are what takes longest), the short kind behind.
         LaunchTimer timer(ctx, "k_agg_mv_chains");
-        hipLaunchKernelGGL(k_agg_mv_chain_groups, dim3((uint32_t)((piece_waves + CHAIN_GROUPS_PER_WAVE - 1) / CHAIN_GROUPS_PER_WAVE)),
-                           dim3(MDB_WAVE), 0, ctx->stream, s, known_totals, values, sums, items, (unsigned int)piece_waves);
+        if (n_long > 0)
+            hipLaunchKernelGGL((k_agg_mv_chain_groups<16>), dim3((uint32_t)((n_long + CHAIN_GROUPS_PER_WAVE - 1) / CHAIN_GROUPS_PER_WAVE)),
+                               dim3(MDB_WAVE), 0, ctx->stream, s, known_totals, values, sums, long_items, (unsigned int)n_long);
+        if (n_short > 0)
+            hipLaunchKernelGGL((k_agg_mv_chain_groups<4>), dim3((uint32_t)((n_short + CHAIN_GROUPS_PER_WAVE - 1) / CHAIN_GROUPS_PER_WAVE)),
+                               dim3(MDB_WAVE), 0, ctx->stream, s, known_totals, values, sums, short_items, (unsigned int)n_short);
         if (index->of_one_call)
             hipLaunchKernelGGL(k_agg_mv_check_cursors, dim3((uint32_t)((in->n + 255) / 256)), dim3(256), 0, ctx->stream, s, known_totals,
                                static_cast<const unsigned long long *>(index->piece_base), sums);
