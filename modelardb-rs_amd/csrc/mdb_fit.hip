@@ -2083,6 +2083,32 @@ struct ValueRange {
     float low, high;
 };
 
+// What folding min_num / max_num over the wave's values in lane order gives (macaque_v.rs:199-204: the first operand is kept
+// on ties, a NaN is never taken over a number; lanes that are not `active` count as NaN): the FIRST of the least values
+// and the first of the greatest - or, where no lane has a number, whatever the last lane holds (a fold through nothing
+// but NaNs ends on the last of them). Not a scan of two floats with the two functions by hand (some 75 vector
+// instructions a batch in a kernel that is bound by them: k_fit_gap<SIZE>), but two unsigned reductions over keys in
+// the values' order - both zeros one key, as they compare equal -, a ballot for the first lane that has the extreme
+// and its value read from there.
+__device__ __forceinline__ ValueRange wave_value_range(bool active, float stored) {
+    const uint32_t bits = __float_as_uint(stored);
+    const bool counts = active && stored == stored;
+    const uint32_t plain = (bits << 1) == 0u ? 0u : bits;
+    const uint32_t key = (plain & 0x80000000u) ? ~plain : (plain | 0x80000000u); // 0x007fffff (-inf) .. 0xff800000 (+inf)
+    const uint32_t least = read_lane(wave_inclusive_scan_all_lanes(counts ? key : 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); },
+                                                                   [](uint32_t x) { return x; }), MDB_WAVE - 1);
+    const uint32_t most = read_lane(wave_inclusive_scan_all_lanes(counts ? key : 0u, [](uint32_t a, uint32_t b) { return max(a, b); },
+                                                                  [](uint32_t x) { return x; }), MDB_WAVE - 1);
+    const uint32_t mine = active ? bits : 0x7fc00000u;
+    if (least == 0xffffffffu) { // (no lane has a number)
+        const float last = __uint_as_float(read_lane(mine, MDB_WAVE - 1));
+        return ValueRange{last, last};
+    }
+    const int first_least = __builtin_ctzll(__ballot(counts && key == least));
+    const int first_most = __builtin_ctzll(__ballot(counts && key == most));
+    return ValueRange{__uint_as_float(read_lane(bits, first_least)), __uint_as_float(read_lane(bits, first_most))};
+}
+
 // A chunk whose models turn out short is not this kernel's: a model costs at least one block of 64 points however
 // short it is, a pass over rejected start points half a block per 64 start points it looks at and four for its
 // second stage. Split mode takes about 100 cycles per point on such data, a block 2 300. Every `window_points` the
@@ -3478,6 +3504,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
     const ChunkTimestamps ts = chunk_timestamps(args.timestamps, item.chunk, args.chunk_offsets[item.chunk]);
     bool regular = true;
     const int64_t expected_delta = (MEASURE && ts.ts && n >= 2) ? ts.ts[item.first + 1] - ts.ts[item.first] : 0;
+    // (asking for a batch's values while the batch before it is worked on: 2.57 -> 2.54 / 3.40 -> 3.45 ms, nothing)
     for (uint32_t base = 1; base < n; base += MDB_WAVE) {
         const uint32_t i = base + lane;
         const bool active = i < n;
@@ -3565,18 +3592,26 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_gap(FitArgs args, const SegIte
         const uint32_t meaningful = 32u - my_leading - my_trailing;
         uint32_t code_bits = 0;
         if (active) code_bits = repeat ? 2u : (opens ? 13u + meaningful : 1u + meaningful);
-        // Exclusive prefix sum of the code lengths: where each code goes.
-        const uint32_t inclusive = wave_inclusive_scan(code_bits, lane, [](uint32_t a, uint32_t b) { return a + b; });
-        const uint32_t batch_bits = read_lane(inclusive, MDB_WAVE - 1);
-        // min / max with the first operand kept on ties, NaN as the neutral element (macaque_v.rs:199-204).
-        // The reduction keeps the order of the values (earlier blocks are the first operand), so that
-        // e.g. the sign of a zero minimum is the one the sequential encoder would report.
-        const float mine = active ? stored : __uint_as_float(0x7fc00000u);
-        const ValueRange range = read_lane(wave_inclusive_scan(ValueRange{mine, mine}, lane, [](ValueRange a, ValueRange b) {
-            return ValueRange{min_num(a.low, b.low), max_num(a.high, b.high)};
-        }), MDB_WAVE - 1);
-        min_value = min_num(min_value, range.low);
-        max_value = max_num(max_value, range.high);
+        // Exclusive prefix sum of the code lengths: where each code goes. (A pass that only measures needs their sum,
+        // and a batch in which no window opens - nearly every batch of noise - has it in closed form: two bits a repeat,
+        // one and the window's a code.)
+        uint32_t inclusive = 0, batch_bits;
+        const unsigned long long opening = WRITE ? 1ull : __ballot(opens);
+        if (!WRITE && opening == 0) {
+            const uint32_t repeats = (uint32_t)__popcll(__ballot(active && repeat)), codes = (uint32_t)__popcll(__ballot(active));
+            batch_bits = 2u * repeats + (codes - repeats) * (33u - window_leading - window_trailing);
+        } else {
+            inclusive = wave_inclusive_scan(code_bits, lane, [](uint32_t a, uint32_t b) { return a + b; });
+            batch_bits = read_lane(inclusive, MDB_WAVE - 1);
+        }
+        // min / max with the first operand kept on ties, NaN as the neutral element (macaque_v.rs:199-204); earlier
+        // batches are the first operand, so that e.g. the sign of a zero minimum is the one the sequential encoder
+        // would report.
+        if (MEASURE) {
+            const ValueRange range = wave_value_range(active, stored);
+            min_value = min_num(min_value, range.low);
+            max_value = max_num(max_value, range.high);
+        }
         if (WRITE) {
             if (active) {
                 const uint32_t at = carry_bits + inclusive - code_bits;
@@ -4004,10 +4039,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_long(FitArgs args, const SegIt
         bits += batch.batch_bits;
         opened = opened || batch.any_opens;
         if (MODE == LONG_SPEC_SIZE) {
-            const float mine = active ? batch.stored : nan32;
-            const ValueRange range = read_lane(wave_inclusive_scan(ValueRange{mine, mine}, lane, [](ValueRange a, ValueRange b) {
-                return ValueRange{min_num(a.low, b.low), max_num(a.high, b.high)};
-            }), MDB_WAVE - 1);
+            const ValueRange range = wave_value_range(active, batch.stored);
             min_value = min_num(min_value, range.low);
             max_value = max_num(max_value, range.high);
         } else {
