@@ -72,7 +72,7 @@ def main():
             n_chunks = len(offsets) - 1
             row = {"series": name, "points": total, "chunks": n_chunks, "chunk_points": chunk_points}
             batches = {}
-            for mode, env in (("default", {}), ("lean", {"MDB_FIT_WAVE": "0"}),
+            for mode, env in (("default", {}), ("wave", {"MDB_FIT_WAVE": "1"}), ("lean", {"MDB_FIT_WAVE": "0"}),
                               ("plain", {"MDB_FIT_WAVE": "0", "MDB_FIT_LEAN": "0"})):
                 for key in ("MDB_FIT_WAVE", "MDB_FIT_LEAN"):
                     os.environ.pop(key, None)
@@ -83,7 +83,7 @@ def main():
                 row[f"{mode}_kernels_ms"] = " ".join(f"{k}={ms:.2f}" for k, ms in sorted(kernels.items(), key=lambda i: -i[1])[:3])
                 batches[mode] = dev.download()
                 dev.free()
-            row["identical"] = batches["lean"].identical(batches["plain"]) and batches["default"].identical(batches["plain"])
+            row["identical"] = all(batches[m].identical(batches["plain"]) for m in ("default", "wave", "lean"))
             print(row, flush=True)
             rows.append(row)
             ctx.dev_free(offsets_dev); ctx.dev_free(first_index_dev)

@@ -37,9 +37,10 @@ def mode(request, monkeypatch):
 
 def runs(rng, length, kinds):
     """A series made of runs of 3..40 points, each of one of `kinds`."""
-    out = []
-    while sum(len(r) for r in out) < length:
+    out, made = [], 0
+    while made < length:
         n = int(rng.integers(3, 41))
+        made += n
         kind = kinds[int(rng.integers(len(kinds)))]
         if kind == "zeros":
             run = np.where(rng.random(n) < 0.5, np.float32(0.0), np.float32(-0.0))
@@ -157,3 +158,29 @@ def test_one_timestamp_for_every_point(hip, kinds):
     timestamps = np.concatenate([np.full(n, 1_000_000 * (k + 1), dtype=np.int64) for k, n in enumerate(lengths)])
     offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
     fit_and_compare(hip, timestamps, values, offsets)
+
+
+def test_more_chunks_than_the_lossy_bounds_hand_the_wave_kernel(hip, mode, monkeypatch):
+    """Under a lossless bound the wave kernel takes a call of ANY number of chunks (it decides by equality and is the
+    fastest fitter there; under lossy bounds it stops at 96 chunks per compute unit): 30 000 chunks of 150 to 200 points,
+    the library's choice - the wave kernel - against the lane-per-chunk fitter on the same call, and the oracle on a sample."""
+    if mode != "library":
+        pytest.skip("the library's own choice is what is tested")
+    rng = np.random.default_rng(99)
+    n_chunks = 30_000
+    lengths = rng.integers(150, 201, n_chunks)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    values = np.resize(runs(rng, 200_000, KINDS["everything"]), int(offsets[-1]))  # (the same 200 000 points over and over)
+    timestamps = (np.arange(int(offsets[-1]), dtype=np.int64) - np.repeat(offsets[:-1].astype(np.int64), lengths)) * 1000
+    hip.profile_enable(True)
+    hip.profile_reset()
+    chosen = hip.compress_chunks(timestamps, values, offsets, LOSSLESS)
+    kernels = {name for name, (calls, _) in hip.profile().items() if calls > 0}
+    hip.profile_enable(False)
+    assert "k_fit_models_wave" in kernels, kernels
+    monkeypatch.setenv("MDB_FIT_WAVE", "0")
+    assert chosen.identical(hip.compress_chunks(timestamps, values, offsets, LOSSLESS))
+    sample = 400
+    end = int(offsets[sample])
+    assert_same_segments(hip.compress_chunks(timestamps[:end], values[:end], offsets[:sample + 1], LOSSLESS),
+                         ora.compress_chunks(timestamps[:end], values[:end], offsets[:sample + 1], LOSSLESS))
