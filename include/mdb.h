@@ -321,7 +321,10 @@ int mdb_profile_reset(mdb_ctx *ctx);
  * side of its calls under names that begin with "host:" (calls and wall-clock milliseconds): host:chunk_list_gather
  * (the host threads' copies into page-locked memory, the copies to the device running behind them),
  * host:chunk_list_upload_tail (what is left of those copies when the last slice is gathered), host:chunk_list_fit,
- * host:chunk_list_download. */
+ * host:chunk_list_download. The jobs of mdb_grid_submit add theirs: host:grid_cursors_by_host_threads,
+ * host:grid_wait_for_the_context, host:grid_upload_segments, host:grid_plan, host:grid_launches,
+ * host:grid_kernels_and_copy_down, host:grid_free_segments. The profile of a context covers the clones its
+ * mdb_grid_submit workers run jobs on: they are switched and reset with it, their launches are counted as its own. */
 int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *total_ms);
 /* Names of all profiled kernels, '\n' separated. */
 int mdb_profile_names(mdb_ctx *ctx, char *out, uint64_t cap);

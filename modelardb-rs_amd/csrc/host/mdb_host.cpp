@@ -486,15 +486,15 @@ GridStream::GridStream(mdb_ctx *ctx, std::vector<Field> schema, ExprPtr maybe_pr
         throw Error("A values-only GridStream cannot evaluate a predicate that is not a time range.");
     if (values_only_) schema_ = {schema_[1]};
     current_batch_ = RecordBatch::new_empty(schema_);
-    // MDB_HOST_GRID_PREFETCH=0: grid a batch when it is polled for and not before (A/B, tests).
-    const char *setting = std::getenv("MDB_HOST_GRID_PREFETCH");
-    prefetch_ = !(setting && std::string(setting) == "0");
+    // MDB_HOST_GRID_PREFETCH=0: grid a batch when it is polled for and not before (A/B, tests); n: n submits ahead.
+    if (const char *setting = std::getenv("MDB_HOST_GRID_PREFETCH"))
+        prefetch_depth_ = static_cast<size_t>(std::min(std::max(std::atoi(setting), 0), 8));
     if (const char *text = std::getenv("MDB_HOST_GRID_COALESCE_SEGMENTS"))
         coalesce_segments_ = static_cast<size_t>(std::max(0ll, std::atoll(text)));
 }
 
 GridStream::~GridStream() {
-    if (ahead_) mdb_grid_cancel(ahead_->raw); // (waits for the job and frees what it made)
+    for (Ticket &ticket : ahead_) mdb_grid_cancel(ticket.raw); // (waits for the job and frees what it made)
 }
 
 // Data points a submit should decompress to, and the segments it may hold at most.
@@ -672,19 +672,26 @@ void GridStream::wait_and_append_to_leftovers_in_current_batch(Ticket ticket) {
 PollState GridStream::poll_next(RecordBatch *out) {
     // grid_exec.rs:402-429
     if (static_cast<size_t>(current_batch_.num_rows - current_batch_offset_) < batch_size_) {
-        std::optional<Ticket> ticket = std::move(ahead_);
-        ahead_.reset();
+        std::optional<Ticket> ticket;
+        if (!ahead_.empty()) {
+            ticket = std::move(ahead_.front());
+            ahead_.pop_front();
+        }
         PollState state = PollState::ReadySome;
         if (!ticket) state = poll_input_and_submit(&ticket);
         if (ticket) {
-            // The submit after this one starts now, so that it is on the GPU while this one comes down.
-            if (prefetch_) {
-                try {
-                    (void)poll_input_and_submit(&ahead_);
-                } catch (...) {
-                    mdb_grid_cancel(ticket->raw);
-                    throw;
+            // The submits after this one start now: their cursors are walked and their segments go up while this
+            // one's points come down (the library runs them on contexts of their own, mdb_grid_submit).
+            try {
+                while (ahead_.size() < prefetch_depth_) {
+                    std::optional<Ticket> next;
+                    (void)poll_input_and_submit(&next);
+                    if (!next) break;
+                    ahead_.push_back(std::move(*next));
                 }
+            } catch (...) {
+                mdb_grid_cancel(ticket->raw);
+                throw;
             }
             wait_and_append_to_leftovers_in_current_batch(std::move(*ticket));
         } else if (state == PollState::ReadyNone && current_batch_offset_ < current_batch_.num_rows) {

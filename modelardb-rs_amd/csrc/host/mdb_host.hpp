@@ -284,6 +284,7 @@ class GridStream : public SegmentStream { // grid_exec.rs:213-437
     // to the host overlaps the upload and the kernels of the next (the reference grids a batch when it is polled
     // for, grid_exec.rs:402-412; the stream returns the same rows in the same order). This is, call for call,
     // what rust/patches/0001-grid_exec.patch does with rust/modelardb_hip's GridTicket.
+    static constexpr size_t GRID_STREAM_SUBMITS_AHEAD = 1;
     struct Ticket {
         std::vector<std::shared_ptr<RecordBatch>> batches;
         mdb_grid_ticket *raw = nullptr;
@@ -293,9 +294,9 @@ class GridStream : public SegmentStream { // grid_exec.rs:213-437
     PollState poll_input_and_submit(std::optional<Ticket> *out);
     void wait_and_append_to_leftovers_in_current_batch(Ticket ticket); // :261-391
     mdb_ctx *ctx_;
-    std::optional<Ticket> ahead_;
+    std::deque<Ticket> ahead_;     // submitted and not yet waited for, oldest first
     bool input_finished_ = false;
-    bool prefetch_ = true;
+    size_t prefetch_depth_ = GRID_STREAM_SUBMITS_AHEAD; // (MDB_HOST_GRID_PREFETCH: 0 = submit when polled, n = that many ahead)
     // Segments per submit: the input hands over 8 192-row batches whatever they decompress to; the stream asks
     // for about 16 M data points per launch and learns the points per segment from the results it has seen.
     uint64_t seen_segments_ = 0, seen_points_ = 0;

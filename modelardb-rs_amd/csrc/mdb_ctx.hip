@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <set>
+#include <string>
 
 #include "mdb_common.hpp"
 
@@ -229,9 +231,26 @@ GridPipeline *ctx_pipeline(mdb_ctx *ctx) {
 }
 
 GridPipeline *ctx_pipeline_install(mdb_ctx *ctx, GridPipeline *fresh) {
-    std::lock_guard<std::mutex> lock(ctx->pipeline_mutex);
-    if (!ctx->pipeline) ctx->pipeline = fresh;
-    return ctx->pipeline;
+    GridPipeline *installed = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->pipeline_mutex);
+        if (!ctx->pipeline) ctx->pipeline = fresh;
+        installed = ctx->pipeline;
+    }
+    if (installed == fresh) { // (no job has been handed to it yet) its clones are profiled if the context is
+        bool profiling = false;
+        {
+            CallGuard lock(ctx);
+            profiling = ctx->profiling;
+        }
+        mdb_ctx *clones[8];
+        const int n = pipeline_clones(ctx, clones, 8);
+        for (int k = 0; k < n; k++) {
+            CallGuard lock(clones[k]);
+            clones[k]->profiling = profiling;
+        }
+    }
+    return installed;
 }
 
 GridPipeline *ctx_pipeline_detach(mdb_ctx *ctx) {
@@ -761,6 +780,23 @@ int mdb::upload_segment_list_locked(mdb_ctx *ctx, const mdb_segments *const *hos
     return 0;
 }
 
+// The profile of a context covers the clones its grid pipeline runs jobs on (mdb_grid_submit): they are switched
+// and cleared with it and their launches are counted as its own. (Lock order: the context, then one clone at a
+// time; a pipeline worker holds the lock of its own context only.)
+namespace {
+template <typename F> int with_context_and_pipeline_clones(mdb_ctx *ctx, F per_context) {
+    mdb_ctx *all[1 + 8] = {ctx};
+    const int n = 1 + (ctx->is_clone ? 0 : mdb::pipeline_clones(ctx, all + 1, 8));
+    for (int k = 0; k < n; k++) {
+        mdb::CallGuard lock(all[k]);
+        if (k > 0) MDB_HIP_CHECK(hipSetDevice(all[k]->device));
+        if (profile_collect(all[k])) return 1;
+        per_context(all[k]);
+    }
+    return 0;
+}
+} // namespace
+
 extern "C" {
 
 int mdb_segments_download(mdb_ctx *ctx, const mdb_segments_owned *dev, mdb_segments_owned **out) {
@@ -971,38 +1007,41 @@ int mdb_are_compressed_timestamps_regular(const uint8_t *compressed_timestamps, 
 
 int mdb_profile_enable(mdb_ctx *ctx, int enabled) {
     if (!ctx) return fail("ctx must not be NULL.");
-    mdb::CallGuard lock(ctx);
-    if (profile_collect(ctx)) return 1;
-    ctx->profiling = enabled != 0;
-    return 0;
+    return with_context_and_pipeline_clones(ctx, [&](mdb_ctx *c) { c->profiling = enabled != 0; });
 }
 
 int mdb_profile_reset(mdb_ctx *ctx) {
     if (!ctx) return fail("ctx must not be NULL.");
-    mdb::CallGuard lock(ctx);
-    if (profile_collect(ctx)) return 1;
-    ctx->kernel_times.clear();
-    return 0;
+    return with_context_and_pipeline_clones(ctx, [&](mdb_ctx *c) { c->kernel_times.clear(); });
 }
 
 int mdb_profile_get(mdb_ctx *ctx, const char *name, uint64_t *launches, double *total_ms) {
     if (!ctx || !name) return fail("ctx and name must not be NULL.");
-    mdb::CallGuard lock(ctx);
-    if (profile_collect(ctx)) return 1;
-    auto it = ctx->kernel_times.find(name);
-    if (launches) *launches = it == ctx->kernel_times.end() ? 0 : it->second.launches;
-    if (total_ms) *total_ms = it == ctx->kernel_times.end() ? 0.0 : it->second.total_ms;
+    uint64_t n = 0;
+    double ms = 0.0;
+    if (with_context_and_pipeline_clones(ctx, [&](mdb_ctx *c) {
+            auto it = c->kernel_times.find(name);
+            if (it == c->kernel_times.end()) return;
+            n += it->second.launches;
+            ms += it->second.total_ms;
+        }))
+        return 1;
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
     return 0;
 }
 
 int mdb_profile_names(mdb_ctx *ctx, char *out, uint64_t cap) {
     if (!ctx || !out || cap == 0) return fail("ctx and out must not be NULL.");
-    mdb::CallGuard lock(ctx);
-    if (profile_collect(ctx)) return 1;
+    std::set<std::string> names;
+    if (with_context_and_pipeline_clones(ctx, [&](mdb_ctx *c) {
+            for (auto &kv : c->kernel_times) names.insert(kv.first);
+        }))
+        return 1;
     std::string joined;
-    for (auto &kv : ctx->kernel_times) {
+    for (const std::string &name : names) {
         if (!joined.empty()) joined += "\n";
-        joined += kv.first;
+        joined += name;
     }
     std::strncpy(out, joined.c_str(), cap - 1);
     out[cap - 1] = 0;

@@ -4657,11 +4657,18 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
     std::vector<unsigned long long> index_piece_base;
     std::vector<MvCursor> index_cursors;
     const MvHostRange host_range{range.lo, range.hi}; // (under a time range: only the segments that reach into it)
+    // (the call's host-side phases next to the kernels' times when the context is profiled: mdb_profile_get, "host:" names)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since_begin = [&t_begin]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     mv_host_index(ins, n_ins, &index_piece_base, &index_cursors, range.enabled ? &host_range : nullptr);
+    const double t_indexed = since_begin();
     mdb::CallGuard lock(ctx);
+    const double t_locked = since_begin();
     MDB_HIP_CHECK(hipSetDevice(ctx->device));
     mdb_segments_owned *dev = nullptr;
     if (upload_segment_list_locked(ctx, ins, n_ins, true, &dev)) return 1;
+    const double t_uploaded = since_begin();
+    double t_planned = t_uploaded, t_launched = t_uploaded, t_down = t_uploaded;
     const uint64_t n_segments = dev->seg.n;
     int rc = 0;
     OwnedGridResult *result = nullptr;
@@ -4669,6 +4676,7 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
         GridPlan plan;
         rc = grid_plan(ctx, &dev->seg, range, &plan);
         if (!rc) rc = mv_host_index_attach(ctx, dev->seg, index_piece_base, index_cursors, &plan.mv_index);
+        t_planned = since_begin();
         const uint64_t total = plan.host_header.total_points;
         // The device staging area mirrors the host block (same gaps), so one copy moves it all.
         const uint64_t front = align_up(reserve_front, 4); // keeps the 16-byte store alignment
@@ -4683,6 +4691,7 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
                              values_only ? nullptr : reinterpret_cast<int64_t *>(base) + front,
                              reinterpret_cast<float *>(base + ts_bytes) + front,
                              reinterpret_cast<uint32_t *>(base + ts_bytes + val_bytes));
+        t_launched = since_begin();
         void *block = nullptr;
         uint64_t capacity = 0;
         if (!rc) rc = ctx->pinned_pool->take(ts_bytes + val_bytes + rows_bytes, &block, &capacity);
@@ -4693,6 +4702,7 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
                                ctx->stream) != hipSuccess)
                 rc = fail("hipMemcpy device to host failed.");
             if (!rc) rc = grid_late_error(ctx, plan);
+            t_down = since_begin();
             if (rc) {
                 ctx->pinned_pool->give(block, capacity);
             } else {
@@ -4714,6 +4724,21 @@ int mdb::grid_batch_owned_list(mdb_ctx *ctx, const mdb_segments *const *ins, uin
         }
     }
     mdb_segments_free(dev);
+    if (ctx->profiling) {
+        const std::pair<const char *, double> phases[] = {
+            {"host:grid_cursors_by_host_threads", t_indexed},          // the walk of the call's long MacaqueV streams
+            {"host:grid_wait_for_the_context", t_locked - t_indexed},  // (the other worker of a pipelined stream has it)
+            {"host:grid_upload_segments", t_uploaded - t_locked},      // staging copy by host threads + the copy to the device
+            {"host:grid_plan", t_planned - t_uploaded},                // prepass, scans, the header's read-back
+            {"host:grid_launches", t_launched - t_planned},            // (asynchronous: the kernels run into the next phase)
+            {"host:grid_kernels_and_copy_down", t_down - t_launched},  // ... which ends when the points are in the page-locked block
+            {"host:grid_free_segments", since_begin() - t_down}};
+        for (const auto &phase : phases) {
+            auto &entry = ctx->kernel_times[phase.first];
+            entry.launches += 1;
+            entry.total_ms += phase.second;
+        }
+    }
     if (rc) return 1;
     *out = &result->c;
     return 0;

@@ -42,6 +42,9 @@ struct GridPipeline; // the workers behind mdb_grid_submit (mdb_pipeline.cpp)
 GridPipeline *ctx_pipeline(mdb_ctx *ctx);
 GridPipeline *ctx_pipeline_install(mdb_ctx *ctx, GridPipeline *fresh);
 GridPipeline *ctx_pipeline_detach(mdb_ctx *ctx);
+// The clones the context's pipeline runs jobs on beside the context itself (mdb_profile_*: their launches count as
+// the context's); they live until the context is closed.
+int pipeline_clones(mdb_ctx *ctx, mdb_ctx **out, int capacity);
 
 // Owner bookkeeping behind mdb_grid_result::priv_.
 struct OwnedGridResult {

@@ -347,14 +347,21 @@ struct mdb_grid_ticket {
 
 namespace mdb {
 
+// The context the first submit came in on, its clones (a stream and buffers each), a worker per context. A job goes
+// to the idle worker of the lowest number (a lone job runs on the caller's own context) or, when all are busy, into
+// ONE queue that whichever worker is free next takes from; results are waited for per ticket, in any order.
+constexpr int PIPELINE_MAX_CONTEXTS = 4;
+constexpr int PIPELINE_DEFAULT_CONTEXTS = 2;
+
 struct GridPipeline {
-    mdb_ctx *contexts[2] = {nullptr, nullptr};
-    std::thread workers[2];
+    mdb_ctx *contexts[PIPELINE_MAX_CONTEXTS] = {};
+    std::thread workers[PIPELINE_MAX_CONTEXTS];
     std::mutex mutex;
     std::condition_variable wake;
-    std::deque<mdb_grid_ticket *> queues[2];
+    std::deque<mdb_grid_ticket *> queue;
+    mdb_grid_ticket *handed[PIPELINE_MAX_CONTEXTS] = {};
+    bool idle[PIPELINE_MAX_CONTEXTS] = {};
     bool stop = false;
-    uint64_t submitted = 0;
 };
 
 namespace {
@@ -409,16 +416,33 @@ void pipeline_worker(GridPipeline *pipeline, int which) {
         mdb_grid_ticket *ticket = nullptr;
         {
             std::unique_lock<std::mutex> lock(pipeline->mutex);
-            pipeline->wake.wait(lock, [&] { return pipeline->stop || !pipeline->queues[which].empty(); });
-            if (pipeline->queues[which].empty()) return; // (stop, and nothing left to do)
-            ticket = pipeline->queues[which].front();
-            pipeline->queues[which].pop_front();
+            pipeline->idle[which] = true;
+            pipeline->wake.wait(lock, [&] { return pipeline->stop || pipeline->handed[which] || !pipeline->queue.empty(); });
+            pipeline->idle[which] = false;
+            if (pipeline->handed[which]) {
+                ticket = pipeline->handed[which];
+                pipeline->handed[which] = nullptr;
+            } else if (!pipeline->queue.empty()) {
+                ticket = pipeline->queue.front();
+                pipeline->queue.pop_front();
+            } else {
+                return; // (stop, and nothing left to do)
+            }
         }
         run_ticket(pipeline->contexts[which], ticket);
     }
 }
 
 } // namespace
+
+int pipeline_clones(mdb_ctx *ctx, mdb_ctx **out, int capacity) {
+    GridPipeline *pipeline = ctx_pipeline(ctx);
+    int n = 0;
+    if (pipeline)
+        for (int w = 1; w < PIPELINE_MAX_CONTEXTS && n < capacity; w++)
+            if (pipeline->contexts[w]) out[n++] = pipeline->contexts[w];
+    return n;
+}
 
 void pipeline_close(mdb_ctx *ctx) {
     GridPipeline *pipeline = ctx_pipeline_detach(ctx);
@@ -430,7 +454,8 @@ void pipeline_close(mdb_ctx *ctx) {
     pipeline->wake.notify_all();
     for (std::thread &worker : pipeline->workers)
         if (worker.joinable()) worker.join(); // (they finish what is queued: tickets stay valid for their owners)
-    if (pipeline->contexts[1]) (void)mdb_close(pipeline->contexts[1]);
+    for (int w = 1; w < PIPELINE_MAX_CONTEXTS; w++)
+        if (pipeline->contexts[w]) (void)mdb_close(pipeline->contexts[w]);
     delete pipeline;
 }
 
@@ -521,16 +546,23 @@ int mdb_grid_submit(mdb_ctx *ctx, const mdb_grid_input *inputs, uint32_t n_input
             ticket->tag_shifts.push_back(inputs[k].tag_buffer_shift ? inputs[k].tag_buffer_shift[t] : 0);
         }
     }
-    int which = 0;
     GridPipeline *pipeline = ctx_pipeline(ctx);
-    if (!pipeline) { // the first submit on this context: a second context and the two workers
+    if (!pipeline) { // the first submit on this context: its clones and a worker for each
         std::unique_ptr<GridPipeline> fresh(new GridPipeline());
         fresh->contexts[0] = ctx;
-        // MDB_GRID_PIPELINE_CONTEXTS=1: every job on the context itself (A/B: what the second context buys)
+        // MDB_GRID_PIPELINE_CONTEXTS=n, 1..4: 1 = every job on the context itself (A/B: what the clones buy)
         const char *setting = option_text("MDB_GRID_PIPELINE_CONTEXTS");
-        if (!(setting && std::strcmp(setting, "1") == 0) && mdb_clone(ctx, &fresh->contexts[1])) return 1;
-        for (int w = 0; w < 2; w++)
-            if (fresh->contexts[w]) fresh->workers[w] = std::thread(pipeline_worker, fresh.get(), w);
+        const int n_contexts = setting ? std::min(std::max(std::atoi(setting), 1), PIPELINE_MAX_CONTEXTS) : PIPELINE_DEFAULT_CONTEXTS;
+        auto close_clones = [&fresh]() {
+            for (int w = 1; w < PIPELINE_MAX_CONTEXTS; w++)
+                if (fresh->contexts[w]) (void)mdb_close(fresh->contexts[w]);
+        };
+        for (int w = 1; w < n_contexts; w++)
+            if (mdb_clone(ctx, &fresh->contexts[w])) {
+                close_clones();
+                return 1;
+            }
+        for (int w = 0; w < n_contexts; w++) fresh->workers[w] = std::thread(pipeline_worker, fresh.get(), w);
         pipeline = ctx_pipeline_install(ctx, fresh.get());
         if (pipeline == fresh.get()) {
             (void)fresh.release();
@@ -542,14 +574,16 @@ int mdb_grid_submit(mdb_ctx *ctx, const mdb_grid_input *inputs, uint32_t n_input
             fresh->wake.notify_all();
             for (std::thread &worker : fresh->workers)
                 if (worker.joinable()) worker.join();
-            if (fresh->contexts[1]) (void)mdb_close(fresh->contexts[1]);
+            close_clones();
         }
     }
     {
         std::lock_guard<std::mutex> lock(pipeline->mutex);
-        which = pipeline->contexts[1] ? (int)(pipeline->submitted & 1u) : 0;
-        pipeline->submitted += 1;
-        pipeline->queues[which].push_back(ticket.get());
+        int taker = -1;
+        for (int w = 0; w < PIPELINE_MAX_CONTEXTS && taker < 0; w++)
+            if (pipeline->contexts[w] && pipeline->idle[w] && !pipeline->handed[w] && pipeline->queue.empty()) taker = w;
+        if (taker >= 0) pipeline->handed[taker] = ticket.get();
+        else pipeline->queue.push_back(ticket.get());
     }
     pipeline->wake.notify_all();
     *out = ticket.release();

@@ -29,4 +29,4 @@ for label, eb in (("lossless", mdb.error_bound("lossless")), ("relative 1 %", md
         if best is None or seconds < best[0]: best = (seconds, entries, rows, nbytes)
     seconds, entries, rows, nbytes = best
     print(label, f"{len(batch)} segments, {rows} points: {seconds * 1e3:.1f} ms = {rows / seconds:.3g} values/s, {nbytes / seconds / 1e9:.1f} GB/s down", flush=True)
-    print("   ", ", ".join(f"{name} {calls}x {ms:.1f} ms" for name, (calls, ms) in entries[:14]), flush=True)
+    print("   ", ", ".join(f"{name} {calls}x {ms:.1f} ms" for name, (calls, ms) in entries[:26]), flush=True)

@@ -88,6 +88,51 @@ def test_grid_stream_reconstructs_two_series_with_tags(hip, batch_size):
     assert metrics["elapsed_compute_ns"] > 0
 
 
+@pytest.mark.skipif(UNDER_STUB, reason="the stand-in's canned answers are for the default call sequence")
+@pytest.mark.parametrize("contexts, ahead", [("1", "2"), ("3", "2"), ("4", "3"), ("2", "8")])
+def test_more_submits_ahead_on_more_contexts_return_the_same_rows(contexts, ahead, monkeypatch):
+    """MDB_GRID_PIPELINE_CONTEXTS (1..4: the contexts mdb_grid_submit's workers run jobs on) and MDB_HOST_GRID_PREFETCH
+    (the submits GridStream keeps ahead of the one it waits for): whatever they are set to the stream returns the
+    same rows in the same order, and the launches of every worker's context are in the profile of the context the
+    submits were made on - one `host:` entry per submit and phase."""
+    import modelardb_rs_amd as mdb
+    monkeypatch.setenv("MDB_GRID_PIPELINE_CONTEXTS", contexts)
+    monkeypatch.setenv("MDB_HOST_GRID_PREFETCH", ahead)
+    monkeypatch.setenv("MDB_HOST_GRID_COALESCE_SEGMENTS", "2")
+    context = mdb.Context(0)  # (a context of its own: the workers are made by its first submit)
+    try:
+        context.profile_enable(True)
+        stream = host.GridStream(context, tag_names=("sensor",), batch_size=1000)
+        expected_ts, expected_values, expected_tags, submits = [], [], [], 0
+        for seed in range(3):
+            _, _, batch = _series(900 + seed, length=20_000, irregular=seed == 1)
+            for part in _segment_batches(batch, {"sensor": f"sensor-number-{seed}-of-three"}, 2):
+                stream.push(part)
+                submits += 1
+            ts, values, _, _ = ora.grid_batch(batch)
+            expected_ts.append(ts)
+            expected_values.append(values)
+            expected_tags += [f"sensor-number-{seed}-of-three"] * len(ts)
+        stream.finish_input()
+        batches, state = stream.collect()
+        assert state == host.GridStream.READY_NONE
+        ts, values, table = _concat(batches)
+        assert np.array_equal(ts, np.concatenate(expected_ts))
+        assert np.array_equal(values.view(np.uint32), np.concatenate(expected_values).view(np.uint32))
+        assert table.column("sensor").to_pylist() == expected_tags
+        stream.close()
+        profile = context.profile()
+        assert submits > 8
+        made = profile["host:grid_launches"][0]  # (a batch of one row is gathered with the one behind it)
+        assert submits // 2 <= made <= submits, profile
+        assert profile["host:grid_kernels_and_copy_down"][0] == made, profile
+        assert max(calls for name, (calls, _) in profile.items() if name.startswith("k_grid")) >= made, profile
+        context.profile_reset()
+        assert context.profile() == {}
+    finally:
+        context.close()
+
+
 @pytest.mark.parametrize("coalesce", ["learned", "3", "1000000"])
 def test_grid_stream_gathers_input_batches_and_keeps_one_submit_ahead(hip, coalesce, monkeypatch, grid_prefetch):
     """What the patched GridStream::poll_next (rust/patches/0001-grid_exec.patch) does, call for call: input
