@@ -229,6 +229,13 @@ struct MvIndex {
     std::shared_ptr<void> range_acc[2]; // TsWalkRange[n] (freed by its deleter)
     uint64_t range_acc_key[2] = {0, 0};
     bool range_acc_failed[2] = {false, false}; // no memory for it / a fault in the streams: not tried again
+    // And for the sums of the MacaqueV streams (mv_index_stream_sums): where every wave of pieces lists the streams of
+    // two pieces or more that begin in it (an exclusive scan over the waves, the long and the short kind packed into
+    // one word, the totals behind the last wave) - a function of the cursors alone, counted by the first call that
+    // asks and kept (8 B per 64 pieces).
+    bool chains_built = false;
+    void *chain_offsets = nullptr;          // unsigned long long[waves of pieces + 1]
+    unsigned long long chains_listed = 0;   // the totals: long << 32 | short
     // The index of ONE call over host batches (mv_host_index, mdb_grid.hip): made by host threads while the batches
     // are on their way, for the long streams only - a segment without pieces is the serial kernel's - and living in
     // the context's scratch.
@@ -236,10 +243,10 @@ struct MvIndex {
     ~MvIndex() {
         if (of_one_call) return;
         if (cursors || piece_base || ts_piece_base || ts_slots || ts_totals || agg_walk_totals || agg_walk_sums || range_whole ||
-            range_whole_totals) {
+            range_whole_totals || chain_offsets) {
             (void)hipSetDevice(device);
             for (void *allocation : {cursors, piece_base, ts_piece_base, ts_slots, ts_totals, agg_walk_totals, agg_walk_sums,
-                                     range_whole, range_whole_totals})
+                                     range_whole, range_whole_totals, chain_offsets})
                 if (allocation) (void)hipFree(allocation);
         }
     }

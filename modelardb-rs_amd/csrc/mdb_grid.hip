@@ -3378,17 +3378,54 @@ int mv_index_stream_sums(mdb_ctx *ctx, const mdb_segments *in, const DevSegments
     ChainItem *short_items = reinterpret_cast<ChainItem *>(at + counts_bytes + offsets_bytes + block_sums_bytes);
     ChainItem *long_items = short_items + most_items;
     const MvCursor *cursors = static_cast<const MvCursor *>(index->cursors);
-    {
-        // Where every wave of pieces lists the streams of two pieces or more that begin in it.
-        LaunchTimer timer(ctx, "k_agg_mv_chain_count");
-        hipLaunchKernelGGL(k_agg_mv_chain_count, dim3((uint32_t)piece_waves), dim3(MDB_WAVE), 0, ctx->stream, cursors, index->n_pieces, counts);
-    }
-    if (device_exclusive_scan(ctx, ChainCount{counts}, piece_waves, offsets, block_sums, "k_agg_mv_chain_scan")) return 1;
-    // (how many are listed sizes the launches behind the piece kernel: a wave that finds nothing to do still costs a
-    // third of a microsecond, and the most there can be is 5.4 M groups for the mixed series' 10.8 M pieces)
+    // Where every wave of pieces lists the streams of two pieces or more that begin in it: a function of the cursors
+    // alone, so the index of a resident batch keeps it from the first call that asks (MDB_AGG_KEEP_CHAIN_OFFSETS=0:
+    // counted by every call, as the index of one call over host batches is).
     unsigned long long listed = 0;
-    MDB_HIP_CHECK(mail_read(ctx, &listed, offsets + piece_waves, 8));
-    MDB_HIP_CHECK(mail_sync(ctx));
+    bool counted_before = false;
+    const char *keep_setting = option_text("MDB_AGG_KEEP_CHAIN_OFFSETS");
+    const bool keep = !index->of_one_call && !(keep_setting && std::strcmp(keep_setting, "0") == 0);
+    if (keep) {
+        std::lock_guard<std::mutex> lock(index->mutex);
+        if (index->chains_built) {
+            offsets = static_cast<unsigned long long *>(index->chain_offsets);
+            listed = index->chains_listed;
+            counted_before = true;
+        }
+    }
+    if (!counted_before) {
+        void *kept = nullptr;
+        if (keep && hipMalloc(&kept, (piece_waves + 1) * 8) != hipSuccess) { // (no memory to keep it in: counted every time)
+            (void)hipGetLastError();
+            kept = nullptr;
+        }
+        if (kept) offsets = static_cast<unsigned long long *>(kept);
+        {
+            LaunchTimer timer(ctx, "k_agg_mv_chain_count");
+            hipLaunchKernelGGL(k_agg_mv_chain_count, dim3((uint32_t)piece_waves), dim3(MDB_WAVE), 0, ctx->stream, cursors, index->n_pieces, counts);
+        }
+        int failed = device_exclusive_scan(ctx, ChainCount{counts}, piece_waves, offsets, block_sums, "k_agg_mv_chain_scan");
+        // (how many are listed sizes the launches behind the piece kernel: a wave that finds nothing to do still costs a
+        // third of a microsecond, and the most there can be is 5.4 M groups for the mixed series' 10.8 M pieces)
+        if (!failed && (mail_read(ctx, &listed, offsets + piece_waves, 8) != hipSuccess || mail_sync(ctx) != hipSuccess))
+            failed = fail("Could not read how many MacaqueV streams the pieces list.");
+        if (failed) {
+            if (kept) (void)hipFree(kept);
+            return 1;
+        }
+        if (kept) { // (complete: the stream has been waited for) - unless another context's call has left its own meanwhile
+            std::lock_guard<std::mutex> lock(index->mutex);
+            if (!index->chains_built) {
+                index->chain_offsets = kept;
+                index->chains_listed = listed;
+                index->chains_built = true;
+                kept = nullptr;
+            } else {
+                offsets = static_cast<unsigned long long *>(index->chain_offsets);
+            }
+        }
+        if (kept) MDB_HIP_CHECK(hipFree(kept));
+    }
     const uint64_t n_short = listed & 0xffffffffull, n_long = listed >> 32;
     if (n_short > most_items || n_long > most_items) return fail("Internal error: more MacaqueV streams listed than there are pieces for.");
     {

@@ -4,6 +4,8 @@ Bar (from the reference's own tests, crates/modelardb_server/tests/integration_t
 COUNT / MIN / MAX exact; SUM / AVG within 0.001 % relative (the GPU reduces in a fixed tree, the
 reference accumulates sequentially in f64)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -585,6 +587,22 @@ def test_macaque_streams_that_reach_beyond_a_wave_are_added_up_in_stream_order(h
         total += float(np.cumsum(values[first:last + 1], dtype=np.float32)[-1])
     others = hip.agg_batch(segments.take(np.nonzero(segments.model_type_id != 2)[0]), ALL)
     assert abs(state.sum - (total + others.sum)) <= 1e-12 * abs(state.sum)
+    # Where the waves of pieces list their streams is a function of the cursors: counted by the first call, kept with
+    # the batch's index for the later ones (MDB_AGG_KEEP_CHAIN_OFFSETS=0: counted by every call) - the same sums either way.
+    assert "k_agg_mv_chain_count" in kernels
+    hip.profile_enable(True)
+    hip.profile_reset()
     again = hip.agg_batch_dev(resident, ALL)
+    later = hip.profile()
+    assert "k_agg_mv_chain_count" not in later and "k_agg_mv_chains" in later and "k_agg_mv_pieces" in later
     assert np.float64(again.sum).tobytes() == np.float64(state.sum).tobytes() and again.count == state.count
+    os.environ["MDB_AGG_KEEP_CHAIN_OFFSETS"] = "0"
+    try:
+        hip.profile_reset()
+        counted = hip.agg_batch_dev(resident, ALL)
+        assert "k_agg_mv_chain_count" in hip.profile()
+    finally:
+        del os.environ["MDB_AGG_KEEP_CHAIN_OFFSETS"]
+        hip.profile_enable(False)
+    assert np.float64(counted.sum).tobytes() == np.float64(state.sum).tobytes() and counted.count == state.count
     resident.free()
