@@ -73,6 +73,7 @@ enum ScratchSlot {
     SCRATCH_FIT_IN_VALUES,
     SCRATCH_FIT_IN_OFFSETS,
     SCRATCH_FIT_WAVE,
+    SCRATCH_FIT_REJECTS,
     SCRATCH_MV_HOST_INDEX,
     SCRATCH_FIT_SMALL,
     SCRATCH_AGG_CHAIN_LIST,

@@ -858,9 +858,19 @@ struct SplitArgs {
     // Per chunk, or nullptr: 0 = this chunk has its models already (k_fit_models_wave), it gets no pieces and
     // is not walked.
     const unsigned int *chunk_left;
+    // Or nullptr: a bit per point, set where k_fit_reject_flags has found that NO model can begin (see there), laid
+    // out by piece - piece u of the call owns words [u * reject_words_per_piece, ...), bit k of word w is point
+    // 64 w + k of the piece - so that the words of a chunk follow each other.
+    const unsigned long long *reject_words;
+    uint32_t reject_words_per_piece;
 };
 
 constexpr uint32_t ENTRY_REJECTED = 1u;
+// (no model accepted from here either, but said by k_fit_reject_flags before any lane came by: NOT a lane's track. A
+// model's entry is its end + 2 and a model has eight points or more, so 2 is nobody's end.)
+constexpr uint32_t ENTRY_FLAGGED = 2u;
+__device__ __forceinline__ bool entry_is_a_track(uint32_t entry) { return entry == ENTRY_REJECTED || entry > ENTRY_FLAGGED; }
+__device__ __forceinline__ uint32_t entry_for_the_walk(uint32_t entry) { return entry == ENTRY_FLAGGED ? ENTRY_REJECTED : entry; }
 constexpr uint32_t ENTRY_END_BIAS = 2u;
 
 struct PieceCount {
@@ -1500,6 +1510,15 @@ __device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs 
     LaneMask active_m = lanes_where(active);
     LaneMask pmc_fits_m = ~0ull, swing_fits_m = ~0ull, swing_finite_m = 0;
     const LaneMask pmc_fast_m = pmc_fast.enabled ? ~0ull : 0ull;
+    // (split mode under a lossy bound) k_fit_reject_flags' bits of 128 points from point `flags_first` of the chunk on -
+    // the two words that every top-up of the ring fetches with the values - and the words of this lane's chunk.
+    constexpr bool FLAGGED = SPLIT && KIND != MDB_EB_LOSSLESS && !HAS_TS;
+    const bool flagged = FLAGGED && split.reject_words != nullptr;
+    unsigned long long flags_near = 0, flags_far = 0;
+    uint32_t flags_first = 0;
+    const unsigned long long *__restrict__ chunk_flag_words =
+        flagged ? split.reject_words + (active ? split.piece_base[chunk] * split.reject_words_per_piece : 0ull) : nullptr;
+    const uint32_t last_flag_word = n > 0 ? (n - 1u) >> 6 : 0u;
     uint32_t steps_left = ROTATE ? rotation.stretch_steps : 0u;
     if (ROTATE) {
         // The group goes on where it was left (the first time: where k_fit_rotation_begin says; the ring starts at the lane's next point).
@@ -1600,6 +1619,31 @@ __device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs 
             }
             if (active_m == 0) break;
         }
+        if (FLAGGED && flagged) {
+            // Start points at which no model can begin (k_fit_reject_flags: both fitters certainly end before their eighth
+            // point; their entries say so already) are passed over without a point being fed: a whole run of them at once,
+            // as far as the lane's two words of bits reach - which is further than its ring of values does, so a lane in
+            // a long run of them asks for memory once per hundred points, not once per ring.
+            for (int more = 0; more < 2; more++) { // (a run of more than 64: the second word's worth)
+                const uint32_t offset = current - flags_first; // (unsigned: a start point in front of the words is out of them too)
+                const unsigned long long window = offset < 64u ? (flags_near >> offset) | (offset ? flags_far << (64u - offset) : 0ull)
+                                                               : flags_far >> (offset & 63u);
+                const LaneMask candidate_m = active_m & lanes_where(j == current) & lanes_where(offset < 128u) & lanes_where((window & 1ull) != 0ull);
+                if (candidate_m == 0) break;
+                bool met = false;
+                if (in_lanes(candidate_m)) {
+                    const uint32_t ones = ~window ? (uint32_t)__builtin_ctzll(~window) : 64u;
+                    current += min(ones, 128u - offset); // (a set bit says that seven more points of the chunk follow: current < n)
+                    j = current;
+                    // (past the end of its piece a lane looks for another lane's tracks)
+                    if (current >= piece_end &&
+                        entry_is_a_track(__hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                        met = true;
+                }
+                active_m &= ~lanes_where(met);
+            }
+            if (active_m == 0) break;
+        }
         const LaneMask feeding_m = active_m & lanes_where(j < n) & (pmc_fits_m | swing_fits_m);
         const uint32_t position = j + misalign; // of point j, counted from the 16-byte boundary
         const uint32_t group = position >> 2;
@@ -1633,6 +1677,13 @@ __device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs 
                     }
                 }
             }
+            unsigned long long flags_low = 0, flags_high = 0;
+            // (the words from the one with the point the lane feeds next)
+            const uint32_t flags_word = min(j >> 6, last_flag_word);
+            if (FLAGGED && flagged) { // (with the values' loads: one wait for all)
+                flags_low = chunk_flag_words[flags_word];
+                flags_high = chunk_flag_words[min(flags_word + 1u, last_flag_word)];
+            }
 #pragma unroll
             for (int k = 0; k < LEAN_LOADS; k++) {
                 const uint32_t g = first_group + (uint32_t)k;
@@ -1642,6 +1693,11 @@ __device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs 
                     ring_ts[row][lane] = make_longlong2(fetched_ts[k][0], fetched_ts[k][1]);
                     ring_ts[row + 1][lane] = make_longlong2(fetched_ts[k][2], fetched_ts[k][3]);
                 }
+            }
+            if (FLAGGED && flagged && lane_active) {
+                flags_near = flags_low;
+                flags_far = flags_word < last_flag_word ? flags_high : 0ull; // (the chunk's last word has no successor)
+                flags_first = flags_word << 6;
             }
             loaded_group = max(first_group, end_group);
             if (loaded_group > low_group + LEAN_GROUPS) low_group = loaded_group - LEAN_GROUPS;
@@ -1866,8 +1922,8 @@ __device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs 
                     if (!SPLIT) plans[chunk] = {n_models, gaps.finish(n)};
                     ends = true;
                 } else if (SPLIT && current >= piece_end &&
-                           __hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                           entry_is_a_track(__hip_atomic_load(&split.entry[base + current], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT))) {
                     ends = true; // some lane has been here: the chain from this point on is recorded
                 } else {
                     pmc_min = nan32;
@@ -1946,6 +2002,133 @@ __device__ __forceinline__ void lean_group(const FitArgs &args, const SplitArgs 
         }
     }
 #endif
+}
+
+// ---- k_fit_reject_flags (split mode under a lossy bound) ------------------------------------------------------
+//
+// On data that no model fits (the Random runs of the reference's acceptance recipe, compression.rs:733-863, under a
+// bound of 1 %) the greedy loop spends its time on start points it rejects: both fitters are fed until PMC-Mean has
+// failed (by the second or third point) and Swing has (by the third or fourth), the builder finds that neither model
+// pays for its 29 bytes (fewer than eight points: types.rs:84-101, compression.rs:238), the point becomes a residual
+// and the same happens one point later - four to five steps of 107 cycles per point, and a lane of such a piece keeps
+// its wave for four times as long as a lane whose piece is all models. Whether a start point is rejected is a function
+// of the eight values from it on, so it is asked of all points at once here, one lane per point, conservatively:
+//   * PMC-Mean certainly ends before its eighth point if for some m <= 8 the first m values' maximum and minimum are
+//     further apart than any average can be from both (relative: |r - a| <= |r| e for r = min and r = max needs
+//     max - min <= (|min| + |max|) e; absolute: max - min <= 2 e; pmc_mean.rs:58-76 with models/mod.rs's test, whose f32
+//     roundings - three of 2^-24 - are covered by the factor 1 + 2^-16);
+//   * Swing certainly ends before its eighth point if some point j in 2..7 lies outside the cone its first two points
+//     open - the lines from (t0, v0) through (t1, v1 +- deviation(v1)), swing.rs:130-140 - by more than its own deviation:
+//     every later pair of bounds goes through (t0, v0) with slopes between those two (a bound only moves inwards,
+//     swing.rs:141-198). The fitter evaluates its lines as slope * t + intercept in f64, so what it sees differs from
+//     the exact cone by rounding: the margin 2^-46 (|slope| (|t0| + |tj|) + |v0| + |v1| + |vj| + the cone's half width)
+//     is 128 ulps of the largest term any of those evaluations has.
+// Only where both are certain, all eight values are finite and all eight lie in the chunk is the point's bit set: the
+// fitter (lean_group) takes a set bit as "rejected" without feeding a point, an unset one says nothing. Regular
+// timestamps only (the lean fitter's values-only form).
+constexpr uint32_t FLAG_PIECES = 8; // pieces per workgroup of k_fit_reject_flags
+template <int KIND>
+__global__ __launch_bounds__(256) void k_fit_reject_flags(FitArgs args, SplitArgs split, unsigned long long *__restrict__ words,
+                                                          unsigned long long *__restrict__ bits_set) {
+    // (a workgroup takes FLAG_PIECES pieces one after the other: finding the first one's chunk is a few trips to memory
+    // one after the other, which a piece of 512 points is too little work to hide)
+    const uint64_t first_unit = (uint64_t)blockIdx.x * FLAG_PIECES;
+    if (first_unit >= split.n_pieces) return;
+    const uint64_t unit0 = first_unit;
+    // The piece's chunk: the last c with piece_base[c] <= unit (the same for the whole workgroup: scalar loads). Chunks
+    // of one length have as many pieces each, so the search starts where that would put it and widens from there - a
+    // bisection of 15 000 chunks is fourteen trips to memory one after the other, and there are millions of pieces.
+    uint64_t lo = 0, hi = args.n_chunks;
+    {
+        const uint64_t guess = min(unit0 * args.n_chunks / split.n_pieces, args.n_chunks - 1);
+        uint64_t reach = 1;
+        if (split.piece_base[guess] <= unit0) {
+            lo = guess;
+            while (lo + reach < args.n_chunks && split.piece_base[lo + reach] <= unit0) {
+                lo += reach;
+                reach *= 2;
+            }
+            hi = min(lo + reach, args.n_chunks);
+        } else {
+            hi = guess;
+            while (hi > reach && split.piece_base[hi - reach] > unit0) {
+                hi -= reach;
+                reach *= 2;
+            }
+            lo = hi > reach ? hi - reach : 0;
+        }
+    }
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (split.piece_base[mid] <= unit0) lo = mid;
+        else hi = mid;
+    }
+    uint64_t chunk = lo;
+    const int lane = threadIdx.x % MDB_WAVE, wave = threadIdx.x / MDB_WAVE;
+    uint32_t set_here = 0;
+    for (uint64_t unit = first_unit; unit < min(first_unit + FLAG_PIECES, split.n_pieces); unit++) {
+    while (chunk + 1 < args.n_chunks && split.piece_base[chunk + 1] <= unit) chunk++; // (the next piece's chunk: this one or one close behind)
+    const uint32_t first_point = (uint32_t)(unit - split.piece_base[chunk]) * split.piece_points;
+    const uint64_t base = args.chunk_offsets[chunk];
+    const uint64_t length64 = args.chunk_offsets[chunk + 1] - base;
+    const uint32_t n = length64 > COUNT_MASK - ENTRY_END_BIAS ? 0u : (uint32_t)length64; // (too long: the fitter reports it)
+    const ChunkTimestamps regular_ts = chunk_timestamps(args.timestamps, chunk, base);
+    // Everything below is an upper bound of what the fitters allow, in f32 with room for its own roundings (a few of 2^-24
+    // each against factors of 1 + 2^-12 and terms of 2^-15 of the magnitudes): a bit that is not set costs time, never a byte.
+    const float roomy = 1.0f + 0x1p-12f;
+    const float factor = (float)deviation_factor(args.eb).factor * roomy; // (of the deviation Swing allows: a bound from above)
+    const float pmc_bound = (KIND == MDB_EB_RELATIVE ? args.eb.value / 100.0f : 2.0f * args.eb.value) * roomy;
+    const float interval = (float)regular_ts.interval;
+    // 2^-46 (|t0| + |tk|) / interval of any window of the piece, from above
+    const float times = 0x1p-45f * (fabsf((float)regular_ts.first) + ((float)first_point + (float)split.piece_points + 8.0f) * interval) / interval * roomy;
+    const float *__restrict__ values = args.values + base;
+    for (uint32_t row = (uint32_t)wave; row < split.reject_words_per_piece; row += 256 / MDB_WAVE) {
+        const uint32_t point = first_point + row * (uint32_t)MDB_WAVE + (uint32_t)lane;
+        bool rejected = false;
+        if (point < n && n - point > 7u) { // (all eight in the chunk)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = values[point + (uint32_t)k];
+            // (all eight finite: a product with zero of anything else is a NaN)
+            float zero = 0.0f;
+            float lowest = v[0], highest = v[0];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                zero = __builtin_fmaf(v[k], 0.0f, zero);
+                lowest = fminf(lowest, v[k]);
+                highest = fmaxf(highest, v[k]);
+            }
+            // PMC-Mean: had it accepted all eight, the eighth average would be within the bound of their minimum and of
+            // their maximum
+            const float magnitudes = fabsf(lowest) + fabsf(highest);
+            const float allowed = KIND == MDB_EB_RELATIVE ? magnitudes * pmc_bound : pmc_bound;
+            // (relative: magnitudes whose differences could be subnormal floats are left to the fitter)
+            const bool pmc_ends = (KIND != MDB_EB_RELATIVE || magnitudes >= 0x1p-60f) && highest - lowest > allowed;
+            // Swing: a point outside the first cone by more than the largest deviation among the eight and the room for
+            // the roundings on either side
+            const float rise = v[1] - v[0];
+            const float deviation1 = (KIND == MDB_EB_RELATIVE ? fabsf(v[1]) * factor : factor) * roomy;
+            const float largest = fmaxf(fabsf(lowest), fabsf(highest));
+            const float deviation_any = KIND == MDB_EB_RELATIVE ? largest * factor : factor;
+            const float constant = deviation_any * roomy + 0x1p-15f * largest + (fabsf(rise) + deviation1) * times;
+            bool swing_ends = false;
+#pragma unroll
+            for (int k = 2; k < 8; k++) {
+                const float middle = __builtin_fmaf((float)k, rise, v[0]);
+                swing_ends = swing_ends || fabsf(v[k] - middle) > __builtin_fmaf((float)k, deviation1, constant);
+            }
+            rejected = zero == 0.0f && pmc_ends && swing_ends;
+        }
+        if (point < n) split.entry[base + point] = rejected ? ENTRY_FLAGGED : 0u;
+        const unsigned long long word = __ballot(rejected);
+        if (lane == 0) words[unit * split.reject_words_per_piece + row] = word;
+        set_here += (uint32_t)__popcll(word);
+    }
+    // (how many there are decides whether the fitter looks at the bits at all: estimated from the first wave's rows of
+    // every 8th workgroup - an addition to one address takes its turn behind all the others, some 7 ns each: one per
+    // wave was 40 ms of them, one per wave of every 16th piece still 3)
+    }
+    if (lane == 0 && wave == 0 && set_here && (blockIdx.x & 7u) == 0u) atomicAdd(bits_set, (unsigned long long)set_here);
 }
 
 template <bool SPLIT, int KIND, bool HAS_TS = false, bool ROTATE = false>
@@ -2126,6 +2309,10 @@ struct WaveLeave {
     // MDB_FIT_DEBUG: models, rejected start points, passes over 64 start points, blocks of 64 points, scans of a
     // Swing block, models fitted by one lane, chunks left (nullptr: not counted).
     unsigned long long *counts;
+    // The probe (probe_stride != 0): the launch's wave b takes chunk b * probe_stride, starts somewhere inside it, fits
+    // one window's worth of points and says in n_left whether the pace there is one to leave the chunk at ([0]) and that
+    // it has looked ([1]); what it writes besides is written again by the launch that fits the chunks.
+    uint32_t probe_stride;
 };
 
 enum WaveCount { WAVE_MODELS, WAVE_REJECTED, WAVE_START_PASSES, WAVE_BLOCKS, WAVE_SWING_SCANS, WAVE_BY_ONE_LANE,
@@ -2162,6 +2349,11 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
     __shared__ uint32_t survivors[2 * MDB_WAVE];
     const int lane = threadIdx.x;
     uint64_t chunk = blockIdx.x;
+    const bool probe = !PIECES && leave.probe_stride != 0u;
+    if (probe) {
+        chunk = (uint64_t)blockIdx.x * leave.probe_stride;
+        if (chunk >= args.n_chunks) return;
+    }
     uint32_t first_point = 0;
     if (PIECES) {
         // The chunk of this piece: the last c with piece_base[c] <= the piece's number (the same for all lanes).
@@ -2237,7 +2429,12 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 #endif
         }
     };
-    if (!PIECES && leave.chunk_left && n > leave.max_chunk_points) {
+    if (probe) { // (a window somewhere in the chunk, not the same place in every chunk)
+        if (n < 2u * leave.window_points) return;
+        current = (uint32_t)(((chunk * 2654435761ull) >> 7) % (n / leave.window_points - 1u)) * leave.window_points;
+        looked_at = current;
+        next_look = current + leave.window_points;
+    } else if (!PIECES && leave.chunk_left && n > leave.max_chunk_points) {
         if (lane == 0) {
             leave.chunk_left[chunk] = 1u;
             atomicAdd(leave.n_left, 1u);
@@ -2245,7 +2442,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         }
         return;
     }
-    if (!PIECES && leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
+    if (!probe && !PIECES && leave.chunk_left && lane == 0) leave.chunk_left[chunk] = 0u;
 
     // The sums of the queued Swing models, one lane per model, and with them the models' last values.
     auto flush_pending = [&]() {
@@ -2528,7 +2725,14 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
 
     while (current < n) {
         if (visited(current)) break; // (pieces) the chain from here on is in the table
-        if (!PIECES && leave.chunk_left && current >= next_look) {
+        if (probe && current >= next_look) { // (the pace of this window, judged as a chunk's first one is)
+            if (lane == 0) {
+                if ((uint64_t)half_steps * leave.points_per_step > 2ull * (current - looked_at)) atomicAdd(leave.n_left, 1u);
+                atomicAdd(leave.n_left + 1, 1u);
+            }
+            return;
+        }
+        if (!probe && !PIECES && leave.chunk_left && current >= next_look) {
             // (what is left of the chunk at the pace of this window against the whole chunk in split mode)
             if ((uint64_t)half_steps * leave.points_per_step * (n - current) > 2ull * (current - looked_at) * n) {
                 if (lane == 0) {
@@ -2959,7 +3163,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
                 // (the stretch behind a long model - sine data pays this once per model: one load, not the unrolled
                 // thirty-two of the long stretch with all but one masked off; a lone wave issues an instruction every
                 // five cycles or so, and a 65 536-point buffer's walk was 0.18 ms instead of 0.08)
-                const uint32_t one = (uint32_t)lane < stretch_size ? split.entry[base + stretch_first + lane] : ENTRY_REJECTED;
+                const uint32_t one = (uint32_t)lane < stretch_size ? entry_for_the_walk(split.entry[base + stretch_first + lane]) : ENTRY_REJECTED;
                 if ((uint32_t)lane < stretch_size) staged[lane] = one;
                 live_groups = __ballot(one != ENTRY_REJECTED) ? 1u : 0u;
             } else {
@@ -2967,7 +3171,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
 #pragma unroll
                     for (uint32_t g = 0; g < GROUPS; g++) {
                         const uint32_t k = g * MDB_WAVE + lane;
-                        ahead[g] = k < stretch_size ? split.entry[base + stretch_first + k] : ENTRY_REJECTED;
+                        ahead[g] = k < stretch_size ? entry_for_the_walk(split.entry[base + stretch_first + k]) : ENTRY_REJECTED;
                     }
                 }
 #pragma unroll
@@ -2984,7 +3188,7 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_walk(const unsigned long long 
                 ahead_first = stretch_first + WALK_STRETCH;
                 ahead_size = WALK_STRETCH;
 #pragma unroll
-                for (uint32_t g = 0; g < GROUPS; g++) ahead[g] = split.entry[base + ahead_first + g * MDB_WAVE + lane];
+                for (uint32_t g = 0; g < GROUPS; g++) ahead[g] = entry_for_the_walk(split.entry[base + ahead_first + g * MDB_WAVE + lane]);
             }
             wave_sync();
         }
@@ -4628,6 +4832,10 @@ static uint32_t fit_wave_number(const char *name, uint32_t otherwise) {
 }
 
 constexpr uint32_t FIT_LEFT_PIECE_POINTS = 512; // pieces of the chunks k_fit_models_wave leaves to split mode
+// ... and of all chunks when the probe sends them there untried (the mixed series at 1 % with k_fit_reject_flags, whole call:
+// 39.1 ms in pieces of 256 points, 33.3 / 32.3 / 31.9 / 32.8 / 33.0 / 34.4 in pieces of 512 / 768 / 1 024 / 1 536 / 2 048 / 3 072)
+constexpr uint32_t FIT_UNTRIED_PIECE_POINTS = 1024;
+constexpr unsigned long long FIT_FLAGS_WORTH_ONE_IN = 8; // the fitter looks at k_fit_reject_flags' bits if one point in so many has its bit set
 
 static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64_t total_points) {
     if (const char *forced = option_text("MDB_FIT_PIECE_POINTS")) {
@@ -4635,7 +4843,9 @@ static uint32_t split_piece_points(const mdb_ctx *ctx, uint64_t n_chunks, uint64
         if (value == 1) return 0;
         if (value >= 64) return (uint32_t)std::min<long long>(value, 1 << 30);
     }
-    const uint64_t target_lanes = (uint64_t)std::max(ctx->compute_units, 1) * 4 * MDB_WAVE * 2;
+    // (MDB_FIT_SPLIT_WAVES_PER_SIMD: the waves of pieces asked for per SIMD, 2 unless set)
+    const uint64_t waves_per_simd = fit_wave_number("MDB_FIT_SPLIT_WAVES_PER_SIMD", 2);
+    const uint64_t target_lanes = (uint64_t)std::max(ctx->compute_units, 1) * 4 * MDB_WAVE * std::max<uint64_t>(waves_per_simd, 1);
     if (n_chunks == 0 || n_chunks >= target_lanes / 2) return 0;
     if (total_points * 12 > (48ull << 30)) return 0; // the per-point table would be too large
     const uint64_t piece = std::max<uint64_t>(512, align_up(total_points / target_lanes + 1, 64));
@@ -4797,10 +5007,22 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 FIT_CHECK(hipMalloc(reinterpret_cast<void **>(&leave.counts), WAVE_COUNTS * 8));
                 FIT_CHECK(hipMemsetAsync(leave.counts, 0, WAVE_COUNTS * 8, ctx->stream));
             }
-            {
-                LaunchTimer timer(ctx, "k_fit_models_wave");
+            // The probe (lossy bounds, calls of many chunks that may leave): a wave for every 17th chunk fits one window of
+            // 1 024 points somewhere in it and says whether that pace is one to leave a chunk at. Where a quarter of the
+            // windows are - data whose models are short in many places, the mixed series at 1 %: three chunks of four leave,
+            // each after some thousand points, and what the waves spend on them before is a third of the call (14.4 of
+            // 44 ms) - every chunk goes to split mode untried. A tenth of a millisecond and one wait for the host
+            // (MDB_FIT_WAVE_PROBE=0: no probe).
+            const char *probe_setting = option_text("MDB_FIT_WAVE_PROBE");
+            const uint32_t probe_stride = 17;
+            const bool probing = leave.chunk_left && eb.kind != MDB_EB_LOSSLESS && n_chunks >= 64u * probe_stride &&
+                                 !(probe_setting && std::strcmp(probe_setting, "0") == 0);
+            bool untried = false; // every chunk is left to split mode without a wave having fitted it
+            auto launch_waves = [&](uint32_t stride, uint64_t grid) {
+                leave.probe_stride = stride;
+                LaunchTimer timer(ctx, stride ? "k_fit_models_wave_probe" : "k_fit_models_wave");
 #define MDB_LAUNCH_WAVE(KIND, HAS_TS)                                                                                    \
-    hipLaunchKernelGGL((k_fit_models_wave<KIND, HAS_TS>), dim3((uint32_t)n_chunks), dim3(MDB_WAVE), 0, ctx->stream, args, \
+    hipLaunchKernelGGL((k_fit_models_wave<KIND, HAS_TS>), dim3((uint32_t)grid), dim3(MDB_WAVE), 0, ctx->stream, args, \
                        leave, SplitArgs{}, record_base, records, plans, error_flag)
                 if (eb.kind == MDB_EB_RELATIVE) {
                     if (ts) MDB_LAUNCH_WAVE(MDB_EB_RELATIVE, true);
@@ -4813,6 +5035,22 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                     else MDB_LAUNCH_WAVE(MDB_EB_LOSSLESS, false);
                 }
 #undef MDB_LAUNCH_WAVE
+            };
+            if (probing) {
+                launch_waves(probe_stride, (n_chunks + probe_stride - 1) / probe_stride);
+                unsigned int seen[2] = {0, 0}; // windows at a pace to leave at, windows looked at
+                FIT_CHECK(mail_read(ctx, seen, leave.n_left, 8));
+                FIT_CHECK(mail_sync(ctx));
+                if (option_text("MDB_FIT_DEBUG"))
+                    std::fprintf(stderr, "[fit] k_fit_models_wave_probe: %u of %u windows at a pace to leave the chunk at\n", seen[0], seen[1]);
+                untried = seen[1] >= 32u && 4ull * seen[0] >= seen[1];
+                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 8, ctx->stream));
+            }
+            if (untried) {
+                // (every chunk counts as left: any non-zero word says so)
+                FIT_CHECK(hipMemsetAsync(leave.chunk_left, 1, n_chunks * 4, ctx->stream));
+            } else {
+                launch_waves(0, n_chunks);
             }
             if (leave.counts) {
                 unsigned long long counts[WAVE_COUNTS] = {};
@@ -4835,6 +5073,10 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 unsigned int left[2] = {0, 0};
                 FIT_CHECK(mail_read(ctx, left, leave.n_left, 8));
                 FIT_CHECK(mail_sync(ctx));
+                if (untried) { // (all of them; "some for their length alone" if the average chunk is anywhere near that length)
+                    left[0] = (unsigned int)n_chunks;
+                    left[1] = points_end / n_chunks > leave.max_chunk_points / 2u ? 1u : 0u;
+                }
                 const unsigned int n_left = left[0];
                 if (n_left > 0) {
                     split_mode = true;
@@ -4848,7 +5090,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                     // be as long as the others, as for a call that goes to split mode by itself)
                     if (!option_text("MDB_FIT_PIECE_POINTS")) {
                         if (left[1] == 0) {
-                            piece_points = std::min<uint32_t>(piece_points, FIT_LEFT_PIECE_POINTS);
+                            piece_points = std::min<uint32_t>(piece_points, untried ? FIT_UNTRIED_PIECE_POINTS : FIT_LEFT_PIECE_POINTS);
                         } else {
                             const uint32_t for_these = split_piece_points(ctx, n_left, points_end / n_chunks * n_left);
                             if (for_these != 0) piece_points = for_these;
@@ -4968,13 +5210,48 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                                                            align_up((n_chunks + 1) * 8, 64));
             split.p0 = reinterpret_cast<float *>(split.entry + table_points);
             split.p1 = split.p0 + table_points;
-            FIT_CHECK(hipMemsetAsync(split.entry, 0, table_points * 4, ctx->stream));
             FIT_TRY(device_exclusive_scan(ctx, PieceCount{args.chunk_offsets, piece_points, split_only}, n_chunks, piece_base,
                                           block_sums, "k_fit_scan"));
             unsigned long long n_pieces = 0;
             FIT_CHECK(mail_read(ctx, &n_pieces, piece_base + n_chunks, 8));
             FIT_CHECK(mail_sync(ctx));
             split.n_pieces = n_pieces;
+            // The start points at which no model can begin, found for all points at once (k_fit_reject_flags; the lean
+            // fitter's values-only form under a lossy bound; MDB_FIT_REJECT_FLAGS=0: every start point fed to the fitters).
+            // (the kernel writes the entry of every point that has a piece - 0 or "no model from here": no clearing then)
+            const char *flags_setting = option_text("MDB_FIT_REJECT_FLAGS");
+            const bool with_flags = n_pieces > 0 && lean && !ts && !lean_ts && eb.kind != MDB_EB_LOSSLESS && piece_points % MDB_WAVE == 0 &&
+                                    !(flags_setting && std::strcmp(flags_setting, "0") == 0);
+            if (!with_flags) FIT_CHECK(hipMemsetAsync(split.entry, 0, table_points * 4, ctx->stream));
+            if (with_flags) {
+                split.reject_words_per_piece = piece_points / MDB_WAVE;
+                const uint64_t n_words = n_pieces * split.reject_words_per_piece;
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_REJECTS, (n_words + 1) * 8, &p));
+                unsigned long long *words = static_cast<unsigned long long *>(p);
+                unsigned long long *bits_set = words + n_words;
+                FIT_CHECK(hipMemsetAsync(bits_set, 0, 8, ctx->stream));
+                split.reject_words = words;
+                {
+                    LaunchTimer timer(ctx, "k_fit_reject_flags");
+                    if (eb.kind == MDB_EB_RELATIVE)
+                        hipLaunchKernelGGL(k_fit_reject_flags<MDB_EB_RELATIVE>, dim3((uint32_t)((n_pieces + FLAG_PIECES - 1) / FLAG_PIECES)), dim3(256), 0, ctx->stream, args, split, words, bits_set);
+                    else
+                        hipLaunchKernelGGL(k_fit_reject_flags<MDB_EB_ABSOLUTE>, dim3((uint32_t)((n_pieces + FLAG_PIECES - 1) / FLAG_PIECES)), dim3(256), 0, ctx->stream, args, split, words, bits_set);
+                }
+                // Few of them (sine + noise under a bound of the noise's size: 26-point models, hardly a start point that
+                // certainly fails): the fitter's look at the bits every step would cost more than it saves (7.5 -> 8.4 ms).
+                // The entries that say "no model from here" stay: a lane that comes by overwrites them like any other.
+                unsigned long long set = 0;
+                FIT_CHECK(mail_read(ctx, &set, bits_set, 8));
+                FIT_CHECK(mail_sync(ctx));
+                set *= 8 * (256 / MDB_WAVE); // (counted in one wave's rows of every 8th workgroup)
+                if (option_text("MDB_FIT_DEBUG"))
+                    std::fprintf(stderr, "[fit] k_fit_reject_flags: %llu pieces of %u points, about %llu start points at which no model can begin\n",
+                                 n_pieces, piece_points, set);
+                if (set * FIT_FLAGS_WORTH_ONE_IN < n_pieces * (unsigned long long)piece_points &&
+                    !(flags_setting && std::strcmp(flags_setting, "1") == 0))
+                    split.reject_words = nullptr;
+            }
             if (n_pieces > 0) {
                 LaunchTimer timer(ctx, "k_fit_models_split");
                 const uint32_t fit_blocks = (uint32_t)((n_pieces + FIT_THREADS - 1) / FIT_THREADS);
