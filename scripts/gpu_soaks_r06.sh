@@ -14,3 +14,6 @@ MDB_FIT_WAVE=0 MDB_AGG_RANGE_PIECES=0 MDB_GRID_TS_CACHE=0 MDB_SOAK_CASES=2000 ti
 MDB_SOAK_ROTATING_CASES=400 MDB_SOAK_CASES=1 MDB_SOAK_HOST_CASES=1 timeout 1200 python -m pytest tests/test_gpu_soak.py -x -q -m gpu -k rotating > gpurun_out/r06/soak6.log 2>&1; grep -E "passed|failed" gpurun_out/r06/soak6.log | tail -1
 # (seventh, round 6) the lossless wave path on every call of the soak that has a lossless bound: one wave per chunk, no small driver
 MDB_FIT_WAVE=1 MDB_FIT_SMALL=0 MDB_SOAK_CASES=3000 timeout 1200 python -m pytest tests/test_gpu_soak.py -x -q -m gpu -k "random_series" > gpurun_out/r06/soak7.log 2>&1; grep -E "passed|failed" gpurun_out/r06/soak7.log | tail -1
+# (eighth and ninth, round 6) split mode with k_fit_reject_flags' bits looked at however few are set: pieces of 64 and of 192 points
+MDB_FIT_WAVE=0 MDB_FIT_SMALL=0 MDB_FIT_PIECE_POINTS=64 MDB_FIT_REJECT_FLAGS=1 MDB_SOAK_CASES=3000 timeout 1200 python -m pytest tests/test_gpu_soak.py -x -q -m gpu -k "random_series" > gpurun_out/r06/soak8.log 2>&1; grep -E "passed|failed" gpurun_out/r06/soak8.log | tail -1
+MDB_FIT_WAVE=0 MDB_FIT_SMALL=0 MDB_FIT_PIECE_POINTS=192 MDB_FIT_REJECT_FLAGS=1 MDB_SOAK_CASES=3000 timeout 1200 python -m pytest tests/test_gpu_soak.py -x -q -m gpu -k "random_series" > gpurun_out/r06/soak9.log 2>&1; grep -E "passed|failed" gpurun_out/r06/soak9.log | tail -1
