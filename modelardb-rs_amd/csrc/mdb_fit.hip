@@ -2729,6 +2729,8 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
             if (lane == 0) {
                 if ((uint64_t)half_steps * leave.points_per_step > 2ull * (current - looked_at)) atomicAdd(leave.n_left, 1u);
                 atomicAdd(leave.n_left + 1, 1u);
+                // (the model that ran out of the window went on for another window's length or more: long ones)
+                if (current - looked_at >= 2u * leave.window_points) atomicAdd(leave.n_left + 2, 1u);
             }
             return;
         }
@@ -2852,6 +2854,14 @@ __global__ __launch_bounds__(MDB_WAVE) void k_fit_models_wave(FitArgs args, Wave
         double upper_slope = nan, lower_slope = nan;
         uint32_t position = current;
         while ((pmc_alive || swing_alive) && position < n) {
+            if (probe && position >= next_look + leave.window_points) {
+                // (the probe: this model has gone on for a window's length past the window - a long one; no need to see its end)
+                if (lane == 0) {
+                    atomicAdd(leave.n_left + 1, 1u);
+                    atomicAdd(leave.n_left + 2, 1u);
+                }
+                return;
+            }
             counted[WAVE_BLOCKS] += 1;
             half_steps += 2;
             const uint32_t index = position + lane;
@@ -4990,7 +5000,7 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
         if (wave) {
             WaveLeave leave{};
             if (wave_setting != 1 && piece_points != 0) {
-                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_WAVE, (n_chunks + 2) * 4, &p));
+                FIT_TRY(scratch_reserve(ctx, SCRATCH_FIT_WAVE, (n_chunks + 4) * 4, &p));
                 leave.chunk_left = static_cast<unsigned int *>(p);
                 leave.n_left = leave.chunk_left + n_chunks;
                 leave.window_points = fit_wave_number("MDB_FIT_WAVE_WINDOW_POINTS", 1024);
@@ -5000,22 +5010,26 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
                 // moved chunks to the slower side: 41 ms at 3, 54 at 12, 81 at 45 - measured with k_fit_models as
                 // split mode's fitter; the lean one that has replaced it is a fifth faster, which does not turn that.)
                 leave.points_per_step = fit_wave_number("MDB_FIT_WAVE_POINTS_PER_STEP", eb.kind == MDB_EB_LOSSLESS ? 3 : 20);
-                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 8, ctx->stream));
+                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 16, ctx->stream));
             }
             const bool count_steps = option_text("MDB_FIT_DEBUG") != nullptr;
             if (count_steps) {
                 FIT_CHECK(hipMalloc(reinterpret_cast<void **>(&leave.counts), WAVE_COUNTS * 8));
                 FIT_CHECK(hipMemsetAsync(leave.counts, 0, WAVE_COUNTS * 8, ctx->stream));
             }
-            // The probe (lossy bounds, calls of many chunks that may leave): a wave for every 17th chunk fits one window of
-            // 1 024 points somewhere in it and says whether that pace is one to leave a chunk at. Where a quarter of the
-            // windows are - data whose models are short in many places, the mixed series at 1 %: three chunks of four leave,
-            // each after some thousand points, and what the waves spend on them before is a third of the call (14.4 of
-            // 44 ms) - every chunk goes to split mode untried. A tenth of a millisecond and one wait for the host
-            // (MDB_FIT_WAVE_PROBE=0: no probe).
+            // The probe (lossy bounds, calls whose chunks may leave): a wave for every 17th chunk (every chunk of a call of a
+            // few hundred) fits one window of 1 024 points somewhere in it and says whether that pace is one to leave a chunk
+            // at. The call then goes ONE way. A quarter of the windows slow - models short in many places, the mixed series
+            // at 1 %: 36 % - and every chunk goes to split mode untried: what waves spend on chunks before they leave them
+            // was a third of that call (14.4 of 44 ms). Fewer, and every chunk keeps its wave to its end: a chunk that leaves
+            // for ONE rough window hands split mode its long models too, which speculative pieces fit once each - smooth
+            // series with a tenth of their windows rough took 79 ms that way, 18.8 with a wave per chunk to the end, and split
+            // mode for all of it 62 (profiles/r06/probe_rough_smooth.txt: the two ways cross where a quarter of the windows
+            // are slow; leaving chunk by chunk was the slowest or near it in every row). A tenth of a millisecond and one
+            // wait for the host (MDB_FIT_WAVE_PROBE=0: no probe, chunks leave one by one as before).
             const char *probe_setting = option_text("MDB_FIT_WAVE_PROBE");
-            const uint32_t probe_stride = 17;
-            const bool probing = leave.chunk_left && eb.kind != MDB_EB_LOSSLESS && n_chunks >= 64u * probe_stride &&
+            const uint32_t probe_stride = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_chunks / 256, 1), 17);
+            const bool probing = leave.chunk_left && eb.kind != MDB_EB_LOSSLESS && n_chunks >= 64u &&
                                  !(probe_setting && std::strcmp(probe_setting, "0") == 0);
             bool untried = false; // every chunk is left to split mode without a wave having fitted it
             auto launch_waves = [&](uint32_t stride, uint64_t grid) {
@@ -5038,13 +5052,17 @@ int compress_chunks_dev_locked(mdb_ctx *ctx, const int64_t *ts, const float *val
             };
             if (probing) {
                 launch_waves(probe_stride, (n_chunks + probe_stride - 1) / probe_stride);
-                unsigned int seen[2] = {0, 0}; // windows at a pace to leave at, windows looked at
-                FIT_CHECK(mail_read(ctx, seen, leave.n_left, 8));
+                unsigned int seen[4] = {0, 0, 0, 0}; // windows at a pace to leave at, windows looked at, windows out of which a model ran for another window's length
+                FIT_CHECK(mail_read(ctx, seen, leave.n_left, 16));
                 FIT_CHECK(mail_sync(ctx));
                 if (option_text("MDB_FIT_DEBUG"))
-                    std::fprintf(stderr, "[fit] k_fit_models_wave_probe: %u of %u windows at a pace to leave the chunk at\n", seen[0], seen[1]);
-                untried = seen[1] >= 32u && 4ull * seen[0] >= seen[1];
-                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 8, ctx->stream));
+                    std::fprintf(stderr, "[fit] k_fit_models_wave_probe: %u of %u windows at a pace to leave the chunk at, %u in models of more than a window's length\n",
+                                 seen[0], seen[1], seen[2]);
+                if (seen[1] >= 32u) {
+                    untried = 4ull * seen[0] >= seen[1];
+                    if (!untried) leave.points_per_step = 0; // (no pace is one to leave at: only a chunk's length is)
+                }
+                FIT_CHECK(hipMemsetAsync(leave.n_left, 0, 16, ctx->stream));
             }
             if (untried) {
                 // (every chunk counts as left: any non-zero word says so)
