@@ -2078,7 +2078,7 @@ __global__ __launch_bounds__(256) void k_fit_reject_flags(FitArgs args, SplitArg
     const float roomy = 1.0f + 0x1p-12f;
     const float factor = (float)deviation_factor(args.eb).factor * roomy; // (of the deviation Swing allows: a bound from above)
     const float pmc_bound = (KIND == MDB_EB_RELATIVE ? args.eb.value / 100.0f : 2.0f * args.eb.value) * roomy;
-    const float interval = (float)regular_ts.interval;
+    const float interval = fabsf((float)regular_ts.interval); // (a magnitude: a bound from above whatever its sign)
     // 2^-46 (|t0| + |tk|) / interval of any window of the piece, from above
     const float times = 0x1p-45f * (fabsf((float)regular_ts.first) + ((float)first_point + (float)split.piece_points + 8.0f) * interval) / interval * roomy;
     const float *__restrict__ values = args.values + base;
