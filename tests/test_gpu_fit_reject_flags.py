@@ -131,3 +131,29 @@ def test_the_probe_sends_a_call_of_short_models_to_split_mode_untried(hip, monke
                 assert "k_fit_models_wave" not in kernels and {"k_fit_models_split", "k_fit_reject_flags", "k_fit_walk"} <= kernels, kernels
             if texture == "smooth":
                 assert "k_fit_models_wave" in kernels and "k_fit_models_split" not in kernels, kernels
+
+
+@pytest.mark.parametrize("texture", ["noisy", "smooth"])
+def test_the_probe_with_timestamps_that_are_loaded(hip, texture):
+    """Irregular timestamps (exact as f64: the wave kernel and the lean fitter take them loaded): the probe's waves read
+    them like any other, the call goes one way, the flags stay out of it (they are the values-only fitter's) - and the
+    segments are the oracle's."""
+    eb = BOUNDS["rel1"]
+    rng = np.random.default_rng(11)
+    n_chunks, points = 600, 4096
+    offsets = np.arange(0, n_chunks * points + 1, points, dtype=np.uint64)
+    timestamps = np.cumsum(rng.integers(1, 400, n_chunks * points)).astype(np.int64) + 1_600_000_000_000
+    values = 300.0 + 100.0 * np.sin(np.arange(n_chunks * points) / 3000.0)
+    if texture == "noisy":
+        values = values + rng.uniform(-4.0, 4.0, n_chunks * points)
+    values = values.astype(np.float32)
+    expected = ora.compress_chunks(timestamps, values, offsets, eb)
+    hip.profile_enable(True)
+    hip.profile_reset()
+    got = hip.compress_chunks(timestamps, values, offsets, eb)
+    kernels = _kernels(hip)
+    hip.profile_enable(False)
+    assert_same_segments(got, expected)
+    assert "k_fit_models_wave_probe" in kernels and "k_fit_reject_flags" not in kernels, kernels
+    assert ("k_fit_models_split" in kernels) == (texture == "noisy"), kernels
+    assert ("k_fit_models_wave" in kernels) == (texture == "smooth"), kernels
